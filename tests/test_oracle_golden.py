@@ -1,0 +1,116 @@
+"""Pins the oracle (oracle/esc_oracle.py) to golden vectors produced by the real reference
+(oracle/gen_golden.py).  CPU only."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, synth_state
+from esc import synth
+from oracle.esc_oracle import EscOracle, Trace, patch_merge, split_dimension
+
+
+def _oracle(name):
+    g = load_golden(name)
+    cfg = json.loads(str(g["config_json"]))
+    return EscOracle(cfg, synth_state(name)), g, cfg
+
+
+def _rms(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
+
+
+@pytest.mark.parametrize("name", ["base", "large"])
+def test_codes_and_audio_all_streams(name):
+    orc, g, cfg = _oracle(name)
+    x = torch.from_numpy(synth.pcm_to_float(g["pcm"]))
+    ref_codes = torch.from_numpy(g["codes"].astype(np.int64))
+    streams = range(1, cfg["max_streams"] + 1) if name == "base" else (1, 4, 6)
+    for s in streams:
+        codes, shape = orc.encode(x, s)
+        assert codes.dtype == torch.int64 and tuple(shape) == tuple(g["feat_shape"])
+        assert torch.equal(codes, ref_codes[:, :s]), f"{name} S={s}"
+        audio = orc.decode(codes, shape).numpy()
+        ref = g[f"audio_s{s}"]
+        got = audio if s == cfg["max_streams"] else audio[:, ::8]
+        assert got.shape == ref.shape
+        assert _rms(got, ref) <= 1e-6
+        rms = np.sqrt((audio.astype(np.float64) ** 2).mean(axis=1))
+        np.testing.assert_allclose(rms, g[f"audio_rms_s{s}"], rtol=1e-5)
+
+
+def test_forward_eval_matches_encode_decode_and_losses():
+    orc, g, cfg = _oracle("base")
+    x = torch.from_numpy(synth.pcm_to_float(g["pcm"]))
+    for s in (1, 3, 6):
+        out = orc.forward_eval(x, None, s)
+        codes, shape = orc.encode(x, s)
+        assert torch.equal(out["codes"], codes)
+        assert _rms(out["recon_audio"].numpy(), orc.decode(codes, shape).numpy()) <= 1e-7
+        np.testing.assert_allclose(out["cm_loss"].numpy(), g[f"cm_loss_s{s}"], rtol=2e-5)
+        assert out["recon_feat"].shape == (2, 2, 192, 600) and out["raw_feat"].shape == (2, 2, 192, 601)
+
+
+@pytest.mark.parametrize("L", [16000, 24000])
+def test_edge_lengths(L):
+    orc, _, cfg = _oracle("base")
+    e = load_golden("edge")
+    x = torch.from_numpy(synth.pcm_to_float(e[f"L{L}_pcm"]))
+    codes, shape = orc.encode(x, 6)
+    assert tuple(shape) == tuple(e[f"L{L}_feat_shape"])
+    assert torch.equal(codes, torch.from_numpy(e[f"L{L}_codes"].astype(np.int64)))
+    for s in (1, 3, 6):
+        a = orc.decode(codes[:, :s], shape).numpy()
+        ref = e[f"L{L}_audio_s{s}"]
+        assert _rms(a if s == 6 else a[:, ::8], ref) <= 1e-6
+
+
+@pytest.mark.parametrize("L", [1280, 1200])
+def test_tiny_per_layer_activations(L):
+    orc, g, cfg = _oracle("tiny")
+    x = torch.from_numpy(synth.pcm_to_float(g[f"L{L}_pcm"]))
+    tr = Trace()
+    codes, shape = orc.encode(x, 3, trace=tr)
+    assert torch.equal(codes, torch.from_numpy(g[f"L{L}_codes"].astype(np.int64)))
+    np.testing.assert_allclose(tr.feat.numpy(), g[f"L{L}_feat"], atol=1e-6)
+    for i, h in enumerate(tr.enc_hs):
+        np.testing.assert_allclose(h.numpy(), g[f"L{L}_enc{i}"], atol=2e-6, rtol=1e-5)
+    orc.decode(codes, shape, trace=tr)
+    # reference decode() returns [z0, block outputs..., de-embedded feature]; post_nn is not recorded there
+    nb = len(cfg["h_dims"]) - 1
+    for i in range(nb + 1):
+        np.testing.assert_allclose(tr.dec_hs[i].numpy(), g[f"L{L}_dec{i}"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(tr.recon_feat.numpy(), g[f"L{L}_dec{nb + 1}"], atol=2e-6, rtol=1e-5)
+    # margins recorded by the oracle agree with the reference's own
+    m = torch.stack(tr.margins, dim=1).numpy()
+    np.testing.assert_allclose(m, g[f"L{L}_margins"], atol=1e-5)
+
+
+def test_invariants_prefix_batch_range():
+    orc, g, cfg = _oracle("base")
+    x = torch.from_numpy(synth.pcm_to_float(g["pcm"]))
+    full, shape = orc.encode(x, 6)
+    assert int(full.min()) >= 0 and int(full.max()) < cfg["codebook_size"]
+    for s in (1, 2, 5):
+        assert torch.equal(orc.encode(x, s)[0], full[:, :s])
+    one, _ = orc.encode(x[1:2], 6)
+    assert torch.equal(one, full[1:2])          # batch invariance
+    assert orc.max_bps == 9.0
+
+
+def test_merge_odd_height_and_uneven_split():
+    # PatchMerge pads an odd H with a zero row before the unshuffle (scale.py:106-108)
+    torch.manual_seed(1)
+    C, H, W = 6, 5, 4
+    sd = {"m.norm.weight": torch.rand(2 * C) + 0.5, "m.norm.bias": torch.randn(2 * C) * 0.1,
+          "m.down.weight": torch.randn(8, 2 * C)}
+    x = torch.randn(2, H * W, C)
+    y = patch_merge(x, H, sd, "m.")
+    assert y.shape == (2, 3 * W, 8)
+    xp = torch.cat([x.view(2, H, W, C), torch.zeros(2, 1, W, C)], 1)
+    row = torch.cat([xp[:, 4, 1], xp[:, 5, 1]], -1)     # h'=2, w=1
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(row, (2 * C,), sd["m.norm.weight"], sd["m.norm.bias"]),
+                                     sd["m.down.weight"])
+    np.testing.assert_allclose(y[:, 2 * W + 1].numpy(), ref.numpy(), atol=1e-6)
+    assert split_dimension(128, 3) == [42, 42, 44] and split_dimension(1536, 3) == [512] * 3
