@@ -1,0 +1,55 @@
+"""Builds libescx.so (HIP, gfx950) in-tree: efficient-speech-codec_amd/esc/lib/libescx.so.
+
+    python efficient-speech-codec_amd/build.py [--force]
+
+hipcc cross-compiles for gfx950 without a GPU.  The .so is git-ignored but travels with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "esc", "lib")
+OBJ_DIR = os.path.join(HERE, "build")
+LIB = os.path.join(OUT_DIR, "libescx.so")
+SOURCES = ["escx_api.cpp", "gemm_swin.hip", "gemm_misc.hip", "kernels_misc.hip"]
+HEADERS = ["gemm_engine.h", "kernels.h", "launchers.h", "escx_internal.h", os.path.join("..", "..", "include", "escx.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest(deps):
+        return LIB
+    os.makedirs(OUT_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(srcs)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,872 @@
+// libescx C ABI implementation: handle, parameter packing, workspace, and the launch sequences of
+// ESC.encode / ESC.decode / ESC.forward(eval).  Reference citations are relative to /root/reference/.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "escx_internal.h"
+#include "launchers.h"
+
+using namespace escx;
+
+namespace escx {
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_err = buf;
+}
+}  // namespace escx
+
+extern "C" const char* escx_last_error(void) { return g_err.c_str(); }
+extern "C" const char* escx_version(void) { return "escx 0.1 (gfx950, fp32 MFMA)"; }
+
+// ------------------------------------------------------------------------------------------------
+// configuration -> geometry
+// ------------------------------------------------------------------------------------------------
+static int roundup4(int x) { return rup(x, 4); }
+
+static void add_block_keys(std::vector<std::string>& keys, const std::string& p) {
+    for (const char* k : {"norm1.weight", "norm1.bias", "attn.relative_position_bias_table", "attn.qkv.weight", "attn.qkv.bias",
+                          "attn.proj.weight", "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.linear_1.weight",
+                          "mlp.linear_1.bias", "mlp.linear_2.weight", "mlp.linear_2.bias"})
+        keys.push_back(p + k);
+}
+
+static int build_geometry(escx_handle_s* h) {
+    const escx_config& c = h->cfg;
+    const int n = c.n_scales;
+    if (n < 2 || n > ESCX_MAX_SCALES) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_scales=%d out of range", n);
+    if (c.window_size != 4) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "only window_size=4 is implemented (got %d)", c.window_size);
+    if (c.max_streams != n) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "max_streams (%d) must equal len(h_dims) (%d): one decoder block per "
+                                      "residual stream (csrvq.py:108-122)", c.max_streams, n);
+    if (c.in_freq % c.patch_f != 0) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "in_freq must be divisible by patch_size[0]");
+    if (c.overlap < 1 || c.group_size < 1 || c.group_size > 8) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad overlap/group_size");
+    h->n = n;
+    h->F = c.in_freq; h->Fp = rup(c.in_freq, 16);
+    h->n_fft = (c.in_freq - 1) * 2;                               // base.py:22
+    if (c.win_length > h->n_fft || c.win_length < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "win_length must be in [1, n_fft]");
+    h->left = (h->n_fft - c.win_length) / 2;                      // torch.stft centres the window inside n_fft
+    h->winP = rup(c.win_length, 16);
+    h->C0 = c.h_dims[0]; h->C0p = rup(h->C0, 16);
+    h->Kpe = rup(c.in_dim * c.patch_f * c.patch_t, 16);
+    h->Q = c.patch_f * c.patch_t;
+
+    auto make_layer = [&](const std::string& prefix, int C, int nH, int scale, int Cout) -> int {
+        Layer L; L.prefix = prefix; L.C = C; L.Cp = rup(C, 16); L.nH = nH;
+        if (nH < 1 || C % nH != 0) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "%s: dim %d not divisible by heads %d", prefix.c_str(), C, nH);
+        L.hd = C / nH; L.hdp = roundup4(L.hd);
+        if (L.hdp > 64) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "head_dim %d > 64", L.hd);
+        L.Nqkv = rup(3 * nH * L.hdp, 16); L.Ko = rup(nH * L.hdp, 16);
+        L.hidden = (int)(C * c.mlp_ratio); L.hiddenP = rup(L.hidden, 16);
+        L.scale = scale; L.Cout = Cout; L.CoutP = rup(Cout, 16);
+        L.blocks.resize(c.swin_depth);
+        h->layers.push_back(L);
+        return 0;
+    };
+    // encoder: pre_nn + blocks (base.py:124-141); decoder: blocks + post_nn with reversed dims/heads (codecs.py:24-28)
+    int rc;
+    if ((rc = make_layer("encoder.pre_nn.", c.h_dims[0], c.swin_heads[0], 0, c.h_dims[0]))) return rc;
+    for (int i = 0; i + 1 < n; ++i)
+        if ((rc = make_layer("encoder.blocks." + std::to_string(i) + ".", c.h_dims[i], c.swin_heads[i], 1, c.h_dims[i + 1]))) return rc;
+    for (int j = 0; j + 1 < n; ++j)
+        if ((rc = make_layer("decoder.blocks." + std::to_string(j) + ".", c.h_dims[n - 1 - j], c.swin_heads[n - 2 - j], 2,
+                             c.h_dims[n - 2 - j]))) return rc;
+    if ((rc = make_layer("decoder.post_nn.", c.h_dims[0], c.swin_heads[0], 0, c.h_dims[0]))) return rc;
+
+    const int H0 = c.in_freq / c.patch_f;
+    for (int s = 0; s < c.max_streams; ++s) {                     // base.py:49-69
+        Quant q; q.prefix = "quantizers." + std::to_string(s) + ".";
+        q.C = c.h_dims[n - 1 - std::max(s - 1, 0)]; q.Cp = rup(q.C, 16);
+        q.Hq = (s == 0) ? H0 >> (c.max_streams - 1) : H0 >> (c.max_streams - s);
+        if (q.Hq < 1) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "quantizer %d has in_freq 0", s);
+        q.d = c.codebook_dims[s]; q.dt = roundup4(q.d);
+        if (q.d < 1 || q.dt > 64) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "codebook_dim %d unsupported", q.d);
+        q.Nz = rup(c.group_size * q.dt, 16); q.Kup = q.Nz;
+        q.Kq = c.overlap * q.Hq * q.Cp;
+        h->quants.push_back(q);
+    }
+
+    // required state_dict keys
+    auto& K = h->required;
+    for (int s = 0; s < c.max_streams; ++s)
+        for (int g = 0; g < c.group_size; ++g) {
+            const std::string p = "quantizers." + std::to_string(s) + ".";
+            K.push_back(p + "vqs." + std::to_string(g) + ".embedding.weight");
+            K.push_back(p + "down_projs." + std::to_string(g) + ".weight");
+            K.push_back(p + "up_projs." + std::to_string(g) + ".weight");
+        }
+    for (const char* k : {"proj.weight", "proj.bias", "norm.weight", "norm.bias"}) K.push_back(std::string("encoder.patch_embed.") + k);
+    for (const Layer& L : h->layers) {
+        for (int j = 0; j < c.swin_depth; ++j) add_block_keys(K, L.prefix + "swint_blocks." + std::to_string(j) + ".");
+        if (L.scale) {
+            K.push_back(L.prefix + "subsample.norm.weight"); K.push_back(L.prefix + "subsample.norm.bias");
+            K.push_back(L.prefix + (L.scale == 1 ? "subsample.down.weight" : "subsample.up.weight"));
+        }
+    }
+    for (const char* k : {"de_proj1.weight", "de_proj1.bias", "de_proj2.weight", "de_proj2.bias"})
+        K.push_back(std::string("decoder.patch_deembed.") + k);
+    return 0;
+}
+
+extern "C" int escx_create(const escx_config* cfg, int device, escx_handle* out) {
+    if (!cfg || !out) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null argument");
+    int ndev = 0;
+    ESCX_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, ndev);
+    escx_handle_s* h = new escx_handle_s();
+    h->cfg = *cfg; h->device = device;
+    int rc = build_geometry(h);
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return ESCX_OK;
+}
+
+extern "C" void escx_destroy(escx_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->wts.base) (void)hipFree(h->wts.base);
+    if (h->ws.base) (void)hipFree(h->ws.base);
+    for (auto& kv : h->maps) (void)hipFree(kv.second);
+    delete h;
+}
+
+extern "C" int escx_num_required_keys(escx_handle h) { return h ? (int)h->required.size() : 0; }
+extern "C" const char* escx_required_key(escx_handle h, int i) {
+    return (h && i >= 0 && i < (int)h->required.size()) ? h->required[i].c_str() : nullptr;
+}
+
+extern "C" int escx_set_param(escx_handle h, const char* key, const float* host, const int64_t* shape, int ndim) {
+    if (!h || !key || !host || (ndim > 0 && !shape)) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null argument");
+    Param p; size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { p.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    p.data.assign(host, host + n);
+    h->params[key] = std::move(p);
+    h->finalized = false;
+    return ESCX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// packing
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Packer {
+    escx_handle_s* h;
+    std::vector<float> host;                    // staging image of the weight arena
+    std::string missing;
+    const Param* get(const std::string& key, std::initializer_list<int64_t> shape) {
+        auto it = h->params.find(key);
+        if (it == h->params.end()) { if (missing.empty()) missing = "missing key " + key; return nullptr; }
+        const Param& p = it->second;
+        if (p.shape != std::vector<int64_t>(shape)) {
+            if (missing.empty()) missing = "shape mismatch for " + key;
+            return nullptr;
+        }
+        return &p;
+    }
+    size_t alloc(size_t n) { size_t off = (host.size() + 63) / 64 * 64; host.resize(off + n, 0.f); return off; }
+};
+
+inline double hann(int k, int n) { return 0.5 - 0.5 * std::cos(2.0 * M_PI * (double)k / (double)n); }
+}  // namespace
+
+#define GETP(var, key, ...) const Param* var = pk.get(key, {__VA_ARGS__}); if (!var) ESCX_FAIL(ESCX_ERR_STATE, "%s", pk.missing.c_str())
+
+extern "C" int escx_finalize_params(escx_handle h) {
+    if (!h) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null handle");
+    ESCX_HIP(hipSetDevice(h->device));
+    const escx_config& c = h->cfg;
+    Packer pk{h};
+    std::vector<std::pair<float**, size_t>> fix;      // (destination pointer slot, offset in floats)
+    auto put = [&](float** slot, size_t n) -> float* { size_t off = pk.alloc(n); fix.push_back({slot, off}); return nullptr; };
+    (void)put;
+    auto slot = [&](float** dst, size_t n) -> size_t { size_t off = pk.alloc(n); fix.push_back({dst, off}); return off; };
+
+    // ---- transformer layers ----
+    for (Layer& L : h->layers) {
+        const int C = L.C, Cp = L.Cp, nH = L.nH, hd = L.hd, hdp = L.hdp;
+        for (int j = 0; j < c.swin_depth; ++j) {
+            const std::string p = L.prefix + "swint_blocks." + std::to_string(j) + ".";
+            BlockW& bw = L.blocks[j];
+            GETP(n1w, p + "norm1.weight", C); GETP(n1b, p + "norm1.bias", C);
+            GETP(tab, p + "attn.relative_position_bias_table", 49, nH);
+            GETP(qw, p + "attn.qkv.weight", 3 * C, C); GETP(qb, p + "attn.qkv.bias", 3 * C);
+            GETP(pw, p + "attn.proj.weight", C, C); GETP(pb, p + "attn.proj.bias", C);
+            GETP(n2w, p + "norm2.weight", C); GETP(n2b, p + "norm2.bias", C);
+            GETP(w1, p + "mlp.linear_1.weight", L.hidden, C); GETP(b1, p + "mlp.linear_1.bias", L.hidden);
+            GETP(w2, p + "mlp.linear_2.weight", C, L.hidden); GETP(b2, p + "mlp.linear_2.bias", C);
+            size_t o;
+            o = slot(&bw.ln1_g, Cp); std::copy(n1w->data.begin(), n1w->data.end(), pk.host.begin() + o);
+            o = slot(&bw.ln1_b, Cp); std::copy(n1b->data.begin(), n1b->data.end(), pk.host.begin() + o);
+            o = slot(&bw.wqkv, (size_t)L.Nqkv * Cp);
+            size_t ob = slot(&bw.bqkv, L.Nqkv);
+            for (int w = 0; w < 3; ++w) for (int hh = 0; hh < nH; ++hh) for (int d = 0; d < hd; ++d) {
+                const int src = w * C + hh * hd + d, dst = w * nH * hdp + hh * hdp + d;
+                std::copy(qw->data.begin() + (size_t)src * C, qw->data.begin() + (size_t)(src + 1) * C, pk.host.begin() + o + (size_t)dst * Cp);
+                pk.host[ob + dst] = qb->data[src];
+            }
+            // relative position bias gathered per head: index = (dh+3)*7 + (dw+3)  (attention.py:195-205)
+            o = slot(&bw.bias_tab, (size_t)nH * 256);
+            for (int hh = 0; hh < nH; ++hh) for (int i = 0; i < 16; ++i) for (int jj = 0; jj < 16; ++jj) {
+                const int idx = ((i >> 2) - (jj >> 2) + 3) * 7 + ((i & 3) - (jj & 3) + 3);
+                pk.host[o + ((size_t)hh * 16 + i) * 16 + jj] = tab->data[(size_t)idx * nH + hh];
+            }
+            o = slot(&bw.wproj, (size_t)Cp * L.Ko);
+            for (int r = 0; r < C; ++r) for (int hh = 0; hh < nH; ++hh) for (int d = 0; d < hd; ++d)
+                pk.host[o + (size_t)r * L.Ko + hh * hdp + d] = pw->data[(size_t)r * C + hh * hd + d];
+            o = slot(&bw.bproj, Cp); std::copy(pb->data.begin(), pb->data.end(), pk.host.begin() + o);
+            o = slot(&bw.ln2_g, Cp); std::copy(n2w->data.begin(), n2w->data.end(), pk.host.begin() + o);
+            o = slot(&bw.ln2_b, Cp); std::copy(n2b->data.begin(), n2b->data.end(), pk.host.begin() + o);
+            o = slot(&bw.w1, (size_t)L.hiddenP * Cp);
+            for (int r = 0; r < L.hidden; ++r) std::copy(w1->data.begin() + (size_t)r * C, w1->data.begin() + (size_t)(r + 1) * C, pk.host.begin() + o + (size_t)r * Cp);
+            o = slot(&bw.b1, L.hiddenP); std::copy(b1->data.begin(), b1->data.end(), pk.host.begin() + o);
+            o = slot(&bw.w2, (size_t)Cp * L.hiddenP);
+            for (int r = 0; r < C; ++r) std::copy(w2->data.begin() + (size_t)r * L.hidden, w2->data.begin() + (size_t)(r + 1) * L.hidden, pk.host.begin() + o + (size_t)r * L.hiddenP);
+            o = slot(&bw.b2, Cp); std::copy(b2->data.begin(), b2->data.end(), pk.host.begin() + o);
+        }
+        if (L.scale == 1) {          // PatchMerge: norm over [s][C] -> [s][Cp]; down.weight [Cout][2C] -> [CoutP][2Cp]
+            GETP(nw, L.prefix + "subsample.norm.weight", 2 * C); GETP(nb, L.prefix + "subsample.norm.bias", 2 * C);
+            GETP(dw, L.prefix + "subsample.down.weight", L.Cout, 2 * C);
+            size_t og = slot(&L.sub_g, 2 * Cp), ob = slot(&L.sub_b, 2 * Cp), ow = slot(&L.sub_w, (size_t)L.CoutP * 2 * Cp);
+            for (int s = 0; s < 2; ++s) for (int cc = 0; cc < C; ++cc) {
+                pk.host[og + s * Cp + cc] = nw->data[s * C + cc]; pk.host[ob + s * Cp + cc] = nb->data[s * C + cc];
+                for (int r = 0; r < L.Cout; ++r) pk.host[ow + (size_t)r * 2 * Cp + s * Cp + cc] = dw->data[(size_t)r * 2 * C + s * C + cc];
+            }
+        } else if (L.scale == 2) {   // PatchSplit: up.weight [2*Cout][C] -> [2*CoutP][Cp]
+            GETP(nw, L.prefix + "subsample.norm.weight", C); GETP(nb, L.prefix + "subsample.norm.bias", C);
+            GETP(uw, L.prefix + "subsample.up.weight", 2 * L.Cout, C);
+            size_t og = slot(&L.sub_g, Cp), ob = slot(&L.sub_b, Cp), ow = slot(&L.sub_w, (size_t)2 * L.CoutP * Cp);
+            std::copy(nw->data.begin(), nw->data.end(), pk.host.begin() + og);
+            std::copy(nb->data.begin(), nb->data.end(), pk.host.begin() + ob);
+            for (int s = 0; s < 2; ++s) for (int r = 0; r < L.Cout; ++r)
+                std::copy(uw->data.begin() + (size_t)(s * L.Cout + r) * C, uw->data.begin() + (size_t)(s * L.Cout + r + 1) * C,
+                          pk.host.begin() + ow + (size_t)(s * L.CoutP + r) * Cp);
+        }
+    }
+
+    // ---- patch embed / de-embed ----
+    {
+        const int C0 = h->C0, C0p = h->C0p, Kin = c.in_dim * c.patch_f * c.patch_t, Q = h->Q;
+        GETP(w, "encoder.patch_embed.proj.weight", C0, c.in_dim, c.patch_f, c.patch_t);
+        GETP(b, "encoder.patch_embed.proj.bias", C0);
+        GETP(g, "encoder.patch_embed.norm.weight", C0); GETP(be, "encoder.patch_embed.norm.bias", C0);
+        size_t o = slot(&h->pe_w, (size_t)C0p * h->Kpe);
+        for (int r = 0; r < C0; ++r) std::copy(w->data.begin() + (size_t)r * Kin, w->data.begin() + (size_t)(r + 1) * Kin, pk.host.begin() + o + (size_t)r * h->Kpe);
+        o = slot(&h->pe_b, C0p); std::copy(b->data.begin(), b->data.end(), pk.host.begin() + o);
+        o = slot(&h->pe_g, C0p); std::copy(g->data.begin(), g->data.end(), pk.host.begin() + o);
+        o = slot(&h->pe_beta, C0p); std::copy(be->data.begin(), be->data.end(), pk.host.begin() + o);
+
+        GETP(w1, "decoder.patch_deembed.de_proj1.weight", (int64_t)C0 * Q, C0, 5, 5);
+        GETP(b1, "decoder.patch_deembed.de_proj1.bias", (int64_t)C0 * Q);
+        GETP(w2, "decoder.patch_deembed.de_proj2.weight", c.in_dim, C0, 3, 3);
+        GETP(b2, "decoder.patch_deembed.de_proj2.bias", c.in_dim);
+        const size_t K1 = (size_t)25 * C0p;
+        size_t ow = slot(&h->dc1_w, (size_t)Q * C0p * K1), ob = slot(&h->dc1_b, (size_t)Q * C0p);
+        // pixel_shuffle splits the conv channel dim as (s1, s2, C): o = q*C0 + co  (scale.py:16-23,78)
+        for (int q = 0; q < Q; ++q) for (int co = 0; co < C0; ++co) {
+            const size_t orow = (size_t)q * C0 + co, prow = (size_t)q * C0p + co;
+            pk.host[ob + prow] = b1->data[orow];
+            for (int ci = 0; ci < C0; ++ci) for (int kh = 0; kh < 5; ++kh) for (int kw = 0; kw < 5; ++kw)
+                pk.host[ow + prow * K1 + (size_t)(kh * 5 + kw) * C0p + ci] = w1->data[((orow * C0 + ci) * 5 + kh) * 5 + kw];
+        }
+        // conv2 runs on the TIME-major map (D0 = time, D1 = freq): tap (t0 over time = kw, t1 over freq = kh)
+        const size_t K2 = (size_t)9 * C0p;
+        ow = slot(&h->dc2_w, (size_t)16 * K2); ob = slot(&h->dc2_b, 16);
+        if (c.in_dim > 4) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "in_dim > 4");
+        for (int oc = 0; oc < c.in_dim; ++oc) {
+            pk.host[ob + oc] = b2->data[oc];
+            for (int ci = 0; ci < C0; ++ci) for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw)
+                pk.host[ow + (size_t)oc * K2 + (size_t)(kw * 3 + kh) * C0p + ci] = w2->data[(((size_t)oc * C0 + ci) * 3 + kh) * 3 + kw];
+        }
+    }
+
+    // ---- windowed DFT / inverse DFT matrices (base.py:22-47; torch.stft / torch.istft semantics) ----
+    {
+        const int win = c.win_length, N = h->n_fft, F = h->F, Fp = h->Fp, left = h->left;
+        std::vector<double> w(win);
+        auto it = h->params.find("ft.window");
+        for (int k = 0; k < win; ++k) w[k] = (it != h->params.end() && (int)it->second.data.size() == win) ? (double)it->second.data[k] : hann(k, win);
+        size_t o = slot(&h->dft_w, (size_t)2 * Fp * h->winP);
+        for (int f = 0; f < F; ++f) for (int k = 0; k < win; ++k) {
+            const double ang = 2.0 * M_PI * (double)((long long)f * (k + left) % N) / (double)N;
+            pk.host[o + (size_t)f * h->winP + k] = (float)(w[k] * std::cos(ang));
+            pk.host[o + (size_t)(Fp + f) * h->winP + k] = (float)(-w[k] * std::sin(ang));
+        }
+        std::vector<double> wi(win);
+        auto it2 = h->params.find("ift.window");
+        for (int k = 0; k < win; ++k) wi[k] = (it2 != h->params.end() && (int)it2->second.data.size() == win) ? (double)it2->second.data[k] : hann(k, win);
+        o = slot(&h->idft_w, (size_t)h->winP * 2 * Fp);
+        for (int j = 0; j < win; ++j) for (int f = 0; f < F; ++f) {
+            const double coef = (f == 0 || (N % 2 == 0 && f == N / 2)) ? 1.0 : 2.0;   // Hermitian completion of a onesided spectrum
+            const double ang = 2.0 * M_PI * (double)((long long)f * (j + left) % N) / (double)N;
+            pk.host[o + (size_t)j * 2 * Fp + f] = (float)(wi[j] * coef * std::cos(ang) / N);
+            pk.host[o + (size_t)j * 2 * Fp + Fp + f] = (float)(-wi[j] * coef * std::sin(ang) / N);
+        }
+        o = slot(&h->win2, h->winP);
+        for (int j = 0; j < win; ++j) { const float wf = (float)wi[j]; pk.host[o + j] = wf * wf; }
+    }
+
+    // ---- product quantisers ----
+    const int G = c.group_size, Ksz = c.codebook_size;
+    for (Quant& q : h->quants) {
+        const int fix = q.Hq * q.C, D = c.overlap * fix;
+        std::vector<int> dims(G, D / G); dims[G - 1] = D - (D / G) * (G - 1);     // quantization.py:380-386
+        size_t owd = slot(&q.wd, (size_t)q.Nz * q.Kq), owu = slot(&q.wup, (size_t)q.Kq * q.Kup);
+        size_t ocn = slot(&q.cbn, (size_t)G * Ksz * q.dt), oc2 = slot(&q.c2, (size_t)G * Ksz), ocr = slot(&q.cbraw, (size_t)G * Ksz * q.dt);
+        int start = 0;
+        for (int g = 0; g < G; ++g) {
+            const std::string gs = std::to_string(g);
+            GETP(emb, q.prefix + "vqs." + gs + ".embedding.weight", Ksz, q.d);
+            GETP(dw, q.prefix + "down_projs." + gs + ".weight", q.d, dims[g]);
+            GETP(uw, q.prefix + "up_projs." + gs + ".weight", dims[g], q.d);
+            for (int e = 0; e < dims[g]; ++e) {
+                const int flat = start + e;                                     // (o, c, h) order: quantization.py:400-409
+                const int o = flat / fix, r = flat - o * fix, cc = r / q.Hq, hh = r - cc * q.Hq;
+                const size_t col = (size_t)(o * q.Hq + hh) * q.Cp + cc;         // internal (o, h, c) order
+                for (int j = 0; j < q.d; ++j) {
+                    pk.host[owd + (size_t)(g * q.dt + j) * q.Kq + col] = dw->data[(size_t)j * dims[g] + e];
+                    pk.host[owu + col * q.Kup + g * q.dt + j] = uw->data[(size_t)e * q.d + j];
+                }
+            }
+            for (int k = 0; k < Ksz; ++k) {
+                const float* row = emb->data.data() + (size_t)k * q.d;
+                float ss = 0.f;
+                for (int j = 0; j < q.d; ++j) ss += row[j] * row[j];
+                const float den = c.l2norm ? std::max(std::sqrt(ss), 1e-12f) : 1.0f;   // F.normalize (codebook.py:32)
+                float s2 = 0.f;
+                for (int j = 0; j < q.d; ++j) {
+                    const float v = row[j] / den;
+                    pk.host[ocn + ((size_t)g * Ksz + k) * q.dt + j] = v;
+                    pk.host[ocr + ((size_t)g * Ksz + k) * q.dt + j] = row[j];
+                    s2 += v * v;
+                }
+                pk.host[oc2 + (size_t)g * Ksz + k] = s2;
+            }
+            start += dims[g];
+        }
+    }
+
+    // ---- upload ----
+    if (h->wts.base) { ESCX_HIP(hipFree(h->wts.base)); h->wts = Arena(); }
+    const size_t bytes = pk.host.size() * sizeof(float);
+    ESCX_HIP(hipMalloc((void**)&h->wts.base, bytes));
+    h->wts.cap = h->wts.used = bytes;
+    ESCX_HIP(hipMemcpy(h->wts.base, pk.host.data(), bytes, hipMemcpyHostToDevice));
+    for (auto& f : fix) *f.first = reinterpret_cast<float*>(h->wts.base) + f.second;
+    h->finalized = true;
+    return ESCX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// geometry for a batch, index maps, workspace
+// ------------------------------------------------------------------------------------------------
+static int make_shapes(escx_handle_s* h, int B, int T, Shapes* out) {
+    const escx_config& c = h->cfg;
+    if (B < 1 || T < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "batch and frame count must be positive");
+    Shapes s; s.B = B; s.L = 0;
+    s.T = T;
+    s.W = s.T / c.patch_t;                      // the strided conv drops a trailing odd frame (scale.py:42)
+    s.H0 = c.in_freq / c.patch_f;
+    if (s.W < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "input too short");
+    if (s.W % c.overlap != 0) ESCX_FAIL(ESCX_ERR_ASSERT, "Time dimension must be multiple of overlap");   // quantization.py:407
+    s.Tq = s.W / c.overlap;
+    int H = s.H0;
+    s.encH.push_back(H);
+    for (int i = 0; i + 1 < h->n; ++i) { H = (H + 1) / 2; s.encH.push_back(H); }
+    // the decoder doubles H per block; residuals need matching shapes (csrvq.py:15-17) and the quantisers a fixed in_freq
+    for (int st = 0; st < c.max_streams; ++st) {
+        const int scale = h->n - 1 - std::max(st - 1, 0);
+        if (h->quants[st].Hq != s.encH[scale])
+            ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "in_freq/patch (%d) must be divisible by 2^(max_streams-1)", s.H0);
+    }
+    *out = s;
+    return 0;
+}
+
+static int get_map(escx_handle_s* h, int H, int W, int shift, const int** out) {
+    auto key = std::make_tuple(H, W, shift);
+    auto it = h->maps.find(key);
+    if (it != h->maps.end()) { *out = it->second; return 0; }
+    std::vector<int> m;
+    if (shift >= 0) {                           // window slots -> source token (attention.py:139-155, 246-250)
+        const int Hp = rup(H, 4), Wp = rup(W, 4), nWw = Wp / 4;
+        m.resize((size_t)Hp * Wp);
+        for (int hh = 0; hh < Hp; ++hh) for (int ww = 0; ww < Wp; ++ww) {
+            const int sh = (hh + shift) % Hp, sw = (ww + shift) % Wp;       // roll(-shift) over the PADDED map
+            const int slot = (((hh >> 2) * nWw + (ww >> 2)) << 4) + ((hh & 3) << 2) + (ww & 3);
+            m[slot] = (sh < H && sw < W) ? sh * W + sw : -1;
+        }
+    } else {                                    // PatchMerge rows (scale.py:104-112)
+        const int H2 = (H + 1) / 2;
+        m.resize((size_t)H2 * W * 2);
+        for (int h2 = 0; h2 < H2; ++h2) for (int w = 0; w < W; ++w) {
+            m[((size_t)h2 * W + w) * 2 + 0] = (2 * h2) * W + w;
+            m[((size_t)h2 * W + w) * 2 + 1] = (2 * h2 + 1 < H) ? (2 * h2 + 1) * W + w : -1;
+        }
+    }
+    int* d = nullptr;
+    ESCX_HIP(hipMalloc((void**)&d, m.size() * sizeof(int)));
+    ESCX_HIP(hipMemcpy(d, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice));
+    h->maps[key] = d;
+    *out = d;
+    return 0;
+}
+
+extern "C" int64_t escx_workspace_bytes(escx_handle h) { return h ? (int64_t)h->ws.cap : 0; }
+
+static bool ws_fits(escx_handle_s* h, int B, int T) {
+    return h->ws.base && h->shp.B >= B && h->shp.W == T / h->cfg.patch_t && h->shp.T >= T;
+}
+
+static int reserve_frames(escx_handle_s* h, int B, int T) {
+    ESCX_HIP(hipSetDevice(h->device));
+    Shapes s;
+    int rc = make_shapes(h, B, T, &s);
+    if (rc) return rc;
+    const escx_config& c = h->cfg;
+    const int n = h->n;
+    // pre-build every index map the whole-path calls will need
+    const int* dummy;
+    for (int li = 0; li < 2 * n; ++li) {
+        const Layer& Ly = h->layers[li];
+        int H;
+        if (li < n) H = s.encH[std::max(li - 1, 0)];
+        else if (li < 2 * n - 1) H = s.encH[n - 1 - (li - n)];
+        else H = s.encH[0];
+        if ((rc = get_map(h, H, s.W, 0, &dummy))) return rc;
+        if ((rc = get_map(h, H, s.W, 2, &dummy))) return rc;
+        if (Ly.scale == 1 && (rc = get_map(h, H, s.W, -1, &dummy))) return rc;
+    }
+    if (ws_fits(h, B, T)) return ESCX_OK;
+
+    // size every buffer (floats)
+    size_t work = 0, xn = 0, qkv = 0, ob = 0, hid = 0, dec = 0, zp = 0;
+    std::vector<size_t> ehs(n);
+    for (int i = 0; i < n; ++i) ehs[i] = (size_t)B * s.encH[i] * s.W * rup(c.h_dims[i], 16);
+    for (int li = 0; li < 2 * n; ++li) {
+        const Layer& Ly = h->layers[li];
+        int H;
+        if (li < n) H = s.encH[std::max(li - 1, 0)];
+        else if (li < 2 * n - 1) H = s.encH[n - 1 - (li - n)];
+        else H = s.encH[0];
+        const size_t tokens = (size_t)B * H * s.W, slots = (size_t)B * rup(H, 4) * rup(s.W, 4);
+        work = std::max(work, tokens * Ly.Cp);
+        xn = std::max({xn, slots * Ly.Cp, tokens * Ly.Cp, Ly.scale == 1 ? (size_t)B * ((H + 1) / 2) * s.W * 2 * Ly.Cp : 0});
+        qkv = std::max(qkv, slots * Ly.Nqkv);
+        ob = std::max(ob, slots * Ly.Ko);
+        hid = std::max(hid, tokens * Ly.hiddenP);
+        if (li >= n) dec = std::max({dec, tokens * Ly.Cp, (size_t)B * (Ly.scale == 2 ? 2 * H : H) * s.W * Ly.CoutP});
+    }
+    for (const Quant& q : h->quants) {
+        const int sp = pvq_down_splits(B * s.Tq, q.Kq, q.Cp);
+        zp = std::max(zp, (size_t)sp * B * s.Tq * q.Nz);
+    }
+    const int T2 = c.patch_t * s.W, F2 = c.patch_f * s.H0;
+    const size_t spec = (size_t)B * s.T * c.in_dim * h->Fp;
+    const size_t deemb = (size_t)B * T2 * F2 * h->C0p;
+    const size_t rspec = (size_t)B * T2 * c.in_dim * h->Fp;
+    const size_t frames = (size_t)B * T2 * h->winP;
+    const size_t stage = std::max({work, dec, spec, rspec});
+    const size_t codes = (size_t)B * c.max_streams * c.group_size * s.Tq * 2;      // int64 as 2 floats
+    size_t total = 0;
+    auto add = [&](size_t nfl) { total += (nfl * sizeof(float) + 255) / 256 * 256; };
+    add(spec); for (int i = 0; i < n; ++i) add(ehs[i]);
+    add(work); add(xn); add(qkv); add(ob); add(hid); add(dec); add(dec); add(zp); add(deemb); add(rspec); add(frames);
+    add(stage); add(stage); add(codes); add(B);
+
+    if (h->ws.base) { ESCX_HIP(hipDeviceSynchronize()); ESCX_HIP(hipFree(h->ws.base)); h->ws = Arena(); }
+    ESCX_HIP(hipMalloc((void**)&h->ws.base, total));
+    ESCX_HIP(hipMemset(h->ws.base, 0, total));
+    h->ws.cap = total; h->ws.used = 0;
+    h->spec = h->ws.take(spec);
+    h->enc_hs.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) h->enc_hs[i] = h->ws.take(ehs[i]);
+    h->work = h->ws.take(work); h->xn = h->ws.take(xn); h->qkv = h->ws.take(qkv); h->obuf = h->ws.take(ob); h->hid = h->ws.take(hid);
+    h->decA = h->ws.take(dec); h->decB = h->ws.take(dec); h->zpart = h->ws.take(zp); h->zpart_cap = zp;
+    h->deemb = h->ws.take(deemb); h->rspec = h->ws.take(rspec); h->frames = h->ws.take(frames);
+    h->stageA = h->ws.take(stage); h->stageB = h->ws.take(stage);
+    h->codes_tmp = reinterpret_cast<long long*>(h->ws.take(codes));
+    h->loss = h->ws.take(B);
+    if (!h->loss) ESCX_FAIL(ESCX_ERR_STATE, "workspace sizing bug");
+    h->shp = s;
+    return ESCX_OK;
+}
+
+extern "C" int escx_reserve(escx_handle h, int B, int L) {
+    if (!h) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null handle");
+    if (L < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_samples must be positive");
+    return reserve_frames(h, B, 1 + L / h->cfg.hop_length);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch sequences
+// ------------------------------------------------------------------------------------------------
+static int check_ready(escx_handle_s* h) {
+    if (!h) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null handle");
+    if (!h->finalized) ESCX_FAIL(ESCX_ERR_STATE, "parameters not finalised (call escx_finalize_params)");
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) ESCX_FAIL(ESCX_ERR_HIP, "hipSetDevice failed");
+    return 0;
+}
+
+static int ensure_ws(escx_handle_s* h, int B, int T, Shapes* s) {
+    if (!ws_fits(h, B, T)) {
+        int rc = reserve_frames(h, B, T);
+        if (rc) return rc;
+    }
+    return make_shapes(h, B, T, s);
+}
+
+static int frames_of(escx_handle_s* h, int L) { return 1 + L / h->cfg.hop_length; }
+// frame count to reserve when only the latent width is known (decode first): the largest T that maps to W
+static int frames_for_width(escx_handle_s* h, int W) {
+    if (h->ws.base && h->shp.W == W) return h->shp.T;
+    return h->cfg.patch_t * W + h->cfg.patch_t - 1;
+}
+
+namespace {
+struct TmpBuf {                      // test-path scratch for the stage-level entry points (synchronous)
+    float* p = nullptr;
+    ~TmpBuf() { if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); } }
+    int alloc(size_t n_floats) { return hipMalloc((void**)&p, std::max<size_t>(n_floats, 1) * sizeof(float)) == hipSuccess ? 0 : -1; }
+};
+}  // namespace
+
+static int launch_ok(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) ESCX_FAIL(ESCX_ERR_HIP, "%s: kernel launch failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+// One TransformerLayer on padded token maps.  x_in is read-only; y receives (B, H'*W, CoutP).
+// attention.py:48-91 (layer), 129-178 (block): LN1 -> pad -> roll -> windows -> attention -> reverse -> residual -> MLP.
+static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float* y, int B, int H, int W, int* Hout, hipStream_t st) {
+    const int tokens = H * W, M = B * tokens;
+    const int Hp = rup(H, 4), Wp = rup(W, 4), slots = Hp * Wp, Ms = B * slots;
+    float* cur = L.scale ? h->work : y;
+    const float* src = x_in;
+    int rc;
+    for (size_t j = 0; j < L.blocks.size(); ++j) {
+        const BlockW& bw = L.blocks[j];
+        const int shift = (j % 2 == 0) ? 0 : 2;                               // attention.py:29
+        const int* map;
+        if ((rc = get_map(h, H, W, shift, &map))) return rc;
+        ln_rows(1, src, h->xn, bw.ln1_g, bw.ln1_b, map, slots, tokens, Ms, L.C, L.Cp, st);
+        gemm_qkv(h->xn, L.Cp, Ms, bw.wqkv, L.Nqkv, L.Cp, h->qkv, bw.bqkv, L.nH * L.hdp, 1.0f / std::sqrt((float)L.hd), st);
+        if (window_attention(h->qkv, bw.bias_tab, h->obuf, Ms / 16, L.nH, L.hdp, L.Nqkv, L.Ko, Hp / 4, Wp / 4, shift > 0, st))
+            ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "head_dim %d unsupported by the attention kernel", L.hd);
+        gemm_proj_scatter(h->obuf, L.Ko, Ms, bw.wproj, L.Cp, L.Ko, cur, src, bw.bproj, map, slots, tokens, st);
+        ln_rows(0, cur, h->xn, bw.ln2_g, bw.ln2_b, nullptr, tokens, tokens, M, L.C, L.Cp, st);
+        gemm_gelu(h->xn, L.Cp, M, bw.w1, L.hiddenP, L.Cp, h->hid, bw.b1, st);
+        gemm_residual(h->hid, L.hiddenP, M, bw.w2, L.Cp, L.hiddenP, cur, bw.b2, cur, st);
+        src = cur;
+    }
+    if (L.scale == 1) {
+        const int H2 = (H + 1) / 2;
+        const int* map;
+        if ((rc = get_map(h, H, W, -1, &map))) return rc;
+        ln_rows(2, cur, h->xn, L.sub_g, L.sub_b, map, H2 * W, tokens, B * H2 * W, L.C, L.Cp, st);
+        gemm_store(h->xn, 2 * L.Cp, B * H2 * W, L.sub_w, L.CoutP, 2 * L.Cp, y, L.CoutP, nullptr, st);
+        *Hout = H2;
+    } else if (L.scale == 2) {
+        ln_rows(0, cur, h->xn, L.sub_g, L.sub_b, nullptr, tokens, tokens, M, L.C, L.Cp, st);
+        gemm_split(h->xn, L.Cp, M, L.sub_w, 2 * L.CoutP, L.Cp, y, H, W, L.CoutP, st);
+        *Hout = 2 * H;
+    } else {
+        *Hout = H;
+    }
+    return launch_ok(L.prefix.c_str());
+}
+
+static int run_stft(escx_handle_s* h, const float* wave, int B, int L, int T, float* spec, hipStream_t st) {
+    gemm_frames(wave, B, L, T, h->cfg.hop_length, h->left - h->n_fft / 2, h->dft_w, h->cfg.in_dim * h->Fp, h->winP, spec, st);
+    return launch_ok("stft");
+}
+
+static int run_patch_embed(escx_handle_s* h, const float* spec, int B, int T, int W, float* tok, hipStream_t st) {
+    const escx_config& c = h->cfg;
+    const int H0 = c.in_freq / c.patch_f;
+    gemm_patch(spec, B, T, c.in_dim, h->Fp, H0, W, c.patch_f, c.patch_t, h->pe_w, h->C0p, h->Kpe, tok, h->pe_b, st);
+    ln_rows(0, tok, tok, h->pe_g, h->pe_beta, nullptr, H0 * W, H0 * W, B * H0 * W, h->C0, h->C0p, st);
+    return launch_ok("patch_embed");
+}
+
+static int run_encoder(escx_handle_s* h, const Shapes& s, hipStream_t st) {     // base.py:143-158
+    int rc, H = s.H0, Hn;
+    if ((rc = run_patch_embed(h, h->spec, s.B, s.T, s.W, h->stageA, st))) return rc;
+    if ((rc = run_layer(h, h->layers[0], h->stageA, h->enc_hs[0], s.B, H, s.W, &Hn, st))) return rc;
+    for (int i = 0; i + 1 < h->n; ++i) {
+        if ((rc = run_layer(h, h->layers[1 + i], h->enc_hs[i], h->enc_hs[i + 1], s.B, H, s.W, &Hn, st))) return rc;
+        H = Hn;
+    }
+    return 0;
+}
+
+static int run_pvq_encode(escx_handle_s* h, const Quant& q, const float* enc, const float* dec, int B, int W, long long* codes,
+                          long long bstride, float* loss, hipStream_t st) {
+    const escx_config& c = h->cfg;
+    const int Tq = W / c.overlap, M = B * Tq;
+    const int splits = pvq_down_splits(M, q.Kq, q.Cp);
+    if ((size_t)splits * M * q.Nz > h->zpart_cap) ESCX_FAIL(ESCX_ERR_STATE, "split-K scratch too small");
+    gemm_pvq_down(enc, dec, B, q.Hq, W, q.Cp, c.overlap, q.wd, q.Nz, q.Kq, h->zpart, splits, st);
+    if (pvq_search(h->zpart, splits, M, q.Nz, q.cbn, q.c2, q.cbraw, c.group_size, c.codebook_size, q.d, q.dt, Tq, codes, bstride, loss,
+                   1.0f / ((float)Tq * q.d * c.group_size), c.l2norm, st))
+        ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "codebook_dim %d unsupported by the search kernel", q.d);
+    return launch_ok("pvq_encode");
+}
+
+static int run_pvq_decode(escx_handle_s* h, const Quant& q, const long long* codes, long long bstride, const float* dec, int B, int W,
+                          float* out, hipStream_t st) {
+    const escx_config& c = h->cfg;
+    gemm_pvq_up(codes, bstride, q.cbraw, c.group_size, c.codebook_size, q.dt, B, q.Hq, W, q.Cp, c.overlap, q.wup, q.Kq, q.Kup, dec, out, st);
+    return launch_ok("pvq_decode");
+}
+
+static int run_deembed(escx_handle_s* h, const float* tok, int B, int W, float* rspec, hipStream_t st) {   // scale.py:73-81
+    const escx_config& c = h->cfg;
+    const int H0 = c.in_freq / c.patch_f;
+    gemm_conv_deembed1(tok, B, H0, W, h->C0p, h->dc1_w, h->Q * h->C0p, h->deemb, h->dc1_b, c.patch_f, c.patch_t, st);
+    gemm_conv_spec(h->deemb, B, c.patch_t * W, c.patch_f * H0, h->C0p, h->dc2_w, rspec, h->dc2_b, h->Fp, c.in_dim, st);
+    return launch_ok("patch_deembed");
+}
+
+static int run_istft(escx_handle_s* h, const float* rspec, int B, int T2, float* wave, hipStream_t st) {  // base.py:39-47
+    const escx_config& c = h->cfg;
+    gemm_store(rspec, c.in_dim * h->Fp, B * T2, h->idft_w, h->winP, c.in_dim * h->Fp, h->frames, h->winP, nullptr, st);
+    istft_ola(h->frames, h->win2, wave, B, T2, h->winP, c.win_length, c.hop_length, h->left, h->n_fft / 2, c.hop_length * (T2 - 1), st);
+    return launch_ok("istft");
+}
+
+// frame-major padded spectrum [rows][in_dim*Fp] <-> reference-ordered [rows][in_dim][F]
+static void spec_unpad(escx_handle_s* h, const float* src, float* dst, long long rows, hipStream_t st) {
+    unpad_rows(src, dst, rows * h->cfg.in_dim, h->F, h->Fp, st);
+}
+static void spec_pad(escx_handle_s* h, const float* src, float* dst, long long rows, hipStream_t st) {
+    pad_rows(src, dst, rows * h->cfg.in_dim, h->F, h->Fp, st);
+}
+
+extern "C" int escx_num_frames(escx_handle h, int n_samples) { return h ? 1 + n_samples / h->cfg.hop_length : 0; }
+extern "C" int escx_output_samples(escx_handle h, int feat_w) { return h ? h->cfg.hop_length * (h->cfg.patch_t * feat_w - 1) : 0; }
+
+// csrvq.py:131-158
+static int run_csvq_encode(escx_handle_s* h, const Shapes& s, int S, long long* codes, hipStream_t st) {
+    const escx_config& c = h->cfg;
+    const int n = h->n, G = c.group_size;
+    const long long bstride = (long long)S * G * s.Tq, sstride = (long long)G * s.Tq;
+    int rc, H = s.encH[n - 1], Hn;
+    if ((rc = run_pvq_encode(h, h->quants[0], h->enc_hs[n - 1], nullptr, s.B, s.W, codes, bstride, nullptr, st))) return rc;
+    if (S == 1) return 0;
+    float* dec = h->decA; float* other = h->decB;
+    if ((rc = run_pvq_decode(h, h->quants[0], codes, bstride, nullptr, s.B, s.W, dec, st))) return rc;
+    for (int i = 0; i < S - 1; ++i) {
+        const Quant& q = h->quants[i + 1];
+        if ((rc = run_pvq_encode(h, q, h->enc_hs[n - 1 - i], dec, s.B, s.W, codes + (i + 1) * sstride, bstride, nullptr, st))) return rc;
+        if (i + 2 == S) break;                                               // csrvq.py:151
+        if ((rc = run_pvq_decode(h, q, codes + (i + 1) * sstride, bstride, dec, s.B, s.W, dec, st))) return rc;
+        if ((rc = run_layer(h, h->layers[n + i], dec, other, s.B, H, s.W, &Hn, st))) return rc;
+        std::swap(dec, other); H = Hn;
+    }
+    return 0;
+}
+
+extern "C" int escx_encode(escx_handle h, const float* wave, int B, int L, int S, int64_t* codes, int* fh, int* fw, void* stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!wave || !codes) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
+    if (S < 1 || S > h->cfg.max_streams) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "num_streams=%d outside [1, %d]", S, h->cfg.max_streams);
+    if (L <= h->n_fft / 2) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_samples=%d too short for reflect padding of %d", L, h->n_fft / 2);
+    Shapes s; if ((rc = ensure_ws(h, B, frames_of(h, L), &s))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = run_stft(h, wave, B, L, s.T, h->spec, st))) return rc;
+    if ((rc = run_encoder(h, s, st))) return rc;
+    if ((rc = run_csvq_encode(h, s, S, (long long*)codes, st))) return rc;
+    if (fh) *fh = s.encH[h->n - 1];
+    if (fw) *fw = s.W;
+    return ESCX_OK;
+}
+
+// csrvq.py:160-183 + codecs.py:83-94
+static int run_csvq_decode(escx_handle_s* h, const long long* codes, int B, int S, int Hb, int W, float* rspec, hipStream_t st) {
+    const escx_config& c = h->cfg;
+    const int n = h->n, G = c.group_size, Tq = W / c.overlap;
+    const long long bstride = (long long)S * G * Tq, sstride = (long long)G * Tq;
+    int rc, H = Hb, Hn;
+    float* dec = h->decA; float* other = h->decB;
+    if ((rc = run_pvq_decode(h, h->quants[0], codes, bstride, nullptr, B, W, dec, st))) return rc;
+    for (int i = 0; i + 1 < n; ++i) {
+        if (i < S - 1 && (rc = run_pvq_decode(h, h->quants[i + 1], codes + (i + 1) * sstride, bstride, dec, B, W, dec, st))) return rc;
+        if ((rc = run_layer(h, h->layers[n + i], dec, other, B, H, W, &Hn, st))) return rc;
+        std::swap(dec, other); H = Hn;
+    }
+    if ((rc = run_layer(h, h->layers[2 * n - 1], dec, other, B, H, W, &Hn, st))) return rc;
+    return run_deembed(h, other, B, W, rspec, st);
+}
+
+extern "C" int escx_decode(escx_handle h, const int64_t* codes, int B, int S, int fh, int fw, float* wave_out, float* recon_feat,
+                           void* stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!codes || !wave_out) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
+    const escx_config& c = h->cfg;
+    if (S < 1 || S > c.max_streams) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "codes.size(1)=%d outside [1, %d]", S, c.max_streams);
+    if (fw < 1 || fw % c.overlap) ESCX_FAIL(ESCX_ERR_ASSERT, "Time dimension must be multiple of overlap");
+    Shapes s; if ((rc = ensure_ws(h, B, frames_for_width(h, fw), &s))) return rc;
+    if (s.W != fw || s.encH[h->n - 1] != fh) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "feat_shape (%d,%d) does not match the model (%d,%d)", fh, fw, s.encH[h->n - 1], s.W);
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = run_csvq_decode(h, (const long long*)codes, B, S, fh, fw, h->rspec, st))) return rc;
+    const int T2 = c.patch_t * fw;
+    if ((rc = run_istft(h, h->rspec, B, T2, wave_out, st))) return rc;
+    if (recon_feat) spec_unpad(h, h->rspec, recon_feat, (long long)B * T2, st);
+    return launch_ok("decode");
+}
+
+extern "C" int escx_forward(escx_handle h, const float* wave, int B, int L, int S, int64_t* codes, float* wave_out, float* raw_feat,
+                            float* recon_feat, float* cm_loss, void* stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!wave || !codes || !wave_out) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
+    const escx_config& c = h->cfg;
+    if (S < 1 || S > c.max_streams) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "num_streams=%d outside [1, %d]", S, c.max_streams);
+    if (L <= h->n_fft / 2) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_samples=%d too short for reflect padding of %d", L, h->n_fft / 2);
+    Shapes s; if ((rc = ensure_ws(h, B, frames_of(h, L), &s))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int n = h->n, G = c.group_size;
+    const long long bstride = (long long)S * G * s.Tq, sstride = (long long)G * s.Tq;
+    long long* cd = (long long*)codes;
+    if ((rc = run_stft(h, wave, B, L, s.T, h->spec, st))) return rc;
+    if (raw_feat) spec_unpad(h, h->spec, raw_feat, (long long)B * s.T, st);
+    if ((rc = run_encoder(h, s, st))) return rc;
+    float* loss = cm_loss ? h->loss : nullptr;
+    if (loss) ESCX_HIP(hipMemsetAsync(loss, 0, sizeof(float) * B, st));
+    // csrvq.py:97-129 in eval mode: stream 0, then (stream i+1, block i) pairs; untransmitted streams pass through
+    int H = s.encH[n - 1], Hn;
+    float* dec = h->decA; float* other = h->decB;
+    if ((rc = run_pvq_encode(h, h->quants[0], h->enc_hs[n - 1], nullptr, B, s.W, cd, bstride, loss, st))) return rc;
+    if ((rc = run_pvq_decode(h, h->quants[0], cd, bstride, nullptr, B, s.W, dec, st))) return rc;
+    for (int i = 0; i + 1 < n; ++i) {
+        if (i < S - 1) {
+            const Quant& q = h->quants[i + 1];
+            if ((rc = run_pvq_encode(h, q, h->enc_hs[n - 1 - i], dec, B, s.W, cd + (i + 1) * sstride, bstride, loss, st))) return rc;
+            if ((rc = run_pvq_decode(h, q, cd + (i + 1) * sstride, bstride, dec, B, s.W, dec, st))) return rc;
+        }
+        if ((rc = run_layer(h, h->layers[n + i], dec, other, B, H, s.W, &Hn, st))) return rc;
+        std::swap(dec, other); H = Hn;
+    }
+    if ((rc = run_layer(h, h->layers[2 * n - 1], dec, other, B, H, s.W, &Hn, st))) return rc;
+    if ((rc = run_deembed(h, other, B, s.W, h->rspec, st))) return rc;
+    const int T2 = c.patch_t * s.W;
+    if ((rc = run_istft(h, h->rspec, B, T2, wave_out, st))) return rc;
+    if (recon_feat) spec_unpad(h, h->rspec, recon_feat, (long long)B * T2, st);
+    if (cm_loss) ESCX_HIP(hipMemcpyAsync(cm_loss, loss, sizeof(float) * B, hipMemcpyDeviceToDevice, st));
+    return launch_ok("forward");
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage-level entry points (reference layouts in and out)
+// ------------------------------------------------------------------------------------------------
+extern "C" int escx_spec_transform(escx_handle h, const float* wave, int B, int L, float* spec, void* stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!wave || !spec || B < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
+    if (L <= h->n_fft / 2) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_samples=%d too short for reflect padding of %d", L, h->n_fft / 2);
+    const int T = frames_of(h, L);
+    TmpBuf t; if (t.alloc((size_t)B * T * h->cfg.in_dim * h->Fp)) ESCX_FAIL(ESCX_ERR_HIP, "hipMalloc failed");
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = run_stft(h, wave, B, L, T, t.p, st))) return rc;
+    spec_unpad(h, t.p, spec, (long long)B * T, st);
+    return launch_ok("spec_transform");
+}
+
+extern "C" int escx_audio_reconstruct(escx_handle h, const float* spec, int B, int T, float* wave, void* stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!spec || !wave || B < 1 || T < 2) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument (need at least 2 frames)");
+    TmpBuf ts, tf;
+    if (ts.alloc((size_t)B * T * h->cfg.in_dim * h->Fp) || tf.alloc((size_t)B * T * h->winP)) ESCX_FAIL(ESCX_ERR_HIP, "hipMalloc failed");
+    hipStream_t st = (hipStream_t)stream;
+    const escx_config& c = h->cfg;
+    spec_pad(h, spec, ts.p, (long long)B * T, st);
+    gemm_store(ts.p, c.in_dim * h->Fp, B * T, h->idft_w, h->winP, c.in_dim * h->Fp, tf.p, h->winP, nullptr, st);
+    istft_ola(tf.p, h->win2, wave, B, T, h->winP, c.win_length, c.hop_length, h->left, h->n_fft / 2, c.hop_length * (T - 1), st);
+    return launch_ok("audio_reconstruct");
+}
+
+extern "C" int escx_patch_embed(escx_handle h, const float* spec, int B, int T, float* tokens, void* stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    const escx_config& c = h->cfg;
+    const int W = T / c.patch_t, H0 = c.in_freq / c.patch_f;
+    if (!spec || !tokens || B < 1 || W < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
+    TmpBuf ts, tt;
+    if (ts.alloc((size_t)B * T * c.in_dim * h->Fp) || tt.alloc((size_t)B * H0 * W * h->C0p)) ESCX_FAIL(ESCX_ERR_HIP, "hipMalloc failed");
+    hipStream_t st = (hipStream_t)stream;
+    spec_pad(h, spec, ts.p, (long long)B * T, st);
+    if ((rc = run_patch_embed(h, ts.p, B, T, W, tt.p, st))) return rc;
+    unpad_rows(tt.p, tokens, (long long)B * H0 * W, h->C0, h->C0p, st);
+    return launch_ok("patch_embed");
+}
+
+static int stage_ws_for_w(escx_handle_s* h, int B, int W, Shapes* s) { return ensure_ws(h, B, frames_for_width(h, W), s); }
+
+extern "C" int escx_transformer_layer(escx_handle h, int layer_id, const float* x, int B, int H, int W, float* y, int* H_out, void* stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (layer_id < 0 || layer_id >= 2 * h->n) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "layer_id out of range");
+    const Layer& L = h->layers[layer_id];
+    Shapes s; if ((rc = stage_ws_for_w(h, B, W, &s))) return rc;
+    if ((size_t)H > (size_t)2 * s.H0) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "H too large for this model");
+    hipStream_t st = (hipStream_t)stream;
+    int Hn;
+    // stage buffers are sized for the largest map of the model; H*Cp never exceeds that for valid (layer, H) pairs
+    const size_t need = (size_t)B * H * W * L.Cp, cap = std::max<size_t>((size_t)B * s.H0 * s.W * h->C0p, 1);
+    size_t big = 0; for (int i = 0; i < h->n; ++i) big = std::max(big, (size_t)B * s.encH[i] * s.W * rup(h->cfg.h_dims[i], 16));
+    if (need > std::max(cap, big)) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "(H=%d, W=%d) is larger than any map of this layer", H, W);
+    pad_rows(x, h->stageA, (long long)B * H * W, L.C, L.Cp, st);
+    if ((rc = run_layer(h, L, h->stageA, h->stageB, B, H, W, &Hn, st))) return rc;
+    unpad_rows(h->stageB, y, (long long)B * Hn * W, L.scale ? L.Cout : L.C, L.scale ? L.CoutP : L.Cp, st);
+    if (H_out) *H_out = Hn;
+    return launch_ok("transformer_layer");
+}
+
+extern "C" int escx_pvq_encode(escx_handle h, int sid, const float* enc, const float* dec, int B, int W, int64_t* codes, int64_t bstride,
+                               void* stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (sid < 0 || sid >= h->cfg.max_streams) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "stream_id out of range");
+    if (W % h->cfg.overlap) ESCX_FAIL(ESCX_ERR_ASSERT, "Time dimension must be multiple of overlap");
+    const Quant& q = h->quants[sid];
+    Shapes s; if ((rc = stage_ws_for_w(h, B, W, &s))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)B * q.Hq * W;
+    pad_rows(enc, h->stageA, rows, q.C, q.Cp, st);
+    if (dec) pad_rows(dec, h->stageB, rows, q.C, q.Cp, st);
+    return run_pvq_encode(h, q, h->stageA, dec ? h->stageB : nullptr, B, W, (long long*)codes, bstride, nullptr, st);
+}
+
+extern "C" int escx_pvq_decode(escx_handle h, int sid, const int64_t* codes, int64_t bstride, const float* dec, int B, int W, float* out,
+                               void* stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (sid < 0 || sid >= h->cfg.max_streams) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "stream_id out of range");
+    if (W % h->cfg.overlap) ESCX_FAIL(ESCX_ERR_ASSERT, "Time dimension must be multiple of overlap");
+    const Quant& q = h->quants[sid];
+    Shapes s; if ((rc = stage_ws_for_w(h, B, W, &s))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)B * q.Hq * W;
+    if (dec) pad_rows(dec, h->stageB, rows, q.C, q.Cp, st);
+    if ((rc = run_pvq_decode(h, q, (const long long*)codes, bstride, dec ? h->stageB : nullptr, B, W, h->stageA, st))) return rc;
+    unpad_rows(h->stageA, out, rows, q.C, q.Cp, st);
+    return launch_ok("pvq_decode");
+}
+
+extern "C" int escx_patch_deembed(escx_handle h, const float* tokens, int B, int W, float* spec, void* stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    Shapes s; if ((rc = stage_ws_for_w(h, B, W, &s))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    pad_rows(tokens, h->stageA, (long long)B * s.H0 * W, h->C0, h->C0p, st);
+    if ((rc = run_deembed(h, h->stageA, B, W, h->rspec, st))) return rc;
+    spec_unpad(h, h->rspec, spec, (long long)B * h->cfg.patch_t * W, st);
+    return launch_ok("patch_deembed");
+}
+
+extern "C" int escx_codes_narrow(const int64_t* codes, int16_t* out, int64_t n, void* stream) {
+    codes_narrow((const long long*)codes, (short*)out, n, (hipStream_t)stream);
+    return launch_ok("codes_narrow");
+}
+extern "C" int escx_codes_widen(const int16_t* in, int64_t* codes, int64_t n, void* stream) {
+    codes_widen((const short*)in, (long long*)codes, n, (hipStream_t)stream);
+    return launch_ok("codes_widen");
+}

@@ -1,0 +1,89 @@
+// Internal host-side structures of libescx (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/escx.h"
+
+namespace escx {
+
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+void set_error(const char* fmt, ...);
+
+#define ESCX_FAIL(code, ...) do { ::escx::set_error(__VA_ARGS__); return (code); } while (0)
+#define ESCX_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+        ::escx::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return ESCX_ERR_HIP; } } while (0)
+
+struct Param { std::vector<float> data; std::vector<int64_t> shape; };
+
+struct Arena {                       // device bump allocator
+    char* base = nullptr; size_t cap = 0, used = 0;
+    float* take(size_t n_floats) {
+        size_t bytes = (n_floats * sizeof(float) + 255) / 256 * 256;
+        if (used + bytes > cap) return nullptr;
+        float* p = reinterpret_cast<float*>(base + used); used += bytes; return p;
+    }
+};
+
+struct BlockW {                      // one SwinBlock, packed
+    float *ln1_g, *ln1_b, *wqkv, *bqkv, *bias_tab, *wproj, *bproj, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
+};
+
+struct Layer {                       // one TransformerLayer (attention.py:9-91)
+    std::string prefix;
+    int C, Cp, nH, hd, hdp, Nqkv, Ko, hidden, hiddenP;
+    int scale;                       // 0 none, 1 down (PatchMerge), 2 up (PatchSplit)
+    int Cout, CoutP;
+    std::vector<BlockW> blocks;
+    float *sub_g = nullptr, *sub_b = nullptr, *sub_w = nullptr;
+};
+
+struct Quant {                       // one ProductVectorQuantize (quantization.py:7-136)
+    std::string prefix;
+    int C, Cp, Hq, d, dt, Nz, Kq, Kup;
+    float *wd, *cbn, *c2, *cbraw, *wup;
+};
+
+struct Shapes {                      // geometry for one (batch, n_samples)
+    int B = 0, L = 0, T = 0, W = 0, H0 = 0, Tq = 0;
+    std::vector<int> encH;           // H at encoder scale i (i = 0..n-1)
+};
+
+}  // namespace escx
+
+struct escx_handle_s {
+    escx_config cfg;
+    int device = 0;
+    int n = 0;                       // n_scales
+    int F = 0, Fp = 0, n_fft = 0, left = 0, winP = 0, Kpe = 0, C0 = 0, C0p = 0, Q = 0;
+    std::map<std::string, escx::Param> params;
+    std::vector<std::string> required;
+    bool finalized = false;
+
+    escx::Arena wts;                 // packed weights
+    std::vector<escx::Layer> layers; // 2n entries (see escx_transformer_layer)
+    std::vector<escx::Quant> quants; // max_streams entries
+    float *pe_w = nullptr, *pe_b = nullptr, *pe_g = nullptr, *pe_beta = nullptr;
+    float *dc1_w = nullptr, *dc1_b = nullptr, *dc2_w = nullptr, *dc2_b = nullptr;
+    float *dft_w = nullptr, *idft_w = nullptr, *win2 = nullptr;
+
+    // workspace
+    escx::Arena ws;
+    escx::Shapes shp;                // shapes the workspace was sized for
+    float *spec = nullptr, *work = nullptr, *xn = nullptr, *qkv = nullptr, *obuf = nullptr, *hid = nullptr;
+    float *decA = nullptr, *decB = nullptr, *zpart = nullptr, *deemb = nullptr, *rspec = nullptr, *frames = nullptr;
+    float *stageA = nullptr, *stageB = nullptr, *loss = nullptr;
+    long long* codes_tmp = nullptr;
+    std::vector<float*> enc_hs;
+    size_t zpart_cap = 0;
+
+    // index maps (device), keyed by (H, W, shift) ; shift = -1 -> merge map
+    std::map<std::tuple<int, int, int>, int*> maps;
+};

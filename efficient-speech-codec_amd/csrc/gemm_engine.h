@@ -1,0 +1,366 @@
+// fp32 MFMA GEMM engine for gfx950 (MI355X):  Out = epilogue( A_loader(m, k) . W[n][k] )
+//
+// Every dense contraction of the ESC hot path (QKV / proj / MLP / merge / split linears, the 5x5 and 3x3
+// de-embedding convolutions as implicit GEMMs, the windowed DFT and inverse DFT, the quantiser down/up
+// projections) is this one kernel with a pluggable A-side loader and a pluggable epilogue.
+//
+//  * arithmetic: v_mfma_f32_16x16x4_f32 -- exact fp32 (bitwise an fmaf chain), 157 TFLOP/s peak.  The
+//    emitted code indices must be bit-exact against the fp32 reference, so no bf16/fp16/xf32 anywhere.
+//  * operands are swapped on purpose: the WEIGHT tile is the MFMA "A" operand and the ACTIVATION tile the
+//    "B" operand, so that a lane ends up holding 4 consecutive output features of one output row and
+//    the epilogue is a single 16-byte store per lane (bias / residual loads are 16-byte too).
+//  * K and N are padded to multiples of 16 in every internal layout (weights are packed once on the host
+//    with zero padding), which keeps every global access 16-byte aligned and the MFMA tiles full.
+//  * 256 threads = 4 waves stacked along M; each wave owns (BM/4) x BN of the block tile.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace escx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int BK, class Loader, class Epi>
+__global__ __launch_bounds__(256) void gemm_kernel(Loader ld, const float* __restrict__ Wt, int M, int Np,
+                                                   int Kp, int k_per_z, Epi ep) {
+    static_assert(BM % 64 == 0 && BN % 16 == 0 && BK % 16 == 0, "tile shape");
+    constexpr int LDS_LD = BK + 4;             // +1 access width: rows land on different bank groups
+    constexpr int TM = BM / 64;                // 16-row MFMA tiles per wave along M
+    constexpr int TN = BN / 16;
+    constexpr int KV = BK / 4;                 // float4 per tile row
+    constexpr int A4 = BM * KV;
+    constexpr int B4 = BN * KV;
+    constexpr int AJ = (A4 + 255) / 256;
+
+    __shared__ float As[BM * LDS_LD];
+    __shared__ float Bs[BN * LDS_LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int kbeg = blockIdx.z * k_per_z;
+    const int kend = min(Kp, kbeg + k_per_z);
+
+    typename Loader::Ctx ctx[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int i = tid + j * 256;
+        ctx[j] = ld.make_ctx(m0 + (i < A4 ? i / KV : 0));
+    }
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = zero4();
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int i = tid + j * 256;
+            if (A4 % 256 == 0 || i < A4) {
+                const int row = i / KV, c4 = i % KV;
+                st4(&As[row * LDS_LD + 4 * c4], ld.load4(ctx[j], k0, 4 * c4));
+            }
+        }
+#pragma unroll
+        for (int i = tid; i < B4; i += 256) {
+            const int row = i / KV, c4 = i % KV;
+            const int n = n0 + row;
+            f32x4 v = zero4();
+            if (n < Np) v = ld4(Wt + (size_t)n * Kp + k0 + 4 * c4);
+            st4(&Bs[row * LDS_LD + 4 * c4], v);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            f32x4 af[TM], wf[TN];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) af[b] = ld4(&As[(wave * (BM / 4) + b * 16 + l15) * LDS_LD + kk + 4 * lg]);
+#pragma unroll
+            for (int a = 0; a < TN; ++a) wf[a] = ld4(&Bs[(a * 16 + l15) * LDS_LD + kk + 4 * lg]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[a][r], af[b][r], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // lane holds D[n = 4*lg + r][m = l15] of every 16x16 tile: 4 consecutive output features of one row
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const int m = m0 + wave * (BM / 4) + b * 16 + l15;
+        if (m >= M) continue;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int n = n0 + a * 16 + 4 * lg;
+            if (n < Np) ep.store(m, n, acc[a][b], blockIdx.z);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A-side loaders.  make_ctx(m) is evaluated once per thread-row before the K loop; load4(ctx, k0, kin)
+// returns A[m][k0+kin .. +3] (k0 is block-uniform, kin the offset inside the BK tile).
+// ------------------------------------------------------------------------------------------------
+struct PlainA {                 // A[m][k], row stride lda (multiple of 4 floats)
+    const float* A; int lda; int M;
+    typedef const float* Ctx;
+    __device__ __forceinline__ Ctx make_ctx(int m) const { return m < M ? A + (size_t)m * lda : nullptr; }
+    __device__ __forceinline__ f32x4 load4(Ctx c, int k0, int kin) const { return c ? ld4(c + k0 + kin) : zero4(); }
+};
+
+struct ConvA {                  // implicit-GEMM 'same' convolution over a (D0, D1) grid of Cp-wide tokens
+    const float* x; int D0, D1, Cp, T0, T1, M;      // k = (t0*T1 + t1)*Cp + c ; requires BK | Cp
+    struct Ctx { int base; int i0; int i1; };
+    __device__ __forceinline__ Ctx make_ctx(int m) const {
+        Ctx c; c.base = -1; c.i0 = 0; c.i1 = 0;
+        if (m < M) { const int b = m / (D0 * D1); const int r = m - b * D0 * D1; c.i0 = r / D1; c.i1 = r - c.i0 * D1; c.base = b * D0 * D1; }
+        return c;
+    }
+    __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
+        const int tap = k0 / Cp, cc = k0 - tap * Cp + kin;
+        const int t0 = tap / T1, t1 = tap - t0 * T1;
+        const int j0 = c.i0 + t0 - T0 / 2, j1 = c.i1 + t1 - T1 / 2;
+        if (c.base < 0 || j0 < 0 || j0 >= D0 || j1 < 0 || j1 >= D1) return zero4();
+        return ld4(x + ((size_t)(c.base + j0 * D1 + j1)) * Cp + cc);
+    }
+};
+
+struct FrameA {                 // STFT framing with reflect padding: A[(b,f)][k] = wave[b][reflect(f*hop + k + off)]
+    const float* wave; int L, T, hop, off, M;
+    struct Ctx { const float* w; int start; };
+    __device__ __forceinline__ Ctx make_ctx(int m) const {
+        Ctx c; c.w = nullptr; c.start = 0;
+        if (m < M) { const int b = m / T, f = m - b * T; c.w = wave + (size_t)b * L; c.start = f * hop + off; }
+        return c;
+    }
+    __device__ __forceinline__ float at(const float* w, int p) const {
+        if (p < 0) p = -p;
+        if (p >= L) p = 2 * (L - 1) - p;
+        return w[p];
+    }
+    __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
+        if (!c.w) return zero4();
+        const int p = c.start + k0 + kin;
+        f32x4 v; v[0] = at(c.w, p); v[1] = at(c.w, p + 1); v[2] = at(c.w, p + 2); v[3] = at(c.w, p + 3);
+        return v;
+    }
+};
+
+struct PatchA {                 // PatchEmbed gather: A[(b,ph,pw)][k=(c,df,dt)] = spec[b][pt*pw+dt][c*Fp + pf*ph+df]
+    const float* spec; int T, ldf, Fp, H, W, pf, pt, K, M;   // ldf = in_dim*Fp (row stride of a frame)
+    struct Ctx { const float* p; };
+    __device__ __forceinline__ Ctx make_ctx(int m) const {
+        Ctx c; c.p = nullptr;
+        if (m < M) { const int b = m / (H * W); const int r = m - b * H * W; const int ph = r / W, pw = r - ph * W;
+                     c.p = spec + ((size_t)b * T + (size_t)pt * pw) * ldf + pf * ph; }
+        return c;
+    }
+    __device__ __forceinline__ float one(const float* p, int k) const {
+        if (k >= K) return 0.f;
+        const int c = k / (pf * pt); const int r = k - c * pf * pt; const int df = r / pt, dt = r - df * pt;
+        return p[(size_t)dt * ldf + c * Fp + df];
+    }
+    __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
+        if (!c.p) return zero4();
+        f32x4 v; const int k = k0 + kin;
+        v[0] = one(c.p, k); v[1] = one(c.p, k + 1); v[2] = one(c.p, k + 2); v[3] = one(c.p, k + 3);
+        return v;
+    }
+};
+
+struct ResidualGatherA {        // PVQ framing of (enc - dec): A[(b,t)][k=(o,h,c)] ; requires BK | Cp
+    const float* enc; const float* dec; int Hq, W, Cp, Tq, ov, M;
+    typedef int Ctx;            // element offset of token (b, h=0, w=ov*t), or -1
+    __device__ __forceinline__ Ctx make_ctx(int m) const {
+        if (m >= M) return -1;
+        const int b = m / Tq, t = m - b * Tq;
+        return (b * Hq * W + ov * t) * Cp;
+    }
+    __device__ __forceinline__ f32x4 load4(Ctx c, int k0, int kin) const {
+        if (c < 0) return zero4();
+        const int oh = k0 / Cp, cc = k0 - oh * Cp + kin;
+        const int o = oh / Hq, h = oh - o * Hq;
+        const size_t idx = (size_t)c + (size_t)(h * W + o) * Cp + cc;
+        f32x4 v = ld4(enc + idx);
+        if (dec) v -= ld4(dec + idx);
+        return v;
+    }
+};
+
+struct CodeGatherA {            // PVQ de-quantisation: A[(b,t)][g*dt + j] = codebook_g[code[b,g,t]][j]
+    const long long* codes; long long bstride; const float* cb; int G, Ksz, dt, Tq, M;
+    struct Ctx { const long long* c; };
+    __device__ __forceinline__ Ctx make_ctx(int m) const {
+        Ctx c; c.c = nullptr;
+        if (m < M) { const int b = m / Tq, t = m - b * Tq; c.c = codes + (size_t)b * bstride + t; }
+        return c;
+    }
+    __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
+        const int k = k0 + kin; const int g = k / dt;
+        if (!c.c || g >= G) return zero4();
+        const long long code = c.c[(size_t)g * Tq];
+        return ld4(cb + ((size_t)g * Ksz + (size_t)code) * dt + (k - g * dt));
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Epilogues: store(m, n, v, z) with v = 4 consecutive output features n..n+3 of row m.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+struct EpiStore {               // out[m][n] = v (+ bias[n])
+    float* out; int ldo; const float* bias;
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        if (bias) v += ld4(bias + n);
+        st4(out + (size_t)m * ldo + n, v);
+    }
+};
+
+struct EpiGelu {                // out = gelu(v + bias)   (exact erf form, nn.GELU default)
+    float* out; int ldo; const float* bias;
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        v += ld4(bias + n);
+        v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+        st4(out + (size_t)m * ldo + n, v);
+    }
+};
+
+struct EpiResidual {            // out = res + (v + bias)   (in-place safe: out may alias res)
+    float* out; int ldo; const float* bias; const float* res;
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        v += ld4(bias + n);
+        st4(out + (size_t)m * ldo + n, ld4(res + (size_t)m * ldo + n) + v);
+    }
+};
+
+struct EpiQkv {                 // out = (v + bias), q columns (n < nq) additionally * scale  (attention.py:225)
+    float* out; int ldo; const float* bias; int nq; float scale;
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        v += ld4(bias + n);
+        if (n < nq) v *= scale;
+        st4(out + (size_t)m * ldo + n, v);
+    }
+};
+
+struct EpiProjScatter {         // window reverse + un-roll + crop + residual: out[tok] = shortcut[tok] + (v + bias)
+    float* out; const float* shortcut; const float* bias; const int* map; int slots, tokens, Cp;
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        const int b = m / slots, s = m - b * slots;
+        const int tok = map[s];
+        if (tok < 0) return;
+        const size_t idx = ((size_t)b * tokens + tok) * Cp + n;
+        v += ld4(bias + n);
+        st4(out + idx, ld4(shortcut + idx) + v);
+    }
+};
+
+struct EpiSplit {               // PatchSplit pixel shuffle (2,1): out[(b, 2h+s, w)][c] = v[(b,h,w)][s*C2p + c]
+    float* out; int H, W, C2p;
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        const int b = m / (H * W); const int r = m - b * H * W; const int h = r / W, w = r - h * W;
+        const int s = n / C2p, c = n - s * C2p;
+        st4(out + ((size_t)(b * 2 * H + 2 * h + s) * W + w) * C2p + c, v);
+    }
+};
+
+struct EpiDeembed1 {            // conv5x5 bias + pixel shuffle (pf,pt) into a TIME-major (b, t, f, Cp) map
+    float* out; const float* bias; int H, W, Cp, pf, pt;
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        const int b = m / (H * W); const int r = m - b * H * W; const int h = r / W, w = r - h * W;
+        const int q = n / Cp, c = n - q * Cp;
+        const int s1 = q / pt, s2 = q - s1 * pt;
+        const int f = pf * h + s1, t = pt * w + s2;
+        v += ld4(bias + n);
+        st4(out + (((size_t)b * (pt * W) + t) * (pf * H) + f) * Cp + c, v);
+    }
+};
+
+struct EpiSpec {                // conv3x3 -> frame-major spectrum: rows m = (b, t, f); out[(b,t)][ch*Fp + f]
+    float* out; const float* bias; int T, F, Fp, in_dim;
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        if (n >= in_dim) return;
+        const int bt = m / F, f = m - bt * F;
+        float* o = out + (size_t)bt * (in_dim * Fp) + f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < in_dim) o[(n + r) * Fp] = v[r] + bias[n + r];
+    }
+};
+
+struct EpiPvqAdd {              // un-frame + post_fuse: out[(b,h,ov*t+o)][c] = dec[...] + v   (csrvq.py:19-21)
+    float* out; const float* dec; int Hq, W, Cp, Tq, ov;
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        const int b = m / Tq, t = m - b * Tq;
+        const int oh = n / Cp, c = n - oh * Cp;
+        const int o = oh / Hq, h = oh - o * Hq;
+        const size_t idx = ((size_t)(b * Hq + h) * W + ov * t + o) * Cp + c;
+        if (dec) v += ld4(dec + idx);
+        st4(out + idx, v);
+    }
+};
+
+struct EpiPartial {             // split-K partial sums, reduced in a fixed order by the consumer (deterministic)
+    float* out; int M, Np;
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, int z) const {
+        st4(out + ((size_t)z * M + m) * Np + n, v);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Host-side tile selection and launch.
+// ------------------------------------------------------------------------------------------------
+inline int pick_bk(int Kp) { return Kp % 48 == 0 ? 48 : (Kp % 32 == 0 ? 32 : 16); }
+inline int pick_bn(int Np) {
+    // smallest padded width first, widest tile as tie-break
+    const int cands[4] = {96, 48, 32, 16};
+    int best = 16, best_cost = 1 << 30;
+    for (int c : cands) { const int cost = (Np + c - 1) / c * c; if (cost < best_cost) { best_cost = cost; best = c; } }
+    return best;
+}
+
+template <int BM, int BN, int BK, class Loader, class Epi>
+inline void launch_tile(const Loader& ld, const float* Wt, int M, int Np, int Kp, int splits, const Epi& ep, hipStream_t s) {
+    int kIters = Kp / BK;
+    int per = (kIters + splits - 1) / splits;
+    dim3 grid((M + BM - 1) / BM, (Np + BN - 1) / BN, (kIters + per - 1) / per);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, Loader, Epi>), grid, dim3(256), 0, s, ld, Wt, M, Np, Kp, per * BK, ep);
+}
+
+template <int BM, int BK, class Loader, class Epi>
+inline void launch_bn(int BN, const Loader& ld, const float* Wt, int M, int Np, int Kp, int splits, const Epi& ep, hipStream_t s) {
+    switch (BN) {
+        case 96: launch_tile<BM, 96, BK>(ld, Wt, M, Np, Kp, splits, ep, s); break;
+        case 48: launch_tile<BM, 48, BK>(ld, Wt, M, Np, Kp, splits, ep, s); break;
+        case 32: launch_tile<BM, 32, BK>(ld, Wt, M, Np, Kp, splits, ep, s); break;
+        default: launch_tile<BM, 16, BK>(ld, Wt, M, Np, Kp, splits, ep, s); break;
+    }
+}
+
+// Generic entry: picks BN from Np and BK from Kp (or uses the caller's BK when a loader constrains it).
+template <int BM, class Loader, class Epi>
+inline void launch_gemm(const Loader& ld, const float* Wt, int M, int Np, int Kp, const Epi& ep, hipStream_t s,
+                        int splits = 1, int force_bk = 0) {
+    const int BN = pick_bn(Np);
+    const int BK = force_bk ? force_bk : pick_bk(Kp);
+    switch (BK) {
+        case 48: launch_bn<BM, 48>(BN, ld, Wt, M, Np, Kp, splits, ep, s); break;
+        case 32: launch_bn<BM, 32>(BN, ld, Wt, M, Np, Kp, splits, ep, s); break;
+        default: launch_bn<BM, 16>(BN, ld, Wt, M, Np, Kp, splits, ep, s); break;
+    }
+}
+
+}  // namespace escx

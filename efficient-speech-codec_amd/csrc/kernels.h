@@ -1,0 +1,317 @@
+// Non-GEMM kernels of the ESC hot path (gfx950): LayerNorm + gather, 4x4-window attention core,
+// codebook search (distance + argmin), inverse-STFT overlap-add, layout converters.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gemm_engine.h"
+
+namespace escx {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over rows made of SEGS segments of Cp floats (C real channels each), optionally gathered.
+//   MODE 0: identity rows               (norm2, PatchSplit.norm, PatchEmbed.norm)
+//   MODE 1: window gather (SEGS == 1)   map[slot] = source token or -1; a -1 slot is a ZERO row placed
+//                                       AFTER the norm (attention.py:135-143: pad follows norm1)
+//   MODE 2: merge gather (SEGS == 2)    map[2*row+s] = source token or -1; a -1 segment is a zero row that
+//                                       PARTICIPATES in the statistics (scale.py:106-112: pad precedes norm)
+// 16 lanes per row, float4 per lane per step; two-pass mean / variance in registers-equivalent order.
+// ------------------------------------------------------------------------------------------------
+template <int SEGS, int MODE>
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const int* __restrict__ map, int rows_per_clip, int src_rows_per_clip,
+                                                      int total_rows, int C, int Cp, float eps) {
+    const int sub = threadIdx.x & 15;
+    const int grp = (blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int ngrp = (gridDim.x * 256) >> 4;
+    const int V = Cp / 4;                       // float4 per segment
+    for (int row = grp; row < total_rows; row += ngrp) {
+        const int b = row / rows_per_clip, rr = row - b * rows_per_clip;
+        const float* sp[SEGS];
+        bool zero_out = false;
+#pragma unroll
+        for (int s = 0; s < SEGS; ++s) {
+            int srow = (MODE == 0) ? rr : map[rr * SEGS + s];
+            if (srow < 0) { sp[s] = nullptr; if (MODE == 1) zero_out = true; }
+            else sp[s] = src + ((size_t)b * src_rows_per_clip + srow) * Cp;
+        }
+        float* dp = dst + (size_t)row * (SEGS * Cp);
+        if (zero_out) {
+            for (int v = sub; v < V; v += 16) st4(dp + 4 * v, zero4());
+            continue;
+        }
+        // pass 1: mean over the real channels
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < SEGS; ++s)
+            if (sp[s])
+                for (int v = sub; v < V; v += 16) {
+                    f32x4 x = ld4(sp[s] + 4 * v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (4 * v + e < C) sum += x[e];
+                }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 16);
+        const float mean = sum / (float)(SEGS * C);
+        float var = 0.f;
+#pragma unroll
+        for (int s = 0; s < SEGS; ++s)
+            for (int v = sub; v < V; v += 16) {
+                f32x4 x = sp[s] ? ld4(sp[s] + 4 * v) : zero4();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (4 * v + e < C) { const float d = x[e] - mean; var += d * d; }
+            }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) var += __shfl_xor(var, o, 16);
+        const float rstd = 1.0f / sqrtf(var / (float)(SEGS * C) + eps);
+#pragma unroll
+        for (int s = 0; s < SEGS; ++s)
+            for (int v = sub; v < V; v += 16) {
+                f32x4 x = sp[s] ? ld4(sp[s] + 4 * v) : zero4();
+                const f32x4 g = ld4(gamma + s * Cp + 4 * v), bb = ld4(beta + s * Cp + 4 * v);
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (4 * v + e < C) ? (x[e] - mean) * rstd * g[e] + bb[e] : 0.f;
+                st4(dp + s * Cp + 4 * v, y);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Window attention core (attention.py:222-241) for 4x4 windows: one wave per (window, head).
+//   qkv : [B*nW*16][ldq]  columns: which*(nH*hdp) + h*hdp + d ; q is already scaled, pad dims are 0
+//   bias: [nH][16][16]    relative-position bias gathered per head (attention.py:228-231)
+//   out : [B*nW*16][ldo]  columns: h*hdp + d  (head concat, padded heads)
+// S^T = K.Q^T on the MFMA (swapped so a lane holds one query row's scores for keys 4g..4g+3), softmax
+// across the 4 lane groups with two shuffles, then O^T = V^T.P^T, again lane = (query, 4 consecutive d).
+// STEPS = hdp/4 MFMA k-steps; lane (i, g) feeds dims STEPS*g .. STEPS*g+STEPS-1 (k-slot remap is free).
+// ------------------------------------------------------------------------------------------------
+template <int STEPS>
+__global__ __launch_bounds__(256) void window_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+                                                               float* __restrict__ out, int total_pairs, int nH, int ldq, int ldo,
+                                                               int nWh, int nWw, int shifted) {
+    constexpr int HDP = 4 * STEPS;
+    constexpr int DT = (HDP + 15) / 16;        // 16-wide output tiles per head
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, g = lane >> 4;
+    const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * 256) >> 6;
+    const int kOff = nH * HDP, vOff = 2 * nH * HDP;
+    for (int pair = wave_global; pair < total_pairs; pair += nwaves) {
+        const int win = pair / nH, h = pair - win * nH;
+        const float* base = qkv + (size_t)win * 16 * ldq + h * HDP;
+        const float* rowp = base + (size_t)i * ldq + STEPS * g;
+        float kf[STEPS], qf[STEPS];
+#pragma unroll
+        for (int r = 0; r < STEPS; ++r) { qf[r] = rowp[r]; kf[r] = rowp[kOff + r]; }
+        f32x4 s = zero4();
+#pragma unroll
+        for (int r = 0; r < STEPS; ++r) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[r], qf[r], s, 0, 0, 0);
+        // lane (query i, group g) holds S[i][key 4g + r]
+        s += ld4(bias + ((size_t)h * 16 + i) * 16 + 4 * g);
+        if (shifted) {                          // attention.py:56-75 regions, evaluated on the fly
+            const int wloc = win % (nWh * nWw);
+            const int wh = wloc / nWw, ww = wloc - wh * nWw;
+            const bool lastH = (wh == nWh - 1), lastW = (ww == nWw - 1);
+            const int qh = i >> 2, qw = i & 3;
+            const int labq = 3 * (lastH ? (qh < 2 ? 1 : 2) : 0) + (lastW ? (qw < 2 ? 1 : 2) : 0);
+            const int labkh = 3 * (lastH ? (g < 2 ? 1 : 2) : 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int labk = labkh + (lastW ? (r < 2 ? 1 : 2) : 0);
+                s[r] += (labk != labq) ? -100.0f : 0.0f;
+            }
+        }
+        float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        f32x4 p;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = expf(s[r] - mx);
+        float den = (p[0] + p[1]) + (p[2] + p[3]);
+        den += __shfl_xor(den, 16);
+        den += __shfl_xor(den, 32);
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] *= inv;
+        // O^T[d][query] = sum_key V[key][d] * P[query][key]; k-slot (g, r) <-> key 4g + r
+        float* orow = out + ((size_t)win * 16 + i) * ldo + h * HDP;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const int d = t * 16 + i;
+            f32x4 o = zero4();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float vv = (d < HDP) ? base[(size_t)(4 * g + r) * ldq + vOff + d] : 0.f;
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, p[r], o, 0, 0, 0);
+            }
+            if (t * 16 + 4 * g < HDP) st4(orow + t * 16 + 4 * g, o);
+        }
+        if (h == 0 && nH * HDP < ldo) {         // keep the K padding of the projection GEMM at exact zero
+            for (int c = nH * HDP + g; c < ldo; c += 4) out[((size_t)win * 16 + i) * ldo + c] = 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Codebook search (codebook.py:20-43): for 16 framed vectors of one product-VQ group per block,
+//   z = sum of split-K partials (fixed order) ; zn = z / max(||z||, 1e-12)
+//   dist[n] = (sum zn^2 - (2 zn).c_n) + ||c_n||^2  with c_n the pre-normalised code ; argmin, lowest index
+//   wins ties, NaN wins over everything (torch.min semantics).
+// The (2 zn).c^T products run on the MFMA with the CODEBOOK tile as the row operand so that a lane owns
+// one vector and walks its codes in increasing index order; the 1024 x d codebook (<=128 KB) is read
+// straight from L2 -- each fragment is used exactly once per block, so an LDS copy would add traffic.
+// ------------------------------------------------------------------------------------------------
+struct SearchArgs {
+    const float* zpart; int splits; int M; int ldz;       // partials [splits][M][ldz]; group g at column g*dt
+    const float* cbn; const float* c2; const float* cbraw; // [G][Ksz][dt], [G][Ksz], [G][Ksz][dt]
+    int Ksz, d, Tq;
+    long long* codes; long long bstride;                   // codes[b*bstride + g*Tq + t]
+    float* loss; float loss_scale;                         // optional: loss[b] += scale * sum_j (cb[code][j]-z[j])^2
+    int l2norm;
+};
+
+__device__ __forceinline__ bool arg_better(float d1, int i1, float d2, int i2) {
+    const bool n1 = d1 != d1, n2 = d2 != d2;
+    if (n1 || n2) return n1 && (!n2 || i1 < i2);
+    return d1 < d2 || (d1 == d2 && i1 < i2);
+}
+
+template <int STEPS>
+__global__ __launch_bounds__(256) void pvq_search_kernel(SearchArgs a) {
+    constexpr int DT = 4 * STEPS;
+    __shared__ float zs[16][DT + 1];
+    __shared__ float zn2[16][DT];
+    __shared__ float asum[16];
+    __shared__ float bestd[4][16];
+    __shared__ int besti[4][16];
+    const int g = blockIdx.y;
+    const int m0 = blockIdx.x * 16;
+    const int tid = threadIdx.x;
+    // 1) reduce split-K partials in a fixed order
+    for (int e = tid; e < 16 * DT; e += 256) {
+        const int r = e / DT, j = e - r * DT;
+        const int m = m0 + r;
+        float z = 0.f;
+        if (m < a.M && j < a.d)
+            for (int s = 0; s < a.splits; ++s) z += a.zpart[((size_t)s * a.M + m) * a.ldz + g * DT + j];
+        zs[r][j] = z;
+    }
+    __syncthreads();
+    // 2) F.normalize(z) and sum(zn^2) (codebook.py:31-36); one thread per vector, sequential like a row reduction
+    if (tid < 16) {
+        float ss = 0.f;
+        for (int j = 0; j < a.d; ++j) ss += zs[tid][j] * zs[tid][j];
+        const float den = a.l2norm ? fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
+        float s2 = 0.f;
+        for (int j = 0; j < DT; ++j) {
+            const float zn = (j < a.d) ? zs[tid][j] / den : 0.f;
+            s2 += zn * zn;
+            zn2[tid][j] = 2.0f * zn;
+        }
+        asum[tid] = s2;
+    }
+    __syncthreads();
+    // 3) distances + running argmin
+    const int lane = tid & 63, wave = tid >> 6;
+    const int vi = lane & 15, lg = lane >> 4;
+    float zf[STEPS];
+#pragma unroll
+    for (int r = 0; r < STEPS; ++r) zf[r] = zn2[vi][STEPS * lg + r];
+    const float av = asum[vi];
+    const float* cb = a.cbn + (size_t)g * a.Ksz * DT;
+    const float* c2 = a.c2 + (size_t)g * a.Ksz;
+    float bd = __builtin_inff();
+    int bi = 0x7fffffff;
+    bool have = false;
+    const int per_wave = (a.Ksz + 3) / 4;
+    const int cbeg = wave * per_wave, cend = min(a.Ksz, cbeg + per_wave);
+    for (int c0 = cbeg; c0 < cend; c0 += 16) {
+        const int crow = c0 + vi;
+        float cf[STEPS];
+#pragma unroll
+        for (int r = 0; r < STEPS; ++r) cf[r] = (crow < cend) ? cb[(size_t)crow * DT + STEPS * lg + r] : 0.f;
+        f32x4 dot = zero4();
+#pragma unroll
+        for (int r = 0; r < STEPS; ++r) dot = __builtin_amdgcn_mfma_f32_16x16x4f32(cf[r], zf[r], dot, 0, 0, 0);
+        // lane (vector vi, group lg) holds dot for codes c0 + 4*lg + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int code = c0 + 4 * lg + r;
+            if (code < cend) {
+                const float dist = (av - dot[r]) + c2[code];
+                if (!have || arg_better(dist, code, bd, bi)) { bd = dist; bi = code; have = true; }
+            }
+        }
+    }
+    if (!have) { bd = __builtin_inff(); bi = 0x7fffffff; }
+    // across the 4 lane groups of the wave
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const float od = __shfl_xor(bd, o);
+        const int oi = __shfl_xor(bi, o);
+        if (arg_better(od, oi, bd, bi)) { bd = od; bi = oi; }
+    }
+    if (lg == 0) { bestd[wave][vi] = bd; besti[wave][vi] = bi; }
+    __syncthreads();
+    if (tid < 16) {
+        float d0 = bestd[0][tid]; int i0 = besti[0][tid];
+        for (int w = 1; w < 4; ++w) if (arg_better(bestd[w][tid], besti[w][tid], d0, i0)) { d0 = bestd[w][tid]; i0 = besti[w][tid]; }
+        const int m = m0 + tid;
+        if (m < a.M) {
+            const int b = m / a.Tq, t = m - b * a.Tq;
+            a.codes[(size_t)b * a.bstride + (size_t)g * a.Tq + t] = (long long)i0;
+            if (a.loss) {       // eval-mode commitment loss: mse(z_q, z_e).mean([1,2]) / groups (codebook.py:72-73)
+                const float* q = a.cbraw + ((size_t)g * a.Ksz + i0) * DT;
+                float e = 0.f;
+                for (int j = 0; j < a.d; ++j) { const float df = q[j] - zs[tid][j]; e += df * df; }
+                atomicAdd(a.loss + b, e * a.loss_scale);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Inverse STFT tail: overlap-add of windowed inverse-DFT frames and division by the window envelope
+// (torch.istft semantics: center=True trims n_fft/2, length = hop*(T-1)).
+//   frames: [B*T][ldf] holds w[j] * irfft(frame)[left + j], j in [0, win)
+// ------------------------------------------------------------------------------------------------
+__global__ void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ win2, float* __restrict__ wave,
+                                 int B, int T, int ldf, int win, int hop, int left, int half, int out_len) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * out_len) return;
+    const int b = idx / out_len, s = idx - b * out_len;
+    const int p = s + half - left;               // position relative to the start of frame 0's window support
+    int t_hi = p / hop; if (t_hi > T - 1) t_hi = T - 1;
+    float acc = 0.f, env = 0.f;
+    for (int t = t_hi; t >= 0; --t) {
+        const int j = p - t * hop;
+        if (j >= win) break;
+        acc += frames[((size_t)b * T + t) * ldf + j];
+        env += win2[j];
+    }
+    wave[idx] = acc / env;
+}
+
+// layout converters between reference (unpadded) rows and internal padded rows
+__global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long long rows, int C, int Cp) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * Cp) return;
+    const long long r = idx / Cp; const int c = (int)(idx - r * Cp);
+    dst[idx] = c < C ? src[r * C + c] : 0.f;
+}
+__global__ void unpad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long long rows, int C, int Cp) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * C) return;
+    const long long r = idx / C; const int c = (int)(idx - r * C);
+    dst[idx] = src[r * Cp + c];
+}
+__global__ void codes_narrow_kernel(const long long* __restrict__ in, short* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (short)in[i];
+}
+__global__ void codes_widen_kernel(const short* __restrict__ in, long long* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (long long)in[i];
+}
+
+}  // namespace escx

@@ -1,0 +1,78 @@
+// Launchers for the non-GEMM kernels.
+#include "kernels.h"
+#include "launchers.h"
+
+namespace escx {
+
+static inline int grid_for(long long work_items, int per_block, int cap = 4096) {
+    long long g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+void ln_rows(int mode, const float* src, float* dst, const float* gamma, const float* beta, const int* map, int rows_per_clip,
+             int src_rows_per_clip, int total_rows, int C, int Cp, hipStream_t s) {
+    const int grid = grid_for(total_rows, 16, 8192);
+    const float eps = 1e-5f;
+    if (mode == 0)
+        hipLaunchKernelGGL((ln_rows_kernel<1, 0>), dim3(grid), dim3(256), 0, s, src, dst, gamma, beta, map, rows_per_clip,
+                           src_rows_per_clip, total_rows, C, Cp, eps);
+    else if (mode == 1)
+        hipLaunchKernelGGL((ln_rows_kernel<1, 1>), dim3(grid), dim3(256), 0, s, src, dst, gamma, beta, map, rows_per_clip,
+                           src_rows_per_clip, total_rows, C, Cp, eps);
+    else
+        hipLaunchKernelGGL((ln_rows_kernel<2, 2>), dim3(grid), dim3(256), 0, s, src, dst, gamma, beta, map, rows_per_clip,
+                           src_rows_per_clip, total_rows, C, Cp, eps);
+}
+
+int window_attention(const float* qkv, const float* bias, float* out, int total_windows, int nH, int hdp, int ldq, int ldo, int nWh,
+                     int nWw, int shifted, hipStream_t s) {
+    const long long pairs = (long long)total_windows * nH;
+    const int grid = grid_for(pairs, 4, 16384);
+#define ESCX_ATT(S) case S: hipLaunchKernelGGL((window_attention_kernel<S>), dim3(grid), dim3(256), 0, s, qkv, bias, out, (int)pairs, \
+                                               nH, ldq, ldo, nWh, nWw, shifted); return 0;
+    switch (hdp / 4) {
+        ESCX_ATT(1) ESCX_ATT(2) ESCX_ATT(3) ESCX_ATT(4) ESCX_ATT(5) ESCX_ATT(6) ESCX_ATT(7) ESCX_ATT(8)
+        ESCX_ATT(12) ESCX_ATT(16)
+        default: return -1;
+    }
+#undef ESCX_ATT
+}
+
+int pvq_search(const float* zpart, int splits, int M, int ldz, const float* cbn, const float* c2, const float* cbraw, int G, int Ksz,
+               int d, int dt, int Tq, long long* codes, long long bstride, float* loss, float loss_scale, int l2norm, hipStream_t s) {
+    SearchArgs a{zpart, splits, M, ldz, cbn, c2, cbraw, Ksz, d, Tq, codes, bstride, loss, loss_scale, l2norm};
+    dim3 grid((M + 15) / 16, G);
+#define ESCX_SRCH(S) case S: hipLaunchKernelGGL((pvq_search_kernel<S>), grid, dim3(256), 0, s, a); return 0;
+    switch (dt / 4) {
+        ESCX_SRCH(1) ESCX_SRCH(2) ESCX_SRCH(3) ESCX_SRCH(4) ESCX_SRCH(5) ESCX_SRCH(6) ESCX_SRCH(7) ESCX_SRCH(8)
+        ESCX_SRCH(12) ESCX_SRCH(16)
+        default: return -1;
+    }
+#undef ESCX_SRCH
+}
+
+void istft_ola(const float* frames, const float* win2, float* wave, int B, int T, int ldf, int win, int hop, int left, int half,
+               int out_len, hipStream_t s) {
+    const long long n = (long long)B * out_len;
+    hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, frames, win2, wave, B, T, ldf, win, hop,
+                       left, half, out_len);
+}
+
+void pad_rows(const float* src, float* dst, long long rows, int C, int Cp, hipStream_t s) {
+    const long long n = rows * Cp;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, C, Cp);
+}
+void unpad_rows(const float* src, float* dst, long long rows, int C, int Cp, hipStream_t s) {
+    const long long n = rows * C;
+    hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, C, Cp);
+}
+void codes_narrow(const long long* in, short* out, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(codes_narrow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+}
+void codes_widen(const short* in, long long* out, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(codes_widen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+}
+
+}  // namespace escx

@@ -1,0 +1,47 @@
+// Host-callable launchers (one per kernel group); implemented in gemm_swin.hip / gemm_misc.hip / kernels_misc.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace escx {
+
+// ---- Swin block / scale-change linears (gemm_swin.hip) ----
+void gemm_qkv(const float* A, int lda, int M, const float* W, int Np, int Kp, float* out, const float* bias,
+              int nq, float scale, hipStream_t s);
+void gemm_proj_scatter(const float* A, int lda, int M, const float* W, int Np, int Kp, float* out, const float* shortcut,
+                       const float* bias, const int* map, int slots, int tokens, hipStream_t s);
+void gemm_gelu(const float* A, int lda, int M, const float* W, int Np, int Kp, float* out, const float* bias, hipStream_t s);
+void gemm_residual(const float* A, int lda, int M, const float* W, int Np, int Kp, float* out, const float* bias,
+                   const float* res, hipStream_t s);
+void gemm_store(const float* A, int lda, int M, const float* W, int Np, int Kp, float* out, int ldo, const float* bias, hipStream_t s);
+void gemm_split(const float* A, int lda, int M, const float* W, int Np, int Kp, float* out, int H, int Wd, int C2p, hipStream_t s);
+
+// ---- everything else that is a contraction (gemm_misc.hip) ----
+void gemm_frames(const float* wave, int B, int L, int T, int hop, int off, const float* W, int Np, int Kp, float* out, hipStream_t s);
+void gemm_patch(const float* spec, int B, int T, int in_dim, int Fp, int H, int Wd, int pf, int pt, const float* W, int Np, int Kp,
+                float* out, const float* bias, hipStream_t s);
+void gemm_conv_deembed1(const float* x, int B, int H, int Wd, int Cp, const float* W, int Np, float* out, const float* bias,
+                        int pf, int pt, hipStream_t s);
+void gemm_conv_spec(const float* x, int B, int T, int F, int Cp, const float* W, float* out, const float* bias, int Fp, int in_dim,
+                    hipStream_t s);
+void gemm_pvq_down(const float* enc, const float* dec, int B, int Hq, int Wd, int Cp, int ov, const float* W, int Np, int Kp,
+                   float* zpart, int splits, hipStream_t s);
+int pvq_down_splits(int M, int Kp, int Cp);
+void gemm_pvq_up(const long long* codes, long long bstride, const float* cbraw, int G, int Ksz, int dt, int B, int Hq, int Wd, int Cp,
+                 int ov, const float* W, int Np, int Kp, const float* dec, float* out, hipStream_t s);
+
+// ---- non-GEMM kernels (kernels_misc.hip) ----
+// mode 0: identity rows; 1: window gather (pad rows -> zeros after norm); 2: merge gather (2 segments)
+void ln_rows(int mode, const float* src, float* dst, const float* gamma, const float* beta, const int* map, int rows_per_clip,
+             int src_rows_per_clip, int total_rows, int C, int Cp, hipStream_t s);
+int window_attention(const float* qkv, const float* bias, float* out, int total_windows, int nH, int hdp, int ldq, int ldo, int nWh,
+                     int nWw, int shifted, hipStream_t s);
+int pvq_search(const float* zpart, int splits, int M, int ldz, const float* cbn, const float* c2, const float* cbraw, int G, int Ksz,
+               int d, int dt, int Tq, long long* codes, long long bstride, float* loss, float loss_scale, int l2norm, hipStream_t s);
+void istft_ola(const float* frames, const float* win2, float* wave, int B, int T, int ldf, int win, int hop, int left, int half,
+               int out_len, hipStream_t s);
+void pad_rows(const float* src, float* dst, long long rows, int C, int Cp, hipStream_t s);
+void unpad_rows(const float* src, float* dst, long long rows, int C, int Cp, hipStream_t s);
+void codes_narrow(const long long* in, short* out, long long n, hipStream_t s);
+void codes_widen(const short* in, long long* out, long long n, hipStream_t s);
+
+}  // namespace escx

@@ -1,0 +1,1 @@
+from .codecs import ESC, make_model, model_dict  # noqa: F401

@@ -1,0 +1,352 @@
+"""esc.ESC -- host side of the MI355X-native ESC codec.
+
+Keeps the reference's Python surface (`/root/reference/esc/models/codecs.py:9-94,183-200`): the constructor
+kwargs, `.encode(x, num_streams) -> (codes, feat_shape)`, `.decode(codes, feat_shape) -> wave`, the eval-mode
+`.forward(x, x_feat, num_streams)` dict, `max_streams`, `max_bps`, `make_model`, and the reference state_dict
+key layout (so reference checkpoints load with `load_state_dict`).  The parameters live here as ordinary
+`nn.Parameter`s; the arithmetic lives in libescx.so (hand-written HIP for gfx950) reached through ctypes.
+There is NO PyTorch/CPU implementation of the path in this package: a CPU tensor or a missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, List, Literal, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import _native
+
+__all__ = ["ESC", "make_model", "model_dict", "state_manifest"]
+
+
+def _rel_pos_index(ws: int) -> torch.Tensor:
+    """(dh+ws-1)*(2ws-1) + (dw+ws-1); reference attention.py:195-205."""
+    ih = torch.arange(ws).repeat_interleave(ws)
+    iw = torch.arange(ws).repeat(ws)
+    return ((ih[:, None] - ih[None, :] + ws - 1) * (2 * ws - 1) + (iw[:, None] - iw[None, :] + ws - 1)).long()
+
+
+def state_manifest(cfg: dict) -> Dict[str, Tuple[int, ...]]:
+    """key -> shape of the reference state_dict for this configuration."""
+    h, heads, depth, ws = list(cfg["h_dims"]), list(cfg["swin_heads"]), cfg["swin_depth"], cfg["window_size"]
+    n, S, G = len(h), cfg["max_streams"], cfg["group_size"]
+    pf, pt = cfg["patch_size"]
+    win = int(cfg["win_len"] * cfg["sr"] * 1e-3)
+    man: Dict[str, Tuple[int, ...]] = {"ft.window": (win,), "ift.window": (win,)}
+    dec = h[::-1]
+    H0 = cfg["in_freq"] // pf
+    for s in range(S):                                                  # base.py:49-69
+        C = dec[max(s - 1, 0)]
+        Hq = H0 // 2 ** (S - 1) if s == 0 else H0 // 2 ** (S - s)
+        D = cfg["overlap"] * Hq * C
+        dims = [D // G] * G
+        dims[-1] = D - (D // G) * (G - 1)
+        d = cfg["codebook_dims"][s]
+        for g in range(G):
+            man[f"quantizers.{s}.vqs.{g}.embedding.weight"] = (cfg["codebook_size"], d)
+        for g in range(G):
+            man[f"quantizers.{s}.down_projs.{g}.weight"] = (d, dims[g])
+        for g in range(G):
+            man[f"quantizers.{s}.up_projs.{g}.weight"] = (dims[g], d)
+
+    def block(p, C, nH):
+        hid = int(C * cfg["mlp_ratio"])
+        for j in range(depth):
+            q = f"{p}swint_blocks.{j}."
+            man[q + "norm1.weight"] = (C,); man[q + "norm1.bias"] = (C,)
+            man[q + "attn.relative_position_bias_table"] = ((2 * ws - 1) ** 2, nH)
+            man[q + "attn.relative_position_index"] = (ws * ws, ws * ws)
+            man[q + "attn.qkv.weight"] = (3 * C, C); man[q + "attn.qkv.bias"] = (3 * C,)
+            man[q + "attn.proj.weight"] = (C, C); man[q + "attn.proj.bias"] = (C,)
+            man[q + "norm2.weight"] = (C,); man[q + "norm2.bias"] = (C,)
+            man[q + "mlp.linear_1.weight"] = (hid, C); man[q + "mlp.linear_1.bias"] = (hid,)
+            man[q + "mlp.linear_2.weight"] = (C, hid); man[q + "mlp.linear_2.bias"] = (C,)
+
+    for i in range(n - 1):
+        p = f"encoder.blocks.{i}."
+        block(p, h[i], heads[i])
+        man[p + "subsample.norm.weight"] = (2 * h[i],); man[p + "subsample.norm.bias"] = (2 * h[i],)
+        man[p + "subsample.down.weight"] = (h[i + 1], 2 * h[i])
+    man["encoder.patch_embed.proj.weight"] = (h[0], cfg["in_dim"], pf, pt)
+    man["encoder.patch_embed.proj.bias"] = (h[0],)
+    man["encoder.patch_embed.norm.weight"] = (h[0],); man["encoder.patch_embed.norm.bias"] = (h[0],)
+    block("encoder.pre_nn.", h[0], heads[0])
+    rh = heads[::-1]
+    for j in range(n - 1):
+        p = f"decoder.blocks.{j}."
+        block(p, dec[j], rh[j])
+        man[p + "subsample.norm.weight"] = (dec[j],); man[p + "subsample.norm.bias"] = (dec[j],)
+        man[p + "subsample.up.weight"] = (2 * dec[j + 1], dec[j])
+    man["decoder.patch_deembed.de_proj1.weight"] = (h[0] * pf * pt, h[0], 5, 5)
+    man["decoder.patch_deembed.de_proj1.bias"] = (h[0] * pf * pt,)
+    man["decoder.patch_deembed.de_proj2.weight"] = (cfg["in_dim"], h[0], 3, 3)
+    man["decoder.patch_deembed.de_proj2.bias"] = (cfg["in_dim"],)
+    block("decoder.post_nn.", dec[-1], rh[-1])
+    return man
+
+
+def _init_tensor(key: str, shape) -> torch.Tensor:
+    """Default initialisation with the distributions the reference's modules use."""
+    if key.endswith("relative_position_index"):
+        return _rel_pos_index(int(math.isqrt(shape[0])))
+    if key.endswith(".window"):
+        return torch.hann_window(shape[0])
+    t = torch.empty(shape)
+    if ".norm" in key:
+        return t.fill_(1.0) if key.endswith("weight") else t.zero_()
+    if key.endswith("relative_position_bias_table"):
+        return nn.init.trunc_normal_(t, std=0.02)                       # attention.py:212
+    if key.endswith("embedding.weight"):
+        return nn.init.kaiming_normal_(t)                               # codebook.py:14
+    fan_in = shape[1] * (shape[2] * shape[3] if len(shape) == 4 else 1) if len(shape) > 1 else shape[0]
+    bound = 1.0 / math.sqrt(max(fan_in, 1))
+    return t.uniform_(-bound, bound)
+
+
+class _Node(nn.Module):
+    """Plain container so that parameters register under the reference's dotted key names."""
+
+
+def _attach(root: nn.Module, key: str, tensor: torch.Tensor, buffer: bool):
+    parts = key.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    if buffer:
+        mod.register_buffer(parts[-1], tensor, persistent=True)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+class ESC(nn.Module):
+    """Efficient Speech Codec (cross-scale residual VQ + Swin transformers), MI355X-native execution."""
+
+    def __init__(self, in_dim: int = 2, in_freq: int = 192, h_dims: list = [45, 72, 96, 144, 192, 384],
+                 max_streams: int = 6, win_len: int = 20, hop_len: int = 5, sr: int = 16000,
+                 patch_size: list = [3, 2], swin_heads: list = [3, 6, 12, 24, 24], swin_depth: int = 2,
+                 window_size: int = 4, mlp_ratio: float = 4.,
+                 overlap: int = 2, group_size: int = 3,
+                 codebook_size: int = 1024, codebook_dims: list = [8, 8, 8, 8, 8, 8],
+                 l2norm: bool = True, backbone: Literal['transformer', 'convolution'] = 'transformer',
+                 kernel_size: list = [5, 2], conv_depth: int = 1) -> None:
+        super().__init__()
+        if backbone != "transformer":
+            raise NotImplementedError("only backbone='transformer' (csvq+swinT) is implemented; the convolution "
+                                      "backbone is an ablation outside the accelerated path")
+        self.cfg = dict(in_dim=in_dim, in_freq=in_freq, h_dims=list(h_dims), max_streams=max_streams, win_len=win_len,
+                        hop_len=hop_len, sr=sr, patch_size=list(patch_size), swin_heads=list(swin_heads),
+                        swin_depth=swin_depth, window_size=window_size, mlp_ratio=float(mlp_ratio), overlap=overlap,
+                        group_size=group_size, codebook_size=codebook_size, codebook_dims=list(codebook_dims),
+                        l2norm=bool(l2norm), backbone=backbone)
+        self.in_freq, self.in_dim = in_freq, in_dim                      # base.py:16-20
+        self.max_streams = max_streams
+        self.enc_h_dims = list(h_dims)
+        self.dec_h_dims = list(h_dims)[::-1]
+        self.win_length = int(win_len * sr * 1e-3)                       # base.py:23
+        self.hop_length = int(hop_len * sr * 1e-3)                       # base.py:24
+        self.max_bps = (2 / overlap) * max_streams * math.log2(codebook_size) * group_size // (20 * patch_size[1] // 2)  # base.py:70
+        if len(codebook_dims) < max_streams or len(swin_heads) < len(h_dims) - 1:
+            raise ValueError("codebook_dims / swin_heads shorter than the number of streams / scales")
+
+        for key, shape in state_manifest(self.cfg).items():
+            is_buf = key.endswith("relative_position_index") or key.endswith(".window")
+            _attach(self, key, _init_tensor(key, shape), is_buf)
+
+        self._handles: Dict[int, ctypes.c_void_p] = {}
+        self._dirty = True
+
+    # ---- weight management ------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        self._dirty = True
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        sd = dict(state_dict)
+        own = self.state_dict()
+        for k in ("ft.window", "ift.window"):            # torchaudio buffers: optional in incoming checkpoints
+            if k not in sd:
+                sd[k] = own[k]
+        for k in own:                                    # the index buffer is regenerated if absent
+            if k.endswith("relative_position_index") and k not in sd:
+                sd[k] = own[k]
+        self._dirty = True
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def refresh_weights(self):
+        """Call after mutating parameters in place (optimizer steps etc.); `.to()`/`load_state_dict` do it for you."""
+        self._dirty = True
+
+    def _c_config(self) -> _native.EscxConfig:
+        c = self.cfg
+        cc = _native.EscxConfig()
+        cc.in_dim, cc.in_freq, cc.n_scales = c["in_dim"], c["in_freq"], len(c["h_dims"])
+        for i, v in enumerate(c["h_dims"]):
+            cc.h_dims[i] = v
+        cc.max_streams = c["max_streams"]
+        cc.win_length, cc.hop_length = self.win_length, self.hop_length
+        cc.patch_f, cc.patch_t = c["patch_size"]
+        for i, v in enumerate(c["swin_heads"][:_native.MAX_SCALES]):
+            cc.swin_heads[i] = v
+        cc.swin_depth, cc.window_size, cc.mlp_ratio = c["swin_depth"], c["window_size"], c["mlp_ratio"]
+        cc.overlap, cc.group_size, cc.codebook_size = c["overlap"], c["group_size"], c["codebook_size"]
+        for i, v in enumerate(c["codebook_dims"][:_native.MAX_SCALES]):
+            cc.codebook_dims[i] = v
+        cc.l2norm = int(c["l2norm"])
+        return cc
+
+    def _handle(self, device: torch.device):
+        lib = _native.load()
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if self._dirty:
+            for hd in self._handles.values():
+                lib.escx_destroy(hd)
+            self._handles = {}
+            self._dirty = False
+        if idx not in self._handles:
+            hd = ctypes.c_void_p()
+            cc = self._c_config()
+            _native.check(lib.escx_create(ctypes.byref(cc), idx, ctypes.byref(hd)))
+            try:
+                for key, t in self.state_dict().items():
+                    if not t.is_floating_point():
+                        continue
+                    host = t.detach().to("cpu", torch.float32).contiguous()
+                    shape = (ctypes.c_int64 * max(host.dim(), 1))(*host.shape)
+                    _native.check(lib.escx_set_param(hd, key.encode(), host.data_ptr(), shape, host.dim()))
+                _native.check(lib.escx_finalize_params(hd))
+            except Exception:
+                lib.escx_destroy(hd)
+                raise
+            self._handles[idx] = hd
+        return lib, self._handles[idx]
+
+    def __del__(self):
+        try:
+            lib = _native.load()
+            for hd in self._handles.values():
+                lib.escx_destroy(hd)
+        except Exception:
+            pass
+
+    @staticmethod
+    def _need_gpu(t: torch.Tensor, what: str):
+        if not t.is_cuda:
+            raise RuntimeError(f"esc.ESC (MI355X build): {what} must live on a HIP device (got {t.device}); "
+                               "this package has no CPU implementation of the encode/decode path")
+
+    @staticmethod
+    def _stream(device) -> ctypes.c_void_p:
+        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    def reserve(self, batch: int, n_samples: int, device=None):
+        """Pre-size the workspace (otherwise done on first use; resizing synchronises the device)."""
+        device = torch.device(device) if device is not None else next(self.parameters()).device
+        lib, hd = self._handle(device)
+        _native.check(lib.escx_reserve(hd, batch, n_samples))
+
+    def latent_shape(self, n_samples: int) -> Tuple[int, int]:
+        pf, pt = self.cfg["patch_size"]
+        T = 1 + n_samples // self.hop_length
+        H = self.in_freq // pf
+        for _ in range(len(self.enc_h_dims) - 1):
+            H = (H + 1) // 2
+        return H, T // pt
+
+    # ---- public API (codecs.py:48-94) ---------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, num_streams: int = 6):
+        """(Bs, L) waveform -> codes (Bs, num_streams, group_size, W/overlap) int64, feat_shape (H, W)."""
+        if x.dim() != 2:
+            raise ValueError("x must have shape (Bs, L)")
+        self._need_gpu(x, "x")
+        x = x.to(torch.float32).contiguous()
+        lib, hd = self._handle(x.device)
+        B, L = x.shape
+        _, W = self.latent_shape(L)
+        if W % self.cfg["overlap"] != 0:
+            raise AssertionError("Time dimension must be multiple of overlap")       # quantization.py:407
+        codes = torch.empty((B, int(num_streams), self.cfg["group_size"], W // self.cfg["overlap"]), dtype=torch.int64,
+                            device=x.device)
+        fh, fw = ctypes.c_int(), ctypes.c_int()
+        with torch.cuda.device(x.device):
+            _native.check(lib.escx_encode(hd, x.data_ptr(), B, L, int(num_streams), codes.data_ptr(), ctypes.byref(fh),
+                                          ctypes.byref(fw), self._stream(x.device)))
+        return codes, (fh.value, fw.value)
+
+    @torch.no_grad()
+    def decode(self, codes: torch.Tensor, feat_shape=(2, 1000), return_feat: bool = False):
+        """codes (Bs, num_streams, group_size, *) + feat_shape (H, W) -> waveform (Bs, hop*(2W-1))."""
+        if codes.dim() != 4:
+            raise ValueError("codes must have shape (Bs, num_streams, group_size, T)")
+        self._need_gpu(codes, "codes")
+        codes = codes.to(torch.int64).contiguous()
+        lib, hd = self._handle(codes.device)
+        B, S, G, Tq = codes.shape
+        H, W = int(feat_shape[0]), int(feat_shape[1])
+        if G != self.cfg["group_size"] or Tq * self.cfg["overlap"] != W:
+            raise ValueError(f"codes shape {tuple(codes.shape)} does not match feat_shape {(H, W)}")
+        pt = self.cfg["patch_size"][1]
+        out = torch.empty((B, self.hop_length * (pt * W - 1)), dtype=torch.float32, device=codes.device)
+        feat = torch.empty((B, pt * W, self.in_dim, self.in_freq), dtype=torch.float32, device=codes.device) if return_feat else None
+        with torch.cuda.device(codes.device):
+            _native.check(lib.escx_decode(hd, codes.data_ptr(), B, S, H, W, out.data_ptr(),
+                                          feat.data_ptr() if return_feat else None, self._stream(codes.device)))
+        if return_feat:
+            return out, feat.permute(0, 2, 3, 1)
+        return out
+
+    def forward_one_step(self, x, x_feat=None, num_streams=6, freeze_codebook=False):
+        if self.training or freeze_codebook:
+            raise NotImplementedError("training-mode forward (STE, codebook losses, backward) is outside the accelerated "
+                                      "inference path; call model.eval() first")
+        if x_feat is not None:
+            raise NotImplementedError("forward(x_feat=...) with a precomputed spectrum is not implemented; pass x_feat=None")
+        if x.dim() != 2:
+            raise ValueError("x must have shape (Bs, L)")
+        self._need_gpu(x, "x")
+        xin = x.to(torch.float32).contiguous()
+        lib, hd = self._handle(xin.device)
+        B, L = xin.shape
+        S = int(num_streams)
+        _, W = self.latent_shape(L)
+        if W % self.cfg["overlap"] != 0:
+            raise AssertionError("Time dimension must be multiple of overlap")
+        pt = self.cfg["patch_size"][1]
+        T = 1 + L // self.hop_length
+        dev = xin.device
+        codes = torch.empty((B, S, self.cfg["group_size"], W // self.cfg["overlap"]), dtype=torch.int64, device=dev)
+        recon = torch.empty((B, self.hop_length * (pt * W - 1)), dtype=torch.float32, device=dev)
+        raw_feat = torch.empty((B, T, self.in_dim, self.in_freq), dtype=torch.float32, device=dev)
+        recon_feat = torch.empty((B, pt * W, self.in_dim, self.in_freq), dtype=torch.float32, device=dev)
+        cm = torch.empty((B,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _native.check(lib.escx_forward(hd, xin.data_ptr(), B, L, S, codes.data_ptr(), recon.data_ptr(), raw_feat.data_ptr(),
+                                           recon_feat.data_ptr(), cm.data_ptr(), self._stream(dev)))
+        return {"cm_loss": cm, "cb_loss": cm.clone(), "raw_audio": x, "recon_audio": recon,
+                "raw_feat": raw_feat.permute(0, 2, 3, 1), "recon_feat": recon_feat.permute(0, 2, 3, 1), "codes": codes}
+
+    def forward(self, x, x_feat, num_streams, freeze_codebook=False):
+        """Eval-mode forward of the reference (codecs.py:48-66): dict with cm_loss, cb_loss, raw_audio, recon_audio,
+        raw_feat (Bs,2,F,T), recon_feat (Bs,2,F,T'), codes."""
+        num_streams = self.max_streams if freeze_codebook else num_streams
+        with torch.no_grad():
+            return self.forward_one_step(x, x_feat, num_streams, freeze_codebook)
+
+
+model_dict = {"csvq+swinT": ESC}
+
+
+def make_model(model_config, model_name: str = "csvq+swinT"):
+    """codecs.py:190-200.  `model_name` defaults to the ESC codec so that scripts/compress.py:22 (which passes only the
+    config) works."""
+    if model_name not in model_dict:
+        raise NotImplementedError(f"{model_name} is not available in the MI355X build (only csvq+swinT); "
+                                  "rvq+* and *+conv are ablation models outside the accelerated path")
+    m = model_dict[model_name]
+    if isinstance(model_config, dict):
+        return m(**model_config)
+    return m(**vars(model_config))

@@ -1,0 +1,134 @@
+/*
+ * escx.h -- C ABI of the MI355X-native ESC encode/decode hot path (libescx.so, HIP / gfx950).
+ *
+ * The reference (yzGuu830/efficient-speech-codec) is pure Python; it has no FFI layer.  The boundary
+ * this library replaces is the body of `esc.ESC.encode/.decode/.forward` (esc/models/codecs.py:30-94)
+ * and the modules underneath.  Each entry point below names the reference function it stands for.
+ * The reference-side binding a maintainer would add is a ctypes stub: see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative escx_status on failure; the message for the
+ *     calling thread is available from escx_last_error().  Nothing throws across the ABI.
+ *   - `*_dev` pointers are device pointers owned by the caller (e.g. torch `tensor.data_ptr()`);
+ *     `stream` is a hipStream_t passed as void* (0 = the null stream).  Calls are asynchronous with
+ *     respect to the host unless stated otherwise.
+ *   - parameters are uploaded once from HOST fp32 buffers under the reference's state_dict key names
+ *      and packed into MFMA-friendly padded layouts owned by the handle.
+ *   - the handle owns one workspace, sized by escx_reserve(); a handle serves one stream at a time.
+ *   - stage-level entry points take and return tensors in the REFERENCE layouts (unpadded), so they can
+ *     be compared one-to-one with the reference functions; the whole-path calls keep activations in the
+ *     internal padded layouts between kernels.
+ */
+#ifndef ESCX_H
+#define ESCX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESCX_MAX_SCALES 8
+
+typedef enum {
+    ESCX_OK = 0,
+    ESCX_ERR_INVALID_ARG = -1,      /* bad shape / null pointer / unknown key             */
+    ESCX_ERR_UNSUPPORTED = -2,      /* configuration outside what the kernels implement   */
+    ESCX_ERR_HIP = -3,              /* a HIP runtime call failed                          */
+    ESCX_ERR_STATE = -4,            /* e.g. parameters not finalised                      */
+    ESCX_ERR_ASSERT = -5            /* a reference assertion would have fired             */
+} escx_status;
+
+/* Mirrors the kwargs of esc.ESC.__init__ (esc/models/codecs.py:11-18). */
+typedef struct {
+    int32_t in_dim;                         /* 2                                           */
+    int32_t in_freq;                        /* 192  -> n_fft = 2*(in_freq-1)               */
+    int32_t n_scales;                       /* len(h_dims) = 6                             */
+    int32_t h_dims[ESCX_MAX_SCALES];        /* 45,72,96,144,192,384                        */
+    int32_t max_streams;                    /* 6                                           */
+    int32_t win_length;                     /* int(win_len*sr*1e-3) = 320                  */
+    int32_t hop_length;                     /* int(hop_len*sr*1e-3) = 80                   */
+    int32_t patch_f, patch_t;               /* 3, 2                                        */
+    int32_t swin_heads[ESCX_MAX_SCALES];    /* encoder order: 3,6,12,24,24                 */
+    int32_t swin_depth;                     /* 2 (Base) / 4 (Large)                        */
+    int32_t window_size;                    /* 4 (only 4 is implemented)                   */
+    float   mlp_ratio;                      /* 4.0                                         */
+    int32_t overlap;                        /* 2                                           */
+    int32_t group_size;                     /* 3                                           */
+    int32_t codebook_size;                  /* 1024                                        */
+    int32_t codebook_dims[ESCX_MAX_SCALES]; /* per stream                                  */
+    int32_t l2norm;                         /* 1                                           */
+} escx_config;
+
+typedef struct escx_handle_s* escx_handle;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+const char* escx_last_error(void);
+const char* escx_version(void);
+/* ESC.__init__ (codecs.py:11-28, base.py:12-27,49-71): validates the configuration, derives geometry. */
+int escx_create(const escx_config* cfg, int device, escx_handle* out);
+void escx_destroy(escx_handle h);
+
+/* nn.Module.load_state_dict (compress.py:23-25): one call per state_dict entry, HOST fp32, C-contiguous.
+ * Keys: SURVEY.md appendix C.  `*.relative_position_index` and `*.window` are accepted and ignored
+ * (the index is regenerated, the window is folded into the DFT matrices). */
+int escx_set_param(escx_handle h, const char* key, const float* host_data, const int64_t* shape, int ndim);
+/* Packs (pads, permutes, pre-normalises codebooks) and uploads; fails if a required key is missing. */
+int escx_finalize_params(escx_handle h);
+/* Number of keys escx_finalize_params() requires, and the i-th one (for load_state_dict(strict=True)). */
+int escx_num_required_keys(escx_handle h);
+const char* escx_required_key(escx_handle h, int i);
+
+/* Allocates the workspace for batches up to `batch` clips of `n_samples` samples (synchronous; never
+ * call while capturing a graph).  Whole-path calls reserve on demand. */
+int escx_reserve(escx_handle h, int batch, int n_samples);
+int64_t escx_workspace_bytes(escx_handle h);
+
+/* ---- whole path ----------------------------------------------------------------------------- */
+/* ESC.encode (codecs.py:68-81): wave (B,L) f32 -> codes (B,num_streams,group_size,W/overlap) int64,
+ * feat_shape (H_bottom, W) written to host ints. */
+int escx_encode(escx_handle h, const float* wave_dev, int batch, int n_samples, int num_streams,
+                int64_t* codes_dev, int* feat_h, int* feat_w, void* stream);
+/* ESC.decode (codecs.py:83-94): codes (B,S,G,T) int64 + feat_shape -> wave (B, hop*(2W-1)) f32.
+ * recon_feat_dev (optional, may be NULL): (B, 2W, 2, in_freq) f32 frame-major spectrum, i.e. the
+ * reference's recon_feat (B,2,F,T) permuted (0,3,1,2). */
+int escx_decode(escx_handle h, const int64_t* codes_dev, int batch, int num_streams, int feat_h, int feat_w,
+                float* wave_out_dev, float* recon_feat_dev, void* stream);
+/* ESC.forward in eval mode (codecs.py:30-66, csrvq.py:97-129): encoder once, quantise + decode in one pass.
+ * raw_feat_dev (optional): (B, T, 2, in_freq) frame-major; cm_loss_dev (optional): (B,) f32 (== cb_loss). */
+int escx_forward(escx_handle h, const float* wave_dev, int batch, int n_samples, int num_streams,
+                 int64_t* codes_dev, float* wave_out_dev, float* raw_feat_dev, float* recon_feat_dev,
+                 float* cm_loss_dev, void* stream);
+int escx_num_frames(escx_handle h, int n_samples);      /* T = 1 + n_samples / hop                      */
+int escx_output_samples(escx_handle h, int feat_w);     /* hop * (patch_t * W - 1)                      */
+
+/* ---- stage level (reference layouts; used by the parity tests) ------------------------------- */
+/* BaseAudioCodec.spec_transform (base.py:29-37): (B,L) -> (B,T,2,F) frame-major [= (B,2,F,T).permute(0,3,1,2)] */
+int escx_spec_transform(escx_handle h, const float* wave_dev, int batch, int n_samples, float* spec_dev, void* stream);
+/* BaseAudioCodec.audio_reconstruct (base.py:39-47): (B,T,2,F) -> (B, hop*(T-1)) */
+int escx_audio_reconstruct(escx_handle h, const float* spec_dev, int batch, int n_frames, float* wave_dev, void* stream);
+/* PatchEmbed.forward (scale.py:42-50): spec (B,T,2,F) -> tokens (B, H*W, C0) */
+int escx_patch_embed(escx_handle h, const float* spec_dev, int batch, int n_frames, float* tokens_dev, void* stream);
+/* TransformerLayer.forward (attention.py:48-91).  layer_id: 0 = encoder.pre_nn, 1..n-1 = encoder.blocks[i-1],
+ * n..2n-2 = decoder.blocks[i-n], 2n-1 = decoder.post_nn  (n = n_scales).  x (B,H*W,C) -> y (B,H'*W,C'). */
+int escx_transformer_layer(escx_handle h, int layer_id, const float* x_dev, int batch, int H, int W,
+                           float* y_dev, int* H_out, void* stream);
+/* CrossScaleRVQ.csrvq_encode / PVQ.encode (csrvq.py:50-54, quantization.py:74-91, codebook.py:20-43):
+ * codes[b,g,t] for residual = enc - dec (dec may be NULL -> residual = enc).  codes_dev: (B,G,T) int64
+ * with `code_batch_stride` elements between clips (lets the caller write straight into (B,S,G,T)). */
+int escx_pvq_encode(escx_handle h, int stream_id, const float* enc_dev, const float* dec_dev, int batch, int W,
+                    int64_t* codes_dev, int64_t code_batch_stride, void* stream);
+/* CrossScaleRVQ.csrvq_decode / PVQ.decode (csrvq.py:56-60, quantization.py:93-108): out = dec + dequant(codes). */
+int escx_pvq_decode(escx_handle h, int stream_id, const int64_t* codes_dev, int64_t code_batch_stride,
+                    const float* dec_dev, int batch, int W, float* out_dev, void* stream);
+/* PatchDeEmbed.forward (scale.py:73-81): tokens (B,H0*W,C0) -> spec (B, 2W, 2, F) frame-major */
+int escx_patch_deembed(escx_handle h, const float* tokens_dev, int batch, int W, float* spec_dev, void* stream);
+
+/* ---- code packing for transport (10-bit codes; all-gather payload) --------------------------- */
+int escx_codes_narrow(const int64_t* codes_dev, int16_t* out_dev, int64_t n, void* stream);
+int escx_codes_widen(const int16_t* in_dev, int64_t* codes_dev, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESCX_H */

@@ -1,0 +1,280 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the committed golden vectors.
+
+Tolerances: integer codes bit-exact; audio <= 1e-4 RMS (north_star); intermediate fp32 activations are compared
+relative to their own RMS at 2e-5 (pure fp32 re-association noise)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import build_models, code_report, rel_rms, rms
+from conftest import load_golden
+from esc import synth, _native
+
+pytestmark = pytest.mark.gpu
+
+ACT_TOL = 2e-5
+AUDIO_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    return build_models("tiny")
+
+
+@pytest.fixture(scope="module")
+def base():
+    return build_models("base")
+
+
+def _h(model):
+    return model._handle(torch.device("cuda:0"))
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+# ---------------------------------------------------------------- stage level (tiny + base) -------------------
+@pytest.mark.parametrize("L", [1280, 1200, 700])
+def test_spec_transform_and_inverse(tiny, L):
+    from oracle import esc_oracle as O
+    model, orc, g, cfg = tiny
+    lib, hd = _h(model)
+    x = torch.from_numpy(synth.pcm_to_float(synth.noise_clip_int16(f"stft-{L}", 3 * L))).view(3, L)
+    ref = O.spec_transform(x, orc.cfg)                          # (B,2,F,T)
+    B, _, F, T = ref.shape
+    out = torch.empty(B, T, 2, F, device="cuda")
+    _native.check(lib.escx_spec_transform(hd, _ptr(x.cuda()), B, L, _ptr(out), None))
+    got = out.permute(0, 2, 3, 1).cpu()
+    assert rel_rms(got, ref) < ACT_TOL
+    # inverse on the reference spectrum (drop the odd frame like the codec does)
+    T2 = (T // 2) * 2
+    ref_wave = O.audio_reconstruct(ref[..., :T2].contiguous(), orc.cfg)
+    spec_in = ref[..., :T2].permute(0, 3, 1, 2).contiguous().cuda()
+    wave = torch.empty(B, ref_wave.shape[1], device="cuda")
+    _native.check(lib.escx_audio_reconstruct(hd, _ptr(spec_in), B, T2, _ptr(wave), None))
+    assert rel_rms(wave.cpu(), ref_wave) < ACT_TOL
+
+
+def test_spec_transform_base_size(base):
+    from oracle import esc_oracle as O
+    model, orc, g, cfg = base
+    lib, hd = _h(model)
+    x = torch.from_numpy(synth.pcm_to_float(g["pcm"]))
+    ref = O.spec_transform(x, orc.cfg)
+    B, _, F, T = ref.shape
+    out = torch.empty(B, T, 2, F, device="cuda")
+    _native.check(lib.escx_spec_transform(hd, _ptr(x.cuda()), B, x.shape[1], _ptr(out), None))
+    assert rel_rms(out.permute(0, 2, 3, 1).cpu(), ref) < ACT_TOL
+
+
+@pytest.mark.parametrize("which", ["tiny", "base"])
+def test_patch_embed_and_deembed(which, request):
+    from oracle import esc_oracle as O
+    model, orc, g, cfg = request.getfixturevalue(which)
+    lib, hd = _h(model)
+    torch.manual_seed(3)
+    F = cfg["in_freq"]; T = 61 if which == "tiny" else 121
+    feat = torch.randn(2, 2, F, T) * 0.5
+    ref = O.patch_embed(feat, orc.sd, "encoder.patch_embed.", cfg["patch_size"])
+    spec = feat.permute(0, 3, 1, 2).contiguous().cuda()
+    tok = torch.empty(ref.shape, device="cuda")
+    _native.check(lib.escx_patch_embed(hd, _ptr(spec), 2, T, _ptr(tok), None))
+    assert rel_rms(tok.cpu(), ref) < ACT_TOL
+    # de-embed: tokens -> spectrum
+    H0, W = F // cfg["patch_size"][0], T // 2
+    x = torch.randn(2, H0 * W, cfg["h_dims"][0])
+    ref2 = O.patch_deembed(x, H0, orc.sd, "decoder.patch_deembed.", cfg["patch_size"])   # (B,2,F,2W)
+    out = torch.empty(2, 2 * W, 2, F, device="cuda")
+    _native.check(lib.escx_patch_deembed(hd, _ptr(x.cuda()), 2, W, _ptr(out), None))
+    assert rel_rms(out.permute(0, 2, 3, 1).cpu(), ref2) < ACT_TOL
+
+
+def _layer_cases(cfg):
+    """(layer_id, prefix, C, heads, scale, natural H)"""
+    h, heads = cfg["h_dims"], cfg["swin_heads"]
+    n = len(h)
+    H0 = cfg["in_freq"] // cfg["patch_size"][0]
+    cases = [(0, "encoder.pre_nn.", h[0], heads[0], None, H0)]
+    H = H0
+    for i in range(n - 1):
+        cases.append((1 + i, f"encoder.blocks.{i}.", h[i], heads[i], "down", H)); H = (H + 1) // 2
+    dh, rh = h[::-1], heads[::-1]
+    for j in range(n - 1):
+        cases.append((n + j, f"decoder.blocks.{j}.", dh[j], rh[j], "up", H)); H *= 2
+    cases.append((2 * n - 1, "decoder.post_nn.", dh[-1], rh[-1], None, H))
+    return cases
+
+
+@pytest.mark.parametrize("which,W", [("tiny", 32), ("tiny", 30), ("base", 20), ("base", 22)])
+def test_every_transformer_layer(which, W, request):
+    """All (C, heads) pairs, shifted + unshifted blocks, W%4 in {0,2} (window padding), H=2 bottom scale, merge/split."""
+    from oracle import esc_oracle as O
+    model, orc, g, cfg = request.getfixturevalue(which)
+    lib, hd = _h(model)
+    torch.manual_seed(11)
+    for lid, pfx, C, nH, scale, H in _layer_cases(cfg):
+        x = torch.randn(2, H * W, C)
+        ref, Hr, _ = O.transformer_layer(x, H, W, orc.sd, pfx, nH, cfg["swin_depth"], cfg["window_size"], scale)
+        y = torch.empty(ref.shape, device="cuda")
+        Hn = ctypes.c_int()
+        _native.check(lib.escx_transformer_layer(hd, lid, _ptr(x.cuda()), 2, H, W, _ptr(y), ctypes.byref(Hn), None))
+        assert Hn.value == Hr
+        err = rel_rms(y.cpu(), ref)
+        assert err < ACT_TOL, f"{which} layer {lid} ({pfx}) H={H} W={W}: rel rms {err:.3e}"
+
+
+def test_merge_with_odd_height(base):
+    from oracle import esc_oracle as O
+    model, orc, g, cfg = base
+    lib, hd = _h(model)
+    torch.manual_seed(5)
+    H, W, C = 7, 20, cfg["h_dims"][1]                 # encoder.blocks.1 with an odd H -> zero row before the unshuffle
+    x = torch.randn(2, H * W, C)
+    ref, Hr, _ = O.transformer_layer(x, H, W, orc.sd, "encoder.blocks.1.", cfg["swin_heads"][1], 2, 4, "down")
+    y = torch.empty(ref.shape, device="cuda"); Hn = ctypes.c_int()
+    _native.check(lib.escx_transformer_layer(hd, 2, _ptr(x.cuda()), 2, H, W, _ptr(y), ctypes.byref(Hn), None))
+    assert Hn.value == Hr == 4 and rel_rms(y.cpu(), ref) < ACT_TOL
+
+
+@pytest.mark.parametrize("which", ["tiny", "base"])
+def test_pvq_encode_decode_every_stream(which, request):
+    from oracle import esc_oracle as O
+    model, orc, g, cfg = request.getfixturevalue(which)
+    lib, hd = _h(model)
+    torch.manual_seed(7)
+    W, B = 24, 3
+    G = cfg["group_size"]
+    for s in range(cfg["max_streams"]):
+        C = orc.dec_dims[max(s - 1, 0)]; Hq = orc.q_freq[s]
+        enc = torch.randn(B, Hq * W, C); dec = torch.randn(B, Hq * W, C) * 0.5
+        margins = []
+        ref = O.pvq_encode(enc - dec, orc.sd, f"quantizers.{s}.", Hq, cfg["overlap"], G, cfg["l2norm"], margins=margins)
+        codes = torch.full((B, G, W // 2), -1, dtype=torch.int64, device="cuda")
+        _native.check(lib.escx_pvq_encode(hd, s, _ptr(enc.cuda()), _ptr(dec.cuda()), B, W, _ptr(codes), G * (W // 2), None))
+        got = codes.cpu()
+        m = torch.stack(margins, 1)
+        bad = (got != ref)
+        # a mismatch is only tolerable where the reference's own best/second-best gap is at fp32 noise level
+        assert not bad.any() or float(m[bad].max()) < 2e-6, f"stream {s}: {int(bad.sum())} mismatches, margins {m[bad][:5]}"
+        assert int(bad.sum()) <= 1
+        refq = O.pvq_decode(ref, orc.sd, f"quantizers.{s}.", Hq, cfg["overlap"]) + dec
+        out = torch.empty(B, Hq * W, C, device="cuda")
+        _native.check(lib.escx_pvq_decode(hd, s, _ptr(ref.cuda()), G * (W // 2), _ptr(dec.cuda()), B, W, _ptr(out), None))
+        assert rel_rms(out.cpu(), refq) < ACT_TOL
+        # residual = enc (dec NULL) path used by stream 0
+        ref0 = O.pvq_encode(enc, orc.sd, f"quantizers.{s}.", Hq, cfg["overlap"], G, cfg["l2norm"])
+        _native.check(lib.escx_pvq_encode(hd, s, _ptr(enc.cuda()), None, B, W, _ptr(codes), G * (W // 2), None))
+        assert int((codes.cpu() != ref0).sum()) <= 1
+
+
+def test_search_tie_break_and_degenerate_vectors(tiny):
+    """All-zero residual: every distance is ~||c_hat||^2; the reference's lowest-index-wins rule must hold on ties."""
+    from oracle import esc_oracle as O
+    model, orc, g, cfg = tiny
+    lib, hd = _h(model)
+    W, B, G = 8, 1, cfg["group_size"]
+    C, Hq = orc.dec_dims[0], orc.q_freq[0]
+    enc = torch.zeros(B, Hq * W, C)
+    codes = torch.full((B, G, W // 2), -1, dtype=torch.int64, device="cuda")
+    _native.check(lib.escx_pvq_encode(hd, 0, _ptr(enc.cuda()), None, B, W, _ptr(codes), G * (W // 2), None))
+    got = codes.cpu()
+    assert int(got.min()) >= 0 and int(got.max()) < cfg["codebook_size"]
+    # every frame of a group sees the same distances -> the same code
+    assert (got == got[..., :1]).all()
+
+
+# ---------------------------------------------------------------- whole path vs golden ------------------------
+@pytest.mark.parametrize("name", ["tiny", "base", "large"])
+def test_codes_bit_exact_and_audio_vs_golden(name):
+    model, orc, g, cfg = build_models(name)
+    S = cfg["max_streams"]
+    if name == "tiny":
+        cases = [(torch.from_numpy(synth.pcm_to_float(g[f"L{L}_pcm"])), g[f"L{L}_codes"], g[f"L{L}_margins"],
+                  {s: g[f"L{L}_audio_s{s}"] for s in range(1, S + 1)}) for L in (1280, 1200)]
+    else:
+        cases = [(torch.from_numpy(synth.pcm_to_float(g["pcm"])), g["codes"], g["margins"],
+                  {s: g[f"audio_s{s}"] for s in range(1, S + 1)})]
+    for x, ref_codes, margins, audio in cases:
+        xg = x.cuda()
+        for s in range(1, S + 1):
+            codes, shape = model.encode(xg, s)
+            assert codes.dtype == torch.int64 and codes.shape[1] == s
+            ref = ref_codes[:, :s].astype(np.int64)
+            assert np.array_equal(codes.cpu().numpy(), ref), f"{name} S={s}: " + code_report(codes.cpu().numpy(), ref, margins[:, :s])
+            wave = model.decode(torch.from_numpy(ref).cuda(), shape).cpu().numpy()
+            gold = audio[s]
+            got = wave if s == S else wave[:, ::8]
+            assert got.shape == gold.shape
+            assert rms(got, gold) <= AUDIO_TOL, f"{name} S={s}: audio rms {rms(got, gold):.3e}"
+
+
+@pytest.mark.parametrize("L", [16000, 24000])
+def test_edge_lengths_vs_golden(base, L):
+    model, orc, g, cfg = base
+    e = load_golden("edge")
+    x = torch.from_numpy(synth.pcm_to_float(e[f"L{L}_pcm"])).cuda()
+    codes, shape = model.encode(x, 6)
+    assert tuple(shape) == tuple(e[f"L{L}_feat_shape"])
+    ref = e[f"L{L}_codes"].astype(np.int64)
+    assert np.array_equal(codes.cpu().numpy(), ref), code_report(codes.cpu().numpy(), ref, e[f"L{L}_margins"])
+    for s in (1, 3, 6):
+        wave = model.decode(codes[:, :s].contiguous(), shape).cpu().numpy()
+        assert rms(wave if s == 6 else wave[:, ::8], e[f"L{L}_audio_s{s}"]) <= AUDIO_TOL
+
+
+def test_forward_eval_dict(base):
+    model, orc, g, cfg = base
+    x = torch.from_numpy(synth.pcm_to_float(g["pcm"])).cuda()
+    for s in (1, 4, 6):
+        out = model(**dict(x=x, x_feat=None, num_streams=s))
+        assert set(out) == {"cm_loss", "cb_loss", "raw_audio", "recon_audio", "raw_feat", "recon_feat", "codes"}
+        codes, shape = model.encode(x, s)
+        assert torch.equal(out["codes"], codes)
+        wave = model.decode(codes, shape)
+        assert torch.equal(out["recon_audio"], wave), "forward(eval) must equal decode(encode()) bit for bit"
+        np.testing.assert_allclose(out["cm_loss"].cpu().numpy(), g[f"cm_loss_s{s}"], rtol=1e-4)
+        assert out["raw_feat"].shape == (2, 2, 192, 601) and out["recon_feat"].shape == (2, 2, 192, 600)
+        ref = orc.forward_eval(x.cpu(), None, s)
+        assert rel_rms(out["raw_feat"].cpu(), ref["raw_feat"]) < ACT_TOL
+        assert rel_rms(out["recon_feat"].cpu(), ref["recon_feat"]) < 1e-4
+
+
+def test_full_size_invariants_batch36(base):
+    """BASELINE config 2 size (B=36, 3 s clips): prefix property, batch invariance, determinism, code range."""
+    model, orc, g, cfg = base
+    pcm = np.stack([synth.noise_clip_int16(f"bench-{i}", 48000) for i in range(36)])
+    x = torch.from_numpy(synth.pcm_to_float(pcm)).cuda()
+    full, shape = model.encode(x, 6)
+    assert full.shape == (36, 6, 3, 150) and tuple(shape) == (2, 300)
+    assert int(full.min()) >= 0 and int(full.max()) < 1024
+    again, _ = model.encode(x, 6)
+    assert torch.equal(full, again)                                        # run-to-run deterministic
+    for s in (1, 2, 3, 5):
+        part, _ = model.encode(x, s)
+        assert torch.equal(part, full[:, :s])                              # prefix property
+    sub, _ = model.encode(x[5:9].contiguous(), 6)
+    assert torch.equal(sub, full[5:9])                                     # batch invariance
+    wave = model.decode(full, shape)
+    assert wave.shape == (36, 47920) and torch.isfinite(wave).all()
+    w1 = model.decode(full[7:8].contiguous(), shape)
+    assert torch.equal(w1, wave[7:8])
+    # oracle on a bounded sample of the same batch (3 clips)
+    oc, _ = orc.encode(x[:3].cpu(), 6)
+    assert torch.equal(oc, full[:3].cpu()), code_report(full[:3].cpu().numpy(), oc.numpy())
+    ow = orc.decode(oc, shape)
+    assert rms(wave[:3].cpu().numpy(), ow.numpy()) <= AUDIO_TOL
+
+
+def test_decode_partial_streams_and_errors(base):
+    model, orc, g, cfg = base
+    x = torch.from_numpy(synth.pcm_to_float(g["pcm"])).cuda()
+    codes, shape = model.encode(x, 6)
+    for s in (1, 2, 6):                                                    # csrvq.py:174-177: missing streams pass through
+        w = model.decode(codes[:, :s].contiguous(), shape).cpu()
+        ref = orc.decode(codes[:, :s].cpu(), shape)
+        assert rms(w.numpy(), ref.numpy()) <= AUDIO_TOL
+    with pytest.raises(AssertionError, match="multiple of overlap"):        # quantization.py:407 (T=302 -> W=151)
+        model.encode(torch.zeros(1, 24080, device="cuda"), 6)
