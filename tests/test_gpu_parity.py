@@ -46,7 +46,8 @@ def test_spec_transform_and_inverse(tiny, L):
     ref = O.spec_transform(x, orc.cfg)                          # (B,2,F,T)
     B, _, F, T = ref.shape
     out = torch.empty(B, T, 2, F, device="cuda")
-    _native.check(lib.escx_spec_transform(hd, _ptr(x.cuda()), B, L, _ptr(out), None))
+    xg = x.cuda()
+    _native.check(lib.escx_spec_transform(hd, _ptr(xg), B, L, _ptr(out), None))
     got = out.permute(0, 2, 3, 1).cpu()
     assert rel_rms(got, ref) < ACT_TOL
     # inverse on the reference spectrum (drop the odd frame like the codec does)
@@ -66,7 +67,8 @@ def test_spec_transform_base_size(base):
     ref = O.spec_transform(x, orc.cfg)
     B, _, F, T = ref.shape
     out = torch.empty(B, T, 2, F, device="cuda")
-    _native.check(lib.escx_spec_transform(hd, _ptr(x.cuda()), B, x.shape[1], _ptr(out), None))
+    xg = x.cuda()
+    _native.check(lib.escx_spec_transform(hd, _ptr(xg), B, x.shape[1], _ptr(out), None))
     assert rel_rms(out.permute(0, 2, 3, 1).cpu(), ref) < ACT_TOL
 
 
@@ -88,7 +90,8 @@ def test_patch_embed_and_deembed(which, request):
     x = torch.randn(2, H0 * W, cfg["h_dims"][0])
     ref2 = O.patch_deembed(x, H0, orc.sd, "decoder.patch_deembed.", cfg["patch_size"])   # (B,2,F,2W)
     out = torch.empty(2, 2 * W, 2, F, device="cuda")
-    _native.check(lib.escx_patch_deembed(hd, _ptr(x.cuda()), 2, W, _ptr(out), None))
+    xg = x.cuda()
+    _native.check(lib.escx_patch_deembed(hd, _ptr(xg), 2, W, _ptr(out), None))
     assert rel_rms(out.permute(0, 2, 3, 1).cpu(), ref2) < ACT_TOL
 
 
@@ -120,7 +123,8 @@ def test_every_transformer_layer(which, W, request):
         ref, Hr, _ = O.transformer_layer(x, H, W, orc.sd, pfx, nH, cfg["swin_depth"], cfg["window_size"], scale)
         y = torch.empty(ref.shape, device="cuda")
         Hn = ctypes.c_int()
-        _native.check(lib.escx_transformer_layer(hd, lid, _ptr(x.cuda()), 2, H, W, _ptr(y), ctypes.byref(Hn), None))
+        xg = x.cuda()
+        _native.check(lib.escx_transformer_layer(hd, lid, _ptr(xg), 2, H, W, _ptr(y), ctypes.byref(Hn), None))
         assert Hn.value == Hr
         err = rel_rms(y.cpu(), ref)
         assert err < ACT_TOL, f"{which} layer {lid} ({pfx}) H={H} W={W}: rel rms {err:.3e}"
@@ -135,7 +139,8 @@ def test_merge_with_odd_height(base):
     x = torch.randn(2, H * W, C)
     ref, Hr, _ = O.transformer_layer(x, H, W, orc.sd, "encoder.blocks.1.", cfg["swin_heads"][1], 2, 4, "down")
     y = torch.empty(ref.shape, device="cuda"); Hn = ctypes.c_int()
-    _native.check(lib.escx_transformer_layer(hd, 2, _ptr(x.cuda()), 2, H, W, _ptr(y), ctypes.byref(Hn), None))
+    xg = x.cuda()
+    _native.check(lib.escx_transformer_layer(hd, 2, _ptr(xg), 2, H, W, _ptr(y), ctypes.byref(Hn), None))
     assert Hn.value == Hr == 4 and rel_rms(y.cpu(), ref) < ACT_TOL
 
 
@@ -153,7 +158,8 @@ def test_pvq_encode_decode_every_stream(which, request):
         margins = []
         ref = O.pvq_encode(enc - dec, orc.sd, f"quantizers.{s}.", Hq, cfg["overlap"], G, cfg["l2norm"], margins=margins)
         codes = torch.full((B, G, W // 2), -1, dtype=torch.int64, device="cuda")
-        _native.check(lib.escx_pvq_encode(hd, s, _ptr(enc.cuda()), _ptr(dec.cuda()), B, W, _ptr(codes), G * (W // 2), None))
+        encg, decg, refg = enc.cuda(), dec.cuda(), ref.cuda()
+        _native.check(lib.escx_pvq_encode(hd, s, _ptr(encg), _ptr(decg), B, W, _ptr(codes), G * (W // 2), None))
         got = codes.cpu()
         m = torch.stack(margins, 1)
         bad = (got != ref)
@@ -162,11 +168,11 @@ def test_pvq_encode_decode_every_stream(which, request):
         assert int(bad.sum()) <= 1
         refq = O.pvq_decode(ref, orc.sd, f"quantizers.{s}.", Hq, cfg["overlap"]) + dec
         out = torch.empty(B, Hq * W, C, device="cuda")
-        _native.check(lib.escx_pvq_decode(hd, s, _ptr(ref.cuda()), G * (W // 2), _ptr(dec.cuda()), B, W, _ptr(out), None))
+        _native.check(lib.escx_pvq_decode(hd, s, _ptr(refg), G * (W // 2), _ptr(decg), B, W, _ptr(out), None))
         assert rel_rms(out.cpu(), refq) < ACT_TOL
         # residual = enc (dec NULL) path used by stream 0
         ref0 = O.pvq_encode(enc, orc.sd, f"quantizers.{s}.", Hq, cfg["overlap"], G, cfg["l2norm"])
-        _native.check(lib.escx_pvq_encode(hd, s, _ptr(enc.cuda()), None, B, W, _ptr(codes), G * (W // 2), None))
+        _native.check(lib.escx_pvq_encode(hd, s, _ptr(encg), None, B, W, _ptr(codes), G * (W // 2), None))
         assert int((codes.cpu() != ref0).sum()) <= 1
 
 
@@ -179,7 +185,8 @@ def test_search_tie_break_and_degenerate_vectors(tiny):
     C, Hq = orc.dec_dims[0], orc.q_freq[0]
     enc = torch.zeros(B, Hq * W, C)
     codes = torch.full((B, G, W // 2), -1, dtype=torch.int64, device="cuda")
-    _native.check(lib.escx_pvq_encode(hd, 0, _ptr(enc.cuda()), None, B, W, _ptr(codes), G * (W // 2), None))
+    encg = enc.cuda()
+    _native.check(lib.escx_pvq_encode(hd, 0, _ptr(encg), None, B, W, _ptr(codes), G * (W // 2), None))
     got = codes.cpu()
     assert int(got.min()) >= 0 and int(got.max()) < cfg["codebook_size"]
     # every frame of a group sees the same distances -> the same code
