@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""ESC-Base 9 kbps encode+decode throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = ESC.encode (STFT -> encoder -> 6 cross-scale VQ streams) + [N>1: all-gather of the codes over RCCL] +
+ESC.decode (de-quantise -> decoder -> ISTFT) on 36 synthetic 3 s / 16 kHz clips per GPU (BASELINE configs[1]; at N=8
+this is configs[3]: 288 clips).  Weak scaling: per-GPU work is fixed.  Inputs are resident in HBM before the timed region.
+Weights are the deterministic name-keyed synthetic ESC-Base weights (no checkpoints exist offline); fp32 throughout.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "efficient-speech-codec_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CLIPS_PER_GPU = 36
+N_SAMPLES = 48000
+NUM_STREAMS = 6
+FLOP_PER_CLIP = 56.75e9            # BASELINE.md section 3 (2xMAC over linear/bmm/conv, S=6)
+PEAK_F32_MFMA = 157.3e12           # MI355X_MICROARCH.md chip table
+PEAK_HBM = 8.0e12
+
+
+def base_config():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "base.npz"))
+    return json.loads(str(g["config_json"]))
+
+
+def build_model(device):
+    from esc import synth
+    from esc.models import make_model
+    from esc.models.codecs import state_manifest
+    cfg = base_config()
+    model = make_model(cfg)
+    sd = {}
+    for k, shp in state_manifest(model.cfg).items():
+        v = synth.synth_tensor(k, shp)
+        if k.endswith(".window"):
+            v = torch.hann_window(shp[0]).numpy()
+        sd[k] = torch.from_numpy(np.ascontiguousarray(v))
+    model.load_state_dict(sd, strict=True)
+    return model.to(device).eval(), cfg, sd
+
+
+def synth_batch(n, rank):
+    from esc import synth
+    pcm = np.stack([synth.noise_clip_int16(f"bench-r{rank}-{i}", N_SAMPLES) for i in range(n)])
+    return torch.from_numpy(synth.pcm_to_float(pcm))
+
+
+def cpu_baseline(cfg, sd, x_cpu):
+    """The oracle (CPU restatement of the reference; the reference itself never travels) on the host cores.
+    Eager ATen on these small ops scales badly past a few dozen threads, so a short sweep picks the thread count."""
+    from oracle.esc_oracle import EscOracle
+    avail = os.cpu_count() or 1
+    orc = EscOracle(cfg, sd)
+    n = min(4, x_cpu.shape[0])
+    xs = x_cpu[:n]
+
+    def once():
+        t0 = time.perf_counter()
+        codes, shape = orc.encode(xs, NUM_STREAMS)
+        orc.decode(codes, shape)
+        return time.perf_counter() - t0
+
+    best_t, best_thr = None, 1
+    for thr in sorted({min(avail, t) for t in (8, 16, 32, 64)}):
+        torch.set_num_threads(thr)
+        once()                                          # warm-up at this thread count
+        t = once()
+        if best_t is None or t < best_t:
+            best_t, best_thr = t, thr
+    torch.set_num_threads(best_thr)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        once()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 12:
+            break
+    return {"value": round(reps * n * 3.0 / el, 3), "unit": "audio-seconds/sec", "cores": best_thr, "kind": "port",
+            "sample": f"{reps} x encode+decode of {n} clips (3 s each), oracle/esc_oracle.py, torch {torch.__version__} CPU fp32, "
+                      f"{best_thr} of {avail} host threads (best of a 8/16/32/64 sweep)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from esc.distributed import all_gather_codes
+    model, cfg, sd = build_model(device)
+    x_cpu = synth_batch(CLIPS_PER_GPU, rank)
+    x = x_cpu.to(device)
+    model.reserve(CLIPS_PER_GPU, N_SAMPLES, device)
+
+    def step():
+        codes, shape = model.encode(x, NUM_STREAMS)
+        allc = all_gather_codes(codes) if world > 1 else codes
+        wave = model.decode(codes, shape)
+        return allc, wave
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        allc, wave = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert allc.shape[0] == CLIPS_PER_GPU * world and torch.isfinite(wave).all()
+
+    # per-kernel pass: HIP events around every launch, on the stream the kernels run on
+    lib, hd = model._handle(device)
+    roofline = None
+    if rank == 0:
+        lib.escx_profile_enable(hd, 1)
+        for _ in range(args.profile_steps):
+            c, s = model.encode(x, NUM_STREAMS)
+            model.decode(c, s)
+        torch.cuda.synchronize(device)
+        lib.escx_profile_enable(hd, 0)
+        recs = json.loads(lib.escx_profile_report(hd).decode())
+        tot = sum(r["ms"] for r in recs)
+        recs.sort(key=lambda r: -r["ms"])
+        dom = recs[0]
+        avg_s = dom["ms"] / dom["calls"] * 1e-3
+        flops_per_launch = dom["flops"] / dom["calls"]
+        bytes_per_launch = dom["bytes"] / dom["calls"]
+        mfma_bound = flops_per_launch / PEAK_F32_MFMA >= bytes_per_launch / PEAK_HBM
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom["name"])
+            except Exception:
+                traffic = None
+        if mfma_bound:
+            ach = flops_per_launch / avg_s
+            roofline = {"bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": traffic}
+        else:
+            ach = bytes_per_launch / avg_s
+            roofline = {"bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM, 4), "traffic": traffic}
+        roofline.update({"kernel": dom["name"], "avg_us": round(avg_s * 1e6, 2), "launches_per_step": dom["calls"] // args.profile_steps,
+                         "share_of_gpu_time": round(dom["ms"] / tot, 4),
+                         "whole_path_mfma_frac": round(FLOP_PER_CLIP * CLIPS_PER_GPU * args.profile_steps / (tot * 1e-3) / PEAK_F32_MFMA, 4)})
+        if os.environ.get("ESCX_BENCH_BREAKDOWN"):
+            for r in recs:
+                print(f"# {r['name']:28s} calls {r['calls']:4d}  {r['ms'] / args.profile_steps:9.3f} ms/step  "
+                      f"{r['flops'] / max(r['ms'], 1e-9) / 1e9:9.1f} TFLOP/s  {r['bytes'] / max(r['ms'], 1e-9) / 1e6:9.1f} GB/s", file=sys.stderr)
+
+    if rank == 0:
+        audio_s = CLIPS_PER_GPU * world * args.steps * (N_SAMPLES / 16000.0)
+        out = {
+            "metric": "audio-seconds/sec encode+decode, ESC-Base 9kbps 3s@16kHz",
+            "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ESC-Base 9kbps, batch={CLIPS_PER_GPU} 3-sec 16kHz clips per GPU, num_streams=6, "
+                                   f"encode+decode (BASELINE configs[{1 if world == 1 else 3}])",
+                       "global_batch": CLIPS_PER_GPU * world, "clip_samples": N_SAMPLES, "num_streams": NUM_STREAMS,
+                       "parallelism": f"dp{world}" + (" + all_gather(codes int16)" if world > 1 else ""),
+                       "weights": "deterministic name-keyed synthetic (esc/synth.py)",
+                       "frames_per_sec": round(audio_s / elapsed * 200.0, 1)},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, x_cpu)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -540,6 +540,53 @@ static int launch_ok(const char* what) {
     return 0;
 }
 
+// ---- per-launch profiler ---------------------------------------------------------------------
+static hipEvent_t prof_event(escx_handle_s* h) {
+    if (!h->prof_pool.empty()) { hipEvent_t e = h->prof_pool.back(); h->prof_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+struct ProfScope {
+    escx_handle_s* h; hipStream_t st; hipEvent_t a;
+    ProfScope(escx_handle_s* h_, hipStream_t s) : h(h_), st(s), a(nullptr) { if (h->prof) { a = prof_event(h); (void)hipEventRecord(a, st); } }
+    void end(const std::string& name, double flops, double bytes) {
+        if (!a) return;
+        hipEvent_t b = prof_event(h); (void)hipEventRecord(b, st);
+        h->prof_recs.push_back({name, flops, bytes, a, b}); a = nullptr;
+    }
+};
+#define PROF(name, flops, bytes, stmt) do { ProfScope _ps(h, st); stmt; if (h->prof) _ps.end(name, flops, bytes); } while (0)
+
+extern "C" int escx_profile_enable(escx_handle h, int enable) {
+    if (!h) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null handle");
+    if (enable) { for (auto& r : h->prof_recs) { h->prof_pool.push_back(r.a); h->prof_pool.push_back(r.b); } h->prof_recs.clear(); }
+    h->prof = enable != 0;
+    return ESCX_OK;
+}
+
+extern "C" const char* escx_profile_report(escx_handle h) {
+    if (!h) return "[]";
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    struct Agg { int calls = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::map<std::string, Agg> agg; std::vector<std::string> order;
+    for (auto& r : h->prof_recs) {
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, r.a, r.b);
+        if (!agg.count(r.name)) order.push_back(r.name);
+        Agg& g = agg[r.name]; g.calls++; g.ms += ms; g.flops += r.flops; g.bytes += r.bytes;
+    }
+    std::string js = "[";
+    char buf[512];
+    for (size_t i = 0; i < order.size(); ++i) {
+        const Agg& g = agg[order[i]];
+        snprintf(buf, sizeof(buf), "%s{\"name\":\"%s\",\"calls\":%d,\"ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e}", i ? "," : "",
+                 order[i].c_str(), g.calls, g.ms, g.flops, g.bytes);
+        js += buf;
+    }
+    js += "]";
+    h->prof_json = js;
+    return h->prof_json.c_str();
+}
+
 // One TransformerLayer on padded token maps.  x_in is read-only; y receives (B, H'*W, CoutP).
 // attention.py:48-91 (layer), 129-178 (block): LN1 -> pad -> roll -> windows -> attention -> reverse -> residual -> MLP.
 static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float* y, int B, int H, int W, int* Hout, hipStream_t st) {
@@ -553,26 +600,40 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         const int shift = (j % 2 == 0) ? 0 : 2;                               // attention.py:29
         const int* map;
         if ((rc = get_map(h, H, W, shift, &map))) return rc;
-        ln_rows(1, src, h->xn, bw.ln1_g, bw.ln1_b, map, slots, tokens, Ms, L.C, L.Cp, st);
-        gemm_qkv(h->xn, L.Cp, Ms, bw.wqkv, L.Nqkv, L.Cp, h->qkv, bw.bqkv, L.nH * L.hdp, 1.0f / std::sqrt((float)L.hd), st);
-        if (window_attention(h->qkv, bw.bias_tab, h->obuf, Ms / 16, L.nH, L.hdp, L.Nqkv, L.Ko, Hp / 4, Wp / 4, shift > 0, st))
-            ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "head_dim %d unsupported by the attention kernel", L.hd);
-        gemm_proj_scatter(h->obuf, L.Ko, Ms, bw.wproj, L.Cp, L.Ko, cur, src, bw.bproj, map, slots, tokens, st);
-        ln_rows(0, cur, h->xn, bw.ln2_g, bw.ln2_b, nullptr, tokens, tokens, M, L.C, L.Cp, st);
-        gemm_gelu(h->xn, L.Cp, M, bw.w1, L.hiddenP, L.Cp, h->hid, bw.b1, st);
-        gemm_residual(h->hid, L.hiddenP, M, bw.w2, L.Cp, L.hiddenP, cur, bw.b2, cur, st);
+        const std::string tag = h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string();
+        const double dM = M, dMs = Ms, dC = L.C, f4 = sizeof(float);
+        PROF("ln1_gather" + tag, 0, (dM + dMs) * dC * f4,
+             ln_rows(1, src, h->xn, bw.ln1_g, bw.ln1_b, map, slots, tokens, Ms, L.C, L.Cp, st));
+        PROF("gemm_qkv" + tag, 2 * dMs * dC * 3 * dC, (dMs * 4 * dC + 3 * dC * dC) * f4,
+             gemm_qkv(h->xn, L.Cp, Ms, bw.wqkv, L.Nqkv, L.Cp, h->qkv, bw.bqkv, L.nH * L.hdp, 1.0f / std::sqrt((float)L.hd), st));
+        int arc = 0;
+        PROF("window_attn" + tag, 4 * dMs * 16 * dC, dMs * 4 * dC * f4,
+             arc = window_attention(h->qkv, bw.bias_tab, h->obuf, Ms / 16, L.nH, L.hdp, L.Nqkv, L.Ko, Hp / 4, Wp / 4, shift > 0, st));
+        if (arc) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "head_dim %d unsupported by the attention kernel", L.hd);
+        PROF("gemm_proj" + tag, 2 * dMs * dC * dC, (dMs * dC + 2 * dM * dC + dC * dC) * f4,
+             gemm_proj_scatter(h->obuf, L.Ko, Ms, bw.wproj, L.Cp, L.Ko, cur, src, bw.bproj, map, slots, tokens, st));
+        PROF("ln2" + tag, 0, 2 * dM * dC * f4,
+             ln_rows(0, cur, h->xn, bw.ln2_g, bw.ln2_b, nullptr, tokens, tokens, M, L.C, L.Cp, st));
+        PROF("gemm_fc1_gelu" + tag, 2 * dM * dC * L.hidden, (dM * (dC + L.hidden) + dC * L.hidden) * f4,
+             gemm_gelu(h->xn, L.Cp, M, bw.w1, L.hiddenP, L.Cp, h->hid, bw.b1, st));
+        PROF("gemm_fc2_res" + tag, 2 * dM * dC * L.hidden, (dM * (2 * dC + L.hidden) + dC * L.hidden) * f4,
+             gemm_residual(h->hid, L.hiddenP, M, bw.w2, L.Cp, L.hiddenP, cur, bw.b2, cur, st));
         src = cur;
     }
     if (L.scale == 1) {
         const int H2 = (H + 1) / 2;
         const int* map;
         if ((rc = get_map(h, H, W, -1, &map))) return rc;
-        ln_rows(2, cur, h->xn, L.sub_g, L.sub_b, map, H2 * W, tokens, B * H2 * W, L.C, L.Cp, st);
-        gemm_store(h->xn, 2 * L.Cp, B * H2 * W, L.sub_w, L.CoutP, 2 * L.Cp, y, L.CoutP, nullptr, st);
+        PROF("merge_ln", 0, 2.0 * M * L.C * 4,
+             ln_rows(2, cur, h->xn, L.sub_g, L.sub_b, map, H2 * W, tokens, B * H2 * W, L.C, L.Cp, st));
+        PROF("merge_gemm", 2.0 * B * H2 * W * 2 * L.C * L.Cout, (double)B * H2 * W * (2 * L.C + L.Cout) * 4,
+             gemm_store(h->xn, 2 * L.Cp, B * H2 * W, L.sub_w, L.CoutP, 2 * L.Cp, y, L.CoutP, nullptr, st));
         *Hout = H2;
     } else if (L.scale == 2) {
-        ln_rows(0, cur, h->xn, L.sub_g, L.sub_b, nullptr, tokens, tokens, M, L.C, L.Cp, st);
-        gemm_split(h->xn, L.Cp, M, L.sub_w, 2 * L.CoutP, L.Cp, y, H, W, L.CoutP, st);
+        PROF("split_ln", 0, 2.0 * M * L.C * 4,
+             ln_rows(0, cur, h->xn, L.sub_g, L.sub_b, nullptr, tokens, tokens, M, L.C, L.Cp, st));
+        PROF("split_gemm", 2.0 * M * L.C * 2 * L.Cout, (double)M * (L.C + 2 * L.Cout) * 4,
+             gemm_split(h->xn, L.Cp, M, L.sub_w, 2 * L.CoutP, L.Cp, y, H, W, L.CoutP, st));
         *Hout = 2 * H;
     } else {
         *Hout = H;
@@ -581,15 +642,19 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
 }
 
 static int run_stft(escx_handle_s* h, const float* wave, int B, int L, int T, float* spec, hipStream_t st) {
-    gemm_frames(wave, B, L, T, h->cfg.hop_length, h->left - h->n_fft / 2, h->dft_w, h->cfg.in_dim * h->Fp, h->winP, spec, st);
+    PROF("stft_dft_gemm", 2.0 * B * T * h->cfg.win_length * 2 * h->F, ((double)B * L + (double)B * T * 2 * h->F) * 4,
+         gemm_frames(wave, B, L, T, h->cfg.hop_length, h->left - h->n_fft / 2, h->dft_w, h->cfg.in_dim * h->Fp, h->winP, spec, st));
     return launch_ok("stft");
 }
 
 static int run_patch_embed(escx_handle_s* h, const float* spec, int B, int T, int W, float* tok, hipStream_t st) {
     const escx_config& c = h->cfg;
     const int H0 = c.in_freq / c.patch_f;
-    gemm_patch(spec, B, T, c.in_dim, h->Fp, H0, W, c.patch_f, c.patch_t, h->pe_w, h->C0p, h->Kpe, tok, h->pe_b, st);
-    ln_rows(0, tok, tok, h->pe_g, h->pe_beta, nullptr, H0 * W, H0 * W, B * H0 * W, h->C0, h->C0p, st);
+    const double toks = (double)B * H0 * W;
+    PROF("patch_embed_gemm", 2.0 * toks * c.in_dim * c.patch_f * c.patch_t * h->C0, ((double)B * T * 2 * h->F + toks * h->C0) * 4,
+         gemm_patch(spec, B, T, c.in_dim, h->Fp, H0, W, c.patch_f, c.patch_t, h->pe_w, h->C0p, h->Kpe, tok, h->pe_b, st));
+    PROF("patch_embed_ln", 0, 2 * toks * h->C0 * 4,
+         ln_rows(0, tok, tok, h->pe_g, h->pe_beta, nullptr, H0 * W, H0 * W, B * H0 * W, h->C0, h->C0p, st));
     return launch_ok("patch_embed");
 }
 
@@ -610,32 +675,43 @@ static int run_pvq_encode(escx_handle_s* h, const Quant& q, const float* enc, co
     const int Tq = W / c.overlap, M = B * Tq;
     const int splits = pvq_down_splits(M, q.Kq, q.Cp);
     if ((size_t)splits * M * q.Nz > h->zpart_cap) ESCX_FAIL(ESCX_ERR_STATE, "split-K scratch too small");
-    gemm_pvq_down(enc, dec, B, q.Hq, W, q.Cp, c.overlap, q.wd, q.Nz, q.Kq, h->zpart, splits, st);
-    if (pvq_search(h->zpart, splits, M, q.Nz, q.cbn, q.c2, q.cbraw, c.group_size, c.codebook_size, q.d, q.dt, Tq, codes, bstride, loss,
-                   1.0f / ((float)Tq * q.d * c.group_size), c.l2norm, st))
-        ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "codebook_dim %d unsupported by the search kernel", q.d);
+    const double vec = (double)c.overlap * q.Hq * q.C;
+    PROF("pvq_down_gemm", 2.0 * M * vec * q.d, (double)M * vec * (dec ? 2 : 1) * 4,
+         gemm_pvq_down(enc, dec, B, q.Hq, W, q.Cp, c.overlap, q.wd, q.Nz, q.Kq, h->zpart, splits, st));
+    int src_rc = 0;
+    PROF("pvq_search", 2.0 * M * c.group_size * c.codebook_size * q.d, ((double)c.group_size * c.codebook_size * q.d + (double)M * c.group_size * q.d) * 4,
+         src_rc = pvq_search(h->zpart, splits, M, q.Nz, q.cbn, q.c2, q.cbraw, c.group_size, c.codebook_size, q.d, q.dt, Tq, codes, bstride,
+                             loss, 1.0f / ((float)Tq * q.d * c.group_size), c.l2norm, st));
+    if (src_rc) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "codebook_dim %d unsupported by the search kernel", q.d);
     return launch_ok("pvq_encode");
 }
 
 static int run_pvq_decode(escx_handle_s* h, const Quant& q, const long long* codes, long long bstride, const float* dec, int B, int W,
                           float* out, hipStream_t st) {
     const escx_config& c = h->cfg;
-    gemm_pvq_up(codes, bstride, q.cbraw, c.group_size, c.codebook_size, q.dt, B, q.Hq, W, q.Cp, c.overlap, q.wup, q.Kq, q.Kup, dec, out, st);
+    const double vec = (double)c.overlap * q.Hq * q.C, Mv = (double)B * (W / c.overlap);
+    PROF("pvq_up_gemm", 2.0 * Mv * vec * q.d, Mv * vec * (dec ? 2 : 1) * 4,
+         gemm_pvq_up(codes, bstride, q.cbraw, c.group_size, c.codebook_size, q.dt, B, q.Hq, W, q.Cp, c.overlap, q.wup, q.Kq, q.Kup, dec, out, st));
     return launch_ok("pvq_decode");
 }
 
 static int run_deembed(escx_handle_s* h, const float* tok, int B, int W, float* rspec, hipStream_t st) {   // scale.py:73-81
     const escx_config& c = h->cfg;
     const int H0 = c.in_freq / c.patch_f;
-    gemm_conv_deembed1(tok, B, H0, W, h->C0p, h->dc1_w, h->Q * h->C0p, h->deemb, h->dc1_b, c.patch_f, c.patch_t, st);
-    gemm_conv_spec(h->deemb, B, c.patch_t * W, c.patch_f * H0, h->C0p, h->dc2_w, rspec, h->dc2_b, h->Fp, c.in_dim, st);
+    const double toks = (double)B * H0 * W, pix = toks * h->Q;
+    PROF("deembed_conv5x5", 2.0 * toks * 25 * h->C0 * h->C0 * h->Q, (toks * h->C0 + pix * h->C0) * 4,
+         gemm_conv_deembed1(tok, B, H0, W, h->C0p, h->dc1_w, h->Q * h->C0p, h->deemb, h->dc1_b, c.patch_f, c.patch_t, st));
+    PROF("deembed_conv3x3", 2.0 * pix * 9 * h->C0 * c.in_dim, (pix * h->C0 + pix * c.in_dim) * 4,
+         gemm_conv_spec(h->deemb, B, c.patch_t * W, c.patch_f * H0, h->C0p, h->dc2_w, rspec, h->dc2_b, h->Fp, c.in_dim, st));
     return launch_ok("patch_deembed");
 }
 
 static int run_istft(escx_handle_s* h, const float* rspec, int B, int T2, float* wave, hipStream_t st) {  // base.py:39-47
     const escx_config& c = h->cfg;
-    gemm_store(rspec, c.in_dim * h->Fp, B * T2, h->idft_w, h->winP, c.in_dim * h->Fp, h->frames, h->winP, nullptr, st);
-    istft_ola(h->frames, h->win2, wave, B, T2, h->winP, c.win_length, c.hop_length, h->left, h->n_fft / 2, c.hop_length * (T2 - 1), st);
+    PROF("istft_idft_gemm", 2.0 * B * T2 * c.win_length * 2 * h->F, (double)B * T2 * (2 * h->F + c.win_length) * 4,
+         gemm_store(rspec, c.in_dim * h->Fp, B * T2, h->idft_w, h->winP, c.in_dim * h->Fp, h->frames, h->winP, nullptr, st));
+    PROF("istft_overlap_add", 0, (double)B * T2 * c.win_length * 4 + (double)B * c.hop_length * (T2 - 1) * 4,
+         istft_ola(h->frames, h->win2, wave, B, T2, h->winP, c.win_length, c.hop_length, h->left, h->n_fft / 2, c.hop_length * (T2 - 1), st));
     return launch_ok("istft");
 }
 

@@ -86,4 +86,11 @@ struct escx_handle_s {
 
     // index maps (device), keyed by (H, W, shift) ; shift = -1 -> merge map
     std::map<std::tuple<int, int, int>, int*> maps;
+
+    // per-launch HIP-event profiler (escx_profile_*); off by default
+    bool prof = false;
+    struct ProfRec { std::string name; double flops, bytes; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    std::string prof_json;
 };

@@ -325,10 +325,10 @@ struct EpiPartial {             // split-K partial sums, reduced in a fixed orde
 // ------------------------------------------------------------------------------------------------
 inline int pick_bk(int Kp) { return Kp % 48 == 0 ? 48 : (Kp % 32 == 0 ? 32 : 16); }
 inline int pick_bn(int Np) {
-    // smallest padded width first, widest tile as tie-break
+    // padded width, with a mild preference for wide tiles (every N tile re-stages the A tile)
     const int cands[4] = {96, 48, 32, 16};
-    int best = 16, best_cost = 1 << 30;
-    for (int c : cands) { const int cost = (Np + c - 1) / c * c; if (cost < best_cost) { best_cost = cost; best = c; } }
+    int best = 16; double best_cost = 1e30;
+    for (int c : cands) { const double cost = (double)((Np + c - 1) / c * c) * (1.0 + 8.0 / c); if (cost < best_cost) { best_cost = cost; best = c; } }
     return best;
 }
 

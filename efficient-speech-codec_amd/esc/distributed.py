@@ -1,0 +1,83 @@
+"""Batch sharding across the GPUs of one node: one process per GPU, clips are independent end to end, the only
+exchange step is one all-gather of the emitted codes (RCCL over xGMI via torch.distributed, backend "nccl").
+
+The reference has no inference-time collective; this is the BASELINE.json config-4 path.
+Codes are 10-bit values carried as int64 by the API; they travel as int16 (4x fewer bytes on the links).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, near-equal split of `total` clips; earlier ranks take the remainder."""
+    base, rem = divmod(total, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def narrow_codes(codes: torch.Tensor) -> torch.Tensor:
+    """int64 (values < 2^15) -> int16; HIP kernel on device tensors, torch cast for host tensors (gloo tests)."""
+    if codes.is_cuda:
+        from . import _native
+        lib = _native.load()
+        out = torch.empty(codes.shape, dtype=torch.int16, device=codes.device)
+        c = codes.contiguous()
+        with torch.cuda.device(codes.device):
+            _native.check(lib.escx_codes_narrow(ctypes.c_void_p(c.data_ptr()), ctypes.c_void_p(out.data_ptr()), c.numel(),
+                                                ctypes.c_void_p(torch.cuda.current_stream(codes.device).cuda_stream)))
+        return out
+    return codes.to(torch.int16)
+
+
+def widen_codes(codes16: torch.Tensor) -> torch.Tensor:
+    if codes16.is_cuda:
+        from . import _native
+        lib = _native.load()
+        out = torch.empty(codes16.shape, dtype=torch.int64, device=codes16.device)
+        c = codes16.contiguous()
+        with torch.cuda.device(codes16.device):
+            _native.check(lib.escx_codes_widen(ctypes.c_void_p(c.data_ptr()), ctypes.c_void_p(out.data_ptr()), c.numel(),
+                                               ctypes.c_void_p(torch.cuda.current_stream(codes16.device).cuda_stream)))
+        return out
+    return codes16.to(torch.int64)
+
+
+def all_gather_codes(codes_local: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """(B_local, S, G, T) int64 on every rank -> (sum B_local, S, G, T) int64 on every rank, rank order.
+
+    Equal shard sizes use one all_gather_into_tensor (a single direct collective: the payload is <= 0.2 MB per rank,
+    latency-bound, nowhere near the per-link xGMI bandwidth); ragged shards fall back to all_gather of padded shards."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return codes_local
+    world = dist.get_world_size(group)
+    small = narrow_codes(codes_local)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=small.device) for _ in range(world)]
+    mine = torch.tensor([small.shape[0]], dtype=torch.int64, device=small.device)
+    dist.all_gather(sizes, mine, group=group)
+    counts = [int(s.item()) for s in sizes]
+    if len(set(counts)) == 1:
+        out = torch.empty((world * counts[0],) + tuple(small.shape[1:]), dtype=torch.int16, device=small.device)
+        try:
+            dist.all_gather_into_tensor(out, small.contiguous(), group=group)
+        except (RuntimeError, NotImplementedError):        # gloo builds without the fused form
+            parts = [torch.empty_like(small) for _ in range(world)]
+            dist.all_gather(parts, small.contiguous(), group=group)
+            out = torch.cat(parts, dim=0)
+        return widen_codes(out)
+    mx = max(counts)
+    pad = torch.zeros((mx,) + tuple(small.shape[1:]), dtype=torch.int16, device=small.device)
+    pad[: small.shape[0]] = small
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return widen_codes(torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0))
+
+
+def encode_sharded(model, x_local: torch.Tensor, num_streams: int = 6, group: Optional[dist.ProcessGroup] = None):
+    """Each rank encodes its own clips; returns (codes of the WHOLE batch on every rank, local codes, feat_shape)."""
+    codes_local, shape = model.encode(x_local, num_streams)
+    return all_gather_codes(codes_local, group), codes_local, shape

@@ -124,6 +124,13 @@ int escx_pvq_decode(escx_handle h, int stream_id, const int64_t* codes_dev, int6
 /* PatchDeEmbed.forward (scale.py:73-81): tokens (B,H0*W,C0) -> spec (B, 2W, 2, F) frame-major */
 int escx_patch_deembed(escx_handle h, const float* tokens_dev, int batch, int W, float* spec_dev, void* stream);
 
+/* ---- per-kernel timing (HIP events recorded on the caller's stream around every launch) ------- */
+/* enable != 0 starts recording (and clears earlier records); enable == 0 stops. */
+int escx_profile_enable(escx_handle h, int enable);
+/* Synchronises, aggregates by kernel label and returns a JSON array
+ * [{"name":..., "calls":n, "ms":total, "flops":algorithmic, "bytes":algorithmic}, ...] valid until the next call. */
+const char* escx_profile_report(escx_handle h);
+
 /* ---- code packing for transport (10-bit codes; all-gather payload) --------------------------- */
 int escx_codes_narrow(const int64_t* codes_dev, int16_t* out_dev, int64_t n, void* stream);
 int escx_codes_widen(const int16_t* in_dev, int64_t* codes_dev, int64_t n, void* stream);
