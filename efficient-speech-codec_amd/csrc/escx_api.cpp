@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "escx_internal.h"
@@ -60,6 +61,9 @@ static int build_geometry(escx_handle_s* h) {
         L.hd = C / nH; L.hdp = roundup4(L.hd);
         if (L.hdp > 64) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "head_dim %d > 64", L.hd);
         L.Nqkv = rup(3 * nH * L.hdp, 16); L.Ko = rup(nH * L.hdp, 16);
+        if (L.hd <= 8) { L.attn_mode = 1; L.n_groups = (nH + 1) / 2; }
+        else if (L.hd <= 16) { L.attn_mode = 0; L.n_groups = nH; }
+        else if (L.hd <= 32) { L.attn_mode = 2; L.n_groups = nH; }
         L.hidden = (int)(C * c.mlp_ratio); L.hiddenP = rup(L.hidden, 16);
         L.scale = scale; L.Cout = Cout; L.CoutP = rup(Cout, 16);
         L.blocks.resize(c.swin_depth);
@@ -118,6 +122,10 @@ extern "C" int escx_create(const escx_config* cfg, int device, escx_handle* out)
     if (device < 0 || device >= ndev) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, ndev);
     escx_handle_s* h = new escx_handle_s();
     h->cfg = *cfg; h->device = device;
+    { const char* e = getenv("ESCX_NO_FUSED"); h->use_fused = !(e && e[0] == '1'); }
+    { const char* e = getenv("ESCX_MLP_VARIANT"); if (e && e[0]) h->mlp_variant = atoi(e); }
+    { const char* e = getenv("ESCX_ATTN_NW"); if (e && e[0]) h->attn_nw = atoi(e); }
+    { const char* e = getenv("ESCX_NO_FUSED_ATTN"); h->use_fused_attn = !(e && e[0] == '1'); }
     int rc = build_geometry(h);
     if (rc) { delete h; return rc; }
     *out = h;
@@ -170,6 +178,15 @@ struct Packer {
 };
 
 inline double hann(int k, int n) { return 0.5 - 0.5 * std::cos(2.0 * M_PI * (double)k / (double)n); }
+
+// MFMA fragment order: element (tn, kk, lane = 16*g + i, j) = W[16 tn + i][16 kk + 4 g + j]; one (tn, kk) block is
+// the 1 KiB a wave fetches with a single coalesced 16-byte-per-lane load.
+template <class F>
+void pack_frag(float* dst, int n_tiles, int k_tiles, F at) {
+    for (int tn = 0; tn < n_tiles; ++tn) for (int kk = 0; kk < k_tiles; ++kk) for (int g = 0; g < 4; ++g)
+        for (int i = 0; i < 16; ++i) for (int j = 0; j < 4; ++j)
+            dst[((((size_t)tn * k_tiles + kk) * 64) + 16 * g + i) * 4 + j] = at(16 * tn + i, 16 * kk + 4 * g + j);
+}
 }  // namespace
 
 #define GETP(var, key, ...) const Param* var = pk.get(key, {__VA_ARGS__}); if (!var) ESCX_FAIL(ESCX_ERR_STATE, "%s", pk.missing.c_str())
@@ -225,6 +242,69 @@ extern "C" int escx_finalize_params(escx_handle h) {
             o = slot(&bw.w2, (size_t)Cp * L.hiddenP);
             for (int r = 0; r < C; ++r) std::copy(w2->data.begin() + (size_t)r * L.hidden, w2->data.begin() + (size_t)(r + 1) * L.hidden, pk.host.begin() + o + (size_t)r * L.hiddenP);
             o = slot(&bw.b2, Cp); std::copy(b2->data.begin(), b2->data.end(), pk.host.begin() + o);
+            if (L.attn_mode >= 0) {   // fused attention stream: per head group the Q, K, V and projection tiles in fragment order
+                const int mode = L.attn_mode, NG = L.n_groups, KK = Cp / 16;
+                const int TPG = mode == 2 ? 8 : 4, NBr = mode == 2 ? 6 : 3;
+                // (head, dim) addressed by row/k-slot i of half-tile `half` of group g; -1 when padding
+                auto hd_of = [&](int g, int half, int i, int* hh, int* dd) {
+                    if (mode == 0) { *hh = g; *dd = i; }
+                    else if (mode == 1) { *hh = 2 * g + (i >> 3); *dd = i & 7; }
+                    else { *hh = g; *dd = 16 * half + i; }
+                    return *hh < nH && *dd < hd;
+                };
+                size_t ow = slot(&bw.waf, (size_t)NG * TPG * KK * 256), obb = slot(&bw.baf, (size_t)NG * NBr * 16);
+                size_t obt = slot(&bw.bias_tab_f, (size_t)(mode == 1 ? 2 * NG : NG) * 256);
+                for (int hh = 0; hh < nH; ++hh) for (int i2 = 0; i2 < 16; ++i2) for (int jj = 0; jj < 16; ++jj) {
+                    const int idx = ((i2 >> 2) - (jj >> 2) + 3) * 7 + ((i2 & 3) - (jj & 3) + 3);
+                    pk.host[obt + ((size_t)hh * 16 + i2) * 16 + jj] = tab->data[(size_t)idx * nH + hh];
+                }
+                for (int g = 0; g < NG; ++g) {
+                    // tile order: mode 0/1 [Q,K,V,P]; mode 2 [Q_lo,K_lo,Q_hi,K_hi,V_lo,P_lo,V_hi,P_hi]
+                    struct T { int which; int half; };           // which: 0 q, 1 k, 2 v, 3 proj
+                    const T order4[4] = {{0, 0}, {1, 0}, {2, 0}, {3, 0}};
+                    const T order8[8] = {{0, 0}, {1, 0}, {0, 1}, {1, 1}, {2, 0}, {3, 0}, {2, 1}, {3, 1}};
+                    for (int ti = 0; ti < TPG; ++ti) {
+                        const T tt = mode == 2 ? order8[ti] : order4[ti];
+                        float* dstp = pk.host.data() + ow + ((size_t)g * TPG + ti) * KK * 256;
+                        if (tt.which < 3) {
+                            pack_frag(dstp, 1, KK, [&](int i2, int kx) {
+                                int hh, dd; if (!hd_of(g, tt.half, i2, &hh, &dd) || kx >= C) return 0.f;
+                                return qw->data[(size_t)(tt.which * C + hh * hd + dd) * C + kx]; });
+                            // bias rows: mode 0/1 [q,k,v]; mode 2 [q_lo,k_lo,q_hi,k_hi,v_lo,v_hi]
+                            const int brow = mode == 2 ? (tt.which == 2 ? 4 + tt.half : 2 * tt.half + tt.which) : tt.which;
+                            for (int i2 = 0; i2 < 16; ++i2) {
+                                int hh, dd;
+                                pk.host[obb + ((size_t)g * NBr + brow) * 16 + i2] = hd_of(g, tt.half, i2, &hh, &dd) ? qb->data[tt.which * C + hh * hd + dd] : 0.f;
+                            }
+                        } else {    // projection: N = Cp output tiles (to), K = this tile's 16 k-slots
+                            for (int to = 0; to < KK; ++to) for (int gq = 0; gq < 4; ++gq) for (int i2 = 0; i2 < 16; ++i2) for (int j = 0; j < 4; ++j) {
+                                int hh, dd; const int n = 16 * to + i2;
+                                const bool ok = hd_of(g, tt.half, 4 * gq + j, &hh, &dd) && n < C;
+                                dstp[(((size_t)to * 64) + 16 * gq + i2) * 4 + j] = ok ? pw->data[(size_t)n * C + hh * hd + dd] : 0.f;
+                            }
+                        }
+                    }
+                }
+            }
+            {   // fragment-ordered copies for the fused MLP kernel
+                const int hid = L.hidden;
+                o = slot(&bw.w1f, (size_t)L.hiddenP * Cp);
+                pack_frag(pk.host.data() + o, L.hiddenP / 16, Cp / 16, [&](int n, int k) { return (n < hid && k < C) ? w1->data[(size_t)n * C + k] : 0.f; });
+                o = slot(&bw.w2f, (size_t)Cp * L.hiddenP);
+                pack_frag(pk.host.data() + o, Cp / 16, L.hiddenP / 16, [&](int n, int k) { return (n < C && k < hid) ? w2->data[(size_t)n * hid + k] : 0.f; });
+                // combined per-hidden-tile stream: [ht][ KK fc1 blocks (kk) | KK fc2 blocks (to) ][64][4]
+                const int KK = Cp / 16, HT = L.hiddenP / 16;
+                const size_t o1 = fix[fix.size() - 2].second, o2 = fix[fix.size() - 1].second;
+                o = slot(&bw.wcf, (size_t)2 * L.hiddenP * Cp);
+                for (int ht = 0; ht < HT; ++ht) {
+                    for (int kk = 0; kk < KK; ++kk)
+                        std::copy(pk.host.begin() + o1 + ((size_t)ht * KK + kk) * 256, pk.host.begin() + o1 + ((size_t)ht * KK + kk + 1) * 256,
+                                  pk.host.begin() + o + ((size_t)ht * 2 * KK + kk) * 256);
+                    for (int to = 0; to < KK; ++to)
+                        std::copy(pk.host.begin() + o2 + ((size_t)to * HT + ht) * 256, pk.host.begin() + o2 + ((size_t)to * HT + ht + 1) * 256,
+                                  pk.host.begin() + o + ((size_t)ht * 2 * KK + KK + to) * 256);
+                }
+            }
         }
         if (L.scale == 1) {          // PatchMerge: norm over [s][C] -> [s][Cp]; down.weight [Cout][2C] -> [CoutP][2Cp]
             GETP(nw, L.prefix + "subsample.norm.weight", 2 * C); GETP(nb, L.prefix + "subsample.norm.bias", 2 * C);
@@ -587,6 +667,15 @@ extern "C" const char* escx_profile_report(escx_handle h) {
     return h->prof_json.c_str();
 }
 
+// (TM, NW) of the LDS-staged fused MLP per padded width, from the B=36 sweep in profiles/ (ESCX_MLP_VARIANT overrides)
+static int mlp_variant_for(int Cp) {
+    switch (Cp) {
+        case 48: case 80: case 144: return 3;      // TM=1, 8 waves
+        case 384: return 2;                        // TM=1, 6 waves (21600 rows -> 225 workgroups on 256 CUs)
+        default: return 1;                         // TM=1, 4 waves
+    }
+}
+
 // One TransformerLayer on padded token maps.  x_in is read-only; y receives (B, H'*W, CoutP).
 // attention.py:48-91 (layer), 129-178 (block): LN1 -> pad -> roll -> windows -> attention -> reverse -> residual -> MLP.
 static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float* y, int B, int H, int W, int* Hout, hipStream_t st) {
@@ -602,6 +691,16 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         if ((rc = get_map(h, H, W, shift, &map))) return rc;
         const std::string tag = h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string();
         const double dM = M, dMs = Ms, dC = L.C, f4 = sizeof(float);
+        bool attn_done = false;
+        if (h->use_fused && h->use_fused_attn && L.attn_mode >= 0) {
+            int frc = 0;
+            const int nw = h->attn_nw ? h->attn_nw : 4;
+            PROF("attn_fused" + tag, 2 * dMs * dC * 4 * dC + 4 * dMs * 16 * dC, 2 * dM * dC * f4,
+                 frc = attn_fused(src, cur, L.Cp, L.C, L.attn_mode, L.n_groups, bw.ln1_g, bw.ln1_b, bw.waf, bw.baf, bw.bias_tab_f, bw.bproj,
+                                  map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, st));
+            attn_done = (frc == 0);
+        }
+        if (!attn_done) {
         PROF("ln1_gather" + tag, 0, (dM + dMs) * dC * f4,
              ln_rows(1, src, h->xn, bw.ln1_g, bw.ln1_b, map, slots, tokens, Ms, L.C, L.Cp, st));
         PROF("gemm_qkv" + tag, 2 * dMs * dC * 3 * dC, (dMs * 4 * dC + 3 * dC * dC) * f4,
@@ -612,6 +711,14 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         if (arc) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "head_dim %d unsupported by the attention kernel", L.hd);
         PROF("gemm_proj" + tag, 2 * dMs * dC * dC, (dMs * dC + 2 * dM * dC + dC * dC) * f4,
              gemm_proj_scatter(h->obuf, L.Ko, Ms, bw.wproj, L.Cp, L.Ko, cur, src, bw.bproj, map, slots, tokens, st));
+        }
+        if (h->use_fused) {
+            int frc = 0;
+            PROF("mlp_fused" + tag, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
+                 frc = mlp_fused(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP,
+                                 h->mlp_variant >= 0 ? h->mlp_variant : mlp_variant_for(L.Cp), st));
+            if (frc == 0) { src = cur; continue; }
+        }
         PROF("ln2" + tag, 0, 2 * dM * dC * f4,
              ln_rows(0, cur, h->xn, bw.ln2_g, bw.ln2_b, nullptr, tokens, tokens, M, L.C, L.Cp, st));
         PROF("gemm_fc1_gelu" + tag, 2 * dM * dC * L.hidden, (dM * (dC + L.hidden) + dC * L.hidden) * f4,

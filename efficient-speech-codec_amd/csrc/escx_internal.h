@@ -34,11 +34,15 @@ struct Arena {                       // device bump allocator
 
 struct BlockW {                      // one SwinBlock, packed
     float *ln1_g, *ln1_b, *wqkv, *bqkv, *bias_tab, *wproj, *bproj, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
+    float *w1f, *w2f;                // fc1 / fc2 in MFMA fragment order ([n-tile][k-step][lane][4]) for the fused MLP
+    float *wcf;                      // per hidden tile [fc1 fragments | fc2 fragments]: the LDS-staged fused MLP's stream
+    float *waf, *baf, *bias_tab_f;   // fused attention: weight stream [group][tile][KK][64][4], tile biases, padded bias table
 };
 
 struct Layer {                       // one TransformerLayer (attention.py:9-91)
     std::string prefix;
     int C, Cp, nH, hd, hdp, Nqkv, Ko, hidden, hiddenP;
+    int attn_mode = -1, n_groups = 0; // fused attention head->tile mapping (fused_attn.h), -1 = not supported
     int scale;                       // 0 none, 1 down (PatchMerge), 2 up (PatchSplit)
     int Cout, CoutP;
     std::vector<BlockW> blocks;
@@ -66,6 +70,10 @@ struct escx_handle_s {
     std::map<std::string, escx::Param> params;
     std::vector<std::string> required;
     bool finalized = false;
+    bool use_fused = true;           // ESCX_NO_FUSED=1 selects the unfused GEMM pipeline (A/B and fallback)
+    int mlp_variant = -1;            // ESCX_MLP_VARIANT overrides the per-layer choice (tuning)
+    int attn_nw = 0;                 // ESCX_ATTN_NW: waves per workgroup of the fused attention kernel (4 or 8)
+    bool use_fused_attn = true;      // ESCX_NO_FUSED_ATTN=1
 
     escx::Arena wts;                 // packed weights
     std::vector<escx::Layer> layers; // 2n entries (see escx_transformer_layer)

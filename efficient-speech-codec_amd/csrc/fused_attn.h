@@ -1,0 +1,306 @@
+// Fused shifted-window attention half of a Swin block for gfx950 (attention.py:129-176, 215-244):
+//
+//   x <- x + proj( softmax( (q*scale) k^T + rel_pos_bias [+ shift mask] ) v ),  q,k,v = qkv(LN(x))  per 4x4 window
+//
+// One wave owns TMW windows (16 tokens each) end to end, entirely in registers:
+//   1. gathers its window's tokens through the (pad, roll, partition) index map straight into the MFMA
+//      operand layout and LayerNorms them in registers; padded slots become zero rows AFTER the norm
+//      (attention.py:135-143), and still take part as keys/values with k = v = bias (attention.py:150-151);
+//   2. per head group: Q and K tiles with the weights as the row operand -> lane (token, 4 dims) == the
+//      operand layout of S^T = K.Q^T, so scores come straight from the accumulators; V with the operands
+//      swapped -> lane (dim, 4 tokens) == the row-operand layout of O^T = V^T.P^T; the softmaxed P tile is
+//      already the column operand.  O^T leaves lane (token, 4 dims) == operand layout of the projection;
+//   3. projection accumulates over head groups; epilogue adds bias + shortcut and scatters 16 B per lane
+//      back through the index map (window reverse + un-roll + crop).
+// q, k, v, the 16x16 scores and the attention output never touch memory (the unfused path writes/reads
+// 4x the activation for them).  Head dims map to 16-row MFMA tiles in three ways (MODE):
+//   0: head_dim <= 16, one head per tile      (15, 12, 16 in ESC-Base)
+//   1: head_dim <= 8, two heads per tile      (8, 6): scores via k-slot masking, outputs by lane select
+//   2: head_dim <= 32, one head over two tiles (24)
+// The NW waves of a workgroup stream the weights (host-packed in fragment order) through a double-buffered
+// LDS ring filled by global_load_lds_dwordx4, UT tiles per stage.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gemm_engine.h"
+
+namespace escx {
+
+struct AttnArgs {
+    const float* src;           // [B*tokens][CP] block input (also the shortcut)
+    float* dst;                 // [B*tokens][CP] output (may alias src: windows own disjoint tokens)
+    const float* gamma; const float* beta;
+    const f32x4* wf;            // weight stream: [group][tile][KK][64] fragments
+    const float* bqkv;          // [group][3*NT][16] biases of the Q/K/V tiles, in stream order
+    const float* bias_tab;      // [heads padded][16][16]
+    const float* bproj;         // [CP]
+    const int* map;             // [slots] window slot -> token or -1
+    int slots, tokens, n_windows, nWh, nWw, shifted, C, n_groups;
+    float scale, eps;
+};
+
+// softmax over the 16 keys of one query row held as 4 values x 4 lane groups (attention.py:226-238)
+__device__ __forceinline__ f32x4 window_softmax(f32x4 s, const float* bias_h, int l15, int lg, bool shifted, bool lastH, bool lastW) {
+    s += ld4(bias_h + l15 * 16 + 4 * lg);
+    if (shifted) {
+        const int qh = l15 >> 2, qw = l15 & 3;
+        const int labq = 3 * (lastH ? (qh < 2 ? 1 : 2) : 0) + (lastW ? (qw < 2 ? 1 : 2) : 0);
+        const int labkh = 3 * (lastH ? (lg < 2 ? 1 : 2) : 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int labk = labkh + (lastW ? (r < 2 ? 1 : 2) : 0);
+            s[r] += (labk != labq) ? -100.0f : 0.0f;
+        }
+    }
+    float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    f32x4 p;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] = expf(s[r] - mx);
+    float den = (p[0] + p[1]) + (p[2] + p[3]);
+    den += __shfl_xor(den, 16);
+    den += __shfl_xor(den, 32);
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] *= inv;
+    return p;
+}
+
+template <int CP, int MODE, int UT, int TMW, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fused_kernel(AttnArgs a) {
+    constexpr int KK = CP / 16;
+    constexpr int TPG = (MODE == 2) ? 8 : 4;    // weight tiles per head group
+    constexpr int NB = (MODE == 2) ? 6 : 3;     // bias rows per group
+    static_assert(TPG % UT == 0, "stage size must divide the tiles of a head group");
+    __shared__ f32x4 wbuf[2][UT * KK * 64];
+
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wave = threadIdx.x >> 6;
+    const int win0 = (blockIdx.x * NW + wave) * TMW;
+    const int n_stages = a.n_groups * (TPG / UT);
+
+    auto issue = [&](int stage, int buf) {
+        const f32x4* src = a.wf + (size_t)stage * (UT * KK * 64) + lane;
+        for (int c = wave; c < UT * KK; c += NW)
+            __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(&wbuf[buf][c * 64]), 16, 0, 0);
+    };
+    issue(0, 0);
+
+    // ---- 1. gather + LayerNorm in registers ------------------------------------------------------
+    const int nW = a.nWh * a.nWw;
+    f32x4 xf[TMW][KK];
+    int tok[TMW];                               // this lane's token row (element offset / CP), or -1
+    bool lastH[TMW], lastW[TMW];
+#pragma unroll
+    for (int t = 0; t < TMW; ++t) {
+        const int win = win0 + t;
+        tok[t] = -1; lastH[t] = false; lastW[t] = false;
+        if (win < a.n_windows) {
+            const int b = win / nW, wloc = win - b * nW;
+            const int wh = wloc / a.nWw, ww = wloc - wh * a.nWw;
+            lastH[t] = (wh == a.nWh - 1); lastW[t] = (ww == a.nWw - 1);
+            const int tk = a.map[wloc * 16 + l15];
+            if (tk >= 0) tok[t] = b * a.tokens + tk;
+        }
+        const float* xr = a.src + (size_t)(tok[t] < 0 ? 0 : tok[t]) * CP + 4 * lg;
+        float s = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            xf[t][kk] = tok[t] >= 0 ? ld4(xr + 16 * kk) : zero4();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) s += xf[t][kk][e];
+        }
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        const float mean = s / (float)a.C;
+        float v = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) { const float d = xf[t][kk][e] - mean; v += d * d; }
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        const float rstd = 1.0f / sqrtf(v / (float)a.C + a.eps);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const f32x4 g = ld4(a.gamma + 16 * kk + 4 * lg), bb = ld4(a.beta + 16 * kk + 4 * lg);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                xf[t][kk][e] = (tok[t] >= 0 && 16 * kk + 4 * lg + e < a.C) ? (xf[t][kk][e] - mean) * rstd * g[e] + bb[e] : 0.f;
+        }
+    }
+
+    f32x4 acc[KK][TMW];
+#pragma unroll
+    for (int o = 0; o < KK; ++o)
+#pragma unroll
+        for (int t = 0; t < TMW; ++t) acc[o][t] = zero4();
+
+    int stage = 0;
+    const f32x4* wb = nullptr;
+    auto next_stage = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (stage + 1 < n_stages) issue(stage + 1, (stage + 1) & 1);
+        wb = &wbuf[stage & 1][lane];
+        ++stage;
+    };
+    // tile GEMM with the weight tile as the row operand: out[t] = W_tile . x^T  -> lane (token l15, rows 4lg + r)
+    auto gemm_w_rows = [&](const f32x4* wt, f32x4* out) {
+        f32x4 o2[TMW];
+#pragma unroll
+        for (int t = 0; t < TMW; ++t) { out[t] = zero4(); o2[t] = zero4(); }
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const f32x4 w = wt[kk * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < TMW; ++t) {
+                    if (TMW == 1 && (r & 1)) o2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xf[t][kk][r], o2[t], 0, 0, 0);
+                    else out[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xf[t][kk][r], out[t], 0, 0, 0);
+                }
+        }
+        if (TMW == 1) out[0] += o2[0];
+    };
+    // swapped: out[t] = x . W_tile^T -> lane (row l15 of the weight tile, tokens 4lg + r)
+    auto gemm_x_rows = [&](const f32x4* wt, f32x4* out) {
+        f32x4 o2[TMW];
+#pragma unroll
+        for (int t = 0; t < TMW; ++t) { out[t] = zero4(); o2[t] = zero4(); }
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const f32x4 w = wt[kk * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < TMW; ++t) {
+                    if (TMW == 1 && (r & 1)) o2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[t][kk][r], w[r], o2[t], 0, 0, 0);
+                    else out[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[t][kk][r], w[r], out[t], 0, 0, 0);
+                }
+        }
+        if (TMW == 1) out[0] += o2[0];
+    };
+    auto proj_accumulate = [&](const f32x4* wt, const f32x4* o) {
+#pragma unroll
+        for (int to = 0; to < KK; ++to) {
+            const f32x4 w = wt[to * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < TMW; ++t)
+                    acc[to][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], o[t][r], acc[to][t], 0, 0, 0);
+        }
+    };
+
+    // ---- 2. head groups ----------------------------------------------------------------------------
+    for (int g = 0; g < a.n_groups; ++g) {
+        const float* bg = a.bqkv + (size_t)g * NB * 16;
+        int tile = 0;
+        auto tile_ptr = [&]() -> const f32x4* {
+            if (tile % UT == 0) next_stage();
+            const f32x4* p = wb + (tile % UT) * KK * 64;
+            ++tile;
+            return p;
+        };
+        f32x4 q[TMW], k[TMW], vt[TMW], o[TMW];
+        if constexpr (MODE != 2) {
+            gemm_w_rows(tile_ptr(), q);
+            { const f32x4 bq = ld4(bg + 4 * lg);
+#pragma unroll
+              for (int t = 0; t < TMW; ++t) q[t] = (q[t] + bq) * a.scale; }
+            gemm_w_rows(tile_ptr(), k);
+            { const f32x4 bk = ld4(bg + 16 + 4 * lg);
+#pragma unroll
+              for (int t = 0; t < TMW; ++t) k[t] += bk; }
+            f32x4 p0[TMW], p1[TMW];
+#pragma unroll
+            for (int t = 0; t < TMW; ++t) {
+                if constexpr (MODE == 0) {
+                    f32x4 s = zero4();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s = __builtin_amdgcn_mfma_f32_16x16x4f32(k[t][r], q[t][r], s, 0, 0, 0);
+                    p0[t] = window_softmax(s, a.bias_tab + (size_t)g * 256, l15, lg, a.shifted, lastH[t], lastW[t]);
+                } else {        // two heads share the tile: head A on k-slot groups 0,1 and head B on 2,3
+                    f32x4 sa = zero4(), sb = zero4();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k[t][r], lg < 2 ? q[t][r] : 0.f, sa, 0, 0, 0);
+                        sb = __builtin_amdgcn_mfma_f32_16x16x4f32(k[t][r], lg < 2 ? 0.f : q[t][r], sb, 0, 0, 0);
+                    }
+                    p0[t] = window_softmax(sa, a.bias_tab + (size_t)(2 * g) * 256, l15, lg, a.shifted, lastH[t], lastW[t]);
+                    p1[t] = window_softmax(sb, a.bias_tab + (size_t)(2 * g + 1) * 256, l15, lg, a.shifted, lastH[t], lastW[t]);
+                }
+            }
+            gemm_x_rows(tile_ptr(), vt);
+            { const float bv = bg[32 + l15];
+#pragma unroll
+              for (int t = 0; t < TMW; ++t) vt[t] += bv; }
+#pragma unroll
+            for (int t = 0; t < TMW; ++t) {
+                f32x4 oa = zero4();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oa = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[t][r], p0[t][r], oa, 0, 0, 0);
+                if constexpr (MODE == 1) {
+                    f32x4 ob = zero4();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ob = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[t][r], p1[t][r], ob, 0, 0, 0);
+                    o[t] = lg < 2 ? oa : ob;        // lane holds dims 4lg + r: dims 0-7 are head A's, 8-15 head B's
+                } else {
+                    o[t] = oa;
+                }
+            }
+            proj_accumulate(tile_ptr(), o);
+        } else {                // MODE 2: stream order [Q_lo, K_lo, Q_hi, K_hi, V_lo, P_lo, V_hi, P_hi]
+            f32x4 s[TMW];
+#pragma unroll
+            for (int t = 0; t < TMW; ++t) s[t] = zero4();
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                gemm_w_rows(tile_ptr(), q);
+                { const f32x4 bq = ld4(bg + (2 * half) * 16 + 4 * lg);
+#pragma unroll
+                  for (int t = 0; t < TMW; ++t) q[t] = (q[t] + bq) * a.scale; }
+                gemm_w_rows(tile_ptr(), k);
+                { const f32x4 bk = ld4(bg + (2 * half + 1) * 16 + 4 * lg);
+#pragma unroll
+                  for (int t = 0; t < TMW; ++t) k[t] += bk; }
+#pragma unroll
+                for (int t = 0; t < TMW; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(k[t][r], q[t][r], s[t], 0, 0, 0);
+            }
+            f32x4 p[TMW];
+#pragma unroll
+            for (int t = 0; t < TMW; ++t) p[t] = window_softmax(s[t], a.bias_tab + (size_t)g * 256, l15, lg, a.shifted, lastH[t], lastW[t]);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                gemm_x_rows(tile_ptr(), vt);
+                { const float bv = bg[(4 + half) * 16 + l15];
+#pragma unroll
+                  for (int t = 0; t < TMW; ++t) vt[t] += bv; }
+#pragma unroll
+                for (int t = 0; t < TMW; ++t) {
+                    o[t] = zero4();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[t][r], p[t][r], o[t], 0, 0, 0);
+                }
+                proj_accumulate(tile_ptr(), o);
+            }
+        }
+    }
+
+    // ---- 3. bias + shortcut, scatter through the map ----------------------------------------------
+#pragma unroll
+    for (int t = 0; t < TMW; ++t) {
+        if (tok[t] < 0) continue;
+        const float* sr = a.src + (size_t)tok[t] * CP + 4 * lg;
+        float* dr = a.dst + (size_t)tok[t] * CP + 4 * lg;
+#pragma unroll
+        for (int o = 0; o < KK; ++o) {
+            const f32x4 v = acc[o][t] + ld4(a.bproj + 16 * o + 4 * lg);
+            st4(dr + 16 * o, ld4(sr + 16 * o) + v);
+        }
+    }
+}
+
+}  // namespace escx

@@ -1,0 +1,249 @@
+// Fused Swin MLP for gfx950:  x <- x + W2 . gelu(W1 . LN(x) + b1) + b2     (attention.py:177, 258-272)
+//
+// Wave-autonomous, register-resident, barrier-free.  One wave owns 16*TM token rows end to end:
+//   1. loads its rows straight into the MFMA *operand* layout (lane (row = l&15, k-slot group g = l>>4)
+//      holds x[row][16kk + 4g .. +3]) and LayerNorms them in registers (row statistics are an in-lane sum
+//      plus two cross-lane shuffles over the 4 k-slot groups);
+//   2. walks the hidden dimension 16 units at a time: fc1 tile -> bias -> exact-erf GELU -> fc2 partial.
+//      The fc1 accumulator tile D[n][m] leaves lane (m = l&15, g) holding h[m][16t + 4g + r], r = 0..3,
+//      which is *already* the operand layout of the fc2 MFMA with k-slot (g, r) <-> hidden unit 16t+4g+r.
+//      The tokens x 4C hidden activation therefore never exists anywhere but in 4*TM registers;
+//   3. adds bias + residual and stores 16 bytes per lane.
+// Weights are pre-packed on the host in fragment order ([tile][k-step][lane][4]) so that every weight
+// fetch is one fully coalesced 1 KiB wave load from L2 (all waves walk the same 2 x 4C x C floats, which
+// stay L2-resident); no LDS staging is needed because a fragment is consumed by exactly one wave-level
+// MFMA sequence and TM row tiles amortise it inside the wave.
+// Arithmetic: v_mfma_f32_16x16x4_f32 (exact fp32).  Algorithmic traffic: read x once, write x once.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gemm_engine.h"
+
+namespace escx {
+
+struct MlpArgs {
+    float* x;                   // [M][CP] in/out
+    const float* gamma; const float* beta;      // LayerNorm (norm2), padded to CP
+    const f32x4* w1f; const float* b1;          // fc1 fragments [HT][KK][64], bias [16*HT]
+    const f32x4* w2f; const float* b2;          // fc2 fragments [KK][HT][64], bias [CP]
+    const f32x4* wcf;                           // per hidden tile: [HT][KK fc1 fragments | KK fc2 fragments][64] (LDS-staged variant)
+    int M, C, HT;
+    float eps;
+};
+
+template <int CP, int TM>
+__global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
+    constexpr int KK = CP / 16;
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int m0 = wave * (16 * TM);
+    if (m0 >= a.M) return;
+
+    // ---- 1. rows -> operand layout, LayerNorm in registers -------------------------------------
+    f32x4 xf[TM][KK];
+    float mean[TM], rstd[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int row = m0 + t * 16 + l15;
+        const float* xr = a.x + (size_t)row * CP + 4 * lg;
+        float s = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            xf[t][kk] = row < a.M ? ld4(xr + 16 * kk) : zero4();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) s += xf[t][kk][e];
+        }
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        mean[t] = s / (float)a.C;
+        float v = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) { const float d = xf[t][kk][e] - mean[t]; v += d * d; }
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        rstd[t] = 1.0f / sqrtf(v / (float)a.C + a.eps);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        const f32x4 g = ld4(a.gamma + 16 * kk + 4 * lg), b = ld4(a.beta + 16 * kk + 4 * lg);
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                xf[t][kk][e] = (16 * kk + 4 * lg + e < a.C) ? (xf[t][kk][e] - mean[t]) * rstd[t] * g[e] + b[e] : 0.f;
+    }
+
+    // ---- 2. hidden tiles: fc1 -> GELU -> fc2 partial, all in registers ---------------------------
+    f32x4 acc[KK][TM];
+#pragma unroll
+    for (int o = 0; o < KK; ++o)
+#pragma unroll
+        for (int t = 0; t < TM; ++t) acc[o][t] = zero4();
+
+    const f32x4* w1 = a.w1f + lane;
+    const f32x4* w2 = a.w2f + lane;
+    for (int ht = 0; ht < a.HT; ++ht) {
+        f32x4 h[TM], h2[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) { h[t] = zero4(); h2[t] = zero4(); }
+        const f32x4* w1t = w1 + (size_t)ht * KK * 64;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const f32x4 w = w1t[kk * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {
+                    if (TM == 1 && (r & 1)) h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xf[t][kk][r], h2[t], 0, 0, 0);
+                    else h[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xf[t][kk][r], h[t], 0, 0, 0);
+                }
+        }
+        const f32x4 bb = ld4(a.b1 + 16 * ht + 4 * lg);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            if (TM == 1) h[t] += h2[t];
+            h[t] += bb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[t][e] = gelu_erf(h[t][e]);
+        }
+#pragma unroll
+        for (int o = 0; o < KK; ++o) {
+            const f32x4 w = w2[((size_t)o * a.HT + ht) * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+                    acc[o][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], h[t][r], acc[o][t], 0, 0, 0);
+        }
+    }
+
+    // ---- 3. bias + residual, 16 B per lane -------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int row = m0 + t * 16 + l15;
+        if (row >= a.M) continue;
+        float* xr = a.x + (size_t)row * CP + 4 * lg;
+#pragma unroll
+        for (int o = 0; o < KK; ++o) {
+            const f32x4 v = acc[o][t] + ld4(a.b2 + 16 * o + 4 * lg);
+            st4(xr + 16 * o, ld4(xr + 16 * o) + v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block-cooperative variant for wide layers: the same register-resident chain per wave, but the NW waves of a
+// workgroup share each hidden tile's 2*KK KiB of weight fragments through LDS.  The fragments are DMA'd
+// global -> LDS with `global_load_lds_dwordx4` (lane-linear destination == fragment order, so no swizzle
+// and conflict-free ds_read_b128), double-buffered: tile t+1 streams in while tile t is on the MFMA.
+// L2 -> CU weight traffic drops NW-fold versus the wave-autonomous kernel, which is what wide layers need
+// (at C = 384 one pass over fc1+fc2 is 4.7 MB).
+// ------------------------------------------------------------------------------------------------
+template <int CP, int TM, int NW>
+__global__ __launch_bounds__(64 * NW) void mlp_fused_lds_kernel(MlpArgs a) {
+    constexpr int KK = CP / 16;
+    constexpr int CH = 2 * KK;                  // 1 KiB chunks per hidden tile
+    __shared__ f32x4 wbuf[2][CH * 64];
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wave = threadIdx.x >> 6;
+    const int m0 = (blockIdx.x * NW + wave) * (16 * TM);
+
+    auto issue = [&](int ht, int buf) {
+        const f32x4* src = a.wcf + (size_t)ht * CH * 64 + lane;
+        for (int c = wave; c < CH; c += NW)
+            __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(&wbuf[buf][c * 64]), 16, 0, 0);
+    };
+    issue(0, 0);
+
+    f32x4 xf[TM][KK];
+    float mean[TM], rstd[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int row = m0 + t * 16 + l15;
+        const float* xr = a.x + (size_t)row * CP + 4 * lg;
+        float s = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            xf[t][kk] = row < a.M ? ld4(xr + 16 * kk) : zero4();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) s += xf[t][kk][e];
+        }
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        mean[t] = s / (float)a.C;
+        float v = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) { const float d = xf[t][kk][e] - mean[t]; v += d * d; }
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        rstd[t] = 1.0f / sqrtf(v / (float)a.C + a.eps);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        const f32x4 g = ld4(a.gamma + 16 * kk + 4 * lg), b = ld4(a.beta + 16 * kk + 4 * lg);
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                xf[t][kk][e] = (16 * kk + 4 * lg + e < a.C) ? (xf[t][kk][e] - mean[t]) * rstd[t] * g[e] + b[e] : 0.f;
+    }
+
+    f32x4 acc[KK][TM];
+#pragma unroll
+    for (int o = 0; o < KK; ++o)
+#pragma unroll
+        for (int t = 0; t < TM; ++t) acc[o][t] = zero4();
+
+    for (int ht = 0; ht < a.HT; ++ht) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                        // tile ht is in LDS for every wave; nobody still reads the other buffer
+        if (ht + 1 < a.HT) issue(ht + 1, (ht + 1) & 1);
+        const f32x4* wb = &wbuf[ht & 1][lane];
+        f32x4 h[TM], h2[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) { h[t] = zero4(); h2[t] = zero4(); }
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const f32x4 w = wb[kk * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {
+                    if (TM == 1 && (r & 1)) h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xf[t][kk][r], h2[t], 0, 0, 0);
+                    else h[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xf[t][kk][r], h[t], 0, 0, 0);
+                }
+        }
+        const f32x4 bb = ld4(a.b1 + 16 * ht + 4 * lg);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            if (TM == 1) h[t] += h2[t];
+            h[t] += bb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[t][e] = gelu_erf(h[t][e]);
+        }
+#pragma unroll
+        for (int o = 0; o < KK; ++o) {
+            const f32x4 w = wb[(KK + o) * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+                    acc[o][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], h[t][r], acc[o][t], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int row = m0 + t * 16 + l15;
+        if (row >= a.M) continue;
+        float* xr = a.x + (size_t)row * CP + 4 * lg;
+#pragma unroll
+        for (int o = 0; o < KK; ++o) {
+            const f32x4 v = acc[o][t] + ld4(a.b2 + 16 * o + 4 * lg);
+            st4(xr + 16 * o, ld4(xr + 16 * o) + v);
+        }
+    }
+}
+
+}  // namespace escx

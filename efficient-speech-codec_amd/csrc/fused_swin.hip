@@ -1,0 +1,115 @@
+// Launchers for the fused (wave-autonomous, register-resident) Swin kernels.
+#include "fused_attn.h"
+#include "fused_mlp.h"
+#include "launchers.h"
+
+namespace escx {
+
+template <int CP, int TM>
+static void launch_mlp(const MlpArgs& a, hipStream_t s) {
+    const int waves = (a.M + 16 * TM - 1) / (16 * TM);
+    hipLaunchKernelGGL((mlp_fused_kernel<CP, TM>), dim3((waves + 3) / 4), dim3(256), 0, s, a);
+}
+
+template <int CP, int TM, int NW>
+static void launch_mlp_lds(const MlpArgs& a, hipStream_t s) {
+    const int rows = 16 * TM * NW;
+    hipLaunchKernelGGL((mlp_fused_lds_kernel<CP, TM, NW>), dim3((a.M + rows - 1) / rows), dim3(64 * NW), 0, s, a);
+}
+
+// variant: 0 = wave-autonomous; otherwise LDS-staged with (TM, NW) = 1:(1,4) 2:(1,6) 3:(1,8) 4:(2,4) 5:(2,8)
+template <int CP>
+static int launch_mlp_lds_variant(int variant, const MlpArgs& a, hipStream_t s) {
+    switch (variant) {
+        case 1: launch_mlp_lds<CP, 1, 4>(a, s); return 0;
+        case 2: launch_mlp_lds<CP, 1, 6>(a, s); return 0;
+        case 3: launch_mlp_lds<CP, 1, 8>(a, s); return 0;
+        case 4: if constexpr (CP <= 192) { launch_mlp_lds<CP, 2, 4>(a, s); return 0; } return -1;
+        case 5: if constexpr (CP <= 192) { launch_mlp_lds<CP, 2, 8>(a, s); return 0; } return -1;
+        default: return -1;
+    }
+}
+
+int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* w1f, const float* b1,
+              const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, hipStream_t s) {
+    MlpArgs a{x, gamma, beta, reinterpret_cast<const f32x4*>(w1f), b1, reinterpret_cast<const f32x4*>(w2f), b2,
+              reinterpret_cast<const f32x4*>(wcf), M, C, hiddenP / 16, 1e-5f};
+    if (variant > 0) {
+        switch (Cp) {
+            case 48: return launch_mlp_lds_variant<48>(variant, a, s);
+            case 80: return launch_mlp_lds_variant<80>(variant, a, s);
+            case 96: return launch_mlp_lds_variant<96>(variant, a, s);
+            case 144: return launch_mlp_lds_variant<144>(variant, a, s);
+            case 192: return launch_mlp_lds_variant<192>(variant, a, s);
+            case 384: return launch_mlp_lds_variant<384>(variant, a, s);
+            default: break;     // fall through to the wave-autonomous kernel
+        }
+    }
+    switch (Cp) {
+        case 16: launch_mlp<16, 4>(a, s); return 0;
+        case 32: launch_mlp<32, 4>(a, s); return 0;
+        case 48: launch_mlp<48, 4>(a, s); return 0;
+        case 64: launch_mlp<64, 4>(a, s); return 0;
+        case 80: launch_mlp<80, 4>(a, s); return 0;
+        case 96: launch_mlp<96, 2>(a, s); return 0;
+        case 112: launch_mlp<112, 2>(a, s); return 0;
+        case 128: launch_mlp<128, 2>(a, s); return 0;
+        case 144: launch_mlp<144, 2>(a, s); return 0;
+        case 160: launch_mlp<160, 2>(a, s); return 0;
+        case 192: launch_mlp<192, 2>(a, s); return 0;
+        case 256: launch_mlp<256, 1>(a, s); return 0;
+        case 288: launch_mlp<288, 1>(a, s); return 0;
+        case 384: launch_mlp<384, 1>(a, s); return 0;
+        default: return -1;
+    }
+}
+
+// ---- fused window attention --------------------------------------------------------------------
+template <int CP, int MODE, int NW>
+static void launch_attn(const AttnArgs& a, hipStream_t s) {
+    constexpr int UT = CP <= 96 ? 4 : (CP <= 192 ? 2 : 1);
+    constexpr int TMW = CP <= 96 ? 2 : 1;
+    const int per_block = TMW * NW;
+    hipLaunchKernelGGL((attn_fused_kernel<CP, MODE, UT, TMW, NW>), dim3((a.n_windows + per_block - 1) / per_block), dim3(64 * NW), 0, s, a);
+}
+
+template <int CP>
+static int launch_attn_cp(int mode, int nw, const AttnArgs& a, hipStream_t s) {
+    if (nw == 8) {
+        switch (mode) {
+            case 0: launch_attn<CP, 0, 8>(a, s); return 0;
+            case 1: launch_attn<CP, 1, 8>(a, s); return 0;
+            case 2: launch_attn<CP, 2, 8>(a, s); return 0;
+        }
+    } else {
+        switch (mode) {
+            case 0: launch_attn<CP, 0, 4>(a, s); return 0;
+            case 1: launch_attn<CP, 1, 4>(a, s); return 0;
+            case 2: launch_attn<CP, 2, 4>(a, s); return 0;
+        }
+    }
+    return -1;
+}
+
+int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_groups, const float* gamma, const float* beta,
+               const float* wf, const float* bqkv, const float* bias_tab, const float* bproj, const int* map, int slots, int tokens,
+               int n_windows, int nWh, int nWw, int shifted, float scale, int nw, hipStream_t s) {
+    AttnArgs a{src, dst, gamma, beta, reinterpret_cast<const f32x4*>(wf), bqkv, bias_tab, bproj, map, slots, tokens, n_windows,
+               nWh, nWw, shifted, C, n_groups, scale, 1e-5f};
+    switch (Cp) {
+        case 16: return launch_attn_cp<16>(mode, nw, a, s);
+        case 32: return launch_attn_cp<32>(mode, nw, a, s);
+        case 48: return launch_attn_cp<48>(mode, nw, a, s);
+        case 64: return launch_attn_cp<64>(mode, nw, a, s);
+        case 80: return launch_attn_cp<80>(mode, nw, a, s);
+        case 96: return launch_attn_cp<96>(mode, nw, a, s);
+        case 128: return launch_attn_cp<128>(mode, nw, a, s);
+        case 144: return launch_attn_cp<144>(mode, nw, a, s);
+        case 192: return launch_attn_cp<192>(mode, nw, a, s);
+        case 256: return launch_attn_cp<256>(mode, nw, a, s);
+        case 384: return launch_attn_cp<384>(mode, nw, a, s);
+        default: return -1;
+    }
+}
+
+}  // namespace escx

@@ -15,6 +15,15 @@ void gemm_residual(const float* A, int lda, int M, const float* W, int Np, int K
 void gemm_store(const float* A, int lda, int M, const float* W, int Np, int Kp, float* out, int ldo, const float* bias, hipStream_t s);
 void gemm_split(const float* A, int lda, int M, const float* W, int Np, int Kp, float* out, int H, int Wd, int C2p, hipStream_t s);
 
+// ---- fused register-resident Swin kernels (fused_swin.hip); return -1 when the width is not instantiated ----
+int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* w1f, const float* b1,
+              const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, hipStream_t s);
+
+// mode: 0 one head (<=16 dims) per tile, 1 two heads (<=8 dims) per tile, 2 one head (<=32 dims) over two tiles
+int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_groups, const float* gamma, const float* beta,
+               const float* wf, const float* bqkv, const float* bias_tab, const float* bproj, const int* map, int slots, int tokens,
+               int n_windows, int nWh, int nWw, int shifted, float scale, int nw, hipStream_t s);
+
 // ---- everything else that is a contraction (gemm_misc.hip) ----
 void gemm_frames(const float* wave, int B, int L, int T, int hop, int off, const float* W, int Np, int Kp, float* out, hipStream_t s);
 void gemm_patch(const float* spec, int B, int T, int in_dim, int Fp, int H, int Wd, int pf, int pt, const float* W, int Np, int Kp,
