@@ -1045,6 +1045,10 @@ extern "C" int escx_patch_deembed(escx_handle h, const float* tokens, int B, int
     return launch_ok("patch_deembed");
 }
 
+extern "C" int escx_test_math(const float* x, float* y, int64_t n, int which, void* stream) {
+    test_math(x, y, n, which, (hipStream_t)stream);
+    return launch_ok("test_math");
+}
 extern "C" int escx_codes_narrow(const int64_t* codes, int16_t* out, int64_t n, void* stream) {
     codes_narrow((const long long*)codes, (short*)out, n, (hipStream_t)stream);
     return launch_ok("codes_narrow");

@@ -56,7 +56,7 @@ __device__ __forceinline__ f32x4 window_softmax(f32x4 s, const float* bias_h, in
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     f32x4 p;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) p[r] = expf(s[r] - mx);
+    for (int r = 0; r < 4; ++r) p[r] = exp_fast(s[r] - mx);
     float den = (p[0] + p[1]) + (p[2] + p[3]);
     den += __shfl_xor(den, 16);
     den += __shfl_xor(den, 32);
@@ -182,13 +182,16 @@ __global__ __launch_bounds__(64 * NW) void attn_fused_kernel(AttnArgs a) {
     };
     auto proj_accumulate = [&](const f32x4* wt, const f32x4* o) {
 #pragma unroll
-        for (int to = 0; to < KK; ++to) {
+        for (int to = 0; to < KK; to += 2) {    // two output tiles per step: no back-to-back MFMAs on one accumulator
             const f32x4 w = wt[to * 64];
+            const f32x4 wn = (to + 1 < KK) ? wt[(to + 1) * 64] : zero4();
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int t = 0; t < TMW; ++t)
+                for (int t = 0; t < TMW; ++t) {
                     acc[to][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], o[t][r], acc[to][t], 0, 0, 0);
+                    if (to + 1 < KK) acc[to + 1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[r], o[t][r], acc[to + 1][t], 0, 0, 0);
+                }
         }
     };
 

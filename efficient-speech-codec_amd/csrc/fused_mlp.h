@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
             if (TM == 1) h[t] += h2[t];
             h[t] += bb;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h[t][e] = gelu_erf(h[t][e]);
+            for (int e = 0; e < 4; ++e) h[t][e] = gelu_bf(h[t][e]);
         }
 #pragma unroll
         for (int o = 0; o < KK; ++o) {
@@ -139,10 +139,11 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
 // L2 -> CU weight traffic drops NW-fold versus the wave-autonomous kernel, which is what wide layers need
 // (at C = 384 one pass over fc1+fc2 is 4.7 MB).
 // ------------------------------------------------------------------------------------------------
-template <int CP, int TM, int NW>
+template <int CP, int TM, int NW, int ABL = 0>      // ABL: timing-only ablation bits (never used by the product path)
 __global__ __launch_bounds__(64 * NW) void mlp_fused_lds_kernel(MlpArgs a) {
     constexpr int KK = CP / 16;
-    constexpr int CH = 2 * KK;                  // 1 KiB chunks per hidden tile
+    constexpr int CH = 2 * KK;                  // 1 KiB fragments per hidden tile: KK of fc1 then KK of fc2
+    constexpr int PD = 3;                       // LDS -> register prefetch distance (fragments)
     __shared__ f32x4 wbuf[2][CH * 64];
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -195,41 +196,70 @@ __global__ __launch_bounds__(64 * NW) void mlp_fused_lds_kernel(MlpArgs a) {
 #pragma unroll
         for (int t = 0; t < TM; ++t) acc[o][t] = zero4();
 
+    f32x4 bias_next = ld4(a.b1 + 4 * lg);      // fc1 bias of tile 0; later tiles are fetched one stage ahead
     for (int ht = 0; ht < a.HT; ++ht) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                        // tile ht is in LDS for every wave; nobody still reads the other buffer
-        if (ht + 1 < a.HT) issue(ht + 1, (ht + 1) & 1);
-        const f32x4* wb = &wbuf[ht & 1][lane];
+        if (!(ABL & 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                    // tile ht is in LDS for every wave; nobody still reads the other buffer
+        }
+        if (ht + 1 < a.HT && !(ABL & 32)) issue(ht + 1, (ht + 1) & 1);
+        const f32x4 bb = bias_next;
+        if (ht + 1 < a.HT) bias_next = ld4(a.b1 + 16 * (ht + 1) + 4 * lg);
+        const f32x4* wb = (ABL & 4) ? &wbuf[0][0] : &wbuf[ht & 1][lane];
+
+        // fragment ring: the LDS read of fragment f + PD is in flight while fragment f feeds the MFMAs
+        f32x4 ring[PD];
+#pragma unroll
+        for (int i = 0; i < PD; ++i) ring[i] = wb[i * 64];
         f32x4 h[TM], h2[TM];
 #pragma unroll
         for (int t = 0; t < TM; ++t) { h[t] = zero4(); h2[t] = zero4(); }
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            const f32x4 w = wb[kk * 64];
+        for (int f = 0; f < KK; ++f) {
+            const f32x4 w = ring[f % PD];
+            if (f + PD < CH) ring[f % PD] = wb[(f + PD) * 64];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int t = 0; t < TM; ++t) {
-                    if (TM == 1 && (r & 1)) h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xf[t][kk][r], h2[t], 0, 0, 0);
-                    else h[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xf[t][kk][r], h[t], 0, 0, 0);
+                    if (TM == 1 && (r & 1)) h2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xf[t][f][r], h2[t], 0, 0, 0);
+                    else h[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xf[t][f][r], h[t], 0, 0, 0);
                 }
         }
-        const f32x4 bb = ld4(a.b1 + 16 * ht + 4 * lg);
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             if (TM == 1) h[t] += h2[t];
             h[t] += bb;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h[t][e] = gelu_erf(h[t][e]);
+            for (int e = 0; e < 4; ++e) h[t][e] = (ABL & 1) ? h[t][e] * 0.5f : gelu_bf(h[t][e]);
         }
+        // fc2: two output tiles per step so that consecutive MFMAs never hit the same accumulator
 #pragma unroll
-        for (int o = 0; o < KK; ++o) {
-            const f32x4 w = wb[(KK + o) * 64];
+        for (int o = 0; o < KK; o += 2) {
+            const int f = KK + o;
+            const f32x4 w = ring[f % PD];
+            if (f + PD < CH) ring[f % PD] = wb[(f + PD) * 64];
+            f32x4 wn = zero4();
+            if (o + 1 < KK) {
+                wn = ring[(f + 1) % PD];
+                if (f + 1 + PD < CH) ring[(f + 1) % PD] = wb[(f + 1 + PD) * 64];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int t = 0; t < TM; ++t)
+                for (int t = 0; t < TM; ++t) {
                     acc[o][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], h[t][r], acc[o][t], 0, 0, 0);
+                    if (o + 1 < KK) acc[o + 1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[r], h[t][r], acc[o + 1][t], 0, 0, 0);
+                }
+        }
+        // Pin the software pipeline: hipcc otherwise sinks every ds_read to just before its first use and
+        // waits lgkmcnt(0) there, idling the matrix pipe for a full LDS round trip every 8 MFMAs.
+#pragma unroll
+        for (int i = 0; i < PD; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int f = 0; f < CH; ++f) {
+            if (f + PD < CH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM, 0);
         }
     }
 

@@ -30,10 +30,33 @@ static int launch_mlp_lds_variant(int variant, const MlpArgs& a, hipStream_t s) 
     }
 }
 
+template <int CP, int TM, int NW, int ABL>
+static void launch_mlp_abl(const MlpArgs& a, hipStream_t s) {
+    const int rows = 16 * TM * NW;
+    hipLaunchKernelGGL((mlp_fused_lds_kernel<CP, TM, NW, ABL>), dim3((a.M + rows - 1) / rows), dim3(64 * NW), 0, s, a);
+}
+
 int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* w1f, const float* b1,
               const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, hipStream_t s) {
     MlpArgs a{x, gamma, beta, reinterpret_cast<const f32x4*>(w1f), b1, reinterpret_cast<const f32x4*>(w2f), b2,
               reinterpret_cast<const f32x4*>(wcf), M, C, hiddenP / 16, 1e-5f};
+    if (variant >= 100) {      // timing-only ablations: variant = 100 + ABL bits
+        const int abl = variant - 100;
+        if (Cp == 192) {
+            switch (abl) {
+                case 0: launch_mlp_abl<192, 1, 4, 0>(a, s); return 0;
+                case 1: launch_mlp_abl<192, 1, 4, 1>(a, s); return 0;
+                case 2: launch_mlp_abl<192, 1, 4, 2>(a, s); return 0;
+                case 3: launch_mlp_abl<192, 1, 4, 3>(a, s); return 0;
+                case 4: launch_mlp_abl<192, 1, 4, 4>(a, s); return 0;
+                case 6: launch_mlp_abl<192, 1, 4, 6>(a, s); return 0;
+                case 7: launch_mlp_abl<192, 1, 4, 7>(a, s); return 0;
+                case 34: launch_mlp_abl<192, 1, 4, 34>(a, s); return 0;
+                case 39: launch_mlp_abl<192, 1, 4, 39>(a, s); return 0;
+            }
+        }
+        variant = 1;
+    }
     if (variant > 0) {
         switch (Cp) {
             case 48: return launch_mlp_lds_variant<48>(variant, a, s);

@@ -222,6 +222,36 @@ struct CodeGatherA {            // PVQ de-quantisation: A[(b,t)][g*dt + j] = cod
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// Branch-free fp32 erf, max error 1.1 ulp over the whole range (fitted and checked in fp64; tests/test_gpu_parity.py
+// re-checks it on the device).  libm's erff is a tree of data-dependent branches, which splits the fused MLP's
+// inner loop into basic blocks and stops the scheduler from hiding the VALU work under the MFMAs; this form is
+// ~25 straight-line VALU ops.   |x| <= 0.92: x + x*P6(x^2) ;  else: sign(x) * (1 - exp(Q8(min(|x|,4)))), Q8 ~ log(erfc).
+__device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float erf_bf(float x) {
+    const float t = fabsf(x), s = x * x;
+    float a = 8.404849359067157e-05f;
+    a = fmaf(a, s, -0.0008151340298354626f);
+    a = fmaf(a, s, 0.0052018375135958195f);
+    a = fmaf(a, s, -0.026859745383262634f);
+    a = fmaf(a, s, 0.11283702403306961f);
+    a = fmaf(a, s, -0.37612634897232056f);
+    a = fmaf(a, s, 0.12837916612625122f);
+    a = fmaf(a, x, x);
+    const float u = fminf(t, 4.0f);
+    float r = 1.612904043213348e-06f;
+    r = fmaf(r, u, -4.556713975034654e-05f);
+    r = fmaf(r, u, 0.0005925663863308728f);
+    r = fmaf(r, u, -0.004739245865494013f);
+    r = fmaf(r, u, 0.026361873373389244f);
+    r = fmaf(r, u, -0.10997311770915985f);
+    r = fmaf(r, u, -0.6319426894187927f);
+    r = fmaf(r, u, -1.130163311958313f);
+    r = fmaf(r, u, 0.00030238047474995255f);
+    const float b = copysignf(1.0f - exp_fast(r), x);
+    return t <= 0.92f ? a : b;
+}
+__device__ __forceinline__ float gelu_bf(float x) { return 0.5f * x * (1.0f + erf_bf(x * 0.70710678118654752440f)); }
+
 struct EpiStore {               // out[m][n] = v (+ bias[n])
     float* out; int ldo; const float* bias;
     __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {

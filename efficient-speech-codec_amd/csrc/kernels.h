@@ -305,6 +305,11 @@ __global__ void unpad_rows_kernel(const float* __restrict__ src, float* __restri
     const long long r = idx / C; const int c = (int)(idx - r * C);
     dst[idx] = src[r * Cp + c];
 }
+__global__ void test_math_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, int which) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    y[i] = which == 0 ? gelu_bf(x[i]) : (which == 1 ? erf_bf(x[i]) : (which == 2 ? exp_fast(x[i]) : gelu_erf(x[i])));
+}
 __global__ void codes_narrow_kernel(const long long* __restrict__ in, short* __restrict__ out, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (short)in[i];

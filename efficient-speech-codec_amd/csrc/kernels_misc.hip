@@ -68,6 +68,9 @@ void unpad_rows(const float* src, float* dst, long long rows, int C, int Cp, hip
     const long long n = rows * C;
     hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, C, Cp);
 }
+void test_math(const float* x, float* y, long long n, int which, hipStream_t s) {
+    hipLaunchKernelGGL(test_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n, which);
+}
 void codes_narrow(const long long* in, short* out, long long n, hipStream_t s) {
     hipLaunchKernelGGL(codes_narrow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
 }

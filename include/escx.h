@@ -131,6 +131,10 @@ int escx_profile_enable(escx_handle h, int enable);
  * [{"name":..., "calls":n, "ms":total, "flops":algorithmic, "bytes":algorithmic}, ...] valid until the next call. */
 const char* escx_profile_report(escx_handle h);
 
+/* Device math used inside the fused kernels, exposed for the accuracy tests: which = 0 gelu (branch-free erf),
+ * 1 erf (branch-free), 2 exp via v_exp_f32, 3 gelu via libm erff (the unfused epilogue). */
+int escx_test_math(const float* x_dev, float* y_dev, int64_t n, int which, void* stream);
+
 /* ---- code packing for transport (10-bit codes; all-gather payload) --------------------------- */
 int escx_codes_narrow(const int64_t* codes_dev, int16_t* out_dev, int64_t n, void* stream);
 int escx_codes_widen(const int16_t* in_dev, int64_t* codes_dev, int64_t n, void* stream);

@@ -193,6 +193,35 @@ def test_search_tie_break_and_degenerate_vectors(tiny):
     assert (got == got[..., :1]).all()
 
 
+def test_device_math_accuracy():
+    """The branch-free erf/GELU and the v_exp_f32 exponential used inside the fused kernels, against fp64."""
+    from scipy import special
+    lib = _native.load()
+    x = torch.cat([torch.linspace(-9, 9, 2_000_001), torch.linspace(-1.5, 1.5, 1_000_001), torch.tensor([0.0, -0.0, 1e-20, -1e-20, 30.0, -30.0])]).float()
+    xg = x.cuda(); yg = torch.empty_like(xg)
+    x64 = x.double().numpy()
+    _native.check(lib.escx_test_math(_ptr(xg), _ptr(yg), xg.numel(), 1, None))
+    erf_ref = special.erf(x64)
+    ulp = np.spacing(np.abs(erf_ref).astype(np.float32)).astype(np.float64)
+    err = np.abs(yg.cpu().double().numpy() - erf_ref) / np.maximum(ulp, 1e-45)
+    assert err[np.abs(x64) > 1e-10].max() < 2.0, f"erf max ulp error {err.max()}"
+    _native.check(lib.escx_test_math(_ptr(xg), _ptr(yg), xg.numel(), 0, None))
+    g_ref = 0.5 * x64 * (1.0 + erf_ref_scaled(x64))
+    g_torch = torch.nn.functional.gelu(x).double().numpy()          # what the reference computes on CPU
+    got = yg.cpu().double().numpy()
+    assert np.abs(got - g_ref).max() <= np.abs(g_torch - g_ref).max() * 1.5 + 1e-9
+    assert (np.abs(got - g_torch) <= 4e-7 * np.maximum(1.0, np.abs(x64))).all()     # within ~3 ulp of the reference's value
+    xe = torch.linspace(-104, 0, 1_000_001).float(); xeg = xe.cuda(); ye = torch.empty_like(xeg)
+    _native.check(lib.escx_test_math(_ptr(xeg), _ptr(ye), xeg.numel(), 2, None))
+    ref = np.exp(xe.double().numpy())
+    assert (np.abs(ye.cpu().double().numpy() - ref) <= 2e-7 * ref * np.maximum(1.0, np.abs(xe.double().numpy())) + 1e-38).all()
+
+
+def erf_ref_scaled(x64):
+    from scipy import special
+    return special.erf(x64 / np.sqrt(2.0))
+
+
 # ---------------------------------------------------------------- whole path vs golden ------------------------
 @pytest.mark.parametrize("name", ["tiny", "base", "large"])
 def test_codes_bit_exact_and_audio_vs_golden(name):
