@@ -60,21 +60,23 @@ def all_gather_codes(codes_local: torch.Tensor, group: Optional[dist.ProcessGrou
     mine = torch.tensor([small.shape[0]], dtype=torch.int64, device=small.device)
     dist.all_gather(sizes, mine, group=group)
     counts = [int(s.item()) for s in sizes]
+    # collectives move bytes: RCCL/gloo have no int16 type, so the int16 payload is viewed as uint8
     if len(set(counts)) == 1:
         out = torch.empty((world * counts[0],) + tuple(small.shape[1:]), dtype=torch.int16, device=small.device)
+        src8 = small.contiguous().view(torch.uint8)
         try:
-            dist.all_gather_into_tensor(out, small.contiguous(), group=group)
-        except (RuntimeError, NotImplementedError):        # gloo builds without the fused form
-            parts = [torch.empty_like(small) for _ in range(world)]
-            dist.all_gather(parts, small.contiguous(), group=group)
-            out = torch.cat(parts, dim=0)
+            dist.all_gather_into_tensor(out.view(torch.uint8), src8, group=group)
+        except (RuntimeError, NotImplementedError):        # backends without the fused form
+            parts = [torch.empty_like(src8) for _ in range(world)]
+            dist.all_gather(parts, src8, group=group)
+            out = torch.cat(parts, dim=0).view(torch.int16)
         return widen_codes(out)
     mx = max(counts)
     pad = torch.zeros((mx,) + tuple(small.shape[1:]), dtype=torch.int16, device=small.device)
     pad[: small.shape[0]] = small
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
-    return widen_codes(torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0))
+    parts = [torch.empty_like(pad.view(torch.uint8)) for _ in range(world)]
+    dist.all_gather(parts, pad.view(torch.uint8), group=group)
+    return widen_codes(torch.cat([p.view(torch.int16)[:c] for p, c in zip(parts, counts)], dim=0))
 
 
 def encode_sharded(model, x_local: torch.Tensor, num_streams: int = 6, group: Optional[dist.ProcessGroup] = None):

@@ -1,0 +1,76 @@
+"""N>1 path on CPU: two gloo ranks shard a batch, all-gather their codes (int16 on the wire) and must reproduce the
+single-process result exactly.  The per-rank 'encoder' here is the oracle (test infrastructure) -- what is under test
+is esc.distributed: shard bounds, narrowing/widening, equal and ragged all-gathers, rank order."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, ragged, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "efficient-speech-codec_amd"))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import json
+    from conftest import load_golden, synth_state
+    from esc import synth
+    from esc.distributed import all_gather_codes, shard_bounds
+    from oracle.esc_oracle import EscOracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    g = load_golden("tiny")
+    orc = EscOracle(json.loads(str(g["config_json"])), synth_state("tiny"))
+    pcm = np.stack([synth.noise_clip_int16(f"dist-{i}", 1280) for i in range(total)])
+    x = torch.from_numpy(synth.pcm_to_float(pcm))
+    if ragged:
+        lo, hi = shard_bounds(total, world, rank)
+    else:
+        per = total // world
+        lo, hi = rank * per, (rank + 1) * per
+    local, _ = orc.encode(x[lo:hi], 3)
+    full = all_gather_codes(local)
+    if rank == 0:
+        ref, _ = orc.encode(x[: (total if ragged else world * (total // world))], 3)
+        np.save(os.path.join(out_dir, f"ok_{int(ragged)}.npy"), np.array([int(torch.equal(full, ref)), full.shape[0], int(full.dtype == torch.int64)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ragged,total", [(False, 6), (True, 5)])
+def test_two_rank_all_gather_matches_single_process(tmp_path, ragged, total):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, total, ragged, str(tmp_path)), nprocs=2, join=True)
+    ok = np.load(tmp_path / f"ok_{int(ragged)}.npy")
+    assert ok[0] == 1 and ok[1] == (total if ragged else 2 * (total // 2)) and ok[2] == 1
+
+
+def test_shard_bounds_and_code_narrowing():
+    sys.path.insert(0, os.path.join(ROOT, "efficient-speech-codec_amd"))
+    from esc.distributed import narrow_codes, shard_bounds, widen_codes
+    for total in (1, 7, 36, 288):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    codes = torch.randint(0, 1024, (4, 6, 3, 150))
+    assert narrow_codes(codes).dtype == torch.int16
+    assert torch.equal(widen_codes(narrow_codes(codes)), codes)

@@ -314,3 +314,24 @@ def test_decode_partial_streams_and_errors(base):
         assert rms(w.numpy(), ref.numpy()) <= AUDIO_TOL
     with pytest.raises(AssertionError, match="multiple of overlap"):        # quantization.py:407 (T=302 -> W=151)
         model.encode(torch.zeros(1, 24080, device="cuda"), 6)
+
+
+def test_fused_and_unfused_pipelines_agree(base, monkeypatch):
+    """The register-resident fused Swin kernels against the plain GEMM pipeline (ESCX_NO_FUSED=1): same codes, audio
+    within fp32 re-association noise.  Also checks the int16 transport kernels."""
+    import os
+    from esc.models import make_model
+    from conftest import synth_state
+    from esc.distributed import narrow_codes, widen_codes
+    model, orc, g, cfg = base
+    x = torch.from_numpy(synth.pcm_to_float(g["pcm"])).cuda()
+    codes, shape = model.encode(x, 6)
+    wave = model.decode(codes, shape)
+    monkeypatch.setenv("ESCX_NO_FUSED", "1")
+    plain = make_model(cfg); plain.load_state_dict(synth_state("base")); plain = plain.cuda().eval()
+    c2, s2 = plain.encode(x, 6)
+    w2 = plain.decode(c2, s2)
+    monkeypatch.delenv("ESCX_NO_FUSED")
+    assert torch.equal(codes, c2), code_report(codes.cpu().numpy(), c2.cpu().numpy(), g["margins"])
+    assert rms(wave.cpu().numpy(), w2.cpu().numpy()) < 2e-6
+    assert narrow_codes(codes).dtype == torch.int16 and torch.equal(widen_codes(narrow_codes(codes)), codes)
