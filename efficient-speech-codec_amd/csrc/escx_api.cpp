@@ -124,6 +124,7 @@ extern "C" int escx_create(const escx_config* cfg, int device, escx_handle* out)
     h->cfg = *cfg; h->device = device;
     { const char* e = getenv("ESCX_NO_FUSED"); h->use_fused = !(e && e[0] == '1'); }
     { const char* e = getenv("ESCX_MLP_VARIANT"); if (e && e[0]) h->mlp_variant = atoi(e); }
+    { const char* e = getenv("ESCX_DEEMBED_TWO_STAGE"); h->deembed_two_stage = (e && e[0] == '1'); }
     { const char* e = getenv("ESCX_ATTN_NW"); if (e && e[0]) h->attn_nw = atoi(e); }
     { const char* e = getenv("ESCX_NO_FUSED_ATTN"); h->use_fused_attn = !(e && e[0] == '1'); }
     int rc = build_geometry(h);
@@ -360,6 +361,51 @@ extern "C" int escx_finalize_params(escx_handle h) {
             for (int ci = 0; ci < C0; ++ci) for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw)
                 pk.host[ow + (size_t)oc * K2 + (size_t)(kw * 3 + kh) * C0p + ci] = w2->data[(((size_t)oc * C0 + ci) * 3 + kh) * 3 + kw];
         }
+    }
+
+    // ---- composed de-embedding: conv3x3 o pixel_shuffle o conv5x5 has no non-linearity in between (scale.py:73-81), so it is ONE
+    //      linear map from a 7x7 coarse neighbourhood (x C0) to the in_dim*pf*pt fine outputs of a coarse pixel: 11x fewer FLOPs
+    //      than the two convolutions (the 270-channel expansion collapses).  Folded in fp64.  The 3x3 zero-pads the FINE map, so
+    //      coarse pixels on the first/last row/column use variants that drop the out-of-range fine neighbours.
+    {
+        const int C0 = h->C0, C0p = h->C0p, Q = h->Q, pf = c.patch_f, pt = c.patch_t, NO = c.in_dim * Q;
+        const Param* w1 = &h->params["decoder.patch_deembed.de_proj1.weight"]; const Param* b1 = &h->params["decoder.patch_deembed.de_proj1.bias"];
+        const Param* w2 = &h->params["decoder.patch_deembed.de_proj2.weight"]; const Param* b2 = &h->params["decoder.patch_deembed.de_proj2.bias"];
+        const size_t Kc = (size_t)49 * C0;
+        std::vector<double> wc((size_t)16 * NO * Kc, 0.0), bc((size_t)16 * NO, 0.0);
+        auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+        for (int eh = 0; eh < 4; ++eh) for (int ew = 0; ew < 4; ++ew) {
+            const int v = 4 * eh + ew;
+            for (int co = 0; co < c.in_dim; ++co) for (int s1 = 0; s1 < pf; ++s1) for (int s2 = 0; s2 < pt; ++s2) {
+                const int n = co * Q + s1 * pt + s2;
+                double* wrow = wc.data() + ((size_t)v * NO + n) * Kc;
+                bc[(size_t)v * NO + n] = b2->data[co];
+                for (int a = 0; a < 3; ++a) for (int bq = 0; bq < 3; ++bq) {
+                    const int dh0 = fdiv(s1 + a - 1, pf), s1n = s1 + a - 1 - dh0 * pf;
+                    const int dw0 = fdiv(s2 + bq - 1, pt), s2n = s2 + bq - 1 - dw0 * pt;
+                    if ((dh0 < 0 && (eh & 1)) || (dh0 > 0 && (eh & 2)) || (dw0 < 0 && (ew & 1)) || (dw0 > 0 && (ew & 2))) continue;   // fine neighbour outside
+                    const int qn = s1n * pt + s2n;
+                    for (int cc = 0; cc < C0; ++cc) {
+                        const double w2v = w2->data[(((size_t)co * C0 + cc) * 3 + a) * 3 + bq];
+                        const size_t orow = (size_t)qn * C0 + cc;
+                        bc[(size_t)v * NO + n] += w2v * b1->data[orow];
+                        for (int ci = 0; ci < C0; ++ci) for (int kh = 0; kh < 5; ++kh) for (int kw = 0; kw < 5; ++kw) {
+                            const int dh = dh0 + kh - 2, dw = dw0 + kw - 2;
+                            wrow[(size_t)((dh + 3) * 7 + (dw + 3)) * C0 + ci] += w2v * w1->data[((orow * C0 + ci) * 5 + kh) * 5 + kw];
+                        }
+                    }
+                }
+            }
+        }
+        size_t o = slot(&h->dcc_w, (size_t)16 * 49 * C0p);
+        for (int n = 0; n < NO; ++n) for (int tap = 0; tap < 49; ++tap) for (int ci = 0; ci < C0; ++ci)
+            pk.host[o + (size_t)n * 49 * C0p + (size_t)tap * C0p + ci] = (float)wc[(size_t)n * Kc + (size_t)tap * C0 + ci];
+        o = slot(&h->dcc_b, 16);
+        for (int n = 0; n < NO; ++n) pk.host[o + n] = (float)bc[n];
+        o = slot(&h->dcv_w, (size_t)16 * NO * Kc);
+        for (size_t i = 0; i < (size_t)16 * NO * Kc; ++i) pk.host[o + i] = (float)wc[i];
+        o = slot(&h->dcv_b, (size_t)16 * NO);
+        for (size_t i = 0; i < (size_t)16 * NO; ++i) pk.host[o + i] = (float)bc[i];
     }
 
     // ---- windowed DFT / inverse DFT matrices (base.py:22-47; torch.stft / torch.istft semantics) ----
@@ -805,6 +851,15 @@ static int run_pvq_decode(escx_handle_s* h, const Quant& q, const long long* cod
 static int run_deembed(escx_handle_s* h, const float* tok, int B, int W, float* rspec, hipStream_t st) {   // scale.py:73-81
     const escx_config& c = h->cfg;
     const int H0 = c.in_freq / c.patch_f;
+    if (!h->deembed_two_stage && c.in_dim * h->Q <= 16) {
+        const double tk = (double)B * H0 * W;
+        PROF("deembed_composed7x7", 2.0 * tk * 49 * h->C0 * c.in_dim * h->Q, (tk * h->C0 + tk * c.in_dim * h->Q) * 4,
+             gemm_deembed_composed(tok, B, H0, W, h->C0p, h->dcc_w, rspec, h->dcc_b, c.patch_f, c.patch_t, c.in_dim, h->Fp, st));
+        int brc = 0;
+        PROF("deembed_border", 0, 0,
+             brc = deembed_border(tok, h->dcv_w, h->dcv_b, rspec, B, H0, W, h->C0, h->C0p, c.patch_f, c.patch_t, c.in_dim, h->Fp, st));
+        if (brc == 0) return launch_ok("patch_deembed");
+    }
     const double toks = (double)B * H0 * W, pix = toks * h->Q;
     PROF("deembed_conv5x5", 2.0 * toks * 25 * h->C0 * h->C0 * h->Q, (toks * h->C0 + pix * h->C0) * 4,
          gemm_conv_deembed1(tok, B, H0, W, h->C0p, h->dc1_w, h->Q * h->C0p, h->deemb, h->dc1_b, c.patch_f, c.patch_t, st));

@@ -81,6 +81,8 @@ struct escx_handle_s {
     float *pe_w = nullptr, *pe_b = nullptr, *pe_g = nullptr, *pe_beta = nullptr;
     float *dc1_w = nullptr, *dc1_b = nullptr, *dc2_w = nullptr, *dc2_b = nullptr;
     float *dft_w = nullptr, *idft_w = nullptr, *win2 = nullptr;
+    float *dcc_w = nullptr, *dcc_b = nullptr, *dcv_w = nullptr, *dcv_b = nullptr;   // composed de-embedding: interior GEMM weights, border variants
+    bool deembed_two_stage = false;  // ESCX_DEEMBED_TWO_STAGE=1: run conv5x5 and conv3x3 separately (A/B, fallback)
 
     // workspace
     escx::Arena ws;

@@ -331,6 +331,21 @@ struct EpiSpec {                // conv3x3 -> frame-major spectrum: rows m = (b,
     }
 };
 
+struct EpiDeembedC {            // composed de-embedding: n = (cout, s1, s2) -> frame-major spectrum [(b, pt*w+s2)][cout*Fp + pf*h+s1]
+    float* out; const float* bias; int H, W, pf, pt, in_dim, Fp;
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        const int b = m / (H * W); const int r0 = m - b * H * W; const int h = r0 / W, w = r0 - h * W;
+        const int Q = pf * pt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nn = n + r;
+            if (nn >= in_dim * Q) continue;
+            const int co = nn / Q, q = nn - co * Q, s1 = q / pt, s2 = q - s1 * pt;
+            out[((size_t)(b * (pt * W) + pt * w + s2) * in_dim + co) * Fp + pf * h + s1] = v[r] + bias[nn];
+        }
+    }
+};
+
 struct EpiPvqAdd {              // un-frame + post_fuse: out[(b,h,ov*t+o)][c] = dec[...] + v   (csrvq.py:19-21)
     float* out; const float* dec; int Hq, W, Cp, Tq, ov;
     __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {

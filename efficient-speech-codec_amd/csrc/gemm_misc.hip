@@ -30,6 +30,15 @@ void gemm_conv_spec(const float* x, int B, int T, int F, int Cp, const float* W,
     launch_gemm<64>(ld, W, B * T * F, 16, 9 * Cp, EpiSpec{out, bias, T, F, Fp, in_dim}, s, 1, pick_bk(Cp));
 }
 
+void gemm_deembed_composed(const float* x, int B, int H, int Wd, int Cp, const float* W, float* out, const float* bias, int pf, int pt,
+                           int in_dim, int Fp, hipStream_t s) {
+    ConvA ld{x, H, Wd, Cp, 7, 7, B * H * Wd};
+    const int M = B * H * Wd;
+    EpiDeembedC ep{out, bias, H, Wd, pf, pt, in_dim, Fp};
+    if (M >= 32768) launch_gemm<128>(ld, W, M, 16, 49 * Cp, ep, s, 1, pick_bk(Cp));
+    else launch_gemm<64>(ld, W, M, 16, 49 * Cp, ep, s, 1, pick_bk(Cp));
+}
+
 int pvq_down_splits(int M, int Kp, int Cp) {
     const int BK = pick_bk(Cp);
     const int kIters = Kp / BK;

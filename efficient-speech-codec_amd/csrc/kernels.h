@@ -292,6 +292,54 @@ __global__ void istft_ola_kernel(const float* __restrict__ frames, const float* 
     wave[idx] = acc / env;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Border pixels of the composed de-embedding.  The 3x3 convolution zero-pads the FINE (pixel-shuffled) map, so
+// outputs on the first/last fine row/column must drop the neighbours that fall outside; they use a variant of the
+// composed 7x7 weights (escx_api.cpp: compose_deembed).  One wave per border coarse pixel, K split over lanes.
+//   wv: [16 variants][NO][49][C] unpadded, bv: [16][NO]; variant = 4*eh + ew, e = 1 first, 2 last, 3 both.
+// ------------------------------------------------------------------------------------------------
+template <int NO>
+__global__ __launch_bounds__(256) void deembed_border_kernel(const float* __restrict__ x, const float* __restrict__ wv,
+                                                             const float* __restrict__ bv, float* __restrict__ out, int B, int H, int W,
+                                                             int C, int Cp, int pf, int pt, int in_dim, int Fp) {
+    const int per_clip = 2 * W + 2 * (H > 2 ? H - 2 : 0);          // rows 0 and H-1 in full, then the two side columns
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B * per_clip) return;
+    const int b = wave / per_clip; int i = wave - b * per_clip;
+    int h, w;
+    if (i < W) { h = 0; w = i; }
+    else if (i < 2 * W) { h = H - 1; w = i - W; }
+    else { i -= 2 * W; h = 1 + (i >> 1); w = (i & 1) ? W - 1 : 0; }
+    if (H == 1 && i >= W && i < 2 * W) return;                       // the single row was already handled
+    if (W == 1 && i >= 2 * W && (i & 1)) return;
+    const int eh = (h == 0 ? 1 : 0) | (h == H - 1 ? 2 : 0), ew = (w == 0 ? 1 : 0) | (w == W - 1 ? 2 : 0);
+    const int K = 49 * C;
+    const float* wvar = wv + (size_t)(4 * eh + ew) * NO * K;
+    float acc[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) acc[o] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const int tap = k / C, ci = k - tap * C;
+        const int hh = h + tap / 7 - 3, ww = w + tap % 7 - 3;
+        if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+        const float xv = x[((size_t)(b * H + hh) * W + ww) * Cp + ci];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) acc[o] = fmaf(wvar[(size_t)o * K + k], xv, acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) acc[o] += __shfl_xor(acc[o], sft);
+    }
+    if (lane == 0) {
+        const int Q = pf * pt;
+        for (int o = 0; o < NO; ++o) {
+            const int co = o / Q, q = o - co * Q, s1 = q / pt, s2 = q - s1 * pt;
+            out[((size_t)(b * (pt * W) + pt * w + s2) * in_dim + co) * Fp + pf * h + s1] = acc[o] + bv[(4 * eh + ew) * NO + o];
+        }
+    }
+}
+
 // layout converters between reference (unpadded) rows and internal padded rows
 __global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long long rows, int C, int Cp) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;

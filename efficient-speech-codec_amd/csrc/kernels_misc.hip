@@ -68,6 +68,20 @@ void unpad_rows(const float* src, float* dst, long long rows, int C, int Cp, hip
     const long long n = rows * C;
     hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, C, Cp);
 }
+int deembed_border(const float* x, const float* wv, const float* bv, float* out, int B, int H, int W, int C, int Cp, int pf, int pt,
+                   int in_dim, int Fp, hipStream_t s) {
+    const int per_clip = 2 * W + 2 * (H > 2 ? H - 2 : 0);
+    const long long waves = (long long)B * per_clip;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    const int NO = in_dim * pf * pt;
+    if (NO == 12) hipLaunchKernelGGL((deembed_border_kernel<12>), dim3(grid), dim3(256), 0, s, x, wv, bv, out, B, H, W, C, Cp, pf, pt, in_dim, Fp);
+    else if (NO == 8) hipLaunchKernelGGL((deembed_border_kernel<8>), dim3(grid), dim3(256), 0, s, x, wv, bv, out, B, H, W, C, Cp, pf, pt, in_dim, Fp);
+    else if (NO == 6) hipLaunchKernelGGL((deembed_border_kernel<6>), dim3(grid), dim3(256), 0, s, x, wv, bv, out, B, H, W, C, Cp, pf, pt, in_dim, Fp);
+    else if (NO == 4) hipLaunchKernelGGL((deembed_border_kernel<4>), dim3(grid), dim3(256), 0, s, x, wv, bv, out, B, H, W, C, Cp, pf, pt, in_dim, Fp);
+    else return -1;
+    return 0;
+}
+
 void test_math(const float* x, float* y, long long n, int which, hipStream_t s) {
     hipLaunchKernelGGL(test_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n, which);
 }

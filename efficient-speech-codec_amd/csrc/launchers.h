@@ -32,6 +32,11 @@ void gemm_conv_deembed1(const float* x, int B, int H, int Wd, int Cp, const floa
                         int pf, int pt, hipStream_t s);
 void gemm_conv_spec(const float* x, int B, int T, int F, int Cp, const float* W, float* out, const float* bias, int Fp, int in_dim,
                     hipStream_t s);
+// composed de-embedding (conv3x3 o pixel-shuffle o conv5x5 folded into one 7x7 convolution with in_dim*pf*pt outputs)
+void gemm_deembed_composed(const float* x, int B, int H, int Wd, int Cp, const float* W, float* out, const float* bias, int pf, int pt,
+                           int in_dim, int Fp, hipStream_t s);
+int deembed_border(const float* x, const float* wv, const float* bv, float* out, int B, int H, int W, int C, int Cp, int pf, int pt,
+                   int in_dim, int Fp, hipStream_t s);
 void gemm_pvq_down(const float* enc, const float* dec, int B, int Hq, int Wd, int Cp, int ov, const float* W, int Np, int Kp,
                    float* zpart, int splits, hipStream_t s);
 int pvq_down_splits(int M, int Kp, int Cp);
