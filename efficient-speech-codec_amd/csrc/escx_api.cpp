@@ -315,6 +315,13 @@ extern "C" int escx_finalize_params(escx_handle h) {
                 pk.host[og + s * Cp + cc] = nw->data[s * C + cc]; pk.host[ob + s * Cp + cc] = nb->data[s * C + cc];
                 for (int r = 0; r < L.Cout; ++r) pk.host[ow + (size_t)r * 2 * Cp + s * Cp + cc] = dw->data[(size_t)r * 2 * C + s * C + cc];
             }
+            {
+                const int Cout = L.Cout;
+                size_t of = slot(&L.sub_wf, (size_t)L.CoutP * 2 * Cp);
+                pack_frag(pk.host.data() + of, L.CoutP / 16, 2 * Cp / 16, [&](int n, int k) {
+                    const int s2 = k / Cp, cc = k - s2 * Cp;
+                    return (n < Cout && cc < C) ? dw->data[(size_t)n * 2 * C + s2 * C + cc] : 0.f; });
+            }
         } else if (L.scale == 2) {   // PatchSplit: up.weight [2*Cout][C] -> [2*CoutP][Cp]
             GETP(nw, L.prefix + "subsample.norm.weight", C); GETP(nb, L.prefix + "subsample.norm.bias", C);
             GETP(uw, L.prefix + "subsample.up.weight", 2 * L.Cout, C);
@@ -324,6 +331,13 @@ extern "C" int escx_finalize_params(escx_handle h) {
             for (int s = 0; s < 2; ++s) for (int r = 0; r < L.Cout; ++r)
                 std::copy(uw->data.begin() + (size_t)(s * L.Cout + r) * C, uw->data.begin() + (size_t)(s * L.Cout + r + 1) * C,
                           pk.host.begin() + ow + (size_t)(s * L.CoutP + r) * Cp);
+            {
+                const int Cout = L.Cout, CoutP = L.CoutP;
+                size_t of = slot(&L.sub_wf, (size_t)2 * CoutP * Cp);
+                pack_frag(pk.host.data() + of, 2 * CoutP / 16, Cp / 16, [&](int n, int k) {
+                    const int s2 = n / CoutP, r = n - s2 * CoutP;
+                    return (r < Cout && k < C) ? uw->data[(size_t)(s2 * Cout + r) * C + k] : 0.f; });
+            }
         }
     }
 
@@ -777,16 +791,28 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         const int H2 = (H + 1) / 2;
         const int* map;
         if ((rc = get_map(h, H, W, -1, &map))) return rc;
+        int mrc = -1;
+        if (h->use_fused)
+            PROF("merge_fused", 2.0 * B * H2 * W * 2 * L.C * L.Cout, ((double)M * L.C + (double)B * H2 * W * L.Cout) * 4,
+                 mrc = rowgemm_fused(2, cur, y, L.sub_g, L.sub_b, L.sub_wf, map, B * H2 * W, H2 * W, tokens, L.C, L.Cp, L.CoutP, 0, 0, 0, 0, st));
+        if (mrc != 0) {
         PROF("merge_ln", 0, 2.0 * M * L.C * 4,
              ln_rows(2, cur, h->xn, L.sub_g, L.sub_b, map, H2 * W, tokens, B * H2 * W, L.C, L.Cp, st));
         PROF("merge_gemm", 2.0 * B * H2 * W * 2 * L.C * L.Cout, (double)B * H2 * W * (2 * L.C + L.Cout) * 4,
              gemm_store(h->xn, 2 * L.Cp, B * H2 * W, L.sub_w, L.CoutP, 2 * L.Cp, y, L.CoutP, nullptr, st));
+        }
         *Hout = H2;
     } else if (L.scale == 2) {
+        int src2 = -1;
+        if (h->use_fused)
+            PROF("split_fused", 2.0 * M * L.C * 2 * L.Cout, (double)M * (L.C + 2 * L.Cout) * 4,
+                 src2 = rowgemm_fused(1, cur, y, L.sub_g, L.sub_b, L.sub_wf, nullptr, M, tokens, tokens, L.C, L.Cp, 2 * L.CoutP, 1, H, W, L.CoutP, st));
+        if (src2 != 0) {
         PROF("split_ln", 0, 2.0 * M * L.C * 4,
              ln_rows(0, cur, h->xn, L.sub_g, L.sub_b, nullptr, tokens, tokens, M, L.C, L.Cp, st));
         PROF("split_gemm", 2.0 * M * L.C * 2 * L.Cout, (double)M * (L.C + 2 * L.Cout) * 4,
              gemm_split(h->xn, L.Cp, M, L.sub_w, 2 * L.CoutP, L.Cp, y, H, W, L.CoutP, st));
+        }
         *Hout = 2 * H;
     } else {
         *Hout = H;

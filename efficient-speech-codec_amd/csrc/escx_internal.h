@@ -47,6 +47,7 @@ struct Layer {                       // one TransformerLayer (attention.py:9-91)
     int Cout, CoutP;
     std::vector<BlockW> blocks;
     float *sub_g = nullptr, *sub_b = nullptr, *sub_w = nullptr;
+    float *sub_wf = nullptr;         // scale-change weights in fragment order (fused LN + linear)
 };
 
 struct Quant {                       // one ProductVectorQuantize (quantization.py:7-136)

@@ -1,6 +1,7 @@
 // Launchers for the fused (wave-autonomous, register-resident) Swin kernels.
 #include "fused_attn.h"
 #include "fused_mlp.h"
+#include "fused_rowgemm.h"
 #include "launchers.h"
 
 namespace escx {
@@ -83,6 +84,45 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
         case 256: launch_mlp<256, 1>(a, s); return 0;
         case 288: launch_mlp<288, 1>(a, s); return 0;
         case 384: launch_mlp<384, 1>(a, s); return 0;
+        default: return -1;
+    }
+}
+
+// ---- fused LN + linear for PatchMerge / PatchSplit ----
+template <int KP, int SEGS>
+static void launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
+    constexpr int KK = KP / 16;
+    constexpr int UT = KK <= 6 ? 4 : (KK <= 12 ? 2 : 1);
+    constexpr int TM = KP <= 192 ? 2 : 1;
+    constexpr int NW = 4;
+    const int rows = 16 * TM * NW;
+    hipLaunchKernelGGL((rowgemm_fused_kernel<KP, SEGS, TM, NW, UT>), dim3((a.M + rows - 1) / rows), dim3(64 * NW), 0, s, a);
+}
+
+int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, const float* beta, const float* wf, const int* map, int M,
+                  int rows_per_clip, int src_rows_per_clip, int C, int Cp, int Np, int split, int H, int W, int C2p, hipStream_t s) {
+    RowGemmArgs a{x, out, gamma, beta, reinterpret_cast<const f32x4*>(wf), map, M, rows_per_clip, src_rows_per_clip, C, Cp, Np / 16,
+                  split, H, W, C2p, 1e-5f};
+    const int KP = segs * Cp;
+    if (segs == 1) {
+        switch (KP) {
+            case 16: launch_rowgemm<16, 1>(a, s); return 0;
+            case 48: launch_rowgemm<48, 1>(a, s); return 0;
+            case 80: launch_rowgemm<80, 1>(a, s); return 0;
+            case 96: launch_rowgemm<96, 1>(a, s); return 0;
+            case 144: launch_rowgemm<144, 1>(a, s); return 0;
+            case 192: launch_rowgemm<192, 1>(a, s); return 0;
+            case 384: launch_rowgemm<384, 1>(a, s); return 0;
+            default: return -1;
+        }
+    }
+    switch (KP) {
+        case 32: launch_rowgemm<32, 2>(a, s); return 0;
+        case 96: launch_rowgemm<96, 2>(a, s); return 0;
+        case 160: launch_rowgemm<160, 2>(a, s); return 0;
+        case 192: launch_rowgemm<192, 2>(a, s); return 0;
+        case 288: launch_rowgemm<288, 2>(a, s); return 0;
+        case 384: launch_rowgemm<384, 2>(a, s); return 0;
         default: return -1;
     }
 }
