@@ -109,8 +109,11 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU implementation")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("ESCX_BENCH_FORCE_DIST") == "1"     # the latter: exercise RCCL with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)
 
     from esc.distributed import all_gather_codes
@@ -121,12 +124,12 @@ def main():
 
     def step():
         codes, shape = model.encode(x, NUM_STREAMS)
-        allc = all_gather_codes(codes) if world > 1 else codes
+        allc = all_gather_codes(codes, force=use_dist) if use_dist else codes
         wave = model.decode(codes, shape)
         return allc, wave
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -138,7 +141,7 @@ def main():
         allc, wave = step()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -205,7 +208,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

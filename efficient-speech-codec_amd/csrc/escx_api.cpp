@@ -124,6 +124,7 @@ extern "C" int escx_create(const escx_config* cfg, int device, escx_handle* out)
     h->cfg = *cfg; h->device = device;
     { const char* e = getenv("ESCX_NO_FUSED"); h->use_fused = !(e && e[0] == '1'); }
     { const char* e = getenv("ESCX_MLP_VARIANT"); if (e && e[0]) h->mlp_variant = atoi(e); }
+    { const char* e = getenv("ESCX_STREAMS"); if (e && e[0]) h->parts = std::min(std::max(atoi(e), 1), (int)escx_handle_s::MAX_PARTS); }
     { const char* e = getenv("ESCX_DEEMBED_TWO_STAGE"); h->deembed_two_stage = (e && e[0] == '1'); }
     { const char* e = getenv("ESCX_ATTN_NW"); if (e && e[0]) h->attn_nw = atoi(e); }
     { const char* e = getenv("ESCX_NO_FUSED_ATTN"); h->use_fused_attn = !(e && e[0] == '1'); }
@@ -137,7 +138,12 @@ extern "C" void escx_destroy(escx_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->wts.base) (void)hipFree(h->wts.base);
-    if (h->ws.base) (void)hipFree(h->ws.base);
+    for (auto& S : h->sets) if (S.ws.base) (void)hipFree(S.ws.base);
+    for (int i = 0; i < escx_handle_s::MAX_PARTS; ++i) {
+        if (h->sx[i]) (void)hipStreamDestroy(h->sx[i]);
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (auto& kv : h->maps) (void)hipFree(kv.second);
     delete h;
 }
@@ -554,14 +560,29 @@ static int get_map(escx_handle_s* h, int H, int W, int shift, const int** out) {
     return 0;
 }
 
-extern "C" int64_t escx_workspace_bytes(escx_handle h) { return h ? (int64_t)h->ws.cap : 0; }
-
-static bool ws_fits(escx_handle_s* h, int B, int T) {
-    return h->ws.base && h->shp.B >= B && h->shp.W == T / h->cfg.patch_t && h->shp.T >= T;
+extern "C" int64_t escx_workspace_bytes(escx_handle h) {
+    int64_t t = 0;
+    if (h) for (auto& S : h->sets) t += (int64_t)S.ws.cap;
+    return t;
 }
 
-static int reserve_frames(escx_handle_s* h, int B, int T) {
+static void use_set(escx_handle_s* h, int i) { static_cast<WsFields&>(*h) = h->sets[i]; }
+// number of parts a batch of B clips is split into, and the clips one workspace set must hold
+static int n_parts(escx_handle_s* h, int B) { return std::max(1, std::min(h->parts, B)); }
+static int set_clips(escx_handle_s* h, int B) { const int k = n_parts(h, B); return (B + k - 1) / k; }
+
+static bool ws_fits(escx_handle_s* h, int B, int T) {
+    const int need = set_clips(h, B), sets = n_parts(h, B);
+    for (int i = 0; i < sets; ++i) {
+        const WsFields& S = h->sets[i];
+        if (!(S.ws.base && S.shp.B >= need && S.shp.W == T / h->cfg.patch_t && S.shp.T >= T)) return false;
+    }
+    return true;
+}
+
+static int reserve_frames(escx_handle_s* h, int Btotal, int T) {
     ESCX_HIP(hipSetDevice(h->device));
+    const int B = set_clips(h, Btotal), sets = n_parts(h, Btotal);
     Shapes s;
     int rc = make_shapes(h, B, T, &s);
     if (rc) return rc;
@@ -579,7 +600,12 @@ static int reserve_frames(escx_handle_s* h, int B, int T) {
         if ((rc = get_map(h, H, s.W, 2, &dummy))) return rc;
         if (Ly.scale == 1 && (rc = get_map(h, H, s.W, -1, &dummy))) return rc;
     }
-    if (ws_fits(h, B, T)) return ESCX_OK;
+    if (ws_fits(h, Btotal, T)) return ESCX_OK;
+    if (!h->ev_fork) ESCX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int i = 1; i < sets; ++i) if (!h->sx[i]) {
+        ESCX_HIP(hipStreamCreateWithFlags(&h->sx[i], hipStreamNonBlocking));
+        ESCX_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+    }
 
     // size every buffer (floats)
     size_t work = 0, xn = 0, qkv = 0, ob = 0, hid = 0, dec = 0, zp = 0;
@@ -605,7 +631,7 @@ static int reserve_frames(escx_handle_s* h, int B, int T) {
     }
     const int T2 = c.patch_t * s.W, F2 = c.patch_f * s.H0;
     const size_t spec = (size_t)B * s.T * c.in_dim * h->Fp;
-    const size_t deemb = (size_t)B * T2 * F2 * h->C0p;
+    const size_t deemb = h->deembed_two_stage ? (size_t)B * T2 * F2 * h->C0p : 64;
     const size_t rspec = (size_t)B * T2 * c.in_dim * h->Fp;
     const size_t frames = (size_t)B * T2 * h->winP;
     const size_t stage = std::max({work, dec, spec, rspec});
@@ -616,21 +642,29 @@ static int reserve_frames(escx_handle_s* h, int B, int T) {
     add(work); add(xn); add(qkv); add(ob); add(hid); add(dec); add(dec); add(zp); add(deemb); add(rspec); add(frames);
     add(stage); add(stage); add(codes); add(B);
 
-    if (h->ws.base) { ESCX_HIP(hipDeviceSynchronize()); ESCX_HIP(hipFree(h->ws.base)); h->ws = Arena(); }
-    ESCX_HIP(hipMalloc((void**)&h->ws.base, total));
-    ESCX_HIP(hipMemset(h->ws.base, 0, total));
-    h->ws.cap = total; h->ws.used = 0;
-    h->spec = h->ws.take(spec);
-    h->enc_hs.assign(n, nullptr);
-    for (int i = 0; i < n; ++i) h->enc_hs[i] = h->ws.take(ehs[i]);
-    h->work = h->ws.take(work); h->xn = h->ws.take(xn); h->qkv = h->ws.take(qkv); h->obuf = h->ws.take(ob); h->hid = h->ws.take(hid);
-    h->decA = h->ws.take(dec); h->decB = h->ws.take(dec); h->zpart = h->ws.take(zp); h->zpart_cap = zp;
-    h->deemb = h->ws.take(deemb); h->rspec = h->ws.take(rspec); h->frames = h->ws.take(frames);
-    h->stageA = h->ws.take(stage); h->stageB = h->ws.take(stage);
-    h->codes_tmp = reinterpret_cast<long long*>(h->ws.take(codes));
-    h->loss = h->ws.take(B);
-    if (!h->loss) ESCX_FAIL(ESCX_ERR_STATE, "workspace sizing bug");
-    h->shp = s;
+    ESCX_HIP(hipDeviceSynchronize());
+    for (int si = 0; si < escx_handle_s::MAX_PARTS; ++si) {
+        WsFields& S = h->sets[si];
+        if (S.ws.base) { ESCX_HIP(hipFree(S.ws.base)); }
+        S = WsFields();
+        if (si >= sets) continue;
+        ESCX_HIP(hipMalloc((void**)&S.ws.base, total));
+        ESCX_HIP(hipMemset(S.ws.base, 0, total));
+        S.ws.cap = total; S.ws.used = 0;
+        S.spec = S.ws.take(spec);
+        S.enc_hs.assign(n, nullptr);
+        for (int i = 0; i < n; ++i) S.enc_hs[i] = S.ws.take(ehs[i]);
+        S.work = S.ws.take(work); S.xn = S.ws.take(xn); S.qkv = S.ws.take(qkv); S.obuf = S.ws.take(ob); S.hid = S.ws.take(hid);
+        S.decA = S.ws.take(dec); S.decB = S.ws.take(dec); S.zpart = S.ws.take(zp); S.zpart_cap = zp;
+        S.deemb = S.ws.take(deemb); S.rspec = S.ws.take(rspec); S.frames = S.ws.take(frames);
+        S.stageA = S.ws.take(stage); S.stageB = S.ws.take(stage);
+        S.codes_tmp = reinterpret_cast<long long*>(S.ws.take(codes));
+        S.loss = S.ws.take(B);
+        if (!S.loss) ESCX_FAIL(ESCX_ERR_STATE, "workspace sizing bug");
+        S.shp = s;
+    }
+    h->n_sets = sets;
+    use_set(h, 0);
     return ESCX_OK;
 }
 
@@ -656,7 +690,32 @@ static int ensure_ws(escx_handle_s* h, int B, int T, Shapes* s) {
         int rc = reserve_frames(h, B, T);
         if (rc) return rc;
     }
+    use_set(h, 0);
     return make_shapes(h, B, T, s);
+}
+
+// Whole-path calls: run `part(first_clip, n_clips, stream)` once, or as two halves on two streams joined by events.
+// Clips are independent end to end, so the halves never exchange data; overlapping them lets one half's kernels fill
+// the CUs the other half's tail workgroups leave idle (a 36-clip layer launches only ~1.3-2.6 workgroups per CU).
+template <class F>
+static int run_halves(escx_handle_s* h, int B, hipStream_t st, F part) {
+    const int k = std::min(n_parts(h, B), h->n_sets);
+    if (k <= 1) { use_set(h, 0); return part(0, B, st); }
+    const int per = (B + k - 1) / k;
+    const bool concurrent = !h->prof;                      // per-kernel event timing needs the launches serialised
+    if (concurrent) ESCX_HIP(hipEventRecord(h->ev_fork, st));
+    int rc = 0;
+    for (int i = 0; i < k && !rc; ++i) {
+        const int b0 = i * per, nb = std::min(per, B - b0);
+        if (nb <= 0) break;
+        hipStream_t si = (concurrent && i > 0) ? h->sx[i] : st;
+        if (concurrent && i > 0) ESCX_HIP(hipStreamWaitEvent(si, h->ev_fork, 0));
+        use_set(h, i);
+        rc = part(b0, nb, si);
+        if (concurrent && i > 0) { ESCX_HIP(hipEventRecord(h->ev_join[i], si)); ESCX_HIP(hipStreamWaitEvent(st, h->ev_join[i], 0)); }
+    }
+    use_set(h, 0);
+    return rc;
 }
 
 static int frames_of(escx_handle_s* h, int L) { return 1 + L / h->cfg.hop_length; }
@@ -941,10 +1000,14 @@ extern "C" int escx_encode(escx_handle h, const float* wave, int B, int L, int S
     if (S < 1 || S > h->cfg.max_streams) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "num_streams=%d outside [1, %d]", S, h->cfg.max_streams);
     if (L <= h->n_fft / 2) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_samples=%d too short for reflect padding of %d", L, h->n_fft / 2);
     Shapes s; if ((rc = ensure_ws(h, B, frames_of(h, L), &s))) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    if ((rc = run_stft(h, wave, B, L, s.T, h->spec, st))) return rc;
-    if ((rc = run_encoder(h, s, st))) return rc;
-    if ((rc = run_csvq_encode(h, s, S, (long long*)codes, st))) return rc;
+    const long long cstride = (long long)S * h->cfg.group_size * s.Tq;
+    rc = run_halves(h, B, (hipStream_t)stream, [&](int b0, int nb, hipStream_t st) -> int {
+        Shapes sp = s; sp.B = nb; int r;
+        if ((r = run_stft(h, wave + (size_t)b0 * L, nb, L, sp.T, h->spec, st))) return r;
+        if ((r = run_encoder(h, sp, st))) return r;
+        return run_csvq_encode(h, sp, S, (long long*)codes + b0 * cstride, st);
+    });
+    if (rc) return rc;
     if (fh) *fh = s.encH[h->n - 1];
     if (fw) *fw = s.W;
     return ESCX_OK;
@@ -976,12 +1039,16 @@ extern "C" int escx_decode(escx_handle h, const int64_t* codes, int B, int S, in
     if (fw < 1 || fw % c.overlap) ESCX_FAIL(ESCX_ERR_ASSERT, "Time dimension must be multiple of overlap");
     Shapes s; if ((rc = ensure_ws(h, B, frames_for_width(h, fw), &s))) return rc;
     if (s.W != fw || s.encH[h->n - 1] != fh) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "feat_shape (%d,%d) does not match the model (%d,%d)", fh, fw, s.encH[h->n - 1], s.W);
-    hipStream_t st = (hipStream_t)stream;
-    if ((rc = run_csvq_decode(h, (const long long*)codes, B, S, fh, fw, h->rspec, st))) return rc;
-    const int T2 = c.patch_t * fw;
-    if ((rc = run_istft(h, h->rspec, B, T2, wave_out, st))) return rc;
-    if (recon_feat) spec_unpad(h, h->rspec, recon_feat, (long long)B * T2, st);
-    return launch_ok("decode");
+    const int T2 = c.patch_t * fw, out_len = c.hop_length * (T2 - 1);
+    const long long cstride = (long long)S * c.group_size * (fw / c.overlap);
+    rc = run_halves(h, B, (hipStream_t)stream, [&](int b0, int nb, hipStream_t st) -> int {
+        int r;
+        if ((r = run_csvq_decode(h, (const long long*)codes + b0 * cstride, nb, S, fh, fw, h->rspec, st))) return r;
+        if ((r = run_istft(h, h->rspec, nb, T2, wave_out + (size_t)b0 * out_len, st))) return r;
+        if (recon_feat) spec_unpad(h, h->rspec, recon_feat + (size_t)b0 * T2 * c.in_dim * h->F, (long long)nb * T2, st);
+        return launch_ok("decode");
+    });
+    return rc;
 }
 
 extern "C" int escx_forward(escx_handle h, const float* wave, int B, int L, int S, int64_t* codes, float* wave_out, float* raw_feat,
@@ -992,36 +1059,38 @@ extern "C" int escx_forward(escx_handle h, const float* wave, int B, int L, int 
     if (S < 1 || S > c.max_streams) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "num_streams=%d outside [1, %d]", S, c.max_streams);
     if (L <= h->n_fft / 2) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_samples=%d too short for reflect padding of %d", L, h->n_fft / 2);
     Shapes s; if ((rc = ensure_ws(h, B, frames_of(h, L), &s))) return rc;
-    hipStream_t st = (hipStream_t)stream;
     const int n = h->n, G = c.group_size;
     const long long bstride = (long long)S * G * s.Tq, sstride = (long long)G * s.Tq;
-    long long* cd = (long long*)codes;
-    if ((rc = run_stft(h, wave, B, L, s.T, h->spec, st))) return rc;
-    if (raw_feat) spec_unpad(h, h->spec, raw_feat, (long long)B * s.T, st);
-    if ((rc = run_encoder(h, s, st))) return rc;
-    float* loss = cm_loss ? h->loss : nullptr;
-    if (loss) ESCX_HIP(hipMemsetAsync(loss, 0, sizeof(float) * B, st));
-    // csrvq.py:97-129 in eval mode: stream 0, then (stream i+1, block i) pairs; untransmitted streams pass through
-    int H = s.encH[n - 1], Hn;
-    float* dec = h->decA; float* other = h->decB;
-    if ((rc = run_pvq_encode(h, h->quants[0], h->enc_hs[n - 1], nullptr, B, s.W, cd, bstride, loss, st))) return rc;
-    if ((rc = run_pvq_decode(h, h->quants[0], cd, bstride, nullptr, B, s.W, dec, st))) return rc;
-    for (int i = 0; i + 1 < n; ++i) {
-        if (i < S - 1) {
-            const Quant& q = h->quants[i + 1];
-            if ((rc = run_pvq_encode(h, q, h->enc_hs[n - 1 - i], dec, B, s.W, cd + (i + 1) * sstride, bstride, loss, st))) return rc;
-            if ((rc = run_pvq_decode(h, q, cd + (i + 1) * sstride, bstride, dec, B, s.W, dec, st))) return rc;
+    const int T2 = c.patch_t * s.W, out_len = c.hop_length * (T2 - 1);
+    return run_halves(h, B, (hipStream_t)stream, [&](int b0, int nb, hipStream_t st) -> int {
+        Shapes sp = s; sp.B = nb; int r;
+        long long* cd = (long long*)codes + b0 * bstride;
+        if ((r = run_stft(h, wave + (size_t)b0 * L, nb, L, sp.T, h->spec, st))) return r;
+        if (raw_feat) spec_unpad(h, h->spec, raw_feat + (size_t)b0 * sp.T * c.in_dim * h->F, (long long)nb * sp.T, st);
+        if ((r = run_encoder(h, sp, st))) return r;
+        float* loss = cm_loss ? h->loss : nullptr;
+        if (loss) ESCX_HIP(hipMemsetAsync(loss, 0, sizeof(float) * nb, st));
+        // csrvq.py:97-129 in eval mode: stream 0, then (stream i+1, block i) pairs; untransmitted streams pass through
+        int H = sp.encH[n - 1], Hn;
+        float* dec = h->decA; float* other = h->decB;
+        if ((r = run_pvq_encode(h, h->quants[0], h->enc_hs[n - 1], nullptr, nb, sp.W, cd, bstride, loss, st))) return r;
+        if ((r = run_pvq_decode(h, h->quants[0], cd, bstride, nullptr, nb, sp.W, dec, st))) return r;
+        for (int i = 0; i + 1 < n; ++i) {
+            if (i < S - 1) {
+                const Quant& q = h->quants[i + 1];
+                if ((r = run_pvq_encode(h, q, h->enc_hs[n - 1 - i], dec, nb, sp.W, cd + (i + 1) * sstride, bstride, loss, st))) return r;
+                if ((r = run_pvq_decode(h, q, cd + (i + 1) * sstride, bstride, dec, nb, sp.W, dec, st))) return r;
+            }
+            if ((r = run_layer(h, h->layers[n + i], dec, other, nb, H, sp.W, &Hn, st))) return r;
+            std::swap(dec, other); H = Hn;
         }
-        if ((rc = run_layer(h, h->layers[n + i], dec, other, B, H, s.W, &Hn, st))) return rc;
-        std::swap(dec, other); H = Hn;
-    }
-    if ((rc = run_layer(h, h->layers[2 * n - 1], dec, other, B, H, s.W, &Hn, st))) return rc;
-    if ((rc = run_deembed(h, other, B, s.W, h->rspec, st))) return rc;
-    const int T2 = c.patch_t * s.W;
-    if ((rc = run_istft(h, h->rspec, B, T2, wave_out, st))) return rc;
-    if (recon_feat) spec_unpad(h, h->rspec, recon_feat, (long long)B * T2, st);
-    if (cm_loss) ESCX_HIP(hipMemcpyAsync(cm_loss, loss, sizeof(float) * B, hipMemcpyDeviceToDevice, st));
-    return launch_ok("forward");
+        if ((r = run_layer(h, h->layers[2 * n - 1], dec, other, nb, H, sp.W, &Hn, st))) return r;
+        if ((r = run_deembed(h, other, nb, sp.W, h->rspec, st))) return r;
+        if ((r = run_istft(h, h->rspec, nb, T2, wave_out + (size_t)b0 * out_len, st))) return r;
+        if (recon_feat) spec_unpad(h, h->rspec, recon_feat + (size_t)b0 * T2 * c.in_dim * h->F, (long long)nb * T2, st);
+        if (cm_loss) ESCX_HIP(hipMemcpyAsync(cm_loss + b0, loss, sizeof(float) * nb, hipMemcpyDeviceToDevice, st));
+        return launch_ok("forward");
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1066,7 +1135,12 @@ extern "C" int escx_patch_embed(escx_handle h, const float* spec, int B, int T, 
     return launch_ok("patch_embed");
 }
 
-static int stage_ws_for_w(escx_handle_s* h, int B, int W, Shapes* s) { return ensure_ws(h, B, frames_for_width(h, W), s); }
+// stage-level calls run the whole batch on set 0, so ask for a workspace whose HALF holds B clips
+static int stage_ws_for_w(escx_handle_s* h, int B, int W, Shapes* s) {
+    int rc = ensure_ws(h, h->parts * B, frames_for_width(h, W), s);
+    if (!rc) s->B = B;
+    return rc;
+}
 
 extern "C" int escx_transformer_layer(escx_handle h, int layer_id, const float* x, int B, int H, int W, float* y, int* H_out, void* stream) {
     int rc = check_ready(h); if (rc) return rc;

@@ -61,9 +61,20 @@ struct Shapes {                      // geometry for one (batch, n_samples)
     std::vector<int> encH;           // H at encoder scale i (i = 0..n-1)
 };
 
+struct WsFields {                    // one workspace: every scratch buffer of the launch sequences
+    Arena ws;
+    Shapes shp;                      // shapes this set was sized for (shp.B = clips it can hold)
+    float *spec = nullptr, *work = nullptr, *xn = nullptr, *qkv = nullptr, *obuf = nullptr, *hid = nullptr;
+    float *decA = nullptr, *decB = nullptr, *zpart = nullptr, *deemb = nullptr, *rspec = nullptr, *frames = nullptr;
+    float *stageA = nullptr, *stageB = nullptr, *loss = nullptr;
+    long long* codes_tmp = nullptr;
+    std::vector<float*> enc_hs;
+    size_t zpart_cap = 0;
+};
+
 }  // namespace escx
 
-struct escx_handle_s {
+struct escx_handle_s : escx::WsFields {      // the inherited fields are the CURRENT set (swapped by use_set)
     escx_config cfg;
     int device = 0;
     int n = 0;                       // n_scales
@@ -85,15 +96,13 @@ struct escx_handle_s {
     float *dcc_w = nullptr, *dcc_b = nullptr, *dcv_w = nullptr, *dcv_b = nullptr;   // composed de-embedding: interior GEMM weights, border variants
     bool deembed_two_stage = false;  // ESCX_DEEMBED_TWO_STAGE=1: run conv5x5 and conv3x3 separately (A/B, fallback)
 
-    // workspace
-    escx::Arena ws;
-    escx::Shapes shp;                // shapes the workspace was sized for
-    float *spec = nullptr, *work = nullptr, *xn = nullptr, *qkv = nullptr, *obuf = nullptr, *hid = nullptr;
-    float *decA = nullptr, *decB = nullptr, *zpart = nullptr, *deemb = nullptr, *rspec = nullptr, *frames = nullptr;
-    float *stageA = nullptr, *stageB = nullptr, *loss = nullptr;
-    long long* codes_tmp = nullptr;
-    std::vector<float*> enc_hs;
-    size_t zpart_cap = 0;
+    // two workspace sets: whole-path calls split the batch in halves (clips are independent) and run them on two streams
+    static constexpr int MAX_PARTS = 4;
+    escx::WsFields sets[MAX_PARTS];
+    int n_sets = 1;
+    int parts = 2;                   // ESCX_STREAMS=k (1..4): batch split into k parts on k streams; 1 = single stream
+    hipStream_t sx[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};   // extra streams (part 0 runs on the caller's stream)
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
 
     // index maps (device), keyed by (H, W, shift) ; shift = -1 -> merge map
     std::map<std::tuple<int, int, int>, int*> maps;

@@ -47,12 +47,12 @@ def widen_codes(codes16: torch.Tensor) -> torch.Tensor:
     return codes16.to(torch.int64)
 
 
-def all_gather_codes(codes_local: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+def all_gather_codes(codes_local: torch.Tensor, group: Optional[dist.ProcessGroup] = None, force: bool = False) -> torch.Tensor:
     """(B_local, S, G, T) int64 on every rank -> (sum B_local, S, G, T) int64 on every rank, rank order.
 
     Equal shard sizes use one all_gather_into_tensor (a single direct collective: the payload is <= 0.2 MB per rank,
     latency-bound, nowhere near the per-link xGMI bandwidth); ragged shards fall back to all_gather of padded shards."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return codes_local
     world = dist.get_world_size(group)
     small = narrow_codes(codes_local)
