@@ -3,6 +3,12 @@
 Drop-in for the reference package's public surface (`/root/reference/esc/__init__.py:1`,
 `esc/models/__init__.py:1`): `from esc import ESC`, `from esc.models import make_model`.
 """
-from .models import ESC, make_model  # noqa: F401
+import os as _os
+
+# Batch halves run on two HIP streams; give the runtime enough hardware queues that they do not share one with
+# RCCL's / torch's streams (only effective if set before the first HIP call of the process -- see DESIGN.md section 5).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from .models import ESC, make_model  # noqa: F401,E402
 
 __all__ = ["ESC", "make_model"]

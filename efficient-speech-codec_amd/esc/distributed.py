@@ -7,7 +7,7 @@ Codes are 10-bit values carried as int64 by the API; they travel as int16 (4x fe
 from __future__ import annotations
 
 import ctypes
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -47,22 +47,20 @@ def widen_codes(codes16: torch.Tensor) -> torch.Tensor:
     return codes16.to(torch.int64)
 
 
-def all_gather_codes(codes_local: torch.Tensor, group: Optional[dist.ProcessGroup] = None, force: bool = False) -> torch.Tensor:
+def all_gather_codes(codes_local: torch.Tensor, group: Optional[dist.ProcessGroup] = None, force: bool = False,
+                     counts: Optional[Sequence[int]] = None) -> torch.Tensor:
     """(B_local, S, G, T) int64 on every rank -> (sum B_local, S, G, T) int64 on every rank, rank order.
 
-    Equal shard sizes use one all_gather_into_tensor (a single direct collective: the payload is <= 0.2 MB per rank,
-    latency-bound, nowhere near the per-link xGMI bandwidth); ragged shards fall back to all_gather of padded shards."""
+    No host synchronisation: shard sizes are never exchanged.  Equal shards (the default) use one
+    all_gather_into_tensor -- a single direct collective: the payload is <= 0.2 MB per rank, latency-bound, nowhere near
+    the per-link xGMI bandwidth.  Ragged shards pass `counts` (every rank can compute them with `shard_bounds`) and
+    gather zero-padded shards.  Collectives move bytes: RCCL/gloo have no int16 type, so the payload is viewed as uint8."""
     if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return codes_local
     world = dist.get_world_size(group)
     small = narrow_codes(codes_local)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=small.device) for _ in range(world)]
-    mine = torch.tensor([small.shape[0]], dtype=torch.int64, device=small.device)
-    dist.all_gather(sizes, mine, group=group)
-    counts = [int(s.item()) for s in sizes]
-    # collectives move bytes: RCCL/gloo have no int16 type, so the int16 payload is viewed as uint8
-    if len(set(counts)) == 1:
-        out = torch.empty((world * counts[0],) + tuple(small.shape[1:]), dtype=torch.int16, device=small.device)
+    if counts is None or len(set(counts)) == 1:
+        out = torch.empty((world * small.shape[0],) + tuple(small.shape[1:]), dtype=torch.int16, device=small.device)
         src8 = small.contiguous().view(torch.uint8)
         try:
             dist.all_gather_into_tensor(out.view(torch.uint8), src8, group=group)
@@ -71,6 +69,7 @@ def all_gather_codes(codes_local: torch.Tensor, group: Optional[dist.ProcessGrou
             dist.all_gather(parts, src8, group=group)
             out = torch.cat(parts, dim=0).view(torch.int16)
         return widen_codes(out)
+    assert len(counts) == world and counts[dist.get_rank(group)] == small.shape[0]
     mx = max(counts)
     pad = torch.zeros((mx,) + tuple(small.shape[1:]), dtype=torch.int16, device=small.device)
     pad[: small.shape[0]] = small
@@ -79,7 +78,8 @@ def all_gather_codes(codes_local: torch.Tensor, group: Optional[dist.ProcessGrou
     return widen_codes(torch.cat([p.view(torch.int16)[:c] for p, c in zip(parts, counts)], dim=0))
 
 
-def encode_sharded(model, x_local: torch.Tensor, num_streams: int = 6, group: Optional[dist.ProcessGroup] = None):
+def encode_sharded(model, x_local: torch.Tensor, num_streams: int = 6, group: Optional[dist.ProcessGroup] = None,
+                   counts: Optional[Sequence[int]] = None):
     """Each rank encodes its own clips; returns (codes of the WHOLE batch on every rank, local codes, feat_shape)."""
     codes_local, shape = model.encode(x_local, num_streams)
-    return all_gather_codes(codes_local, group), codes_local, shape
+    return all_gather_codes(codes_local, group, counts=counts), codes_local, shape

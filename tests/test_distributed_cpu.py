@@ -45,7 +45,8 @@ def _worker(rank, world, port, total, ragged, out_dir):
         per = total // world
         lo, hi = rank * per, (rank + 1) * per
     local, _ = orc.encode(x[lo:hi], 3)
-    full = all_gather_codes(local)
+    counts = [shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)] if ragged else None
+    full = all_gather_codes(local, counts=counts)
     if rank == 0:
         ref, _ = orc.encode(x[: (total if ragged else world * (total // world))], 3)
         np.save(os.path.join(out_dir, f"ok_{int(ragged)}.npy"), np.array([int(torch.equal(full, ref)), full.shape[0], int(full.dtype == torch.int64)]))
