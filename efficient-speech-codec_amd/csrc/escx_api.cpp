@@ -786,14 +786,15 @@ extern "C" const char* escx_profile_report(escx_handle h) {
     return h->prof_json.c_str();
 }
 
-// (TM, NW) of the LDS-staged fused MLP per padded width, from the B=36 sweep in profiles/ (ESCX_MLP_VARIANT overrides)
-static int mlp_variant_for(int Cp) {
-    switch (Cp) {
-        case 48: case 80: case 144: return 3;      // TM=1, 8 waves
-        case 384: return 2;                        // TM=1, 6 waves (21600 rows -> 225 workgroups on 256 CUs)
-        default: return 1;                         // TM=1, 4 waves
-    }
+// Waves per workgroup (4 or 8) for the fused kernels.  A wave owns `units` 16-row tiles; a workgroup's waves spread over the
+// 4 SIMDs of a CU and workgroups are dealt round-robin to the 256 CUs, so the makespan in tile-times is
+//   ceil(workgroups / 256) * ceil(NW / 4) * units.
+// 8 waves share each weight fragment between twice as many rows (half the L2->LDS traffic) and win ties.
+static int pick_nw(long long tiles, int units) {
+    auto cost = [&](int nw) { const long long wg = (tiles / units + nw - 1) / nw; return ((wg + 255) / 256) * ((nw + 3) / 4) * units; };
+    return cost(8) <= cost(4) ? 8 : 4;
 }
+static int mlp_variant_for(int M) { return pick_nw((M + 15) / 16, 1) == 8 ? 3 : 1; }     // fused_swin.hip: 1 = (TM 1, NW 4), 3 = (TM 1, NW 8)
 
 // One TransformerLayer on padded token maps.  x_in is read-only; y receives (B, H'*W, CoutP).
 // attention.py:48-91 (layer), 129-178 (block): LN1 -> pad -> roll -> windows -> attention -> reverse -> residual -> MLP.
@@ -813,7 +814,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         bool attn_done = false;
         if (h->use_fused && h->use_fused_attn && L.attn_mode >= 0) {
             int frc = 0;
-            const int nw = h->attn_nw ? h->attn_nw : 4;
+            const int nw = h->attn_nw ? h->attn_nw : pick_nw(Ms / 16, L.Cp <= 96 ? 2 : 1);
             PROF("attn_fused" + tag, 2 * dMs * dC * 4 * dC + 4 * dMs * 16 * dC, 2 * dM * dC * f4,
                  frc = attn_fused(src, cur, L.Cp, L.C, L.attn_mode, L.n_groups, bw.ln1_g, bw.ln1_b, bw.waf, bw.baf, bw.bias_tab_f, bw.bproj,
                                   map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, st));
@@ -835,7 +836,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             int frc = 0;
             PROF("mlp_fused" + tag, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
                  frc = mlp_fused(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP,
-                                 h->mlp_variant >= 0 ? h->mlp_variant : mlp_variant_for(L.Cp), st));
+                                 h->mlp_variant >= 0 ? h->mlp_variant : mlp_variant_for(M), st));
             if (frc == 0) { src = cur; continue; }
         }
         PROF("ln2" + tag, 0, 2 * dM * dC * f4,
