@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fused_kernel(AttnArgs a) {
 
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: keeps the DMA issue loop scalar
     const int win0 = (blockIdx.x * NW + wave) * TMW;
     const int n_stages = a.n_groups * (TPG / UT);
 

@@ -28,6 +28,7 @@ struct MlpArgs {
     const f32x4* wcf;                           // per hidden tile: [HT][KK fc1 fragments | KK fc2 fragments][64] (LDS-staged variant)
     int M, C, HT;
     float eps;
+    unsigned long long* trace;                  // debug (ABL bit 64): per-wave cycle sums of the main-loop phases
 };
 
 template <int CP, int TM>
@@ -139,15 +140,20 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
 // L2 -> CU weight traffic drops NW-fold versus the wave-autonomous kernel, which is what wide layers need
 // (at C = 384 one pass over fc1+fc2 is 4.7 MB).
 // ------------------------------------------------------------------------------------------------
+// Occupancy target: the loop has serial phases (DMA issue, GELU, barrier) that only a co-resident wave can cover, so the
+// register budget is capped to fit 3-4 waves per SIMD where the tile sizes allow (s_memtime traces: with one wave per SIMD a
+// hidden tile takes ~5600 cycles for 3072 cycles of MFMA work).
+template <int CP, int TM> constexpr int mlp_min_waves() { return (CP * TM <= 96) ? 4 : ((CP * TM <= 192) ? 3 : 1); }
+
 template <int CP, int TM, int NW, int ABL = 0>      // ABL: timing-only ablation bits (never used by the product path)
-__global__ __launch_bounds__(64 * NW) void mlp_fused_lds_kernel(MlpArgs a) {
+__global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_lds_kernel(MlpArgs a) {
     constexpr int KK = CP / 16;
     constexpr int CH = 2 * KK;                  // 1 KiB fragments per hidden tile: KK of fc1 then KK of fc2
     constexpr int PD = 3;                       // LDS -> register prefetch distance (fragments)
     __shared__ f32x4 wbuf[2][CH * 64];
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: keeps the DMA issue loop scalar
     const int m0 = (blockIdx.x * NW + wave) * (16 * TM);
 
     auto issue = [&](int ht, int buf) {
@@ -197,12 +203,18 @@ __global__ __launch_bounds__(64 * NW) void mlp_fused_lds_kernel(MlpArgs a) {
         for (int t = 0; t < TM; ++t) acc[o][t] = zero4();
 
     f32x4 bias_next = ld4(a.b1 + 4 * lg);      // fc1 bias of tile 0; later tiles are fetched one stage ahead
+    unsigned long long tr[6] = {0, 0, 0, 0, 0, 0};
+#define ESCX_TS(var) unsigned long long var = 0; if (ABL & 64) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    ESCX_TS(t_begin)
     for (int ht = 0; ht < a.HT; ++ht) {
+        ESCX_TS(t0)
         if (!(ABL & 2)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                    // tile ht is in LDS for every wave; nobody still reads the other buffer
         }
+        ESCX_TS(t1)
         if (ht + 1 < a.HT && !(ABL & 32)) issue(ht + 1, (ht + 1) & 1);
+        ESCX_TS(t2)
         const f32x4 bb = bias_next;
         if (ht + 1 < a.HT) bias_next = ld4(a.b1 + 16 * (ht + 1) + 4 * lg);
         const f32x4* wb = (ABL & 4) ? &wbuf[0][0] : &wbuf[ht & 1][lane];
@@ -226,6 +238,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_fused_lds_kernel(MlpArgs a) {
                     else h[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xf[t][f][r], h[t], 0, 0, 0);
                 }
         }
+        ESCX_TS(t3)
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             if (TM == 1) h[t] += h2[t];
@@ -233,6 +246,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_fused_lds_kernel(MlpArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) h[t][e] = (ABL & 1) ? h[t][e] * 0.5f : gelu_bf(h[t][e]);
         }
+        ESCX_TS(t4)
         // fc2: two output tiles per step so that consecutive MFMAs never hit the same accumulator
 #pragma unroll
         for (int o = 0; o < KK; o += 2) {
@@ -252,16 +266,30 @@ __global__ __launch_bounds__(64 * NW) void mlp_fused_lds_kernel(MlpArgs a) {
                     if (o + 1 < KK) acc[o + 1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[r], h[t][r], acc[o + 1][t], 0, 0, 0);
                 }
         }
+        ESCX_TS(t5)
+        if (ABL & 64) { tr[0] += t1 - t0; tr[1] += t2 - t1; tr[2] += t3 - t2; tr[3] += t4 - t3; tr[4] += t5 - t4; }
         // Pin the software pipeline: hipcc otherwise sinks every ds_read to just before its first use and
         // waits lgkmcnt(0) there, idling the matrix pipe for a full LDS round trip every 8 MFMAs.
+        if (!(ABL & 64)) {
 #pragma unroll
-        for (int i = 0; i < PD; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            for (int i = 0; i < PD; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
-        for (int f = 0; f < CH; ++f) {
-            if (f + PD < CH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM, 0);
+            for (int f = 0; f < CH; ++f) {
+                if (f + PD < CH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM, 0);
+            }
         }
     }
+    if (ABL & 64) {
+        ESCX_TS(t_end)
+        tr[5] = t_end - t_begin;
+        if (lane == 0 && a.trace) {
+            unsigned long long* o = a.trace + (size_t)(blockIdx.x * NW + wave) * 8;
+            for (int i = 0; i < 6; ++i) o[i] = tr[i];
+            o[6] = t_begin; o[7] = t_end;
+        }
+    }
+#undef ESCX_TS
 
 #pragma unroll
     for (int t = 0; t < TM; ++t) {

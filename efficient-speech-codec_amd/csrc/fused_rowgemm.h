@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64 * NW) void rowgemm_fused_kernel(RowGemmArgs a) {
     __shared__ f32x4 wbuf[2][UT * KK * 64];
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: keeps the DMA issue loop scalar
     const int m0 = (blockIdx.x * NW + wave) * (16 * TM);
     const int n_stages = (a.NT + UT - 1) / UT;
 

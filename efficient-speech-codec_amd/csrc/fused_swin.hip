@@ -37,10 +37,13 @@ static void launch_mlp_abl(const MlpArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((mlp_fused_lds_kernel<CP, TM, NW, ABL>), dim3((a.M + rows - 1) / rows), dim3(64 * NW), 0, s, a);
 }
 
+static unsigned long long* g_mlp_trace = nullptr;      // debug only (ESCX_MLP_VARIANT=164): 8 x u64 per wave, see fused_mlp.h
+void mlp_set_trace(unsigned long long* p) { g_mlp_trace = p; }
+
 int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* w1f, const float* b1,
               const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, hipStream_t s) {
     MlpArgs a{x, gamma, beta, reinterpret_cast<const f32x4*>(w1f), b1, reinterpret_cast<const f32x4*>(w2f), b2,
-              reinterpret_cast<const f32x4*>(wcf), M, C, hiddenP / 16, 1e-5f};
+              reinterpret_cast<const f32x4*>(wcf), M, C, hiddenP / 16, 1e-5f, g_mlp_trace};
     if (variant >= 100) {      // timing-only ablations: variant = 100 + ABL bits
         const int abl = variant - 100;
         if (Cp == 192) {
@@ -54,6 +57,7 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
                 case 7: launch_mlp_abl<192, 1, 4, 7>(a, s); return 0;
                 case 34: launch_mlp_abl<192, 1, 4, 34>(a, s); return 0;
                 case 39: launch_mlp_abl<192, 1, 4, 39>(a, s); return 0;
+                case 64: launch_mlp_abl<192, 1, 4, 64>(a, s); return 0;
             }
         }
         variant = 1;

@@ -22,6 +22,7 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
 // LN + linear for PatchMerge (segs = 2, map gives the two source rows) / PatchSplit (segs = 1, split = 1: pixel-shuffled store)
 int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, const float* beta, const float* wf, const int* map, int M,
                   int rows_per_clip, int src_rows_per_clip, int C, int Cp, int Np, int split, int H, int W, int C2p, hipStream_t s);
+void mlp_set_trace(unsigned long long* p);
 // mode: 0 one head (<=16 dims) per tile, 1 two heads (<=8 dims) per tile, 2 one head (<=32 dims) over two tiles
 int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_groups, const float* gamma, const float* beta,
                const float* wf, const float* bqkv, const float* bias_tab, const float* bproj, const int* map, int slots, int tokens,

@@ -133,6 +133,8 @@ const char* escx_profile_report(escx_handle h);
 
 /* Device math used inside the fused kernels, exposed for the accuracy tests: which = 0 gelu (branch-free erf),
  * 1 erf (branch-free), 2 exp via v_exp_f32, 3 gelu via libm erff (the unfused epilogue). */
+/* Debug: per-wave cycle counters of the fused MLP main loop (kernel built with the trace flag, ESCX_MLP_VARIANT=164). */
+int escx_debug_mlp_trace(unsigned long long* dev_buf);
 int escx_test_math(const float* x_dev, float* y_dev, int64_t n, int which, void* stream);
 
 /* ---- code packing for transport (10-bit codes; all-gather payload) --------------------------- */

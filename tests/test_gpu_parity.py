@@ -337,3 +337,47 @@ def test_fused_and_unfused_pipelines_agree(base, monkeypatch):
     assert torch.equal(codes, c2), code_report(codes.cpu().numpy(), c2.cpu().numpy(), g["margins"])
     assert rms(wave.cpu().numpy(), w2.cpu().numpy()) < 2e-6
     assert narrow_codes(codes).dtype == torch.int16 and torch.equal(widen_codes(narrow_codes(codes)), codes)
+
+
+def test_variable_bitrate_sweep_batch64(base):
+    """BASELINE config 3: batch 64, num_streams 1..6 (the RVQ early-exit path).  Prefix property against the S=6 run,
+    decode of every prefix finite and S-dependent, oracle agreement on a 2-clip sample per S."""
+    model, orc, g, cfg = base
+    pcm = np.stack([synth.noise_clip_int16(f"vbr-{i}", 48000, amp=0.05 + 0.01 * (i % 7)) for i in range(64)])
+    x = torch.from_numpy(synth.pcm_to_float(pcm)).cuda()
+    full, shape = model.encode(x, 6)
+    prev = None
+    for s in range(1, 7):
+        codes, shp = model.encode(x, s)
+        assert tuple(shp) == tuple(shape) and codes.shape == (64, s, 3, 150)
+        assert torch.equal(codes, full[:, :s])
+        wave = model.decode(codes, shape)
+        assert wave.shape == (64, 47920) and torch.isfinite(wave).all()
+        if prev is not None:
+            assert not torch.equal(wave, prev)
+        prev = wave
+        oc, _ = orc.encode(x[30:32].cpu(), s)
+        assert torch.equal(oc, codes[30:32].cpu()), code_report(codes[30:32].cpu().numpy(), oc.numpy())
+        assert rms(wave[30:32].cpu().numpy(), orc.decode(oc, shape).numpy()) <= AUDIO_TOL
+
+
+def test_c_abi_error_paths(base):
+    """Status codes and messages of the C ABI (nothing throws across it)."""
+    model, orc, g, cfg = base
+    lib, hd = _h(model)
+    x = torch.zeros(1, 48000, device="cuda"); codes = torch.zeros(1, 6, 3, 150, dtype=torch.int64, device="cuda")
+    fh, fw = ctypes.c_int(), ctypes.c_int()
+    assert lib.escx_encode(hd, _ptr(x), 1, 48000, 7, _ptr(codes), ctypes.byref(fh), ctypes.byref(fw), None) == _native.ESCX_ERR_INVALID_ARG
+    assert b"num_streams" in lib.escx_last_error()
+    assert lib.escx_encode(hd, None, 1, 48000, 6, _ptr(codes), None, None, None) == _native.ESCX_ERR_INVALID_ARG
+    assert lib.escx_encode(hd, _ptr(x), 1, 100, 6, _ptr(codes), None, None, None) == _native.ESCX_ERR_INVALID_ARG      # shorter than the reflect pad
+    assert lib.escx_encode(hd, _ptr(x), 1, 24080, 6, _ptr(codes), None, None, None) == _native.ESCX_ERR_ASSERT          # W = 151 is odd
+    assert b"multiple of overlap" in lib.escx_last_error()
+    out = torch.zeros(1, 47920, device="cuda")
+    assert lib.escx_decode(hd, _ptr(codes), 1, 6, 3, 300, _ptr(out), None, None) == _native.ESCX_ERR_INVALID_ARG         # wrong feat_shape
+    assert lib.escx_transformer_layer(hd, 99, _ptr(x), 1, 4, 4, _ptr(out), None, None) == _native.ESCX_ERR_INVALID_ARG
+    with pytest.raises(ValueError):
+        model.decode(torch.zeros(1, 6, 2, 150, dtype=torch.int64, device="cuda"), (2, 300))
+    # the handle still works after errors
+    c, s = model.encode(torch.from_numpy(synth.pcm_to_float(g["pcm"])).cuda(), 6)
+    assert np.array_equal(c.cpu().numpy(), g["codes"].astype(np.int64))
