@@ -60,6 +60,8 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
                 case 64: launch_mlp_abl<192, 1, 4, 64>(a, s); return 0;
             }
         }
+        if (Cp == 384 && abl == 64) { launch_mlp_abl<384, 1, 4, 64>(a, s); return 0; }
+        if (Cp == 48 && abl == 64) { launch_mlp_abl<48, 1, 8, 64>(a, s); return 0; }
         variant = 1;
     }
     if (variant > 0) {
