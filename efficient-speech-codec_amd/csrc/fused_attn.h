@@ -66,8 +66,11 @@ __device__ __forceinline__ f32x4 window_softmax(f32x4 s, const float* bias_h, in
     return p;
 }
 
+// register budget capped for 3-4 waves per SIMD where the tile sizes allow (same reasoning as the fused MLP)
+template <int CP, int TMW> constexpr int attn_min_waves() { return (CP * TMW <= 96) ? 4 : ((CP * TMW <= 192) ? 3 : 1); }
+
 template <int CP, int MODE, int UT, int TMW, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_fused_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fused_kernel(AttnArgs a) {
     constexpr int KK = CP / 16;
     constexpr int TPG = (MODE == 2) ? 8 : 4;    // weight tiles per head group
     constexpr int NB = (MODE == 2) ? 6 : 3;     // bias rows per group

@@ -381,3 +381,21 @@ def test_c_abi_error_paths(base):
     # the handle still works after errors
     c, s = model.encode(torch.from_numpy(synth.pcm_to_float(g["pcm"])).cuda(), 6)
     assert np.array_equal(c.cpu().numpy(), g["codes"].astype(np.int64))
+
+
+def test_long_clip_10s_and_default_feat_shape(base):
+    """A 10 s clip (L=160000 -> W=1000, the decode() default feat_shape) against the oracle; attention is local, so
+    cost and correctness are length-independent."""
+    model, orc, g, cfg = base
+    pcm = synth.voiced_clip_int16("long-0", 160000)
+    x = torch.from_numpy(synth.pcm_to_float(pcm))[None]
+    codes, shape = model.encode(x.cuda(), 6)
+    assert tuple(shape) == (2, 1000) and codes.shape == (1, 6, 3, 500)
+    margins = []
+    tr = __import__("oracle.esc_oracle", fromlist=["Trace"]).Trace()
+    oc, oshape = orc.encode(x, 6, trace=tr)
+    m = torch.stack(tr.margins, dim=1).numpy()
+    assert torch.equal(oc, codes.cpu()), code_report(codes.cpu().numpy(), oc.numpy(), m)
+    wave = model.decode(codes)                     # default feat_shape=(2, 1000)
+    assert wave.shape == (1, 80 * 1999)
+    assert rms(wave.cpu().numpy(), orc.decode(oc, oshape).numpy()) <= AUDIO_TOL
