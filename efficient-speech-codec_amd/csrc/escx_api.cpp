@@ -1206,6 +1206,16 @@ extern "C" int escx_test_math(const float* x, float* y, int64_t n, int which, vo
     test_math(x, y, n, which, (hipStream_t)stream);
     return launch_ok("test_math");
 }
+extern "C" int escx_codes_pack10(const int64_t* codes, uint8_t* out, int64_t n, void* stream) {
+    if (!codes || !out || n < 0) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
+    codes_pack10((const long long*)codes, out, n, (hipStream_t)stream);
+    return launch_ok("codes_pack10");
+}
+extern "C" int escx_codes_unpack10(const uint8_t* in, int64_t* codes, int64_t n, void* stream) {
+    if (!codes || !in || n < 0) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
+    codes_unpack10(in, (long long*)codes, n, (hipStream_t)stream);
+    return launch_ok("codes_unpack10");
+}
 extern "C" int escx_codes_narrow(const int64_t* codes, int16_t* out, int64_t n, void* stream) {
     codes_narrow((const long long*)codes, (short*)out, n, (hipStream_t)stream);
     return launch_ok("codes_narrow");

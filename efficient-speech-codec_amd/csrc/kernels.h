@@ -353,6 +353,26 @@ __global__ void unpad_rows_kernel(const float* __restrict__ src, float* __restri
     const long long r = idx / C; const int c = (int)(idx - r * C);
     dst[idx] = src[r * Cp + c];
 }
+// Wire format of the codes: every code is log2(codebook_size) = 10 bits, so 6 x 3 x 50 codes/s x 10 b = 9 kbps
+// exactly (base.py:70).  4 codes -> 5 bytes, little-endian bit order; n is padded to a multiple of 4 with zero codes.
+__global__ void codes_pack10_kernel(const long long* __restrict__ in, unsigned char* __restrict__ out, long long n) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q * 4 >= n) return;
+    unsigned long long v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const long long i = q * 4 + j; v |= (unsigned long long)((i < n ? in[i] : 0) & 1023) << (10 * j); }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) out[q * 5 + j] = (unsigned char)(v >> (8 * j));
+}
+__global__ void codes_unpack10_kernel(const unsigned char* __restrict__ in, long long* __restrict__ out, long long n) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q * 4 >= n) return;
+    unsigned long long v = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) v |= (unsigned long long)in[q * 5 + j] << (8 * j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const long long i = q * 4 + j; if (i < n) out[i] = (long long)((v >> (10 * j)) & 1023); }
+}
 __global__ void test_math_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, int which) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

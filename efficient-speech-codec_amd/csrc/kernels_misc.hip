@@ -82,6 +82,14 @@ int deembed_border(const float* x, const float* wv, const float* bv, float* out,
     return 0;
 }
 
+void codes_pack10(const long long* in, unsigned char* out, long long n, hipStream_t s) {
+    const long long q = (n + 3) / 4;
+    hipLaunchKernelGGL(codes_pack10_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, s, in, out, n);
+}
+void codes_unpack10(const unsigned char* in, long long* out, long long n, hipStream_t s) {
+    const long long q = (n + 3) / 4;
+    hipLaunchKernelGGL(codes_unpack10_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, s, in, out, n);
+}
 void test_math(const float* x, float* y, long long n, int which, hipStream_t s) {
     hipLaunchKernelGGL(test_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n, which);
 }

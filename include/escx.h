@@ -138,6 +138,9 @@ int escx_debug_mlp_trace(unsigned long long* dev_buf);
 int escx_test_math(const float* x_dev, float* y_dev, int64_t n, int which, void* stream);
 
 /* ---- code packing for transport (10-bit codes; all-gather payload) --------------------------- */
+/* 10-bit wire format (codebook_size 1024): n codes <-> 5*ceil(n/4) bytes; 6 streams x 3 groups x 50 Hz x 10 b = 9 kbps (base.py:70). */
+int escx_codes_pack10(const int64_t* codes_dev, uint8_t* out_dev, int64_t n, void* stream);
+int escx_codes_unpack10(const uint8_t* in_dev, int64_t* codes_dev, int64_t n, void* stream);
 int escx_codes_narrow(const int64_t* codes_dev, int16_t* out_dev, int64_t n, void* stream);
 int escx_codes_widen(const int16_t* in_dev, int64_t* codes_dev, int64_t n, void* stream);
 

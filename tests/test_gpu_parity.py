@@ -399,3 +399,31 @@ def test_long_clip_10s_and_default_feat_shape(base):
     wave = model.decode(codes)                     # default feat_shape=(2, 1000)
     assert wave.shape == (1, 80 * 1999)
     assert rms(wave.cpu().numpy(), orc.decode(oc, oshape).numpy()) <= AUDIO_TOL
+
+
+def test_bitstream_and_compress_harness(base, tmp_path):
+    """10-bit wire format round trip (9 kbps payload exactly) and the scipy-based compress harness."""
+    import subprocess, sys, os
+    from scipy.io import wavfile
+    from esc import bitstream
+    from conftest import ROOT
+    model, orc, g, cfg = base
+    x = torch.from_numpy(synth.pcm_to_float(g["pcm"])).cuda()
+    codes, shape = model.encode(x, 6)
+    blob = bitstream.pack_codes(codes, shape)
+    assert len(blob) == 16 + codes.numel() * 10 // 8
+    assert (len(blob) - 16) * 8 / 3.0 / codes.shape[0] == 9000.0 == bitstream.payload_bits_per_second(6)
+    back, shp = bitstream.unpack_codes(blob)
+    assert torch.equal(back, codes) and tuple(shp) == tuple(shape)
+    odd = codes.reshape(-1)[:1001].reshape(1, 1, 1, 1001).contiguous()           # length not a multiple of 4
+    b2, _ = bitstream.unpack_codes(bitstream.pack_codes(odd, (2, 2002)))
+    assert torch.equal(b2, odd)
+    wav = tmp_path / "clip.wav"
+    wavfile.write(wav, 16000, g["pcm"][0])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "compress.py"), "--input", str(wav), "--save_path", str(tmp_path / "out"),
+                          "--synthetic", "base", "--num_streams", "6"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    saved = torch.load(tmp_path / "out" / "encoded_9.0kbps_clip.pth")
+    assert torch.equal(saved, codes[:1].cpu())
+    sr, rec = wavfile.read(tmp_path / "out" / "decoded_9.0kbps_clip.wav")
+    assert sr == 16000 and rms(rec, g["audio_s6"][0]) <= AUDIO_TOL
