@@ -702,7 +702,10 @@ static int run_halves(escx_handle_s* h, int B, hipStream_t st, F part) {
     const int k = std::min(n_parts(h, B), h->n_sets);
     if (k <= 1) { use_set(h, 0); return part(0, B, st); }
     const int per = (B + k - 1) / k;
-    const bool concurrent = !h->prof;                      // per-kernel event timing needs the launches serialised
+    // Event timing stays valid under concurrency (each kernel is bracketed on its own stream); ESCX_PROF_SERIAL=1 puts the
+    // parts back to back on the caller's stream when isolated per-kernel durations are wanted.
+    static const bool prof_serial = [] { const char* e = getenv("ESCX_PROF_SERIAL"); return e && e[0] == '1'; }();
+    const bool concurrent = !(h->prof && (prof_serial || h->prof_isolated));
     if (concurrent) ESCX_HIP(hipEventRecord(h->ev_fork, st));
     int rc = 0;
     for (int i = 0; i < k && !rc; ++i) {
@@ -759,6 +762,7 @@ extern "C" int escx_profile_enable(escx_handle h, int enable) {
     if (!h) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null handle");
     if (enable) { for (auto& r : h->prof_recs) { h->prof_pool.push_back(r.a); h->prof_pool.push_back(r.b); } h->prof_recs.clear(); }
     h->prof = enable != 0;
+    h->prof_isolated = enable == 2;      // 2: run the batch parts back to back so that kernels do not share the GPU
     return ESCX_OK;
 }
 

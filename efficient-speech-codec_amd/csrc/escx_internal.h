@@ -108,7 +108,7 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     std::map<std::tuple<int, int, int>, int*> maps;
 
     // per-launch HIP-event profiler (escx_profile_*); off by default
-    bool prof = false;
+    bool prof = false, prof_isolated = false;
     struct ProfRec { std::string name; double flops, bytes; hipEvent_t a, b; };
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;

@@ -125,7 +125,8 @@ int escx_pvq_decode(escx_handle h, int stream_id, const int64_t* codes_dev, int6
 int escx_patch_deembed(escx_handle h, const float* tokens_dev, int batch, int W, float* spec_dev, void* stream);
 
 /* ---- per-kernel timing (HIP events recorded on the caller's stream around every launch) ------- */
-/* enable != 0 starts recording (and clears earlier records); enable == 0 stops. */
+/* enable != 0 starts recording (and clears earlier records); enable == 0 stops.  enable == 2 additionally runs the batch parts
+ * back to back on the caller's stream, so that each kernel is timed alone on the GPU. */
 int escx_profile_enable(escx_handle h, int enable);
 /* Synchronises, aggregates by kernel label and returns a JSON array
  * [{"name":..., "calls":n, "ms":total, "flops":algorithmic, "bytes":algorithmic}, ...] valid until the next call. */
