@@ -127,6 +127,7 @@ extern "C" int escx_create(const escx_config* cfg, int device, escx_handle* out)
     { const char* e = getenv("ESCX_STREAMS"); if (e && e[0]) h->parts = std::min(std::max(atoi(e), 1), (int)escx_handle_s::MAX_PARTS); }
     { const char* e = getenv("ESCX_DEEMBED_TWO_STAGE"); h->deembed_two_stage = (e && e[0] == '1'); }
     { const char* e = getenv("ESCX_ATTN_NW"); if (e && e[0]) h->attn_nw = atoi(e); }
+    { const char* e = getenv("ESCX_NO_ATTN_PACK"); h->attn_pack = !(e && e[0] == '1'); }
     { const char* e = getenv("ESCX_NO_FUSED_ATTN"); h->use_fused_attn = !(e && e[0] == '1'); }
     int rc = build_geometry(h);
     if (rc) { delete h; return rc; }
@@ -818,8 +819,10 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         bool attn_done = false;
         if (h->use_fused && h->use_fused_attn && L.attn_mode >= 0) {
             int frc = 0;
-            const int nw = h->attn_nw ? h->attn_nw : pick_nw(Ms / 16, L.Cp <= 96 ? 2 : 1);
-            PROF("attn_fused" + tag, 2 * dMs * dC * 4 * dC + 4 * dMs * 16 * dC, 2 * dM * dC * f4,
+            int nw = h->attn_nw ? h->attn_nw : pick_nw(Ms / 16, L.Cp <= 96 ? 2 : 1);
+            if (H == 2 && W % 4 == 0 && h->attn_pack) nw = -(h->attn_nw ? h->attn_nw : pick_nw((Ms / 16 + 1) / 2, 1));    // packed half-window pairs
+            const double proj_rows = nw < 0 ? dM : dMs;         // packed pairs project only the real tokens
+            PROF("attn_fused" + tag, 2 * proj_rows * dC * 4 * dC + 4 * dMs * 16 * dC, 2 * dM * dC * f4,
                  frc = attn_fused(src, cur, L.Cp, L.C, L.attn_mode, L.n_groups, bw.ln1_g, bw.ln1_b, bw.waf, bw.baf, bw.bias_tab_f, bw.bproj,
                                   map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, st));
             attn_done = (frc == 0);

@@ -86,6 +86,7 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     int mlp_variant = -1;            // ESCX_MLP_VARIANT overrides the per-layer choice (tuning)
     int attn_nw = 0;                 // ESCX_ATTN_NW: waves per workgroup of the fused attention kernel (4 or 8)
     bool use_fused_attn = true;      // ESCX_NO_FUSED_ATTN=1
+    bool attn_pack = true;           // ESCX_NO_ATTN_PACK=1: do not pack half-real windows of the H == 2 scale
 
     escx::Arena wts;                 // packed weights
     std::vector<escx::Layer> layers; // 2n entries (see escx_transformer_layer)

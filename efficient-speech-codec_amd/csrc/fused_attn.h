@@ -309,4 +309,176 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Packed variant for the H = 2 scale (ESC's bottom of the decoder, C = 384): every 4x4 window there is 8 real tokens
+// plus 8 zero-padded ones (attention.py:139-143), so a window-per-tile kernel spends half of its projection MFMAs on
+// rows whose q/k/v are just the bias.  Here one 16-row tile carries the real tokens of TWO windows (rows 0-7: window A,
+// rows 8-15: window B).  Q/K/V and the output projection run once per pair; for the 16x16 attention of each window the
+// key / value operands are rebuilt in registers: real slots come from the packed tile (a half-row swap for K, a
+// lane-group swap for V^T), padded slots are the bias.  Requires H == 2, W % 4 == 0, one head per tile (MODE 0).
+// ------------------------------------------------------------------------------------------------
+template <int CP, int UT, int NW>
+__global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packed_kernel(AttnArgs a) {
+    constexpr int KK = CP / 16;
+    constexpr int TPG = 4;
+    static_assert(TPG % UT == 0, "stage size must divide the tiles of a head group");
+    __shared__ f32x4 wbuf[2][UT * KK * 64];
+
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = blockIdx.x * NW + wave;
+    const int n_stages = a.n_groups * (TPG / UT);
+
+    auto issue = [&](int stage, int buf) {
+        const f32x4* src = a.wf + (size_t)stage * (UT * KK * 64) + lane;
+        for (int c = wave; c < UT * KK; c += NW)
+            __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(&wbuf[buf][c * 64]), 16, 0, 0);
+    };
+    issue(0, 0);
+
+    // ---- gather: packed row j <- window (2*pair + j/8), slot (j%8) + off ; off = 8 in shifted blocks (the real rows roll down)
+    const int nW = a.nWh * a.nWw;                           // nWh == 1 here
+    const int off = a.shifted ? 8 : 0;
+    const bool isB = l15 >= 8;
+    const int win = 2 * pair + (isB ? 1 : 0);
+    const int qslot = (l15 & 7) + off;
+    int tok = -1; bool lastW = false;
+    if (win < a.n_windows) {
+        const int b = win / nW, wloc = win - b * nW;
+        lastW = (wloc % a.nWw) == a.nWw - 1;
+        const int tk = a.map[wloc * 16 + qslot];
+        if (tk >= 0) tok = b * a.tokens + tk;
+    }
+    f32x4 xf[KK];
+    {
+        const float* xr = a.src + (size_t)(tok < 0 ? 0 : tok) * CP + 4 * lg;
+        float s = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            xf[kk] = tok >= 0 ? ld4(xr + 16 * kk) : zero4();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) s += xf[kk][e];
+        }
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        const float mean = s / (float)a.C;
+        float v = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) { const float d = xf[kk][e] - mean; v += d * d; }
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        const float rstd = 1.0f / sqrtf(v / (float)a.C + a.eps);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const f32x4 g = ld4(a.gamma + 16 * kk + 4 * lg), bb = ld4(a.beta + 16 * kk + 4 * lg);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                xf[kk][e] = (tok >= 0 && 16 * kk + 4 * lg + e < a.C) ? (xf[kk][e] - mean) * rstd * g[e] + bb[e] : 0.f;
+        }
+    }
+    // which lanes hold real keys / values of a window, and whether the packed rows must be moved to reach their slots
+    const bool key_real = (l15 >> 3) == (off >> 3);         // K operand: lane = key slot
+    const bool val_real = (lg >> 1) == (off >> 3);          // V^T operand: lane group = 4 key slots
+    const bool moveA = off != 0, moveB = off != 8;
+
+    f32x4 acc[KK];
+#pragma unroll
+    for (int o = 0; o < KK; ++o) acc[o] = zero4();
+
+    int stage = 0;
+    const f32x4* wb = nullptr;
+    auto next_stage = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (stage + 1 < n_stages) issue(stage + 1, (stage + 1) & 1);
+        wb = &wbuf[stage & 1][lane];
+        ++stage;
+    };
+    auto tile_gemm = [&](const f32x4* wt, bool x_rows) -> f32x4 {
+        f32x4 o1 = zero4(), o2 = zero4();
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const f32x4 w = wt[kk * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (x_rows) {
+                    if (r & 1) o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[kk][r], w[r], o2, 0, 0, 0);
+                    else o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[kk][r], w[r], o1, 0, 0, 0);
+                } else {
+                    if (r & 1) o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xf[kk][r], o2, 0, 0, 0);
+                    else o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xf[kk][r], o1, 0, 0, 0);
+                }
+            }
+        }
+        return o1 + o2;
+    };
+
+    for (int g = 0; g < a.n_groups; ++g) {
+        const float* bg = a.bqkv + (size_t)g * 3 * 16;
+        int tile = 0;
+        auto tile_ptr = [&]() -> const f32x4* {
+            if (tile % UT == 0) next_stage();
+            const f32x4* p = wb + (tile % UT) * KK * 64;
+            ++tile;
+            return p;
+        };
+        const f32x4 bq = ld4(bg + 4 * lg), bk = ld4(bg + 16 + 4 * lg);
+        const float bv = bg[32 + l15];
+        f32x4 q = (tile_gemm(tile_ptr(), false) + bq) * a.scale;
+        f32x4 k = tile_gemm(tile_ptr(), false) + bk;
+        // scores of both windows against every packed query; a lane keeps its own window's row
+        f32x4 kA, kB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float km = __shfl_xor(k[r], 8);
+            kA[r] = key_real ? (moveA ? km : k[r]) : bk[r];
+            kB[r] = key_real ? (moveB ? km : k[r]) : bk[r];
+        }
+        f32x4 sA = zero4(), sB = zero4();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sA = __builtin_amdgcn_mfma_f32_16x16x4f32(kA[r], q[r], sA, 0, 0, 0);
+            sB = __builtin_amdgcn_mfma_f32_16x16x4f32(kB[r], q[r], sB, 0, 0, 0);
+        }
+        const f32x4 p = window_softmax(isB ? sB : sA, a.bias_tab + (size_t)g * 256, qslot, lg, a.shifted, true, lastW);
+        f32x4 vt = tile_gemm(tile_ptr(), true) + bv;
+        f32x4 vA, vB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float vm = __shfl_xor(vt[r], 32);
+            vA[r] = val_real ? (moveA ? vm : vt[r]) : bv;
+            vB[r] = val_real ? (moveB ? vm : vt[r]) : bv;
+        }
+        f32x4 oA = zero4(), oB = zero4();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            oA = __builtin_amdgcn_mfma_f32_16x16x4f32(vA[r], p[r], oA, 0, 0, 0);
+            oB = __builtin_amdgcn_mfma_f32_16x16x4f32(vB[r], p[r], oB, 0, 0, 0);
+        }
+        const f32x4 o = isB ? oB : oA;
+        const f32x4* wt = tile_ptr();
+#pragma unroll
+        for (int to = 0; to < KK; to += 2) {
+            const f32x4 w = wt[to * 64];
+            const f32x4 wn = (to + 1 < KK) ? wt[(to + 1) * 64] : zero4();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], o[r], acc[to], 0, 0, 0);
+                if (to + 1 < KK) acc[to + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[r], o[r], acc[to + 1], 0, 0, 0);
+            }
+        }
+    }
+
+    if (tok >= 0) {
+        const float* sr = a.src + (size_t)tok * CP + 4 * lg;
+        float* dr = a.dst + (size_t)tok * CP + 4 * lg;
+#pragma unroll
+        for (int o = 0; o < KK; ++o) {
+            const f32x4 v = acc[o] + ld4(a.bproj + 16 * o + 4 * lg);
+            st4(dr + 16 * o, ld4(sr + 16 * o) + v);
+        }
+    }
+}
+
 }  // namespace escx

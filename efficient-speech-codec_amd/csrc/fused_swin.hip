@@ -160,11 +160,27 @@ static int launch_attn_cp(int mode, int nw, const AttnArgs& a, hipStream_t s) {
     return -1;
 }
 
+template <int CP, int NW>
+static void launch_attn_packed(const AttnArgs& a, hipStream_t s) {
+    constexpr int UT = CP <= 96 ? 4 : (CP <= 192 ? 2 : 1);
+    const int pairs = (a.n_windows + 1) / 2;
+    hipLaunchKernelGGL((attn_packed_kernel<CP, UT, NW>), dim3((pairs + NW - 1) / NW), dim3(64 * NW), 0, s, a);
+}
+
 int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_groups, const float* gamma, const float* beta,
                const float* wf, const float* bqkv, const float* bias_tab, const float* bproj, const int* map, int slots, int tokens,
                int n_windows, int nWh, int nWw, int shifted, float scale, int nw, hipStream_t s) {
     AttnArgs a{src, dst, gamma, beta, reinterpret_cast<const f32x4*>(wf), bqkv, bias_tab, bproj, map, slots, tokens, n_windows,
                nWh, nWw, shifted, C, n_groups, scale, 1e-5f};
+    // H == 2 scale with no padding along W: two half-real windows share one tile (nw < 0 encodes "packing allowed", |nw| waves)
+    if (nw < 0) {
+        nw = -nw;
+        if (mode == 0) {
+#define ESCX_PACK(CPV) case CPV: if (nw == 8) launch_attn_packed<CPV, 8>(a, s); else launch_attn_packed<CPV, 4>(a, s); return 0;
+            switch (Cp) { ESCX_PACK(64) ESCX_PACK(96) ESCX_PACK(128) ESCX_PACK(192) ESCX_PACK(256) ESCX_PACK(384) default: break; }
+#undef ESCX_PACK
+        }
+    }
     switch (Cp) {
         case 16: return launch_attn_cp<16>(mode, nw, a, s);
         case 32: return launch_attn_cp<32>(mode, nw, a, s);
