@@ -213,7 +213,13 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
             __syncthreads();                    // tile ht is in LDS for every wave; nobody still reads the other buffer
         }
         ESCX_TS(t1)
-        if (ht + 1 < a.HT && !(ABL & 32)) issue(ht + 1, (ht + 1) & 1);
+        // The next stage's DMA is not issued in one burst after the barrier (each 1 KiB global_load_lds costs 70-180 issue cycles during
+        // which this wave feeds no MFMA, and the burst's landing slows the fc1 LDS reads) but one piece every DSTEP fragments of fc1.
+        constexpr bool SPREAD = (ABL & 256) == 0;
+        if (!SPREAD && ht + 1 < a.HT && !(ABL & 32)) issue(ht + 1, (ht + 1) & 1);
+        // SPREAD: the last stage re-loads tile HT-1 into the idle buffer (harmless) so that the loop body stays branch-free
+        const f32x4* dsrc = a.wcf + (size_t)min(ht + 1, a.HT - 1) * CH * 64 + lane;
+        f32x4* ddst = &wbuf[(ht + 1) & 1][0];
         ESCX_TS(t2)
         const f32x4 bb = bias_next;
         if (ht + 1 < a.HT) bias_next = ld4(a.b1 + 16 * (ht + 1) + 4 * lg);
@@ -230,6 +236,14 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
         for (int f = 0; f < KK; ++f) {
             const f32x4 w = ring[f % PD];
             if (f + PD < CH) ring[f % PD] = wb[(f + PD) * 64];
+            if constexpr (SPREAD) {             // one 1 KiB DMA every DSTEP fragments, all issued within the fc1 phase
+                constexpr int NDMA = (CH + NW - 1) / NW, DSTEP = KK / NDMA > 0 ? KK / NDMA : 1;
+                if (f % DSTEP == 0 && f / DSTEP < NDMA) {
+                    const int c = wave + (f / DSTEP) * NW;
+                    if (CH % NW == 0 || c < CH)
+                        __builtin_amdgcn_global_load_lds((const void*)(dsrc + c * 64), (__attribute__((address_space(3))) void*)(ddst + c * 64), 16, 0, 0);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll

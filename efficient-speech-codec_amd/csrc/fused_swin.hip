@@ -61,6 +61,10 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
             }
         }
         if (Cp == 384 && abl == 64) { launch_mlp_abl<384, 1, 4, 64>(a, s); return 0; }
+        if (abl == 256) {       // A/B: next stage's DMA issued as one burst after the barrier instead of spread over fc1
+            if (Cp == 384) { launch_mlp_abl<384, 1, 4, 256>(a, s); return 0; }
+            if (Cp == 192) { launch_mlp_abl<192, 1, 4, 256>(a, s); return 0; }
+        }
         if (Cp == 48 && abl == 64) { launch_mlp_abl<48, 1, 8, 64>(a, s); return 0; }
         variant = 1;
     }
