@@ -83,12 +83,18 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
     const int win0 = (blockIdx.x * NW + wave) * TMW;
     const int n_stages = a.n_groups * (TPG / UT);
 
-    auto issue = [&](int stage, int buf) {
-        const f32x4* src = a.wf + (size_t)stage * (UT * KK * 64) + lane;
-        for (int c = wave; c < UT * KK; c += NW)
-            __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(&wbuf[buf][c * 64]), 16, 0, 0);
+    // Weight stream: stage s+1 is DMA'd into the idle LDS buffer while stage s feeds the MFMAs.  The pieces (1 KiB each) are
+    // not issued in one burst: every tile GEMM step calls dma_piece(), which spreads the issue cost and the landing traffic.
+    const f32x4* dma_src = a.wf + lane;
+    f32x4* dma_dst = &wbuf[0][0];
+    int dma_c = wave;                           // next piece of the pending stage this wave has to issue
+    auto dma_piece = [&]() {
+        if (dma_c < UT * KK) {
+            __builtin_amdgcn_global_load_lds((const void*)(dma_src + dma_c * 64), (__attribute__((address_space(3))) void*)(dma_dst + dma_c * 64), 16, 0, 0);
+            dma_c += NW;
+        }
     };
-    issue(0, 0);
+    while (dma_c < UT * KK) dma_piece();        // stage 0 up front
 
     // ---- 1. gather + LayerNorm in registers ------------------------------------------------------
     const int nW = a.nWh * a.nWw;
@@ -141,9 +147,14 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
     int stage = 0;
     const f32x4* wb = nullptr;
     auto next_stage = [&]() {
+        while (dma_c < UT * KK) dma_piece();    // whatever is left of the pending stage
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (stage + 1 < n_stages) issue(stage + 1, (stage + 1) & 1);
+        if (stage + 1 < n_stages) {             // arm the DMA of the following stage; the pieces go out during this stage's MFMAs
+            dma_src = a.wf + (size_t)(stage + 1) * (UT * KK * 64) + lane;
+            dma_dst = &wbuf[(stage + 1) & 1][0];
+            dma_c = wave;
+        }
         wb = &wbuf[stage & 1][lane];
         ++stage;
     };
@@ -155,6 +166,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const f32x4 w = wt[kk * 64];
+            if ((kk & 1) == 0) dma_piece();
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -173,6 +185,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const f32x4 w = wt[kk * 64];
+            if ((kk & 1) == 0) dma_piece();
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
