@@ -343,12 +343,16 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
     const int pair = blockIdx.x * NW + wave;
     const int n_stages = a.n_groups * (TPG / UT);
 
-    auto issue = [&](int stage, int buf) {
-        const f32x4* src = a.wf + (size_t)stage * (UT * KK * 64) + lane;
-        for (int c = wave; c < UT * KK; c += NW)
-            __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(&wbuf[buf][c * 64]), 16, 0, 0);
+    const f32x4* dma_src = a.wf + lane;         // spread DMA issue, as in attn_fused_kernel
+    f32x4* dma_dst = &wbuf[0][0];
+    int dma_c = wave;
+    auto dma_piece = [&]() {
+        if (dma_c < UT * KK) {
+            __builtin_amdgcn_global_load_lds((const void*)(dma_src + dma_c * 64), (__attribute__((address_space(3))) void*)(dma_dst + dma_c * 64), 16, 0, 0);
+            dma_c += NW;
+        }
     };
-    issue(0, 0);
+    while (dma_c < UT * KK) dma_piece();
 
     // ---- gather: packed row j <- window (2*pair + j/8), slot (j%8) + off ; off = 8 in shifted blocks (the real rows roll down)
     const int nW = a.nWh * a.nWw;                           // nWh == 1 here
@@ -402,9 +406,14 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
     int stage = 0;
     const f32x4* wb = nullptr;
     auto next_stage = [&]() {
+        while (dma_c < UT * KK) dma_piece();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (stage + 1 < n_stages) issue(stage + 1, (stage + 1) & 1);
+        if (stage + 1 < n_stages) {
+            dma_src = a.wf + (size_t)(stage + 1) * (UT * KK * 64) + lane;
+            dma_dst = &wbuf[(stage + 1) & 1][0];
+            dma_c = wave;
+        }
         wb = &wbuf[stage & 1][lane];
         ++stage;
     };
@@ -413,6 +422,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const f32x4 w = wt[kk * 64];
+            if ((kk & 1) == 0) dma_piece();
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (x_rows) {
