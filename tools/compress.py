@@ -1,52 +1,6 @@
 #!/usr/bin/env python
-"""compress-equivalent harness (reference: scripts/compress.py:17-36) for environments without torchaudio:
-wav I/O through scipy.  Writes decoded_<kbps>kbps_<name>.wav and encoded_<kbps>kbps_<name>.esc (10-bit payload) /.pth.
-
-    python tools/compress.py --input audio.wav --model_path ./esc9kbps --num_streams 6 --device cuda
-    python tools/compress.py --input audio.wav --synthetic base --device cuda        # no checkpoint: synthetic weights
-"""
-import argparse, json, os, sys
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+"""Wrapper: the compress harness lives in efficient-speech-codec_amd/scripts/compress.py (python -m scripts.compress)."""
+import os, runpy, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "efficient-speech-codec_amd"))
-import numpy as np, torch, yaml
-from scipy.io import wavfile
-from esc.models import make_model
-from esc import bitstream, synth
-from esc.models.codecs import state_manifest
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--input", required=True); ap.add_argument("--save_path", default="./output")
-    ap.add_argument("--model_path", default=None); ap.add_argument("--synthetic", default=None, help="base|large: name-keyed synthetic weights")
-    ap.add_argument("--num_streams", type=int, default=6); ap.add_argument("--device", default="cuda")
-    a = ap.parse_args()
-    sr, pcm = wavfile.read(a.input)
-    x = pcm.astype(np.float32) / 32768.0 if pcm.dtype == np.int16 else pcm.astype(np.float32)
-    x = torch.from_numpy(np.atleast_2d(x.T if x.ndim == 2 else x)).to(a.device)          # channels are the batch (compress.py:19-20)
-    if a.model_path:
-        cfg = yaml.safe_load(open(f"{a.model_path}/config.yaml"))["model"]
-        model = make_model(cfg)
-        model.load_state_dict(torch.load(f"{a.model_path}/model.pth", map_location="cpu")["model_state_dict"])
-    else:
-        cfg = json.loads(str(np.load(os.path.join(ROOT, "tests", "golden", f"{a.synthetic or 'base'}.npz"))["config_json"]))
-        model = make_model(cfg)
-        model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(synth.synth_tensor(k, s))) for k, s in state_manifest(model.cfg).items()
-                               if not k.endswith(".window")})
-    model = model.to(a.device).eval()
-    codes, size = model.encode(x, num_streams=a.num_streams)
-    recon = model.decode(codes, size)
-    os.makedirs(a.save_path, exist_ok=True)
-    fname = os.path.basename(a.input); stem = fname.rsplit(".", 1)[0]; kbps = a.num_streams * 1.5
-    wavfile.write(f"{a.save_path}/decoded_{kbps}kbps_{fname}", sr, np.clip(recon.T.cpu().numpy().squeeze(), -1, 1))
-    torch.save(codes.cpu(), f"{a.save_path}/encoded_{kbps}kbps_{stem}.pth")
-    blob = bitstream.pack_codes(codes, size)
-    open(f"{a.save_path}/encoded_{kbps}kbps_{stem}.esc", "wb").write(blob)
-    dur = x.shape[1] / sr
-    print(f"compression outputs saved into {a.save_path}: {len(blob)} bytes for {dur:.2f} s x {x.shape[0]} ch "
-          f"= {(len(blob) - 16) * 8 / dur / x.shape[0] / 1000:.2f} kbps payload")
-
-
-if __name__ == "__main__":
-    main()
+runpy.run_module("scripts.compress", run_name="__main__")
