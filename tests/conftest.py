@@ -39,6 +39,16 @@ def synth_state(name):
     return out
 
 
+@pytest.fixture(scope="session", autouse=True)
+def built_library():
+    """libescx.so is git-ignored: build it in-tree if this checkout does not have it yet (hipcc cross-compiles without a GPU)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("escx_build", os.path.join(ROOT, "efficient-speech-codec_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build(force=False, verbose=False)
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
