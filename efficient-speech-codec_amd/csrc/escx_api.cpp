@@ -124,6 +124,8 @@ extern "C" int escx_create(const escx_config* cfg, int device, escx_handle* out)
     h->cfg = *cfg; h->device = device;
     { const char* e = getenv("ESCX_NO_FUSED"); h->use_fused = !(e && e[0] == '1'); }
     { const char* e = getenv("ESCX_MLP_VARIANT"); if (e && e[0]) h->mlp_variant = atoi(e); }
+    { const char* e = getenv("ESCX_MLP_HS"); if (e && e[0]) h->mlp_hs = atoi(e); }
+    { const char* e = getenv("ESCX_ATTN_GS"); if (e && e[0]) h->attn_gs = atoi(e); }
     { const char* e = getenv("ESCX_STREAMS"); if (e && e[0]) h->parts = std::min(std::max(atoi(e), 1), (int)escx_handle_s::MAX_PARTS); }
     { const char* e = getenv("ESCX_DEEMBED_TWO_STAGE"); h->deembed_two_stage = (e && e[0] == '1'); }
     { const char* e = getenv("ESCX_ATTN_NW"); if (e && e[0]) h->attn_nw = atoi(e); }
@@ -799,6 +801,16 @@ static int pick_nw(long long tiles, int units) {
     auto cost = [&](int nw) { const long long wg = (tiles / units + nw - 1) / nw; return ((wg + 255) / 256) * ((nw + 3) / 4) * units; };
     return cost(8) <= cost(4) ? 8 : 4;
 }
+// Hidden split of the fused MLP (fused_mlp.h): at the deep scales a clip has so few token rows (600 / 1200 at C = 384 / 192
+// for 3 s) that one wave per 16-row tile cannot fill 1024 SIMDs at serving batch sizes, so three workgroups share a row block
+// and a combine pass adds their fc2 partial sums in fixed order.  The rule depends on the layer geometry only - never on the
+// batch - so that a clip's arithmetic (and therefore its codes) is identical in any batch or shard it is processed in.
+// The partial sums live in the (otherwise unused) hidden-activation buffer of the unfused path: needs hiddenP >= 3 * Cp.
+static int mlp_hs_for(int tokens_per_clip, int HT, int Cp) { return (tokens_per_clip <= 1200 && HT % 3 == 0 && HT * 16 >= 3 * Cp) ? 3 : 1; }
+// The same split over the head groups of the fused attention (partials share the buffer; an MLP always follows on the same
+// stream).  Measured: -19 % on the isolated C = 384 kernel but neutral end to end with two parts in flight, so it is off unless
+// ESCX_ATTN_GS_TOKENS raises the limit (single-clip latency is where it pays).
+static int attn_gs_for(int tokens_per_clip, int n_groups, int hiddenP, int Cp) { static const int lim = [] { const char* e = getenv("ESCX_ATTN_GS_TOKENS"); return e && e[0] ? atoi(e) : 0; }(); return (tokens_per_clip <= lim && n_groups % 3 == 0 && hiddenP >= 3 * Cp) ? 3 : 1; }
 static int mlp_variant_for(int M) { return pick_nw((M + 15) / 16, 1) == 8 ? 3 : 1; }     // fused_swin.hip: 1 = (TM 1, NW 4), 3 = (TM 1, NW 8)
 
 // One TransformerLayer on padded token maps.  x_in is read-only; y receives (B, H'*W, CoutP).
@@ -822,9 +834,10 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             int nw = h->attn_nw ? h->attn_nw : pick_nw(Ms / 16, L.Cp <= 96 ? 2 : 1);
             if (H == 2 && W % 4 == 0 && h->attn_pack) nw = -(h->attn_nw ? h->attn_nw : pick_nw((Ms / 16 + 1) / 2, 1));    // packed half-window pairs
             const double proj_rows = nw < 0 ? dM : dMs;         // packed pairs project only the real tokens
+            const int gs = h->attn_gs > 0 ? (L.hiddenP >= h->attn_gs * L.Cp ? h->attn_gs : 1) : attn_gs_for(tokens, L.n_groups, L.hiddenP, L.Cp);
             PROF("attn_fused" + tag, 2 * proj_rows * dC * 4 * dC + 4 * dMs * 16 * dC, 2 * dM * dC * f4,
                  frc = attn_fused(src, cur, L.Cp, L.C, L.attn_mode, L.n_groups, bw.ln1_g, bw.ln1_b, bw.waf, bw.baf, bw.bias_tab_f, bw.bproj,
-                                  map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, st));
+                                  map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, gs, h->hid, M, st));
             attn_done = (frc == 0);
         }
         if (!attn_done) {
@@ -841,9 +854,10 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         }
         if (h->use_fused) {
             int frc = 0;
+            const int hs = (h->mlp_hs > 0 && L.hiddenP >= h->mlp_hs * L.Cp) ? h->mlp_hs : mlp_hs_for(tokens, L.hiddenP / 16, L.Cp);
+            const int variant = h->mlp_variant >= 0 ? h->mlp_variant : (hs > 1 ? 1 : mlp_variant_for(M));
             PROF("mlp_fused" + tag, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
-                 frc = mlp_fused(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP,
-                                 h->mlp_variant >= 0 ? h->mlp_variant : mlp_variant_for(M), st));
+                 frc = mlp_fused(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP, variant, hs, h->hid, st));
             if (frc == 0) { src = cur; continue; }
         }
         PROF("ln2" + tag, 0, 2 * dM * dC * f4,

@@ -84,6 +84,8 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     bool finalized = false;
     bool use_fused = true;           // ESCX_NO_FUSED=1 selects the unfused GEMM pipeline (A/B and fallback)
     int mlp_variant = -1;            // ESCX_MLP_VARIANT overrides the per-layer choice (tuning)
+    int attn_gs = 0;                 // ESCX_ATTN_GS: same for the head groups of the fused attention
+    int mlp_hs = 0;                  // ESCX_MLP_HS: 0 = automatic hidden split, 1 = off, n = force n-way (tuning)
     int attn_nw = 0;                 // ESCX_ATTN_NW: waves per workgroup of the fused attention kernel (4 or 8)
     bool use_fused_attn = true;      // ESCX_NO_FUSED_ATTN=1
     bool attn_pack = true;           // ESCX_NO_ATTN_PACK=1: do not pack half-real windows of the H == 2 scale

@@ -36,6 +36,9 @@ struct AttnArgs {
     const int* map;             // [slots] window slot -> token or -1
     int slots, tokens, n_windows, nWh, nWw, shifted, C, n_groups;
     float scale, eps;
+    // Head-group split (same idea as MlpArgs::HS): workgroup (wb, gs) walks head groups [gs*n_groups/GS, (gs+1)*n_groups/GS) and
+    // stores its projection partial sums to partial[gs][rows][CP]; rows_combine_kernel adds them in fixed order.
+    int GS; float* partial; int rows;
 };
 
 // softmax over the 16 keys of one query row held as 4 values x 4 lane groups (attention.py:226-238)
@@ -80,12 +83,16 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: keeps the DMA issue loop scalar
-    const int win0 = (blockIdx.x * NW + wave) * TMW;
-    const int n_stages = a.n_groups * (TPG / UT);
+    const int GS = a.GS > 1 ? a.GS : 1;
+    const int wgb = blockIdx.x / GS, gs = blockIdx.x - wgb * GS;
+    const int g0 = gs * (a.n_groups / GS), g1 = g0 + a.n_groups / GS;
+    const int win0 = (wgb * NW + wave) * TMW;
+    const int n_stages = (g1 - g0) * (TPG / UT);
+    const f32x4* wfb = a.wf + (size_t)g0 * TPG * KK * 64;
 
     // Weight stream: stage s+1 is DMA'd into the idle LDS buffer while stage s feeds the MFMAs.  The pieces (1 KiB each) are
     // not issued in one burst: every tile GEMM step calls dma_piece(), which spreads the issue cost and the landing traffic.
-    const f32x4* dma_src = a.wf + lane;
+    const f32x4* dma_src = wfb + lane;
     f32x4* dma_dst = &wbuf[0][0];
     int dma_c = wave;                           // next piece of the pending stage this wave has to issue
     auto dma_piece = [&]() {
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (stage + 1 < n_stages) {             // arm the DMA of the following stage; the pieces go out during this stage's MFMAs
-            dma_src = a.wf + (size_t)(stage + 1) * (UT * KK * 64) + lane;
+            dma_src = wfb + (size_t)(stage + 1) * (UT * KK * 64) + lane;
             dma_dst = &wbuf[(stage + 1) & 1][0];
             dma_c = wave;
         }
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
     };
 
     // ---- 2. head groups ----------------------------------------------------------------------------
-    for (int g = 0; g < a.n_groups; ++g) {
+    for (int g = g0; g < g1; ++g) {
         const float* bg = a.bqkv + (size_t)g * NB * 16;
         int tile = 0;
         auto tile_ptr = [&]() -> const f32x4* {
@@ -309,6 +316,16 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
     }
 
     // ---- 3. bias + shortcut, scatter through the map ----------------------------------------------
+    if (GS > 1) {
+#pragma unroll
+        for (int t = 0; t < TMW; ++t) {
+            if (tok[t] < 0) continue;
+            float* pr = a.partial + ((size_t)gs * a.rows + tok[t]) * CP + 4 * lg;
+#pragma unroll
+            for (int o = 0; o < KK; ++o) st4(pr + 16 * o, acc[o][t]);
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < TMW; ++t) {
         if (tok[t] < 0) continue;
@@ -340,10 +357,14 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = blockIdx.x * NW + wave;
-    const int n_stages = a.n_groups * (TPG / UT);
+    const int GS = a.GS > 1 ? a.GS : 1;
+    const int wgb = blockIdx.x / GS, gs = blockIdx.x - wgb * GS;
+    const int g0 = gs * (a.n_groups / GS), g1 = g0 + a.n_groups / GS;
+    const int pair = wgb * NW + wave;
+    const int n_stages = (g1 - g0) * (TPG / UT);
+    const f32x4* wfb = a.wf + (size_t)g0 * TPG * KK * 64;
 
-    const f32x4* dma_src = a.wf + lane;         // spread DMA issue, as in attn_fused_kernel
+    const f32x4* dma_src = wfb + lane;          // spread DMA issue, as in attn_fused_kernel
     f32x4* dma_dst = &wbuf[0][0];
     int dma_c = wave;
     auto dma_piece = [&]() {
@@ -410,7 +431,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (stage + 1 < n_stages) {
-            dma_src = a.wf + (size_t)(stage + 1) * (UT * KK * 64) + lane;
+            dma_src = wfb + (size_t)(stage + 1) * (UT * KK * 64) + lane;
             dma_dst = &wbuf[(stage + 1) & 1][0];
             dma_c = wave;
         }
@@ -437,7 +458,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
         return o1 + o2;
     };
 
-    for (int g = 0; g < a.n_groups; ++g) {
+    for (int g = g0; g < g1; ++g) {
         const float* bg = a.bqkv + (size_t)g * 3 * 16;
         int tile = 0;
         auto tile_ptr = [&]() -> const f32x4* {
@@ -493,6 +514,14 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
         }
     }
 
+    if (GS > 1) {
+        if (tok >= 0) {
+            float* pr = a.partial + ((size_t)gs * a.rows + tok) * CP + 4 * lg;
+#pragma unroll
+            for (int o = 0; o < KK; ++o) st4(pr + 16 * o, acc[o]);
+        }
+        return;
+    }
     if (tok >= 0) {
         const float* sr = a.src + (size_t)tok * CP + 4 * lg;
         float* dr = a.dst + (size_t)tok * CP + 4 * lg;

@@ -29,6 +29,10 @@ struct MlpArgs {
     int M, C, HT;
     float eps;
     unsigned long long* trace;                  // debug (ABL bit 64): per-wave cycle sums of the main-loop phases
+    // Hidden split (LDS-staged kernel only): with fewer row tiles than SIMDs (deep layers at small batch) the grid is
+    // row-blocks x HS and workgroup (rb, hs) walks hidden tiles [hs*HT/HS, (hs+1)*HT/HS); the fc2 partial sums go to
+    // partial[hs][M][CP] and mlp_combine_kernel adds them in fixed order (deterministic, no atomics).
+    int HS; float* partial;
 };
 
 template <int CP, int TM>
@@ -154,14 +158,17 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: keeps the DMA issue loop scalar
-    const int m0 = (blockIdx.x * NW + wave) * (16 * TM);
+    const int HS = a.HS > 1 ? a.HS : 1;
+    const int rb = blockIdx.x / HS, hs = blockIdx.x - rb * HS;
+    const int ht0 = hs * (a.HT / HS), ht1 = ht0 + a.HT / HS;
+    const int m0 = (rb * NW + wave) * (16 * TM);
 
     auto issue = [&](int ht, int buf) {
         const f32x4* src = a.wcf + (size_t)ht * CH * 64 + lane;
         for (int c = wave; c < CH; c += NW)
             __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(&wbuf[buf][c * 64]), 16, 0, 0);
     };
-    issue(0, 0);
+    issue(ht0, ht0 & 1);
 
     f32x4 xf[TM][KK];
     float mean[TM], rstd[TM];
@@ -202,11 +209,11 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
 #pragma unroll
         for (int t = 0; t < TM; ++t) acc[o][t] = zero4();
 
-    f32x4 bias_next = ld4(a.b1 + 4 * lg);      // fc1 bias of tile 0; later tiles are fetched one stage ahead
+    f32x4 bias_next = ld4(a.b1 + 16 * ht0 + 4 * lg);      // fc1 bias of the first tile; later tiles are fetched one stage ahead
     unsigned long long tr[6] = {0, 0, 0, 0, 0, 0};
 #define ESCX_TS(var) unsigned long long var = 0; if (ABL & 64) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
     ESCX_TS(t_begin)
-    for (int ht = 0; ht < a.HT; ++ht) {
+    for (int ht = ht0; ht < ht1; ++ht) {
         ESCX_TS(t0)
         if (!(ABL & 2)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -216,13 +223,13 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
         // The next stage's DMA is not issued in one burst after the barrier (each 1 KiB global_load_lds costs 70-180 issue cycles during
         // which this wave feeds no MFMA, and the burst's landing slows the fc1 LDS reads) but one piece every DSTEP fragments of fc1.
         constexpr bool SPREAD = (ABL & 256) == 0;
-        if (!SPREAD && ht + 1 < a.HT && !(ABL & 32)) issue(ht + 1, (ht + 1) & 1);
-        // SPREAD: the last stage re-loads tile HT-1 into the idle buffer (harmless) so that the loop body stays branch-free
-        const f32x4* dsrc = a.wcf + (size_t)min(ht + 1, a.HT - 1) * CH * 64 + lane;
+        if (!SPREAD && ht + 1 < ht1 && !(ABL & 32)) issue(ht + 1, (ht + 1) & 1);
+        // SPREAD: the last stage re-loads its own tile into the idle buffer (harmless) so that the loop body stays branch-free
+        const f32x4* dsrc = a.wcf + (size_t)min(ht + 1, ht1 - 1) * CH * 64 + lane;
         f32x4* ddst = &wbuf[(ht + 1) & 1][0];
         ESCX_TS(t2)
         const f32x4 bb = bias_next;
-        if (ht + 1 < a.HT) bias_next = ld4(a.b1 + 16 * (ht + 1) + 4 * lg);
+        if (ht + 1 < ht1) bias_next = ld4(a.b1 + 16 * (ht + 1) + 4 * lg);
         const f32x4* wb = (ABL & 4) ? &wbuf[0][0] : &wbuf[ht & 1][lane];
 
         // fragment ring: the LDS read of fragment f + PD is in flight while fragment f feeds the MFMAs
@@ -305,6 +312,17 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
     }
 #undef ESCX_TS
 
+    if (HS > 1) {               // raw fc2 partial sums; bias + residual are applied by mlp_combine_kernel
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int row = m0 + t * 16 + l15;
+            if (row >= a.M) continue;
+            float* pr = a.partial + ((size_t)hs * a.M + row) * CP + 4 * lg;
+#pragma unroll
+            for (int o = 0; o < KK; ++o) st4(pr + 16 * o, acc[o][t]);
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         const int row = m0 + t * 16 + l15;
@@ -316,6 +334,21 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
             st4(xr + 16 * o, ld4(xr + 16 * o) + v);
         }
     }
+}
+
+
+// dst = src + (((P0 + P1) + ... + P_{n-1}) + bias) : fixed summation order, 16 B per lane, HBM-bound ((n + 2) * M * CP * 4 bytes).
+// Second pass of the hidden-split MLP and of the head-group-split attention (dst may alias src).
+__global__ __launch_bounds__(256) void rows_combine_kernel(float* dst, const float* src, const float* __restrict__ partial,
+                                                           const float* __restrict__ bias, long long M, int CP, int n) {
+    const long long n4 = M * CP / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % CP);
+    f32x4 v = ld4(partial + i * 4);
+    for (int h = 1; h < n; ++h) v += ld4(partial + ((size_t)h * M * CP) + i * 4);
+    v += ld4(bias + c);
+    st4(dst + i * 4, ld4(src + i * 4) + v);
 }
 
 }  // namespace escx
