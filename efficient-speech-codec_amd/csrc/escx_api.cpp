@@ -834,11 +834,13 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             int nw = h->attn_nw ? h->attn_nw : pick_nw(Ms / 16, L.Cp <= 96 ? 2 : 1);
             if (H == 2 && W % 4 == 0 && h->attn_pack) nw = -(h->attn_nw ? h->attn_nw : pick_nw((Ms / 16 + 1) / 2, 1));    // packed half-window pairs
             const double proj_rows = nw < 0 ? dM : dMs;         // packed pairs project only the real tokens
-            const int gs = h->attn_gs > 0 ? (L.hiddenP >= h->attn_gs * L.Cp ? h->attn_gs : 1) : attn_gs_for(tokens, L.n_groups, L.hiddenP, L.Cp);
+            int gs = h->attn_gs > 0 ? (L.hiddenP >= h->attn_gs * L.Cp ? h->attn_gs : 1) : attn_gs_for(tokens, L.n_groups, L.hiddenP, L.Cp);
             PROF("attn_fused" + tag, 2 * proj_rows * dC * 4 * dC + 4 * dMs * 16 * dC, 2 * dM * dC * f4,
                  frc = attn_fused(src, cur, L.Cp, L.C, L.attn_mode, L.n_groups, bw.ln1_g, bw.ln1_b, bw.waf, bw.baf, bw.bias_tab_f, bw.bproj,
-                                  map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, gs, h->hid, M, st));
+                                  map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, &gs, h->hid, M, st));
             attn_done = (frc == 0);
+            if (attn_done && gs > 1)
+                PROF("attn_combine" + tag, 0, (gs + 2) * dM * L.Cp * f4, rows_combine(cur, src, h->hid, bw.bproj, M, L.Cp, gs, st));
         }
         if (!attn_done) {
         PROF("ln1_gather" + tag, 0, (dM + dMs) * dC * f4,
@@ -854,10 +856,12 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         }
         if (h->use_fused) {
             int frc = 0;
-            const int hs = (h->mlp_hs > 0 && L.hiddenP >= h->mlp_hs * L.Cp) ? h->mlp_hs : mlp_hs_for(tokens, L.hiddenP / 16, L.Cp);
+            int hs = (h->mlp_hs > 0 && L.hiddenP >= h->mlp_hs * L.Cp) ? h->mlp_hs : mlp_hs_for(tokens, L.hiddenP / 16, L.Cp);
             const int variant = h->mlp_variant >= 0 ? h->mlp_variant : (hs > 1 ? 1 : mlp_variant_for(M));
             PROF("mlp_fused" + tag, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
-                 frc = mlp_fused(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP, variant, hs, h->hid, st));
+                 frc = mlp_fused(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP, variant, &hs, h->hid, st));
+            if (frc == 0 && hs > 1)
+                PROF("mlp_combine" + tag, 0, (hs + 2) * dM * L.Cp * f4, rows_combine(cur, cur, h->hid, bw.b2, M, L.Cp, hs, st));
             if (frc == 0) { src = cur; continue; }
         }
         PROF("ln2" + tag, 0, 2 * dM * dC * f4,

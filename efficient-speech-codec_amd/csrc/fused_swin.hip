@@ -17,10 +17,6 @@ static void launch_mlp_lds(const MlpArgs& a, hipStream_t s) {
     const int rows = 16 * TM * NW;
     const int hs = a.HS > 1 ? a.HS : 1;
     hipLaunchKernelGGL((mlp_fused_lds_kernel<CP, TM, NW>), dim3(((a.M + rows - 1) / rows) * hs), dim3(64 * NW), 0, s, a);
-    if (hs > 1) {
-        const long long n4 = (long long)a.M * CP / 4;
-        hipLaunchKernelGGL(rows_combine_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.x, (const float*)a.x, (const float*)a.partial, a.b2, (long long)a.M, CP, hs);
-    }
 }
 
 // variant: 0 = wave-autonomous; otherwise LDS-staged with (TM, NW) = 1:(1,4) 2:(1,6) 3:(1,8) 4:(2,4) 5:(2,8)
@@ -45,9 +41,18 @@ static void launch_mlp_abl(const MlpArgs& a, hipStream_t s) {
 static unsigned long long* g_mlp_trace = nullptr;      // debug only (ESCX_MLP_VARIANT=164): 8 x u64 per wave, see fused_mlp.h
 void mlp_set_trace(unsigned long long* p) { g_mlp_trace = p; }
 
+void rows_combine(float* dst, const float* src, const float* partial, const float* bias, long long M, int Cp, int n, hipStream_t s) {
+    const long long n4 = M * Cp / 4;
+    hipLaunchKernelGGL(rows_combine_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dst, src, partial, bias, M, Cp, n);
+}
+
+// *hs: requested hidden split in, split actually used out (> 1: x is untouched, partial[hs][M][Cp] is filled, the caller runs rows_combine)
 int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* w1f, const float* b1,
-              const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, int hs, float* partial, hipStream_t s) {
-    if (hs > 1 && (variant <= 0 || variant >= 100 || !partial || (hiddenP / 16) % hs)) hs = 1;
+              const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, int* hs_io, float* partial, hipStream_t s) {
+    int hs = hs_io ? *hs_io : 1;
+    const bool lds_width = Cp == 48 || Cp == 80 || Cp == 96 || Cp == 144 || Cp == 192 || Cp == 384;
+    if (hs > 1 && (variant <= 0 || variant >= 100 || variant > 3 || !lds_width || !partial || (hiddenP / 16) % hs)) hs = 1;
+    if (hs_io) *hs_io = hs;
     MlpArgs a{x, gamma, beta, reinterpret_cast<const f32x4*>(w1f), b1, reinterpret_cast<const f32x4*>(w2f), b2,
               reinterpret_cast<const f32x4*>(wcf), M, C, hiddenP / 16, 1e-5f, g_mlp_trace, hs, partial};
     if (variant >= 100) {      // timing-only ablations: variant = 100 + ABL bits
@@ -144,14 +149,6 @@ int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, cons
 }
 
 // ---- fused window attention --------------------------------------------------------------------
-template <int CP>
-static void attn_combine(const AttnArgs& a, hipStream_t s) {
-    if (a.GS <= 1) return;
-    const long long n4 = (long long)a.rows * CP / 4;
-    hipLaunchKernelGGL(rows_combine_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.dst, a.src, (const float*)a.partial, a.bproj,
-                       (long long)a.rows, CP, a.GS);
-}
-
 template <int CP, int MODE, int NW>
 static void launch_attn(const AttnArgs& a, hipStream_t s) {
     constexpr int UT = CP <= 96 ? 4 : (CP <= 192 ? 2 : 1);
@@ -159,7 +156,6 @@ static void launch_attn(const AttnArgs& a, hipStream_t s) {
     const int per_block = TMW * NW;
     const int gs = a.GS > 1 ? a.GS : 1;
     hipLaunchKernelGGL((attn_fused_kernel<CP, MODE, UT, TMW, NW>), dim3(((a.n_windows + per_block - 1) / per_block) * gs), dim3(64 * NW), 0, s, a);
-    attn_combine<CP>(a, s);
 }
 
 template <int CP>
@@ -186,13 +182,14 @@ static void launch_attn_packed(const AttnArgs& a, hipStream_t s) {
     const int pairs = (a.n_windows + 1) / 2;
     const int gs = a.GS > 1 ? a.GS : 1;
     hipLaunchKernelGGL((attn_packed_kernel<CP, UT, NW>), dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), 0, s, a);
-    attn_combine<CP>(a, s);
 }
 
 int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_groups, const float* gamma, const float* beta,
                const float* wf, const float* bqkv, const float* bias_tab, const float* bproj, const int* map, int slots, int tokens,
-               int n_windows, int nWh, int nWw, int shifted, float scale, int nw, int gs, float* partial, int rows, hipStream_t s) {
+               int n_windows, int nWh, int nWw, int shifted, float scale, int nw, int* gs_io, float* partial, int rows, hipStream_t s) {
+    int gs = gs_io ? *gs_io : 1;        // head-group split: same in/out convention as mlp_fused
     if (gs > 1 && (!partial || n_groups % gs)) gs = 1;
+    if (gs_io) *gs_io = gs;
     AttnArgs a{src, dst, gamma, beta, reinterpret_cast<const f32x4*>(wf), bqkv, bias_tab, bproj, map, slots, tokens, n_windows,
                nWh, nWw, shifted, C, n_groups, scale, 1e-5f, gs, partial, rows};
     // H == 2 scale with no padding along W: two half-real windows share one tile (nw < 0 encodes "packing allowed", |nw| waves)

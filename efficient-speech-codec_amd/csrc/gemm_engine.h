@@ -250,7 +250,24 @@ __device__ __forceinline__ float erf_bf(float x) {
     const float b = copysignf(1.0f - exp_fast(r), x);
     return t <= 0.92f ? a : b;
 }
-__device__ __forceinline__ float gelu_bf(float x) { return 0.5f * x * (1.0f + erf_bf(x * 0.70710678118654752440f)); }
+// Exact-erf GELU of the fused kernels, 13 straight-line VALU ops (the erf_bf form above costs 29, and at C <= 96 the fused MLP
+// issues more VALU than the matrix pipe can hide):  gelu(x) = x*Phi(x) = max(x, 0) - 0.5*|x| * erfc(|x|/sqrt2), with
+// erfc(a/sqrt2) = 2^Q8(a) fitted on [0, 5.8] (weighted minimax on the GELU's absolute error, fp64; beyond 5.8 the term is < 4e-8).
+// |gelu_bf - gelu| <= 1.25 * 2^-24 * max(|x|, 1) over the whole line - the 0.5*x*(1 + erff(x/sqrt2)) evaluation of the
+// reference measures 1.8 on the same scale (1 + erf loses the tail to rounding); escx_test_math / test_device_math re-check both.
+__device__ __forceinline__ float gelu_bf(float x) {
+    const float a = fminf(fabsf(x), 5.8f);
+    float r = -1.6904631365832756e-06f;
+    r = fmaf(r, a, 2.5084045773837715e-05f);
+    r = fmaf(r, a, -0.0001144662601291202f);
+    r = fmaf(r, a, -0.0003233331080991775f);
+    r = fmaf(r, a, 0.007333371322602034f);
+    r = fmaf(r, a, -0.052714187651872635f);
+    r = fmaf(r, a, -0.4591154456138611f);
+    r = fmaf(r, a, -1.151123285293579f);
+    r = fmaf(r, a, 1.126017423302983e-06f);
+    return fmaf(-0.5f * fabsf(x), __builtin_amdgcn_exp2f(r), fmaxf(x, 0.0f));
+}
 
 struct EpiStore {               // out[m][n] = v (+ bias[n])
     float* out; int ldo; const float* bias;

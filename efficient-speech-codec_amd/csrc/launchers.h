@@ -17,7 +17,8 @@ void gemm_split(const float* A, int lda, int M, const float* W, int Np, int Kp, 
 
 // ---- fused register-resident Swin kernels (fused_swin.hip); return -1 when the width is not instantiated ----
 int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* w1f, const float* b1,
-              const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, int hs, float* partial, hipStream_t s);
+              const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, int* hs_io, float* partial, hipStream_t s);
+void rows_combine(float* dst, const float* src, const float* partial, const float* bias, long long M, int Cp, int n, hipStream_t s);
 
 // LN + linear for PatchMerge (segs = 2, map gives the two source rows) / PatchSplit (segs = 1, split = 1: pixel-shuffled store)
 int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, const float* beta, const float* wf, const int* map, int M,
@@ -26,7 +27,7 @@ void mlp_set_trace(unsigned long long* p);
 // mode: 0 one head (<=16 dims) per tile, 1 two heads (<=8 dims) per tile, 2 one head (<=32 dims) over two tiles
 int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_groups, const float* gamma, const float* beta,
                const float* wf, const float* bqkv, const float* bias_tab, const float* bproj, const int* map, int slots, int tokens,
-               int n_windows, int nWh, int nWw, int shifted, float scale, int nw, int gs, float* partial, int rows, hipStream_t s);
+               int n_windows, int nWh, int nWw, int shifted, float scale, int nw, int* gs_io, float* partial, int rows, hipStream_t s);
 
 // ---- everything else that is a contraction (gemm_misc.hip) ----
 void gemm_frames(const float* wave, int B, int L, int T, int hop, int off, const float* W, int Np, int Kp, float* out, hipStream_t s);
