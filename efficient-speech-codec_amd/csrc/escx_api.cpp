@@ -831,8 +831,8 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         bool attn_done = false;
         if (h->use_fused && h->use_fused_attn && L.attn_mode >= 0) {
             int frc = 0;
-            int nw = h->attn_nw ? h->attn_nw : pick_nw(Ms / 16, L.Cp <= 96 ? 2 : 1);
-            if (H == 2 && W % 4 == 0 && h->attn_pack) nw = -(h->attn_nw ? h->attn_nw : pick_nw((Ms / 16 + 1) / 2, 1));    // packed half-window pairs
+            int nw = h->attn_nw ? h->attn_nw : (L.Cp > 192 ? 4 : pick_nw(Ms / 16, L.Cp <= 96 ? 2 : 1));    // 8 waves cap the kernel at 256 VGPRs: spills above C = 192
+            if (H == 2 && W % 4 == 0 && h->attn_pack) nw = -(h->attn_nw ? h->attn_nw : (L.Cp > 192 ? 4 : pick_nw((Ms / 16 + 1) / 2, 1)));    // packed half-window pairs
             const double proj_rows = nw < 0 ? dM : dMs;         // packed pairs project only the real tokens
             int gs = h->attn_gs > 0 ? (L.hiddenP >= h->attn_gs * L.Cp ? h->attn_gs : 1) : attn_gs_for(tokens, L.n_groups, L.hiddenP, L.Cp);
             PROF("attn_fused" + tag, 2 * proj_rows * dC * 4 * dC + 4 * dMs * 16 * dC, 2 * dM * dC * f4,

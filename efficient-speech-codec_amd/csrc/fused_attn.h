@@ -42,8 +42,8 @@ struct AttnArgs {
 };
 
 // softmax over the 16 keys of one query row held as 4 values x 4 lane groups (attention.py:226-238)
-__device__ __forceinline__ f32x4 window_softmax(f32x4 s, const float* bias_h, int l15, int lg, bool shifted, bool lastH, bool lastW) {
-    s += ld4(bias_h + l15 * 16 + 4 * lg);
+__device__ __forceinline__ f32x4 window_softmax(f32x4 s, f32x4 bias_row, int l15, int lg, bool shifted, bool lastH, bool lastW) {
+    s += bias_row;              // bias_tab[head][query l15][keys 4lg..4lg+3], loaded by the caller a whole GEMM ahead of its use
     if (shifted) {
         const int qh = l15 >> 2, qw = l15 & 3;
         const int labq = 3 * (lastH ? (qh < 2 ? 1 : 2) : 0) + (lastW ? (qw < 2 ? 1 : 2) : 0);
@@ -55,14 +55,12 @@ __device__ __forceinline__ f32x4 window_softmax(f32x4 s, const float* bias_h, in
         }
     }
     float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = max_groups(mx);
     f32x4 p;
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[r] = exp_fast(s[r] - mx);
     float den = (p[0] + p[1]) + (p[2] + p[3]);
-    den += __shfl_xor(den, 16);
-    den += __shfl_xor(den, 32);
+    den = sum_groups(den);
     const float inv = 1.0f / den;
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[r] *= inv;
@@ -70,7 +68,10 @@ __device__ __forceinline__ f32x4 window_softmax(f32x4 s, const float* bias_h, in
 }
 
 // register budget capped for 3-4 waves per SIMD where the tile sizes allow (same reasoning as the fused MLP)
-template <int CP, int TMW> constexpr int attn_min_waves() { return (CP * TMW <= 96) ? 4 : ((CP * TMW <= 192) ? 3 : 1); }
+#ifndef ESCX_ATTN_OCC3
+#define ESCX_ATTN_OCC3 160
+#endif
+template <int CP, int TMW> constexpr int attn_min_waves() { return (CP * TMW <= 96) ? 4 : ((CP * TMW <= ESCX_ATTN_OCC3) ? 3 : ((CP * TMW <= 192) ? 2 : 1)); }
 
 template <int CP, int MODE, int UT, int TMW, int NW>
 __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fused_kernel(AttnArgs a) {
@@ -90,18 +91,24 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
     const int n_stages = (g1 - g0) * (TPG / UT);
     const f32x4* wfb = a.wf + (size_t)g0 * TPG * KK * 64;
 
-    // Weight stream: stage s+1 is DMA'd into the idle LDS buffer while stage s feeds the MFMAs.  The pieces (1 KiB each) are
-    // not issued in one burst: every tile GEMM step calls dma_piece(), which spreads the issue cost and the landing traffic.
+    // Weight stream: stage s+1 is DMA'd into the idle LDS buffer while stage s feeds the MFMAs.  The NPW pieces (1 KiB each) a
+    // wave owes per stage are not issued in one burst but one per dma_slot() call, which the tile GEMMs make every other
+    // k-step.  `slot` is a compile-time constant after unrolling, so the schedule is static and branch-free: the compiler
+    // can count the VMEM operations in flight (precise vmcnt for the bias loads) and schedule across the whole stage.
+    constexpr int NP = UT * KK, NPW = (NP + NW - 1) / NW;
     const f32x4* dma_src = wfb + lane;
     f32x4* dma_dst = &wbuf[0][0];
-    int dma_c = wave;                           // next piece of the pending stage this wave has to issue
-    auto dma_piece = [&]() {
-        if (dma_c < UT * KK) {
-            __builtin_amdgcn_global_load_lds((const void*)(dma_src + dma_c * 64), (__attribute__((address_space(3))) void*)(dma_dst + dma_c * 64), 16, 0, 0);
-            dma_c += NW;
+    int slot = 0;
+    auto dma_slot = [&]() {
+        if (slot < NPW) {
+            int c = wave + slot * NW;
+            if (NP % NW != 0) c = min(c, NP - 1);       // tail: a duplicate of the last piece (same bytes, harmless)
+            __builtin_amdgcn_global_load_lds((const void*)(dma_src + c * 64), (__attribute__((address_space(3))) void*)(dma_dst + c * 64), 16, 0, 0);
         }
+        ++slot;
     };
-    while (dma_c < UT * KK) dma_piece();        // stage 0 up front
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) dma_slot();   // stage 0 up front
 
     // ---- 1. gather + LayerNorm in registers ------------------------------------------------------
     const int nW = a.nWh * a.nWw;
@@ -127,14 +134,14 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) s += xf[t][kk][e];
         }
-        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        s = sum_groups(s);
         const float mean = s / (float)a.C;
         float v = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) { const float d = xf[t][kk][e] - mean; v += d * d; }
-        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        v = sum_groups(v);
         const float rstd = 1.0f / sqrtf(v / (float)a.C + a.eps);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
@@ -151,29 +158,55 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
 #pragma unroll
         for (int t = 0; t < TMW; ++t) acc[o][t] = zero4();
 
-    int stage = 0;
+    // LDS -> register fragment ring over the whole stage (UT tiles = NP consecutive 1 KiB fragments): the read of fragment
+    // f + PD is in flight while fragment f feeds the MFMAs, across tile boundaries; only the first PD reads of a stage are
+    // exposed.  `frag` and `slot` are compile-time constants after unrolling.  The sched_group_barrier sequence pins the order
+    // (hipcc otherwise sinks each ds_read to its first use and waits, and sinks every DMA piece to the end of the stage where
+    // the vmcnt(0) before the next barrier would wait out the whole L2 round trip).
+    constexpr int PD = NP < 3 ? NP : 3;
+#define ESCX_SGB_DS() __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)
+#define ESCX_SGB_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
+#define ESCX_SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+    int stage = 0, frag = 0;
     const f32x4* wb = nullptr;
+    f32x4 ring[PD];
     auto next_stage = [&]() {
-        while (dma_c < UT * KK) dma_piece();    // whatever is left of the pending stage
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) dma_slot();               // whatever is left of the pending stage (none when the GEMMs offered enough slots)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (stage + 1 < n_stages) {             // arm the DMA of the following stage; the pieces go out during this stage's MFMAs
-            dma_src = wfb + (size_t)(stage + 1) * (UT * KK * 64) + lane;
-            dma_dst = &wbuf[(stage + 1) & 1][0];
-            dma_c = wave;
-        }
+        // arm the DMA of the following stage; after the last one its own tiles are re-loaded into the idle buffer (harmless)
+        dma_src = wfb + (size_t)min(stage + 1, n_stages - 1) * (UT * KK * 64) + lane;
+        dma_dst = &wbuf[(stage + 1) & 1][0];
+        slot = 0;
         wb = &wbuf[stage & 1][lane];
         ++stage;
+        frag = 0;
+#pragma unroll
+        for (int i = 0; i < PD; ++i) { ring[i] = wb[i * 64]; ESCX_SGB_DS(); }
     };
+    auto next_frag = [&]() -> f32x4 {
+        const f32x4 w = ring[frag % PD];
+        if (frag + PD < NP) { ring[frag % PD] = wb[(frag + PD) * 64]; ESCX_SGB_DS(); }
+        ++frag;
+        return w;
+    };
+    auto dma_pinned = [&]() {
+        const bool issues = slot < NPW;
+        dma_slot();
+        if (issues) ESCX_SGB_VMEM(1);
+    };
+    int tile = 0;
+    auto begin_tile = [&]() { if (tile % UT == 0) next_stage(); ++tile; };
     // tile GEMM with the weight tile as the row operand: out[t] = W_tile . x^T  -> lane (token l15, rows 4lg + r)
-    auto gemm_w_rows = [&](const f32x4* wt, f32x4* out) {
+    auto gemm_w_rows = [&](f32x4* out) {
         f32x4 o2[TMW];
 #pragma unroll
         for (int t = 0; t < TMW; ++t) { out[t] = zero4(); o2[t] = zero4(); }
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            const f32x4 w = wt[kk * 64];
-            if ((kk & 1) == 0) dma_piece();
+            const f32x4 w = next_frag();
+            if ((kk & 1) == 0) dma_pinned();
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -181,18 +214,19 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
                     if (TMW == 1 && (r & 1)) o2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xf[t][kk][r], o2[t], 0, 0, 0);
                     else out[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xf[t][kk][r], out[t], 0, 0, 0);
                 }
+            ESCX_SGB_MFMA(4 * TMW);
         }
         if (TMW == 1) out[0] += o2[0];
     };
     // swapped: out[t] = x . W_tile^T -> lane (row l15 of the weight tile, tokens 4lg + r)
-    auto gemm_x_rows = [&](const f32x4* wt, f32x4* out) {
+    auto gemm_x_rows = [&](f32x4* out) {
         f32x4 o2[TMW];
 #pragma unroll
         for (int t = 0; t < TMW; ++t) { out[t] = zero4(); o2[t] = zero4(); }
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            const f32x4 w = wt[kk * 64];
-            if ((kk & 1) == 0) dma_piece();
+            const f32x4 w = next_frag();
+            if ((kk & 1) == 0) dma_pinned();
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -200,14 +234,17 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
                     if (TMW == 1 && (r & 1)) o2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[t][kk][r], w[r], o2[t], 0, 0, 0);
                     else out[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[t][kk][r], w[r], out[t], 0, 0, 0);
                 }
+            ESCX_SGB_MFMA(4 * TMW);
         }
         if (TMW == 1) out[0] += o2[0];
     };
-    auto proj_accumulate = [&](const f32x4* wt, const f32x4* o) {
+    auto proj_accumulate = [&](const f32x4* o) {
 #pragma unroll
         for (int to = 0; to < KK; to += 2) {    // two output tiles per step: no back-to-back MFMAs on one accumulator
-            const f32x4 w = wt[to * 64];
-            const f32x4 wn = (to + 1 < KK) ? wt[(to + 1) * 64] : zero4();
+            const f32x4 w = next_frag();
+            f32x4 wn = zero4();
+            if (to + 1 < KK) wn = next_frag();
+            dma_pinned();
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -215,29 +252,54 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
                     acc[to][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], o[t][r], acc[to][t], 0, 0, 0);
                     if (to + 1 < KK) acc[to + 1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[r], o[t][r], acc[to + 1][t], 0, 0, 0);
                 }
+            if (to + 1 < KK) ESCX_SGB_MFMA(8 * TMW); else ESCX_SGB_MFMA(4 * TMW);
         }
     };
 
-    // ---- 2. head groups ----------------------------------------------------------------------------
-    for (int g = g0; g < g1; ++g) {
+    // Per-group constants (q/k/v biases, relative-position bias rows) are fetched one head group ahead, right behind a stage
+    // barrier: they land under a whole group of MFMA work, and the no-op pin behind the next group's first barrier (whose
+    // vmcnt(0) has already drained everything) keeps the compiler from waiting at their first use with this stage's DMA in flight.
+    struct GroupConst { f32x4 b[4]; f32x4 bt0, bt1; float bv0, bv1; };
+    auto load_consts = [&](int g) -> GroupConst {
+        GroupConst c;
         const float* bg = a.bqkv + (size_t)g * NB * 16;
-        int tile = 0;
-        auto tile_ptr = [&]() -> const f32x4* {
-            if (tile % UT == 0) next_stage();
-            const f32x4* p = wb + (tile % UT) * KK * 64;
-            ++tile;
-            return p;
-        };
+        if constexpr (MODE != 2) {
+            c.b[0] = ld4(bg + 4 * lg); c.b[1] = ld4(bg + 16 + 4 * lg); c.b[2] = zero4(); c.b[3] = zero4();
+            c.bv0 = bg[32 + l15]; c.bv1 = 0.f;
+            const float* bt = a.bias_tab + (size_t)(MODE == 1 ? 2 * g : g) * 256 + l15 * 16 + 4 * lg;
+            c.bt0 = ld4(bt); c.bt1 = (MODE == 1) ? ld4(bt + 256) : zero4();
+            ESCX_SGB_VMEM(MODE == 1 ? 5 : 4);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c.b[i] = ld4(bg + i * 16 + 4 * lg);
+            c.bv0 = bg[4 * 16 + l15]; c.bv1 = bg[5 * 16 + l15];
+            c.bt0 = ld4(a.bias_tab + (size_t)g * 256 + l15 * 16 + 4 * lg); c.bt1 = zero4();
+            ESCX_SGB_VMEM(7);
+        }
+        return c;
+    };
+    auto pin_consts = [&](GroupConst& c) {
+        asm volatile("" : "+v"(c.b[0]), "+v"(c.b[1]), "+v"(c.bt0), "+v"(c.bv0));
+        if constexpr (MODE == 1) asm volatile("" : "+v"(c.bt1));
+        if constexpr (MODE == 2) asm volatile("" : "+v"(c.b[2]), "+v"(c.b[3]), "+v"(c.bv1));
+    };
+
+    // ---- 2. head groups ----------------------------------------------------------------------------
+    GroupConst cur = load_consts(g0);
+    for (int g = g0; g < g1; ++g) {
+        tile = 0;
+        begin_tile();                           // stage barrier
+        pin_consts(cur);
+        const GroupConst nxt = load_consts(min(g + 1, g1 - 1));
         f32x4 q[TMW], k[TMW], vt[TMW], o[TMW];
         if constexpr (MODE != 2) {
-            gemm_w_rows(tile_ptr(), q);
-            { const f32x4 bq = ld4(bg + 4 * lg);
+            gemm_w_rows(q);
 #pragma unroll
-              for (int t = 0; t < TMW; ++t) q[t] = (q[t] + bq) * a.scale; }
-            gemm_w_rows(tile_ptr(), k);
-            { const f32x4 bk = ld4(bg + 16 + 4 * lg);
+            for (int t = 0; t < TMW; ++t) q[t] = (q[t] + cur.b[0]) * a.scale;
+            begin_tile();
+            gemm_w_rows(k);
 #pragma unroll
-              for (int t = 0; t < TMW; ++t) k[t] += bk; }
+            for (int t = 0; t < TMW; ++t) k[t] += cur.b[1];
             f32x4 p0[TMW], p1[TMW];
 #pragma unroll
             for (int t = 0; t < TMW; ++t) {
@@ -245,7 +307,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
                     f32x4 s = zero4();
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s = __builtin_amdgcn_mfma_f32_16x16x4f32(k[t][r], q[t][r], s, 0, 0, 0);
-                    p0[t] = window_softmax(s, a.bias_tab + (size_t)g * 256, l15, lg, a.shifted, lastH[t], lastW[t]);
+                    p0[t] = window_softmax(s, cur.bt0, l15, lg, a.shifted, lastH[t], lastW[t]);
                 } else {        // two heads share the tile: head A on k-slot groups 0,1 and head B on 2,3
                     f32x4 sa = zero4(), sb = zero4();
 #pragma unroll
@@ -253,14 +315,15 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
                         sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k[t][r], lg < 2 ? q[t][r] : 0.f, sa, 0, 0, 0);
                         sb = __builtin_amdgcn_mfma_f32_16x16x4f32(k[t][r], lg < 2 ? 0.f : q[t][r], sb, 0, 0, 0);
                     }
-                    p0[t] = window_softmax(sa, a.bias_tab + (size_t)(2 * g) * 256, l15, lg, a.shifted, lastH[t], lastW[t]);
-                    p1[t] = window_softmax(sb, a.bias_tab + (size_t)(2 * g + 1) * 256, l15, lg, a.shifted, lastH[t], lastW[t]);
+                    p0[t] = window_softmax(sa, cur.bt0, l15, lg, a.shifted, lastH[t], lastW[t]);
+                    p1[t] = window_softmax(sb, cur.bt1, l15, lg, a.shifted, lastH[t], lastW[t]);
                 }
             }
-            gemm_x_rows(tile_ptr(), vt);
-            { const float bv = bg[32 + l15];
+            ESCX_SGB_MFMA((MODE == 0 ? 4 : 8) * TMW);
+            begin_tile();
+            gemm_x_rows(vt);
 #pragma unroll
-              for (int t = 0; t < TMW; ++t) vt[t] += bv; }
+            for (int t = 0; t < TMW; ++t) vt[t] += cur.bv0;
 #pragma unroll
             for (int t = 0; t < TMW; ++t) {
                 f32x4 oa = zero4();
@@ -275,45 +338,54 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
                     o[t] = oa;
                 }
             }
-            proj_accumulate(tile_ptr(), o);
+            ESCX_SGB_MFMA((MODE == 0 ? 4 : 8) * TMW);
+            begin_tile();
+            proj_accumulate(o);
         } else {                // MODE 2: stream order [Q_lo, K_lo, Q_hi, K_hi, V_lo, P_lo, V_hi, P_hi]
             f32x4 s[TMW];
 #pragma unroll
             for (int t = 0; t < TMW; ++t) s[t] = zero4();
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                gemm_w_rows(tile_ptr(), q);
-                { const f32x4 bq = ld4(bg + (2 * half) * 16 + 4 * lg);
+                if (half) begin_tile();
+                gemm_w_rows(q);
 #pragma unroll
-                  for (int t = 0; t < TMW; ++t) q[t] = (q[t] + bq) * a.scale; }
-                gemm_w_rows(tile_ptr(), k);
-                { const f32x4 bk = ld4(bg + (2 * half + 1) * 16 + 4 * lg);
+                for (int t = 0; t < TMW; ++t) q[t] = (q[t] + cur.b[2 * half]) * a.scale;
+                begin_tile();
+                gemm_w_rows(k);
 #pragma unroll
-                  for (int t = 0; t < TMW; ++t) k[t] += bk; }
+                for (int t = 0; t < TMW; ++t) k[t] += cur.b[2 * half + 1];
 #pragma unroll
                 for (int t = 0; t < TMW; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(k[t][r], q[t][r], s[t], 0, 0, 0);
+                ESCX_SGB_MFMA(4 * TMW);
             }
             f32x4 p[TMW];
 #pragma unroll
-            for (int t = 0; t < TMW; ++t) p[t] = window_softmax(s[t], a.bias_tab + (size_t)g * 256, l15, lg, a.shifted, lastH[t], lastW[t]);
+            for (int t = 0; t < TMW; ++t) p[t] = window_softmax(s[t], cur.bt0, l15, lg, a.shifted, lastH[t], lastW[t]);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                gemm_x_rows(tile_ptr(), vt);
-                { const float bv = bg[(4 + half) * 16 + l15];
+                begin_tile();
+                gemm_x_rows(vt);
 #pragma unroll
-                  for (int t = 0; t < TMW; ++t) vt[t] += bv; }
+                for (int t = 0; t < TMW; ++t) vt[t] += (half ? cur.bv1 : cur.bv0);
 #pragma unroll
                 for (int t = 0; t < TMW; ++t) {
                     o[t] = zero4();
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[t][r], p[t][r], o[t], 0, 0, 0);
                 }
-                proj_accumulate(tile_ptr(), o);
+                ESCX_SGB_MFMA(4 * TMW);
+                begin_tile();
+                proj_accumulate(o);
             }
         }
+        cur = nxt;
     }
+#undef ESCX_SGB_DS
+#undef ESCX_SGB_VMEM
+#undef ESCX_SGB_MFMA
 
     // ---- 3. bias + shortcut, scatter through the map ----------------------------------------------
     if (GS > 1) {
@@ -364,16 +436,20 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
     const int n_stages = (g1 - g0) * (TPG / UT);
     const f32x4* wfb = a.wf + (size_t)g0 * TPG * KK * 64;
 
-    const f32x4* dma_src = wfb + lane;          // spread DMA issue, as in attn_fused_kernel
+    constexpr int NP = UT * KK, NPW = (NP + NW - 1) / NW;      // static, branch-free DMA schedule as in attn_fused_kernel
+    const f32x4* dma_src = wfb + lane;
     f32x4* dma_dst = &wbuf[0][0];
-    int dma_c = wave;
-    auto dma_piece = [&]() {
-        if (dma_c < UT * KK) {
-            __builtin_amdgcn_global_load_lds((const void*)(dma_src + dma_c * 64), (__attribute__((address_space(3))) void*)(dma_dst + dma_c * 64), 16, 0, 0);
-            dma_c += NW;
+    int slot = 0;
+    auto dma_slot = [&]() {
+        if (slot < NPW) {
+            int c = wave + slot * NW;
+            if (NP % NW != 0) c = min(c, NP - 1);
+            __builtin_amdgcn_global_load_lds((const void*)(dma_src + c * 64), (__attribute__((address_space(3))) void*)(dma_dst + c * 64), 16, 0, 0);
         }
+        ++slot;
     };
-    while (dma_c < UT * KK) dma_piece();
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) dma_slot();
 
     // ---- gather: packed row j <- window (2*pair + j/8), slot (j%8) + off ; off = 8 in shifted blocks (the real rows roll down)
     const int nW = a.nWh * a.nWw;                           // nWh == 1 here
@@ -398,14 +474,14 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) s += xf[kk][e];
         }
-        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        s = sum_groups(s);
         const float mean = s / (float)a.C;
         float v = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) { const float d = xf[kk][e] - mean; v += d * d; }
-        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        v = sum_groups(v);
         const float rstd = 1.0f / sqrtf(v / (float)a.C + a.eps);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
@@ -424,26 +500,46 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
 #pragma unroll
     for (int o = 0; o < KK; ++o) acc[o] = zero4();
 
-    int stage = 0;
+    constexpr int PD = NP < 3 ? NP : 3;         // stage-long fragment ring + pinned schedule, as in attn_fused_kernel
+#define ESCX_SGB_DS() __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)
+#define ESCX_SGB_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
+#define ESCX_SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+    int stage = 0, frag = 0;
     const f32x4* wb = nullptr;
+    f32x4 ring[PD];
     auto next_stage = [&]() {
-        while (dma_c < UT * KK) dma_piece();
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) dma_slot();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (stage + 1 < n_stages) {
-            dma_src = wfb + (size_t)(stage + 1) * (UT * KK * 64) + lane;
-            dma_dst = &wbuf[(stage + 1) & 1][0];
-            dma_c = wave;
-        }
+        dma_src = wfb + (size_t)min(stage + 1, n_stages - 1) * (UT * KK * 64) + lane;
+        dma_dst = &wbuf[(stage + 1) & 1][0];
+        slot = 0;
         wb = &wbuf[stage & 1][lane];
         ++stage;
+        frag = 0;
+#pragma unroll
+        for (int i = 0; i < PD; ++i) { ring[i] = wb[i * 64]; ESCX_SGB_DS(); }
     };
-    auto tile_gemm = [&](const f32x4* wt, bool x_rows) -> f32x4 {
+    auto next_frag = [&]() -> f32x4 {
+        const f32x4 w = ring[frag % PD];
+        if (frag + PD < NP) { ring[frag % PD] = wb[(frag + PD) * 64]; ESCX_SGB_DS(); }
+        ++frag;
+        return w;
+    };
+    auto dma_pinned = [&]() {
+        const bool issues = slot < NPW;
+        dma_slot();
+        if (issues) ESCX_SGB_VMEM(1);
+    };
+    int tile = 0;
+    auto begin_tile = [&]() { if (tile % UT == 0) next_stage(); ++tile; };
+    auto tile_gemm = [&](bool x_rows) -> f32x4 {
         f32x4 o1 = zero4(), o2 = zero4();
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            const f32x4 w = wt[kk * 64];
-            if ((kk & 1) == 0) dma_piece();
+            const f32x4 w = next_frag();
+            if ((kk & 1) == 0) dma_pinned();
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (x_rows) {
@@ -454,28 +550,36 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
                     else o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xf[kk][r], o1, 0, 0, 0);
                 }
             }
+            ESCX_SGB_MFMA(4);
         }
         return o1 + o2;
     };
-
-    for (int g = g0; g < g1; ++g) {
+    struct GroupConst { f32x4 bq, bk, bt; float bv; };
+    auto load_consts = [&](int g) -> GroupConst {
         const float* bg = a.bqkv + (size_t)g * 3 * 16;
-        int tile = 0;
-        auto tile_ptr = [&]() -> const f32x4* {
-            if (tile % UT == 0) next_stage();
-            const f32x4* p = wb + (tile % UT) * KK * 64;
-            ++tile;
-            return p;
-        };
-        const f32x4 bq = ld4(bg + 4 * lg), bk = ld4(bg + 16 + 4 * lg);
-        const float bv = bg[32 + l15];
-        f32x4 q = (tile_gemm(tile_ptr(), false) + bq) * a.scale;
-        f32x4 k = tile_gemm(tile_ptr(), false) + bk;
+        GroupConst c;
+        c.bq = ld4(bg + 4 * lg); c.bk = ld4(bg + 16 + 4 * lg); c.bv = bg[32 + l15];
+        c.bt = ld4(a.bias_tab + (size_t)g * 256 + qslot * 16 + 4 * lg);
+        ESCX_SGB_VMEM(4);
+        return c;
+    };
+
+    GroupConst cur = load_consts(g0);
+    for (int g = g0; g < g1; ++g) {
+        tile = 0;
+        begin_tile();
+        asm volatile("" : "+v"(cur.bq), "+v"(cur.bk), "+v"(cur.bt), "+v"(cur.bv));     // see attn_fused_kernel
+        const GroupConst nxt = load_consts(min(g + 1, g1 - 1));
+        const f32x4 bk = cur.bk;
+        const float bv = cur.bv;
+        f32x4 q = (tile_gemm(false) + cur.bq) * a.scale;
+        begin_tile();
+        f32x4 k = tile_gemm(false) + bk;
         // scores of both windows against every packed query; a lane keeps its own window's row
         f32x4 kA, kB;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float km = __shfl_xor(k[r], 8);
+            const float km = lane_xor8(k[r]);
             kA[r] = key_real ? (moveA ? km : k[r]) : bk[r];
             kB[r] = key_real ? (moveB ? km : k[r]) : bk[r];
         }
@@ -485,12 +589,14 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
             sA = __builtin_amdgcn_mfma_f32_16x16x4f32(kA[r], q[r], sA, 0, 0, 0);
             sB = __builtin_amdgcn_mfma_f32_16x16x4f32(kB[r], q[r], sB, 0, 0, 0);
         }
-        const f32x4 p = window_softmax(isB ? sB : sA, a.bias_tab + (size_t)g * 256, qslot, lg, a.shifted, true, lastW);
-        f32x4 vt = tile_gemm(tile_ptr(), true) + bv;
+        ESCX_SGB_MFMA(8);
+        const f32x4 p = window_softmax(isB ? sB : sA, cur.bt, qslot, lg, a.shifted, true, lastW);
+        begin_tile();
+        f32x4 vt = tile_gemm(true) + bv;
         f32x4 vA, vB;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float vm = __shfl_xor(vt[r], 32);
+            const float vm = lane_xor32(vt[r], lg >= 2);
             vA[r] = val_real ? (moveA ? vm : vt[r]) : bv;
             vB[r] = val_real ? (moveB ? vm : vt[r]) : bv;
         }
@@ -500,19 +606,27 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
             oA = __builtin_amdgcn_mfma_f32_16x16x4f32(vA[r], p[r], oA, 0, 0, 0);
             oB = __builtin_amdgcn_mfma_f32_16x16x4f32(vB[r], p[r], oB, 0, 0, 0);
         }
+        ESCX_SGB_MFMA(8);
         const f32x4 o = isB ? oB : oA;
-        const f32x4* wt = tile_ptr();
+        begin_tile();
 #pragma unroll
         for (int to = 0; to < KK; to += 2) {
-            const f32x4 w = wt[to * 64];
-            const f32x4 wn = (to + 1 < KK) ? wt[(to + 1) * 64] : zero4();
+            const f32x4 w = next_frag();
+            f32x4 wn = zero4();
+            if (to + 1 < KK) wn = next_frag();
+            dma_pinned();
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], o[r], acc[to], 0, 0, 0);
                 if (to + 1 < KK) acc[to + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[r], o[r], acc[to + 1], 0, 0, 0);
             }
+            if (to + 1 < KK) ESCX_SGB_MFMA(8); else ESCX_SGB_MFMA(4);
         }
+        cur = nxt;
     }
+#undef ESCX_SGB_DS
+#undef ESCX_SGB_VMEM
+#undef ESCX_SGB_MFMA
 
     if (GS > 1) {
         if (tok >= 0) {

@@ -58,14 +58,14 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) s += xf[t][kk][e];
         }
-        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        s = sum_groups(s);
         mean[t] = s / (float)a.C;
         float v = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) { const float d = xf[t][kk][e] - mean[t]; v += d * d; }
-        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        v = sum_groups(v);
         rstd[t] = 1.0f / sqrtf(v / (float)a.C + a.eps);
     }
 #pragma unroll
@@ -183,14 +183,14 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) s += xf[t][kk][e];
         }
-        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        s = sum_groups(s);
         mean[t] = s / (float)a.C;
         float v = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) { const float d = xf[t][kk][e] - mean[t]; v += d * d; }
-        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        v = sum_groups(v);
         rstd[t] = 1.0f / sqrtf(v / (float)a.C + a.eps);
     }
 #pragma unroll

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64 * NW) void rowgemm_fused_kernel(RowGemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (c + e < a.C) sum += xf[t][kk][e];
         }
-        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+        sum = sum_groups(sum);
         const float mean = sum / (float)(SEGS * a.C);
         float v = 0.f;
 #pragma unroll
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64 * NW) void rowgemm_fused_kernel(RowGemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (c + e < a.C) { const float d = xf[t][kk][e] - mean; v += d * d; }
         }
-        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        v = sum_groups(v);
         const float rstd = 1.0f / sqrtf(v / (float)(SEGS * a.C) + a.eps);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {

@@ -220,6 +220,41 @@ struct CodeGatherA {            // PVQ de-quantisation: A[(b,t)][g*dt + j] = cod
 // ------------------------------------------------------------------------------------------------
 // Epilogues: store(m, n, v, z) with v = 4 consecutive output features n..n+3 of row m.
 // ------------------------------------------------------------------------------------------------
+// Cross-lane butterflies over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48) on the VALU: gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange half-rows between two registers, so one swap + one op replaces a
+// ds_bpermute round trip through the LDS pipe (~100 cycles of latency per step in the softmax / LayerNorm chains).
+__device__ __forceinline__ float sum_xor16(float v) {
+    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+__device__ __forceinline__ float sum_xor32(float v) {
+    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+__device__ __forceinline__ float vmax(float a, float b) {       // plain v_max_f32: fmaxf on bit-cast values costs two extra canonicalising ops
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float max_xor16(float v) {
+    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return vmax(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+__device__ __forceinline__ float max_xor32(float v) {
+    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return vmax(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+__device__ __forceinline__ float sum_groups(float v) { return sum_xor32(sum_xor16(v)); }
+__device__ __forceinline__ float max_groups(float v) { return max_xor32(max_xor16(v)); }
+// value of lane l^32 / l^8
+__device__ __forceinline__ float lane_xor32(float v, bool upper_half) {
+    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(upper_half ? q[0] : q[1]);
+}
+__device__ __forceinline__ float lane_xor8(float v) {           // DPP row_ror:8 inside each 16-lane row
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x128, 0xf, 0xf, true));
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // Branch-free fp32 erf, max error 1.1 ulp over the whole range (fitted and checked in fp64; tests/test_gpu_parity.py
