@@ -403,11 +403,11 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
         if (tok[t] < 0) continue;
         const float* sr = a.src + (size_t)tok[t] * CP + 4 * lg;
         float* dr = a.dst + (size_t)tok[t] * CP + 4 * lg;
+        f32x4 res[KK];          // all loads, then all stores (dst may alias src: interleaved, every store fences the next load)
 #pragma unroll
-        for (int o = 0; o < KK; ++o) {
-            const f32x4 v = acc[o][t] + ld4(a.bproj + 16 * o + 4 * lg);
-            st4(dr + 16 * o, ld4(sr + 16 * o) + v);
-        }
+        for (int o = 0; o < KK; ++o) { res[o] = ld4(sr + 16 * o); acc[o][t] += ld4(a.bproj + 16 * o + 4 * lg); }
+#pragma unroll
+        for (int o = 0; o < KK; ++o) st4(dr + 16 * o, res[o] + acc[o][t]);
     }
 }
 
@@ -639,11 +639,11 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
     if (tok >= 0) {
         const float* sr = a.src + (size_t)tok * CP + 4 * lg;
         float* dr = a.dst + (size_t)tok * CP + 4 * lg;
+        f32x4 res[KK];
 #pragma unroll
-        for (int o = 0; o < KK; ++o) {
-            const f32x4 v = acc[o] + ld4(a.bproj + 16 * o + 4 * lg);
-            st4(dr + 16 * o, ld4(sr + 16 * o) + v);
-        }
+        for (int o = 0; o < KK; ++o) { res[o] = ld4(sr + 16 * o); acc[o] += ld4(a.bproj + 16 * o + 4 * lg); }
+#pragma unroll
+        for (int o = 0; o < KK; ++o) st4(dr + 16 * o, res[o] + acc[o]);
     }
 }
 

@@ -123,16 +123,18 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
     }
 
     // ---- 3. bias + residual, 16 B per lane -------------------------------------------------------
+    // all loads first, then all stores: interleaved, the compiler must assume a store may alias the next load and waits out one
+    // memory round trip per 64 bytes
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         const int row = m0 + t * 16 + l15;
         if (row >= a.M) continue;
         float* xr = a.x + (size_t)row * CP + 4 * lg;
+        f32x4 res[KK];
 #pragma unroll
-        for (int o = 0; o < KK; ++o) {
-            const f32x4 v = acc[o][t] + ld4(a.b2 + 16 * o + 4 * lg);
-            st4(xr + 16 * o, ld4(xr + 16 * o) + v);
-        }
+        for (int o = 0; o < KK; ++o) { res[o] = ld4(xr + 16 * o); acc[o][t] += ld4(a.b2 + 16 * o + 4 * lg); }
+#pragma unroll
+        for (int o = 0; o < KK; ++o) st4(xr + 16 * o, res[o] + acc[o][t]);
     }
 }
 
@@ -228,8 +230,11 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
         const f32x4* dsrc = a.wcf + (size_t)min(ht + 1, ht1 - 1) * CH * 64 + lane;
         f32x4* ddst = &wbuf[(ht + 1) & 1][0];
         ESCX_TS(t2)
-        const f32x4 bb = bias_next;
-        if (ht + 1 < ht1) bias_next = ld4(a.b1 + 16 * (ht + 1) + 4 * lg);
+        // The no-op pin makes the compiler wait for this tile's bias HERE, behind the vmcnt(0) above (free), instead of at its first
+        // use after the fc1 MFMAs - where a vmcnt(0) would also wait out the DMA pieces issued in between (an L2 round trip per tile).
+        f32x4 bb = bias_next;
+        asm volatile("" : "+v"(bb));
+        bias_next = ld4(a.b1 + 16 * min(ht + 1, ht1 - 1) + 4 * lg);
         const f32x4* wb = (ABL & 4) ? &wbuf[0][0] : &wbuf[ht & 1][lane];
 
         // fragment ring: the LDS read of fragment f + PD is in flight while fragment f feeds the MFMAs
@@ -246,9 +251,9 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
             if constexpr (SPREAD) {             // one 1 KiB DMA every DSTEP fragments, all issued within the fc1 phase
                 constexpr int NDMA = (CH + NW - 1) / NW, DSTEP = KK / NDMA > 0 ? KK / NDMA : 1;
                 if (f % DSTEP == 0 && f / DSTEP < NDMA) {
-                    const int c = wave + (f / DSTEP) * NW;
-                    if (CH % NW == 0 || c < CH)
-                        __builtin_amdgcn_global_load_lds((const void*)(dsrc + c * 64), (__attribute__((address_space(3))) void*)(ddst + c * 64), 16, 0, 0);
+                    int c = wave + (f / DSTEP) * NW;
+                    if (CH % NW != 0) c = min(c, CH - 1);       // tail: a duplicate of the last piece (same bytes) keeps the loop body branch-free
+                    __builtin_amdgcn_global_load_lds((const void*)(dsrc + c * 64), (__attribute__((address_space(3))) void*)(ddst + c * 64), 16, 0, 0);
                 }
             }
 #pragma unroll
@@ -292,11 +297,16 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
         // Pin the software pipeline: hipcc otherwise sinks every ds_read to just before its first use and
         // waits lgkmcnt(0) there, idling the matrix pipe for a full LDS round trip every 8 MFMAs.
         if (!(ABL & 64)) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // next tile's fc1 bias
 #pragma unroll
             for (int i = 0; i < PD; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
             for (int f = 0; f < CH; ++f) {
                 if (f + PD < CH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if constexpr (SPREAD) {     // the DMA pieces stay where they are issued (unpinned, the scheduler sinks them to the end of the stage)
+                    constexpr int NDMA = (CH + NW - 1) / NW, DSTEP = KK / NDMA > 0 ? KK / NDMA : 1;
+                    if (f < KK && f % DSTEP == 0 && f / DSTEP < NDMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
                 __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM, 0);
             }
         }
@@ -323,16 +333,18 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
         }
         return;
     }
+    // all loads first, then all stores: interleaved, the compiler must assume a store may alias the next load and waits out one
+    // memory round trip per 64 bytes
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         const int row = m0 + t * 16 + l15;
         if (row >= a.M) continue;
         float* xr = a.x + (size_t)row * CP + 4 * lg;
+        f32x4 res[KK];
 #pragma unroll
-        for (int o = 0; o < KK; ++o) {
-            const f32x4 v = acc[o][t] + ld4(a.b2 + 16 * o + 4 * lg);
-            st4(xr + 16 * o, ld4(xr + 16 * o) + v);
-        }
+        for (int o = 0; o < KK; ++o) { res[o] = ld4(xr + 16 * o); acc[o][t] += ld4(a.b2 + 16 * o + 4 * lg); }
+#pragma unroll
+        for (int o = 0; o < KK; ++o) st4(xr + 16 * o, res[o] + acc[o][t]);
     }
 }
 
