@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
         for (int i = 0; i < PD; ++i) ring[i] = wb[i * 64];
         f32x4 h[TM], h2[TM];
 #pragma unroll
-        for (int t = 0; t < TM; ++t) { h[t] = zero4(); h2[t] = zero4(); }
+        for (int t = 0; t < TM; ++t) { h[t] = bb; h2[t] = zero4(); }   // the fc1 bias rides in the accumulator (one VALU add less per tile)
 #pragma unroll
         for (int f = 0; f < KK; ++f) {
             const f32x4 w = ring[f % PD];
@@ -268,7 +268,6 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             if (TM == 1) h[t] += h2[t];
-            h[t] += bb;
 #pragma unroll
             for (int e = 0; e < 4; ++e) h[t][e] = (ABL & 1) ? h[t][e] * 0.5f : gelu_bf(h[t][e]);
         }
