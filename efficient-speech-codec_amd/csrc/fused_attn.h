@@ -39,6 +39,7 @@ struct AttnArgs {
     // Head-group split (same idea as MlpArgs::HS): workgroup (wb, gs) walks head groups [gs*n_groups/GS, (gs+1)*n_groups/GS) and
     // stores its projection partial sums to partial[gs][rows][CP]; rows_combine_kernel adds them in fixed order.
     int GS; float* partial; int rows;
+    unsigned long long* trace;  // tuning builds only (-DESCX_ATTN_TRACE): per-wave cycle sums of the head-group phases
 };
 
 // softmax over the 16 keys of one query row held as 4 values x 4 lane groups (attention.py:226-238)
@@ -174,7 +175,9 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
 #pragma unroll
         for (int i = 0; i < NPW; ++i) dma_slot();               // whatever is left of the pending stage (none when the GEMMs offered enough slots)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef ESCX_ATTN_NOBARRIER     // timing experiment only (results are wrong without the barrier)
         __syncthreads();
+#endif
         // arm the DMA of the following stage; after the last one its own tiles are re-loaded into the idle buffer (harmless)
         dma_src = wfb + (size_t)min(stage + 1, n_stages - 1) * (UT * KK * 64) + lane;
         dma_dst = &wbuf[(stage + 1) & 1][0];
@@ -285,12 +288,21 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
     };
 
     // ---- 2. head groups ----------------------------------------------------------------------------
+#ifdef ESCX_ATTN_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define ESCX_TS(var) unsigned long long var; { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    ESCX_TS(t_begin)
+#else
+#define ESCX_TS(var)
+#endif
     GroupConst cur = load_consts(g0);
     for (int g = g0; g < g1; ++g) {
         tile = 0;
+        ESCX_TS(t0)
         begin_tile();                           // stage barrier
         pin_consts(cur);
         const GroupConst nxt = load_consts(min(g + 1, g1 - 1));
+        ESCX_TS(t1)
         f32x4 q[TMW], k[TMW], vt[TMW], o[TMW];
         if constexpr (MODE != 2) {
             gemm_w_rows(q);
@@ -300,6 +312,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
             gemm_w_rows(k);
 #pragma unroll
             for (int t = 0; t < TMW; ++t) k[t] += cur.b[1];
+            ESCX_TS(t2)
             f32x4 p0[TMW], p1[TMW];
 #pragma unroll
             for (int t = 0; t < TMW; ++t) {
@@ -320,10 +333,12 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
                 }
             }
             ESCX_SGB_MFMA((MODE == 0 ? 4 : 8) * TMW);
+            ESCX_TS(t3)
             begin_tile();
             gemm_x_rows(vt);
 #pragma unroll
             for (int t = 0; t < TMW; ++t) vt[t] += cur.bv0;
+            ESCX_TS(t4)
 #pragma unroll
             for (int t = 0; t < TMW; ++t) {
                 f32x4 oa = zero4();
@@ -339,8 +354,13 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
                 }
             }
             ESCX_SGB_MFMA((MODE == 0 ? 4 : 8) * TMW);
+            ESCX_TS(t5)
             begin_tile();
             proj_accumulate(o);
+            ESCX_TS(t6)
+#ifdef ESCX_ATTN_TRACE
+            tr[0] += t1 - t0; tr[1] += t2 - t1; tr[2] += t3 - t2; tr[3] += t4 - t3; tr[4] += t5 - t4; tr[5] += t6 - t5;
+#endif
         } else {                // MODE 2: stream order [Q_lo, K_lo, Q_hi, K_hi, V_lo, P_lo, V_hi, P_hi]
             f32x4 s[TMW];
 #pragma unroll
@@ -383,6 +403,17 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
         }
         cur = nxt;
     }
+#ifdef ESCX_ATTN_TRACE
+    {
+        ESCX_TS(t_end)
+        if (lane == 0 && a.trace) {
+            unsigned long long* o = a.trace + (size_t)(blockIdx.x * NW + wave) * 8;
+            for (int i = 0; i < 6; ++i) o[i] = tr[i];
+            o[6] = t_begin; o[7] = t_end;
+        }
+    }
+#endif
+#undef ESCX_TS
 #undef ESCX_SGB_DS
 #undef ESCX_SGB_VMEM
 #undef ESCX_SGB_MFMA

@@ -191,7 +191,7 @@ int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_grou
     if (gs > 1 && (!partial || n_groups % gs)) gs = 1;
     if (gs_io) *gs_io = gs;
     AttnArgs a{src, dst, gamma, beta, reinterpret_cast<const f32x4*>(wf), bqkv, bias_tab, bproj, map, slots, tokens, n_windows,
-               nWh, nWw, shifted, C, n_groups, scale, 1e-5f, gs, partial, rows};
+               nWh, nWw, shifted, C, n_groups, scale, 1e-5f, gs, partial, rows, g_mlp_trace};
     // H == 2 scale with no padding along W: two half-real windows share one tile (nw < 0 encodes "packing allowed", |nw| waves)
     if (nw < 0) {
         nw = -nw;
