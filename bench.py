@@ -104,7 +104,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--profile-steps", type=int, default=6)
+    ap.add_argument("--skip-isolated", action="store_true",
+                    help="omit the isolated-kernel timing pass (used under rocprofv3 so that its per-kernel averages cover two-stream launches only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -192,24 +194,25 @@ def main():
                                   "so the duration includes sharing the GPU (ESCX_PROF_SERIAL=1 isolates kernels)") if streams > 1 else "single stream",
                          "share_of_gpu_time": round(dom["ms"] / tot, 4),
                          "executed_gflop_per_clip": round(sum(r["flops"] for r in recs) / args.profile_steps / CLIPS_PER_GPU / 1e9, 2)})
-        # the same kernel timed alone on the GPU (batch parts back to back instead of overlapped)
-        lib.escx_profile_enable(hd, 2)
-        for _ in range(args.profile_steps):
-            c, s = model.encode(x, NUM_STREAMS)
-            model.decode(c, s)
-        torch.cuda.synchronize(device)
-        lib.escx_profile_enable(hd, 0)
-        iso = {r["name"]: r for r in json.loads(lib.escx_profile_report(hd).decode())}
-        if dom["name"] in iso:
-            r = iso[dom["name"]]
-            iso_s = r["ms"] / r["calls"] * 1e-3
-            roofline["isolated_avg_us"] = round(iso_s * 1e6, 2)
-            roofline["isolated_frac"] = round((flops_per_launch / iso_s / PEAK_F32_MFMA) if mfma_bound else (bytes_per_launch / iso_s / PEAK_HBM), 4)
-        if os.environ.get("ESCX_BENCH_BREAKDOWN"):
-            recs = sorted(iso.values(), key=lambda r: -r["ms"])      # the isolated timings are the readable ones
-            for r in recs:
-                print(f"# {r['name']:28s} calls {r['calls']:4d}  {r['ms'] / args.profile_steps:9.3f} ms/step  "
-                      f"{r['flops'] / max(r['ms'], 1e-9) / 1e9:9.1f} TFLOP/s  {r['bytes'] / max(r['ms'], 1e-9) / 1e6:9.1f} GB/s", file=sys.stderr)
+        if not args.skip_isolated:
+            # the same kernel timed alone on the GPU (batch parts back to back instead of overlapped)
+            lib.escx_profile_enable(hd, 2)
+            for _ in range(args.profile_steps):
+                c, s = model.encode(x, NUM_STREAMS)
+                model.decode(c, s)
+            torch.cuda.synchronize(device)
+            lib.escx_profile_enable(hd, 0)
+            iso = {r["name"]: r for r in json.loads(lib.escx_profile_report(hd).decode())}
+            if dom["name"] in iso:
+                r = iso[dom["name"]]
+                iso_s = r["ms"] / r["calls"] * 1e-3
+                roofline["isolated_avg_us"] = round(iso_s * 1e6, 2)
+                roofline["isolated_frac"] = round((flops_per_launch / iso_s / PEAK_F32_MFMA) if mfma_bound else (bytes_per_launch / iso_s / PEAK_HBM), 4)
+            if os.environ.get("ESCX_BENCH_BREAKDOWN"):
+                recs = sorted(iso.values(), key=lambda r: -r["ms"])      # the isolated timings are the readable ones
+                for r in recs:
+                    print(f"# {r['name']:28s} calls {r['calls']:4d}  {r['ms'] / args.profile_steps:9.3f} ms/step  "
+                          f"{r['flops'] / max(r['ms'], 1e-9) / 1e9:9.1f} TFLOP/s  {r['bytes'] / max(r['ms'], 1e-9) / 1e6:9.1f} GB/s", file=sys.stderr)
 
     if rank == 0:
         audio_s = CLIPS_PER_GPU * world * args.steps * (N_SAMPLES / 16000.0)

@@ -161,7 +161,16 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
     const int l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: keeps the DMA issue loop scalar
     const int HS = a.HS > 1 ? a.HS : 1;
-    const int rb = blockIdx.x / HS, hs = blockIdx.x - rb * HS;
+    // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  The HS workgroups of one row block
+    // sit 8 apart in the grid, so they share an XCD: the rows come from HBM once and the other HS-1 reads hit that L2.
+    // (The last nrb % 8 row blocks are laid out plainly instead of padding the grid: a few padded workgroups would open a whole
+    // extra dispatch round at one workgroup per CU.)
+    int rb = blockIdx.x, hs = 0;
+    if (HS > 1) {
+        const int nrb = (a.M + 16 * TM * NW - 1) / (16 * TM * NW), full = nrb & ~7, i = blockIdx.x;
+        if (i < full * HS) { const int grp = i / (8 * HS), r = i - grp * (8 * HS); rb = grp * 8 + (r & 7); hs = r >> 3; }
+        else { const int j = i - full * HS; rb = full + j / HS; hs = j - (j / HS) * HS; }
+    }
     const int ht0 = hs * (a.HT / HS), ht1 = ht0 + a.HT / HS;
     const int m0 = (rb * NW + wave) * (16 * TM);
 
