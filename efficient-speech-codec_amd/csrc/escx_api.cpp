@@ -128,6 +128,7 @@ extern "C" int escx_create(const escx_config* cfg, int device, escx_handle* out)
     { const char* e = getenv("ESCX_ATTN_GS"); if (e && e[0]) h->attn_gs = atoi(e); }
     { const char* e = getenv("ESCX_STREAMS"); if (e && e[0]) h->parts = std::min(std::max(atoi(e), 1), (int)escx_handle_s::MAX_PARTS); }
     { const char* e = getenv("ESCX_DEEMBED_TWO_STAGE"); h->deembed_two_stage = (e && e[0] == '1'); }
+    { const char* e = getenv("ESCX_DEEMBED_GEMM"); h->deembed_halo = !(e && e[0] == '1'); }
     { const char* e = getenv("ESCX_ATTN_NW"); if (e && e[0]) h->attn_nw = atoi(e); }
     { const char* e = getenv("ESCX_NO_ATTN_PACK"); h->attn_pack = !(e && e[0] == '1'); }
     { const char* e = getenv("ESCX_NO_FUSED_ATTN"); h->use_fused_attn = !(e && e[0] == '1'); }
@@ -425,6 +426,14 @@ extern "C" int escx_finalize_params(escx_handle h) {
             pk.host[o + (size_t)n * 49 * C0p + (size_t)tap * C0p + ci] = (float)wc[(size_t)n * Kc + (size_t)tap * C0 + ci];
         o = slot(&h->dcc_b, 16);
         for (int n = 0; n < NO; ++n) pk.host[o + n] = (float)bc[n];
+        // the same interior weights as MFMA fragments [tap][kk][lane][4] for the halo-tiled kernel: lane (n = l & 15, g = l >> 4), channel 16kk + 4g + r
+        const int KKd = C0p / 16;
+        o = slot(&h->dch_w, (size_t)49 * KKd * 256);
+        if (NO <= 16)
+            for (int tap = 0; tap < 49; ++tap) for (int kk = 0; kk < KKd; ++kk) for (int l = 0; l < 64; ++l) for (int r = 0; r < 4; ++r) {
+                const int n = l & 15, ci = 16 * kk + 4 * (l >> 4) + r;
+                pk.host[o + ((size_t)(tap * KKd + kk) * 64 + l) * 4 + r] = (n < NO && ci < C0) ? (float)wc[(size_t)n * Kc + (size_t)tap * C0 + ci] : 0.f;
+            }
         o = slot(&h->dcv_w, (size_t)16 * NO * Kc);
         for (size_t i = 0; i < (size_t)16 * NO * Kc; ++i) pk.host[o + i] = (float)wc[i];
         o = slot(&h->dcv_b, (size_t)16 * NO);
@@ -964,6 +973,11 @@ static int run_deembed(escx_handle_s* h, const float* tok, int B, int W, float* 
     const int H0 = c.in_freq / c.patch_f;
     if (!h->deembed_two_stage && c.in_dim * h->Q <= 16) {
         const double tk = (double)B * H0 * W;
+        int hrc = -1;
+        if (h->deembed_halo)
+            PROF("deembed_composed7x7", 2.0 * tk * 49 * h->C0 * c.in_dim * h->Q, (tk * h->C0 + tk * c.in_dim * h->Q) * 4,
+                 hrc = deembed7_fused(tok, B, H0, W, h->C0p, h->dch_w, h->dcc_b, rspec, c.patch_f, c.patch_t, c.in_dim, h->Fp, st));
+        if (hrc != 0)
         PROF("deembed_composed7x7", 2.0 * tk * 49 * h->C0 * c.in_dim * h->Q, (tk * h->C0 + tk * c.in_dim * h->Q) * 4,
              gemm_deembed_composed(tok, B, H0, W, h->C0p, h->dcc_w, rspec, h->dcc_b, c.patch_f, c.patch_t, c.in_dim, h->Fp, st));
         int brc = 0;

@@ -97,6 +97,8 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     float *dc1_w = nullptr, *dc1_b = nullptr, *dc2_w = nullptr, *dc2_b = nullptr;
     float *dft_w = nullptr, *idft_w = nullptr, *win2 = nullptr;
     float *dcc_w = nullptr, *dcc_b = nullptr, *dcv_w = nullptr, *dcv_b = nullptr;   // composed de-embedding: interior GEMM weights, border variants
+    float* dch_w = nullptr;          // the interior weights as MFMA fragments for the halo-tiled kernel
+    bool deembed_halo = true;        // ESCX_DEEMBED_GEMM=1: implicit-GEMM form of the composed convolution instead (A/B, fallback)
     bool deembed_two_stage = false;  // ESCX_DEEMBED_TWO_STAGE=1: run conv5x5 and conv3x3 separately (A/B, fallback)
 
     // two workspace sets: whole-path calls split the batch in halves (clips are independent) and run them on two streams

@@ -2,6 +2,7 @@
 #include "fused_attn.h"
 #include "fused_mlp.h"
 #include "fused_rowgemm.h"
+#include "fused_deembed.h"
 #include "launchers.h"
 
 namespace escx {
@@ -144,6 +145,20 @@ int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, cons
         case 192: launch_rowgemm<192, 2>(a, s); return 0;
         case 288: launch_rowgemm<288, 2>(a, s); return 0;
         case 384: launch_rowgemm<384, 2>(a, s); return 0;
+        default: return -1;
+    }
+}
+
+// ---- halo-tiled composed de-embedding -----------------------------------------------------------
+int deembed7_fused(const float* tok, int B, int H, int W, int Cp, const float* wfrag, const float* bias, float* out, int pf, int pt,
+                   int in_dim, int Fp, hipStream_t s) {
+    DeembedArgs a{tok, reinterpret_cast<const f32x4*>(wfrag), bias, out, B, H, W, pf, pt, in_dim, Fp, in_dim * pf * pt};
+    if (a.n_out > 16) return -1;
+    const int grid = B * ((H + 7) / 8) * ((W + 31) / 32);
+    switch (Cp) {               // LDS: (8+6) x (32+6) pixels x (Cp+4) dwords + two 7-tap weight stages <= 160 KiB
+        case 16: hipLaunchKernelGGL(deembed7_kernel<16>, dim3(grid), dim3(512), 0, s, a); return 0;
+        case 32: hipLaunchKernelGGL(deembed7_kernel<32>, dim3(grid), dim3(512), 0, s, a); return 0;
+        case 48: hipLaunchKernelGGL(deembed7_kernel<48>, dim3(grid), dim3(512), 0, s, a); return 0;
         default: return -1;
     }
 }

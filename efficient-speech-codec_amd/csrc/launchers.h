@@ -24,6 +24,9 @@ void rows_combine(float* dst, const float* src, const float* partial, const floa
 int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, const float* beta, const float* wf, const int* map, int M,
                   int rows_per_clip, int src_rows_per_clip, int C, int Cp, int Np, int split, int H, int W, int C2p, hipStream_t s);
 void mlp_set_trace(unsigned long long* p);
+// halo-tiled composed de-embedding (fused_deembed.h); -1 when the width / output count is not instantiated
+int deembed7_fused(const float* tok, int B, int H, int W, int Cp, const float* wfrag, const float* bias, float* out, int pf, int pt,
+                   int in_dim, int Fp, hipStream_t s);
 // mode: 0 one head (<=16 dims) per tile, 1 two heads (<=8 dims) per tile, 2 one head (<=32 dims) over two tiles
 int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_groups, const float* gamma, const float* beta,
                const float* wf, const float* bqkv, const float* bias_tab, const float* bproj, const int* map, int slots, int tokens,
