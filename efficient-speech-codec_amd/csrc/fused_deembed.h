@@ -17,6 +17,7 @@
 // Algorithmic traffic: read x once (+ halo), write the spectrum once.  Bound: MFMA (2 * 49 * CP * 16 FLOP per pixel).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "gemm_engine.h"
 
 namespace escx {
@@ -55,42 +56,61 @@ __global__ __launch_bounds__(512) void deembed7_kernel(DeembedArgs a) {
     issue_row(0, 0);
 
     // ---- tile + halo -> LDS (zeros outside the map) ------------------------------------------------
-    {
-        constexpr int NV = HH * HW * KK * 4;    // 16-byte vectors
-        const float* xb = a.x + (size_t)b * a.H * a.W * CP;
-        for (int v = tid; v < NV; v += 512) {
-            const int pix = v / (KK * 4), q = v - pix * (KK * 4);
-            const int ph = pix / HW, pw = pix - ph * HW;
-            const int gh = h0 - 3 + ph, gw = w0 - 3 + pw;
-            f32x4 val = zero4();
-            if (gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) val = ld4(xb + ((size_t)gh * a.W + gw) * CP + 4 * q);
-            *reinterpret_cast<f32x4*>(&xs[pix * PS + 4 * q]) = val;
-        }
-    }
+    // Tap row dh reads halo rows dh .. dh + TH - 1, so only the first TH rows are needed up front; row TH + dh is fetched during
+    // step dh (at most one 16-byte vector per thread) and written to LDS before the next barrier.
+    const float* xb = a.x + (size_t)b * a.H * a.W * CP;
+    auto halo_vec = [&](int v) -> f32x4 {       // vector v of the halo tile: pixel v / (4 KK), channels 4 * (v % (4 KK)) ..
+        const int pix = v / (KK * 4), q = v - pix * (KK * 4);
+        const int ph = pix / HW, pw = pix - ph * HW;
+        const int gh = h0 - 3 + ph, gw = w0 - 3 + pw;
+        return (gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) ? ld4(xb + ((size_t)gh * a.W + gw) * CP + 4 * q) : zero4();
+    };
+    auto halo_put = [&](int v, f32x4 val) {
+        const int pix = v / (KK * 4), q = v - pix * (KK * 4);
+        *reinterpret_cast<f32x4*>(&xs[pix * PS + 4 * q]) = val;
+    };
+    constexpr int ROWV = HW * KK * 4;           // vectors per halo row
+    static_assert(ROWV <= 512, "one vector per thread per extra halo row");
+    for (int v = tid; v < TH * ROWV; v += 512) halo_put(v, halo_vec(v));
 
     // ---- 49 taps ------------------------------------------------------------------------------------
+    const bool seg1 = w0 + 16 < a.W;            // the last column tile of a 16-aligned-but-not-32-aligned map has one segment only
     f32x4 acc[2] = {zero4(), zero4()};
     const float* xrow = &xs[(wave * HW + l15) * PS + 4 * lg];          // this wave's tile row, pixel l15 of segment 0, tap (0, 0)
-    for (int dh = 0; dh < 7; ++dh) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                        // tap row dh is in LDS (and, first time, the halo tile); nobody still reads the other buffer
-        issue_row(min(dh + 1, 6), (dh + 1) & 1);
+    auto tap_row = [&](auto two_segments, int dh) {
+        constexpr bool TWO = decltype(two_segments)::value;
+        constexpr int NS = 7 * KK;              // (dw, kk) steps; the LDS reads of step s + 1 are in flight while step s feeds the MFMAs
         const f32x4* wb = &wr[dh & 1][lane];
         const float* xr = xrow + dh * HW * PS;
+        f32x4 w[2], x0[2], x1[2];
+        auto fetch = [&](int st, int slot) {
+            const int dw = st / KK, kk = st - dw * KK;
+            w[slot] = wb[st * 64];
+            x0[slot] = *reinterpret_cast<const f32x4*>(xr + dw * PS + 16 * kk);
+            if (TWO) x1[slot] = *reinterpret_cast<const f32x4*>(xr + (dw + 16) * PS + 16 * kk);
+            __builtin_amdgcn_sched_group_barrier(0x100, TWO ? 3 : 2, 0);
+        };
+        fetch(0, 0);
 #pragma unroll
-        for (int dw = 0; dw < 7; ++dw) {
+        for (int st = 0; st < NS; ++st) {
+            if (st + 1 < NS) fetch(st + 1, (st + 1) & 1);
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) {
-                const f32x4 w = wb[(dw * KK + kk) * 64];
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr + dw * PS + 16 * kk);
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(xr + (dw + 16) * PS + 16 * kk);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], x0[r], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], x1[r], acc[1], 0, 0, 0);
-                }
+            for (int r = 0; r < 4; ++r) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[st & 1][r], x0[st & 1][r], acc[0], 0, 0, 0);
+                if (TWO) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[st & 1][r], x1[st & 1][r], acc[1], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_group_barrier(0x008, TWO ? 8 : 4, 0);
         }
+    };
+    for (int dh = 0; dh < 7; ++dh) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                        // tap row dh and halo row TH + dh - 1 are in LDS; nobody still reads the other weight buffer
+        issue_row(min(dh + 1, 6), (dh + 1) & 1);
+        const bool extra = dh < 6 && tid < ROWV;
+        f32x4 nv = zero4();
+        if (extra) nv = halo_vec((TH + dh) * ROWV + tid);
+        if (seg1) tap_row(std::true_type{}, dh); else tap_row(std::false_type{}, dh);
+        if (extra) halo_put((TH + dh) * ROWV + tid, nv);
     }
 
     // ---- bias + store: lane (pixel, outputs 4lg .. 4lg+3) -----------------------------------------
