@@ -806,10 +806,16 @@ extern "C" const char* escx_profile_report(escx_handle h) {
 // 4 SIMDs of a CU and workgroups are dealt round-robin to the 256 CUs, so the makespan in tile-times is
 //   ceil(workgroups / 256) * ceil(NW / 4) * units.
 // 8 waves share each weight fragment between twice as many rows (half the L2->LDS traffic) and win ties.
-static int pick_nw(long long tiles, int units) {
+// `cap` = waves per SIMD the kernel's register budget allows (mlp_min_waves / attn_min_waves): at 3, an 8-wave workgroup leaves
+// the third slot of every SIMD empty (one workgroup = 2 waves per SIMD, a second one does not fit), so 4-wave workgroups it is.
+static int pick_nw(long long tiles, int units, int cap = 4) {
+    static const bool cap_rule = [] { const char* e = getenv("ESCX_NW_CAP_RULE"); return !(e && e[0] == '0'); }();
+    if (cap == 3 && cap_rule) return 4;
     auto cost = [&](int nw) { const long long wg = (tiles / units + nw - 1) / nw; return ((wg + 255) / 256) * ((nw + 3) / 4) * units; };
     return cost(8) <= cost(4) ? 8 : 4;
 }
+static int mlp_cap(int Cp) { return Cp <= 96 ? 4 : (Cp <= 192 ? 3 : 1); }                              // fused_mlp.h: mlp_min_waves<CP, 1>
+static int attn_cap(int Cp, int tmw) { const int v = Cp * tmw; return v <= 96 ? 4 : (v <= 160 ? 3 : (v <= 192 ? 2 : 1)); }   // fused_attn.h: attn_min_waves
 // Hidden split of the fused MLP (fused_mlp.h): at the deep scales a clip has so few token rows (600 / 1200 at C = 384 / 192
 // for 3 s) that one wave per 16-row tile cannot fill 1024 SIMDs at serving batch sizes, so three workgroups share a row block
 // and a combine pass adds their fc2 partial sums in fixed order.  The rule depends on the layer geometry only - never on the
@@ -820,7 +826,7 @@ static int mlp_hs_for(int tokens_per_clip, int HT, int Cp) { return (tokens_per_
 // stream).  Measured: -19 % on the isolated C = 384 kernel but neutral end to end with two parts in flight, so it is off unless
 // ESCX_ATTN_GS_TOKENS raises the limit (single-clip latency is where it pays).
 static int attn_gs_for(int tokens_per_clip, int n_groups, int hiddenP, int Cp) { static const int lim = [] { const char* e = getenv("ESCX_ATTN_GS_TOKENS"); return e && e[0] ? atoi(e) : 0; }(); return (tokens_per_clip <= lim && n_groups % 3 == 0 && hiddenP >= 3 * Cp) ? 3 : 1; }
-static int mlp_variant_for(int M) { return pick_nw((M + 15) / 16, 1) == 8 ? 3 : 1; }     // fused_swin.hip: 1 = (TM 1, NW 4), 3 = (TM 1, NW 8)
+static int mlp_variant_for(int M, int Cp) { return pick_nw((M + 15) / 16, 1, mlp_cap(Cp)) == 8 ? 3 : 1; }     // fused_swin.hip: 1 = (TM 1, NW 4), 3 = (TM 1, NW 8)
 
 // One TransformerLayer on padded token maps.  x_in is read-only; y receives (B, H'*W, CoutP).
 // attention.py:48-91 (layer), 129-178 (block): LN1 -> pad -> roll -> windows -> attention -> reverse -> residual -> MLP.
@@ -840,7 +846,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         bool attn_done = false;
         if (h->use_fused && h->use_fused_attn && L.attn_mode >= 0) {
             int frc = 0;
-            int nw = h->attn_nw ? h->attn_nw : (L.Cp > 192 ? 4 : pick_nw(Ms / 16, L.Cp <= 96 ? 2 : 1));    // 8 waves cap the kernel at 256 VGPRs: spills above C = 192
+            int nw = h->attn_nw ? h->attn_nw : (L.Cp > 192 ? 4 : pick_nw(Ms / 16, attn_windows_per_wave(L.Cp), attn_cap(L.Cp, attn_windows_per_wave(L.Cp))));    // 8 waves cap the kernel at 256 VGPRs: spills above C = 192
             if (H == 2 && W % 4 == 0 && h->attn_pack) nw = -(h->attn_nw ? h->attn_nw : (L.Cp > 192 ? 4 : pick_nw((Ms / 16 + 1) / 2, 1)));    // packed half-window pairs
             const double proj_rows = nw < 0 ? dM : dMs;         // packed pairs project only the real tokens
             int gs = h->attn_gs > 0 ? (L.hiddenP >= h->attn_gs * L.Cp ? h->attn_gs : 1) : attn_gs_for(tokens, L.n_groups, L.hiddenP, L.Cp);
@@ -866,7 +872,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         if (h->use_fused) {
             int frc = 0;
             int hs = (h->mlp_hs > 0 && L.hiddenP >= h->mlp_hs * L.Cp) ? h->mlp_hs : mlp_hs_for(tokens, L.hiddenP / 16, L.Cp);
-            const int variant = h->mlp_variant >= 0 ? h->mlp_variant : (hs > 1 ? 1 : mlp_variant_for(M));
+            const int variant = h->mlp_variant >= 0 ? h->mlp_variant : (hs > 1 ? 1 : mlp_variant_for(M, L.Cp));
             PROF("mlp_fused" + tag, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
                  frc = mlp_fused(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP, variant, &hs, h->hid, st));
             if (frc == 0 && hs > 1)

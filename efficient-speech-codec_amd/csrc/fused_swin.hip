@@ -167,7 +167,7 @@ int deembed7_fused(const float* tok, int B, int H, int W, int Cp, const float* w
 template <int CP, int MODE, int NW>
 static void launch_attn(const AttnArgs& a, hipStream_t s) {
     constexpr int UT = CP <= 96 ? 4 : (CP <= 192 ? 2 : 1);
-    constexpr int TMW = CP <= 96 ? 2 : 1;
+    constexpr int TMW = attn_windows_per_wave(CP);
     const int per_block = TMW * NW;
     const int gs = a.GS > 1 ? a.GS : 1;
     hipLaunchKernelGGL((attn_fused_kernel<CP, MODE, UT, TMW, NW>), dim3(((a.n_windows + per_block - 1) / per_block) * gs), dim3(64 * NW), 0, s, a);

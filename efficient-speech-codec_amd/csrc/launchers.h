@@ -15,6 +15,12 @@ void gemm_residual(const float* A, int lda, int M, const float* W, int Np, int K
 void gemm_store(const float* A, int lda, int M, const float* W, int Np, int Kp, float* out, int ldo, const float* bias, hipStream_t s);
 void gemm_split(const float* A, int lda, int M, const float* W, int Np, int Kp, float* out, int H, int Wd, int C2p, hipStream_t s);
 
+// windows per wave of the fused attention: two up to this padded width (they share every weight fragment), one above
+#ifndef ESCX_ATTN_TMW2_MAX
+#define ESCX_ATTN_TMW2_MAX 48
+#endif
+constexpr int attn_windows_per_wave(int Cp) { return Cp <= ESCX_ATTN_TMW2_MAX ? 2 : 1; }
+
 // ---- fused register-resident Swin kernels (fused_swin.hip); return -1 when the width is not instantiated ----
 int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* w1f, const float* b1,
               const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, int* hs_io, float* partial, hipStream_t s);
