@@ -871,8 +871,11 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         }
         if (h->use_fused) {
             int frc = 0;
+            static const int hs_nw8_cp = [] { const char* e = getenv("ESCX_MLP_HS_NW8_CP"); return e && e[0] ? atoi(e) : 384; }();
+            static const int tm2_max = [] { const char* e = getenv("ESCX_MLP_TM2_MAXCP"); return e && e[0] ? atoi(e) : 0; }();
+            static const int tm2_nw8 = [] { const char* e = getenv("ESCX_MLP_TM2_NW8"); return e && e[0] == '1'; }();
             int hs = (h->mlp_hs > 0 && L.hiddenP >= h->mlp_hs * L.Cp) ? h->mlp_hs : mlp_hs_for(tokens, L.hiddenP / 16, L.Cp);
-            const int variant = h->mlp_variant >= 0 ? h->mlp_variant : (hs > 1 ? 1 : mlp_variant_for(M, L.Cp));
+            const int variant = h->mlp_variant >= 0 ? h->mlp_variant : (hs > 1 ? (L.Cp >= hs_nw8_cp ? 3 : 1) : (L.Cp <= tm2_max ? (tm2_nw8 ? 5 : 4) : mlp_variant_for(M, L.Cp)));
             PROF("mlp_fused" + tag, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
                  frc = mlp_fused(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP, variant, &hs, h->hid, st));
             if (frc == 0 && hs > 1)
