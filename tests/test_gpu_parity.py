@@ -361,6 +361,26 @@ def test_variable_bitrate_sweep_batch64(base):
         assert rms(wave[30:32].cpu().numpy(), orc.decode(oc, shape).numpy()) <= AUDIO_TOL
 
 
+def test_node_batch_288_matches_its_36_clip_shards(base):
+    """BASELINE config 4 size on one GPU (288 clips = 8 ranks x 36): every 36-clip shard, processed alone, must give the same codes
+    and the same audio bit for bit as inside the 288-clip batch (what makes sharding across ranks transparent), and the round trip
+    code -> audio -> ... stays finite.  Oracle agreement on one clip of the last shard."""
+    model, orc, g, cfg = base
+    pcm = np.stack([synth.noise_clip_int16(f"node-r{r}-{i}", 48000, amp=0.04 + 0.02 * (r % 4)) for r in range(8) for i in range(36)])
+    x = torch.from_numpy(synth.pcm_to_float(pcm)).cuda()
+    codes, shape = model.encode(x, 6)
+    assert codes.shape == (288, 6, 3, 150) and int(codes.min()) >= 0 and int(codes.max()) < 1024
+    wave = model.decode(codes, shape)
+    assert wave.shape == (288, 47920) and torch.isfinite(wave).all()
+    for r in (0, 3, 7):
+        sl = slice(36 * r, 36 * r + 36)
+        c_r, _ = model.encode(x[sl].contiguous(), 6)
+        assert torch.equal(c_r, codes[sl]), f"shard {r}: codes depend on the batch"
+        assert torch.equal(model.decode(c_r, shape), wave[sl]), f"shard {r}: audio depends on the batch"
+    oc, _ = orc.encode(x[287:288].cpu(), 6)
+    assert torch.equal(oc, codes[287:288].cpu()), code_report(codes[287:288].cpu().numpy(), oc.numpy())
+
+
 def test_c_abi_error_paths(base):
     """Status codes and messages of the C ABI (nothing throws across it)."""
     model, orc, g, cfg = base

@@ -23,6 +23,7 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" "S
 done
 python $R/tools/pmc_agg.py $O/pmc_sq --json $O/sq_counters.json --top 16 > $O/sq_counters.txt
 cd $R
+ESCX_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_rccl_1rank.json
 timeout 900 python tools/bench_configs.py > $O/other_configs.json 2>$O/other_configs.err
 find $O -name "*.csv" ! -name "kernel_stats.csv" -delete; rm -rf $O/prof $O/pmc_fetch $O/pmc_write $O/pmc_sq
 ls -la $O
