@@ -1250,6 +1250,7 @@ extern "C" int escx_patch_deembed(escx_handle h, const float* tokens, int B, int
 }
 
 extern "C" int escx_debug_mlp_trace(unsigned long long* dev_buf) { mlp_set_trace(dev_buf); return 0; }
+extern "C" int escx_test_fastdiv(int n, int d) { return test_fastdiv(n, d); }
 extern "C" int escx_test_math(const float* x, float* y, int64_t n, int which, void* stream) {
     test_math(x, y, n, which, (hipStream_t)stream);
     return launch_ok("test_math");

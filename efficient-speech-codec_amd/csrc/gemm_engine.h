@@ -111,6 +111,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(Loader ld, const float* __res
     }
 }
 
+// Exact n / d for 0 <= n < 2^31 with a host-computed multiplier (Granlund-Montgomery): one v_mul_hi + shift instead of the ~25
+// VALU instructions of a runtime integer division.  The gather loaders and scatter epilogues divide by runtime extents for
+// every 16-byte access; with K = 16..96 that index arithmetic was 10-17 VALU instructions per MFMA of the PVQ projections.
+struct FastDiv {
+    unsigned mul, shr; int d;
+    FastDiv() : mul(0), shr(0), d(1) {}
+    explicit FastDiv(int dv) : mul(0), shr(0), d(dv) {
+        if (dv > 1) {
+            int lg = 0; while ((1ll << lg) < dv) ++lg;                  // ceil(log2 d)
+            const int p = 31 + lg;
+            mul = (unsigned)(((1ull << p) + (unsigned long long)dv - 1) / (unsigned long long)dv);
+            shr = (unsigned)(p - 32);
+        }
+    }
+    __host__ __device__ __forceinline__ int div(int n) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return d == 1 ? n : (int)(__umulhi((unsigned)n, mul) >> shr);
+#else
+        return d == 1 ? n : (int)((((unsigned long long)(unsigned)n * mul) >> 32) >> shr);
+#endif
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // A-side loaders.  make_ctx(m) is evaluated once per thread-row before the K loop; load4(ctx, k0, kin)
 // returns A[m][k0+kin .. +3] (k0 is block-uniform, kin the offset inside the BK tile).
@@ -140,11 +163,11 @@ struct ConvA {                  // implicit-GEMM 'same' convolution over a (D0, 
 };
 
 struct FrameA {                 // STFT framing with reflect padding: A[(b,f)][k] = wave[b][reflect(f*hop + k + off)]
-    const float* wave; int L, T, hop, off, M;
+    const float* wave; int L, T, hop, off, M; FastDiv dT;
     struct Ctx { const float* w; int start; };
     __device__ __forceinline__ Ctx make_ctx(int m) const {
         Ctx c; c.w = nullptr; c.start = 0;
-        if (m < M) { const int b = m / T, f = m - b * T; c.w = wave + (size_t)b * L; c.start = f * hop + off; }
+        if (m < M) { const int b = dT.div(m), f = m - b * T; c.w = wave + (size_t)b * L; c.start = f * hop + off; }
         return c;
     }
     __device__ __forceinline__ float at(const float* w, int p) const {
@@ -183,17 +206,17 @@ struct PatchA {                 // PatchEmbed gather: A[(b,ph,pw)][k=(c,df,dt)] 
 };
 
 struct ResidualGatherA {        // PVQ framing of (enc - dec): A[(b,t)][k=(o,h,c)] ; requires BK | Cp
-    const float* enc; const float* dec; int Hq, W, Cp, Tq, ov, M;
+    const float* enc; const float* dec; int Hq, W, Cp, Tq, ov, M; FastDiv dTq, dCp, dHq;
     typedef int Ctx;            // element offset of token (b, h=0, w=ov*t), or -1
     __device__ __forceinline__ Ctx make_ctx(int m) const {
         if (m >= M) return -1;
-        const int b = m / Tq, t = m - b * Tq;
+        const int b = dTq.div(m), t = m - b * Tq;
         return (b * Hq * W + ov * t) * Cp;
     }
     __device__ __forceinline__ f32x4 load4(Ctx c, int k0, int kin) const {
         if (c < 0) return zero4();
-        const int oh = k0 / Cp, cc = k0 - oh * Cp + kin;
-        const int o = oh / Hq, h = oh - o * Hq;
+        const int oh = dCp.div(k0), cc = k0 - oh * Cp + kin;
+        const int o = dHq.div(oh), h = oh - o * Hq;
         const size_t idx = (size_t)c + (size_t)(h * W + o) * Cp + cc;
         f32x4 v = ld4(enc + idx);
         if (dec) v -= ld4(dec + idx);
@@ -202,15 +225,15 @@ struct ResidualGatherA {        // PVQ framing of (enc - dec): A[(b,t)][k=(o,h,c
 };
 
 struct CodeGatherA {            // PVQ de-quantisation: A[(b,t)][g*dt + j] = codebook_g[code[b,g,t]][j]
-    const long long* codes; long long bstride; const float* cb; int G, Ksz, dt, Tq, M;
+    const long long* codes; long long bstride; const float* cb; int G, Ksz, dt, Tq, M; FastDiv dTq, ddt;
     struct Ctx { const long long* c; };
     __device__ __forceinline__ Ctx make_ctx(int m) const {
         Ctx c; c.c = nullptr;
-        if (m < M) { const int b = m / Tq, t = m - b * Tq; c.c = codes + (size_t)b * bstride + t; }
+        if (m < M) { const int b = dTq.div(m), t = m - b * Tq; c.c = codes + (size_t)b * bstride + t; }
         return c;
     }
     __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
-        const int k = k0 + kin; const int g = k / dt;
+        const int k = k0 + kin; const int g = ddt.div(k);
         if (!c.c || g >= G) return zero4();
         const long long code = c.c[(size_t)g * Tq];
         return ld4(cb + ((size_t)g * Ksz + (size_t)code) * dt + (k - g * dt));
@@ -399,11 +422,11 @@ struct EpiDeembedC {            // composed de-embedding: n = (cout, s1, s2) -> 
 };
 
 struct EpiPvqAdd {              // un-frame + post_fuse: out[(b,h,ov*t+o)][c] = dec[...] + v   (csrvq.py:19-21)
-    float* out; const float* dec; int Hq, W, Cp, Tq, ov;
+    float* out; const float* dec; int Hq, W, Cp, Tq, ov; FastDiv dTq, dCp, dHq;
     __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
-        const int b = m / Tq, t = m - b * Tq;
-        const int oh = n / Cp, c = n - oh * Cp;
-        const int o = oh / Hq, h = oh - o * Hq;
+        const int b = dTq.div(m), t = m - b * Tq;
+        const int oh = dCp.div(n), c = n - oh * Cp;
+        const int o = dHq.div(oh), h = oh - o * Hq;
         const size_t idx = ((size_t)(b * Hq + h) * W + ov * t + o) * Cp + c;
         if (dec) v += ld4(dec + idx);
         st4(out + idx, v);

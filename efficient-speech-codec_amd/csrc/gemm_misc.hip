@@ -6,7 +6,7 @@
 namespace escx {
 
 void gemm_frames(const float* wave, int B, int L, int T, int hop, int off, const float* W, int Np, int Kp, float* out, hipStream_t s) {
-    FrameA ld{wave, L, T, hop, off, B * T};
+    FrameA ld{wave, L, T, hop, off, B * T, FastDiv(T)};
     launch_gemm<64>(ld, W, B * T, Np, Kp, EpiStore{out, Np, nullptr}, s);
 }
 
@@ -29,6 +29,8 @@ void gemm_conv_spec(const float* x, int B, int T, int F, int Cp, const float* W,
     ConvA ld{x, T, F, Cp, 3, 3, B * T * F};
     launch_gemm<64>(ld, W, B * T * F, 16, 9 * Cp, EpiSpec{out, bias, T, F, Fp, in_dim}, s, 1, pick_bk(Cp));
 }
+
+int test_fastdiv(int n, int d) { return FastDiv(d).div(n); }
 
 void gemm_deembed_composed(const float* x, int B, int H, int Wd, int Cp, const float* W, float* out, const float* bias, int pf, int pt,
                            int in_dim, int Fp, hipStream_t s) {
@@ -53,15 +55,15 @@ int pvq_down_splits(int M, int Kp, int Cp) {
 void gemm_pvq_down(const float* enc, const float* dec, int B, int Hq, int Wd, int Cp, int ov, const float* W, int Np, int Kp,
                    float* zpart, int splits, hipStream_t s) {
     const int Tq = Wd / ov, M = B * Tq;
-    ResidualGatherA ld{enc, dec, Hq, Wd, Cp, Tq, ov, M};
+    ResidualGatherA ld{enc, dec, Hq, Wd, Cp, Tq, ov, M, FastDiv(Tq), FastDiv(Cp), FastDiv(Hq)};
     launch_gemm<64>(ld, W, M, Np, Kp, EpiPartial{zpart, M, Np}, s, splits, pick_bk(Cp));
 }
 
 void gemm_pvq_up(const long long* codes, long long bstride, const float* cbraw, int G, int Ksz, int dt, int B, int Hq, int Wd, int Cp,
                  int ov, const float* W, int Np, int Kp, const float* dec, float* out, hipStream_t s) {
     const int Tq = Wd / ov, M = B * Tq;
-    CodeGatherA ld{codes, bstride, cbraw, G, Ksz, dt, Tq, M};
-    launch_gemm<64>(ld, W, M, Np, Kp, EpiPvqAdd{out, dec, Hq, Wd, Cp, Tq, ov}, s);
+    CodeGatherA ld{codes, bstride, cbraw, G, Ksz, dt, Tq, M, FastDiv(Tq), FastDiv(dt)};
+    launch_gemm<64>(ld, W, M, Np, Kp, EpiPvqAdd{out, dec, Hq, Wd, Cp, Tq, ov, FastDiv(Tq), FastDiv(Cp), FastDiv(Hq)}, s);
 }
 
 }  // namespace escx

@@ -30,6 +30,7 @@ void rows_combine(float* dst, const float* src, const float* partial, const floa
 int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, const float* beta, const float* wf, const int* map, int M,
                   int rows_per_clip, int src_rows_per_clip, int C, int Cp, int Np, int split, int H, int W, int C2p, hipStream_t s);
 void mlp_set_trace(unsigned long long* p);
+int test_fastdiv(int n, int d);       // host evaluation of gemm_engine.h FastDiv (gemm_misc.hip)
 // halo-tiled composed de-embedding (fused_deembed.h); -1 when the width / output count is not instantiated
 int deembed7_fused(const float* tok, int B, int H, int W, int Cp, const float* wfrag, const float* bias, float* out, int pf, int pt,
                    int in_dim, int Fp, hipStream_t s);

@@ -137,6 +137,9 @@ const char* escx_profile_report(escx_handle h);
 /* Debug: per-wave cycle counters of the fused MLP main loop (kernel built with the trace flag, ESCX_MLP_VARIANT=164). */
 int escx_debug_mlp_trace(unsigned long long* dev_buf);
 int escx_test_math(const float* x_dev, float* y_dev, int64_t n, int which, void* stream);
+/* Host-side evaluation of the multiply-high division the gather loaders / scatter epilogues use on the device (gemm_engine.h FastDiv):
+ * returns n / d for 0 <= n < 2^31, 1 <= d < 2^31 (no GPU needed; tests compare it with exact division). */
+int escx_test_fastdiv(int n, int d);
 
 /* ---- code packing for transport (10-bit codes; all-gather payload) --------------------------- */
 /* 10-bit wire format (codebook_size 1024): n codes <-> 5*ceil(n/4) bytes; 6 streams x 3 groups x 50 Hz x 10 b = 9 kbps (base.py:70). */

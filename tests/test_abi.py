@@ -22,6 +22,20 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.escx_version()
 
 
+def test_fast_division_is_exact():
+    """The index arithmetic of the gather / scatter kernels divides by runtime extents with a precomputed multiply-high
+    (gemm_engine.h FastDiv); one wrong quotient would address the wrong token."""
+    import random
+    from esc import _native
+    lib = _native.load()
+    rng = random.Random(7)
+    ds = list(range(1, 400)) + [150, 300, 600, 601, 1000, 4608, 9600, 19200, 48000, 2 ** 20, 2 ** 20 + 1, 2 ** 30, 2 ** 31 - 1] + [rng.randrange(1, 2 ** 31) for _ in range(300)]
+    for d in ds:
+        for n in [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, 3 * d + 1, 2 ** 31 - 1, 2 ** 30] + [rng.randrange(0, 2 ** 31) for _ in range(40)]:
+            if 0 <= n < 2 ** 31:
+                assert lib.escx_test_fastdiv(n, d) == n // d, (n, d)
+
+
 @pytest.mark.parametrize("name", ["base", "large", "tiny"])
 def test_state_dict_contract(name):
     from esc.models import make_model
