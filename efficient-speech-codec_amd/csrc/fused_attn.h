@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
         for (int kk = 0; kk < KK; ++kk) {
             xf[t][kk] = tok[t] >= 0 ? ld4(xr + 16 * kk) : zero4();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) s += xf[t][kk][e];
+            for (int e = 0; e < 4; ++e) s += xf[t][kk][e];            // pad channels are exact zeros
         }
         s = sum_groups(s);
         const float mean = s / (float)a.C;
@@ -141,15 +141,15 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) { const float d = xf[t][kk][e] - mean; v += d * d; }
-        v = sum_groups(v);
+            for (int e = 0; e < 4; ++e) { const float d = xf[t][kk][e] - mean; v += d * d; }
+        v = sum_groups(v) - (float)(CP - a.C) * mean * mean;     // the zero pads each added mean^2
         const float rstd = 1.0f / sqrtf(v / (float)a.C + a.eps);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const f32x4 g = ld4(a.gamma + 16 * kk + 4 * lg), bb = ld4(a.beta + 16 * kk + 4 * lg);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                xf[t][kk][e] = (tok[t] >= 0 && 16 * kk + 4 * lg + e < a.C) ? (xf[t][kk][e] - mean) * rstd * g[e] + bb[e] : 0.f;
+                xf[t][kk][e] = tok[t] >= 0 ? (xf[t][kk][e] - mean) * rstd * g[e] + bb[e] : 0.f;   // gamma = beta = 0 in the pad channels
         }
     }
 
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
         for (int kk = 0; kk < KK; ++kk) {
             xf[kk] = tok >= 0 ? ld4(xr + 16 * kk) : zero4();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) s += xf[kk][e];
+            for (int e = 0; e < 4; ++e) s += xf[kk][e];
         }
         s = sum_groups(s);
         const float mean = s / (float)a.C;
@@ -511,15 +511,15 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) { const float d = xf[kk][e] - mean; v += d * d; }
-        v = sum_groups(v);
+            for (int e = 0; e < 4; ++e) { const float d = xf[kk][e] - mean; v += d * d; }
+        v = sum_groups(v) - (float)(CP - a.C) * mean * mean;     // the zero pads each added mean^2
         const float rstd = 1.0f / sqrtf(v / (float)a.C + a.eps);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const f32x4 g = ld4(a.gamma + 16 * kk + 4 * lg), bb = ld4(a.beta + 16 * kk + 4 * lg);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                xf[kk][e] = (tok >= 0 && 16 * kk + 4 * lg + e < a.C) ? (xf[kk][e] - mean) * rstd * g[e] + bb[e] : 0.f;
+                xf[kk][e] = tok >= 0 ? (xf[kk][e] - mean) * rstd * g[e] + bb[e] : 0.f;
         }
     }
     // which lanes hold real keys / values of a window, and whether the packed rows must be moved to reach their slots

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
         for (int kk = 0; kk < KK; ++kk) {
             xf[t][kk] = row < a.M ? ld4(xr + 16 * kk) : zero4();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) s += xf[t][kk][e];
+            for (int e = 0; e < 4; ++e) s += xf[t][kk][e];            // pad channels are exact zeros
         }
         s = sum_groups(s);
         mean[t] = s / (float)a.C;
@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) { const float d = xf[t][kk][e] - mean[t]; v += d * d; }
-        v = sum_groups(v);
+            for (int e = 0; e < 4; ++e) { const float d = xf[t][kk][e] - mean[t]; v += d * d; }
+        v = sum_groups(v) - (float)(CP - a.C) * mean[t] * mean[t];       // the zero pads each added mean^2
         rstd[t] = 1.0f / sqrtf(v / (float)a.C + a.eps);
     }
 #pragma unroll
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
         for (int t = 0; t < TM; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                xf[t][kk][e] = (16 * kk + 4 * lg + e < a.C) ? (xf[t][kk][e] - mean[t]) * rstd[t] * g[e] + b[e] : 0.f;
+                xf[t][kk][e] = (xf[t][kk][e] - mean[t]) * rstd[t] * g[e] + b[e];    // gamma = beta = 0 in the pads -> 0
     }
 
     // ---- 2. hidden tiles: fc1 -> GELU -> fc2 partial, all in registers ---------------------------
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
         for (int kk = 0; kk < KK; ++kk) {
             xf[t][kk] = row < a.M ? ld4(xr + 16 * kk) : zero4();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) s += xf[t][kk][e];
+            for (int e = 0; e < 4; ++e) s += xf[t][kk][e];            // pad channels are exact zeros
         }
         s = sum_groups(s);
         mean[t] = s / (float)a.C;
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (16 * kk + 4 * lg + e < a.C) { const float d = xf[t][kk][e] - mean[t]; v += d * d; }
-        v = sum_groups(v);
+            for (int e = 0; e < 4; ++e) { const float d = xf[t][kk][e] - mean[t]; v += d * d; }
+        v = sum_groups(v) - (float)(CP - a.C) * mean[t] * mean[t];       // the zero pads each added mean^2
         rstd[t] = 1.0f / sqrtf(v / (float)a.C + a.eps);
     }
 #pragma unroll
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
         for (int t = 0; t < TM; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                xf[t][kk][e] = (16 * kk + 4 * lg + e < a.C) ? (xf[t][kk][e] - mean[t]) * rstd[t] * g[e] + b[e] : 0.f;
+                xf[t][kk][e] = (xf[t][kk][e] - mean[t]) * rstd[t] * g[e] + b[e];    // gamma = beta = 0 in the pads -> 0
     }
 
     f32x4 acc[KK][TM];

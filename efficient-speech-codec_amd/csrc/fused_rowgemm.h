@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64 * NW) void rowgemm_fused_kernel(RowGemmArgs a) {
             const int s = k / SEGK, c = k - s * SEGK;
             xf[t][kk] = sp[s] ? ld4(sp[s] + c) : zero4();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (c + e < a.C) sum += xf[t][kk][e];
+            for (int e = 0; e < 4; ++e) sum += xf[t][kk][e];          // pad channels are exact zeros
         }
         sum = sum_groups(sum);
         const float mean = sum / (float)(SEGS * a.C);
@@ -71,16 +71,16 @@ __global__ __launch_bounds__(64 * NW) void rowgemm_fused_kernel(RowGemmArgs a) {
         for (int kk = 0; kk < KK; ++kk) {
             const int k = 16 * kk + 4 * lg; const int c = k % SEGK;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (c + e < a.C) { const float d = xf[t][kk][e] - mean; v += d * d; }
+            for (int e = 0; e < 4; ++e) { const float d = xf[t][kk][e] - mean; v += d * d; }
         }
-        v = sum_groups(v);
+        v = sum_groups(v) - (float)(SEGS * (SEGK - a.C)) * mean * mean;     // the zero pads each added mean^2
         const float rstd = 1.0f / sqrtf(v / (float)(SEGS * a.C) + a.eps);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const int k = 16 * kk + 4 * lg; const int c = k % SEGK;
             const f32x4 g = ld4(a.gamma + k), bb = ld4(a.beta + k);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xf[t][kk][e] = (c + e < a.C) ? (xf[t][kk][e] - mean) * rstd * g[e] + bb[e] : 0.f;
+            for (int e = 0; e < 4; ++e) xf[t][kk][e] = (xf[t][kk][e] - mean) * rstd * g[e] + bb[e];       // gamma = beta = 0 in the pads
         }
     }
 
