@@ -42,27 +42,34 @@ struct AttnArgs {
     unsigned long long* trace;  // tuning builds only (-DESCX_ATTN_TRACE): per-wave cycle sums of the head-group phases
 };
 
-// softmax over the 16 keys of one query row held as 4 values x 4 lane groups (attention.py:226-238)
-__device__ __forceinline__ f32x4 window_softmax(f32x4 s, f32x4 bias_row, int l15, int lg, bool shifted, bool lastH, bool lastW) {
-    s += bias_row;              // bias_tab[head][query l15][keys 4lg..4lg+3], loaded by the caller a whole GEMM ahead of its use
-    if (shifted) {
-        const int qh = l15 >> 2, qw = l15 & 3;
-        const int labq = 3 * (lastH ? (qh < 2 ? 1 : 2) : 0) + (lastW ? (qw < 2 ? 1 : 2) : 0);
-        const int labkh = 3 * (lastH ? (lg < 2 ? 1 : 2) : 0);
+// Shift mask of one window for this lane's (query l15, keys 4lg..4lg+3): -100 where query and key carry different region labels
+// (attention.py:56-75, 233-236).  It only depends on the window, so it is built once per window, not once per head.
+__device__ __forceinline__ f32x4 window_shift_mask(int l15, int lg, bool lastH, bool lastW) {
+    const int qh = l15 >> 2, qw = l15 & 3;
+    const int labq = 3 * (lastH ? (qh < 2 ? 1 : 2) : 0) + (lastW ? (qw < 2 ? 1 : 2) : 0);
+    const int labkh = 3 * (lastH ? (lg < 2 ? 1 : 2) : 0);
+    f32x4 m;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int labk = labkh + (lastW ? (r < 2 ? 1 : 2) : 0);
-            s[r] += (labk != labq) ? -100.0f : 0.0f;
-        }
+    for (int r = 0; r < 4; ++r) {
+        const int labk = labkh + (lastW ? (r < 2 ? 1 : 2) : 0);
+        m[r] = (labk != labq) ? -100.0f : 0.0f;
     }
+    return m;
+}
+
+// softmax over the 16 keys of one query row held as 4 values x 4 lane groups (attention.py:226-238)
+__device__ __forceinline__ f32x4 window_softmax(f32x4 s, f32x4 bias_row, f32x4 shift_mask, bool shifted) {
+    s += bias_row;              // bias_tab[head][query l15][keys 4lg..4lg+3], loaded by the caller a whole GEMM ahead of its use
+    if (shifted) s += shift_mask;
     float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
     mx = max_groups(mx);
+    const float ml = -mx * 1.44269504088896341f;
     f32x4 p;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) p[r] = exp_fast(s[r] - mx);
+    for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], 1.44269504088896341f, ml));       // exp(s - max)
     float den = (p[0] + p[1]) + (p[2] + p[3]);
     den = sum_groups(den);
-    const float inv = 1.0f / den;
+    const float inv = __builtin_amdgcn_rcpf(den);      // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[r] *= inv;
     return p;
@@ -295,6 +302,9 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
 #else
 #define ESCX_TS(var)
 #endif
+    f32x4 shmask[TMW];
+#pragma unroll
+    for (int t = 0; t < TMW; ++t) shmask[t] = window_shift_mask(l15, lg, lastH[t], lastW[t]);
     GroupConst cur = load_consts(g0);
     for (int g = g0; g < g1; ++g) {
         tile = 0;
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
                     f32x4 s = zero4();
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s = __builtin_amdgcn_mfma_f32_16x16x4f32(k[t][r], q[t][r], s, 0, 0, 0);
-                    p0[t] = window_softmax(s, cur.bt0, l15, lg, a.shifted, lastH[t], lastW[t]);
+                    p0[t] = window_softmax(s, cur.bt0, shmask[t], a.shifted);
                 } else {        // two heads share the tile: head A on k-slot groups 0,1 and head B on 2,3
                     f32x4 sa = zero4(), sb = zero4();
 #pragma unroll
@@ -328,8 +338,8 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
                         sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k[t][r], lg < 2 ? q[t][r] : 0.f, sa, 0, 0, 0);
                         sb = __builtin_amdgcn_mfma_f32_16x16x4f32(k[t][r], lg < 2 ? 0.f : q[t][r], sb, 0, 0, 0);
                     }
-                    p0[t] = window_softmax(sa, cur.bt0, l15, lg, a.shifted, lastH[t], lastW[t]);
-                    p1[t] = window_softmax(sb, cur.bt1, l15, lg, a.shifted, lastH[t], lastW[t]);
+                    p0[t] = window_softmax(sa, cur.bt0, shmask[t], a.shifted);
+                    p1[t] = window_softmax(sb, cur.bt1, shmask[t], a.shifted);
                 }
             }
             ESCX_SGB_MFMA((MODE == 0 ? 4 : 8) * TMW);
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
             }
             f32x4 p[TMW];
 #pragma unroll
-            for (int t = 0; t < TMW; ++t) p[t] = window_softmax(s[t], cur.bt0, l15, lg, a.shifted, lastH[t], lastW[t]);
+            for (int t = 0; t < TMW; ++t) p[t] = window_softmax(s[t], cur.bt0, shmask[t], a.shifted);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 begin_tile();
@@ -595,6 +605,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
         return c;
     };
 
+    const f32x4 shmask = window_shift_mask(qslot, lg, true, lastW);
     GroupConst cur = load_consts(g0);
     for (int g = g0; g < g1; ++g) {
         tile = 0;
@@ -621,7 +632,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
             sB = __builtin_amdgcn_mfma_f32_16x16x4f32(kB[r], q[r], sB, 0, 0, 0);
         }
         ESCX_SGB_MFMA(8);
-        const f32x4 p = window_softmax(isB ? sB : sA, cur.bt, qslot, lg, a.shifted, true, lastW);
+        const f32x4 p = window_softmax(isB ? sB : sA, cur.bt, shmask, a.shifted);
         begin_tile();
         f32x4 vt = tile_gemm(true) + bv;
         f32x4 vA, vB;

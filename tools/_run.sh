@@ -1,4 +1,5 @@
 cd /root/repo
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
 run() { env "$@" timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', d['value'], d['ms_per_step'])"; }
 cp efficient-speech-codec_amd/esc/lib/libescx.so /tmp/new.so
 for i in 1 2 3; do
