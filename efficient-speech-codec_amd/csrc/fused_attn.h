@@ -209,10 +209,10 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
     int tile = 0;
     auto begin_tile = [&]() { if (tile % UT == 0) next_stage(); ++tile; };
     // tile GEMM with the weight tile as the row operand: out[t] = W_tile . x^T  -> lane (token l15, rows 4lg + r)
-    auto gemm_w_rows = [&](f32x4* out) {
+    auto gemm_w_rows = [&](f32x4* out, f32x4 init) {       // init: the tile's bias rides in the accumulator
         f32x4 o2[TMW];
 #pragma unroll
-        for (int t = 0; t < TMW; ++t) { out[t] = zero4(); o2[t] = zero4(); }
+        for (int t = 0; t < TMW; ++t) { out[t] = init; o2[t] = zero4(); }
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const f32x4 w = next_frag();
@@ -229,10 +229,10 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
         if (TMW == 1) out[0] += o2[0];
     };
     // swapped: out[t] = x . W_tile^T -> lane (row l15 of the weight tile, tokens 4lg + r)
-    auto gemm_x_rows = [&](f32x4* out) {
+    auto gemm_x_rows = [&](f32x4* out, f32x4 init) {
         f32x4 o2[TMW];
 #pragma unroll
-        for (int t = 0; t < TMW; ++t) { out[t] = zero4(); o2[t] = zero4(); }
+        for (int t = 0; t < TMW; ++t) { out[t] = init; o2[t] = zero4(); }
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const f32x4 w = next_frag();
@@ -315,13 +315,11 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
         ESCX_TS(t1)
         f32x4 q[TMW], k[TMW], vt[TMW], o[TMW];
         if constexpr (MODE != 2) {
-            gemm_w_rows(q);
+            gemm_w_rows(q, cur.b[0]);
 #pragma unroll
-            for (int t = 0; t < TMW; ++t) q[t] = (q[t] + cur.b[0]) * a.scale;
+            for (int t = 0; t < TMW; ++t) q[t] *= a.scale;
             begin_tile();
-            gemm_w_rows(k);
-#pragma unroll
-            for (int t = 0; t < TMW; ++t) k[t] += cur.b[1];
+            gemm_w_rows(k, cur.b[1]);
             ESCX_TS(t2)
             f32x4 p0[TMW], p1[TMW];
 #pragma unroll
@@ -345,9 +343,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
             ESCX_SGB_MFMA((MODE == 0 ? 4 : 8) * TMW);
             ESCX_TS(t3)
             begin_tile();
-            gemm_x_rows(vt);
-#pragma unroll
-            for (int t = 0; t < TMW; ++t) vt[t] += cur.bv0;
+            gemm_x_rows(vt, f32x4{cur.bv0, cur.bv0, cur.bv0, cur.bv0});
             ESCX_TS(t4)
 #pragma unroll
             for (int t = 0; t < TMW; ++t) {
@@ -378,13 +374,11 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 if (half) begin_tile();
-                gemm_w_rows(q);
+                gemm_w_rows(q, cur.b[2 * half]);
 #pragma unroll
-                for (int t = 0; t < TMW; ++t) q[t] = (q[t] + cur.b[2 * half]) * a.scale;
+                for (int t = 0; t < TMW; ++t) q[t] *= a.scale;
                 begin_tile();
-                gemm_w_rows(k);
-#pragma unroll
-                for (int t = 0; t < TMW; ++t) k[t] += cur.b[2 * half + 1];
+                gemm_w_rows(k, cur.b[2 * half + 1]);
 #pragma unroll
                 for (int t = 0; t < TMW; ++t)
 #pragma unroll
@@ -397,9 +391,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 begin_tile();
-                gemm_x_rows(vt);
-#pragma unroll
-                for (int t = 0; t < TMW; ++t) vt[t] += (half ? cur.bv1 : cur.bv0);
+                { const float bvh = half ? cur.bv1 : cur.bv0; gemm_x_rows(vt, f32x4{bvh, bvh, bvh, bvh}); }
 #pragma unroll
                 for (int t = 0; t < TMW; ++t) {
                     o[t] = zero4();
@@ -575,8 +567,8 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
     };
     int tile = 0;
     auto begin_tile = [&]() { if (tile % UT == 0) next_stage(); ++tile; };
-    auto tile_gemm = [&](bool x_rows) -> f32x4 {
-        f32x4 o1 = zero4(), o2 = zero4();
+    auto tile_gemm = [&](bool x_rows, f32x4 init) -> f32x4 {       // init: the tile's bias rides in the accumulator
+        f32x4 o1 = init, o2 = zero4();
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const f32x4 w = next_frag();
@@ -614,9 +606,9 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
         const GroupConst nxt = load_consts(min(g + 1, g1 - 1));
         const f32x4 bk = cur.bk;
         const float bv = cur.bv;
-        f32x4 q = (tile_gemm(false) + cur.bq) * a.scale;
+        f32x4 q = tile_gemm(false, cur.bq) * a.scale;
         begin_tile();
-        f32x4 k = tile_gemm(false) + bk;
+        f32x4 k = tile_gemm(false, bk);
         // scores of both windows against every packed query; a lane keeps its own window's row
         f32x4 kA, kB;
 #pragma unroll
@@ -634,7 +626,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
         ESCX_SGB_MFMA(8);
         const f32x4 p = window_softmax(isB ? sB : sA, cur.bt, shmask, a.shifted);
         begin_tile();
-        f32x4 vt = tile_gemm(true) + bv;
+        f32x4 vt = tile_gemm(true, f32x4{bv, bv, bv, bv});
         f32x4 vA, vB;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

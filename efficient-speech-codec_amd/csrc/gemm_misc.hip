@@ -41,12 +41,14 @@ void gemm_deembed_composed(const float* x, int B, int H, int Wd, int Cp, const f
     else launch_gemm<64>(ld, W, M, 16, 49 * Cp, ep, s, 1, pick_bk(Cp));
 }
 
-int pvq_down_splits(int M, int Kp, int Cp) {
+// Split-K factor of the PVQ down-projection.  It must not depend on the batch: the partial sums are added in a fixed order, but a
+// different number of slices would re-associate the fp32 sum and could move a near-tie code, i.e. a clip would no longer get the
+// same codes in every batch / shard it is processed in (test_node_batch_288_matches_its_36_clip_shards).
+int pvq_down_splits(int /*M*/, int Kp, int Cp) {
     const int BK = pick_bk(Cp);
     const int kIters = Kp / BK;
-    const int blocksM = (M + 63) / 64;
-    int splits = (768 + blocksM - 1) / blocksM;
-    if (splits > kIters / 2) splits = kIters / 2;
+    int splits = kIters / 2;
+    if (splits > 16) splits = 16;
     if (splits < 1) splits = 1;
     const int per = (kIters + splits - 1) / splits;
     return (kIters + per - 1) / per;
