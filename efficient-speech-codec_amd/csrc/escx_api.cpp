@@ -814,7 +814,7 @@ static int pick_nw(long long tiles, int units, int cap = 4) {
     auto cost = [&](int nw) { const long long wg = (tiles / units + nw - 1) / nw; return ((wg + 255) / 256) * ((nw + 3) / 4) * units; };
     return cost(8) <= cost(4) ? 8 : 4;
 }
-static int mlp_cap(int Cp) { return Cp <= 96 ? 4 : (Cp <= 192 ? 3 : 1); }                              // fused_mlp.h: mlp_min_waves<CP, 1>
+static int mlp_cap(int Cp) { return Cp <= ESCX_MLP_OCC4 ? 4 : (Cp <= 192 ? 3 : 1); }                              // fused_mlp.h: mlp_min_waves<CP, 1>
 static int attn_cap(int Cp, int tmw) { const int v = Cp * tmw; return v <= 96 ? 4 : (v <= 160 ? 3 : (v <= 192 ? 2 : 1)); }   // fused_attn.h: attn_min_waves
 // Hidden split of the fused MLP (fused_mlp.h): at the deep scales a clip has so few token rows (600 / 1200 at C = 384 / 192
 // for 3 s) that one wave per 16-row tile cannot fill 1024 SIMDs at serving batch sizes, so three workgroups share a row block

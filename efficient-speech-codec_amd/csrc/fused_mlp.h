@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gemm_engine.h"
+#include "launchers.h"
 
 namespace escx {
 
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
 // Occupancy target: the loop has serial phases (DMA issue, GELU, barrier) that only a co-resident wave can cover, so the
 // register budget is capped to fit 3-4 waves per SIMD where the tile sizes allow (s_memtime traces: with one wave per SIMD a
 // hidden tile takes ~5600 cycles for 3072 cycles of MFMA work).
-template <int CP, int TM> constexpr int mlp_min_waves() { return (CP * TM <= 96) ? 4 : ((CP * TM <= 192) ? 3 : 1); }
+template <int CP, int TM> constexpr int mlp_min_waves() { return (CP * TM <= ESCX_MLP_OCC4) ? 4 : ((CP * TM <= 192) ? 3 : 1); }
 
 template <int CP, int TM, int NW, int ABL = 0>      // ABL: timing-only ablation bits (never used by the product path)
 __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_lds_kernel(MlpArgs a) {

@@ -15,6 +15,10 @@ void gemm_residual(const float* A, int lda, int M, const float* W, int Np, int K
 void gemm_store(const float* A, int lda, int M, const float* W, int Np, int Kp, float* out, int ldo, const float* bias, hipStream_t s);
 void gemm_split(const float* A, int lda, int M, const float* W, int Np, int Kp, float* out, int H, int Wd, int C2p, hipStream_t s);
 
+// widest padded row (CP * TM) for which the fused MLP is compiled for 4 waves per SIMD (128 VGPRs); 3 waves up to 192
+#ifndef ESCX_MLP_OCC4
+#define ESCX_MLP_OCC4 96
+#endif
 // windows per wave of the fused attention: two up to this padded width (they share every weight fragment), one above
 #ifndef ESCX_ATTN_TMW2_MAX
 #define ESCX_ATTN_TMW2_MAX 48
