@@ -652,7 +652,8 @@ static int reserve_frames(escx_handle_s* h, int Btotal, int T) {
     auto add = [&](size_t nfl) { total += (nfl * sizeof(float) + 255) / 256 * 256; };
     add(spec); for (int i = 0; i < n; ++i) add(ehs[i]);
     add(work); add(xn); add(qkv); add(ob); add(hid); add(dec); add(dec); add(zp); add(deemb); add(rspec); add(frames);
-    add(stage); add(stage); add(codes); add(B);
+    const size_t lterms = (size_t)c.max_streams * c.group_size * B * s.Tq;
+    add(stage); add(stage); add(codes); add(B); add(lterms);
 
     ESCX_HIP(hipDeviceSynchronize());
     for (int si = 0; si < escx_handle_s::MAX_PARTS; ++si) {
@@ -671,7 +672,7 @@ static int reserve_frames(escx_handle_s* h, int Btotal, int T) {
         S.deemb = S.ws.take(deemb); S.rspec = S.ws.take(rspec); S.frames = S.ws.take(frames);
         S.stageA = S.ws.take(stage); S.stageB = S.ws.take(stage);
         S.codes_tmp = reinterpret_cast<long long*>(S.ws.take(codes));
-        S.loss = S.ws.take(B);
+        S.loss = S.ws.take(B); S.loss_terms = S.ws.take(lterms);
         if (!S.loss) ESCX_FAIL(ESCX_ERR_STATE, "workspace sizing bug");
         S.shp = s;
     }
@@ -1100,25 +1101,33 @@ extern "C" int escx_decode(escx_handle h, const int64_t* codes, int B, int S, in
     return rc;
 }
 
-extern "C" int escx_forward(escx_handle h, const float* wave, int B, int L, int S, int64_t* codes, float* wave_out, float* raw_feat,
-                            float* recon_feat, float* cm_loss, void* stream) {
+// codecs.py:30-66 in eval mode.  Exactly one of `wave` (B, L) and `feat` (B, T, in_dim, F: the reference's x_feat (B,F,T,2)
+// permuted to frame-major) is given; with `feat` the STFT is skipped (codecs.py:33-34).
+static int forward_impl(escx_handle h, const float* wave, const float* feat, int B, int L, int T, int S, int64_t* codes, float* wave_out,
+                        float* raw_feat, float* recon_feat, float* cm_loss, void* stream) {
     int rc = check_ready(h); if (rc) return rc;
-    if (!wave || !codes || !wave_out) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
+    if ((!wave && !feat) || !codes || !wave_out) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
     const escx_config& c = h->cfg;
     if (S < 1 || S > c.max_streams) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "num_streams=%d outside [1, %d]", S, c.max_streams);
-    if (L <= h->n_fft / 2) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_samples=%d too short for reflect padding of %d", L, h->n_fft / 2);
-    Shapes s; if ((rc = ensure_ws(h, B, frames_of(h, L), &s))) return rc;
+    if (wave && L <= h->n_fft / 2) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_samples=%d too short for reflect padding of %d", L, h->n_fft / 2);
+    if (!wave && T < c.patch_t) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_frames=%d shorter than one patch", T);
+    if (wave) T = frames_of(h, L);
+    Shapes s; if ((rc = ensure_ws(h, B, T, &s))) return rc;
+    if (s.W % c.overlap) ESCX_FAIL(ESCX_ERR_ASSERT, "Time dimension must be multiple of overlap");
     const int n = h->n, G = c.group_size;
     const long long bstride = (long long)S * G * s.Tq, sstride = (long long)G * s.Tq;
     const int T2 = c.patch_t * s.W, out_len = c.hop_length * (T2 - 1);
     return run_halves(h, B, (hipStream_t)stream, [&](int b0, int nb, hipStream_t st) -> int {
         Shapes sp = s; sp.B = nb; int r;
         long long* cd = (long long*)codes + b0 * bstride;
-        if ((r = run_stft(h, wave + (size_t)b0 * L, nb, L, sp.T, h->spec, st))) return r;
+        if (wave) { if ((r = run_stft(h, wave + (size_t)b0 * L, nb, L, sp.T, h->spec, st))) return r; }
+        else spec_pad(h, feat + (size_t)b0 * sp.T * c.in_dim * h->F, h->spec, (long long)nb * sp.T, st);
         if (raw_feat) spec_unpad(h, h->spec, raw_feat + (size_t)b0 * sp.T * c.in_dim * h->F, (long long)nb * sp.T, st);
         if ((r = run_encoder(h, sp, st))) return r;
-        float* loss = cm_loss ? h->loss : nullptr;
-        if (loss) ESCX_HIP(hipMemsetAsync(loss, 0, sizeof(float) * nb, st));
+        // per-vector commitment terms of stream slot i go to loss_terms[i][G][nb*Tq]; reduced per clip at the end (no atomics)
+        const size_t lslot = (size_t)G * nb * sp.Tq;
+        float* loss = cm_loss ? h->loss_terms : nullptr;
+        int n_slots = 1;
         // csrvq.py:97-129 in eval mode: stream 0, then (stream i+1, block i) pairs; untransmitted streams pass through
         int H = sp.encH[n - 1], Hn;
         float* dec = h->decA; float* other = h->decB;
@@ -1127,7 +1136,8 @@ extern "C" int escx_forward(escx_handle h, const float* wave, int B, int L, int 
         for (int i = 0; i + 1 < n; ++i) {
             if (i < S - 1) {
                 const Quant& q = h->quants[i + 1];
-                if ((r = run_pvq_encode(h, q, h->enc_hs[n - 1 - i], dec, nb, sp.W, cd + (i + 1) * sstride, bstride, loss, st))) return r;
+                if ((r = run_pvq_encode(h, q, h->enc_hs[n - 1 - i], dec, nb, sp.W, cd + (i + 1) * sstride, bstride, loss ? loss + (size_t)(i + 1) * lslot : nullptr, st))) return r;
+                n_slots = i + 2;
                 if ((r = run_pvq_decode(h, q, cd + (i + 1) * sstride, bstride, dec, nb, sp.W, dec, st))) return r;
             }
             if ((r = run_layer(h, h->layers[n + i], dec, other, nb, H, sp.W, &Hn, st))) return r;
@@ -1137,9 +1147,21 @@ extern "C" int escx_forward(escx_handle h, const float* wave, int B, int L, int 
         if ((r = run_deembed(h, other, nb, sp.W, h->rspec, st))) return r;
         if ((r = run_istft(h, h->rspec, nb, T2, wave_out + (size_t)b0 * out_len, st))) return r;
         if (recon_feat) spec_unpad(h, h->rspec, recon_feat + (size_t)b0 * T2 * c.in_dim * h->F, (long long)nb * T2, st);
-        if (cm_loss) ESCX_HIP(hipMemcpyAsync(cm_loss + b0, loss, sizeof(float) * nb, hipMemcpyDeviceToDevice, st));
+        if (cm_loss) loss_reduce(loss, n_slots, G, nb * sp.Tq, sp.Tq, cm_loss + b0, st);
         return launch_ok("forward");
     });
+}
+
+extern "C" int escx_forward(escx_handle h, const float* wave, int B, int L, int S, int64_t* codes, float* wave_out, float* raw_feat,
+                            float* recon_feat, float* cm_loss, void* stream) {
+    if (!wave) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
+    return forward_impl(h, wave, nullptr, B, L, 0, S, codes, wave_out, raw_feat, recon_feat, cm_loss, stream);
+}
+
+extern "C" int escx_forward_feat(escx_handle h, const float* feat, int B, int T, int S, int64_t* codes, float* wave_out, float* recon_feat,
+                                 float* cm_loss, void* stream) {
+    if (!feat) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
+    return forward_impl(h, nullptr, feat, B, 0, T, S, codes, wave_out, nullptr, recon_feat, cm_loss, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -66,7 +66,7 @@ struct WsFields {                    // one workspace: every scratch buffer of t
     Shapes shp;                      // shapes this set was sized for (shp.B = clips it can hold)
     float *spec = nullptr, *work = nullptr, *xn = nullptr, *qkv = nullptr, *obuf = nullptr, *hid = nullptr;
     float *decA = nullptr, *decB = nullptr, *zpart = nullptr, *deemb = nullptr, *rspec = nullptr, *frames = nullptr;
-    float *stageA = nullptr, *stageB = nullptr, *loss = nullptr;
+    float *stageA = nullptr, *stageB = nullptr, *loss = nullptr, *loss_terms = nullptr;     // loss_terms: [max_streams][G][B*Tq] per-vector commitment terms
     long long* codes_tmp = nullptr;
     std::vector<float*> enc_hs;
     size_t zpart_cap = 0;

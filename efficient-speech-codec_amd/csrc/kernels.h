@@ -166,7 +166,7 @@ struct SearchArgs {
     const float* cbn; const float* c2; const float* cbraw; // [G][Ksz][dt], [G][Ksz], [G][Ksz][dt]
     int Ksz, d, Tq;
     long long* codes; long long bstride;                   // codes[b*bstride + g*Tq + t]
-    float* loss; float loss_scale;                         // optional: loss[b] += scale * sum_j (cb[code][j]-z[j])^2
+    float* loss; float loss_scale;                         // optional: loss[g*M + m] = scale * sum_j (cb[code][j]-z[j])^2 (reduced per clip, in fixed order, by loss_reduce_kernel)
     int l2norm;
 };
 
@@ -264,10 +264,26 @@ __global__ __launch_bounds__(256) void pvq_search_kernel(SearchArgs a) {
                 const float* q = a.cbraw + ((size_t)g * a.Ksz + i0) * DT;
                 float e = 0.f;
                 for (int j = 0; j < a.d; ++j) { const float df = q[j] - zs[tid][j]; e += df * df; }
-                atomicAdd(a.loss + b, e * a.loss_scale);
+                a.loss[(size_t)g * a.M + m] = e * a.loss_scale;       // no atomics: the per-clip sum must be run-to-run deterministic
             }
         }
     }
+}
+
+// cm_loss[b] = sum over (stream slot, group, frame) of the per-vector terms written by pvq_search_kernel, in a fixed order:
+// lane l of the clip's wave adds terms l, l+64, ... in increasing index order, then a fixed butterfly joins the 64 lanes.
+// terms: [n_slots][G][M] with M = B*Tq rows laid out (b, t).
+__global__ __launch_bounds__(64) void loss_reduce_kernel(const float* __restrict__ terms, int n_slots, int G, int M, int Tq, float* __restrict__ out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int per = n_slots * G * Tq;
+    float acc = 0.f;
+    for (int i = lane; i < per; i += 64) {
+        const int sg = i / Tq, t = i - sg * Tq;
+        acc += terms[(size_t)sg * M + (size_t)b * Tq + t];
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) out[b] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------

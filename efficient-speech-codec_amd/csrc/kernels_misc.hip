@@ -53,6 +53,10 @@ int pvq_search(const float* zpart, int splits, int M, int ldz, const float* cbn,
 #undef ESCX_SRCH
 }
 
+void loss_reduce(const float* terms, int n_slots, int G, int M, int Tq, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(M / Tq), dim3(64), 0, s, terms, n_slots, G, M, Tq, out);
+}
+
 void istft_ola(const float* frames, const float* win2, float* wave, int B, int T, int ldf, int win, int hop, int left, int half,
                int out_len, hipStream_t s) {
     const long long n = (long long)B * out_len;

@@ -33,6 +33,7 @@ void rows_combine(float* dst, const float* src, const float* partial, const floa
 // LN + linear for PatchMerge (segs = 2, map gives the two source rows) / PatchSplit (segs = 1, split = 1: pixel-shuffled store)
 int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, const float* beta, const float* wf, const int* map, int M,
                   int rows_per_clip, int src_rows_per_clip, int C, int Cp, int Np, int split, int H, int W, int C2p, hipStream_t s);
+void loss_reduce(const float* terms, int n_slots, int G, int M, int Tq, float* out, hipStream_t s);     // per-clip commitment loss, fixed summation order
 void mlp_set_trace(unsigned long long* p);
 int test_fastdiv(int n, int d);       // host evaluation of gemm_engine.h FastDiv (gemm_misc.hip)
 // halo-tiled composed de-embedding (fused_deembed.h); -1 when the width / output count is not instantiated

@@ -36,6 +36,7 @@ SIGNATURES = {
     "escx_encode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, POINTER(c_int), POINTER(c_int), c_void_p]),
     "escx_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "escx_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "escx_forward_feat": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "escx_num_frames": (c_int, [c_void_p, c_int]),
     "escx_output_samples": (c_int, [c_void_p, c_int]),
     "escx_spec_transform": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -304,7 +304,7 @@ class ESC(nn.Module):
             raise NotImplementedError("training-mode forward (STE, codebook losses, backward) is outside the accelerated "
                                       "inference path; call model.eval() first")
         if x_feat is not None:
-            raise NotImplementedError("forward(x_feat=...) with a precomputed spectrum is not implemented; pass x_feat=None")
+            return self._forward_from_feat(x, x_feat, int(num_streams))
         if x.dim() != 2:
             raise ValueError("x must have shape (Bs, L)")
         self._need_gpu(x, "x")
@@ -328,6 +328,31 @@ class ESC(nn.Module):
                                            recon_feat.data_ptr(), cm.data_ptr(), self._stream(dev)))
         return {"cm_loss": cm, "cb_loss": cm.clone(), "raw_audio": x, "recon_audio": recon,
                 "raw_feat": raw_feat.permute(0, 2, 3, 1), "recon_feat": recon_feat.permute(0, 2, 3, 1), "codes": codes}
+
+    def _forward_from_feat(self, x, x_feat, S):
+        """forward(x, x_feat=...) of the reference (codecs.py:33-34): x_feat is the complex STFT as a real tensor laid out
+        (Bs, F, T, 2) - what `rearrange(x_feat, "b h w c -> b c h w")` expects, despite the docstring - and replaces
+        spec_transform(x).  The permutation to the library's frame-major layout is plain data movement."""
+        if x_feat.dim() != 4 or x_feat.shape[1] != self.in_freq or x_feat.shape[3] != self.in_dim:
+            raise ValueError(f"x_feat must have shape (Bs, {self.in_freq}, T, {self.in_dim})")
+        self._need_gpu(x_feat, "x_feat")
+        feat = x_feat.to(torch.float32).permute(0, 2, 3, 1).contiguous()            # (B, T, 2, F)
+        B, T = feat.shape[0], feat.shape[1]
+        pt = self.cfg["patch_size"][1]
+        W = T // pt
+        if W < 1 or W % self.cfg["overlap"] != 0:
+            raise AssertionError("Time dimension must be multiple of overlap")
+        dev = feat.device
+        lib, hd = self._handle(dev)
+        codes = torch.empty((B, S, self.cfg["group_size"], W // self.cfg["overlap"]), dtype=torch.int64, device=dev)
+        recon = torch.empty((B, self.hop_length * (pt * W - 1)), dtype=torch.float32, device=dev)
+        recon_feat = torch.empty((B, pt * W, self.in_dim, self.in_freq), dtype=torch.float32, device=dev)
+        cm = torch.empty((B,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _native.check(lib.escx_forward_feat(hd, feat.data_ptr(), B, T, S, codes.data_ptr(), recon.data_ptr(), recon_feat.data_ptr(),
+                                                cm.data_ptr(), self._stream(dev)))
+        return {"cm_loss": cm, "cb_loss": cm.clone(), "raw_audio": x, "recon_audio": recon,
+                "raw_feat": x_feat.permute(0, 3, 1, 2), "recon_feat": recon_feat.permute(0, 2, 3, 1), "codes": codes}
 
     def forward(self, x, x_feat, num_streams, freeze_codebook=False):
         """Eval-mode forward of the reference (codecs.py:48-66): dict with cm_loss, cb_loss, raw_audio, recon_audio,

@@ -99,6 +99,10 @@ int escx_decode(escx_handle h, const int64_t* codes_dev, int batch, int num_stre
 int escx_forward(escx_handle h, const float* wave_dev, int batch, int n_samples, int num_streams,
                  int64_t* codes_dev, float* wave_out_dev, float* raw_feat_dev, float* recon_feat_dev,
                  float* cm_loss_dev, void* stream);
+/* The same with a precomputed spectrum instead of the waveform (forward(x, x_feat=...), codecs.py:33-34): feat_dev is
+ * (B, T, 2, in_freq) f32 frame-major, i.e. the reference's x_feat (B,F,T,2) permuted (0,2,3,1); the STFT is skipped. */
+int escx_forward_feat(escx_handle h, const float* feat_dev, int batch, int n_frames, int num_streams,
+                      int64_t* codes_dev, float* wave_out_dev, float* recon_feat_dev, float* cm_loss_dev, void* stream);
 int escx_num_frames(escx_handle h, int n_samples);      /* T = 1 + n_samples / hop                      */
 int escx_output_samples(escx_handle h, int feat_w);     /* hop * (patch_t * W - 1)                      */
 

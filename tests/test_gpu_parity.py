@@ -280,6 +280,28 @@ def test_forward_eval_dict(base):
         assert rel_rms(out["recon_feat"].cpu(), ref["recon_feat"]) < 1e-4
 
 
+def test_forward_with_precomputed_spectrum(base):
+    """forward(x, x_feat=...) (codecs.py:33-34): the spectrum the library itself returns, fed back as x_feat (Bs,F,T,2), must
+    reproduce codes, audio and losses bit for bit (the STFT is the only thing skipped); the oracle agrees on codes and audio."""
+    model, orc, g, cfg = base
+    x = torch.from_numpy(synth.pcm_to_float(g["pcm"])).cuda()
+    for s in (6, 2):
+        ref = model(**dict(x=x, x_feat=None, num_streams=s))
+        x_feat = ref["raw_feat"].permute(0, 2, 3, 1).contiguous()              # (B,2,F,T) -> (B,F,T,2)
+        out = model(**dict(x=x, x_feat=x_feat, num_streams=s))
+        assert set(out) == set(ref)
+        assert torch.equal(out["codes"], ref["codes"]) and torch.equal(out["recon_audio"], ref["recon_audio"])
+        assert torch.equal(out["cm_loss"], ref["cm_loss"]) and torch.equal(out["recon_feat"], ref["recon_feat"])
+        assert out["raw_feat"].shape == ref["raw_feat"].shape and torch.equal(out["raw_feat"], ref["raw_feat"])
+        o = orc.forward_eval(x.cpu(), x_feat.cpu(), s)
+        assert torch.equal(o["codes"], out["codes"].cpu()), code_report(out["codes"].cpu().numpy(), o["codes"].numpy())
+        assert rms(out["recon_audio"].cpu().numpy(), o["recon_audio"].numpy()) <= AUDIO_TOL
+    with pytest.raises(ValueError):
+        model(**dict(x=x, x_feat=x_feat[:, :100], num_streams=6))
+    with pytest.raises(AssertionError, match="multiple of overlap"):
+        model(**dict(x=x, x_feat=x_feat[:, :, :302].contiguous(), num_streams=6))      # W = 151, overlap 2
+
+
 def test_full_size_invariants_batch36(base):
     """BASELINE config 2 size (B=36, 3 s clips): prefix property, batch invariance, determinism, code range."""
     model, orc, g, cfg = base
