@@ -280,6 +280,28 @@ def test_forward_eval_dict(base):
         assert rel_rms(out["recon_feat"].cpu(), ref["recon_feat"]) < 1e-4
 
 
+def test_runs_on_the_callers_stream_and_is_deterministic(base):
+    """Work is enqueued on the caller's current stream (the extra part streams fork from and join it): results produced inside a
+    side stream, consumed there without any device-wide sync, equal the default-stream results bit for bit - including the
+    eval-mode losses (no atomics anywhere in the path)."""
+    model, orc, g, cfg = base
+    x = torch.from_numpy(synth.pcm_to_float(g["pcm"])).cuda()
+    ref = model(**dict(x=x, x_feat=None, num_streams=6))
+    again = model(**dict(x=x, x_feat=None, num_streams=6))
+    for k in ("codes", "recon_audio", "cm_loss", "cb_loss", "recon_feat", "raw_feat"):
+        assert torch.equal(ref[k], again[k]), f"{k} is not run-to-run deterministic"
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        xs = x * 1.0                                   # produced on the side stream right before the call
+        codes, shape = model.encode(xs, 6)
+        wave = model.decode(codes, shape)
+        checksum = wave.double().sum()                 # consumed on the side stream right after
+    side.synchronize()
+    assert torch.equal(codes, ref["codes"]) and torch.equal(wave, ref["recon_audio"])
+    assert float(checksum) == float(ref["recon_audio"].double().sum())
+
+
 def test_forward_with_precomputed_spectrum(base):
     """forward(x, x_feat=...) (codecs.py:33-34): the spectrum the library itself returns, fed back as x_feat (Bs,F,T,2), must
     reproduce codes, audio and losses bit for bit (the STFT is the only thing skipped); the oracle agrees on codes and audio."""
