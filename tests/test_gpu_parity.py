@@ -302,6 +302,36 @@ def test_runs_on_the_callers_stream_and_is_deterministic(base):
     assert float(checksum) == float(ref["recon_audio"].double().sum())
 
 
+def test_encode_decode_capture_into_a_hip_graph(base):
+    """After reserve(), a whole encode+decode (two parts on forked streams included) must be capturable into a hipGraph: no
+    allocation, no host synchronisation, no host-side reads inside the calls.  Replaying the graph on new input contents gives
+    the eager results bit for bit."""
+    model, orc, g, cfg = base
+    xa = torch.from_numpy(synth.pcm_to_float(np.stack([synth.noise_clip_int16(f"graph-a{i}", 48000) for i in range(4)]))).cuda()
+    xb = torch.from_numpy(synth.pcm_to_float(np.stack([synth.voiced_clip_int16(f"graph-b{i}", 48000) for i in range(4)]))).cuda()
+    model.reserve(4, 48000, xa.device)
+    eager = {}
+    for name, x in (("a", xa), ("b", xb)):
+        c, shp = model.encode(x, 6)
+        eager[name] = (c.clone(), model.decode(c, shp).clone())
+    x = xa.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            c, shp = model.encode(x, 6); model.decode(c, shp)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        codes, shp = model.encode(x, 6)
+        wave = model.decode(codes, shp)
+    for name, src in (("b", xb), ("a", xa), ("b", xb)):
+        x.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(codes, eager[name][0]) and torch.equal(wave, eager[name][1]), f"graph replay differs from eager on input {name}"
+
+
 def test_forward_with_precomputed_spectrum(base):
     """forward(x, x_feat=...) (codecs.py:33-34): the spectrum the library itself returns, fed back as x_feat (Bs,F,T,2), must
     reproduce codes, audio and losses bit for bit (the STFT is the only thing skipped); the oracle agrees on codes and audio."""
