@@ -413,6 +413,32 @@ def test_fused_and_unfused_pipelines_agree(base, monkeypatch):
     assert narrow_codes(codes).dtype == torch.int16 and torch.equal(widen_codes(narrow_codes(codes)), codes)
 
 
+def test_reloading_weights_after_use_takes_effect(base):
+    """load_state_dict / .to() after the first call must invalidate the packed device copy (compress.py:23-25 loads a checkpoint
+    into an already constructed model): a model that has already run with the fixture weights, reloaded with perturbed ones,
+    matches a fresh model built from the perturbed weights, and returns to the original results when reloaded back."""
+    from esc.models import make_model
+    from conftest import synth_state
+    model, orc, g, cfg = base
+    x = torch.from_numpy(synth.pcm_to_float(g["pcm"])).cuda()
+    sd0 = synth_state("base")
+    used = make_model(cfg); used.load_state_dict(sd0); used = used.cuda().eval()
+    c0, shp = used.encode(x, 6); w0 = used.decode(c0, shp)
+    sd1 = {k: (v * 1.01 if (v.is_floating_point() and "embedding" not in k and "window" not in k) else v) for k, v in sd0.items()}
+    used.load_state_dict(sd1)
+    c1, _ = used.encode(x, 6); w1 = used.decode(c1, shp)
+    fresh = make_model(cfg); fresh.load_state_dict(sd1); fresh = fresh.cuda().eval()
+    cf, _ = fresh.encode(x, 6); wf = fresh.decode(cf, shp)
+    assert torch.equal(c1, cf) and torch.equal(w1, wf)
+    assert not torch.equal(w1, w0), "the reloaded weights were ignored"
+    used.load_state_dict(sd0)
+    c2, _ = used.encode(x, 6)
+    assert torch.equal(c2, c0) and torch.equal(used.decode(c2, shp), w0)
+    moved = used.cpu().cuda()
+    c3, _ = moved.encode(x, 6)
+    assert torch.equal(c3, c0)
+
+
 def test_variable_bitrate_sweep_batch64(base):
     """BASELINE config 3: batch 64, num_streams 1..6 (the RVQ early-exit path).  Prefix property against the S=6 run,
     decode of every prefix finite and S-dependent, oracle agreement on a 2-clip sample per S."""
