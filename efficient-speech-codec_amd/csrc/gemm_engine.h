@@ -235,7 +235,8 @@ struct CodeGatherA {            // PVQ de-quantisation: A[(b,t)][g*dt + j] = cod
     __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
         const int k = k0 + kin; const int g = ddt.div(k);
         if (!c.c || g >= G) return zero4();
-        const long long code = c.c[(size_t)g * Tq];
+        long long code = c.c[(size_t)g * Tq];
+        code = code < 0 ? 0 : (code >= Ksz ? Ksz - 1 : code);     // a corrupt index must not read outside the codebook (F.embedding would raise)
         return ld4(cb + ((size_t)g * Ksz + (size_t)code) * dt + (k - g * dt));
     }
 };

@@ -92,6 +92,7 @@ int escx_encode(escx_handle h, const float* wave_dev, int batch, int n_samples, 
 /* ESC.decode (codecs.py:83-94): codes (B,S,G,T) int64 + feat_shape -> wave (B, hop*(2W-1)) f32.
  * recon_feat_dev (optional, may be NULL): (B, 2W, 2, in_freq) f32 frame-major spectrum, i.e. the
  * reference's recon_feat (B,2,F,T) permuted (0,3,1,2). */
+/* Code indices outside [0, codebook_size) are clamped (the reference's F.embedding raises a device-side assert there). */
 int escx_decode(escx_handle h, const int64_t* codes_dev, int batch, int num_streams, int feat_h, int feat_w,
                 float* wave_out_dev, float* recon_feat_dev, void* stream);
 /* ESC.forward in eval mode (codecs.py:30-66, csrvq.py:97-129): encoder once, quantise + decode in one pass.

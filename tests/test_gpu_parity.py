@@ -481,6 +481,23 @@ def test_node_batch_288_matches_its_36_clip_shards(base):
     assert torch.equal(oc, codes[287:288].cpu()), code_report(codes[287:288].cpu().numpy(), oc.numpy())
 
 
+def test_decode_survives_corrupt_code_indices(base):
+    """A transmitted code outside [0, 1024) must not make the de-quantisation gather read outside the codebook: indices are
+    clamped (documented in escx.h), the other clips of the batch are untouched."""
+    model, orc, g, cfg = base
+    x = torch.from_numpy(synth.pcm_to_float(g["pcm"])).cuda()
+    codes, shape = model.encode(x, 6)
+    good = model.decode(codes, shape)
+    bad = codes.clone()
+    bad[0, 2, 1, 10] = 5000; bad[0, 0, 0, 0] = -7; bad[0, 5, 2, 149] = 2 ** 40
+    clamp = codes.clone()
+    clamp[0, 2, 1, 10] = 1023; clamp[0, 0, 0, 0] = 0; clamp[0, 5, 2, 149] = 1023
+    out = model.decode(bad, shape)
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, model.decode(clamp, shape))
+    assert torch.equal(out[1], good[1])
+
+
 def test_c_abi_error_paths(base):
     """Status codes and messages of the C ABI (nothing throws across it)."""
     model, orc, g, cfg = base
