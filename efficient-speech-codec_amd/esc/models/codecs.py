@@ -271,6 +271,8 @@ class ESC(nn.Module):
             raise AssertionError("Time dimension must be multiple of overlap")       # quantization.py:407
         codes = torch.empty((B, int(num_streams), self.cfg["group_size"], W // self.cfg["overlap"]), dtype=torch.int64,
                             device=x.device)
+        if B == 0:                                      # empty batch: the reference returns empty codes and the latent shape
+            return codes, self.latent_shape(L)
         fh, fw = ctypes.c_int(), ctypes.c_int()
         with torch.cuda.device(x.device):
             _native.check(lib.escx_encode(hd, x.data_ptr(), B, L, int(num_streams), codes.data_ptr(), ctypes.byref(fh),
@@ -292,6 +294,8 @@ class ESC(nn.Module):
         pt = self.cfg["patch_size"][1]
         out = torch.empty((B, self.hop_length * (pt * W - 1)), dtype=torch.float32, device=codes.device)
         feat = torch.empty((B, pt * W, self.in_dim, self.in_freq), dtype=torch.float32, device=codes.device) if return_feat else None
+        if B == 0:
+            return (out, feat.permute(0, 2, 3, 1)) if return_feat else out
         with torch.cuda.device(codes.device):
             _native.check(lib.escx_decode(hd, codes.data_ptr(), B, S, H, W, out.data_ptr(),
                                           feat.data_ptr() if return_feat else None, self._stream(codes.device)))
@@ -323,7 +327,8 @@ class ESC(nn.Module):
         raw_feat = torch.empty((B, T, self.in_dim, self.in_freq), dtype=torch.float32, device=dev)
         recon_feat = torch.empty((B, pt * W, self.in_dim, self.in_freq), dtype=torch.float32, device=dev)
         cm = torch.empty((B,), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        if B > 0:
+          with torch.cuda.device(dev):
             _native.check(lib.escx_forward(hd, xin.data_ptr(), B, L, S, codes.data_ptr(), recon.data_ptr(), raw_feat.data_ptr(),
                                            recon_feat.data_ptr(), cm.data_ptr(), self._stream(dev)))
         return {"cm_loss": cm, "cb_loss": cm.clone(), "raw_audio": x, "recon_audio": recon,

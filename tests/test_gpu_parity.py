@@ -481,6 +481,19 @@ def test_node_batch_288_matches_its_36_clip_shards(base):
     assert torch.equal(oc, codes[287:288].cpu()), code_report(codes[287:288].cpu().numpy(), oc.numpy())
 
 
+def test_empty_batch(base):
+    """Bs = 0 flows through like in the reference (every op there accepts an empty batch): empty codes / audio of the right
+    trailing shapes, and the latent shape of the clip length."""
+    model, orc, g, cfg = base
+    x = torch.zeros(0, 48000, device="cuda")
+    codes, shape = model.encode(x, 4)
+    assert codes.shape == (0, 4, 3, 150) and codes.dtype == torch.int64 and tuple(shape) == (2, 300)
+    assert model.decode(codes, shape).shape == (0, 47920)
+    out = model(**dict(x=x, x_feat=None, num_streams=4))
+    assert out["codes"].shape == (0, 4, 3, 150) and out["recon_audio"].shape == (0, 47920) and out["cm_loss"].shape == (0,)
+    assert out["raw_feat"].shape == (0, 2, 192, 601) and out["recon_feat"].shape == (0, 2, 192, 600)
+
+
 def test_decode_survives_corrupt_code_indices(base):
     """A transmitted code outside [0, 1024) must not make the de-quantisation gather read outside the codebook: indices are
     clamped (documented in escx.h), the other clips of the batch are untouched."""
