@@ -327,10 +327,10 @@ class ESC(nn.Module):
         raw_feat = torch.empty((B, T, self.in_dim, self.in_freq), dtype=torch.float32, device=dev)
         recon_feat = torch.empty((B, pt * W, self.in_dim, self.in_freq), dtype=torch.float32, device=dev)
         cm = torch.empty((B,), dtype=torch.float32, device=dev)
-        if B > 0:
-          with torch.cuda.device(dev):
-            _native.check(lib.escx_forward(hd, xin.data_ptr(), B, L, S, codes.data_ptr(), recon.data_ptr(), raw_feat.data_ptr(),
-                                           recon_feat.data_ptr(), cm.data_ptr(), self._stream(dev)))
+        with torch.cuda.device(dev):
+            if B > 0:                                   # an empty batch returns the (empty) buffers as they are
+                _native.check(lib.escx_forward(hd, xin.data_ptr(), B, L, S, codes.data_ptr(), recon.data_ptr(), raw_feat.data_ptr(),
+                                               recon_feat.data_ptr(), cm.data_ptr(), self._stream(dev)))
         return {"cm_loss": cm, "cb_loss": cm.clone(), "raw_audio": x, "recon_audio": recon,
                 "raw_feat": raw_feat.permute(0, 2, 3, 1), "recon_feat": recon_feat.permute(0, 2, 3, 1), "codes": codes}
 
