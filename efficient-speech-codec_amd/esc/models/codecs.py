@@ -304,7 +304,9 @@ class ESC(nn.Module):
         return out
 
     def forward_one_step(self, x, x_feat=None, num_streams=6, freeze_codebook=False):
-        if self.training or freeze_codebook:
+        if not self.training and freeze_codebook:
+            raise ValueError("``freeze_vq`` must be set False during inference")       # quantization.py:43-44
+        if self.training:
             raise NotImplementedError("training-mode forward (STE, codebook losses, backward) is outside the accelerated "
                                       "inference path; call model.eval() first")
         if x_feat is not None:

@@ -64,6 +64,11 @@ def test_reference_error_behaviour_on_host():
         ESC(backbone="convolution")
     with pytest.raises(NotImplementedError):
         make_model({}, "rvq+swinT")
+    m.eval()
+    with pytest.raises(ValueError, match="freeze_vq"):              # quantization.py:43-44
+        m(torch.zeros(1, 48000), None, 6, freeze_codebook=True)
+    with pytest.raises(ValueError):                                  # x_feat must be (Bs, F, T, 2)
+        m(torch.zeros(1, 48000), torch.zeros(1, 2, 192, 601), 6)
     m.train()
     with pytest.raises(NotImplementedError):
         m(torch.zeros(1, 48000), None, 6)
