@@ -62,24 +62,37 @@ __global__ __launch_bounds__(256) void gemm_kernel(Loader ld, const float* __res
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = zero4();
 
+    // Global -> register -> LDS with the NEXT K step's loads in flight while the current one is on the MFMA: the skinny, many-step
+    // GEMMs this engine serves (PVQ projections, STFT) are bound by one memory round trip per K step otherwise.
+    constexpr int BJ = (B4 + 255) / 256;
+    f32x4 ra[AJ], rb[BJ];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int i = tid + j * 256;
+            ra[j] = (A4 % 256 == 0 || i < A4) ? ld.load4(ctx[j], k0, 4 * (i % KV)) : zero4();
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int i = tid + j * 256;
+            const int row = i / KV, c4 = i % KV;
+            rb[j] = ((B4 % 256 == 0 || i < B4) && n0 + row < Np) ? ld4(Wt + (size_t)(n0 + row) * Kp + k0 + 4 * c4) : zero4();
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int i = tid + j * 256;
-            if (A4 % 256 == 0 || i < A4) {
-                const int row = i / KV, c4 = i % KV;
-                st4(&As[row * LDS_LD + 4 * c4], ld.load4(ctx[j], k0, 4 * c4));
-            }
+            if (A4 % 256 == 0 || i < A4) st4(&As[(i / KV) * LDS_LD + 4 * (i % KV)], ra[j]);
         }
 #pragma unroll
-        for (int i = tid; i < B4; i += 256) {
-            const int row = i / KV, c4 = i % KV;
-            const int n = n0 + row;
-            f32x4 v = zero4();
-            if (n < Np) v = ld4(Wt + (size_t)n * Kp + k0 + 4 * c4);
-            st4(&Bs[row * LDS_LD + 4 * c4], v);
+        for (int j = 0; j < BJ; ++j) {
+            const int i = tid + j * 256;
+            if (B4 % 256 == 0 || i < B4) st4(&Bs[(i / KV) * LDS_LD + 4 * (i % KV)], rb[j]);
         }
         __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             f32x4 af[TM], wf[TN];
@@ -444,7 +457,7 @@ struct EpiPartial {             // split-K partial sums, reduced in a fixed orde
 // ------------------------------------------------------------------------------------------------
 // Host-side tile selection and launch.
 // ------------------------------------------------------------------------------------------------
-inline int pick_bk(int Kp) { return Kp % 48 == 0 ? 48 : (Kp % 32 == 0 ? 32 : 16); }
+inline int pick_bk(int Kp) { return Kp % 48 == 0 ? 48 : (Kp % 80 == 0 ? 80 : (Kp % 32 == 0 ? 32 : 16)); }     // 80: the C = 72 maps (a 16-wide step there means 5x the K steps)
 inline int pick_bn(int Np) {
     // padded width, with a mild preference for wide tiles (every N tile re-stages the A tile)
     const int cands[4] = {96, 48, 32, 16};
@@ -478,6 +491,7 @@ inline void launch_gemm(const Loader& ld, const float* Wt, int M, int Np, int Kp
     const int BN = pick_bn(Np);
     const int BK = force_bk ? force_bk : pick_bk(Kp);
     switch (BK) {
+        case 80: launch_bn<BM, 80>(BN, ld, Wt, M, Np, Kp, splits, ep, s); break;
         case 48: launch_bn<BM, 48>(BN, ld, Wt, M, Np, Kp, splits, ep, s); break;
         case 32: launch_bn<BM, 32>(BN, ld, Wt, M, Np, Kp, splits, ep, s); break;
         default: launch_bn<BM, 16>(BN, ld, Wt, M, Np, Kp, splits, ep, s); break;

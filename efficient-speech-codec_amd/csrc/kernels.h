@@ -191,9 +191,17 @@ __global__ __launch_bounds__(256) void pvq_search_kernel(SearchArgs a) {
     for (int e = tid; e < 16 * DT; e += 256) {
         const int r = e / DT, j = e - r * DT;
         const int m = m0 + r;
+        // all slices are fetched before the first add (a load -> add -> load chain costs one memory round trip per slice); the
+        // sum itself keeps the order 0, 1, 2, ... (pvq_down_splits caps the slice count at 16)
+        float part[16];
+        const bool live = m < a.M && j < a.d;
+        const float* zp = a.zpart + (size_t)(live ? m : 0) * a.ldz + g * DT + (live ? j : 0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) part[s] = (live && s < a.splits) ? zp[(size_t)s * a.M * a.ldz] : 0.f;
         float z = 0.f;
-        if (m < a.M && j < a.d)
-            for (int s = 0; s < a.splits; ++s) z += a.zpart[((size_t)s * a.M + m) * a.ldz + g * DT + j];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) z += part[s];
+        for (int s = 16; s < a.splits; ++s) z += live ? zp[(size_t)s * a.M * a.ldz] : 0.f;
         zs[r][j] = z;
     }
     __syncthreads();
@@ -225,11 +233,20 @@ __global__ __launch_bounds__(256) void pvq_search_kernel(SearchArgs a) {
     bool have = false;
     const int per_wave = (a.Ksz + 3) / 4;
     const int cbeg = wave * per_wave, cend = min(a.Ksz, cbeg + per_wave);
-    for (int c0 = cbeg; c0 < cend; c0 += 16) {
-        const int crow = c0 + vi;
-        float cf[STEPS];
+    // Branch-free, one tile ahead: the codebook rows and the ||c||^2 of tile i+1 are in flight while tile i is on the MFMA.
+    // (With the loads predicated per lane and c2[code] fetched inside the compare loop, every tile cost five serialised L2 round
+    // trips: 40 us per launch for 5 us of work.)  Rows past the end are clamped, their codes are skipped by the range test below.
+    auto load_tile = [&](int c0, float* cf, float* c2v) {
+        const float* p = cb + (size_t)min(c0 + vi, a.Ksz - 1) * DT + STEPS * lg;
 #pragma unroll
-        for (int r = 0; r < STEPS; ++r) cf[r] = (crow < cend) ? cb[(size_t)crow * DT + STEPS * lg + r] : 0.f;
+        for (int r = 0; r < STEPS; ++r) cf[r] = p[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c2v[r] = c2[min(c0 + 4 * lg + r, a.Ksz - 1)];
+    };
+    float cf[STEPS], c2v[4], cfn[STEPS], c2n[4];
+    if (cbeg < cend) load_tile(cbeg, cf, c2v);
+    for (int c0 = cbeg; c0 < cend; c0 += 16) {
+        load_tile(min(c0 + 16, cend - 1), cfn, c2n);            // the last iteration re-reads its own tile (harmless)
         f32x4 dot = zero4();
 #pragma unroll
         for (int r = 0; r < STEPS; ++r) dot = __builtin_amdgcn_mfma_f32_16x16x4f32(cf[r], zf[r], dot, 0, 0, 0);
@@ -238,10 +255,14 @@ __global__ __launch_bounds__(256) void pvq_search_kernel(SearchArgs a) {
         for (int r = 0; r < 4; ++r) {
             const int code = c0 + 4 * lg + r;
             if (code < cend) {
-                const float dist = (av - dot[r]) + c2[code];
+                const float dist = (av - dot[r]) + c2v[r];
                 if (!have || arg_better(dist, code, bd, bi)) { bd = dist; bi = code; have = true; }
             }
         }
+#pragma unroll
+        for (int r = 0; r < STEPS; ++r) cf[r] = cfn[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c2v[r] = c2n[r];
     }
     if (!have) { bd = __builtin_inff(); bi = 0x7fffffff; }
     // across the 4 lane groups of the wave
