@@ -322,7 +322,7 @@ __device__ __forceinline__ float erf_bf(float x) {
     const float b = copysignf(1.0f - exp_fast(r), x);
     return t <= 0.92f ? a : b;
 }
-// Exact-erf GELU of the fused kernels, 12 straight-line VALU ops (the erf_bf form above costs 29, and at C <= 96 the fused MLP
+// Exact-erf GELU of the fused kernels, 11 straight-line VALU ops (the erf_bf form above costs 29, and at C <= 96 the fused MLP
 // issues more VALU than the matrix pipe can hide):  gelu(x) = x*Phi(x) = max(x, 0) - 0.5*|x| * erfc(|x|/sqrt2), with
 // erfc(a/sqrt2) = 2^Q8(a) fitted on [0, 5.8] (weighted minimax on the GELU's absolute error, fp64; beyond 5.8 the term is < 4e-8).
 // |gelu_bf - gelu| <= 1.25 * 2^-24 * max(|x|, 1) over the whole line - the 0.5*x*(1 + erff(x/sqrt2)) evaluation of the
@@ -337,8 +337,8 @@ __device__ __forceinline__ float gelu_bf(float x) {
     r = fmaf(r, a, -0.052714187651872635f);
     r = fmaf(r, a, -0.4591154456138611f);
     r = fmaf(r, a, -1.151123285293579f);
-    r = fmaf(r, a, 1.126017423302983e-06f);
-    return fmaf(-0.5f * fabsf(x), __builtin_amdgcn_exp2f(r), fmaxf(x, 0.0f));
+    r = fmaf(r, a, 1.126017423302983e-06f - 1.0f);             // the factor 1/2 of 0.5*|x|*erfc rides in the exponent
+    return fmaf(-fabsf(x), __builtin_amdgcn_exp2f(r), fmaxf(x, 0.0f));      // |x| and the negation are operand modifiers: 11 ops
 }
 
 struct EpiStore {               // out[m][n] = v (+ bias[n])
