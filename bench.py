@@ -6,7 +6,9 @@
 
 A step = ESC.encode (STFT -> encoder -> 6 cross-scale VQ streams) + [N>1: all-gather of the codes over RCCL] +
 ESC.decode (de-quantise -> decoder -> ISTFT) on 36 synthetic 3 s / 16 kHz clips per GPU (BASELINE configs[1]; at N=8
-this is configs[3]: 288 clips).  Weak scaling: per-GPU work is fixed.  Inputs are resident in HBM before the timed region.
+this is configs[3]: 288 clips).  Default = weak scaling: per-GPU work is fixed.  `--global-batch 288` is the STRONG-scaling mode
+of SURVEY 8(d) config 4: the batch is fixed, rank r takes shard_bounds(288, N, r) clips, "scaling": "strong"; at N=1 it is the
+whole 288-clip batch on one GPU.  Inputs are resident in HBM before the timed region.
 Weights are the deterministic name-keyed synthetic ESC-Base weights (no checkpoints exist offline); fp32 throughout.
 """
 import argparse
@@ -57,10 +59,24 @@ def build_model(device):
     return model.to(device).eval(), cfg, sd
 
 
-def synth_batch(n, rank):
+def synth_batch(n, rank, first=0):
+    """Clips `first .. first+n` of the job.  Weak mode: tags are per rank (`bench-r{rank}-{i}`); strong mode: global clip ids, so
+    that every world size processes the same 288 clips."""
     from esc import synth
-    pcm = np.stack([synth.noise_clip_int16(f"bench-r{rank}-{i}", N_SAMPLES) for i in range(n)])
+    if first is None:
+        tags = [f"bench-r{rank}-{i}" for i in range(n)]
+    else:
+        tags = [f"bench-r{g // CLIPS_PER_GPU}-{g % CLIPS_PER_GPU}" for g in range(first, first + n)]
+    pcm = np.stack([synth.noise_clip_int16(t, N_SAMPLES) for t in tags])
     return torch.from_numpy(synth.pcm_to_float(pcm))
+
+
+def shard_plan(global_batch, world, rank):
+    """(first clip, clips of this rank, per-rank counts).  bench.py's sharding rule == esc.distributed.shard_bounds."""
+    from esc.distributed import shard_bounds
+    counts = [shard_bounds(global_batch, world, r)[1] - shard_bounds(global_batch, world, r)[0] for r in range(world)]
+    lo, hi = shard_bounds(global_batch, world, rank)
+    return lo, hi - lo, counts
 
 
 def cpu_baseline(cfg, sd, x_cpu):
@@ -93,7 +109,18 @@ def cpu_baseline(cfg, sd, x_cpu):
         el = time.perf_counter() - t0
         if el > 10.0 or reps >= 12:
             break
+    # BASELINE configs[0]: ONE 3 s clip through the CPU path (what scripts/compress.py --device cpu does), same thread count
+    one = x_cpu[:1]
+    def single():
+        t0 = time.perf_counter()
+        c1, s1 = orc.encode(one, NUM_STREAMS)
+        orc.decode(c1, s1)
+        return time.perf_counter() - t0
+    single()
+    t1 = min(single() for _ in range(3))
     return {"value": round(reps * n * 3.0 / el, 3), "unit": "audio-seconds/sec", "cores": best_thr, "kind": "port",
+            "single_clip": {"ms": round(t1 * 1e3, 1), "audio_s_per_s": round(3.0 / t1, 2),
+                            "what": "BASELINE configs[0]: one 3 s clip, num_streams=6, encode+decode, oracle on the host cores"},
             "sample": f"{reps} x encode+decode of {n} clips (3 s each), oracle/esc_oracle.py, torch {torch.__version__} CPU fp32, "
                       f"{best_thr} of {avail} host threads (best of a 8/16/32/64 sweep)"}
 
@@ -104,6 +131,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: fix the JOB's batch (e.g. 288 = BASELINE configs[3]) and shard it over the ranks; "
+                         "default 0 = weak scaling with 36 clips per rank")
     ap.add_argument("--profile-steps", type=int, default=6)
     ap.add_argument("--skip-isolated", action="store_true",
                     help="omit the isolated-kernel timing pass (used under rocprofv3 so that its per-kernel averages cover two-stream launches only)")
@@ -125,13 +155,21 @@ def main():
 
     from esc.distributed import all_gather_codes
     model, cfg, sd = build_model(device)
-    x_cpu = synth_batch(CLIPS_PER_GPU, rank)
+    strong = args.global_batch > 0
+    if strong:
+        first, n_local, counts = shard_plan(args.global_batch, world, rank)
+        if n_local < 1:
+            raise SystemExit(f"--global-batch {args.global_batch} leaves rank {rank} of {world} without clips")
+    else:
+        first, n_local, counts = None, CLIPS_PER_GPU, [CLIPS_PER_GPU] * world
+    total_clips = sum(counts)
+    x_cpu = synth_batch(n_local, rank, first)
     x = x_cpu.to(device)
-    model.reserve(CLIPS_PER_GPU, N_SAMPLES, device)
+    model.reserve(n_local, N_SAMPLES, device)
 
     def step():
         codes, shape = model.encode(x, NUM_STREAMS)
-        allc = all_gather_codes(codes, force=use_dist) if (use_dist and not os.environ.get("ESCX_BENCH_SKIP_GATHER")) else codes
+        allc = all_gather_codes(codes, force=use_dist, counts=counts) if (use_dist and not os.environ.get("ESCX_BENCH_SKIP_GATHER")) else codes
         wave = model.decode(codes, shape)
         return allc, wave
 
@@ -152,7 +190,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert (allc.shape[0] == CLIPS_PER_GPU * world or os.environ.get("ESCX_BENCH_SKIP_GATHER")) and torch.isfinite(wave).all()
+    assert (allc.shape[0] == (total_clips if use_dist else n_local) or os.environ.get("ESCX_BENCH_SKIP_GATHER")) and torch.isfinite(wave).all()
 
     # per-kernel pass: HIP events around every launch, on the stream the kernels run on
     lib, hd = model._handle(device)
@@ -189,11 +227,11 @@ def main():
                         "frac": round(ach / PEAK_HBM, 4), "traffic": traffic}
         streams = int(os.environ.get("ESCX_STREAMS", "2"))
         roofline.update({"kernel": dom["name"], "avg_us": round(avg_s * 1e6, 2), "launches_per_step": dom["calls"] // args.profile_steps,
-                         "clips_per_launch": CLIPS_PER_GPU // max(streams, 1),
+                         "clips_per_launch": n_local // max(streams, 1),
                          "note": (f"{streams} streams: each launch covers 1/{streams} of the batch and overlaps with the other part's kernels, "
                                   "so the duration includes sharing the GPU (ESCX_PROF_SERIAL=1 isolates kernels)") if streams > 1 else "single stream",
                          "share_of_gpu_time": round(dom["ms"] / tot, 4),
-                         "executed_gflop_per_clip": round(sum(r["flops"] for r in recs) / args.profile_steps / CLIPS_PER_GPU / 1e9, 2)})
+                         "executed_gflop_per_clip": round(sum(r["flops"] for r in recs) / args.profile_steps / n_local / 1e9, 2)})
         if not args.skip_isolated:
             # the same kernel timed alone on the GPU (batch parts back to back instead of overlapped)
             lib.escx_profile_enable(hd, 2)
@@ -214,25 +252,43 @@ def main():
                     print(f"# {r['name']:28s} calls {r['calls']:4d}  {r['ms'] / args.profile_steps:9.3f} ms/step  "
                           f"{r['flops'] / max(r['ms'], 1e-9) / 1e9:9.1f} TFLOP/s  {r['bytes'] / max(r['ms'], 1e-9) / 1e6:9.1f} GB/s", file=sys.stderr)
 
+    single_gpu = None
+    if rank == 0 and world == 1:
+        # BASELINE configs[0] workload (one 3 s clip) on the GPU, next to cpu_baseline.single_clip
+        x1 = x[:1].contiguous()
+        for _ in range(3):
+            c1, s1 = model.encode(x1, NUM_STREAMS); model.decode(c1, s1)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for _ in range(20):
+            c1, s1 = model.encode(x1, NUM_STREAMS); model.decode(c1, s1)
+        torch.cuda.synchronize(device)
+        ms1 = (time.perf_counter() - t1) / 20 * 1e3
+        single_gpu = {"ms": round(ms1, 3), "audio_s_per_s": round(3.0 / (ms1 * 1e-3), 1)}
+
     if rank == 0:
-        audio_s = CLIPS_PER_GPU * world * args.steps * (N_SAMPLES / 16000.0)
+        audio_s = total_clips * args.steps * (N_SAMPLES / 16000.0)
         out = {
             "metric": "audio-seconds/sec encode+decode, ESC-Base 9kbps 3s@16kHz",
             "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ESC-Base 9kbps, batch={CLIPS_PER_GPU} 3-sec 16kHz clips per GPU, num_streams=6, "
-                                   f"encode+decode (BASELINE configs[{1 if world == 1 else 3}])",
-                       "global_batch": CLIPS_PER_GPU * world, "clip_samples": N_SAMPLES, "num_streams": NUM_STREAMS,
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"ESC-Base 9kbps, batch={total_clips} 3-sec 16kHz clips sharded over {world} GPU(s) "
+                                    f"({min(counts)}-{max(counts)} per rank), num_streams=6, encode+decode (BASELINE configs[3], fixed batch)")
+                                   if strong else
+                                   (f"ESC-Base 9kbps, batch={CLIPS_PER_GPU} 3-sec 16kHz clips per GPU, num_streams=6, "
+                                    f"encode+decode (BASELINE configs[{1 if world == 1 else 3}])"),
+                       "global_batch": total_clips, "clip_samples": N_SAMPLES, "num_streams": NUM_STREAMS,
                        "parallelism": f"dp{world}" + (" + all_gather(codes int16)" if world > 1 else ""),
                        "weights": "deterministic name-keyed synthetic (esc/synth.py)",
-                       "frames_per_sec": round(audio_s / elapsed * 200.0, 1)},
+                       "frames_per_sec": round(audio_s / elapsed * 200.0, 1),
+                       "single_clip_gpu": single_gpu},
             "roofline": roofline,
         }
         if roofline is not None:
             # whole path against the fp32 MFMA peak, from the timed region's wall clock: with the reference's algorithmic FLOPs
             # (56.75 GFLOP/clip) and with the FLOPs actually executed (the de-embedding is algebraically folded)
-            clips_per_s = CLIPS_PER_GPU * world * args.steps / elapsed
+            clips_per_s = total_clips * args.steps / elapsed
             roofline["whole_path_frac_ref_flops"] = round(FLOP_PER_CLIP * clips_per_s / world / PEAK_F32_MFMA, 4)
             roofline["whole_path_frac_executed_flops"] = round(roofline["executed_gflop_per_clip"] * 1e9 * clips_per_s / world / PEAK_F32_MFMA, 4)
         if not args.no_cpu_baseline and world == 1:

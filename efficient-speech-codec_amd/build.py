@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "esc", "lib")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(OUT_DIR, "libescx.so")
-SOURCES = ["escx_api.cpp", "gemm_swin.hip", "gemm_misc.hip", "kernels_misc.hip", "fused_swin.hip"]
+SOURCES = ["escx_api.cpp", "collective.cpp", "gemm_swin.hip", "gemm_misc.hip", "kernels_misc.hip", "fused_swin.hip"]
 HEADERS = ["gemm_engine.h", "kernels.h", "launchers.h", "escx_internal.h", "fused_mlp.h", "fused_attn.h", "fused_rowgemm.h", "fused_deembed.h", os.path.join("..", "..", "include", "escx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + os.environ.get("ESCX_EXTRA_CXXFLAGS", "").split()     # tuning builds only
@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=len(srcs)) as ex:
         objs = list(ex.map(compile_one, srcs))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

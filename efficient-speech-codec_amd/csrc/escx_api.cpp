@@ -149,6 +149,7 @@ extern "C" void escx_destroy(escx_handle h) {
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (auto& kv : h->maps) (void)hipFree(kv.second);
+    if (h->coll_buf) (void)hipFree(h->coll_buf);
     delete h;
 }
 
@@ -564,6 +565,13 @@ static int get_map(escx_handle_s* h, int H, int W, int shift, const int** out) {
             m[((size_t)h2 * W + w) * 2 + 1] = (2 * h2 + 1 < H) ? (2 * h2 + 1) * W + w : -1;
         }
     }
+    // Bounded cache: a caller that streams clips of many different lengths (scripts/test.py on a real data set) would otherwise
+    // grow device memory without limit.  Dropping every map needs the kernels that read them to have finished.
+    if (h->maps.size() >= 768) {
+        ESCX_HIP(hipDeviceSynchronize());
+        for (auto& kv : h->maps) (void)hipFree(kv.second);
+        h->maps.clear();
+    }
     int* d = nullptr;
     ESCX_HIP(hipMalloc((void**)&d, m.size() * sizeof(int)));
     ESCX_HIP(hipMemcpy(d, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -587,7 +595,9 @@ static bool ws_fits(escx_handle_s* h, int B, int T) {
     const int need = set_clips(h, B), sets = n_parts(h, B);
     for (int i = 0; i < sets; ++i) {
         const WsFields& S = h->sets[i];
-        if (!(S.ws.base && S.shp.B >= need && S.shp.W == T / h->cfg.patch_t && S.shp.T >= T)) return false;
+        // capacity, not equality: every buffer is sized by (clips, frames) maxima and grows monotonically with both, so a shorter
+        // clip or a smaller batch reuses the workspace (no hipFree/hipMalloc/synchronise per new length)
+        if (!(S.ws.base && S.shp.B >= need && S.shp.T >= T)) return false;
     }
     return true;
 }
@@ -613,6 +623,14 @@ static int reserve_frames(escx_handle_s* h, int Btotal, int T) {
         if (Ly.scale == 1 && (rc = get_map(h, H, s.W, -1, &dummy))) return rc;
     }
     if (ws_fits(h, Btotal, T)) return ESCX_OK;
+    // grow only: keep the largest batch and clip length seen so far, so that callers alternating between shapes do not thrash
+    if (h->sets[0].ws.base) {
+        const int Bt = std::max(Btotal, h->cap_clips), Tt = std::max(T, h->sets[0].shp.T);
+        if (Bt != Btotal || Tt != T) {
+            Shapes s2;
+            if (make_shapes(h, set_clips(h, Bt), Tt, &s2) == 0) return reserve_frames(h, Bt, Tt);
+        }
+    }
     if (!h->ev_fork) ESCX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     for (int i = 1; i < sets; ++i) if (!h->sx[i]) {
         ESCX_HIP(hipStreamCreateWithFlags(&h->sx[i], hipStreamNonBlocking));
@@ -677,6 +695,7 @@ static int reserve_frames(escx_handle_s* h, int Btotal, int T) {
         S.shp = s;
     }
     h->n_sets = sets;
+    h->cap_clips = Btotal;
     use_set(h, 0);
     return ESCX_OK;
 }
@@ -737,7 +756,6 @@ static int run_halves(escx_handle_s* h, int B, hipStream_t st, F part) {
 static int frames_of(escx_handle_s* h, int L) { return 1 + L / h->cfg.hop_length; }
 // frame count to reserve when only the latent width is known (decode first): the largest T that maps to W
 static int frames_for_width(escx_handle_s* h, int W) {
-    if (h->ws.base && h->shp.W == W) return h->shp.T;
     return h->cfg.patch_t * W + h->cfg.patch_t - 1;
 }
 

@@ -105,9 +105,12 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     static constexpr int MAX_PARTS = 4;
     escx::WsFields sets[MAX_PARTS];
     int n_sets = 1;
+    int cap_clips = 0;               // total clips (over all parts) the current workspace was reserved for
     int parts = 2;                   // ESCX_STREAMS=k (1..4): batch split into k parts on k streams; 1 = single stream
     hipStream_t sx[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};   // extra streams (part 0 runs on the caller's stream)
     hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
+
+    void* coll_buf = nullptr; size_t coll_cap = 0;   // int16 staging of escx_allgather_codes (send | recv)
 
     // index maps (device), keyed by (H, W, shift) ; shift = -1 -> merge map
     std::map<std::tuple<int, int, int>, int*> maps;

@@ -55,6 +55,8 @@ SIGNATURES = {
     "escx_codes_unpack10": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "escx_codes_narrow": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "escx_codes_widen": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "escx_set_rccl_library": (c_int, [c_char_p]),
+    "escx_allgather_codes": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
 }
 
 ESCX_ERR_INVALID_ARG, ESCX_ERR_UNSUPPORTED, ESCX_ERR_HIP, ESCX_ERR_STATE, ESCX_ERR_ASSERT = -1, -2, -3, -4, -5

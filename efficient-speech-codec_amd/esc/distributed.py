@@ -24,7 +24,7 @@ def narrow_codes(codes: torch.Tensor) -> torch.Tensor:
     """int64 (values < 2^15) -> int16; HIP kernel on device tensors, torch cast for host tensors (gloo tests)."""
     if codes.is_cuda:
         from . import _native
-        lib = _native.load()
+        lib = _native.load()          # codes < 2^15: ESC.__init__ refuses codebook_size > 32768
         out = torch.empty(codes.shape, dtype=torch.int16, device=codes.device)
         c = codes.contiguous()
         with torch.cuda.device(codes.device):
@@ -62,9 +62,11 @@ def all_gather_codes(codes_local: torch.Tensor, group: Optional[dist.ProcessGrou
     if counts is None or len(set(counts)) == 1:
         out = torch.empty((world * small.shape[0],) + tuple(small.shape[1:]), dtype=torch.int16, device=small.device)
         src8 = small.contiguous().view(torch.uint8)
-        try:
+        # the collective variant is chosen from the backend UP FRONT (never by catching an exception around a collective: ranks
+        # that disagree on the fallback would deadlock)
+        if str(dist.get_backend(group)).lower() == "nccl":
             dist.all_gather_into_tensor(out.view(torch.uint8), src8, group=group)
-        except (RuntimeError, NotImplementedError):        # backends without the fused form
+        else:
             parts = [torch.empty_like(src8) for _ in range(world)]
             dist.all_gather(parts, src8, group=group)
             out = torch.cat(parts, dim=0).view(torch.int16)

@@ -149,6 +149,8 @@ class ESC(nn.Module):
         self.win_length = int(win_len * sr * 1e-3)                       # base.py:23
         self.hop_length = int(hop_len * sr * 1e-3)                       # base.py:24
         self.max_bps = (2 / overlap) * max_streams * math.log2(codebook_size) * group_size // (20 * patch_size[1] // 2)  # base.py:70
+        if codebook_size > 32768:
+            raise NotImplementedError("codebook_size > 32768: code indices travel as int16 between ranks (esc/distributed.py)")
         if len(codebook_dims) < max_streams or len(swin_heads) < len(h_dims) - 1:
             raise ValueError("codebook_dims / swin_heads shorter than the number of streams / scales")
 

@@ -29,31 +29,42 @@ def parse_args():
     return p.parse_args()
 
 
+def _bitrate_pass(model, batches, metric_funcs, e_counter, device, s):
+    """One sweep of the evaluation set at `s` streams: per-clip metric values and the code utilisation of this bitrate."""
+    scores = {name: [] for name in metric_funcs}
+    e_counter.reset_stats(num_streams=s)
+    for x in batches:
+        x = x.to(device)
+        out = model(x=x, x_feat=None, num_streams=s)
+        for name, fn in metric_funcs.items():
+            scores[name] += fn(x, out["recon_audio"]).tolist()
+        e_counter.update(out["codes"])
+    return scores, e_counter.compute_utilization()[0]
+
+
 @torch.no_grad()
 def eval_epoch(model, eval_loader, metric_funcs, e_counter, device, bps_per_stream, num_streams=None, verbose=True):
+    """Counterpart of the reference's eval_epoch (scripts/test.py:23-55): the same arguments and the same result layout
+    {metric: [mean at each evaluated bitrate, rounded to 4], "utilization": [...]}, bitrates = one (`num_streams`) or 1..max_streams.
+    The model is put in eval mode for the sweep and its previous train/eval flag is restored afterwards (the reference forces
+    train(); here a caller that evaluates an inference-only model keeps an inference-only model)."""
+    was_training = model.training
     model.eval()
-    all_perf = {k: [] for k in metric_funcs}
-    all_perf["utilization"] = []
-    eval_range = range(num_streams, num_streams + 1) if num_streams is not None else range(1, model.max_streams + 1)
-    for s in eval_range:
-        perf = {k: [] for k in metric_funcs}
-        e_counter.reset_stats(num_streams=s)
-        for x in eval_loader:
-            x = x.to(device)
-            outputs = model(**dict(x=x, x_feat=None, num_streams=s))
-            recon_x, codes = outputs["recon_audio"], outputs["codes"]
-            for k, func in metric_funcs.items():
-                perf[k].extend(func(x, recon_x).tolist())
-            e_counter.update(codes)
-        for k, v in perf.items():
-            all_perf[k].append(round(float(np.mean(v)), 4))
-        rate, _ = e_counter.compute_utilization()
-        all_perf["utilization"].append(rate)
-        if verbose:
-            print(f"Test Metrics at {s * bps_per_stream:.2f}kbps: " + " | ".join(f"{k}: {np.mean(v):.4f}" for k, v in perf.items())
-                  + f" | utilization: {rate:.4f}")
-    model.train()
-    return all_perf
+    streams = [num_streams] if num_streams is not None else list(range(1, model.max_streams + 1))
+    table = {name: [] for name in metric_funcs}
+    table["utilization"] = []
+    try:
+        for s in streams:
+            scores, rate = _bitrate_pass(model, eval_loader, metric_funcs, e_counter, device, s)
+            for name, vals in scores.items():
+                table[name].append(round(float(np.mean(vals)), 4))
+            table["utilization"].append(rate)
+            if verbose:
+                line = " | ".join(f"{name}: {np.mean(vals):.4f}" for name, vals in scores.items())
+                print(f"Test Metrics at {s * bps_per_stream:.2f}kbps: {line} | utilization: {rate:.4f}")
+    finally:
+        model.train(was_training)
+    return table
 
 
 def load_model(args):

@@ -153,6 +153,17 @@ int escx_codes_unpack10(const uint8_t* in_dev, int64_t* codes_dev, int64_t n, vo
 int escx_codes_narrow(const int64_t* codes_dev, int16_t* out_dev, int64_t n, void* stream);
 int escx_codes_widen(const int16_t* in_dev, int64_t* codes_dev, int64_t n, void* stream);
 
+/* ---- multi-GPU: the one exchange step of the sharded path (BASELINE configs[3]; SURVEY.md 8(b),(e)) ------------- */
+/* The reference has no inference-time collective (clips are independent end to end); batch shards exchange only the emitted codes.
+ * codes_local_dev: n_local_codes int64 values of this rank (e.g. 36*S*G*T); codes_all_dev: world_size * n_local_codes, rank order.
+ * The codes cross xGMI as int16 (RCCL byte payload).  nccl_comm is the caller's ncclComm_t; libescx resolves RCCL at run time
+ * (dlopen of "librccl.so.1": in a PyTorch process torch's bundled copy, already mapped) so that communicator and collective come
+ * from one RCCL instance; escx_set_rccl_library(path) overrides the name before the first call.  Asynchronous on `stream`, except
+ * that growing the int16 staging buffer synchronises (first call / larger shard).  Equal shard sizes on every rank. */
+int escx_set_rccl_library(const char* path);
+int escx_allgather_codes(escx_handle h, const int64_t* codes_local_dev, int64_t n_local_codes, int64_t* codes_all_dev,
+                         int world_size, void* nccl_comm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,11 +62,46 @@ class _InverseSpectrogram(nn.Module):
 
 
 class _MelSpectrogram(nn.Module):
-    def __init__(self, *a, **k):
+    """torchaudio.transforms.MelSpectrogram (2.0.0 documentation, defaults): Spectrogram(n_fft, win_length, hop_length, hann
+    periodic window, power, center=True, reflect, onesided, un-normalised) followed by MelScale(n_mels, sample_rate, f_min=0,
+    f_max=sample_rate//2, n_stft=n_fft//2+1, norm=None, mel_scale="htk"): mel = fb^T . spec with triangular filters whose corner
+    frequencies are equally spaced on the HTK mel scale  m = 2595 log10(1 + f/700).  Written filter by filter from that
+    description (NOT the pinned wheel: the mel metric / mel loss stay "parity unpinned at the torchaudio boundary")."""
+
+    def __init__(self, sample_rate=16000, n_fft=400, win_length=None, hop_length=None, f_min=0.0, f_max=None, pad=0, n_mels=128,
+                 window_fn=torch.hann_window, power=2.0, normalized=False, wkwargs=None, center=True, pad_mode="reflect",
+                 onesided=None, norm=None, mel_scale="htk"):
         super().__init__()
+        assert norm is None and mel_scale == "htk" and center and pad_mode == "reflect" and not normalized and pad == 0
+        self.n_fft = n_fft
+        self.win_length = win_length if win_length is not None else n_fft
+        self.hop_length = hop_length if hop_length is not None else self.win_length // 2
+        self.power = power
+        f_max = float(sample_rate // 2) if f_max is None else f_max
+        n_freqs = n_fft // 2 + 1
+        import math
+        mel = lambda f: 2595.0 * math.log10(1.0 + f / 700.0)
+        hz = lambda m: 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+        m_lo, m_hi = mel(f_min), mel(f_max)
+        corners = [hz(m_lo + (m_hi - m_lo) * i / (n_mels + 1)) for i in range(n_mels + 2)]
+        fb = torch.zeros(n_freqs, n_mels, dtype=torch.float64)
+        for k in range(n_freqs):
+            f = (sample_rate // 2) * k / (n_freqs - 1)
+            for j in range(n_mels):
+                lo, mid, hi = corners[j], corners[j + 1], corners[j + 2]
+                rise, fall = (f - lo) / (mid - lo), (hi - f) / (hi - mid)
+                fb[k, j] = max(0.0, min(rise, fall))
+        self.register_buffer("fb", fb.float(), persistent=False)
+        self.register_buffer("window", window_fn(self.win_length), persistent=False)
 
     def forward(self, x):
-        raise NotImplementedError("MelSpectrogram is not on the encode/decode path")
+        shape = x.shape
+        spec = torch.stft(x.reshape(-1, shape[-1]), self.n_fft, self.hop_length, self.win_length, self.window, center=True,
+                          pad_mode="reflect", normalized=False, onesided=True, return_complex=True).abs()
+        if self.power != 1:
+            spec = spec.pow(self.power)
+        mel = torch.matmul(spec.transpose(-1, -2), self.fb).transpose(-1, -2)
+        return mel.reshape(shape[:-1] + mel.shape[-2:])
 
 
 def install():

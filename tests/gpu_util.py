@@ -46,3 +46,33 @@ def code_report(got, ref, margins=None):
         ms = [float(margins[tuple(i)]) for i in sel[:8]]
         msg += f"; earliest stream {first_stream}, reference margins there {ms}"
     return msg
+
+
+NEAR_TIE = 2e-6          # best/second-best distance gap below which an argmin flip is fp32 re-association noise (SURVEY hard part 1)
+
+
+def unattributable(got, ref, margins, tol=NEAR_TIE):
+    """Mismatches between (B,S,G,T) code tensors that CANNOT be explained by a reference near-tie.
+
+    Within a clip, streams are sequential: a flip in stream s changes the residual every later stream sees, so only the EARLIEST
+    stream with a mismatch is judged, and there every mismatching (g, t) must sit on a reference margin < tol.  Returns a list of
+    human-readable findings (empty = every difference is attributable; no difference at all = trivially empty)."""
+    got = np.asarray(got); ref = np.asarray(ref); margins = np.asarray(margins)
+    out = []
+    for b in range(got.shape[0]):
+        bad = np.argwhere(got[b] != ref[b])
+        if len(bad) == 0:
+            continue
+        s0 = bad[:, 0].min()
+        for s, g, t in bad[bad[:, 0] == s0]:
+            m = float(margins[b, s, g, t])
+            if not m < tol:
+                out.append(f"clip {b} stream {s} group {g} frame {t}: got {got[b, s, g, t]} ref {ref[b, s, g, t]} margin {m:.3e}")
+    return out
+
+
+def mismatch_summary(got, ref, margins):
+    got = np.asarray(got); ref = np.asarray(ref)
+    bad = np.argwhere(got != ref)
+    clips = sorted(set(int(i) for i in bad[:, 0]))
+    return f"{len(bad)} differing codes in clips {clips}; " + code_report(got, ref, margins)

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, total, ragged, out_dir):
+def _worker(rank, world, port, total, ragged, out_dir, use_bench_plan=False):
     sys.path.insert(0, os.path.join(ROOT, "efficient-speech-codec_amd"))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -39,7 +39,12 @@ def _worker(rank, world, port, total, ragged, out_dir):
     orc = EscOracle(json.loads(str(g["config_json"])), synth_state("tiny"))
     pcm = np.stack([synth.noise_clip_int16(f"dist-{i}", 1280) for i in range(total)])
     x = torch.from_numpy(synth.pcm_to_float(pcm))
-    if ragged:
+    if use_bench_plan:                   # bench.py --global-batch: the strong-scaling shard rule of BASELINE configs[3]
+        import bench
+        lo, n_local, plan_counts = bench.shard_plan(total, world, rank)
+        hi = lo + n_local
+        assert (lo, hi) == shard_bounds(total, world, rank) and sum(plan_counts) == total
+    elif ragged:
         lo, hi = shard_bounds(total, world, rank)
     else:
         per = total // world
@@ -50,6 +55,9 @@ def _worker(rank, world, port, total, ragged, out_dir):
     if rank == 0:
         ref, _ = orc.encode(x[: (total if ragged else world * (total // world))], 3)
         np.save(os.path.join(out_dir, f"ok_{int(ragged)}.npy"), np.array([int(torch.equal(full, ref)), full.shape[0], int(full.dtype == torch.int64)]))
+    elif use_bench_plan:                 # every rank must hold the whole batch, not only rank 0
+        ref, _ = orc.encode(x, 3)
+        assert torch.equal(full, ref)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -75,3 +83,27 @@ def test_shard_bounds_and_code_narrowing():
     codes = torch.randint(0, 1024, (4, 6, 3, 150))
     assert narrow_codes(codes).dtype == torch.int16
     assert torch.equal(widen_codes(narrow_codes(codes)), codes)
+
+
+@pytest.mark.parametrize("world,total", [(4, 288), (4, 290), (3, 36)])
+def test_strong_scaling_shards_of_the_node_batch(tmp_path, world, total):
+    """BASELINE configs[3] on CPU ranks: the fixed 288-clip batch (and an uneven 290 / a 3-way split of 36) sharded with bench.py's
+    own plan, one all-gather of the codes, every rank ends up with the single-process codes of the whole batch in rank order."""
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, total, True, str(tmp_path), True), nprocs=world, join=True)
+    ok = np.load(tmp_path / "ok_1.npy")
+    assert ok[0] == 1 and ok[1] == total and ok[2] == 1
+
+
+def test_bench_shard_plan_is_a_partition():
+    sys.path.insert(0, ROOT)
+    import bench
+    for total in (288, 36, 37):
+        for world in (1, 2, 3, 4, 5, 7, 8):
+            plans = [bench.shard_plan(total, world, r) for r in range(world)]
+            assert plans[0][0] == 0 and sum(p[1] for p in plans) == total
+            assert all(a[0] + a[1] == b[0] for a, b in zip(plans, plans[1:]))
+            assert all(p[2] == plans[0][2] for p in plans) and plans[0][2] == [p[1] for p in plans]
+    # the strong-mode clip tags are global: every world size processes the same 288 clips (first 36 = the weak-mode rank-0 batch)
+    tags36 = [f"bench-r0-{i}" for i in range(36)]
+    assert [f"bench-r{g // bench.CLIPS_PER_GPU}-{g % bench.CLIPS_PER_GPU}" for g in range(36)] == tags36

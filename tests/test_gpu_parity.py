@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import build_models, code_report, rel_rms, rms
+from gpu_util import NEAR_TIE, build_models, code_report, mismatch_summary, rel_rms, rms, unattributable
 from conftest import load_golden
 from esc import synth, _native
 
@@ -163,34 +163,81 @@ def test_pvq_encode_decode_every_stream(which, request):
         got = codes.cpu()
         m = torch.stack(margins, 1)
         bad = (got != ref)
-        # a mismatch is only tolerable where the reference's own best/second-best gap is at fp32 noise level
-        assert not bad.any() or float(m[bad].max()) < 2e-6, f"stream {s}: {int(bad.sum())} mismatches, margins {m[bad][:5]}"
-        assert int(bad.sum()) <= 1
+        # a mismatch is only acceptable where the reference's own best/second-best gap is at fp32 noise level
+        assert not bad.any() or float(m[bad].max()) < NEAR_TIE, f"stream {s}: {int(bad.sum())} mismatches, margins {m[bad][:5]}"
         refq = O.pvq_decode(ref, orc.sd, f"quantizers.{s}.", Hq, cfg["overlap"]) + dec
         out = torch.empty(B, Hq * W, C, device="cuda")
         _native.check(lib.escx_pvq_decode(hd, s, _ptr(refg), G * (W // 2), _ptr(decg), B, W, _ptr(out), None))
         assert rel_rms(out.cpu(), refq) < ACT_TOL
         # residual = enc (dec NULL) path used by stream 0
-        ref0 = O.pvq_encode(enc, orc.sd, f"quantizers.{s}.", Hq, cfg["overlap"], G, cfg["l2norm"])
+        margins0 = []
+        ref0 = O.pvq_encode(enc, orc.sd, f"quantizers.{s}.", Hq, cfg["overlap"], G, cfg["l2norm"], margins=margins0)
         _native.check(lib.escx_pvq_encode(hd, s, _ptr(encg), None, B, W, _ptr(codes), G * (W // 2), None))
-        assert int((codes.cpu() != ref0).sum()) <= 1
+        bad0 = (codes.cpu() != ref0)
+        m0 = torch.stack(margins0, 1)
+        assert not bad0.any() or float(m0[bad0].max()) < NEAR_TIE, f"stream {s} (dec=NULL): {int(bad0.sum())} mismatches, margins {m0[bad0][:5]}"
 
 
 def test_search_tie_break_and_degenerate_vectors(tiny):
-    """All-zero residual: every distance is ~||c_hat||^2; the reference's lowest-index-wins rule must hold on ties."""
+    """SURVEY appendix B #11 / codebook.py:31-40 against the oracle's `codebook_search` (== torch.min semantics):
+      * an EXACT tie (two identical codebook rows, the input equal to them) -> the lower index;
+      * an input equal to a code -> that code;
+      * a NaN in one vector -> index 0 for that vector (every distance is NaN, the first NaN wins), neighbours untouched;
+      * the all-zero residual: every distance is fp32 ||c_hat||^2 ~ 1, the winner is decided by rounding of the normalised
+        codebook norms - the emitted code must be a minimiser of the oracle's distances up to that rounding (excess < 2e-6)."""
     from oracle import esc_oracle as O
-    model, orc, g, cfg = tiny
+    from esc.models import make_model
+    from conftest import synth_state
+    _, orc0, g, cfg = tiny
+    G, ov, Ksz = cfg["group_size"], cfg["overlap"], cfg["codebook_size"]
+    sd = {k: v.clone() for k, v in synth_state("tiny").items()}
+    sid = 1
+    C, Hq, d = orc0.dec_dims[max(sid - 1, 0)], orc0.q_freq[sid], cfg["codebook_dims"][sid]
+    D = ov * Hq * C
+    dims = O.split_dimension(D, G)
+    for gi in range(G):                                    # down-projection = "take the first d entries of the group's sub-vector"
+        w = torch.zeros(d, dims[gi]); w[torch.arange(d), torch.arange(d)] = 1.0
+        sd[f"quantizers.{sid}.down_projs.{gi}.weight"] = w
+        cb = sd[f"quantizers.{sid}.vqs.{gi}.embedding.weight"]
+        cb[40] = cb[9]                                      # rows 9 and 40 identical -> exact tie
+    model = make_model(cfg); model.load_state_dict(sd); model = model.cuda().eval()
     lib, hd = _h(model)
-    W, B, G = 8, 1, cfg["group_size"]
-    C, Hq = orc.dec_dims[0], orc.q_freq[0]
-    enc = torch.zeros(B, Hq * W, C)
-    codes = torch.full((B, G, W // 2), -1, dtype=torch.int64, device="cuda")
+    W, B = 16, 2
+    T = W // ov
+    v = torch.zeros(B, T, D)
+    torch.manual_seed(21)
+    v += 0.01 * torch.randn(B, T, D)                        # everything outside the first d entries is ignored by the selector
+    starts = np.cumsum([0] + dims[:-1])
+    cbs = [sd[f"quantizers.{sid}.vqs.{gi}.embedding.weight"] for gi in range(G)]
+    for gi, st in enumerate(starts):
+        v[:, :, st:st + d] = torch.randn(B, T, d)
+        v[0, 0, st:st + d] = cbs[gi][9]                    # exact tie 9 / 40
+        v[0, 1, st:st + d] = cbs[gi][40] * 2.5             # same direction, other norm: still both rows
+        v[0, 2, st:st + d] = cbs[gi][17]                   # equal to a code
+        v[0, 3, st:st + d] = 0.0                           # degenerate: zero sub-vector
+        v[1, 2, st + 1] = float("nan")                     # NaN in one vector
+    enc = O.pvq_unframes(v, Hq, ov)
+    zes = []
+    ref = O.pvq_encode(enc, sd, f"quantizers.{sid}.", Hq, ov, G, cfg["l2norm"], z_e_out=zes)
+    codes = torch.full((B, G, T), -1, dtype=torch.int64, device="cuda")
     encg = enc.cuda()
-    _native.check(lib.escx_pvq_encode(hd, 0, _ptr(encg), None, B, W, _ptr(codes), G * (W // 2), None))
+    _native.check(lib.escx_pvq_encode(hd, sid, _ptr(encg), None, B, W, _ptr(codes), G * T, None))
     got = codes.cpu()
-    assert int(got.min()) >= 0 and int(got.max()) < cfg["codebook_size"]
-    # every frame of a group sees the same distances -> the same code
-    assert (got == got[..., :1]).all()
+    assert (ref[0, :, 0] == 9).all() and (ref[0, :, 1] == 9).all() and (ref[0, :, 2] == 17).all() and (ref[1, :, 2] == 0).all(), ref
+    strict = torch.ones(B, T, dtype=torch.bool); strict[0, 3] = False
+    for gi in range(G):
+        assert torch.equal(got[:, gi][strict], ref[:, gi][strict]), f"group {gi}: {got[:, gi]} vs {ref[:, gi]}"
+        # all-zero sub-vector: the chosen code must minimise the oracle's own distance expression up to fp32 rounding
+        cbn = torch.nn.functional.normalize(cbs[gi], dim=-1)
+        dist0 = (torch.zeros(1, 1) - (2 * torch.zeros(1, d)) @ cbn.t()) + cbn.pow(2).sum(1, keepdim=True).t()
+        k = int(got[0, gi, 3])
+        assert 0 <= k < Ksz and float(dist0[0, k] - dist0.min()) < NEAR_TIE
+    # whole all-zero map through the stream-0 path (dec = NULL): range + every frame of a group sees the same distances
+    C0, Hq0 = orc0.dec_dims[0], orc0.q_freq[0]
+    z = torch.zeros(1, Hq0 * 8, C0).cuda()
+    c0 = torch.full((1, G, 4), -1, dtype=torch.int64, device="cuda")
+    _native.check(lib.escx_pvq_encode(hd, 0, _ptr(z), None, 1, 8, _ptr(c0), G * 4, None))
+    assert int(c0.min()) >= 0 and int(c0.max()) < Ksz and (c0 == c0[..., :1]).all()
 
 
 def test_device_math_accuracy():
@@ -373,11 +420,84 @@ def test_full_size_invariants_batch36(base):
     assert wave.shape == (36, 47920) and torch.isfinite(wave).all()
     w1 = model.decode(full[7:8].contiguous(), shape)
     assert torch.equal(w1, wave[7:8])
-    # oracle on a bounded sample of the same batch (3 clips)
-    oc, _ = orc.encode(x[:3].cpu(), 6)
-    assert torch.equal(oc, full[:3].cpu()), code_report(full[:3].cpu().numpy(), oc.numpy())
+    # the oracle on the WHOLE batch (~15 s of host time): zero unattributable differences, audio within tolerance
+    tr = __import__("oracle.esc_oracle", fromlist=["Trace"]).Trace()
+    oc, _ = orc.encode(x.cpu(), 6, trace=tr)
+    m = torch.stack(tr.margins, dim=1).numpy()
+    bad = unattributable(full.cpu().numpy(), oc.numpy(), m)
+    assert not bad, "\n".join(bad[:10])
+    same = (full.cpu() == oc).flatten(1).all(1)
+    print(f"[batch36 noise] {int(same.sum())}/36 clips bit-exact; " + mismatch_summary(full.cpu().numpy(), oc.numpy(), m))
     ow = orc.decode(oc, shape)
-    assert rms(wave[:3].cpu().numpy(), ow.numpy()) <= AUDIO_TOL
+    assert rms(wave.cpu().numpy()[same.numpy()], ow.numpy()[same.numpy()]) <= AUDIO_TOL
+
+
+def test_bench_inputs_and_voiced_batch36_against_the_oracle(base):
+    """The exact 36 clips bench.py times (`bench-r0-i`) and a 36-clip voiced batch: every clip compared with the oracle; a
+    difference must sit on a reference near-tie (margin < 2e-6) in the earliest differing stream of its clip."""
+    model, orc, g, cfg = base
+    Trace = __import__("oracle.esc_oracle", fromlist=["Trace"]).Trace
+    for label, pcm in (("bench", np.stack([synth.noise_clip_int16(f"bench-r0-{i}", 48000) for i in range(36)])),
+                       ("voiced", np.stack([synth.voiced_clip_int16(f"voiced36-{i}", 48000) for i in range(36)]))):
+        x = torch.from_numpy(synth.pcm_to_float(pcm))
+        codes, shape = model.encode(x.cuda(), 6)
+        wave = model.decode(codes, shape)
+        tr = Trace()
+        oc, _ = orc.encode(x, 6, trace=tr)
+        m = torch.stack(tr.margins, dim=1).numpy()
+        bad = unattributable(codes.cpu().numpy(), oc.numpy(), m)
+        assert not bad, f"{label}: " + "\n".join(bad[:10])
+        same = (codes.cpu() == oc).flatten(1).all(1).numpy()
+        print(f"[{label}36] {int(same.sum())}/36 clips bit-exact, min margin {m.min():.2e}; " + mismatch_summary(codes.cpu().numpy(), oc.numpy(), m))
+        assert same.sum() >= 30
+        ow = orc.decode(oc, shape).numpy()
+        assert rms(wave.cpu().numpy()[same], ow[same]) <= AUDIO_TOL
+
+
+def test_large_batch36_against_the_oracle():
+    """ESC-Large (depth 4) at the benchmarked batch size: batch invariance inside B=36 and the oracle on 4 of its clips."""
+    model, orc, g, cfg = build_models("large")
+    pcm = np.stack([synth.noise_clip_int16(f"large36-{i}", 48000) for i in range(36)])
+    x = torch.from_numpy(synth.pcm_to_float(pcm))
+    codes, shape = model.encode(x.cuda(), 6)
+    wave = model.decode(codes, shape)
+    assert codes.shape == (36, 6, 3, 150) and torch.isfinite(wave).all()
+    idx = [0, 11, 23, 35]
+    sub, _ = model.encode(x[idx].cuda(), 6)
+    assert torch.equal(sub, codes[idx])
+    tr = __import__("oracle.esc_oracle", fromlist=["Trace"]).Trace()
+    oc, _ = orc.encode(x[idx], 6, trace=tr)
+    m = torch.stack(tr.margins, dim=1).numpy()
+    got = codes[idx].cpu().numpy()
+    bad = unattributable(got, oc.numpy(), m)
+    assert not bad, "\n".join(bad[:10])
+    same = (codes[idx].cpu() == oc).flatten(1).all(1).numpy()
+    print(f"[large36] {int(same.sum())}/4 clips bit-exact, min margin {m.min():.2e}")
+    ow = orc.decode(oc, shape).numpy()
+    assert same.any() and rms(wave[idx].cpu().numpy()[same], ow[same]) <= AUDIO_TOL
+
+
+@pytest.mark.parametrize("name", ["base", "large"])
+def test_unfiltered_reference_clips(name):
+    """tests/golden/unfiltered.npz (oracle/gen_unfiltered_golden.py): the first clips by tag, NO margin-based selection, codes and
+    margins from the real reference (margins down to 3e-7 for Base).  Requirement: no difference that is not a reference near-tie;
+    the report names every difference with its margin."""
+    import json
+    model, orc, g, cfg = build_models(name)
+    u = load_golden("unfiltered")
+    tags = json.loads(str(u[f"{name}_tags"]))
+    pcm = np.stack([(synth.noise_clip_int16 if k == "noise" else synth.voiced_clip_int16)(t, 48000) for k, t in tags])
+    x = torch.from_numpy(synth.pcm_to_float(pcm)).cuda()
+    codes, shape = model.encode(x, cfg["max_streams"])
+    ref, m = u[f"{name}_codes"].astype(np.int64), u[f"{name}_margins"]
+    got = codes.cpu().numpy()
+    bad = unattributable(got, ref, m)
+    same = (got == ref).reshape(len(tags), -1).all(1)
+    print(f"[unfiltered {name}] {int(same.sum())}/{len(tags)} clips bit-exact, reference min margin {m.min():.2e}, "
+          f"{int((m < 1e-5).sum())} codes under 1e-5; " + mismatch_summary(got, ref, m))
+    assert not bad, "\n".join(bad[:10])
+    wave = model.decode(torch.from_numpy(ref).cuda(), shape).cpu().numpy()
+    assert rms(wave[:, ::16], u[f"{name}_audio_sub"]) <= AUDIO_TOL
 
 
 def test_decode_partial_streams_and_errors(base):
@@ -565,6 +685,23 @@ def test_bitstream_and_compress_harness(base, tmp_path):
     assert (len(blob) - 16) * 8 / 3.0 / codes.shape[0] == 9000.0 == bitstream.payload_bits_per_second(6)
     back, shp = bitstream.unpack_codes(blob)
     assert torch.equal(back, codes) and tuple(shp) == tuple(shape)
+    # the documented layout, checked by an independent host unpacker: little-endian, 4 codes -> 5 bytes (40 bits), code i of a
+    # quad occupies bits 10*i .. 10*i+9 of the 40-bit little-endian word
+    payload = np.frombuffer(blob[16:], dtype=np.uint8).reshape(-1, 5).astype(np.uint64)
+    word = sum(payload[:, k] << np.uint64(8 * k) for k in range(5))
+    host = np.stack([(word >> np.uint64(10 * i)) & np.uint64(1023) for i in range(4)], axis=1).reshape(-1)[: codes.numel()]
+    assert np.array_equal(host.astype(np.int64), codes.cpu().numpy().reshape(-1))
+    assert blob[:4] == b"ESC1" and np.frombuffer(blob[4:16], dtype="<u2").tolist() == [2, 6, 3, 150, 2, 300]
+    with pytest.raises(ValueError, match="truncated"):
+        bitstream.unpack_codes(blob[:-7])
+    with pytest.raises(ValueError):
+        bitstream.unpack_codes(b"ESC1" + bytes(12) + blob[16:])                  # zero dimensions in the header
+    with pytest.raises(ValueError, match="outside"):
+        bitstream.pack_codes(codes + 1024, shape)
+    with pytest.raises(ValueError, match="does not match"):
+        bitstream.unpack_codes(bitstream.pack_codes(codes[:, :, :2].contiguous(), shape), model=model)
+    back_m, _ = bitstream.unpack_codes(blob, model=model)
+    assert torch.equal(back_m, codes)
     odd = codes.reshape(-1)[:1001].reshape(1, 1, 1, 1001).contiguous()           # length not a multiple of 4
     b2, _ = bitstream.unpack_codes(bitstream.pack_codes(odd, (2, 2002)))
     assert torch.equal(b2, odd)
@@ -577,3 +714,40 @@ def test_bitstream_and_compress_harness(base, tmp_path):
     assert torch.equal(saved, codes[:1].cpu())
     sr, rec = wavfile.read(tmp_path / "out" / "decoded_9.0kbps_clip.wav")
     assert sr == 16000 and rms(rec, g["audio_s6"][0]) <= AUDIO_TOL
+
+
+def test_allgather_codes_through_the_c_abi_one_rank_rccl(base):
+    """escx_allgather_codes with a real RCCL communicator (one rank: this box has one GPU): the int64 -> int16 -> ncclAllGather ->
+    int64 path returns the local codes.  The communicator is created through ctypes on the same RCCL instance libescx resolves."""
+    import os
+    model, orc, g, cfg = base
+    lib, hd = _h(model)
+    rccl = None
+    for name in ("librccl.so.1", "librccl.so", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so.1"):
+        try:
+            rccl = ctypes.CDLL(name); break
+        except OSError:
+            continue
+    assert rccl is not None, "no RCCL library found"
+    # (libescx's default search resolves the same SONAME, i.e. the same mapped RCCL instance)
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        x = torch.from_numpy(synth.pcm_to_float(g["pcm"])).cuda()
+        codes, _ = model.encode(x, 6)
+        out = torch.full_like(codes, -1)
+        st = torch.cuda.current_stream().cuda_stream
+        _native.check(lib.escx_allgather_codes(hd, _ptr(codes), codes.numel(), _ptr(out), 1, comm, ctypes.c_void_p(st)))
+        torch.cuda.synchronize()
+        assert torch.equal(out, codes)
+        assert lib.escx_allgather_codes(hd, _ptr(codes), 0, _ptr(out), 1, comm, None) == _native.ESCX_ERR_INVALID_ARG
+        assert lib.escx_allgather_codes(hd, _ptr(codes), codes.numel(), _ptr(out), 1, None, None) == _native.ESCX_ERR_INVALID_ARG
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)

@@ -114,3 +114,22 @@ def test_merge_odd_height_and_uneven_split():
                                      sd["m.down.weight"])
     np.testing.assert_allclose(y[:, 2 * W + 1].numpy(), ref.numpy(), atol=1e-6)
     assert split_dimension(128, 3) == [42, 42, 44] and split_dimension(1536, 3) == [512] * 3
+
+
+@pytest.mark.parametrize("name", ["base", "large"])
+def test_unfiltered_reference_clips(name):
+    """oracle/gen_unfiltered_golden.py: the first clips by tag with NO margin-based selection (reference margins down to 3e-7).
+    The oracle runs the same ATen kernels as the reference, so it must reproduce every code and the reference's margins."""
+    orc, _, cfg = _oracle(name)
+    u = load_golden("unfiltered")
+    tags = json.loads(str(u[f"{name}_tags"]))
+    sel = tags if name == "base" else tags[:2]
+    pcm = np.stack([(synth.noise_clip_int16 if k == "noise" else synth.voiced_clip_int16)(t, 48000) for k, t in sel])
+    tr = Trace()
+    codes, shape = orc.encode(torch.from_numpy(synth.pcm_to_float(pcm)), cfg["max_streams"], trace=tr)
+    ref = u[f"{name}_codes"][: len(sel)].astype(np.int64)
+    assert np.array_equal(codes.numpy(), ref)
+    m = torch.stack(tr.margins, dim=1).numpy()
+    np.testing.assert_allclose(m, u[f"{name}_margins"][: len(sel)], atol=1e-5)
+    a = orc.decode(codes, shape).numpy()
+    assert _rms(a[:, ::16], u[f"{name}_audio_sub"][: len(sel)]) <= 1e-6
