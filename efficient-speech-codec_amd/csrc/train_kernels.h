@@ -1,0 +1,829 @@
+// Device code of the TRAINING step (reference: scripts/trainer_no_adv.py:95-118, esc/modules/vq/codebook.py:57-75,
+// esc/modules/vq/quantization.py:31-72, esc/models/csrvq.py:23-48, esc/modules/loss/generator_loss.py:12-74).
+//
+// The forward of a training step reuses the plain GEMM pipeline of the inference path (LN -> QKV GEMM -> window attention -> proj GEMM -> LN ->
+// fc1 -> fc2) with every activation a backward pass needs kept in HBM (288 GB: nothing is recomputed except LayerNorm statistics and the
+// softmax rows).  This file holds what only training needs:
+//   * gemm_dw_kernel      dW[n][k] = sum_m dY[m][n] * X[m][k]  (+ db[n]) on the fp32 MFMA, M split over workgroups, partial sums reduced in a FIXED
+//                         order by reduce_partials_kernel (no atomics anywhere: gradients are run-to-run deterministic)
+//   * ln_bwd_kernel       LayerNorm backward (statistics recomputed), window-gather / merge-gather aware, dgamma/dbeta as fixed-order partials
+//   * attn_bwd_kernel     4x4-window attention core backward (softmax recomputed), relative-position-bias gradient
+//   * loaders / epilogues for the dX GEMMs (gemm_engine.h's kernel with transposed weights)
+//   * product-VQ training forward/backward (straight-through estimator, commitment / codebook losses, embedding gradient by code)
+//   * loss kernels (power-law complex STFT loss, multi-scale mel loss pieces), inverse-STFT backward, AdamW / global-norm clipping
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gemm_engine.h"
+
+namespace escx {
+
+// ------------------------------------------------------------------------------------------------
+// extra A-side loaders (row m, 4 consecutive columns k0+kin..)
+// ------------------------------------------------------------------------------------------------
+struct SlotGatherA {            // rows in window-slot order gathered from a token-major map: A[(b,slot)][k] = x[(b, map[slot])][k], pad slots = 0
+    const float* x; const int* map; int slots, tokens, ld, M; FastDiv dSlots;
+    typedef const float* Ctx;
+    __device__ __forceinline__ Ctx make_ctx(int m) const {
+        if (m >= M) return nullptr;
+        const int b = dSlots.div(m), s = m - b * slots;
+        const int tok = map[s];
+        return tok < 0 ? nullptr : x + ((size_t)b * tokens + tok) * ld;
+    }
+    __device__ __forceinline__ f32x4 load4(Ctx c, int k0, int kin) const { return c ? ld4(c + k0 + kin) : zero4(); }
+};
+
+struct SplitGatherA {           // inverse of the PatchSplit pixel shuffle: A[(b,h,w)][s*C2p + c] = g[(b, 2h+s, w)][c]
+    const float* g; int H, W, C2p, M; FastDiv dHW, dW, dC2p;
+    typedef int Ctx;            // element offset of token (b, 2h, w), or -1
+    __device__ __forceinline__ Ctx make_ctx(int m) const {
+        if (m >= M) return -1;
+        const int b = dHW.div(m), r = m - b * H * W; const int h = dW.div(r), w = r - h * W;
+        return ((b * 2 * H + 2 * h) * W + w) * C2p;
+    }
+    __device__ __forceinline__ f32x4 load4(Ctx c, int k0, int kin) const {
+        if (c < 0) return zero4();
+        const int k = k0 + kin; const int s = dC2p.div(k), cc = k - s * C2p;
+        if (s > 1) return zero4();
+        return ld4(g + (size_t)c + (size_t)s * W * C2p + cc);
+    }
+};
+
+struct ShuffleA {               // inverse of the de-embedding pixel shuffle: A[(b,h,w)][q*Cp + c] = g[(b, t=pt*w+s2, f=pf*h+s1)][c], q = s1*pt+s2
+    const float* g; int H, W, Cp, pf, pt, M; FastDiv dHW, dW, dCp;      // g is the TIME-major fine map [b][pt*W][pf*H][Cp]
+    struct Ctx { int b, h, w; };
+    __device__ __forceinline__ Ctx make_ctx(int m) const {
+        Ctx c; c.b = -1; c.h = 0; c.w = 0;
+        if (m < M) { c.b = dHW.div(m); const int r = m - c.b * H * W; c.h = dW.div(r); c.w = r - c.h * W; }
+        return c;
+    }
+    __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
+        if (c.b < 0) return zero4();
+        const int k = k0 + kin; const int q = dCp.div(k), cc = k - q * Cp;
+        if (q >= pf * pt) return zero4();
+        const int s1 = q / pt, s2 = q - s1 * pt;
+        return ld4(g + (((size_t)c.b * (pt * W) + pt * c.w + s2) * (pf * H) + pf * c.h + s1) * Cp + cc);
+    }
+};
+
+struct ConvShuffleA {           // conv5x5 dX: A[(b,h,w)][k = (tap, q, c)] = dY1[(b, h-dh, w-dw)][q*Cp+c] with dY1 = ShuffleA(g); tap = (kh,kw), dh = kh-2
+    const float* g; int H, W, Cp, pf, pt, M; FastDiv dHW, dW, dCp, dQ;
+    struct Ctx { int b, h, w; };
+    __device__ __forceinline__ Ctx make_ctx(int m) const {
+        Ctx c; c.b = -1; c.h = 0; c.w = 0;
+        if (m < M) { c.b = dHW.div(m); const int r = m - c.b * H * W; c.h = dW.div(r); c.w = r - c.h * W; }
+        return c;
+    }
+    __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
+        if (c.b < 0) return zero4();
+        const int k = k0 + kin; const int tq = dCp.div(k), cc = k - tq * Cp;
+        const int tap = dQ.div(tq), q = tq - tap * (pf * pt);
+        if (tap >= 25) return zero4();
+        const int kh = tap / 5, kw = tap - kh * 5;
+        const int hs = c.h - (kh - 2), ws = c.w - (kw - 2);          // forward: out(h,w) reads in(h+kh-2, w+kw-2)  =>  in(h,w) feeds out(h-(kh-2), w-(kw-2))
+        if (hs < 0 || hs >= H || ws < 0 || ws >= W) return zero4();
+        const int s1 = q / pt, s2 = q - s1 * pt;
+        return ld4(g + (((size_t)c.b * (pt * W) + pt * ws + s2) * (pf * H) + pf * hs + s1) * Cp + cc);
+    }
+};
+
+struct SpecRowsA {              // rows m = (b, t, f) of a frame-major spectrum gradient: A[m][oc] = g[(b,t)][oc*Fp + f], oc < in_dim
+    const float* g; int F, Fp, in_dim, M; FastDiv dF;
+    typedef const float* Ctx;
+    __device__ __forceinline__ Ctx make_ctx(int m) const {
+        if (m >= M) return nullptr;
+        const int bt = dF.div(m), f = m - bt * F;
+        return g + (size_t)bt * (in_dim * Fp) + f;
+    }
+    __device__ __forceinline__ f32x4 load4(Ctx c, int k0, int kin) const {
+        f32x4 v = zero4();
+        if (!c) return v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (k0 + kin + r < in_dim) v[r] = c[(size_t)(k0 + kin + r) * Fp];
+        return v;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// extra epilogues
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_grad(float x) {       // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+struct EpiGeluDual {            // fc1 in training: pre-activation AND activation are kept (attention.py:267-272)
+    float* pre; float* act; int ldo; const float* bias;
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        v += ld4(bias + n);
+        st4(pre + (size_t)m * ldo + n, v);
+        v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+        st4(act + (size_t)m * ldo + n, v);
+    }
+};
+
+struct EpiGeluBwd {             // dh_pre = (dy . W2) * gelu'(h_pre)
+    float* out; int ldo; const float* pre;
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        const f32x4 p = ld4(pre + (size_t)m * ldo + n);
+        v[0] *= gelu_grad(p[0]); v[1] *= gelu_grad(p[1]); v[2] *= gelu_grad(p[2]); v[3] *= gelu_grad(p[3]);
+        st4(out + (size_t)m * ldo + n, v);
+    }
+};
+
+struct EpiAccum {               // out[m][n] += v  (gradient accumulation where a tensor has two consumers)
+    float* out; int ldo;
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        float* p = out + (size_t)m * ldo + n;
+        st4(p, ld4(p) + v);
+    }
+};
+
+struct EpiPvqGrad {             // gradient of the framed residual back on the token maps: d_enc += v, d_dec -= v  (csrvq.py:15-17)
+    float* denc; float* ddec; int Hq, W, Cp, Tq, ov; FastDiv dTq, dCp, dHq;
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        const int b = dTq.div(m), t = m - b * Tq;
+        const int oh = dCp.div(n), c = n - oh * Cp;
+        const int o = dHq.div(oh), h = oh - o * Hq;
+        const size_t idx = ((size_t)(b * Hq + h) * W + ov * t + o) * Cp + c;
+        st4(denc + idx, ld4(denc + idx) + v);
+        if (ddec) st4(ddec + idx, ld4(ddec + idx) - v);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// dW[n][k] = sum_m A[m][n] * B[m][k]   (A = upstream gradient rows, B = saved input rows), optional db[n] = sum_m A[m][n].
+// One workgroup = one 48 x 48 output tile and one slice of M; its 4 waves take alternate 32-row chunks, stage them in their own LDS
+// region and run 9 MFMAs per 4 rows; the waves are then added in the order 0,1,2,3 and the slice's partial tile is written to
+// part[slice][Np][Kp].  reduce_partials_kernel adds the slices in increasing order.
+// ------------------------------------------------------------------------------------------------
+constexpr int DW_T = 3;                 // 16-wide tiles per side of the workgroup tile
+constexpr int DW_LD = 48;               // LDS row stride in floats: 48 % 32 == 16 -> the 4 rows of an MFMA operand read hit different bank groups
+constexpr int DW_MC = 32;               // rows per staged chunk
+
+template <class LdA, class LdB, bool BIAS>
+__global__ __launch_bounds__(256) void gemm_dw_kernel(LdA la, LdB lb, int M, int Np, int Kp, int nblk_k, int m_per_slice,
+                                                      float* __restrict__ part, float* __restrict__ bpart) {
+    __shared__ float lds[4 * 2 * DW_MC * DW_LD];       // per wave: A chunk | B chunk  (4 * 2 * 32 * 48 * 4 B = 48 KB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int bn = blockIdx.x / nblk_k, bk = blockIdx.x - bn * nblk_k;
+    const int n0 = bn * 16 * DW_T, k0 = bk * 16 * DW_T;
+    const int mbeg = blockIdx.y * m_per_slice, mend = min(M, mbeg + m_per_slice);
+    float* As = lds + wave * (2 * DW_MC * DW_LD);
+    float* Bs = As + DW_MC * DW_LD;
+    const bool do_bias = BIAS && bk == 0;
+
+    f32x4 acc[DW_T][DW_T], accb[DW_T];
+#pragma unroll
+    for (int a = 0; a < DW_T; ++a) { accb[a] = zero4();
+#pragma unroll
+        for (int b = 0; b < DW_T; ++b) acc[a][b] = zero4(); }
+
+    // each lane moves 6 float4 per operand per chunk: element e -> (row e / 12, float4 column e % 12)
+    constexpr int V = DW_T * 4;          // float4 per staged row
+    for (int m0 = mbeg + wave * DW_MC; m0 < mend; m0 += 4 * DW_MC) {
+        f32x4 ra[6], rb[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int e = lane + 64 * j; const int row = e / V, c4 = e - row * V;
+            const int m = m0 + row;
+            const int col = 4 * c4;                                  // column inside the 48-wide tile
+            const bool live = m < mend;
+            typename LdA::Ctx ca = la.make_ctx(live ? m : M);
+            typename LdB::Ctx cb = lb.make_ctx(live ? m : M);
+            ra[j] = (n0 + col < Np) ? la.load4(ca, n0 + (col & ~15), col & 15) : zero4();
+            rb[j] = (k0 + col < Kp) ? lb.load4(cb, k0 + (col & ~15), col & 15) : zero4();
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int e = lane + 64 * j; const int row = e / V, c4 = e - row * V;
+            st4(As + row * DW_LD + 4 * c4, ra[j]);
+            st4(Bs + row * DW_LD + 4 * c4, rb[j]);
+        }
+        // a wave only reads what it wrote itself: no workgroup barrier, the LDS queue is in order per wave
+        __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ms = 0; ms < DW_MC / 4; ++ms) {
+            float af[DW_T], bf[DW_T];
+#pragma unroll
+            for (int a = 0; a < DW_T; ++a) af[a] = As[(4 * ms + lg) * DW_LD + 16 * a + l15];
+#pragma unroll
+            for (int b = 0; b < DW_T; ++b) bf[b] = Bs[(4 * ms + lg) * DW_LD + 16 * b + l15];
+#pragma unroll
+            for (int a = 0; a < DW_T; ++a)
+#pragma unroll
+                for (int b = 0; b < DW_T; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+            if (do_bias) {
+                const float one = (l15 == 0) ? 1.0f : 0.0f;           // a column of ones appended to B: its product column is the bias gradient
+#pragma unroll
+                for (int a = 0; a < DW_T; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], one, accb[a], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // add the four waves in the order 0,1,2,3 (fixed), wave 0 writes the slice's partial tile
+    __syncthreads();
+    float* red = lds;                                                // [3 waves][10 tiles][64 lanes][4]
+    if (wave > 0) {
+        float* r = red + (size_t)(wave - 1) * 10 * 256;
+#pragma unroll
+        for (int a = 0; a < DW_T; ++a) {
+#pragma unroll
+            for (int b = 0; b < DW_T; ++b) st4(r + ((a * DW_T + b) * 64 + lane) * 4, acc[a][b]);
+        }
+        if (BIAS) { f32x4 t = accb[0]; t[1] = accb[1][0]; t[2] = accb[2][0]; (void)t; }
+        if (BIAS) {
+#pragma unroll
+            for (int a = 0; a < DW_T; ++a) r[(9 * 64 + lane) * 4 + a] = 0.f;
+        }
+    }
+    // bias accumulators travel in a separate small region to keep the indexing simple
+    __shared__ float redb[3][DW_T][64][4];
+    if (BIAS && wave > 0) {
+#pragma unroll
+        for (int a = 0; a < DW_T; ++a) st4(&redb[wave - 1][a][lane][0], accb[a]);
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const float* r = red + (size_t)w * 10 * 256;
+#pragma unroll
+            for (int a = 0; a < DW_T; ++a) {
+#pragma unroll
+                for (int b = 0; b < DW_T; ++b) acc[a][b] += ld4(r + ((a * DW_T + b) * 64 + lane) * 4);
+                if (BIAS) accb[a] += ld4(&redb[w][a][lane][0]);
+            }
+        }
+        float* po = part + (size_t)blockIdx.y * Np * Kp;
+#pragma unroll
+        for (int a = 0; a < DW_T; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 16 * a + 4 * lg + r;
+                if (n >= Np) continue;
+#pragma unroll
+                for (int b = 0; b < DW_T; ++b) {
+                    const int k = k0 + 16 * b + l15;
+                    if (k < Kp) po[(size_t)n * Kp + k] = acc[a][b][r];
+                }
+                if (do_bias && l15 == 0) bpart[(size_t)blockIdx.y * Np + n] = accb[a][r];
+            }
+    }
+}
+
+// out[i] = sum_s part[s][i], s increasing (fixed order); optional accumulate into out
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int slices, long long n, float* __restrict__ out, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = accumulate ? out[i] : 0.f;
+    for (int k = 0; k < slices; ++k) s += part[(size_t)k * n + i];
+    out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward.  Modes as in ln_rows_kernel; statistics are recomputed from the saved input.
+//   MODE 0: rows = tokens, dy row = row.                         dx[row] = (add ? add[row] : 0) + dLN
+//   MODE 1: rows = tokens, dy row = slot inv[token] of the clip (the forward gathered tokens into window slots; pad slots carry no gradient)
+//   MODE 2: rows = merged rows (2 segments gathered through map); dx goes to the two source tokens (each is used exactly once)
+// dgamma / dbeta: every thread accumulates its channels over the rows it walks, the 16 row groups of a workgroup are added in a fixed
+// order in LDS, and the workgroup writes one partial row; reduce_partials_kernel finishes.  part: [gridDim.x][2][SEGS*Cp]
+// ------------------------------------------------------------------------------------------------
+template <int SEGS, int MODE>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                     const int* __restrict__ map, const float* __restrict__ add, float* __restrict__ dx,
+                                                     float* __restrict__ part, int rows_per_clip, int src_rows_per_clip, int dy_rows_per_clip,
+                                                     int total_rows, int C, int Cp, float eps) {
+    constexpr int MAXV = 6;                       // float4 per thread per segment: Cp <= 384
+    __shared__ float red[16][2 * 2 * 96 * 4 / 16 * 16 / 16];     // placeholder size, replaced below
+    (void)red;
+    extern __shared__ float dyn[];                // [16 groups][2][SEGS*Cp]
+    const int sub = threadIdx.x & 15, gl = threadIdx.x >> 4;
+    const int grp = (blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int ngrp = (gridDim.x * 256) >> 4;
+    const int V = Cp / 4;
+    f32x4 ag[SEGS][MAXV], ab[SEGS][MAXV];
+#pragma unroll
+    for (int s = 0; s < SEGS; ++s)
+#pragma unroll
+        for (int q = 0; q < MAXV; ++q) { ag[s][q] = zero4(); ab[s][q] = zero4(); }
+
+    for (int row = grp; row < total_rows; row += ngrp) {
+        const int b = row / rows_per_clip, rr = row - b * rows_per_clip;
+        const float* sp[SEGS]; float* dp[SEGS];
+        const float* gp;
+        if (MODE == 2) {
+#pragma unroll
+            for (int s = 0; s < SEGS; ++s) {
+                const int srow = map[rr * SEGS + s];
+                sp[s] = srow < 0 ? nullptr : x + ((size_t)b * src_rows_per_clip + srow) * Cp;
+                dp[s] = srow < 0 ? nullptr : dx + ((size_t)b * src_rows_per_clip + srow) * Cp;
+            }
+            gp = dy + (size_t)row * (SEGS * Cp);
+        } else {
+            sp[0] = x + (size_t)row * Cp; dp[0] = dx + (size_t)row * Cp;
+            gp = (MODE == 1) ? dy + ((size_t)b * dy_rows_per_clip + map[rr]) * Cp : dy + (size_t)row * Cp;
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < SEGS; ++s)
+            if (sp[s])
+                for (int v = sub; v < V; v += 16) {
+                    const f32x4 xv = ld4(sp[s] + 4 * v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (4 * v + e < C) sum += xv[e];
+                }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 16);
+        const float mean = sum / (float)(SEGS * C);
+        float var = 0.f;
+#pragma unroll
+        for (int s = 0; s < SEGS; ++s)
+            for (int v = sub; v < V; v += 16) {
+                const f32x4 xv = sp[s] ? ld4(sp[s] + 4 * v) : zero4();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (4 * v + e < C) { const float d = xv[e] - mean; var += d * d; }
+            }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) var += __shfl_xor(var, o, 16);
+        const float rstd = 1.0f / sqrtf(var / (float)(SEGS * C) + eps);
+        // c1 = mean(dy*gamma), c2 = mean(dy*gamma*xhat)
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < SEGS; ++s) {
+            int q = 0;
+            for (int v = sub; v < V; v += 16, ++q) {
+                const f32x4 xv = sp[s] ? ld4(sp[s] + 4 * v) : zero4();
+                const f32x4 g = ld4(gp + s * Cp + 4 * v), gm = ld4(gamma + s * Cp + 4 * v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * v + e < C) {
+                        const float xh = (xv[e] - mean) * rstd, t = g[e] * gm[e];
+                        s1 += t; s2 += t * xh;
+                        ag[s][q][e] += g[e] * xh; ab[s][q][e] += g[e];
+                    }
+            }
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o, 16); s2 += __shfl_xor(s2, o, 16); }
+        const float c1 = s1 / (float)(SEGS * C), c2 = s2 / (float)(SEGS * C);
+#pragma unroll
+        for (int s = 0; s < SEGS; ++s) {
+            if (!dp[s]) continue;
+            for (int v = sub; v < V; v += 16) {
+                const f32x4 xv = ld4(sp[s] + 4 * v);
+                const f32x4 g = ld4(gp + s * Cp + 4 * v), gm = ld4(gamma + s * Cp + 4 * v);
+                f32x4 o = (MODE != 2 && add) ? ld4(add + (size_t)row * Cp + 4 * v) : zero4();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (xv[e] - mean) * rstd;
+                    o[e] = (4 * v + e < C) ? o[e] + rstd * (g[e] * gm[e] - c1 - xh * c2) : 0.f;
+                }
+                st4(dp[s] + 4 * v, o);
+            }
+        }
+    }
+    // workgroup reduction of the per-thread dgamma / dbeta accumulators: group 0 + 1 + ... + 15, fixed order
+    const int RW = SEGS * Cp;
+#pragma unroll
+    for (int s = 0; s < SEGS; ++s) {
+        int q = 0;
+        for (int v = sub; v < V; v += 16, ++q) {
+            st4(dyn + ((size_t)gl * 2 + 0) * RW + s * Cp + 4 * v, ag[s][q]);
+            st4(dyn + ((size_t)gl * 2 + 1) * RW + s * Cp + 4 * v, ab[s][q]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * RW; i += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) t += dyn[(size_t)g2 * 2 * RW + i];
+        part[(size_t)blockIdx.x * 2 * RW + i] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Window attention core backward (attention.py:222-241), one wave per (window, head); the softmax rows are recomputed from q, k.
+//   qkv  : [B*nW*16][ldq]  saved forward tensor (q already scaled)       dout : [B*nW*16][ldo]  gradient of the head-concatenated output
+//   dqkv : [B*nW*16][ldq]  gradient w.r.t. the UNSCALED qkv linear output (q columns are multiplied by `scale` here)
+//   dbias_part : [gridDim.x][nH][16][16]  per-workgroup sums of dS (relative-position bias gradient), reduced afterwards in fixed order
+// grid = (window chunks, nH): a wave keeps ONE head, so that its dS sum stays in registers across the windows it walks.
+// ------------------------------------------------------------------------------------------------
+template <int STEPS>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ bias, const float* __restrict__ dout,
+                                                       float* __restrict__ dqkv, float* __restrict__ dbias_part, int total_windows, int nH,
+                                                       int ldq, int ldo, int nWh, int nWw, int shifted, float scale) {
+    constexpr int HDP = 4 * STEPS;
+    constexpr int DT = (HDP + 15) / 16;
+    __shared__ float tp[4][2][16][17];           // per wave: P and dS, to read them transposed
+    __shared__ float wsum[4][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y;
+    const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    const int kOff = nH * HDP, vOff = 2 * nH * HDP;
+    f32x4 dbsum = zero4();
+    for (int win = wave_global; win < total_windows; win += nwaves) {
+        const float* base = qkv + (size_t)win * 16 * ldq + h * HDP;
+        const float* rowp = base + (size_t)i * ldq + STEPS * g;
+        const float* dorow = dout + ((size_t)win * 16 + i) * ldo + h * HDP + STEPS * g;
+        float kf[STEPS], qf[STEPS], vf[STEPS], df[STEPS];
+#pragma unroll
+        for (int r = 0; r < STEPS; ++r) { qf[r] = rowp[r]; kf[r] = rowp[kOff + r]; vf[r] = rowp[vOff + r]; df[r] = dorow[r]; }
+        f32x4 s = zero4(), dp = zero4();
+#pragma unroll
+        for (int r = 0; r < STEPS; ++r) {
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[r], qf[r], s, 0, 0, 0);       // lane (i, g): S[i][4g + r']
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], df[r], dp, 0, 0, 0);     // lane (i, g): dP[i][4g + r'] = dO[i] . V[4g + r']
+        }
+        s += ld4(bias + ((size_t)h * 16 + i) * 16 + 4 * g);
+        if (shifted) {
+            const int wloc = win % (nWh * nWw);
+            const int wh = wloc / nWw, ww = wloc - wh * nWw;
+            const bool lastH = (wh == nWh - 1), lastW = (ww == nWw - 1);
+            const int qh = i >> 2, qw = i & 3;
+            const int labq = 3 * (lastH ? (qh < 2 ? 1 : 2) : 0) + (lastW ? (qw < 2 ? 1 : 2) : 0);
+            const int labkh = 3 * (lastH ? (g < 2 ? 1 : 2) : 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int labk = labkh + (lastW ? (r < 2 ? 1 : 2) : 0);
+                s[r] += (labk != labq) ? -100.0f : 0.0f;
+            }
+        }
+        float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        f32x4 p;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = expf(s[r] - mx);
+        float den = (p[0] + p[1]) + (p[2] + p[3]);
+        den += __shfl_xor(den, 16);
+        den += __shfl_xor(den, 32);
+        const float inv = 1.0f / den;
+        float dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p[r] *= inv; dot += p[r] * dp[r]; }
+        dot += __shfl_xor(dot, 16);
+        dot += __shfl_xor(dot, 32);
+        f32x4 ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[r] = p[r] * (dp[r] - dot);
+        dbsum += ds;
+        // dQ[i][d] = sum_j dS[i][j] K[j][d]  (same operand pattern as O = P V in the forward), scaled back through q*scale
+        float* dqrow = dqkv + ((size_t)win * 16 + i) * ldq + h * HDP;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const int d = t * 16 + i;
+            f32x4 o = zero4();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float kk = (d < HDP) ? base[(size_t)(4 * g + r) * ldq + kOff + d] : 0.f;
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(kk, ds[r], o, 0, 0, 0);
+            }
+            if (t * 16 + 4 * g < HDP) st4(dqrow + t * 16 + 4 * g, o * scale);
+        }
+        // transposed P and dS through LDS: lane (j, g) then holds P[4g + r][j]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { tp[wave][0][i][4 * g + r] = p[r]; tp[wave][1][i][4 * g + r] = ds[r]; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        f32x4 pt, dst;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pt[r] = tp[wave][0][4 * g + r][i]; dst[r] = tp[wave][1][4 * g + r][i]; }
+        __builtin_amdgcn_wave_barrier();
+        // dV[j][d] = sum_i P[i][j] dO[i][d] ; dK[j][d] = sum_i dS[i][j] Q[i][d]   (lane (j, g): rows of key j)
+        float* dkrow = dqkv + ((size_t)win * 16 + i) * ldq + kOff + h * HDP;
+        float* dvrow = dqkv + ((size_t)win * 16 + i) * ldq + vOff + h * HDP;
+        const float* dobase = dout + (size_t)win * 16 * ldo + h * HDP;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const int d = t * 16 + i;
+            f32x4 ov = zero4(), ok = zero4();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dd = (d < HDP) ? dobase[(size_t)(4 * g + r) * ldo + d] : 0.f;
+                const float qq = (d < HDP) ? base[(size_t)(4 * g + r) * ldq + d] : 0.f;
+                ov = __builtin_amdgcn_mfma_f32_16x16x4f32(dd, pt[r], ov, 0, 0, 0);
+                ok = __builtin_amdgcn_mfma_f32_16x16x4f32(qq, dst[r], ok, 0, 0, 0);
+            }
+            if (t * 16 + 4 * g < HDP) { st4(dvrow + t * 16 + 4 * g, ov); st4(dkrow + t * 16 + 4 * g, ok); }
+        }
+        if (h == 0 && 3 * nH * HDP < ldq)            // tail padding of the qkv width: keep exact zeros (K padding of the dX GEMM)
+            for (int c = 3 * nH * HDP + g; c < ldq; c += 4) dqkv[((size_t)win * 16 + i) * ldq + c] = 0.f;
+    }
+    // relative-position bias gradient: sum the four waves in fixed order, one partial [16][16] per (workgroup, head)
+    st4(&wsum[wave][lane][0], dbsum);
+    __syncthreads();
+    if (wave == 0) {
+        f32x4 t = ld4(&wsum[0][lane][0]);
+        t += ld4(&wsum[1][lane][0]); t += ld4(&wsum[2][lane][0]); t += ld4(&wsum[3][lane][0]);
+        st4(dbias_part + (((size_t)blockIdx.x * nH + h) * 16 + i) * 16 + 4 * g, t);
+    }
+}
+
+// table gradient: dtable[idx][h] = sum over the (i, j) pairs of the 4x4 window with relative index idx of dbias[h][i][j], fixed order
+__global__ void bias_table_grad_kernel(const float* __restrict__ dbias, float* __restrict__ dtable, int nH) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 49 * nH) return;
+    const int idx = e / nH, h = e - idx * nH;
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j)
+            if (((i >> 2) - (j >> 2) + 3) * 7 + ((i & 3) - (j & 3) + 3) == idx) s += dbias[((size_t)h * 16 + i) * 16 + j];
+    dtable[e] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small element-wise helpers
+// ------------------------------------------------------------------------------------------------
+__global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) st4(dst + 4 * i, ld4(dst + 4 * i) + ld4(src + 4 * i));
+}
+__global__ void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ out, long long per_row, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[i] * g[i / per_row];
+}
+// derived layouts refreshed on the device from the flat fp32 parameter buffer: arena[i] = flat[map[i] - 1] (map 0 = structural zero, < 0 = computed elsewhere)
+__global__ void gather_params_kernel(const float* __restrict__ flat, const int* __restrict__ map, float* __restrict__ arena, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = map[i];
+    if (c > 0) arena[i] = flat[c - 1];
+    else if (c == 0) arena[i] = 0.f;
+}
+// gradient of the packed layouts back to the flat reference layout (one-to-one on the regions it is launched on)
+__global__ void scatter_grads_kernel(const float* __restrict__ garena, const int* __restrict__ map, float* __restrict__ gflat, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = map[i];
+    if (c > 0) gflat[c - 1] = garena[i];
+}
+// F.normalize of the codebooks + squared norms (codebook.py:31-36), same summation order as the host packer
+__global__ void codebook_normalize_kernel(const float* __restrict__ raw, float* __restrict__ cbn, float* __restrict__ c2, int rows, int d, int dt, int l2norm) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= rows) return;
+    const float* r = raw + (size_t)k * dt;
+    float ss = 0.f;
+    for (int j = 0; j < d; ++j) ss += r[j] * r[j];
+    const float den = l2norm ? fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
+    float s2 = 0.f;
+    for (int j = 0; j < dt; ++j) { const float v = j < d ? r[j] / den : 0.f; cbn[(size_t)k * dt + j] = v; s2 += v * v; }
+    c2[k] = s2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Product VQ in training mode (codebook.py:57-75, quantization.py:53-64).  One thread per (vector m, group g).
+//   ze  [M][ldz]  projected vectors, group g at columns g*dt .. g*dt+d-1         codes[b*bstride + g*Tq + t]
+//   zup [M][ldz]  what the up-projection sees: STE value z_e + (z_q - z_e), or with frozen codebooks (z_q_ste * 0 + z_e)
+//   terms[g*M + m] = sum_j (z_q - z_e)^2 * loss_scale   (commitment == codebook loss numerically; zero when frozen)
+// ------------------------------------------------------------------------------------------------
+__global__ void pvq_train_fwd_kernel(const float* __restrict__ ze, const long long* __restrict__ codes, long long bstride, const float* __restrict__ cbraw,
+                                     float* __restrict__ zup, float* __restrict__ terms, int M, int G, int Ksz, int d, int dt, int ldz, int Tq,
+                                     float loss_scale, int freeze) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M * G) return;
+    const int g = e / M, m = e - g * M;
+    const int b = m / Tq, t = m - b * Tq;
+    const long long code = codes[(size_t)b * bstride + (size_t)g * Tq + t];
+    const float* q = cbraw + ((size_t)g * Ksz + (size_t)code) * dt;
+    const float* z = ze + (size_t)m * ldz + g * dt;
+    float* o = zup + (size_t)m * ldz + g * dt;
+    float acc = 0.f;
+    for (int j = 0; j < dt; ++j) {
+        if (j < d) {
+            const float df = q[j] - z[j];
+            acc += df * df;
+            const float ste = z[j] + df;                      // z_e + (z_q - z_e).detach()
+            o[j] = freeze ? ste * 0.f + z[j] : ste;
+        } else o[j] = 0.f;
+    }
+    terms[(size_t)g * M + m] = freeze ? 0.f : acc * loss_scale;
+    if (g == 0) for (int c = G * dt; c < ldz; ++c) zup[(size_t)m * ldz + c] = 0.f;
+}
+
+// d z_e = d z_up (straight-through / frozen pass-through) + d(cm_loss) ;  gq = d(cb_loss) w.r.t. the selected code row (per vector)
+__global__ void pvq_train_bwd_kernel(const float* __restrict__ ze, const long long* __restrict__ codes, long long bstride, const float* __restrict__ cbraw,
+                                     const float* __restrict__ dzup, const float* __restrict__ dcm, const float* __restrict__ dcb, float* __restrict__ dze,
+                                     float* __restrict__ gq, int M, int G, int Ksz, int d, int dt, int ldz, int Tq, float loss_scale, int freeze) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M * G) return;
+    const int g = e / M, m = e - g * M;
+    const int b = m / Tq, t = m - b * Tq;
+    const long long code = codes[(size_t)b * bstride + (size_t)g * Tq + t];
+    const float* q = cbraw + ((size_t)g * Ksz + (size_t)code) * dt;
+    const float* z = ze + (size_t)m * ldz + g * dt;
+    const float wm = (dcm && !freeze) ? 2.0f * loss_scale * dcm[b] : 0.f;
+    const float wb = (dcb && !freeze) ? 2.0f * loss_scale * dcb[b] : 0.f;
+    for (int j = 0; j < dt; ++j) {
+        const size_t o = (size_t)m * ldz + g * dt + j;
+        if (j < d) { const float df = z[j] - q[j]; dze[o] = dzup[o] + wm * df; gq[o] = -wb * df; }
+        else { dze[o] = 0.f; gq[o] = 0.f; }
+    }
+    if (g == 0) for (int c = G * dt; c < ldz; ++c) dze[(size_t)m * ldz + c] = 0.f;
+}
+
+// embedding gradient without atomics: one thread per (group, code, dim) walks the vectors in index order and adds those that chose the code
+__global__ void codebook_grad_kernel(const long long* __restrict__ codes, long long bstride, const float* __restrict__ gq, float* __restrict__ dcb,
+                                     int M, int G, int Ksz, int dt, int ldz, int Tq) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= G * Ksz * dt) return;
+    const int j = e % dt; const int gk = e / dt; const int k = gk % Ksz, g = gk / Ksz;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const int b = m / Tq, t = m - b * Tq;
+        if (codes[(size_t)b * bstride + (size_t)g * Tq + t] == k) s += gq[(size_t)m * ldz + g * dt + j];
+    }
+    dcb[e] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// inverse-STFT backward: gradient of the windowed frames from the waveform gradient (istft_ola_kernel transposed)
+// ------------------------------------------------------------------------------------------------
+__global__ void istft_ola_bwd_kernel(const float* __restrict__ dwave, const float* __restrict__ win2, float* __restrict__ dframes, int B, int T,
+                                     int ldf, int win, int hop, int left, int half, int out_len) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * T * ldf) return;
+    const int j = (int)(idx % ldf); const long long bt = idx / ldf; const int t = (int)(bt % T), b = (int)(bt / T);
+    float v = 0.f;
+    if (j < win) {
+        const int p = t * hop + j;                       // position relative to frame 0's window support
+        const int s = p - (half - left);
+        if (s >= 0 && s < out_len) {
+            int t_hi = p / hop; if (t_hi > T - 1) t_hi = T - 1;
+            float env = 0.f;
+            for (int tt = t_hi; tt >= 0; --tt) { const int jj = p - tt * hop; if (jj >= win) break; env += win2[jj]; }
+            v = dwave[(size_t)b * out_len + s] / env;
+        }
+    }
+    dframes[idx] = v;
+}
+
+// conv3x3 dX on the fine time-major map: d_in[(b,t,f)][ci] = sum_{tap,oc} g[(b, t-(kw-1))][oc*Fp + f-(kh-1)] * w[oc][tap=(kw*3+kh)][ci]
+// (w is the packed [16][9*Cp] matrix of the forward implicit GEMM: tap order (t0 over time = kw, t1 over freq = kh))
+__global__ void conv3_dx_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dx, int B, int T, int F, int Fp, int Cp,
+                                int in_dim) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // one thread per (b,t,f, 4 channels)
+    const int V = Cp / 4;
+    if (idx >= (long long)B * T * F * V) return;
+    const int c4 = (int)(idx % V); long long r = idx / V;
+    const int f = (int)(r % F); r /= F; const int t = (int)(r % T), b = (int)(r / T);
+    f32x4 acc = zero4();
+    for (int a = 0; a < 3; ++a) {               // a: time tap (t0), forward reads in(t + a - 1)
+        const int ts = t - (a - 1);
+        if (ts < 0 || ts >= T) continue;
+        for (int bq = 0; bq < 3; ++bq) {        // freq tap (t1)
+            const int fs = f - (bq - 1);
+            if (fs < 0 || fs >= F) continue;
+            for (int oc = 0; oc < in_dim; ++oc) {
+                const float gv = g[((size_t)b * T + ts) * (in_dim * Fp) + oc * Fp + fs];
+                acc += ld4(w + (size_t)oc * 9 * Cp + (size_t)(a * 3 + bq) * Cp + 4 * c4) * gv;
+            }
+        }
+    }
+    st4(dx + ((((size_t)b * T + t) * F + f) * Cp) + 4 * c4, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ComplexSTFTLoss with power-law compression (generator_loss.py:12-35): per clip mean over (2, F, T) of (pl(raw) - pl(recon))^2,
+// pl(x) = sign(x) (|x| + 1e-10)^0.3.  Spectra are frame-major (B, T, in_dim, F).  part[b][block] partial sums; unit gradient optional.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float power_law(float x) { return (x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f)) * powf(fabsf(x) + 1e-10f, 0.3f); }
+__global__ __launch_bounds__(256) void stft_loss_kernel(const float* __restrict__ raw, const float* __restrict__ rec, float* __restrict__ part,
+                                                        float* __restrict__ grad, long long per_clip, int blocks_per_clip, float inv_n) {
+    const int b = blockIdx.y;
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per_clip; i += (long long)blocks_per_clip * 256) {
+        const float a = raw[(size_t)b * per_clip + i], r = rec[(size_t)b * per_clip + i];
+        const float df = power_law(a) - power_law(r);
+        acc += df * df;
+        if (grad) {
+            const float dpl = (r != 0.f) ? 0.3f * powf(fabsf(r) + 1e-10f, -0.7f) : 0.f;       // sign(r)^2 = 1 away from 0; sign(0) = 0 kills the term
+            grad[(size_t)b * per_clip + i] = -2.0f * df * dpl * inv_n;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) part[(size_t)b * blocks_per_clip + blockIdx.x] = red[0] * inv_n;
+}
+// out[b] (+)= sum_k part[b][k], fixed order
+__global__ void row_sum_kernel(const float* __restrict__ part, int n, float* __restrict__ out, int accumulate, float scale) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    float s = 0.f;
+    for (int k = 0; k < n; ++k) s += part[(size_t)b * n + k];
+    out[b] = (accumulate ? out[b] : 0.f) + s * scale;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mel loss pieces (generator_loss.py:37-74).  spec: [B*T][2*Fp] DFT rows (re | im) of raw and recon; mag = |S|.
+// ------------------------------------------------------------------------------------------------
+__global__ void complex_mag_kernel(const float* __restrict__ spec, float* __restrict__ mag, long long rows, int F, int Fp, int Fq) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * Fq) return;
+    const long long r = idx / Fq; const int f = (int)(idx - r * Fq);
+    float v = 0.f;
+    if (f < F) { const float re = spec[r * 2 * Fp + f], im = spec[r * 2 * Fp + Fp + f]; v = sqrtf(re * re + im * im); }
+    mag[idx] = v;
+}
+// per-clip mel terms: |x - y| / n  +  |log10(clamp(x)^2) - log10(clamp(y)^2)| / n ; gradient w.r.t. y (the reconstruction's mel)
+__global__ __launch_bounds__(256) void mel_l1_kernel(const float* __restrict__ xm, const float* __restrict__ ym, float* __restrict__ part,
+                                                     float* __restrict__ gy, int rows_per_clip, int n_mels, int ldm, int blocks_per_clip, float inv_n,
+                                                     float clamp_eps) {
+    const int b = blockIdx.y;
+    __shared__ float red[256];
+    const long long per = (long long)rows_per_clip * ldm;
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long long)blocks_per_clip * 256) {
+        const int c = (int)(i % ldm);
+        const size_t o = (size_t)b * per + i;
+        float gv = 0.f;
+        if (c < n_mels) {
+            const float x = xm[o], y = ym[o];
+            const float xc = fmaxf(x, clamp_eps), yc = fmaxf(y, clamp_eps);
+            const float lx = log10f(xc * xc), ly = log10f(yc * yc);
+            acc += fabsf(x - y) + fabsf(lx - ly);
+            const float s1 = (y > x) ? 1.f : (y < x ? -1.f : 0.f);
+            const float s2 = (ly > lx) ? 1.f : (ly < lx ? -1.f : 0.f);
+            gv = s1 * inv_n + ((y >= clamp_eps) ? s2 * inv_n * 0.86858896380650365530f / yc : 0.f);      // d log10(y^2)/dy = 2 / (y ln 10)
+        }
+        if (gy) gy[o] = gv;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) part[(size_t)b * blocks_per_clip + blockIdx.x] = red[0] * inv_n;
+}
+// d spec = d mag * S / |S|   (|.| of a complex number; zero gradient at S = 0)
+__global__ void complex_mag_bwd_kernel(const float* __restrict__ spec, const float* __restrict__ dmag, float* __restrict__ dspec, long long rows, int F,
+                                       int Fp, int Fq) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * Fp) return;
+    const long long r = idx / Fp; const int f = (int)(idx - r * Fp);
+    float gre = 0.f, gim = 0.f;
+    if (f < F) {
+        const float re = spec[r * 2 * Fp + f], im = spec[r * 2 * Fp + Fp + f];
+        const float m = sqrtf(re * re + im * im);
+        if (m > 0.f) { const float gg = dmag[r * Fq + f] / m; gre = gg * re; gim = gg * im; }
+    }
+    dspec[r * 2 * Fp + f] = gre; dspec[r * 2 * Fp + Fp + f] = gim;
+}
+// framing backward with reflect padding (torch.stft center=True): dwave[b][j] (+)= sum of dframes over every (frame, tap) that read sample j,
+// including the mirrored reads of the padded ends.  padded position i = t*hop + k, sample = reflect(i - pad).
+__global__ void frames_bwd_kernel(const float* __restrict__ dframes, float* __restrict__ dwave, int B, int L, int T, int hop, int n_fft, int ldf,
+                                  int accumulate) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * L) return;
+    const int b = (int)(idx / L), j = (int)(idx - (long long)b * L);
+    const int pad = n_fft / 2;
+    auto gather = [&](int i) {                  // sum over frames covering padded position i
+        float s = 0.f;
+        if (i < 0) return s;
+        int t_hi = i / hop; if (t_hi > T - 1) t_hi = T - 1;
+        for (int t = t_hi; t >= 0; --t) { const int k = i - t * hop; if (k >= n_fft) break; s += dframes[((size_t)b * T + t) * ldf + k]; }
+        return s;
+    };
+    float s = gather(j + pad);
+    if (j >= 1 && j <= pad) s += gather(pad - j);                              // left mirror: padded i < pad reads sample pad - i
+    if (j <= L - 2 && j >= L - 1 - pad) s += gather(pad + 2 * (L - 1) - j);      // right mirror: padded i - pad >= L reads 2(L-1) - (i - pad)
+    dwave[idx] = (accumulate ? dwave[idx] : 0.f) + s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimiser: global-norm clipping + AdamW on flat buffers (trainer_no_adv.py:116-117; torch.optim.AdamW semantics)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc += x[i] * x[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+// norm_out[0] = sqrt(sum part) ; norm_out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))
+__global__ void clip_coef_kernel(const float* __restrict__ part, int n, float max_norm, float* __restrict__ norm_out) {
+    if (threadIdx.x || blockIdx.x) return;
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += part[i];
+    const float nrm = sqrtf(s);
+    norm_out[0] = nrm;
+    const float c = max_norm / (nrm + 1e-6f);
+    norm_out[1] = c < 1.0f ? c : 1.0f;
+}
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                             const float* __restrict__ coef, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * (coef ? coef[1] : 1.0f);
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    pi -= (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+    p[i] = pi;
+}
+
+}  // namespace escx
