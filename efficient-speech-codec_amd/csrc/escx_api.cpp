@@ -150,6 +150,9 @@ extern "C" void escx_destroy(escx_handle h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (auto& kv : h->maps) (void)hipFree(kv.second);
     if (h->coll_buf) (void)hipFree(h->coll_buf);
+    if (h->gmap) (void)hipFree(h->gmap);
+    if (h->garena) (void)hipFree(h->garena);
+    if (h->tape.base) (void)hipFree(h->tape.base);
     delete h;
 }
 
@@ -203,15 +206,16 @@ void pack_frag(float* dst, int n_tiles, int k_tiles, F at) {
 
 #define GETP(var, key, ...) const Param* var = pk.get(key, {__VA_ARGS__}); if (!var) ESCX_FAIL(ESCX_ERR_STATE, "%s", pk.missing.c_str())
 
-extern "C" int escx_finalize_params(escx_handle h) {
-    if (!h) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null handle");
-    ESCX_HIP(hipSetDevice(h->device));
+// Builds the host image of the weight arena from h->params.  `fix` receives (pointer slot, offset) pairs; `computed` the regions whose
+// contents are NOT plain copies of parameter elements (normalised codebooks, DFT matrices, the composed de-embedding); `grads` the
+// primary training layouts, i.e. the regions a backward pass produces gradients for (one-to-one with parameter elements).
+static int pack_image(escx_handle_s* h, std::vector<float>& image, std::vector<std::pair<float**, size_t>>& fix,
+                      std::vector<std::pair<size_t, size_t>>& computed, std::vector<std::pair<size_t, size_t>>& grads) {
     const escx_config& c = h->cfg;
     Packer pk{h};
-    std::vector<std::pair<float**, size_t>> fix;      // (destination pointer slot, offset in floats)
-    auto put = [&](float** slot, size_t n) -> float* { size_t off = pk.alloc(n); fix.push_back({slot, off}); return nullptr; };
-    (void)put;
     auto slot = [&](float** dst, size_t n) -> size_t { size_t off = pk.alloc(n); fix.push_back({dst, off}); return off; };
+    auto cslot = [&](float** dst, size_t n) -> size_t { size_t off = slot(dst, n); computed.push_back({off, n}); return off; };
+    auto gslot = [&](float** dst, size_t n) -> size_t { size_t off = slot(dst, n); grads.push_back({off, n}); return off; };
 
     // ---- transformer layers ----
     for (Layer& L : h->layers) {
@@ -227,10 +231,10 @@ extern "C" int escx_finalize_params(escx_handle h) {
             GETP(w1, p + "mlp.linear_1.weight", L.hidden, C); GETP(b1, p + "mlp.linear_1.bias", L.hidden);
             GETP(w2, p + "mlp.linear_2.weight", C, L.hidden); GETP(b2, p + "mlp.linear_2.bias", C);
             size_t o;
-            o = slot(&bw.ln1_g, Cp); std::copy(n1w->data.begin(), n1w->data.end(), pk.host.begin() + o);
-            o = slot(&bw.ln1_b, Cp); std::copy(n1b->data.begin(), n1b->data.end(), pk.host.begin() + o);
-            o = slot(&bw.wqkv, (size_t)L.Nqkv * Cp);
-            size_t ob = slot(&bw.bqkv, L.Nqkv);
+            o = gslot(&bw.ln1_g, Cp); std::copy(n1w->data.begin(), n1w->data.end(), pk.host.begin() + o);
+            o = gslot(&bw.ln1_b, Cp); std::copy(n1b->data.begin(), n1b->data.end(), pk.host.begin() + o);
+            o = gslot(&bw.wqkv, (size_t)L.Nqkv * Cp);
+            size_t ob = gslot(&bw.bqkv, L.Nqkv);
             for (int w = 0; w < 3; ++w) for (int hh = 0; hh < nH; ++hh) for (int d = 0; d < hd; ++d) {
                 const int src = w * C + hh * hd + d, dst = w * nH * hdp + hh * hdp + d;
                 std::copy(qw->data.begin() + (size_t)src * C, qw->data.begin() + (size_t)(src + 1) * C, pk.host.begin() + o + (size_t)dst * Cp);
@@ -242,18 +246,32 @@ extern "C" int escx_finalize_params(escx_handle h) {
                 const int idx = ((i >> 2) - (jj >> 2) + 3) * 7 + ((i & 3) - (jj & 3) + 3);
                 pk.host[o + ((size_t)hh * 16 + i) * 16 + jj] = tab->data[(size_t)idx * nH + hh];
             }
-            o = slot(&bw.wproj, (size_t)Cp * L.Ko);
+            o = gslot(&bw.wproj, (size_t)Cp * L.Ko);
             for (int r = 0; r < C; ++r) for (int hh = 0; hh < nH; ++hh) for (int d = 0; d < hd; ++d)
                 pk.host[o + (size_t)r * L.Ko + hh * hdp + d] = pw->data[(size_t)r * C + hh * hd + d];
-            o = slot(&bw.bproj, Cp); std::copy(pb->data.begin(), pb->data.end(), pk.host.begin() + o);
-            o = slot(&bw.ln2_g, Cp); std::copy(n2w->data.begin(), n2w->data.end(), pk.host.begin() + o);
-            o = slot(&bw.ln2_b, Cp); std::copy(n2b->data.begin(), n2b->data.end(), pk.host.begin() + o);
-            o = slot(&bw.w1, (size_t)L.hiddenP * Cp);
+            o = gslot(&bw.bproj, Cp); std::copy(pb->data.begin(), pb->data.end(), pk.host.begin() + o);
+            o = gslot(&bw.ln2_g, Cp); std::copy(n2w->data.begin(), n2w->data.end(), pk.host.begin() + o);
+            o = gslot(&bw.ln2_b, Cp); std::copy(n2b->data.begin(), n2b->data.end(), pk.host.begin() + o);
+            o = gslot(&bw.w1, (size_t)L.hiddenP * Cp);
             for (int r = 0; r < L.hidden; ++r) std::copy(w1->data.begin() + (size_t)r * C, w1->data.begin() + (size_t)(r + 1) * C, pk.host.begin() + o + (size_t)r * Cp);
-            o = slot(&bw.b1, L.hiddenP); std::copy(b1->data.begin(), b1->data.end(), pk.host.begin() + o);
-            o = slot(&bw.w2, (size_t)Cp * L.hiddenP);
+            o = gslot(&bw.b1, L.hiddenP); std::copy(b1->data.begin(), b1->data.end(), pk.host.begin() + o);
+            o = gslot(&bw.w2, (size_t)Cp * L.hiddenP);
             for (int r = 0; r < C; ++r) std::copy(w2->data.begin() + (size_t)r * L.hidden, w2->data.begin() + (size_t)(r + 1) * L.hidden, pk.host.begin() + o + (size_t)r * L.hiddenP);
-            o = slot(&bw.b2, Cp); std::copy(b2->data.begin(), b2->data.end(), pk.host.begin() + o);
+            o = gslot(&bw.b2, Cp); std::copy(b2->data.begin(), b2->data.end(), pk.host.begin() + o);
+            {   // transposed copies for the dX GEMMs of the training step (gemm_engine computes A . W^T with W stored [N][K])
+                size_t ot = slot(&bw.wqkvT, (size_t)Cp * L.Nqkv);
+                for (int w = 0; w < 3; ++w) for (int hh = 0; hh < nH; ++hh) for (int d = 0; d < hd; ++d) {
+                    const int src = w * C + hh * hd + d, dst = w * nH * hdp + hh * hdp + d;
+                    for (int k = 0; k < C; ++k) pk.host[ot + (size_t)k * L.Nqkv + dst] = qw->data[(size_t)src * C + k];
+                }
+                ot = slot(&bw.wprojT, (size_t)L.Ko * Cp);
+                for (int r = 0; r < C; ++r) for (int hh = 0; hh < nH; ++hh) for (int d = 0; d < hd; ++d)
+                    pk.host[ot + (size_t)(hh * hdp + d) * Cp + r] = pw->data[(size_t)r * C + hh * hd + d];
+                ot = slot(&bw.w1T, (size_t)Cp * L.hiddenP);
+                for (int r = 0; r < L.hidden; ++r) for (int k = 0; k < C; ++k) pk.host[ot + (size_t)k * L.hiddenP + r] = w1->data[(size_t)r * C + k];
+                ot = slot(&bw.w2T, (size_t)L.hiddenP * Cp);
+                for (int r = 0; r < C; ++r) for (int k = 0; k < L.hidden; ++k) pk.host[ot + (size_t)k * Cp + r] = w2->data[(size_t)r * L.hidden + k];
+            }
             if (L.attn_mode >= 0) {   // fused attention stream: per head group the Q, K, V and projection tiles in fragment order
                 const int mode = L.attn_mode, NG = L.n_groups, KK = Cp / 16;
                 const int TPG = mode == 2 ? 8 : 4, NBr = mode == 2 ? 6 : 3;
@@ -321,10 +339,15 @@ extern "C" int escx_finalize_params(escx_handle h) {
         if (L.scale == 1) {          // PatchMerge: norm over [s][C] -> [s][Cp]; down.weight [Cout][2C] -> [CoutP][2Cp]
             GETP(nw, L.prefix + "subsample.norm.weight", 2 * C); GETP(nb, L.prefix + "subsample.norm.bias", 2 * C);
             GETP(dw, L.prefix + "subsample.down.weight", L.Cout, 2 * C);
-            size_t og = slot(&L.sub_g, 2 * Cp), ob = slot(&L.sub_b, 2 * Cp), ow = slot(&L.sub_w, (size_t)L.CoutP * 2 * Cp);
+            size_t og = gslot(&L.sub_g, 2 * Cp), ob = gslot(&L.sub_b, 2 * Cp), ow = gslot(&L.sub_w, (size_t)L.CoutP * 2 * Cp);
             for (int s = 0; s < 2; ++s) for (int cc = 0; cc < C; ++cc) {
                 pk.host[og + s * Cp + cc] = nw->data[s * C + cc]; pk.host[ob + s * Cp + cc] = nb->data[s * C + cc];
                 for (int r = 0; r < L.Cout; ++r) pk.host[ow + (size_t)r * 2 * Cp + s * Cp + cc] = dw->data[(size_t)r * 2 * C + s * C + cc];
+            }
+            {
+                size_t ot = slot(&L.sub_wT, (size_t)2 * Cp * L.CoutP);          // [2Cp][CoutP]
+                for (int s2 = 0; s2 < 2; ++s2) for (int cc = 0; cc < C; ++cc) for (int r = 0; r < L.Cout; ++r)
+                    pk.host[ot + (size_t)(s2 * Cp + cc) * L.CoutP + r] = dw->data[(size_t)r * 2 * C + s2 * C + cc];
             }
             {
                 const int Cout = L.Cout;
@@ -336,12 +359,17 @@ extern "C" int escx_finalize_params(escx_handle h) {
         } else if (L.scale == 2) {   // PatchSplit: up.weight [2*Cout][C] -> [2*CoutP][Cp]
             GETP(nw, L.prefix + "subsample.norm.weight", C); GETP(nb, L.prefix + "subsample.norm.bias", C);
             GETP(uw, L.prefix + "subsample.up.weight", 2 * L.Cout, C);
-            size_t og = slot(&L.sub_g, Cp), ob = slot(&L.sub_b, Cp), ow = slot(&L.sub_w, (size_t)2 * L.CoutP * Cp);
+            size_t og = gslot(&L.sub_g, Cp), ob = gslot(&L.sub_b, Cp), ow = gslot(&L.sub_w, (size_t)2 * L.CoutP * Cp);
             std::copy(nw->data.begin(), nw->data.end(), pk.host.begin() + og);
             std::copy(nb->data.begin(), nb->data.end(), pk.host.begin() + ob);
             for (int s = 0; s < 2; ++s) for (int r = 0; r < L.Cout; ++r)
                 std::copy(uw->data.begin() + (size_t)(s * L.Cout + r) * C, uw->data.begin() + (size_t)(s * L.Cout + r + 1) * C,
                           pk.host.begin() + ow + (size_t)(s * L.CoutP + r) * Cp);
+            {
+                size_t ot = slot(&L.sub_wT, (size_t)Cp * 2 * L.CoutP);          // [Cp][2*CoutP]
+                for (int s2 = 0; s2 < 2; ++s2) for (int r = 0; r < L.Cout; ++r) for (int k = 0; k < C; ++k)
+                    pk.host[ot + (size_t)k * 2 * L.CoutP + s2 * L.CoutP + r] = uw->data[(size_t)(s2 * L.Cout + r) * C + k];
+            }
             {
                 const int Cout = L.Cout, CoutP = L.CoutP;
                 size_t of = slot(&L.sub_wf, (size_t)2 * CoutP * Cp);
@@ -358,18 +386,18 @@ extern "C" int escx_finalize_params(escx_handle h) {
         GETP(w, "encoder.patch_embed.proj.weight", C0, c.in_dim, c.patch_f, c.patch_t);
         GETP(b, "encoder.patch_embed.proj.bias", C0);
         GETP(g, "encoder.patch_embed.norm.weight", C0); GETP(be, "encoder.patch_embed.norm.bias", C0);
-        size_t o = slot(&h->pe_w, (size_t)C0p * h->Kpe);
+        size_t o = gslot(&h->pe_w, (size_t)C0p * h->Kpe);
         for (int r = 0; r < C0; ++r) std::copy(w->data.begin() + (size_t)r * Kin, w->data.begin() + (size_t)(r + 1) * Kin, pk.host.begin() + o + (size_t)r * h->Kpe);
-        o = slot(&h->pe_b, C0p); std::copy(b->data.begin(), b->data.end(), pk.host.begin() + o);
-        o = slot(&h->pe_g, C0p); std::copy(g->data.begin(), g->data.end(), pk.host.begin() + o);
-        o = slot(&h->pe_beta, C0p); std::copy(be->data.begin(), be->data.end(), pk.host.begin() + o);
+        o = gslot(&h->pe_b, C0p); std::copy(b->data.begin(), b->data.end(), pk.host.begin() + o);
+        o = gslot(&h->pe_g, C0p); std::copy(g->data.begin(), g->data.end(), pk.host.begin() + o);
+        o = gslot(&h->pe_beta, C0p); std::copy(be->data.begin(), be->data.end(), pk.host.begin() + o);
 
         GETP(w1, "decoder.patch_deembed.de_proj1.weight", (int64_t)C0 * Q, C0, 5, 5);
         GETP(b1, "decoder.patch_deembed.de_proj1.bias", (int64_t)C0 * Q);
         GETP(w2, "decoder.patch_deembed.de_proj2.weight", c.in_dim, C0, 3, 3);
         GETP(b2, "decoder.patch_deembed.de_proj2.bias", c.in_dim);
         const size_t K1 = (size_t)25 * C0p;
-        size_t ow = slot(&h->dc1_w, (size_t)Q * C0p * K1), ob = slot(&h->dc1_b, (size_t)Q * C0p);
+        size_t ow = gslot(&h->dc1_w, (size_t)Q * C0p * K1), ob = gslot(&h->dc1_b, (size_t)Q * C0p);
         // pixel_shuffle splits the conv channel dim as (s1, s2, C): o = q*C0 + co  (scale.py:16-23,78)
         for (int q = 0; q < Q; ++q) for (int co = 0; co < C0; ++co) {
             const size_t orow = (size_t)q * C0 + co, prow = (size_t)q * C0p + co;
@@ -377,9 +405,15 @@ extern "C" int escx_finalize_params(escx_handle h) {
             for (int ci = 0; ci < C0; ++ci) for (int kh = 0; kh < 5; ++kh) for (int kw = 0; kw < 5; ++kw)
                 pk.host[ow + prow * K1 + (size_t)(kh * 5 + kw) * C0p + ci] = w1->data[((orow * C0 + ci) * 5 + kh) * 5 + kw];
         }
+        {   // conv5x5 dX as an implicit GEMM over (tap, q, co): W'[ci][(tap*Q + q)*C0p + co] = w1[q*C0 + co][ci][kh][kw], tap = kh*5 + kw
+            size_t ot = slot(&h->dc1_wT, (size_t)C0p * 25 * Q * C0p);
+            for (int q = 0; q < Q; ++q) for (int co = 0; co < C0; ++co) for (int ci = 0; ci < C0; ++ci) for (int kh = 0; kh < 5; ++kh) for (int kw = 0; kw < 5; ++kw)
+                pk.host[ot + (size_t)ci * 25 * Q * C0p + (size_t)((kh * 5 + kw) * Q + q) * C0p + co] =
+                    w1->data[((((size_t)q * C0 + co) * C0 + ci) * 5 + kh) * 5 + kw];
+        }
         // conv2 runs on the TIME-major map (D0 = time, D1 = freq): tap (t0 over time = kw, t1 over freq = kh)
         const size_t K2 = (size_t)9 * C0p;
-        ow = slot(&h->dc2_w, (size_t)16 * K2); ob = slot(&h->dc2_b, 16);
+        ow = gslot(&h->dc2_w, (size_t)16 * K2); ob = gslot(&h->dc2_b, 16);
         if (c.in_dim > 4) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "in_dim > 4");
         for (int oc = 0; oc < c.in_dim; ++oc) {
             pk.host[ob + oc] = b2->data[oc];
@@ -422,22 +456,22 @@ extern "C" int escx_finalize_params(escx_handle h) {
                 }
             }
         }
-        size_t o = slot(&h->dcc_w, (size_t)16 * 49 * C0p);
+        size_t o = cslot(&h->dcc_w, (size_t)16 * 49 * C0p);
         for (int n = 0; n < NO; ++n) for (int tap = 0; tap < 49; ++tap) for (int ci = 0; ci < C0; ++ci)
             pk.host[o + (size_t)n * 49 * C0p + (size_t)tap * C0p + ci] = (float)wc[(size_t)n * Kc + (size_t)tap * C0 + ci];
-        o = slot(&h->dcc_b, 16);
+        o = cslot(&h->dcc_b, 16);
         for (int n = 0; n < NO; ++n) pk.host[o + n] = (float)bc[n];
         // the same interior weights as MFMA fragments [tap][kk][lane][4] for the halo-tiled kernel: lane (n = l & 15, g = l >> 4), channel 16kk + 4g + r
         const int KKd = C0p / 16;
-        o = slot(&h->dch_w, (size_t)49 * KKd * 256);
+        o = cslot(&h->dch_w, (size_t)49 * KKd * 256);
         if (NO <= 16)
             for (int tap = 0; tap < 49; ++tap) for (int kk = 0; kk < KKd; ++kk) for (int l = 0; l < 64; ++l) for (int r = 0; r < 4; ++r) {
                 const int n = l & 15, ci = 16 * kk + 4 * (l >> 4) + r;
                 pk.host[o + ((size_t)(tap * KKd + kk) * 64 + l) * 4 + r] = (n < NO && ci < C0) ? (float)wc[(size_t)n * Kc + (size_t)tap * C0 + ci] : 0.f;
             }
-        o = slot(&h->dcv_w, (size_t)16 * NO * Kc);
+        o = cslot(&h->dcv_w, (size_t)16 * NO * Kc);
         for (size_t i = 0; i < (size_t)16 * NO * Kc; ++i) pk.host[o + i] = (float)wc[i];
-        o = slot(&h->dcv_b, (size_t)16 * NO);
+        o = cslot(&h->dcv_b, (size_t)16 * NO);
         for (size_t i = 0; i < (size_t)16 * NO; ++i) pk.host[o + i] = (float)bc[i];
     }
 
@@ -447,7 +481,7 @@ extern "C" int escx_finalize_params(escx_handle h) {
         std::vector<double> w(win);
         auto it = h->params.find("ft.window");
         for (int k = 0; k < win; ++k) w[k] = (it != h->params.end() && (int)it->second.data.size() == win) ? (double)it->second.data[k] : hann(k, win);
-        size_t o = slot(&h->dft_w, (size_t)2 * Fp * h->winP);
+        size_t o = cslot(&h->dft_w, (size_t)2 * Fp * h->winP);
         for (int f = 0; f < F; ++f) for (int k = 0; k < win; ++k) {
             const double ang = 2.0 * M_PI * (double)((long long)f * (k + left) % N) / (double)N;
             pk.host[o + (size_t)f * h->winP + k] = (float)(w[k] * std::cos(ang));
@@ -456,14 +490,19 @@ extern "C" int escx_finalize_params(escx_handle h) {
         std::vector<double> wi(win);
         auto it2 = h->params.find("ift.window");
         for (int k = 0; k < win; ++k) wi[k] = (it2 != h->params.end() && (int)it2->second.data.size() == win) ? (double)it2->second.data[k] : hann(k, win);
-        o = slot(&h->idft_w, (size_t)h->winP * 2 * Fp);
+        o = cslot(&h->idft_w, (size_t)h->winP * 2 * Fp);
         for (int j = 0; j < win; ++j) for (int f = 0; f < F; ++f) {
             const double coef = (f == 0 || (N % 2 == 0 && f == N / 2)) ? 1.0 : 2.0;   // Hermitian completion of a onesided spectrum
             const double ang = 2.0 * M_PI * (double)((long long)f * (j + left) % N) / (double)N;
             pk.host[o + (size_t)j * 2 * Fp + f] = (float)(wi[j] * coef * std::cos(ang) / N);
             pk.host[o + (size_t)j * 2 * Fp + Fp + f] = (float)(-wi[j] * coef * std::sin(ang) / N);
         }
-        o = slot(&h->win2, h->winP);
+        {   // inverse-DFT matrix transposed ([2Fp][winP]) for the waveform -> spectrum gradient
+            size_t ot = cslot(&h->idft_wT, (size_t)2 * Fp * h->winP);
+            const size_t oi = fix[fix.size() - 2].second;
+            for (int j = 0; j < h->winP; ++j) for (int f = 0; f < 2 * Fp; ++f) pk.host[ot + (size_t)f * h->winP + j] = pk.host[oi + (size_t)j * 2 * Fp + f];
+        }
+        o = cslot(&h->win2, h->winP);
         for (int j = 0; j < win; ++j) { const float wf = (float)wi[j]; pk.host[o + j] = wf * wf; }
     }
 
@@ -472,8 +511,9 @@ extern "C" int escx_finalize_params(escx_handle h) {
     for (Quant& q : h->quants) {
         const int fix = q.Hq * q.C, D = c.overlap * fix;
         std::vector<int> dims(G, D / G); dims[G - 1] = D - (D / G) * (G - 1);     // quantization.py:380-386
-        size_t owd = slot(&q.wd, (size_t)q.Nz * q.Kq), owu = slot(&q.wup, (size_t)q.Kq * q.Kup);
-        size_t ocn = slot(&q.cbn, (size_t)G * Ksz * q.dt), oc2 = slot(&q.c2, (size_t)G * Ksz), ocr = slot(&q.cbraw, (size_t)G * Ksz * q.dt);
+        size_t owd = gslot(&q.wd, (size_t)q.Nz * q.Kq), owu = gslot(&q.wup, (size_t)q.Kq * q.Kup);
+        size_t owdT = slot(&q.wdT, (size_t)q.Kq * q.Nz), owuT = slot(&q.wupT, (size_t)q.Kup * q.Kq);
+        size_t ocn = cslot(&q.cbn, (size_t)G * Ksz * q.dt), oc2 = cslot(&q.c2, (size_t)G * Ksz), ocr = gslot(&q.cbraw, (size_t)G * Ksz * q.dt);
         int start = 0;
         for (int g = 0; g < G; ++g) {
             const std::string gs = std::to_string(g);
@@ -487,6 +527,8 @@ extern "C" int escx_finalize_params(escx_handle h) {
                 for (int j = 0; j < q.d; ++j) {
                     pk.host[owd + (size_t)(g * q.dt + j) * q.Kq + col] = dw->data[(size_t)j * dims[g] + e];
                     pk.host[owu + col * q.Kup + g * q.dt + j] = uw->data[(size_t)e * q.d + j];
+                    pk.host[owdT + col * q.Nz + g * q.dt + j] = dw->data[(size_t)j * dims[g] + e];          // [Kq][Nz]: d residual = d z_e . W_down
+                    pk.host[owuT + (size_t)(g * q.dt + j) * q.Kq + col] = uw->data[(size_t)e * q.d + j];    // [Kup][Kq]: d z_up = d out . W_up
                 }
             }
             for (int k = 0; k < Ksz; ++k) {
@@ -507,21 +549,95 @@ extern "C" int escx_finalize_params(escx_handle h) {
         }
     }
 
-    // ---- upload ----
-    if (h->wts.base) { ESCX_HIP(hipFree(h->wts.base)); h->wts = Arena(); }
-    const size_t bytes = pk.host.size() * sizeof(float);
-    ESCX_HIP(hipMalloc((void**)&h->wts.base, bytes));
-    h->wts.cap = h->wts.used = bytes;
-    ESCX_HIP(hipMemcpy(h->wts.base, pk.host.data(), bytes, hipMemcpyHostToDevice));
+    image.swap(pk.host);
+    return 0;
+}
+
+// canonical flat order of the trainable parameters: the keys escx_finalize_params requires, in that order
+static void build_flat_layout(escx_handle_s* h) {
+    if (!h->flat_keys.empty()) return;
+    size_t off = 0;
+    for (const std::string& k : h->required) {
+        auto it = h->params.find(k);
+        const size_t n = it == h->params.end() ? 0 : it->second.data.size();
+        h->flat_keys.push_back(k); h->flat_off.push_back(off); h->flat_numel.push_back(n);
+        off += n;
+    }
+    h->flat_total = off;
+}
+
+extern "C" int escx_finalize_params(escx_handle h) {
+    if (!h) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null handle");
+    ESCX_HIP(hipSetDevice(h->device));
+    std::vector<float> image;
+    std::vector<std::pair<float**, size_t>> fix;
+    std::vector<std::pair<size_t, size_t>> computed, grads;
+    int rc = pack_image(h, image, fix, computed, grads);
+    if (rc) return rc;
+    // ---- upload (the arena is kept when its size is unchanged: re-packing after an optimiser step does not reallocate) ----
+    const size_t bytes = image.size() * sizeof(float);
+    if (h->wts.base && h->wts.cap != bytes) { ESCX_HIP(hipDeviceSynchronize()); ESCX_HIP(hipFree(h->wts.base)); h->wts = Arena(); }
+    if (!h->wts.base) {
+        ESCX_HIP(hipMalloc((void**)&h->wts.base, bytes));
+        h->wts.cap = h->wts.used = bytes;
+        if (h->gmap) { (void)hipFree(h->gmap); h->gmap = nullptr; }
+    }
+    ESCX_HIP(hipMemcpy(h->wts.base, image.data(), bytes, hipMemcpyHostToDevice));
     for (auto& f : fix) *f.first = reinterpret_cast<float*>(h->wts.base) + f.second;
+    h->grad_regions = grads;
     h->finalized = true;
+    build_flat_layout(h);
+    for (Layer& L : h->layers)
+        for (size_t j = 0; j < L.blocks.size(); ++j) {
+            const std::string key = L.prefix + "swint_blocks." + std::to_string(j) + ".attn.relative_position_bias_table";
+            for (size_t i = 0; i < h->flat_keys.size(); ++i) if (h->flat_keys[i] == key) L.blocks[j].tab_off = (long long)h->flat_off[i];
+        }
     return ESCX_OK;
+}
+
+// Gather map of the arena (training step): the packer is run a second time on parameters whose VALUES are their own flat index + 1
+// (exact in fp32 below 2^24), so every plain-copy element of the image then names the parameter element it came from; 0 = structural
+// zero (padding), -1 = computed region.  One int per arena float, uploaded once per handle.
+int escx::build_gather_map(escx_handle_s* h) {
+    if (h->gmap) return 0;
+    if (!h->finalized) ESCX_FAIL(ESCX_ERR_STATE, "parameters not finalised");
+    if (h->flat_total + 1 >= (size_t)1 << 24) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "model too large for the fp32-coded gather map (%zu parameters)", h->flat_total);
+    std::map<std::string, Param> saved;
+    for (size_t i = 0; i < h->flat_keys.size(); ++i) {
+        Param& p = h->params[h->flat_keys[i]];
+        saved[h->flat_keys[i]] = p;
+        for (size_t e = 0; e < p.data.size(); ++e) p.data[e] = (float)(h->flat_off[i] + e + 1);
+    }
+    std::vector<float> image;
+    std::vector<std::pair<float**, size_t>> fix;
+    std::vector<std::pair<size_t, size_t>> computed, grads;
+    float* dummy_slots = nullptr; (void)dummy_slots;
+    // pack_image writes pointer slots only through `fix`, which is discarded here
+    int rc = pack_image(h, image, fix, computed, grads);
+    for (auto& kv : saved) h->params[kv.first] = kv.second;
+    if (rc) return rc;
+    if (image.size() * sizeof(float) != h->wts.cap) ESCX_FAIL(ESCX_ERR_STATE, "gather map image size mismatch");
+    std::vector<int> gm(image.size(), 0);
+    std::vector<char> is_computed(image.size(), 0);
+    for (auto& r : computed) for (size_t i = r.first; i < r.first + r.second; ++i) is_computed[i] = 1;
+    for (size_t i = 0; i < image.size(); ++i) {
+        if (is_computed[i]) { gm[i] = -1; continue; }
+        const float v = image[i];
+        const long long c = (long long)v;
+        if (v < 0.f || (float)c != v || (size_t)c > h->flat_total) ESCX_FAIL(ESCX_ERR_STATE, "gather map: element %zu is not a plain copy (%g)", i, (double)v);
+        gm[i] = (int)c;
+    }
+    ESCX_HIP(hipSetDevice(h->device));
+    ESCX_HIP(hipMalloc((void**)&h->gmap, gm.size() * sizeof(int)));
+    ESCX_HIP(hipMemcpy(h->gmap, gm.data(), gm.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (!h->garena) ESCX_HIP(hipMalloc((void**)&h->garena, h->wts.cap));
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
 // geometry for a batch, index maps, workspace
 // ------------------------------------------------------------------------------------------------
-static int make_shapes(escx_handle_s* h, int B, int T, Shapes* out) {
+int escx::make_shapes(escx_handle_s* h, int B, int T, Shapes* out) {
     const escx_config& c = h->cfg;
     if (B < 1 || T < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "batch and frame count must be positive");
     Shapes s; s.B = B; s.L = 0;
@@ -544,11 +660,21 @@ static int make_shapes(escx_handle_s* h, int B, int T, Shapes* out) {
     return 0;
 }
 
-static int get_map(escx_handle_s* h, int H, int W, int shift, const int** out) {
+int escx::get_map(escx_handle_s* h, int H, int W, int shift, const int** out) {
     auto key = std::make_tuple(H, W, shift);
     auto it = h->maps.find(key);
     if (it != h->maps.end()) { *out = it->second; return 0; }
     std::vector<int> m;
+    if (shift >= 10) {                          // inverse of the window map: token -> slot (LayerNorm backward of the training step)
+        const int sh0 = shift - 10;
+        const int Hp = rup(H, 4), Wp = rup(W, 4), nWw = Wp / 4;
+        m.assign((size_t)H * W, 0);
+        for (int hh = 0; hh < Hp; ++hh) for (int ww = 0; ww < Wp; ++ww) {
+            const int sh = (hh + sh0) % Hp, sw = (ww + sh0) % Wp;
+            const int slot = (((hh >> 2) * nWw + (ww >> 2)) << 4) + ((hh & 3) << 2) + (ww & 3);
+            if (sh < H && sw < W) m[(size_t)sh * W + sw] = slot;
+        }
+    } else
     if (shift >= 0) {                           // window slots -> source token (attention.py:139-155, 246-250)
         const int Hp = rup(H, 4), Wp = rup(W, 4), nWw = Wp / 4;
         m.resize((size_t)Hp * Wp);
@@ -709,7 +835,7 @@ extern "C" int escx_reserve(escx_handle h, int B, int L) {
 // ------------------------------------------------------------------------------------------------
 // launch sequences
 // ------------------------------------------------------------------------------------------------
-static int check_ready(escx_handle_s* h) {
+int escx::check_ready(escx_handle_s* h) {
     if (!h) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null handle");
     if (!h->finalized) ESCX_FAIL(ESCX_ERR_STATE, "parameters not finalised (call escx_finalize_params)");
     hipError_t e = hipSetDevice(h->device);
@@ -767,27 +893,17 @@ struct TmpBuf {                      // test-path scratch for the stage-level en
 };
 }  // namespace
 
-static int launch_ok(const char* what) {
+int escx::launch_ok(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) ESCX_FAIL(ESCX_ERR_HIP, "%s: kernel launch failed: %s", what, hipGetErrorString(e));
     return 0;
 }
 
-// ---- per-launch profiler ---------------------------------------------------------------------
-static hipEvent_t prof_event(escx_handle_s* h) {
+// ---- per-launch profiler (ProfScope / PROF live in escx_internal.h) ---------------------------
+hipEvent_t escx::prof_event(escx_handle_s* h) {
     if (!h->prof_pool.empty()) { hipEvent_t e = h->prof_pool.back(); h->prof_pool.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
-struct ProfScope {
-    escx_handle_s* h; hipStream_t st; hipEvent_t a;
-    ProfScope(escx_handle_s* h_, hipStream_t s) : h(h_), st(s), a(nullptr) { if (h->prof) { a = prof_event(h); (void)hipEventRecord(a, st); } }
-    void end(const std::string& name, double flops, double bytes) {
-        if (!a) return;
-        hipEvent_t b = prof_event(h); (void)hipEventRecord(b, st);
-        h->prof_recs.push_back({name, flops, bytes, a, b}); a = nullptr;
-    }
-};
-#define PROF(name, flops, bytes, stmt) do { ProfScope _ps(h, st); stmt; if (h->prof) _ps.end(name, flops, bytes); } while (0)
 
 extern "C" int escx_profile_enable(escx_handle h, int enable) {
     if (!h) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null handle");

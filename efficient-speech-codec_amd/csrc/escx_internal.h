@@ -37,6 +37,8 @@ struct BlockW {                      // one SwinBlock, packed
     float *w1f, *w2f;                // fc1 / fc2 in MFMA fragment order ([n-tile][k-step][lane][4]) for the fused MLP
     float *wcf;                      // per hidden tile [fc1 fragments | fc2 fragments]: the LDS-staged fused MLP's stream
     float *waf, *baf, *bias_tab_f;   // fused attention: weight stream [group][tile][KK][64][4], tile biases, padded bias table
+    float *wqkvT = nullptr, *wprojT = nullptr, *w1T = nullptr, *w2T = nullptr;     // transposed copies for the dX GEMMs of the training step
+    long long tab_off = -1;          // flat offset of attn.relative_position_bias_table (its gradient is written there directly)
 };
 
 struct Layer {                       // one TransformerLayer (attention.py:9-91)
@@ -48,12 +50,14 @@ struct Layer {                       // one TransformerLayer (attention.py:9-91)
     std::vector<BlockW> blocks;
     float *sub_g = nullptr, *sub_b = nullptr, *sub_w = nullptr;
     float *sub_wf = nullptr;         // scale-change weights in fragment order (fused LN + linear)
+    float *sub_wT = nullptr;         // transposed for dX (training)
 };
 
 struct Quant {                       // one ProductVectorQuantize (quantization.py:7-136)
     std::string prefix;
     int C, Cp, Hq, d, dt, Nz, Kq, Kup;
     float *wd, *cbn, *c2, *cbraw, *wup;
+    float *wdT = nullptr, *wupT = nullptr;       // transposed for dX (training)
 };
 
 struct Shapes {                      // geometry for one (batch, n_samples)
@@ -73,6 +77,15 @@ struct WsFields {                    // one workspace: every scratch buffer of t
 };
 
 }  // namespace escx
+
+struct escx_handle_s;
+namespace escx {
+int make_shapes(escx_handle_s* h, int B, int T, Shapes* out);
+int get_map(escx_handle_s* h, int H, int W, int shift, const int** out);     // shift 0/2: slot -> token; -1: merge rows; 10/12: token -> slot
+int check_ready(escx_handle_s* h);
+int launch_ok(const char* what);
+int build_gather_map(escx_handle_s* h);
+}
 
 struct escx_handle_s : escx::WsFields {      // the inherited fields are the CURRENT set (swapped by use_set)
     escx_config cfg;
@@ -98,6 +111,18 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     float *dft_w = nullptr, *idft_w = nullptr, *win2 = nullptr;
     float *dcc_w = nullptr, *dcc_b = nullptr, *dcv_w = nullptr, *dcv_b = nullptr;   // composed de-embedding: interior GEMM weights, border variants
     float* dch_w = nullptr;          // the interior weights as MFMA fragments for the halo-tiled kernel
+    float *dc1_wT = nullptr, *idft_wT = nullptr;     // training: conv5x5 dX weights, transposed inverse-DFT matrix
+
+    // ---- training step (train.hip) ----
+    std::vector<std::string> flat_keys;          // canonical flat order of the trainable parameters (== required keys)
+    std::vector<size_t> flat_off, flat_numel;
+    size_t flat_total = 0;
+    int* gmap = nullptr;                         // per arena float: flat index + 1, 0 = zero padding, -1 = computed elsewhere
+    float* garena = nullptr;                     // gradients of the packed layouts, same offsets as the weight arena
+    std::vector<std::pair<size_t, size_t>> grad_regions;     // (offset, n) of the primary training layouts inside the arena
+    escx::Arena tape;                            // activations kept between escx_train_forward and escx_train_backward
+    void* train_state = nullptr;                 // TrainTape* (train.hip)
+    bool composed_stale = false;                 // weights were refreshed on the device: the fp64-folded de-embedding of the inference path is out of date
     bool deembed_halo = true;        // ESCX_DEEMBED_GEMM=1: implicit-GEMM form of the composed convolution instead (A/B, fallback)
     bool deembed_two_stage = false;  // ESCX_DEEMBED_TWO_STAGE=1: run conv5x5 and conv3x3 separately (A/B, fallback)
 
@@ -122,3 +147,17 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     std::vector<hipEvent_t> prof_pool;
     std::string prof_json;
 };
+
+namespace escx {
+hipEvent_t prof_event(escx_handle_s* h);
+struct ProfScope {
+    escx_handle_s* h; hipStream_t st; hipEvent_t a;
+    ProfScope(escx_handle_s* h_, hipStream_t s) : h(h_), st(s), a(nullptr) { if (h->prof) { a = prof_event(h); (void)hipEventRecord(a, st); } }
+    void end(const std::string& name, double flops, double bytes) {
+        if (!a) return;
+        hipEvent_t b = prof_event(h); (void)hipEventRecord(b, st);
+        h->prof_recs.push_back({name, flops, bytes, a, b}); a = nullptr;
+    }
+};
+}  // namespace escx
+#define PROF(name, flops, bytes, stmt) do { ::escx::ProfScope _ps(h, st); stmt; if (h->prof) _ps.end(name, flops, bytes); } while (0)

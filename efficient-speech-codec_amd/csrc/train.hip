@@ -1,0 +1,811 @@
+// Training step of ESC on MI355X: training-mode forward (activations kept), hand-written backward, losses, optimiser.
+// Reference: esc/models/codecs.py:30-66 (forward), esc/models/csrvq.py:23-48,97-129 (cross-scale VQ in training mode),
+// esc/modules/vq/codebook.py:57-75 (STE + losses), esc/modules/vq/quantization.py:31-72 (freeze_vq), scripts/trainer_no_adv.py:95-118 (the step),
+// esc/modules/loss/generator_loss.py:12-74 (losses).  fp32 throughout, like the reference (no AMP there).
+//
+// Design: one stream, whole batch.  The forward is the plain GEMM pipeline with every tensor a backward needs kept on a "tape" (a bump
+// arena in HBM: ~0.85 GB per 3 s clip for ESC-Base, 30 GB at batch 36 out of 288 GB).  The backward walks the tape in reverse; dX are
+// gemm_engine launches with transposed weights, dW/db are gemm_dw launches whose partial sums are reduced in a fixed order.  Gradients
+// land in `garena` (same offsets as the packed weight arena) and are scattered to the flat reference-layout gradient buffer at the end.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "escx_internal.h"
+#include "launchers.h"
+#include "train_kernels.h"
+
+using namespace escx;
+
+namespace {
+
+struct BlockTape { float *x0, *xn1, *qkv, *obuf, *x1, *xn2, *hpre, *hact, *x2; };
+struct LayerTape { std::vector<BlockTape> blk; float* sub_xn = nullptr; float* y = nullptr; int H = 0, Hout = 0; };
+struct QuantTape { bool transmit = false; float *ze = nullptr, *zup = nullptr; const float* enc = nullptr; const float* dec = nullptr; float* out = nullptr; };
+struct TrainTape {
+    bool valid = false;
+    int B = 0, L = 0, S = 0, freeze = 0;
+    Shapes shp;
+    float *spec = nullptr, *pe_pre = nullptr, *tok0 = nullptr, *deemb = nullptr, *rspec = nullptr, *terms = nullptr;
+    long long* codes = nullptr;              // (B, max_streams, G, Tq)
+    std::vector<LayerTape> layers;           // 2n
+    std::vector<float*> enc_hs;              // n
+    std::vector<QuantTape> q;                // max_streams
+    float* post = nullptr;                   // decoder.post_nn output
+    size_t fwd_mark = 0;
+};
+
+TrainTape* tape_of(escx_handle_s* h) {
+    if (!h->train_state) h->train_state = new TrainTape();
+    return static_cast<TrainTape*>(h->train_state);
+}
+
+inline unsigned blocks_for(long long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+// ---- GEMM helpers --------------------------------------------------------------------------------
+template <class Ld, class Epi>
+void gemm_any(const Ld& ld, const float* W, int M, int Np, int Kp, const Epi& ep, hipStream_t st, int force_bk = 0) {
+    launch_gemm<64>(ld, W, M, Np, Kp, ep, st, 1, force_bk);
+}
+template <class Epi>
+void gemm_rows(const float* A, int lda, int M, const float* W, int Np, int Kp, const Epi& ep, hipStream_t st) {
+    gemm_any(PlainA{A, lda, M}, W, M, Np, Kp, ep, st);
+}
+
+struct Scratch {                              // bump allocator over the free tail of the tape
+    Arena* a; size_t mark;
+    explicit Scratch(Arena* ar) : a(ar), mark(ar->used) {}
+    ~Scratch() { a->used = mark; }
+    float* take(size_t n) { return a->take(n); }
+};
+
+constexpr size_t DW_PART_FLOATS = (size_t)10 << 20;      // partial-sum scratch of one dW launch (40 MB)
+
+// dW[Np][Kp] (+ db[Np]) = sum over M rows; la: gradient rows (columns n), lb: saved input rows (columns k)
+template <class LdA, class LdB>
+int dw_launch(escx_handle_s* h, const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
+    const int nbn = (Np + 47) / 48, nbk = (Kp + 47) / 48, blocks = nbn * nbk;
+    int slices = std::max(1, std::min((2048 + blocks - 1) / blocks, (M + 127) / 128));
+    const size_t per = (size_t)Np * Kp + Np;
+    slices = (int)std::min<size_t>(slices, DW_PART_FLOATS / per);
+    if (slices < 1) ESCX_FAIL(ESCX_ERR_STATE, "dW scratch too small for %d x %d", Np, Kp);
+    int mps = ((M + slices - 1) / slices + 127) / 128 * 128;
+    slices = (M + mps - 1) / mps;
+    float* bpart = part + (size_t)slices * Np * Kp;
+    if (db) hipLaunchKernelGGL((gemm_dw_kernel<LdA, LdB, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+    else hipLaunchKernelGGL((gemm_dw_kernel<LdA, LdB, false>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for((long long)Np * Kp)), dim3(256), 0, st, part, slices, (long long)Np * Kp, dW, 0);
+    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for(Np)), dim3(256), 0, st, bpart, slices, (long long)Np, db, 0);
+    return 0;
+}
+
+// LayerNorm backward launcher; dgamma -> dg[SEGS*Cp], dbeta -> dbt[SEGS*Cp]
+int ln_bwd(int mode, const float* x, const float* dy, const float* gamma, const int* map, const float* add, float* dx, float* dg, float* dbt,
+           int rows_per_clip, int src_rows_per_clip, int dy_rows_per_clip, int total_rows, int C, int Cp, float* part, hipStream_t st) {
+    const int segs = mode == 2 ? 2 : 1;
+    const int grid = (int)std::min<long long>(512, ((long long)total_rows + 15) / 16);
+    const size_t shm = (size_t)16 * 2 * segs * Cp * sizeof(float);
+    const int RW = segs * Cp;
+    if (mode == 0) hipLaunchKernelGGL((ln_bwd_kernel<1, 0>), dim3(grid), dim3(256), shm, st, x, dy, gamma, map, add, dx, part, rows_per_clip, src_rows_per_clip, dy_rows_per_clip, total_rows, C, Cp, 1e-5f);
+    else if (mode == 1) hipLaunchKernelGGL((ln_bwd_kernel<1, 1>), dim3(grid), dim3(256), shm, st, x, dy, gamma, map, add, dx, part, rows_per_clip, src_rows_per_clip, dy_rows_per_clip, total_rows, C, Cp, 1e-5f);
+    else hipLaunchKernelGGL((ln_bwd_kernel<2, 2>), dim3(grid), dim3(256), shm, st, x, dy, gamma, map, add, dx, part, rows_per_clip, src_rows_per_clip, dy_rows_per_clip, total_rows, C, Cp, 1e-5f);
+    // part: [grid][2][RW] -> reduce over grid (fixed order) into a [2][RW] row, then to the two destinations
+    float* red = part + (size_t)grid * 2 * RW;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for(2 * RW)), dim3(256), 0, st, part, grid, (long long)2 * RW, red, 0);
+    (void)hipMemcpyAsync(dg, red, (size_t)RW * sizeof(float), hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(dbt, red + RW, (size_t)RW * sizeof(float), hipMemcpyDeviceToDevice, st);
+    return 0;
+}
+constexpr size_t LN_PART_FLOATS = (size_t)513 * 2 * 2 * 384;
+
+int attn_bwd(const float* qkv, const float* bias, const float* dout, float* dqkv, float* dbias, float* part, int total_windows, int nH, int hdp, int ldq,
+             int ldo, int nWh, int nWw, int shifted, float scale, hipStream_t st) {
+    const int gx = (int)std::min<long long>(512, ((long long)total_windows + 3) / 4);
+    dim3 grid(gx, nH);
+#define ESCX_ATB(S) case S: hipLaunchKernelGGL((attn_bwd_kernel<S>), grid, dim3(256), 0, st, qkv, bias, dout, dqkv, part, total_windows, nH, ldq, ldo, nWh, nWw, shifted, scale); break;
+    switch (hdp / 4) {
+        ESCX_ATB(1) ESCX_ATB(2) ESCX_ATB(3) ESCX_ATB(4) ESCX_ATB(5) ESCX_ATB(6) ESCX_ATB(7) ESCX_ATB(8) ESCX_ATB(12) ESCX_ATB(16)
+        default: return -1;
+    }
+#undef ESCX_ATB
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for((long long)nH * 256)), dim3(256), 0, st, part, gx, (long long)nH * 256, dbias, 0);
+    return 0;
+}
+constexpr size_t ATT_PART_FLOATS = (size_t)512 * 64 * 256;
+
+inline float* G(escx_handle_s* h, const float* w) { return h->garena + (w - reinterpret_cast<const float*>(h->wts.base)); }
+
+// ---- tape sizing -----------------------------------------------------------------------------------
+int layer_H(escx_handle_s* h, const Shapes& s, int li) {
+    const int n = h->n;
+    if (li < n) return s.encH[std::max(li - 1, 0)];
+    if (li < 2 * n - 1) return s.encH[n - 1 - (li - n)];
+    return s.encH[0];
+}
+
+size_t pad256(size_t nfl) { return (nfl * sizeof(float) + 255) / 256 * 256; }
+
+size_t tape_bytes(escx_handle_s* h, const Shapes& s) {
+    const escx_config& c = h->cfg;
+    const int n = h->n, B = s.B;
+    size_t tot = 0, act_max = 0, hid_max = 0, qkv_max = 0;
+    auto add = [&](size_t nfl) { tot += pad256(nfl); };
+    add((size_t)B * s.T * c.in_dim * h->Fp);                         // spec
+    const size_t tok0 = (size_t)B * s.H0 * s.W * h->C0p;
+    add(tok0); add(tok0);                                            // pe_pre, tok0
+    for (int li = 0; li < 2 * n; ++li) {
+        const Layer& L = h->layers[li];
+        const int H = layer_H(h, s, li);
+        const size_t M = (size_t)B * H * s.W, Ms = (size_t)B * rup(H, 4) * rup(s.W, 4);
+        for (size_t j = 0; j < L.blocks.size(); ++j) {
+            add(Ms * L.Cp); add(Ms * L.Nqkv); add(Ms * L.Ko); add(M * L.Cp); add(M * L.Cp); add(M * L.hiddenP); add(M * L.hiddenP); add(M * L.Cp);
+        }
+        if (L.scale == 1) { const size_t M2 = (size_t)B * ((H + 1) / 2) * s.W; add(M2 * 2 * L.Cp); add(M2 * L.CoutP); }
+        else if (L.scale == 2) { add(M * L.Cp); add(2 * M * L.CoutP); }
+        act_max = std::max({act_max, M * L.Cp, Ms * L.Cp, Ms * L.Ko, 2 * M * L.CoutP});
+        hid_max = std::max(hid_max, M * L.hiddenP);
+        qkv_max = std::max(qkv_max, Ms * L.Nqkv);
+    }
+    const size_t Mq = (size_t)B * s.Tq;
+    size_t zp_max = 0;
+    for (const Quant& q : h->quants) {
+        add(Mq * q.Nz); add(Mq * q.Nz);                              // ze, zup
+        add((size_t)B * q.Hq * s.W * q.Cp);                          // refined decoder map
+        zp_max = std::max(zp_max, (size_t)pvq_down_splits((int)Mq, q.Kq, q.Cp) * Mq * q.Nz);
+    }
+    add((size_t)c.max_streams * c.group_size * Mq);                  // loss terms
+    add((size_t)B * c.max_streams * c.group_size * s.Tq * 2);        // codes (int64)
+    const int T2 = c.patch_t * s.W, F2 = c.patch_f * s.H0;
+    add((size_t)B * T2 * F2 * h->C0p);                               // de-embedding fine map
+    add((size_t)B * T2 * c.in_dim * h->Fp);                          // rspec
+    // backward scratch (upper bounds): activations-sized gradients, dW partials, LN / attention partials, frames
+    const size_t fine = (size_t)B * T2 * F2 * h->C0p;
+    tot += 12 * pad256(act_max) + 2 * pad256(hid_max) + 2 * pad256(qkv_max) + pad256(zp_max) + 2 * pad256(fine) + pad256(DW_PART_FLOATS) +
+           pad256(LN_PART_FLOATS) + pad256(ATT_PART_FLOATS) + 3 * pad256((size_t)B * T2 * std::max(h->winP, c.in_dim * h->Fp)) + (size_t)n * pad256(act_max) + (64 << 20);
+    return tot;
+}
+
+// ---- forward pieces -----------------------------------------------------------------------------------
+int layer_fwd(escx_handle_s* h, const Layer& L, LayerTape& LT, const float* x_in, int B, int H, int W, hipStream_t st) {
+    Arena& tp = h->tape;
+    const int tokens = H * W, M = B * tokens;
+    const int Hp = rup(H, 4), Wp = rup(W, 4), slots = Hp * Wp, Ms = B * slots;
+    const double dM = M, dMs = Ms, dC = L.C, f4 = 4;
+    LT.H = H;
+    LT.blk.assign(L.blocks.size(), BlockTape());
+    const float* x = x_in;
+    int rc;
+    for (size_t j = 0; j < L.blocks.size(); ++j) {
+        const BlockW& bw = L.blocks[j];
+        BlockTape& bt = LT.blk[j];
+        const int shift = (j % 2 == 0) ? 0 : 2;
+        const int* map;
+        if ((rc = get_map(h, H, W, shift, &map))) return rc;
+        bt.x0 = const_cast<float*>(x);
+        bt.xn1 = tp.take((size_t)Ms * L.Cp); bt.qkv = tp.take((size_t)Ms * L.Nqkv); bt.obuf = tp.take((size_t)Ms * L.Ko);
+        bt.x1 = tp.take((size_t)M * L.Cp); bt.xn2 = tp.take((size_t)M * L.Cp);
+        bt.hpre = tp.take((size_t)M * L.hiddenP); bt.hact = tp.take((size_t)M * L.hiddenP); bt.x2 = tp.take((size_t)M * L.Cp);
+        if (!bt.x2) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small");
+        PROF("T.ln1_gather", 0, (dM + dMs) * dC * f4, ln_rows(1, x, bt.xn1, bw.ln1_g, bw.ln1_b, map, slots, tokens, Ms, L.C, L.Cp, st));
+        PROF("T.gemm_qkv", 2 * dMs * dC * 3 * dC, dMs * 4 * dC * f4,
+             gemm_qkv(bt.xn1, L.Cp, Ms, bw.wqkv, L.Nqkv, L.Cp, bt.qkv, bw.bqkv, L.nH * L.hdp, 1.0f / std::sqrt((float)L.hd), st));
+        int arc = 0;
+        PROF("T.window_attn", 4 * dMs * 16 * dC, dMs * 4 * dC * f4,
+             arc = window_attention(bt.qkv, bw.bias_tab, bt.obuf, Ms / 16, L.nH, L.hdp, L.Nqkv, L.Ko, Hp / 4, Wp / 4, shift > 0, st));
+        if (arc) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "head_dim %d unsupported by the attention kernel", L.hd);
+        PROF("T.gemm_proj", 2 * dMs * dC * dC, (dMs * dC + 2 * dM * dC) * f4,
+             gemm_proj_scatter(bt.obuf, L.Ko, Ms, bw.wproj, L.Cp, L.Ko, bt.x1, x, bw.bproj, map, slots, tokens, st));
+        PROF("T.ln2", 0, 2 * dM * dC * f4, ln_rows(0, bt.x1, bt.xn2, bw.ln2_g, bw.ln2_b, nullptr, tokens, tokens, M, L.C, L.Cp, st));
+        PROF("T.gemm_fc1_gelu", 2 * dM * dC * L.hidden, dM * (dC + 2 * L.hidden) * f4,
+             gemm_rows(bt.xn2, L.Cp, M, bw.w1, L.hiddenP, L.Cp, EpiGeluDual{bt.hpre, bt.hact, L.hiddenP, bw.b1}, st));
+        PROF("T.gemm_fc2_res", 2 * dM * dC * L.hidden, dM * (2 * dC + L.hidden) * f4,
+             gemm_residual(bt.hact, L.hiddenP, M, bw.w2, L.Cp, L.hiddenP, bt.x2, bw.b2, bt.x1, st));
+        x = bt.x2;
+    }
+    if (L.scale == 1) {
+        const int H2 = (H + 1) / 2, M2 = B * H2 * W;
+        const int* map;
+        if ((rc = get_map(h, H, W, -1, &map))) return rc;
+        LT.sub_xn = tp.take((size_t)M2 * 2 * L.Cp); LT.y = tp.take((size_t)M2 * L.CoutP);
+        if (!LT.y) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small");
+        PROF("T.merge_ln", 0, 2.0 * M * L.C * 4, ln_rows(2, x, LT.sub_xn, L.sub_g, L.sub_b, map, H2 * W, tokens, M2, L.C, L.Cp, st));
+        PROF("T.merge_gemm", 2.0 * M2 * 2 * L.C * L.Cout, (double)M2 * (2 * L.C + L.Cout) * 4,
+             gemm_store(LT.sub_xn, 2 * L.Cp, M2, L.sub_w, L.CoutP, 2 * L.Cp, LT.y, L.CoutP, nullptr, st));
+        LT.Hout = H2;
+    } else if (L.scale == 2) {
+        LT.sub_xn = tp.take((size_t)M * L.Cp); LT.y = tp.take((size_t)2 * M * L.CoutP);
+        if (!LT.y) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small");
+        PROF("T.split_ln", 0, 2.0 * M * L.C * 4, ln_rows(0, x, LT.sub_xn, L.sub_g, L.sub_b, nullptr, tokens, tokens, M, L.C, L.Cp, st));
+        PROF("T.split_gemm", 2.0 * M * L.C * 2 * L.Cout, (double)M * (L.C + 2 * L.Cout) * 4,
+             gemm_split(LT.sub_xn, L.Cp, M, L.sub_w, 2 * L.CoutP, L.Cp, LT.y, H, W, L.CoutP, st));
+        LT.Hout = 2 * H;
+    } else {
+        LT.y = const_cast<float*>(x); LT.Hout = H;
+    }
+    return launch_ok(L.prefix.c_str());
+}
+
+// one cross-scale VQ step in training mode (csrvq.py:23-48).  dec == nullptr for stream 0 (enc - 0.0).
+int quant_fwd(escx_handle_s* h, TrainTape& T, int sid, const float* enc, const float* dec, bool transmit, float* zpart, hipStream_t st) {
+    const escx_config& c = h->cfg;
+    const Quant& q = h->quants[sid];
+    const Shapes& s = T.shp;
+    Arena& tp = h->tape;
+    QuantTape& Q = T.q[sid];
+    const int B = s.B, W = s.W, Tq = s.Tq, M = B * Tq, G = c.group_size;
+    const long long bstride = (long long)c.max_streams * G * Tq;
+    long long* codes = T.codes + (long long)sid * G * Tq;
+    Q.transmit = transmit; Q.enc = enc; Q.dec = dec;
+    Q.ze = tp.take((size_t)M * q.Nz); Q.zup = tp.take((size_t)M * q.Nz);
+    if (!Q.zup) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small");
+    const int splits = pvq_down_splits(M, q.Kq, q.Cp);
+    const double vec = (double)c.overlap * q.Hq * q.C;
+    PROF("T.pvq_down", 2.0 * M * vec * q.d, (double)M * vec * (dec ? 2 : 1) * 4,
+         gemm_pvq_down(enc, dec, B, q.Hq, W, q.Cp, c.overlap, q.wd, q.Nz, q.Kq, zpart, splits, st));
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for((long long)M * q.Nz)), dim3(256), 0, st, zpart, splits, (long long)M * q.Nz, Q.ze, 0);
+    int src = 0;
+    PROF("T.pvq_search", 2.0 * M * G * c.codebook_size * q.d, (double)G * c.codebook_size * q.d * 4,
+         src = pvq_search(Q.ze, 1, M, q.Nz, q.cbn, q.c2, q.cbraw, G, c.codebook_size, q.d, q.dt, Tq, codes, bstride, nullptr, 0.f, c.l2norm, st));
+    if (src) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "codebook_dim %d unsupported by the search kernel", q.d);
+    if (!transmit) { Q.out = const_cast<float*>(dec); return launch_ok("quant_fwd"); }      // residual_q *= 0 (csrvq.py:42-44): the refined map IS dec
+    float* terms = T.terms + (size_t)sid * G * M;
+    hipLaunchKernelGGL(pvq_train_fwd_kernel, dim3(blocks_for((long long)M * G)), dim3(256), 0, st, Q.ze, codes, bstride, q.cbraw, Q.zup, terms, M, G,
+                       c.codebook_size, q.d, q.dt, q.Nz, Tq, 1.0f / ((float)Tq * q.d * G), T.freeze);
+    Q.out = tp.take((size_t)B * q.Hq * W * q.Cp);
+    if (!Q.out) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small");
+    PROF("T.pvq_up", 2.0 * M * vec * q.d, (double)M * vec * 2 * 4,
+         gemm_any(PlainA{Q.zup, q.Nz, M}, q.wup, M, q.Kq, q.Kup,
+                  EpiPvqAdd{Q.out, dec, q.Hq, W, q.Cp, Tq, c.overlap, FastDiv(Tq), FastDiv(q.Cp), FastDiv(q.Hq)}, st));
+    return launch_ok("quant_fwd");
+}
+
+int refresh_from_flat(escx_handle_s* h, const float* flat, hipStream_t st) {
+    int rc = build_gather_map(h);
+    if (rc) return rc;
+    const long long n = (long long)(h->wts.cap / sizeof(float));
+    hipLaunchKernelGGL(gather_params_kernel, dim3(blocks_for(n)), dim3(256), 0, st, flat, h->gmap, reinterpret_cast<float*>(h->wts.base), n);
+    const escx_config& c = h->cfg;
+    for (const Quant& q : h->quants) {
+        const int rows = c.group_size * c.codebook_size;
+        hipLaunchKernelGGL(codebook_normalize_kernel, dim3(blocks_for(rows)), dim3(256), 0, st, q.cbraw, q.cbn, q.c2, rows, q.d, q.dt, c.l2norm);
+    }
+    h->composed_stale = true;           // the folded de-embedding of the inference path is a host-side fp64 product: not refreshed here
+    return launch_ok("refresh_from_flat");
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int escx_flat_param_count(escx_handle h) { return h ? (int)h->flat_keys.size() : 0; }
+extern "C" const char* escx_flat_param_key(escx_handle h, int i) { return (h && i >= 0 && i < (int)h->flat_keys.size()) ? h->flat_keys[i].c_str() : nullptr; }
+extern "C" int64_t escx_flat_param_offset(escx_handle h, int i) { return (h && i >= 0 && i < (int)h->flat_off.size()) ? (int64_t)h->flat_off[i] : -1; }
+extern "C" int64_t escx_flat_param_numel(escx_handle h, int i) { return (h && i >= 0 && i < (int)h->flat_numel.size()) ? (int64_t)h->flat_numel[i] : -1; }
+extern "C" int64_t escx_flat_param_total(escx_handle h) { return h ? (int64_t)h->flat_total : 0; }
+
+extern "C" int escx_load_flat_params(escx_handle h, const float* flat_dev, int full, void* stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!flat_dev) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
+    if (!full) return refresh_from_flat(h, flat_dev, (hipStream_t)stream);
+    // full: host round trip, so that the fp64-folded layouts of the inference path are rebuilt too
+    ESCX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    std::vector<float> host(h->flat_total);
+    ESCX_HIP(hipMemcpy(host.data(), flat_dev, h->flat_total * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h->flat_keys.size(); ++i) {
+        Param& p = h->params[h->flat_keys[i]];
+        std::copy(host.begin() + h->flat_off[i], host.begin() + h->flat_off[i] + h->flat_numel[i], p.data.begin());
+    }
+    rc = escx_finalize_params(h);
+    if (!rc) h->composed_stale = false;
+    return rc;
+}
+
+extern "C" int64_t escx_train_tape_bytes(escx_handle h) { return h ? (int64_t)h->tape.cap : 0; }
+
+extern "C" int escx_train_forward(escx_handle h, const float* flat_dev, const float* wave, int B, int L, int S, int freeze, int64_t* codes_out,
+                                  float* wave_out, float* raw_feat, float* recon_feat, float* cm_loss, float* cb_loss, void* stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!wave || !codes_out || !wave_out) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
+    const escx_config& c = h->cfg;
+    if (B < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "batch must be positive");
+    if (S < 1 || S > c.max_streams) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "num_streams=%d outside [1, %d]", S, c.max_streams);
+    if (L <= h->n_fft / 2) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_samples=%d too short for reflect padding of %d", L, h->n_fft / 2);
+    hipStream_t st = (hipStream_t)stream;
+    if (flat_dev && (rc = refresh_from_flat(h, flat_dev, st))) return rc;
+    if ((rc = build_gather_map(h))) return rc;
+    TrainTape& T = *tape_of(h);
+    T.valid = false;
+    Shapes s;
+    if ((rc = make_shapes(h, B, 1 + L / c.hop_length, &s))) return rc;
+    const size_t need = tape_bytes(h, s);
+    if (h->tape.cap < need) {
+        ESCX_HIP(hipDeviceSynchronize());
+        if (h->tape.base) ESCX_HIP(hipFree(h->tape.base));
+        h->tape = Arena();
+        ESCX_HIP(hipMalloc((void**)&h->tape.base, need));
+        h->tape.cap = need;
+    }
+    Arena& tp = h->tape;
+    tp.used = 0;
+    T.B = B; T.L = L; T.S = freeze ? c.max_streams : S; T.freeze = freeze ? 1 : 0; T.shp = s;      // codecs.py:65: frozen codebooks use every stream
+    const int n = h->n, G = c.group_size, Smax = c.max_streams;
+    const int T2 = c.patch_t * s.W, out_len = c.hop_length * (T2 - 1);
+
+    // STFT -> patch embedding (base.py:29-37, scale.py:42-50)
+    T.spec = tp.take((size_t)B * s.T * c.in_dim * h->Fp);
+    const size_t tok0 = (size_t)B * s.H0 * s.W * h->C0p;
+    T.pe_pre = tp.take(tok0); T.tok0 = tp.take(tok0);
+    T.terms = tp.take((size_t)Smax * G * B * s.Tq);
+    T.codes = reinterpret_cast<long long*>(tp.take((size_t)B * Smax * G * s.Tq * 2));
+    if (!T.codes) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small");
+    PROF("T.stft", 2.0 * B * s.T * c.win_length * 2 * h->F, ((double)B * L + (double)B * s.T * 2 * h->F) * 4,
+         gemm_frames(wave, B, L, s.T, c.hop_length, h->left - h->n_fft / 2, h->dft_w, c.in_dim * h->Fp, h->winP, T.spec, st));
+    if (raw_feat) unpad_rows(T.spec, raw_feat, (long long)B * s.T * c.in_dim, h->F, h->Fp, st);
+    PROF("T.patch_embed", 2.0 * tok0 * c.in_dim * c.patch_f * c.patch_t, ((double)B * s.T * 2 * h->F + 2.0 * tok0) * 4,
+         gemm_patch(T.spec, B, s.T, c.in_dim, h->Fp, s.H0, s.W, c.patch_f, c.patch_t, h->pe_w, h->C0p, h->Kpe, T.pe_pre, h->pe_b, st));
+    ln_rows(0, T.pe_pre, T.tok0, h->pe_g, h->pe_beta, nullptr, s.H0 * s.W, s.H0 * s.W, B * s.H0 * s.W, h->C0, h->C0p, st);
+
+    // encoder (base.py:143-158)
+    T.layers.assign(2 * n, LayerTape());
+    T.enc_hs.assign(n, nullptr);
+    if ((rc = layer_fwd(h, h->layers[0], T.layers[0], T.tok0, B, s.H0, s.W, st))) return rc;
+    T.enc_hs[0] = T.layers[0].y;
+    for (int i = 0; i + 1 < n; ++i) {
+        if ((rc = layer_fwd(h, h->layers[1 + i], T.layers[1 + i], T.enc_hs[i], B, s.encH[i], s.W, st))) return rc;
+        T.enc_hs[i + 1] = T.layers[1 + i].y;
+    }
+
+    // cross-scale VQ decoder in training mode (csrvq.py:97-129): every stream is quantised (codes of all max_streams are returned),
+    // streams >= num_streams are masked out of the reconstruction and of the losses
+    T.q.assign(Smax, QuantTape());
+    size_t zp = 0;
+    for (const Quant& q : h->quants) zp = std::max(zp, (size_t)pvq_down_splits(B * s.Tq, q.Kq, q.Cp) * B * s.Tq * q.Nz);
+    float* zpart = tp.take(zp);              // split-K partials of the down-projections (dead once z_e is reduced; reused by every stream)
+    if (!zpart) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small");
+    if ((rc = quant_fwd(h, T, 0, T.enc_hs[n - 1], nullptr, true, zpart, st))) return rc;
+    const float* dec = T.q[0].out;
+    int H = s.encH[n - 1];
+    for (int i = 0; i + 1 < n; ++i) {
+        const bool transmit = i < T.S - 1;
+        if ((rc = quant_fwd(h, T, i + 1, T.enc_hs[n - 1 - i], dec, transmit, zpart, st))) return rc;
+        if ((rc = layer_fwd(h, h->layers[n + i], T.layers[n + i], T.q[i + 1].out, B, H, s.W, st))) return rc;
+        dec = T.layers[n + i].y; H = T.layers[n + i].Hout;
+    }
+    if ((rc = layer_fwd(h, h->layers[2 * n - 1], T.layers[2 * n - 1], dec, B, H, s.W, st))) return rc;
+    T.post = T.layers[2 * n - 1].y;
+
+    // de-embedding as the two convolutions of the reference (scale.py:73-81; the folded 7x7 form of the inference path has no separate weights)
+    const int F2 = c.patch_f * s.H0;
+    T.deemb = tp.take((size_t)B * T2 * F2 * h->C0p);
+    T.rspec = tp.take((size_t)B * T2 * c.in_dim * h->Fp);
+    if (!T.rspec) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small");
+    ESCX_HIP(hipMemsetAsync(T.rspec, 0, (size_t)B * T2 * c.in_dim * h->Fp * sizeof(float), st));       // Fp - F pad columns stay zero
+    {
+        const double toks = (double)B * s.H0 * s.W, pix = toks * h->Q;
+        PROF("T.deembed_conv5x5", 2.0 * toks * 25 * h->C0 * h->C0 * h->Q, (toks * h->C0 + pix * h->C0) * 4,
+             gemm_conv_deembed1(T.post, B, s.H0, s.W, h->C0p, h->dc1_w, h->Q * h->C0p, T.deemb, h->dc1_b, c.patch_f, c.patch_t, st));
+        PROF("T.deembed_conv3x3", 2.0 * pix * 9 * h->C0 * c.in_dim, (pix * h->C0 + pix * c.in_dim) * 4,
+             gemm_conv_spec(T.deemb, B, T2, F2, h->C0p, h->dc2_w, T.rspec, h->dc2_b, h->Fp, c.in_dim, st));
+    }
+    if (recon_feat) unpad_rows(T.rspec, recon_feat, (long long)B * T2 * c.in_dim, h->F, h->Fp, st);
+    {   // inverse STFT (base.py:39-47)
+        Scratch sc(&tp);
+        float* frames = sc.take((size_t)B * T2 * h->winP);
+        if (!frames) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small");
+        PROF("T.istft", 2.0 * B * T2 * c.win_length * 2 * h->F, (double)B * T2 * (2 * h->F + c.win_length) * 4,
+             gemm_store(T.rspec, c.in_dim * h->Fp, B * T2, h->idft_w, h->winP, c.in_dim * h->Fp, frames, h->winP, nullptr, st));
+        istft_ola(frames, h->win2, wave_out, B, T2, h->winP, c.win_length, c.hop_length, h->left, h->n_fft / 2, out_len, st);
+    }
+    // per-clip VQ losses (codebook.py:67-69; quantization.py:57-59,71-72; csrvq.py:42-44): sum over the transmitted streams
+    if (cm_loss) loss_reduce(T.terms, T.S, G, B * s.Tq, s.Tq, cm_loss, st);
+    if (cb_loss) loss_reduce(T.terms, T.S, G, B * s.Tq, s.Tq, cb_loss, st);
+    ESCX_HIP(hipMemcpyAsync(codes_out, T.codes, (size_t)B * Smax * G * s.Tq * sizeof(long long), hipMemcpyDeviceToDevice, st));
+    T.fwd_mark = tp.used;
+    T.valid = true;
+    return launch_ok("train_forward");
+}
+
+namespace {
+
+// backward of one TransformerLayer.  gy: gradient of the layer output (rows of LT.y); returns the gradient of the layer INPUT in *gx
+// (a scratch buffer owned by `sc`, valid until the caller's Scratch dies).
+int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float* gy, int B, int W, float* gflat, Scratch& sc, float** gx, hipStream_t st) {
+    const int H = LT.H, tokens = H * W, M = B * tokens;
+    const int Hp = rup(H, 4), Wp = rup(W, 4), slots = Hp * Wp, Ms = B * slots;
+    float* part = sc.take(DW_PART_FLOATS);
+    float* lnpart = sc.take(LN_PART_FLOATS);
+    float* attpart = sc.take(ATT_PART_FLOATS);
+    float* dcur = sc.take((size_t)M * L.Cp);                 // gradient w.r.t. the current block output
+    float* dx1 = sc.take((size_t)M * L.Cp);
+    float* dxn = sc.take((size_t)std::max(M, Ms) * L.Cp);
+    float* dhpre = sc.take((size_t)M * L.hiddenP);
+    float* dqkv = sc.take((size_t)Ms * L.Nqkv);
+    float* dobuf = sc.take((size_t)Ms * L.Ko);
+    float* dbias = sc.take((size_t)L.nH * 256);
+    float* dprev = sc.take((size_t)M * L.Cp);
+    if (!dprev) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
+    int rc;
+    const float* x_last = LT.blk.back().x2;
+    const float* dlast;                                     // gradient w.r.t. the last block's output
+    if (L.scale == 1) {
+        const int H2 = (H + 1) / 2, M2 = B * H2 * W;
+        const int* map;
+        if ((rc = get_map(h, H, W, -1, &map))) return rc;
+        float* dsub = sc.take((size_t)M2 * 2 * L.Cp);
+        if (!dsub) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
+        if ((rc = dw_launch(h, PlainA{gy, L.CoutP, M2}, PlainA{LT.sub_xn, 2 * L.Cp, M2}, M2, L.CoutP, 2 * L.Cp, G(h, L.sub_w), nullptr, part, st))) return rc;
+        gemm_rows(gy, L.CoutP, M2, L.sub_wT, 2 * L.Cp, L.CoutP, EpiStore{dsub, 2 * L.Cp, nullptr}, st);
+        ln_bwd(2, x_last, dsub, L.sub_g, map, nullptr, dcur, G(h, L.sub_g), G(h, L.sub_b), H2 * W, tokens, 0, M2, L.C, L.Cp, lnpart, st);
+        dlast = dcur;
+    } else if (L.scale == 2) {
+        float* dsub = sc.take((size_t)M * L.Cp);
+        if (!dsub) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
+        SplitGatherA ga{gy, H, W, L.CoutP, M, FastDiv(H * W), FastDiv(W), FastDiv(L.CoutP)};
+        if ((rc = dw_launch(h, ga, PlainA{LT.sub_xn, L.Cp, M}, M, 2 * L.CoutP, L.Cp, G(h, L.sub_w), nullptr, part, st))) return rc;
+        gemm_any(ga, L.sub_wT, M, L.Cp, 2 * L.CoutP, EpiStore{dsub, L.Cp, nullptr}, st, 16);
+        ln_bwd(0, x_last, dsub, L.sub_g, nullptr, nullptr, dcur, G(h, L.sub_g), G(h, L.sub_b), tokens, tokens, tokens, M, L.C, L.Cp, lnpart, st);
+        dlast = dcur;
+    } else {
+        dlast = gy;
+    }
+    const float* dy = dlast;
+    for (int j = (int)L.blocks.size() - 1; j >= 0; --j) {
+        const BlockW& bw = L.blocks[j];
+        const BlockTape& bt = LT.blk[j];
+        const int shift = (j % 2 == 0) ? 0 : 2;
+        const int *map, *inv;
+        if ((rc = get_map(h, H, W, shift, &map))) return rc;
+        if ((rc = get_map(h, H, W, 10 + shift, &inv))) return rc;
+        // ---- MLP: x2 = x1 + W2 gelu(W1 LN2(x1) + b1) + b2 ----
+        PROF("B.dw_fc2", 2.0 * M * L.C * L.hidden, 0,
+             rc = dw_launch(h, PlainA{dy, L.Cp, M}, PlainA{bt.hact, L.hiddenP, M}, M, L.Cp, L.hiddenP, G(h, bw.w2), G(h, bw.b2), part, st));
+        if (rc) return rc;
+        PROF("B.dx_fc2", 2.0 * M * L.C * L.hidden, 0,
+             gemm_rows(dy, L.Cp, M, bw.w2T, L.hiddenP, L.Cp, EpiGeluBwd{dhpre, L.hiddenP, bt.hpre}, st));
+        PROF("B.dw_fc1", 2.0 * M * L.C * L.hidden, 0,
+             rc = dw_launch(h, PlainA{dhpre, L.hiddenP, M}, PlainA{bt.xn2, L.Cp, M}, M, L.hiddenP, L.Cp, G(h, bw.w1), G(h, bw.b1), part, st));
+        if (rc) return rc;
+        PROF("B.dx_fc1", 2.0 * M * L.C * L.hidden, 0,
+             gemm_rows(dhpre, L.hiddenP, M, bw.w1T, L.Cp, L.hiddenP, EpiStore{dxn, L.Cp, nullptr}, st));
+        PROF("B.ln2", 0, 4.0 * M * L.C * 4,
+             ln_bwd(0, bt.x1, dxn, bw.ln2_g, nullptr, dy, dx1, G(h, bw.ln2_g), G(h, bw.ln2_b), tokens, tokens, tokens, M, L.C, L.Cp, lnpart, st));
+        // ---- attention: x1 = x0 + scatter(Wp attn(Wqkv gather(LN1(x0)))) ----
+        SlotGatherA gs{dx1, map, slots, tokens, L.Cp, Ms, FastDiv(slots)};
+        PROF("B.dw_proj", 2.0 * Ms * L.C * L.C, 0,
+             rc = dw_launch(h, gs, PlainA{bt.obuf, L.Ko, Ms}, Ms, L.Cp, L.Ko, G(h, bw.wproj), G(h, bw.bproj), part, st));
+        if (rc) return rc;
+        PROF("B.dx_proj", 2.0 * Ms * L.C * L.C, 0, gemm_any(gs, bw.wprojT, Ms, L.Ko, L.Cp, EpiStore{dobuf, L.Ko, nullptr}, st));
+        int arc = 0;
+        PROF("B.attn_core", 10.0 * Ms * 16 * L.C, 0,
+             arc = attn_bwd(bt.qkv, bw.bias_tab, dobuf, dqkv, dbias, attpart, Ms / 16, L.nH, L.hdp, L.Nqkv, L.Ko, Hp / 4, Wp / 4, shift > 0,
+                            1.0f / std::sqrt((float)L.hd), st));
+        if (arc) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "head_dim %d unsupported by the attention backward kernel", L.hd);
+        if (bw.tab_off >= 0)
+            hipLaunchKernelGGL(bias_table_grad_kernel, dim3(blocks_for(49 * L.nH)), dim3(256), 0, st, dbias, gflat + bw.tab_off, L.nH);
+        PROF("B.dw_qkv", 2.0 * Ms * L.C * 3 * L.C, 0,
+             rc = dw_launch(h, PlainA{dqkv, L.Nqkv, Ms}, PlainA{bt.xn1, L.Cp, Ms}, Ms, L.Nqkv, L.Cp, G(h, bw.wqkv), G(h, bw.bqkv), part, st));
+        if (rc) return rc;
+        PROF("B.dx_qkv", 2.0 * Ms * L.C * 3 * L.C, 0, gemm_rows(dqkv, L.Nqkv, Ms, bw.wqkvT, L.Cp, L.Nqkv, EpiStore{dxn, L.Cp, nullptr}, st));
+        PROF("B.ln1", 0, 4.0 * M * L.C * 4,
+             ln_bwd(1, bt.x0, dxn, bw.ln1_g, inv, dx1, dprev, G(h, bw.ln1_g), G(h, bw.ln1_b), tokens, tokens, slots, M, L.C, L.Cp, lnpart, st));
+        std::swap(dcur, dprev);
+        dy = dcur;
+    }
+    *gx = dcur;
+    return launch_ok("layer_bwd");
+}
+
+// backward of one transmitted quantiser step: gref = gradient of the refined map (post_fuse output).  Accumulates into d_enc (gradient of the
+// encoder map) and, if ddec != nullptr, subtracts from it (pre_fuse: residual = enc - dec).  The +dec path of post_fuse is the caller's.
+int quant_bwd(escx_handle_s* h, TrainTape& T, int sid, const float* gref, float* d_enc, float* ddec, const float* dcm, const float* dcb, Scratch& sc,
+              hipStream_t st) {
+    const escx_config& c = h->cfg;
+    const Quant& q = h->quants[sid];
+    const QuantTape& Q = T.q[sid];
+    const Shapes& s = T.shp;
+    const int B = s.B, W = s.W, Tq = s.Tq, M = B * Tq, Gr = c.group_size;
+    const long long bstride = (long long)c.max_streams * Gr * Tq;
+    const long long* codes = T.codes + (long long)sid * Gr * Tq;
+    float* part = sc.take(DW_PART_FLOATS);
+    float* dzup = sc.take((size_t)M * q.Nz);
+    float* dze = sc.take((size_t)M * q.Nz);
+    float* gq = sc.take((size_t)M * q.Nz);
+    if (!gq) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
+    int rc;
+    ResidualGatherA gfr{gref, nullptr, q.Hq, W, q.Cp, Tq, c.overlap, M, FastDiv(Tq), FastDiv(q.Cp), FastDiv(q.Hq)};        // framed view of the map gradient
+    // up-projection: out_frames = zup . Wup^T   (Wup packed [Kq][Kup])
+    if ((rc = dw_launch(h, gfr, PlainA{Q.zup, q.Nz, M}, M, q.Kq, q.Kup, G(h, q.wup), nullptr, part, st))) return rc;
+    gemm_any(gfr, q.wupT, M, q.Kup, q.Kq, EpiStore{dzup, q.Nz, nullptr}, st, pick_bk(q.Cp));
+    const float scale = 1.0f / ((float)Tq * q.d * Gr);
+    hipLaunchKernelGGL(pvq_train_bwd_kernel, dim3(blocks_for((long long)M * Gr)), dim3(256), 0, st, Q.ze, codes, bstride, q.cbraw, dzup, dcm, dcb, dze, gq,
+                       M, Gr, c.codebook_size, q.d, q.dt, q.Nz, Tq, scale, T.freeze);
+    hipLaunchKernelGGL(codebook_grad_kernel, dim3(blocks_for((long long)Gr * c.codebook_size * 64)), dim3(256), 0, st, codes, bstride, gq, G(h, q.cbraw), M,
+                       Gr, c.codebook_size, q.dt, q.Nz, Tq);
+    // down-projection: ze = residual_frames . Wd^T   (Wd packed [Nz][Kq])
+    ResidualGatherA rfr{Q.enc, Q.dec, q.Hq, W, q.Cp, Tq, c.overlap, M, FastDiv(Tq), FastDiv(q.Cp), FastDiv(q.Hq)};
+    if ((rc = dw_launch(h, PlainA{dze, q.Nz, M}, rfr, M, q.Nz, q.Kq, G(h, q.wd), nullptr, part, st))) return rc;
+    gemm_rows(dze, q.Nz, M, q.wdT, q.Kq, q.Nz, EpiPvqGrad{d_enc, ddec, q.Hq, W, q.Cp, Tq, c.overlap, FastDiv(Tq), FastDiv(q.Cp), FastDiv(q.Hq)}, st);
+    return launch_ok("quant_bwd");
+}
+
+void add_inplace(float* dst, const float* src, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks_for((long long)(n / 4))), dim3(256), 0, st, dst, src, (long long)(n / 4));
+}
+
+}  // namespace
+
+extern "C" int escx_train_backward(escx_handle h, const float* d_wave, const float* d_recon_feat, const float* d_cm, const float* d_cb,
+                                   float* grad_flat, void* stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!grad_flat) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null gradient buffer");
+    TrainTape& T = *tape_of(h);
+    if (!T.valid) ESCX_FAIL(ESCX_ERR_STATE, "escx_train_backward without a preceding escx_train_forward");
+    T.valid = false;                                             // the tape is consumed (scratch overwrites nothing of it, but one backward per forward)
+    const escx_config& c = h->cfg;
+    const Shapes& s = T.shp;
+    hipStream_t st = (hipStream_t)stream;
+    Arena& tp = h->tape;
+    tp.used = T.fwd_mark;
+    const int n = h->n, B = T.B;
+    const int T2 = c.patch_t * s.W, F2 = c.patch_f * s.H0, out_len = c.hop_length * (T2 - 1);
+    ESCX_HIP(hipMemsetAsync(h->garena, 0, h->wts.cap, st));
+    ESCX_HIP(hipMemsetAsync(grad_flat, 0, h->flat_total * sizeof(float), st));
+    Scratch top(&tp);
+    // gradients of the encoder maps (two consumers each: the next encoder layer and a quantiser)
+    std::vector<float*> d_enc(n);
+    for (int i = 0; i < n; ++i) {
+        const size_t nfl = (size_t)B * s.encH[i] * s.W * rup(c.h_dims[i], 16);
+        d_enc[i] = top.take(nfl);
+        if (!d_enc[i]) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
+        ESCX_HIP(hipMemsetAsync(d_enc[i], 0, nfl * sizeof(float), st));
+    }
+    // ---- inverse STFT + de-embedding ----
+    const size_t tok0 = (size_t)B * s.H0 * s.W * h->C0p;
+    float* gtok = top.take(tok0);                                // gradient of decoder.post_nn's output
+    if (!gtok) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
+    {
+        Scratch sc(&tp);
+        const size_t nspec = (size_t)B * T2 * c.in_dim * h->Fp;
+        float* drspec = sc.take(nspec);
+        float* dframes = sc.take((size_t)B * T2 * h->winP);
+        float* ddeemb = sc.take((size_t)B * T2 * F2 * h->C0p);
+        float* part = sc.take(DW_PART_FLOATS);
+        if (!part) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
+        if (d_recon_feat) pad_rows(d_recon_feat, drspec, (long long)B * T2 * c.in_dim, h->F, h->Fp, st);
+        else ESCX_HIP(hipMemsetAsync(drspec, 0, nspec * sizeof(float), st));
+        if (d_wave) {
+            hipLaunchKernelGGL(istft_ola_bwd_kernel, dim3(blocks_for((long long)B * T2 * h->winP)), dim3(256), 0, st, d_wave, h->win2, dframes, B, T2,
+                               h->winP, c.win_length, c.hop_length, h->left, h->n_fft / 2, out_len);
+            PROF("B.istft", 2.0 * B * T2 * c.win_length * 2 * h->F, 0,
+                 gemm_rows(dframes, h->winP, B * T2, h->idft_wT, c.in_dim * h->Fp, h->winP, EpiAccum{drspec, c.in_dim * h->Fp}, st));
+        }
+        // conv3x3 (in: fine map [B][T2][F2][C0p], out: spectrum): dW, db, dX
+        const int Mf = B * T2 * F2;
+        SpecRowsA gsp{drspec, F2, h->Fp, c.in_dim, Mf, FastDiv(F2)};
+        ConvA cfine{T.deemb, T2, F2, h->C0p, 3, 3, Mf};
+        PROF("B.dw_conv3", 2.0 * Mf * 9 * h->C0 * c.in_dim, 0,
+             rc = dw_launch(h, gsp, cfine, Mf, 16, 9 * h->C0p, G(h, h->dc2_w), G(h, h->dc2_b), part, st));
+        if (rc) return rc;
+        PROF("B.dx_conv3", 2.0 * Mf * 9 * h->C0 * c.in_dim, 0,
+             hipLaunchKernelGGL(conv3_dx_kernel, dim3(blocks_for((long long)Mf * (h->C0p / 4))), dim3(256), 0, st, drspec, h->dc2_w, ddeemb, B, T2, F2, h->Fp,
+                                h->C0p, c.in_dim));
+        // conv5x5 + pixel shuffle (in: tokens [B][H0][W][C0p], out: fine map)
+        const int Mt = B * s.H0 * s.W, Q = h->Q;
+        ShuffleA gsh{ddeemb, s.H0, s.W, h->C0p, c.patch_f, c.patch_t, Mt, FastDiv(s.H0 * s.W), FastDiv(s.W), FastDiv(h->C0p)};
+        ConvA ctok{T.post, s.H0, s.W, h->C0p, 5, 5, Mt};
+        PROF("B.dw_conv5", 2.0 * Mt * 25 * h->C0 * h->C0 * Q, 0,
+             rc = dw_launch(h, gsh, ctok, Mt, Q * h->C0p, 25 * h->C0p, G(h, h->dc1_w), G(h, h->dc1_b), part, st));
+        if (rc) return rc;
+        ConvShuffleA gcs{ddeemb, s.H0, s.W, h->C0p, c.patch_f, c.patch_t, Mt, FastDiv(s.H0 * s.W), FastDiv(s.W), FastDiv(h->C0p), FastDiv(Q)};
+        PROF("B.dx_conv5", 2.0 * Mt * 25 * h->C0 * h->C0 * Q, 0,
+             gemm_any(gcs, h->dc1_wT, Mt, h->C0p, 25 * Q * h->C0p, EpiStore{gtok, h->C0p, nullptr}, st, pick_bk(h->C0p)));
+    }
+    // ---- decoder (post_nn, blocks n-2 .. 0) interleaved with the quantisers ----
+    float* gcur = nullptr;
+    Scratch dec_sc(&tp);
+    size_t gdec_floats = tok0;                // running gradient of the decoder map entering the next (earlier) stage
+    for (int li = n; li < 2 * n; ++li) gdec_floats = std::max(gdec_floats, (size_t)B * layer_H(h, s, li) * s.W * h->layers[li].Cp);
+    float* gdec = dec_sc.take(gdec_floats);
+    if (!gdec) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
+    {
+        Scratch sc(&tp);
+        if ((rc = layer_bwd(h, h->layers[2 * n - 1], T.layers[2 * n - 1], gtok, B, s.W, grad_flat, sc, &gcur, st))) return rc;
+        const Layer& L = h->layers[2 * n - 1];
+        ESCX_HIP(hipMemcpyAsync(gdec, gcur, (size_t)B * T.layers[2 * n - 1].H * s.W * L.Cp * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    for (int i = n - 2; i >= 0; --i) {
+        const Layer& L = h->layers[n + i];
+        const LayerTape& LT = T.layers[n + i];
+        const size_t nin = (size_t)B * LT.H * s.W * L.Cp;
+        {
+            Scratch sc(&tp);
+            if ((rc = layer_bwd(h, L, LT, gdec, B, s.W, grad_flat, sc, &gcur, st))) return rc;       // gcur = gradient of the refined map (block input)
+            ESCX_HIP(hipMemcpyAsync(gdec, gcur, nin * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+        // the refined map = dec + residual_q: the +dec path keeps gdec as it is; the quantiser adds to d_enc and subtracts its residual gradient from gdec
+        if (T.q[i + 1].transmit) {           // (every read of the map gradient inside quant_bwd precedes the epilogue that updates it: one buffer serves as both)
+            Scratch sc(&tp);
+            if ((rc = quant_bwd(h, T, i + 1, gdec, d_enc[n - 1 - i], gdec, d_cm, d_cb, sc, st))) return rc;
+        }
+    }
+    {   // stream 0: the refined map is residual_q alone (dec = 0.0)
+        Scratch sc(&tp);
+        if ((rc = quant_bwd(h, T, 0, gdec, d_enc[n - 1], nullptr, d_cm, d_cb, sc, st))) return rc;
+    }
+    // ---- encoder ----
+    for (int i = n - 2; i >= 0; --i) {
+        Scratch sc(&tp);
+        const Layer& L = h->layers[1 + i];
+        if ((rc = layer_bwd(h, L, T.layers[1 + i], d_enc[i + 1], B, s.W, grad_flat, sc, &gcur, st))) return rc;
+        add_inplace(d_enc[i], gcur, (size_t)B * s.encH[i] * s.W * L.Cp, st);
+    }
+    {
+        Scratch sc(&tp);
+        if ((rc = layer_bwd(h, h->layers[0], T.layers[0], d_enc[0], B, s.W, grad_flat, sc, &gcur, st))) return rc;
+        // patch embedding: LN + strided conv as a GEMM over gathered patches (scale.py:42-50); the input is data: no dX
+        float* dpre = sc.take(tok0);
+        float* lnpart = sc.take(LN_PART_FLOATS);
+        float* part = sc.take(DW_PART_FLOATS);
+        if (!part) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
+        const int Mt = B * s.H0 * s.W;
+        ln_bwd(0, T.pe_pre, gcur, h->pe_g, nullptr, nullptr, dpre, G(h, h->pe_g), G(h, h->pe_beta), s.H0 * s.W, s.H0 * s.W, s.H0 * s.W, Mt, h->C0, h->C0p, lnpart, st);
+        PatchA pa{T.spec, s.T, c.in_dim * h->Fp, h->Fp, s.H0, s.W, c.patch_f, c.patch_t, c.in_dim * c.patch_f * c.patch_t, Mt};
+        if ((rc = dw_launch(h, PlainA{dpre, h->C0p, Mt}, pa, Mt, h->C0p, h->Kpe, G(h, h->pe_w), G(h, h->pe_b), part, st))) return rc;
+    }
+    // ---- packed gradients -> flat reference layout ----
+    for (auto& r : h->grad_regions)
+        hipLaunchKernelGGL(scatter_grads_kernel, dim3(blocks_for((long long)r.second)), dim3(256), 0, st, h->garena + r.first, h->gmap + r.first, grad_flat,
+                           (long long)r.second);
+    return launch_ok("train_backward");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// losses (generator_loss.py) with their gradients
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int escx_stft_loss(const float* raw_feat, const float* recon_feat, int B, int64_t per_clip, float* loss, float* d_recon, void* stream) {
+    if (!raw_feat || !recon_feat || !loss || B < 1 || per_clip < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long long per = (long long)per_clip;
+    const int bpc = (int)std::min<long long>(64, (per + 255) / 256);
+    float* part = nullptr;
+    ESCX_HIP(hipMallocAsync((void**)&part, (size_t)B * bpc * sizeof(float), st));
+    hipLaunchKernelGGL(stft_loss_kernel, dim3(bpc, B), dim3(256), 0, st, raw_feat, recon_feat, part, d_recon, per, bpc, 1.0f / (float)per);
+    hipLaunchKernelGGL(row_sum_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, part, bpc, loss, B, 0, 1.0f);
+    ESCX_HIP(hipFreeAsync(part, st));
+    return launch_ok("stft_loss");
+}
+
+namespace {
+const int MEL_WINDOWS[7] = {32, 64, 128, 256, 512, 1024, 2048};
+const int MEL_BINS[7] = {5, 10, 20, 40, 80, 160, 320};
+struct MelScale { int w, hop, F, Fq, n_mels, Mp; float *D, *DT, *fb, *fbT; };
+struct MelState { MelScale sc[7]; float* base = nullptr; int sr = 0; };
+MelState* g_mel[64] = {nullptr};            // per device: DFT / mel filterbank matrices of the 7 resolutions (constants, built once)
+
+int build_mel(int dev, int sr, MelState** out) {
+    if (dev < 0 || dev >= 64) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "device index out of range");
+    if (g_mel[dev] && g_mel[dev]->sr == sr) { *out = g_mel[dev]; return 0; }
+    if (g_mel[dev]) { (void)hipDeviceSynchronize(); (void)hipFree(g_mel[dev]->base); delete g_mel[dev]; g_mel[dev] = nullptr; }
+    MelState* ms = new MelState();
+    std::vector<float> host;
+    std::vector<size_t> offs;
+    auto alloc = [&](size_t n) { size_t o = (host.size() + 63) / 64 * 64; host.resize(o + n, 0.f); return o; };
+    size_t oD[7], oDT[7], ofb[7], ofbT[7];
+    for (int i = 0; i < 7; ++i) {
+        MelScale& m = ms->sc[i];
+        m.w = MEL_WINDOWS[i]; m.hop = m.w / 4; m.F = m.w / 2 + 1; m.Fq = rup(m.F, 16); m.n_mels = MEL_BINS[i]; m.Mp = rup(m.n_mels, 16);
+        oD[i] = alloc((size_t)2 * m.Fq * m.w); oDT[i] = alloc((size_t)m.w * 2 * m.Fq); ofb[i] = alloc((size_t)m.Mp * m.Fq); ofbT[i] = alloc((size_t)m.Fq * m.Mp);
+        for (int f = 0; f < m.F; ++f) for (int k = 0; k < m.w; ++k) {
+            const double win = 0.5 - 0.5 * std::cos(2.0 * M_PI * k / m.w);           // hann, periodic (torch.hann_window default)
+            const double ang = 2.0 * M_PI * (double)((long long)f * k % m.w) / m.w;
+            const float re = (float)(win * std::cos(ang)), im = (float)(-win * std::sin(ang));
+            host[oD[i] + (size_t)f * m.w + k] = re; host[oD[i] + (size_t)(m.Fq + f) * m.w + k] = im;
+            host[oDT[i] + (size_t)k * 2 * m.Fq + f] = re; host[oDT[i] + (size_t)k * 2 * m.Fq + m.Fq + f] = im;
+        }
+        // torchaudio.functional.melscale_fbanks(n_freqs, 0, sr/2, n_mels, sr, norm=None, mel_scale="htk")
+        auto hz2mel = [](double f) { return 2595.0 * std::log10(1.0 + f / 700.0); };
+        auto mel2hz = [](double mm) { return 700.0 * (std::pow(10.0, mm / 2595.0) - 1.0); };
+        const double mlo = hz2mel(0.0), mhi = hz2mel(sr / 2.0);
+        std::vector<double> fp(m.n_mels + 2);
+        for (int j = 0; j < m.n_mels + 2; ++j) fp[j] = mel2hz(mlo + (mhi - mlo) * j / (m.n_mels + 1));
+        for (int f = 0; f < m.F; ++f) {
+            const double fr = (double)(sr / 2) * f / (m.F - 1);
+            for (int j = 0; j < m.n_mels; ++j) {
+                const double down = (fr - fp[j]) / (fp[j + 1] - fp[j]), up = (fp[j + 2] - fr) / (fp[j + 2] - fp[j + 1]);
+                const float v = (float)std::max(0.0, std::min(down, up));
+                host[ofb[i] + (size_t)j * m.Fq + f] = v; host[ofbT[i] + (size_t)f * m.Mp + j] = v;
+            }
+        }
+    }
+    ESCX_HIP(hipMalloc((void**)&ms->base, host.size() * sizeof(float)));
+    ESCX_HIP(hipMemcpy(ms->base, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    for (int i = 0; i < 7; ++i) { ms->sc[i].D = ms->base + oD[i]; ms->sc[i].DT = ms->base + oDT[i]; ms->sc[i].fb = ms->base + ofb[i]; ms->sc[i].fbT = ms->base + ofbT[i]; }
+    ms->sr = sr;
+    g_mel[dev] = ms;
+    *out = ms;
+    return 0;
+}
+}  // namespace
+
+// MelSpectrogramLoss (generator_loss.py:37-74): 7 resolutions, L1 on mel magnitudes + L1 on log10(mel^2); d_recon (B, L) optional.
+// STFTs are windowed-DFT GEMMs (FrameA loader with reflect padding), the mel projection another GEMM; nothing leaves the device.
+extern "C" int escx_mel_loss(const float* raw_wave, const float* recon_wave, int B, int L, int sample_rate, float* loss, float* d_recon, void* stream) {
+    if (!raw_wave || !recon_wave || !loss || B < 1 || sample_rate < 2) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
+    if (L <= 1024) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_samples=%d too short for the 2048-sample mel window (reflect padding)", L);
+    int dev = 0;
+    ESCX_HIP(hipGetDevice(&dev));
+    MelState* msp = nullptr;
+    int rc = build_mel(dev, sample_rate, &msp);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const MelState& ms = *msp;
+    // scratch: sized for the worst scale
+    size_t spec_max = 0, mag_max = 0, mel_max = 0, fr_max = 0;
+    for (int i = 0; i < 7; ++i) {
+        const MelScale& m = ms.sc[i];
+        const size_t rows = (size_t)B * (1 + L / m.hop);
+        spec_max = std::max(spec_max, rows * 2 * m.Fq); mag_max = std::max(mag_max, rows * m.Fq); mel_max = std::max(mel_max, rows * m.Mp);
+        fr_max = std::max(fr_max, rows * m.w);
+    }
+    const int bpc = 64;
+    const size_t total = 2 * spec_max + 3 * mag_max + 3 * mel_max + fr_max + (size_t)B * bpc + 1024;
+    float* buf = nullptr;
+    ESCX_HIP(hipMallocAsync((void**)&buf, total * sizeof(float), st));
+    float* spx = buf; float* spy = spx + spec_max; float* mgx = spy + spec_max; float* mgy = mgx + mag_max; float* dmg = mgy + mag_max;
+    float* mlx = dmg + mag_max; float* mly = mlx + mel_max; float* gml = mly + mel_max; float* dfr = gml + mel_max; float* part = dfr + fr_max;
+    for (int i = 0; i < 7; ++i) {
+        const MelScale& m = ms.sc[i];
+        const int Tm = 1 + L / m.hop; const long long rows = (long long)B * Tm;
+        for (int side = 0; side < 2; ++side) {
+            const float* wv = side ? recon_wave : raw_wave;
+            float* sp = side ? spy : spx; float* mg = side ? mgy : mgx; float* ml = side ? mly : mlx;
+            gemm_frames(wv, B, L, Tm, m.hop, -m.w / 2, m.D, 2 * m.Fq, m.w, sp, st);
+            hipLaunchKernelGGL(complex_mag_kernel, dim3(blocks_for(rows * m.Fq)), dim3(256), 0, st, sp, mg, rows, m.F, m.Fq, m.Fq);
+            gemm_rows(mg, m.Fq, (int)rows, m.fb, m.Mp, m.Fq, EpiStore{ml, m.Mp, nullptr}, st);
+        }
+        hipLaunchKernelGGL(mel_l1_kernel, dim3(bpc, B), dim3(256), 0, st, mlx, mly, part, d_recon ? gml : nullptr, Tm, m.n_mels, m.Mp, bpc,
+                           1.0f / ((float)m.n_mels * Tm), 1e-5f);
+        hipLaunchKernelGGL(row_sum_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, part, bpc, loss, B, i > 0, 1.0f);
+        if (d_recon) {
+            gemm_rows(gml, m.Mp, (int)rows, m.fbT, m.Fq, m.Mp, EpiStore{dmg, m.Fq, nullptr}, st);
+            hipLaunchKernelGGL(complex_mag_bwd_kernel, dim3(blocks_for(rows * m.Fq)), dim3(256), 0, st, spy, dmg, spx, rows, m.F, m.Fq, m.Fq);     // spx is free: reuse as d spec
+            gemm_rows(spx, 2 * m.Fq, (int)rows, m.DT, m.w, 2 * m.Fq, EpiStore{dfr, m.w, nullptr}, st);
+            hipLaunchKernelGGL(frames_bwd_kernel, dim3(blocks_for((long long)B * L)), dim3(256), 0, st, dfr, d_recon, B, L, Tm, m.hop, m.w, m.w, i > 0);
+        }
+    }
+    ESCX_HIP(hipFreeAsync(buf, st));
+    return launch_ok("mel_loss");
+}
+
+extern "C" int escx_scale_rows(const float* x, const float* g, float* out, int rows, int64_t per_row, void* stream) {
+    if (!x || !g || !out || rows < 0 || per_row < 0) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
+    const long long n = (long long)rows * per_row;
+    if (n) hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, g, out, (long long)per_row, n);
+    return launch_ok("scale_rows");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// optimiser on flat buffers (trainer_no_adv.py:116-117: clip_grad_norm_(0.5) + AdamW step)
+// ---------------------------------------------------------------------------------------------------------
+// norm_out_dev[0] = global L2 norm, norm_out_dev[1] = clip coefficient (torch.nn.utils.clip_grad_norm_ semantics); needs 2 + 1024 floats of scratch after it
+extern "C" int escx_grad_norm_clip(const float* grad_flat, int64_t n, float max_norm, float* norm_out_dev, void* stream) {
+    if (!grad_flat || !norm_out_dev || n < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (int)std::min<long long>(1024, (n + 255) / 256);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, st, grad_flat, (long long)n, norm_out_dev + 2);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, st, norm_out_dev + 2, blocks, max_norm, norm_out_dev);
+    return launch_ok("grad_norm_clip");
+}
+// torch.optim.AdamW step t (1-based) on flat parameter / gradient / moment buffers; clip_dev (optional) = output of escx_grad_norm_clip
+extern "C" int escx_adamw_step(float* param_flat, const float* grad_flat, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, const float* clip_dev, void* stream) {
+    if (!param_flat || !grad_flat || !exp_avg || !exp_avg_sq || n < 1 || step < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
+    const float bc1 = 1.0f - std::pow(beta1, (float)step), bc2 = 1.0f - std::pow(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks_for((long long)n)), dim3(256), 0, (hipStream_t)stream, param_flat, grad_flat, exp_avg, exp_avg_sq, (long long)n,
+                       clip_dev, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
+    return launch_ok("adamw_step");
+}

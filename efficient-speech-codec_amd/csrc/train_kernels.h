@@ -224,18 +224,13 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(LdA la, LdB lb, int M, int
     }
     // add the four waves in the order 0,1,2,3 (fixed), wave 0 writes the slice's partial tile
     __syncthreads();
-    float* red = lds;                                                // [3 waves][10 tiles][64 lanes][4]
+    float* red = lds;                                                // [3 waves][9 tiles][64 lanes][4] = 27 KB of the 48 KB staging area
     if (wave > 0) {
-        float* r = red + (size_t)(wave - 1) * 10 * 256;
+        float* r = red + (size_t)(wave - 1) * 9 * 256;
 #pragma unroll
         for (int a = 0; a < DW_T; ++a) {
 #pragma unroll
             for (int b = 0; b < DW_T; ++b) st4(r + ((a * DW_T + b) * 64 + lane) * 4, acc[a][b]);
-        }
-        if (BIAS) { f32x4 t = accb[0]; t[1] = accb[1][0]; t[2] = accb[2][0]; (void)t; }
-        if (BIAS) {
-#pragma unroll
-            for (int a = 0; a < DW_T; ++a) r[(9 * 64 + lane) * 4 + a] = 0.f;
         }
     }
     // bias accumulators travel in a separate small region to keep the indexing simple
@@ -248,7 +243,7 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(LdA la, LdB lb, int M, int
     if (wave == 0) {
 #pragma unroll
         for (int w = 0; w < 3; ++w) {
-            const float* r = red + (size_t)w * 10 * 256;
+            const float* r = red + (size_t)w * 9 * 256;
 #pragma unroll
             for (int a = 0; a < DW_T; ++a) {
 #pragma unroll
@@ -296,8 +291,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                                                      float* __restrict__ part, int rows_per_clip, int src_rows_per_clip, int dy_rows_per_clip,
                                                      int total_rows, int C, int Cp, float eps) {
     constexpr int MAXV = 6;                       // float4 per thread per segment: Cp <= 384
-    __shared__ float red[16][2 * 2 * 96 * 4 / 16 * 16 / 16];     // placeholder size, replaced below
-    (void)red;
     extern __shared__ float dyn[];                // [16 groups][2][SEGS*Cp]
     const int sub = threadIdx.x & 15, gl = threadIdx.x >> 4;
     const int grp = (blockIdx.x * 256 + threadIdx.x) >> 4;
@@ -348,21 +341,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int o = 8; o >= 1; o >>= 1) var += __shfl_xor(var, o, 16);
         const float rstd = 1.0f / sqrtf(var / (float)(SEGS * C) + eps);
-        // c1 = mean(dy*gamma), c2 = mean(dy*gamma*xhat)
+        // c1 = mean(dy*gamma), c2 = mean(dy*gamma*xhat); dgamma += dy*xhat, dbeta += dy
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int s = 0; s < SEGS; ++s) {
-            int q = 0;
-            for (int v = sub; v < V; v += 16, ++q) {
-                const f32x4 xv = sp[s] ? ld4(sp[s] + 4 * v) : zero4();
-                const f32x4 g = ld4(gp + s * Cp + 4 * v), gm = ld4(gamma + s * Cp + 4 * v);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * v + e < C) {
-                        const float xh = (xv[e] - mean) * rstd, t = g[e] * gm[e];
-                        s1 += t; s2 += t * xh;
-                        ag[s][q][e] += g[e] * xh; ab[s][q][e] += g[e];
-                    }
+            for (int q = 0; q < MAXV; ++q) {
+                const int v = sub + 16 * q;
+                if (v < V) {
+                    const f32x4 xv = sp[s] ? ld4(sp[s] + 4 * v) : zero4();
+                    const f32x4 g = ld4(gp + s * Cp + 4 * v), gm = ld4(gamma + s * Cp + 4 * v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * v + e < C) {
+                            const float xh = (xv[e] - mean) * rstd, t = g[e] * gm[e];
+                            s1 += t; s2 += t * xh;
+                            ag[s][q][e] += g[e] * xh; ab[s][q][e] += g[e];
+                        }
+                }
             }
         }
 #pragma unroll
@@ -388,10 +384,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     const int RW = SEGS * Cp;
 #pragma unroll
     for (int s = 0; s < SEGS; ++s) {
-        int q = 0;
-        for (int v = sub; v < V; v += 16, ++q) {
-            st4(dyn + ((size_t)gl * 2 + 0) * RW + s * Cp + 4 * v, ag[s][q]);
-            st4(dyn + ((size_t)gl * 2 + 1) * RW + s * Cp + 4 * v, ab[s][q]);
+#pragma unroll
+        for (int q = 0; q < MAXV; ++q) {
+            const int v = sub + 16 * q;
+            if (v < V) {
+                st4(dyn + ((size_t)gl * 2 + 0) * RW + s * Cp + 4 * v, ag[s][q]);
+                st4(dyn + ((size_t)gl * 2 + 1) * RW + s * Cp + 4 * v, ab[s][q]);
+            }
         }
     }
     __syncthreads();
@@ -488,9 +487,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         for (int r = 0; r < 4; ++r) { tp[wave][0][i][4 * g + r] = p[r]; tp[wave][1][i][4 * g + r] = ds[r]; }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        f32x4 pt, dst;
+        f32x4 pt, dsT;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { pt[r] = tp[wave][0][4 * g + r][i]; dst[r] = tp[wave][1][4 * g + r][i]; }
+        for (int r = 0; r < 4; ++r) { pt[r] = tp[wave][0][4 * g + r][i]; dsT[r] = tp[wave][1][4 * g + r][i]; }
         __builtin_amdgcn_wave_barrier();
         // dV[j][d] = sum_i P[i][j] dO[i][d] ; dK[j][d] = sum_i dS[i][j] Q[i][d]   (lane (j, g): rows of key j)
         float* dkrow = dqkv + ((size_t)win * 16 + i) * ldq + kOff + h * HDP;
@@ -505,7 +504,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 const float dd = (d < HDP) ? dobase[(size_t)(4 * g + r) * ldo + d] : 0.f;
                 const float qq = (d < HDP) ? base[(size_t)(4 * g + r) * ldq + d] : 0.f;
                 ov = __builtin_amdgcn_mfma_f32_16x16x4f32(dd, pt[r], ov, 0, 0, 0);
-                ok = __builtin_amdgcn_mfma_f32_16x16x4f32(qq, dst[r], ok, 0, 0, 0);
+                ok = __builtin_amdgcn_mfma_f32_16x16x4f32(qq, dsT[r], ok, 0, 0, 0);
             }
             if (t * 16 + 4 * g < HDP) { st4(dvrow + t * 16 + 4 * g, ov); st4(dkrow + t * 16 + 4 * g, ok); }
         }
@@ -624,18 +623,26 @@ __global__ void pvq_train_bwd_kernel(const float* __restrict__ ze, const long lo
     if (g == 0) for (int c = G * dt; c < ldz; ++c) dze[(size_t)m * ldz + c] = 0.f;
 }
 
-// embedding gradient without atomics: one thread per (group, code, dim) walks the vectors in index order and adds those that chose the code
-__global__ void codebook_grad_kernel(const long long* __restrict__ codes, long long bstride, const float* __restrict__ gq, float* __restrict__ dcb,
-                                     int M, int G, int Ksz, int dt, int ldz, int Tq) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= G * Ksz * dt) return;
-    const int j = e % dt; const int gk = e / dt; const int k = gk % Ksz, g = gk / Ksz;
-    float s = 0.f;
-    for (int m = 0; m < M; ++m) {
-        const int b = m / Tq, t = m - b * Tq;
-        if (codes[(size_t)b * bstride + (size_t)g * Tq + t] == k) s += gq[(size_t)m * ldz + g * dt + j];
+// embedding gradient without atomics: one wave per (group, code) scans the vectors 64 at a time and adds the rows of those that chose the
+// code in increasing vector order (lane j carries dimension j)
+__global__ __launch_bounds__(256) void codebook_grad_kernel(const long long* __restrict__ codes, long long bstride, const float* __restrict__ gq,
+                                                            float* __restrict__ dcb, int M, int G, int Ksz, int dt, int ldz, int Tq) {
+    const int wv = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wv >= G * Ksz) return;
+    const int g = wv / Ksz, k = wv - g * Ksz;
+    float acc = 0.f;
+    for (int m0 = 0; m0 < M; m0 += 64) {
+        const int m = m0 + lane;
+        bool hit = false;
+        if (m < M) { const int b = m / Tq, t = m - b * Tq; hit = codes[(size_t)b * bstride + (size_t)g * Tq + t] == k; }
+        unsigned long long mask = __ballot(hit);
+        while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            if (lane < dt) acc += gq[(size_t)(m0 + l) * ldz + g * dt + lane];
+        }
     }
-    dcb[e] = s;
+    if (lane < dt) dcb[((size_t)g * Ksz + k) * dt + lane] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -710,8 +717,9 @@ __global__ __launch_bounds__(256) void stft_loss_kernel(const float* __restrict_
     if (threadIdx.x == 0) part[(size_t)b * blocks_per_clip + blockIdx.x] = red[0] * inv_n;
 }
 // out[b] (+)= sum_k part[b][k], fixed order
-__global__ void row_sum_kernel(const float* __restrict__ part, int n, float* __restrict__ out, int accumulate, float scale) {
+__global__ void row_sum_kernel(const float* __restrict__ part, int n, float* __restrict__ out, int rows, int accumulate, float scale) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= rows) return;
     float s = 0.f;
     for (int k = 0; k < n; ++k) s += part[(size_t)b * n + k];
     out[b] = (accumulate ? out[b] : 0.f) + s * scale;

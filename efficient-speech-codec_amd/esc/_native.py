@@ -55,6 +55,20 @@ SIGNATURES = {
     "escx_codes_unpack10": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "escx_codes_narrow": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "escx_codes_widen": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "escx_flat_param_count": (c_int, [c_void_p]),
+    "escx_flat_param_key": (c_char_p, [c_void_p, c_int]),
+    "escx_flat_param_offset": (c_int64, [c_void_p, c_int]),
+    "escx_flat_param_numel": (c_int64, [c_void_p, c_int]),
+    "escx_flat_param_total": (c_int64, [c_void_p]),
+    "escx_load_flat_params": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "escx_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "escx_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "escx_train_tape_bytes": (c_int64, [c_void_p]),
+    "escx_stft_loss": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    "escx_mel_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "escx_scale_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "escx_grad_norm_clip": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p]),
+    "escx_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "escx_set_rccl_library": (c_int, [c_char_p]),
     "escx_allgather_codes": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
 }

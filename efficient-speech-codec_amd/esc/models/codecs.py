@@ -159,6 +159,8 @@ class ESC(nn.Module):
             _attach(self, key, _init_tensor(key, shape), is_buf)
 
         self._handles: Dict[int, ctypes.c_void_p] = {}
+        self._flat: Dict[int, dict] = {}                 # per device: flat fp32 parameter buffer the nn.Parameters are views of
+        self._packed_version: Dict[int, int] = {}        # parameter fingerprint the packed device layouts were derived from
         self._dirty = True
 
     # ---- weight management ------------------------------------------------------------------
@@ -179,8 +181,9 @@ class ESC(nn.Module):
         return super().load_state_dict(sd, strict=strict, **kw)
 
     def refresh_weights(self):
-        """Call after mutating parameters in place (optimizer steps etc.); `.to()`/`load_state_dict` do it for you."""
-        self._dirty = True
+        """Force a re-pack (in-place updates are detected through autograd's version counters; this is for exotic writes, e.g. through
+        raw pointers, that bypass them)."""
+        self._packed_version = {}
 
     def _c_config(self) -> _native.EscxConfig:
         c = self.cfg
@@ -200,13 +203,45 @@ class ESC(nn.Module):
         cc.l2norm = int(c["l2norm"])
         return cc
 
-    def _handle(self, device: torch.device):
+    # ---- flat parameter buffer (training step) ------------------------------------------------
+    def _param_version(self) -> int:
+        """Changes whenever a parameter is modified in place (optimizer.step, param.data.copy_, ...): autograd's version counters."""
+        return sum(p._version for p in self.parameters())
+
+    def _named_params(self) -> Dict[str, nn.Parameter]:
+        return dict(self.named_parameters())
+
+    def _ensure_flat(self, device: torch.device, lib, hd) -> torch.Tensor:
+        """One contiguous fp32 device buffer holding every trainable parameter in the library's canonical order; the nn.Parameters
+        become views into it (so optimizer steps update it in place and the library re-derives its packed layouts on the device
+        without any host copy).  Re-established lazily after .to() / external re-assignment of a parameter's storage."""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        st = self._flat.get(idx)
+        params = self._named_params()
+        if st is None:
+            n = lib.escx_flat_param_count(hd)
+            layout = [(lib.escx_flat_param_key(hd, i).decode(), int(lib.escx_flat_param_offset(hd, i)), int(lib.escx_flat_param_numel(hd, i)))
+                      for i in range(n)]
+            flat = torch.zeros(int(lib.escx_flat_param_total(hd)), dtype=torch.float32, device=device)
+            st = {"flat": flat, "layout": layout}
+            self._flat[idx] = st
+        flat = st["flat"]
+        base = flat.data_ptr()
+        with torch.no_grad():
+            for key, off, n in st["layout"]:
+                p = params[key]
+                if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+                    flat[off:off + n].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
+                    p.data = flat[off:off + n].view(p.shape)
+        return flat
+
+    def _handle(self, device: torch.device, for_training: bool = False):
         lib = _native.load()
         idx = device.index if device.index is not None else torch.cuda.current_device()
         if self._dirty:
             for hd in self._handles.values():
                 lib.escx_destroy(hd)
-            self._handles = {}
+            self._handles, self._flat, self._packed_version = {}, {}, {}
             self._dirty = False
         if idx not in self._handles:
             hd = ctypes.c_void_p()
@@ -224,7 +259,22 @@ class ESC(nn.Module):
                 lib.escx_destroy(hd)
                 raise
             self._handles[idx] = hd
-        return lib, self._handles[idx]
+            self._packed_version[idx] = self._param_version()
+        hd = self._handles[idx]
+        if not for_training and self._packed_version.get(idx) != self._param_version():
+            # parameters were updated in place since the last pack (optimizer steps, manual edits): rebuild every derived layout,
+            # including the host-folded ones of the inference path, from the current values
+            flat = self._ensure_flat(device, lib, hd)
+            with torch.cuda.device(device):
+                _native.check(lib.escx_load_flat_params(hd, ctypes.c_void_p(flat.data_ptr()), 1, self._stream(device)))
+            self._packed_version[idx] = self._param_version()
+        return lib, hd
+
+    def __getstate__(self):
+        """copy.deepcopy / torch.save of the whole module: native handles are per-process device resources and are rebuilt lazily."""
+        state = self.__dict__.copy()
+        state["_handles"], state["_flat"], state["_packed_version"], state["_dirty"] = {}, {}, {}, True
+        return state
 
     def __del__(self):
         try:
@@ -309,8 +359,7 @@ class ESC(nn.Module):
         if not self.training and freeze_codebook:
             raise ValueError("``freeze_vq`` must be set False during inference")       # quantization.py:43-44
         if self.training:
-            raise NotImplementedError("training-mode forward (STE, codebook losses, backward) is outside the accelerated "
-                                      "inference path; call model.eval() first")
+            return self._forward_train(x, x_feat, int(num_streams), bool(freeze_codebook))
         if x_feat is not None:
             return self._forward_from_feat(x, x_feat, int(num_streams))
         if x.dim() != 2:
@@ -363,12 +412,79 @@ class ESC(nn.Module):
         return {"cm_loss": cm, "cb_loss": cm.clone(), "raw_audio": x, "recon_audio": recon,
                 "raw_feat": x_feat.permute(0, 3, 1, 2), "recon_feat": recon_feat.permute(0, 2, 3, 1), "codes": codes}
 
+    def _forward_train(self, x, x_feat, S, freeze):
+        """Training-mode forward (codecs.py:30-46 with csrvq.py:97-129, codebook.py:57-75, quantization.py:53-64): differentiable w.r.t.
+        every parameter through `_TrainStep`; `codes` holds all max_streams streams (every quantiser runs in training mode)."""
+        if x_feat is not None:
+            raise NotImplementedError("training with a precomputed spectrum (x_feat) is not implemented; pass the waveform")
+        if x.dim() != 2:
+            raise ValueError("x must have shape (Bs, L)")
+        self._need_gpu(x, "x")
+        params = tuple(self.parameters())
+        recon, recon_fm, raw_fm, cm, cb, codes = _TrainStep.apply(self, x.to(torch.float32).contiguous(), S, freeze, *params)
+        return {"cm_loss": cm, "cb_loss": cb, "raw_audio": x, "recon_audio": recon,
+                "raw_feat": raw_fm.permute(0, 2, 3, 1), "recon_feat": recon_fm.permute(0, 2, 3, 1), "codes": codes}
+
     def forward(self, x, x_feat, num_streams, freeze_codebook=False):
-        """Eval-mode forward of the reference (codecs.py:48-66): dict with cm_loss, cb_loss, raw_audio, recon_audio,
-        raw_feat (Bs,2,F,T), recon_feat (Bs,2,F,T'), codes."""
+        """codecs.py:48-66: dict with cm_loss, cb_loss, raw_audio, recon_audio, raw_feat (Bs,2,F,T), recon_feat (Bs,2,F,T'), codes.
+        Eval mode: inference path, no autograd graph.  Training mode: differentiable (HIP forward + hand-written HIP backward)."""
         num_streams = self.max_streams if freeze_codebook else num_streams
+        if self.training:
+            return self.forward_one_step(x, x_feat, num_streams, freeze_codebook)
         with torch.no_grad():
             return self.forward_one_step(x, x_feat, num_streams, freeze_codebook)
+
+
+class _TrainStep(torch.autograd.Function):
+    """One training-mode pass through libescx: forward keeps its activations on the handle's tape, backward consumes them and returns
+    d loss / d parameter for every nn.Parameter (views of one flat gradient buffer, the library's canonical order)."""
+
+    @staticmethod
+    def forward(ctx, model, x, S, freeze, *params):
+        dev = x.device
+        lib, hd = model._handle(dev, for_training=True)
+        flat = model._ensure_flat(dev, lib, hd)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        model._packed_version[idx] = None               # the training refresh skips the host-folded inference layouts
+        c = model.cfg
+        B, L = x.shape
+        _, W = model.latent_shape(L)
+        if W % c["overlap"] != 0:
+            raise AssertionError("Time dimension must be multiple of overlap")       # quantization.py:407
+        pt = c["patch_size"][1]
+        T = 1 + L // model.hop_length
+        codes = torch.empty((B, c["max_streams"], c["group_size"], W // c["overlap"]), dtype=torch.int64, device=dev)
+        recon = torch.empty((B, model.hop_length * (pt * W - 1)), dtype=torch.float32, device=dev)
+        raw_fm = torch.empty((B, T, model.in_dim, model.in_freq), dtype=torch.float32, device=dev)
+        recon_fm = torch.empty((B, pt * W, model.in_dim, model.in_freq), dtype=torch.float32, device=dev)
+        cm = torch.empty((B,), dtype=torch.float32, device=dev)
+        cb = torch.empty((B,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _native.check(lib.escx_train_forward(hd, ctypes.c_void_p(flat.data_ptr()), ctypes.c_void_p(x.data_ptr()), B, L, int(S), int(bool(freeze)),
+                                                 ctypes.c_void_p(codes.data_ptr()), ctypes.c_void_p(recon.data_ptr()), ctypes.c_void_p(raw_fm.data_ptr()),
+                                                 ctypes.c_void_p(recon_fm.data_ptr()), ctypes.c_void_p(cm.data_ptr()), ctypes.c_void_p(cb.data_ptr()),
+                                                 model._stream(dev)))
+        ctx.model, ctx.dev, ctx.idx = model, dev, idx
+        ctx.mark_non_differentiable(raw_fm, codes)
+        return recon, recon_fm, raw_fm, cm, cb, codes
+
+    @staticmethod
+    def backward(ctx, d_recon, d_recon_fm, _d_raw, d_cm, d_cb, _d_codes):
+        model, dev = ctx.model, ctx.dev
+        lib, hd = model._handle(dev, for_training=True)
+        st = model._flat[ctx.idx]
+        gflat = torch.empty_like(st["flat"])
+
+        def prep(t):
+            return None if t is None else t.to(torch.float32).contiguous()
+        d_recon, d_recon_fm, d_cm, d_cb = prep(d_recon), prep(d_recon_fm), prep(d_cm), prep(d_cb)
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        with torch.cuda.device(dev):
+            _native.check(lib.escx_train_backward(hd, p(d_recon), p(d_recon_fm), p(d_cm), p(d_cb), ctypes.c_void_p(gflat.data_ptr()), model._stream(dev)))
+        params = model._named_params()
+        by_id = {id(params[k]): gflat[off:off + n].view(params[k].shape) for k, off, n in st["layout"]}
+        grads = tuple(by_id.get(id(q)) for q in model.parameters())
+        return (None, None, None, None) + grads
 
 
 model_dict = {"csvq+swinT": ESC}

@@ -1,0 +1,109 @@
+"""Generator losses of the reference (`/root/reference/esc/modules/loss/generator_loss.py:12-74`) on the MI355X.
+
+Same classes, constructor arguments and call signatures; the arithmetic (power-law compression, the seven STFTs of the mel loss as
+windowed-DFT GEMMs, HTK filterbanks, L1 / log-L1 terms AND their gradients) runs in libescx.so.  Each forward evaluates the per-clip
+loss together with d loss_b / d reconstruction; backward only scales that by the incoming per-clip gradient.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from .. import _native
+
+MEL_WINDOWS = [32, 64, 128, 256, 512, 1024, 2048]
+MEL_BINS = [5, 10, 20, 40, 80, 160, 320]
+SR = 16000
+POWER = 0.3
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _scale_rows(unit: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    lib = _native.load()
+    g = g.to(torch.float32).contiguous()
+    out = torch.empty_like(unit)
+    B = unit.shape[0]
+    with torch.cuda.device(unit.device):
+        _native.check(lib.escx_scale_rows(_ptr(unit), _ptr(g), _ptr(out), B, unit.numel() // max(B, 1), _stream(unit.device)))
+    return out
+
+
+class _StftLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, recon):
+        if not recon.is_cuda:
+            raise RuntimeError("esc.modules losses run on a HIP device only (no CPU implementation in this package)")
+        lib = _native.load()
+        raw_c, rec_c = raw.detach().to(torch.float32).contiguous(), recon.detach().to(torch.float32).contiguous()
+        if raw_c.shape != rec_c.shape:
+            raise RuntimeError(f"The size of raw_feat {tuple(raw_c.shape)} must match recon_feat {tuple(rec_c.shape)}")
+        B = rec_c.shape[0]
+        loss = torch.empty(B, dtype=torch.float32, device=rec_c.device)
+        need = ctx.needs_input_grad[1]
+        unit = torch.empty_like(rec_c) if need else None
+        with torch.cuda.device(rec_c.device):
+            _native.check(lib.escx_stft_loss(_ptr(raw_c), _ptr(rec_c), B, rec_c.numel() // B, _ptr(loss), _ptr(unit), _stream(rec_c.device)))
+        ctx.unit = unit
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, (_scale_rows(ctx.unit, g) if ctx.unit is not None else None)
+
+
+class ComplexSTFTLoss(nn.Module):
+    """L2 loss on power-law compressed complex STFTs (generator_loss.py:12-35).  (B,2,F,T) x (B,2,F,T) -> (B,)."""
+
+    def __init__(self, weight=1.0, power_law=True):
+        super().__init__()
+        if not power_law:
+            raise NotImplementedError("only the power-law compressed form the trainers use is implemented")
+        self.power_law, self.weight = power_law, weight
+
+    def forward(self, raw_feat, recon_feat):
+        return self.weight * _StftLossFn.apply(raw_feat, recon_feat)
+
+
+class _MelLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, recon, sr):
+        if not recon.is_cuda:
+            raise RuntimeError("esc.modules losses run on a HIP device only (no CPU implementation in this package)")
+        lib = _native.load()
+        raw_c, rec_c = raw.detach().to(torch.float32).contiguous(), recon.detach().to(torch.float32).contiguous()
+        if raw_c.shape != rec_c.shape or rec_c.dim() != 2:
+            raise RuntimeError(f"raw_audio {tuple(raw_c.shape)} and recon_audio {tuple(rec_c.shape)} must both be (B, L)")
+        B, L = rec_c.shape
+        loss = torch.empty(B, dtype=torch.float32, device=rec_c.device)
+        need = ctx.needs_input_grad[1]
+        unit = torch.empty_like(rec_c) if need else None
+        with torch.cuda.device(rec_c.device):
+            _native.check(lib.escx_mel_loss(_ptr(raw_c), _ptr(rec_c), B, L, int(sr), _ptr(loss), _ptr(unit), _stream(rec_c.device)))
+        ctx.unit = unit
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, (_scale_rows(ctx.unit, g) if ctx.unit is not None else None), None
+
+
+class MelSpectrogramLoss(nn.Module):
+    """Multi-resolution L1 mel + log-mel loss (generator_loss.py:37-74).  (B,L) x (B,L) -> (B,)."""
+
+    def __init__(self, weight=1.0, win_lengths=MEL_WINDOWS, n_mels=MEL_BINS, clamp_eps=1e-5):
+        super().__init__()
+        if list(win_lengths) != MEL_WINDOWS or list(n_mels) != MEL_BINS or clamp_eps != 1e-5:
+            raise NotImplementedError("the HIP mel loss implements the reference's fixed resolutions (generator_loss.py:6-9)")
+        self.n_mels, self.clamp_eps, self.weight = n_mels, clamp_eps, weight
+
+    def forward(self, raw_audio, recon_audio):
+        return self.weight * _MelLossFn.apply(raw_audio, recon_audio, SR)

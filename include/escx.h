@@ -153,6 +153,46 @@ int escx_codes_unpack10(const uint8_t* in_dev, int64_t* codes_dev, int64_t n, vo
 int escx_codes_narrow(const int64_t* codes_dev, int16_t* out_dev, int64_t n, void* stream);
 int escx_codes_widen(const int16_t* in_dev, int64_t* codes_dev, int64_t n, void* stream);
 
+/* ---- training step (BASELINE configs[4]) --------------------------------------------------------------
+ * Reference: scripts/trainer_no_adv.py:95-118 (step), esc/models/codecs.py:30-66 + esc/models/csrvq.py:23-48,97-129 (training-mode
+ * forward), esc/modules/vq/codebook.py:57-75 (straight-through estimator, commitment / codebook losses),
+ * esc/modules/vq/quantization.py:53-64 (freeze_vq), esc/modules/loss/generator_loss.py:12-74 (losses).  fp32, like the reference.
+ * Trainable parameters live in ONE flat fp32 device buffer owned by the caller, in the order escx_flat_param_*() reports (the keys
+ * escx_finalize_params requires, reference shapes, C-contiguous); gradients are returned in a buffer of the same layout. */
+int escx_flat_param_count(escx_handle h);
+const char* escx_flat_param_key(escx_handle h, int i);
+int64_t escx_flat_param_offset(escx_handle h, int i);        /* in floats */
+int64_t escx_flat_param_numel(escx_handle h, int i);
+int64_t escx_flat_param_total(escx_handle h);
+/* Re-derives every packed layout from the flat buffer.  full == 0: on the device (gather + codebook normalisation; asynchronous),
+ * enough for the training step; full != 0: additionally rebuilds the host-folded layouts of the inference path (synchronous). */
+int escx_load_flat_params(escx_handle h, const float* flat_params_dev, int full, void* stream);
+/* ESC.forward in training mode.  flat_params_dev may be NULL (keep the currently packed weights).  codes_dev: (B, max_streams, G, T)
+ * int64 - every stream is quantised in training mode (csrvq.py:104-113); wave_out (B, hop*(2W-1)); raw_feat (B,T,2,F) and recon_feat
+ * (B,2W,2,F) frame-major, optional; cm_loss / cb_loss (B,), optional.  Activations stay on the handle's tape until the backward. */
+int escx_train_forward(escx_handle h, const float* flat_params_dev, const float* wave_dev, int batch, int n_samples, int num_streams,
+                       int freeze_codebook, int64_t* codes_dev, float* wave_out_dev, float* raw_feat_dev, float* recon_feat_dev,
+                       float* cm_loss_dev, float* cb_loss_dev, void* stream);
+/* Backward of the last escx_train_forward.  Upstream gradients (any may be NULL = zero): d_wave (B, out_len), d_recon_feat (B,2W,2,F),
+ * d_cm_loss / d_cb_loss (B,).  grad_flat_dev receives d loss / d parameter in the flat layout (overwritten, not accumulated). */
+int escx_train_backward(escx_handle h, const float* d_wave_dev, const float* d_recon_feat_dev, const float* d_cm_loss_dev,
+                        const float* d_cb_loss_dev, float* grad_flat_dev, void* stream);
+int64_t escx_train_tape_bytes(escx_handle h);
+/* ComplexSTFTLoss (generator_loss.py:12-35): per-clip loss (B,) = mean over the clip's `per_clip` spectrum values (any layout, the
+ * same for both inputs) of (pl(raw) - pl(recon))^2, pl = power-law compression; optionally d loss_b / d recon_feat. */
+int escx_stft_loss(const float* raw_feat_dev, const float* recon_feat_dev, int batch, int64_t per_clip, float* loss_dev,
+                   float* d_recon_feat_dev, void* stream);
+/* MelSpectrogramLoss (generator_loss.py:37-74; 7 resolutions, windows 32..2048, hop = window/4, HTK mel filterbanks of 5..320 bins,
+ * L1 on the mel magnitudes + L1 on log10(clamp(mel)^2)): per-clip loss (B,) and, optionally, d loss_b / d recon_wave (B,L).
+ * Runs on the current device; the DFT / filterbank matrices are built once per device. */
+int escx_mel_loss(const float* raw_wave_dev, const float* recon_wave_dev, int batch, int n_samples, int sample_rate, float* loss_dev,
+                  float* d_recon_wave_dev, void* stream);
+int escx_scale_rows(const float* x_dev, const float* g_dev, float* out_dev, int rows, int64_t per_row, void* stream);   /* out[r][:] = x[r][:] * g[r] */
+/* clip_grad_norm_ + AdamW on flat buffers (trainer_no_adv.py:116-117).  norm_out_dev: 2 + 1024 floats ([0] = norm, [1] = clip coefficient). */
+int escx_grad_norm_clip(const float* grad_flat_dev, int64_t n, float max_norm, float* norm_out_dev, void* stream);
+int escx_adamw_step(float* param_flat_dev, const float* grad_flat_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, int step,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, const float* clip_dev, void* stream);
+
 /* ---- multi-GPU: the one exchange step of the sharded path (BASELINE configs[3]; SURVEY.md 8(b),(e)) ------------- */
 /* The reference has no inference-time collective (clips are independent end to end); batch shards exchange only the emitted codes.
  * codes_local_dev: n_local_codes int64 values of this rank (e.g. 36*S*G*T); codes_all_dev: world_size * n_local_codes, rank order.

@@ -291,10 +291,11 @@ class Trace:
 
 
 class EscOracle:
-    def __init__(self, cfg: dict, state_dict: Dict[str, Tensor]):
+    def __init__(self, cfg: dict, state_dict: Dict[str, Tensor], keep_graph: bool = False):
         self.cfg = full_config(cfg)
-        self.sd = {k: (v.detach().to(torch.float32) if v.is_floating_point() else v.detach())
-                   for k, v in state_dict.items()}
+        # keep_graph: the tensors are used as they are (leaf tensors with requires_grad for the training-step restatement)
+        self.sd = dict(state_dict) if keep_graph else \
+            {k: (v.detach().to(torch.float32) if v.is_floating_point() else v.detach()) for k, v in state_dict.items()}
         c = self.cfg
         self.S = c["max_streams"]
         self.H0 = c["in_freq"] // c["patch_size"][0]
@@ -429,3 +430,113 @@ class EscOracle:
         return {"cm_loss": cm, "cb_loss": cm.clone(), "raw_audio": x,
                 "recon_audio": audio_reconstruct(recon_feat, c, self.sd.get("ift.window")),
                 "raw_feat": feat, "recon_feat": recon_feat, "codes": torch.stack(codes, dim=1)}
+
+
+    # -- training mode: codecs.py:30-66, csrvq.py:23-48,97-129, quantization.py:31-72, codebook.py:57-75 (differentiable: plain autograd)
+    def forward_train(self, x: Tensor, num_streams: int, freeze_codebook: bool = False) -> dict:
+        c = self.cfg
+        S = self.S if freeze_codebook else num_streams                      # codecs.py:65
+        feat = spec_transform(x, c, self.sd.get("ft.window"))
+        enc_hs, (H, W) = self.encoder(feat)
+
+        def csrvq(enc, dec, sid, transmit):                                 # csrvq.py:23-48 with self.training == True
+            resid = enc - dec
+            zq, code, cb, cm = pvq_forward_train(resid, groups=c["group_size"], l2norm=c["l2norm"], freeze_vq=freeze_codebook, **self._q(sid))
+            if not transmit:                                                # masking non-transmitted streams (:42-44)
+                cm, cb = cm * 0.0, cb * 0.0
+                zq = zq * 0.0
+            return zq + dec, cm, cb, code
+
+        dec, cm_loss, cb_loss, code = csrvq(enc_hs[-1], 0.0, 0, True)       # csrvq.py:104-105
+        codes = [code]
+        for i in range(len(self.dec_dims) - 1):
+            dec, cm_i, cb_i, code_i = csrvq(enc_hs[-1 - i], dec, i + 1, i < S - 1)
+            cm_loss, cb_loss = cm_loss + cm_i, cb_loss + cb_i
+            codes.append(code_i)
+            dec, H, W = self._dec_block(i, dec, H, W)
+        dec, H, W = transformer_layer(dec, H, W, self.sd, "decoder.post_nn.", self.dec_heads[-1], c["swin_depth"], c["window_size"], None)
+        recon_feat = patch_deembed(dec, H, self.sd, "decoder.patch_deembed.", c["patch_size"])
+        return {"cm_loss": cm_loss, "cb_loss": cb_loss, "raw_audio": x,
+                "recon_audio": audio_reconstruct(recon_feat, c, self.sd.get("ift.window")),
+                "raw_feat": feat, "recon_feat": recon_feat, "codes": torch.stack(codes, dim=1)}
+
+
+def pvq_forward_train(z: Tensor, sd, pfx: str, in_freq: int, overlap: int, groups: int, l2norm: bool, freeze_vq: bool):
+    """ProductVectorQuantize.forward in training mode (quantization.py:31-72) with Codebook.forward (codebook.py:57-75):
+    straight-through estimator, commitment / codebook losses, frozen-codebook pass-through.  Returns (z_q map, codes, cb_loss, cm_loss)."""
+    v = pvq_frames(z, in_freq, overlap)
+    B, T, D = v.shape
+    dims = split_dimension(D, groups)
+    outs, codes, cb_loss, cm_loss, s = [], [], 0.0, 0.0, 0
+    for g in range(groups):
+        ze = F.linear(v[..., s:s + dims[g]], sd[f"{pfx}down_projs.{g}.weight"])
+        cb_w = sd[f"{pfx}vqs.{g}.embedding.weight"]
+        code = codebook_search(ze.reshape(B * T, -1), cb_w, l2norm).view(B, T)
+        zq = F.embedding(code, cb_w)
+        cm = F.mse_loss(zq.detach(), ze, reduction="none").mean([1, 2])            # codebook.py:68
+        cb = F.mse_loss(zq, ze.detach(), reduction="none").mean([1, 2])            # codebook.py:69
+        zq = ze + (zq - ze).detach()                                               # codebook.py:70
+        if freeze_vq:                                                              # quantization.py:56-59
+            zq = zq * 0.0 + ze
+            cb, cm = cb * 0.0, cm * 0.0
+        outs.append(F.linear(zq, sd[f"{pfx}up_projs.{g}.weight"]))
+        codes.append(code)
+        cm_loss, cb_loss = cm_loss + cm, cb_loss + cb
+        s += dims[g]
+    return pvq_unframes(torch.cat(outs, dim=-1), in_freq, overlap), torch.stack(codes, dim=1), cb_loss / groups, cm_loss / groups
+
+
+# ----------------------------------------------------------------------------------------------
+# Training losses -- esc/modules/loss/generator_loss.py:12-74
+# ----------------------------------------------------------------------------------------------
+MEL_WINDOWS = [32, 64, 128, 256, 512, 1024, 2048]
+MEL_BINS = [5, 10, 20, 40, 80, 160, 320]
+
+
+def power_law(stft: Tensor, power: float = 0.3, eps: float = 1e-10) -> Tensor:
+    """generator_loss.py:31-35."""
+    return (torch.abs(stft) + eps) ** power * torch.sign(stft)
+
+
+def complex_stft_loss(raw_feat: Tensor, recon_feat: Tensor) -> Tensor:
+    """generator_loss.py:19-29 with power_law=True, weight 1: (B,2,F,T) x (B,2,F,T) -> (B,)."""
+    return F.mse_loss(power_law(raw_feat), power_law(recon_feat), reduction="none").mean([1, 2, 3])
+
+
+def htk_filterbank(n_freqs: int, n_mels: int, sample_rate: int) -> Tensor:
+    """torchaudio.functional.melscale_fbanks(n_freqs, 0, sr/2, n_mels, sr, norm=None, mel_scale="htk") (documented formula)."""
+    freqs = torch.linspace(0, sample_rate // 2, n_freqs, dtype=torch.float64)
+    m_hi = 2595.0 * math.log10(1.0 + (sample_rate / 2) / 700.0)
+    pts = 700.0 * (10.0 ** (torch.linspace(0.0, m_hi, n_mels + 2, dtype=torch.float64) / 2595.0) - 1.0)
+    diff = pts[1:] - pts[:-1]
+    slopes = pts.unsqueeze(0) - freqs.unsqueeze(1)
+    down, up = -slopes[:, :-2] / diff[:-1], slopes[:, 2:] / diff[1:]
+    return torch.clamp(torch.min(down, up), min=0.0).float()
+
+
+def mel_spectrogram(x: Tensor, n_fft: int, n_mels: int, sample_rate: int = 16000) -> Tensor:
+    """torchaudio.transforms.MelSpectrogram(sample_rate, n_fft, win_length=n_fft, hop_length=n_fft//4, n_mels, power=1): (B,L)->(B,n_mels,T)."""
+    spec = torch.stft(x, n_fft, n_fft // 4, n_fft, torch.hann_window(n_fft, dtype=x.dtype), center=True, pad_mode="reflect",
+                      normalized=False, onesided=True, return_complex=True).abs()
+    return torch.matmul(spec.transpose(-1, -2), htk_filterbank(n_fft // 2 + 1, n_mels, sample_rate)).transpose(-1, -2)
+
+
+def mel_spectrogram_loss(raw_audio: Tensor, recon_audio: Tensor, clamp_eps: float = 1e-5) -> Tensor:
+    """generator_loss.py:56-74, weight 1: (B,L) x (B,L) -> (B,)."""
+    loss = 0.0
+    for w, nm in zip(MEL_WINDOWS, MEL_BINS):
+        xm, ym = mel_spectrogram(raw_audio, w, nm), mel_spectrogram(recon_audio, w, nm)
+        loss = loss + F.l1_loss(xm, ym, reduction="none").mean([1, 2])
+        loss = loss + F.l1_loss(xm.clamp(clamp_eps).pow(2).log10(), ym.clamp(clamp_eps).pow(2).log10(), reduction="none").mean([1, 2])
+    return loss
+
+
+LOSS_WEIGHTS = dict(cm_weight=0.25, cb_weight=1.0, mel_weight=0.25, stft_weight=1.0)      # configs/9kbps_esc_base.yaml:29-33
+
+
+def training_loss(out: dict, w: dict = LOSS_WEIGHTS) -> dict:
+    """scripts/trainer_no_adv.py:105-115: the four losses, their weighted sum, and the scalar that is back-propagated."""
+    mel = mel_spectrogram_loss(out["raw_audio"], out["recon_audio"])
+    stft = complex_stft_loss(out["raw_feat"], out["recon_feat"])
+    total = out["cm_loss"] * w["cm_weight"] + out["cb_loss"] * w["cb_weight"] + mel * w["mel_weight"] + stft * w["stft_weight"]
+    return {"mel_loss": mel, "stft_loss": stft, "loss": total, "scalar": total.mean()}

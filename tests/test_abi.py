@@ -69,9 +69,11 @@ def test_reference_error_behaviour_on_host():
         m(torch.zeros(1, 48000), None, 6, freeze_codebook=True)
     with pytest.raises(ValueError):                                  # x_feat must be (Bs, F, T, 2)
         m(torch.zeros(1, 48000), torch.zeros(1, 2, 192, 601), 6)
-    m.train()
-    with pytest.raises(NotImplementedError):
+    m.train()                                                        # training mode is implemented on the device only, like the rest
+    with pytest.raises(RuntimeError, match="HIP device"):
         m(torch.zeros(1, 48000), None, 6)
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 48000), torch.zeros(1, 192, 601, 2), 6)
 
 
 def test_synthetic_weights_are_deterministic():

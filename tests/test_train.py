@@ -1,0 +1,215 @@
+"""Training step: training-mode forward, losses and every parameter gradient.
+
+Fixtures: tests/golden/train.npz = the REAL reference's training-mode forward + its own loss classes + loss.mean().backward()
+(oracle/gen_train_golden.py): per-clip losses, codes, the gradient norm of every parameter, a few full gradients.
+  * CPU (`not gpu`): the oracle's training restatement (plain autograd over oracle/esc_oracle.py) is pinned to those fixtures.
+  * GPU: the HIP training step (through esc.ESC in train mode -> libescx escx_train_forward / escx_train_backward, and the HIP loss
+    modules) against the fixtures and, parameter by parameter, against the oracle's gradients.
+Tolerances (fp32, different summation orders): losses 1e-5 relative, gradients 1e-4 relative RMS per parameter.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, synth_state
+from esc import synth
+
+LOSS_RTOL = 1e-5
+GRAD_TOL = 1e-4
+
+
+def _clips(g, name):
+    tags = json.loads(str(g[f"{name}_tags"]))
+    n = json.loads(str(g["n_samples_json"]))[name]
+    pcm = np.stack([synth.noise_clip_int16(tags[0], n), synth.voiced_clip_int16(tags[1], n)])
+    return torch.from_numpy(synth.pcm_to_float(pcm))
+
+
+def _cfg(name):
+    return json.loads(str(load_golden(name)["config_json"]))
+
+
+def _oracle_step(name, S, freeze, x):
+    from oracle import esc_oracle as O
+    sd = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not k.endswith(".window")) else v) for k, v in synth_state(name).items()}
+    orc = O.EscOracle(_cfg(name), sd, keep_graph=True)
+    out = orc.forward_train(x, S, freeze)
+    ls = O.training_loss(out)
+    ls["scalar"].backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items() if v.is_floating_point() and v.requires_grad}
+    return out, ls, grads
+
+
+def _rel_rms(a, b, floor):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)) / max(float(np.sqrt(np.mean(b ** 2))), floor))
+
+
+def _check_against_fixture(g, tag, keys, losses, codes, grads, grad_tol):
+    for k in ("cm", "cb", "mel", "stft", "loss"):
+        np.testing.assert_allclose(losses[k], g[f"{tag}_{k}"], rtol=LOSS_RTOL, atol=1e-7, err_msg=f"{tag} {k}")
+    assert np.array_equal(np.asarray(codes), g[f"{tag}_codes"].astype(np.int64)), f"{tag}: codes differ from the reference"
+    ref_norm = g[f"{tag}_gnorm"]
+    scale = float(np.sqrt((ref_norm ** 2).sum()))
+    for k, rn in zip(keys, ref_norm):
+        gn = float(np.linalg.norm(np.asarray(grads[k], np.float64)))
+        assert abs(gn - rn) <= grad_tol * max(rn, 1e-6 * scale) + 1e-12, f"{tag}: |grad {k}| = {gn} vs reference {rn}"
+    for key in [f for f in g.files if f.startswith(f"{tag}_g::")]:
+        k = key.split("::", 1)[1]
+        ref = g[key]
+        floor = 1e-6 * scale / np.sqrt(ref.size)
+        err = _rel_rms(grads[k], ref, floor)
+        assert err <= grad_tol, f"{tag}: gradient of {k} rel rms {err:.3e}"
+
+
+# ------------------------------------------------------------------------------------------------ CPU: the oracle is pinned
+@pytest.mark.parametrize("name,cases", [("tiny", None), ("base", [(3, False)])])
+def test_oracle_training_step_matches_reference(name, cases):
+    g = load_golden("train")
+    keys = json.loads(str(g[f"{name}_keys"]))
+    x = _clips(g, name)
+    for S, freeze in (cases or json.loads(str(g["cases_json"]))[name]):
+        out, ls, grads = _oracle_step(name, S, freeze, x)
+        losses = {"cm": out["cm_loss"].detach().numpy() if torch.is_tensor(out["cm_loss"]) else np.zeros(2, np.float32),
+                  "cb": out["cb_loss"].detach().numpy() if torch.is_tensor(out["cb_loss"]) else np.zeros(2, np.float32),
+                  "mel": ls["mel_loss"].detach().numpy(), "stft": ls["stft_loss"].detach().numpy(), "loss": ls["loss"].detach().numpy()}
+        _check_against_fixture(g, f"{name}_s{S}_f{int(freeze)}", keys, losses, out["codes"].numpy(), {k: v.numpy() for k, v in grads.items()}, 2e-5)
+
+
+def test_train_fixture_covers_every_parameter():
+    g = load_golden("train")
+    from esc.models import make_model
+    for name in ("tiny", "base"):
+        keys = json.loads(str(g[f"{name}_keys"]))
+        model = make_model(_cfg(name))
+        assert keys == [k for k, _ in model.named_parameters()] or set(keys) == {k for k, _ in model.named_parameters()}
+
+
+# ------------------------------------------------------------------------------------------------ GPU: the HIP training step
+def _product_step(name, S, freeze, x, w):
+    from esc.models import make_model
+    from esc.modules import ComplexSTFTLoss, MelSpectrogramLoss
+    model = make_model(_cfg(name))
+    model.load_state_dict(synth_state(name))
+    model = model.cuda().train()
+    out = model(**dict(x=x.cuda(), x_feat=None, num_streams=S, freeze_codebook=freeze))
+    mel = MelSpectrogramLoss()(out["raw_audio"], out["recon_audio"])
+    stft = ComplexSTFTLoss()(out["raw_feat"], out["recon_feat"])
+    loss = out["cm_loss"] * w["cm_weight"] + out["cb_loss"] * w["cb_weight"] + mel * w["mel_weight"] + stft * w["stft_weight"]
+    loss.mean().backward()
+    torch.cuda.synchronize()
+    grads = {k: (p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)) for k, p in model.named_parameters()}
+    losses = {"cm": out["cm_loss"].detach().cpu().numpy(), "cb": out["cb_loss"].detach().cpu().numpy(), "mel": mel.detach().cpu().numpy(),
+              "stft": stft.detach().cpu().numpy(), "loss": loss.detach().cpu().numpy()}
+    return model, out, losses, grads
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "base"])
+def test_training_step_losses_and_every_gradient(name):
+    g = load_golden("train")
+    w = json.loads(str(g["weights_json"]))
+    keys = json.loads(str(g[f"{name}_keys"]))
+    x = _clips(g, name)
+    for S, freeze in json.loads(str(g["cases_json"]))[name]:
+        tag = f"{name}_s{S}_f{int(freeze)}"
+        model, out, losses, grads = _product_step(name, S, freeze, x, w)
+        assert out["codes"].shape[1] == model.max_streams and out["recon_audio"].shape == x.shape
+        assert out["raw_feat"].shape == out["recon_feat"].shape
+        _check_against_fixture(g, tag, keys, losses, out["codes"].cpu().numpy(), grads, GRAD_TOL)
+        # every parameter, element by element, against the oracle's autograd gradients
+        _, _, ograds = _oracle_step(name, S, freeze, x)
+        scale = float(np.sqrt(sum(float((v.double() ** 2).sum()) for v in ograds.values())))
+        worst = (0.0, None)
+        for k in keys:
+            ref = ograds[k].numpy()
+            err = _rel_rms(grads[k], ref, 1e-6 * scale / np.sqrt(ref.size))
+            worst = max(worst, (err, k))
+            assert err <= GRAD_TOL, f"{tag}: gradient of {k} rel rms {err:.3e} (|ref| {np.linalg.norm(ref):.3e})"
+        print(f"[{tag}] worst parameter gradient rel rms {worst[0]:.2e} ({worst[1]})")
+
+
+@pytest.mark.gpu
+def test_loss_modules_against_the_oracle():
+    """ComplexSTFTLoss / MelSpectrogramLoss (HIP) vs the oracle's restatement of generator_loss.py: values and d loss / d reconstruction."""
+    from oracle import esc_oracle as O
+    from esc.modules import ComplexSTFTLoss, MelSpectrogramLoss
+    torch.manual_seed(5)
+    raw = 0.1 * torch.randn(3, 6000); rec = (raw + 0.03 * torch.randn(3, 6000)).requires_grad_(True)
+    rec_g = rec.detach().cuda().requires_grad_(True)
+    wts = torch.tensor([0.5, 1.0, 2.0])
+    got = MelSpectrogramLoss()(raw.cuda(), rec_g)
+    (got * wts.cuda()).sum().backward()
+    ref = O.mel_spectrogram_loss(raw, rec)
+    (ref * wts).sum().backward()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=LOSS_RTOL)
+    assert _rel_rms(rec_g.grad.cpu().numpy(), rec.grad.numpy(), 1e-12) <= GRAD_TOL
+    fa = torch.randn(2, 2, 24, 33); fb = (fa + 0.2 * torch.randn(2, 2, 24, 33)).requires_grad_(True)
+    fa[0, 0, 0, :4] = 0.0
+    fb_g = fb.detach().cuda().requires_grad_(True)
+    got = ComplexSTFTLoss()(fa.cuda(), fb_g)
+    got.sum().backward()
+    ref = O.complex_stft_loss(fa, fb)
+    ref.sum().backward()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=LOSS_RTOL)
+    assert _rel_rms(fb_g.grad.cpu().numpy(), fb.grad.numpy(), 1e-12) <= GRAD_TOL
+
+
+@pytest.mark.gpu
+def test_flat_adamw_and_clipping_match_torch():
+    """escx_grad_norm_clip + escx_adamw_step on flat buffers vs torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW (trainer_no_adv.py:116-117)."""
+    import ctypes
+    from esc import _native
+    lib = _native.load()
+    torch.manual_seed(3)
+    n = 100_003
+    p0 = torch.randn(n); grads = [torch.randn(n) * s for s in (0.01, 3.0, 0.2)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.8, 0.95), eps=1e-8, weight_decay=0.05)
+    p = p0.clone().cuda(); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    aux = torch.zeros(2 + 1024, device="cuda")
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    for step, gcpu in enumerate(grads, 1):
+        ref.grad = gcpu.clone()
+        tn = torch.nn.utils.clip_grad_norm_([ref], 0.5)
+        opt.step()
+        gg = gcpu.cuda()
+        _native.check(lib.escx_grad_norm_clip(ptr(gg), n, 0.5, ptr(aux), None))
+        _native.check(lib.escx_adamw_step(ptr(p), ptr(gg), ptr(m), ptr(v), n, step, 1e-3, 0.8, 0.95, 1e-8, 0.05, ptr(aux), None))
+        torch.cuda.synchronize()
+        assert abs(float(aux[0]) - float(tn)) <= 1e-5 * float(tn)
+        np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=2e-7)
+
+
+@pytest.mark.gpu
+def test_eval_after_optimizer_steps_uses_the_updated_weights():
+    """in-place parameter updates (optimizer.step) must be picked up without refresh_weights(); train -> eval -> train
+    round trips keep working and eval after training equals a fresh model loaded with the updated state_dict."""
+    from esc.models import make_model
+    cfg = _cfg("tiny")
+    g = load_golden("train")
+    x = _clips(g, "tiny").cuda()
+    model = make_model(cfg); model.load_state_dict(synth_state("tiny")); model = model.cuda().eval()
+    c0, shp = model.encode(x, 3)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2)
+    model.train()
+    for _ in range(2):
+        out = model(**dict(x=x, x_feat=None, num_streams=3, freeze_codebook=False))
+        (out["cm_loss"] + out["cb_loss"] + (out["recon_audio"] - x).pow(2).mean(1)).mean().backward()
+        opt.step(); opt.zero_grad()
+    model.eval()
+    c1, _ = model.encode(x, 3)
+    w1 = model.decode(c1, shp)
+    fresh = make_model(cfg); fresh.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}); fresh = fresh.cuda().eval()
+    cf, _ = fresh.encode(x, 3)
+    assert torch.equal(c1, cf) and torch.equal(w1, fresh.decode(cf, shp))
+    assert not torch.equal(w1, model.decode(c0, shp)) or not torch.equal(c0, c1)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.0)                                   # in-place write outside any optimizer
+    assert torch.equal(model.encode(x, 3)[0], c1)
+    import copy
+    twin = copy.deepcopy(model)                           # ADVICE: deepcopy / pickling of a used model
+    assert torch.equal(twin.encode(x, 3)[0], c1)
