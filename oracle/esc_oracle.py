@@ -518,7 +518,7 @@ def mel_spectrogram(x: Tensor, n_fft: int, n_mels: int, sample_rate: int = 16000
     """torchaudio.transforms.MelSpectrogram(sample_rate, n_fft, win_length=n_fft, hop_length=n_fft//4, n_mels, power=1): (B,L)->(B,n_mels,T)."""
     spec = torch.stft(x, n_fft, n_fft // 4, n_fft, torch.hann_window(n_fft, dtype=x.dtype), center=True, pad_mode="reflect",
                       normalized=False, onesided=True, return_complex=True).abs()
-    return torch.matmul(spec.transpose(-1, -2), htk_filterbank(n_fft // 2 + 1, n_mels, sample_rate)).transpose(-1, -2)
+    return torch.matmul(spec.transpose(-1, -2), htk_filterbank(n_fft // 2 + 1, n_mels, sample_rate).to(spec.dtype)).transpose(-1, -2)
 
 
 def mel_spectrogram_loss(raw_audio: Tensor, recon_audio: Tensor, clamp_eps: float = 1e-5) -> Tensor:
