@@ -125,8 +125,125 @@ def cpu_baseline(cfg, sd, x_cpu):
                       f"{best_thr} of {avail} host threads (best of a 8/16/32/64 sweep)"}
 
 
+TRAIN_SAMPLES = 47920              # 3 s minus one hop: an even frame count, so that raw and reconstructed spectra have the same T (the trainers' clips)
+TRAIN_WEIGHTS = dict(cm_weight=0.25, cb_weight=1.0, mel_weight=0.25, stft_weight=1.0)       # configs/9kbps_esc_base.yaml:29-33
+
+
+def train_cpu_baseline(cfg, sd, x_cpu):
+    """One training step of the oracle (reference restatement under torch autograd, fp32) on the host cores: bounded sample of 2 clips."""
+    from oracle import esc_oracle as O
+    avail = os.cpu_count() or 1
+    thr = min(avail, 16)
+    torch.set_num_threads(thr)
+    xs = x_cpu[:2]
+
+    def once():
+        leaf = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not k.endswith(".window")) else v) for k, v in sd.items()}
+        orc = O.EscOracle(cfg, leaf, keep_graph=True)
+        t0 = time.perf_counter()
+        out = orc.forward_train(xs, NUM_STREAMS, False)
+        O.training_loss(out)["scalar"].backward()
+        return time.perf_counter() - t0
+    once()
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        once(); reps += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or reps >= 6:
+            break
+    return {"value": round(reps * 2 * (TRAIN_SAMPLES / 16000.0) / el, 3), "unit": "audio-seconds/sec", "cores": thr, "kind": "port",
+            "sample": f"{reps} x (training forward + losses + backward) of 2 clips, oracle/esc_oracle.py under torch autograd, CPU fp32, {thr} of {avail} host threads; "
+                      "no optimiser step"}
+
+
+def run_train(args, rank, world, device, use_dist):
+    """--mode train: the step of scripts/trainer_no_adv.py:95-118 (training forward, mel + complex-STFT + VQ losses, backward, clip 0.5,
+    AdamW) on 36 clips per GPU, ESC-Base, fp32 like the reference (it has no AMP path).  Single-GPU measurement; with N > 1 every rank
+    runs its own replica of the step (no gradient exchange is implemented yet: reported as such)."""
+    from esc.modules import ComplexSTFTLoss, MelSpectrogramLoss
+    from esc.optim import FlatAdamW
+    model, cfg, sd = build_model(device)
+    model.train()
+    from esc import synth
+    pcm = np.stack([synth.noise_clip_int16(f"bench-r{rank}-{i}", TRAIN_SAMPLES) for i in range(CLIPS_PER_GPU)])
+    x_cpu = torch.from_numpy(synth.pcm_to_float(pcm))
+    x = x_cpu.to(device)
+    mel_fn, stft_fn = MelSpectrogramLoss(), ComplexSTFTLoss()
+    opt = FlatAdamW(model, lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, max_grad_norm=0.5, device=device)
+    w = TRAIN_WEIGHTS
+
+    def step():
+        out = model(**dict(x=x, x_feat=None, num_streams=NUM_STREAMS, freeze_codebook=False))
+        loss = (out["cm_loss"] * w["cm_weight"] + out["cb_loss"] * w["cb_weight"] + mel_fn(out["raw_audio"], out["recon_audio"]) * w["mel_weight"]
+                + stft_fn(out["raw_feat"], out["recon_feat"]) * w["stft_weight"])
+        loss.mean().backward()
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    def sync():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(loss).all()
+    if rank != 0:
+        return
+    lib, hd = model._handle(device, for_training=True)
+    lib.escx_profile_enable(hd, 1)
+    psteps = max(2, min(args.profile_steps, 3))
+    for _ in range(psteps):
+        step()
+    torch.cuda.synchronize(device)
+    lib.escx_profile_enable(hd, 0)
+    recs = json.loads(lib.escx_profile_report(hd).decode())
+    tot = sum(r["ms"] for r in recs)
+    recs.sort(key=lambda r: -r["ms"])
+    if os.environ.get("ESCX_BENCH_BREAKDOWN"):
+        for r in recs:
+            print(f"# {r['name']:24s} calls {r['calls']:4d}  {r['ms'] / psteps:9.3f} ms/step  {r['flops'] / max(r['ms'], 1e-9) / 1e9:9.1f} TFLOP/s", file=sys.stderr)
+    dom = next((r for r in recs if r["flops"] > 0), recs[0])
+    avg_s = dom["ms"] / dom["calls"] * 1e-3
+    fl = dom["flops"] / dom["calls"]
+    roofline = {"bound": "mfma", "achieved": round(fl / avg_s / 1e12, 3), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                "frac": round(fl / avg_s / PEAK_F32_MFMA, 4), "traffic": None, "kernel": dom["name"], "avg_us": round(avg_s * 1e6, 2),
+                "launches_per_step": dom["calls"] // psteps, "share_of_profiled_time": round(dom["ms"] / tot, 4),
+                "profiled_ms_per_step": round(tot / psteps, 3),
+                "executed_gflop_per_clip": round(sum(r["flops"] for r in recs) / psteps / CLIPS_PER_GPU / 1e9, 2),
+                "note": "kernel = the GEMM-class launch group with the largest share of the step; traffic not collected in train mode"}
+    audio_s = CLIPS_PER_GPU * world * args.steps * (TRAIN_SAMPLES / 16000.0)
+    roofline["whole_step_frac_executed_flops"] = round(roofline["executed_gflop_per_clip"] * 1e9 * CLIPS_PER_GPU * args.steps / elapsed / PEAK_F32_MFMA, 4)
+    out = {"metric": "audio-seconds/sec trained (forward + mel/STFT/VQ losses + backward + clip + AdamW), ESC-Base 9kbps 3s@16kHz",
+           "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": f"ESC-Base training step (scripts/trainer_no_adv.py:95-118, non-adversarial), batch={CLIPS_PER_GPU} clips of {TRAIN_SAMPLES} samples per GPU, "
+                                  "num_streams=6, fp32 (the reference has no AMP); first slice of BASELINE configs[4]",
+                      "global_batch": CLIPS_PER_GPU * world, "clip_samples": TRAIN_SAMPLES, "num_streams": NUM_STREAMS,
+                      "parallelism": f"dp{world}" + (" (independent replicas: no gradient all-reduce yet)" if world > 1 else ""),
+                      "optimizer": "AdamW (flat, 2 kernels) + clip_grad_norm 0.5", "tape_gb": round(lib.escx_train_tape_bytes(hd) / 2 ** 30, 2),
+                      "steps_per_sec": round(args.steps / elapsed, 3)},
+           "roofline": roofline,
+           "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else train_cpu_baseline(cfg, sd, x_cpu)}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", choices=["codec", "train"], default="codec",
+                    help="codec (default): encode+decode throughput, the BASELINE metric; train: one optimisation step (BASELINE configs[4], first slice)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
@@ -152,6 +269,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)
+
+    if args.mode == "train":
+        run_train(args, rank, world, device, use_dist)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from esc.distributed import all_gather_codes
     model, cfg, sd = build_model(device)

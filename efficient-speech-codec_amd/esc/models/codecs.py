@@ -162,6 +162,7 @@ class ESC(nn.Module):
         self._flat: Dict[int, dict] = {}                 # per device: flat fp32 parameter buffer the nn.Parameters are views of
         self._packed_version: Dict[int, int] = {}        # parameter fingerprint the packed device layouts were derived from
         self._dirty = True
+        self._flat_grad_mode = False
 
     # ---- weight management ------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -234,6 +235,44 @@ class ESC(nn.Module):
                     flat[off:off + n].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
                     p.data = flat[off:off + n].view(p.shape)
         return flat
+
+    # ---- flat-gradient mode (esc.optim.FlatAdamW) ----------------------------------------------------
+    def enable_flat_grads(self, device):
+        """Every p.grad becomes a view of ONE flat gradient buffer that the training backward fills directly (accumulating across
+        backward calls until zero_flat_grads), so that the optimiser is two kernels over flat buffers.  autograd's per-parameter
+        accumulation (and therefore per-parameter hooks such as DDP's) is bypassed in this mode."""
+        device = torch.device(device)
+        lib, hd = self._handle(device, for_training=True)
+        flat = self._ensure_flat(device, lib, hd)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        st = self._flat[idx]
+        if "gflat" not in st:
+            st["gflat"] = torch.zeros_like(flat)
+            st["gfresh"] = True
+        params = self._named_params()
+        for key, off, n in st["layout"]:
+            params[key].grad = st["gflat"][off:off + n].view(params[key].shape)
+        self._flat_grad_mode = True
+
+    def flat_buffers(self, device):
+        device = torch.device(device)
+        lib, hd = self._handle(device, for_training=True)
+        flat = self._ensure_flat(device, lib, hd)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if "gflat" not in self._flat[idx]:
+            self.enable_flat_grads(device)
+        return flat, self._flat[idx]["gflat"]
+
+    def zero_flat_grads(self, device):
+        idx = torch.device(device).index
+        idx = idx if idx is not None else torch.cuda.current_device()
+        st = self._flat.get(idx)
+        if st is not None and "gflat" in st:
+            st["gfresh"] = True                      # the next backward overwrites instead of accumulating: no memset needed
+
+    def note_params_updated(self):
+        """The flat buffer was written by a native kernel (no autograd version bump): mark every packed layout stale."""
+        self._packed_version = {}
 
     def _handle(self, device: torch.device, for_training: bool = False):
         lib = _native.load()
@@ -473,7 +512,8 @@ class _TrainStep(torch.autograd.Function):
         model, dev = ctx.model, ctx.dev
         lib, hd = model._handle(dev, for_training=True)
         st = model._flat[ctx.idx]
-        gflat = torch.empty_like(st["flat"])
+        flat_mode = model._flat_grad_mode and "gflat" in st
+        gflat = st["gflat"] if (flat_mode and st["gfresh"]) else torch.empty_like(st["flat"])
 
         def prep(t):
             return None if t is None else t.to(torch.float32).contiguous()
@@ -482,6 +522,12 @@ class _TrainStep(torch.autograd.Function):
         with torch.cuda.device(dev):
             _native.check(lib.escx_train_backward(hd, p(d_recon), p(d_recon_fm), p(d_cm), p(d_cb), ctypes.c_void_p(gflat.data_ptr()), model._stream(dev)))
         params = model._named_params()
+        if flat_mode:                                   # p.grad are views of st["gflat"]: written in place, nothing for autograd to accumulate
+            if st["gfresh"]:
+                st["gfresh"] = False
+            else:
+                st["gflat"].add_(gflat)
+            return (None, None, None, None) + (None,) * len(params)
         by_id = {id(params[k]): gflat[off:off + n].view(params[k].shape) for k, off, n in st["layout"]}
         grads = tuple(by_id.get(id(q)) for q in model.parameters())
         return (None, None, None, None) + grads

@@ -1,0 +1,68 @@
+"""Optimiser step of the reference trainers on the MI355X: `clip_grad_norm_(params, max_norm)` + `AdamW.step()`
+(`/root/reference/scripts/trainer_no_adv.py:116-117`, `scripts/utils.py:48-49`: torch.optim.AdamW(lr, betas=(0.8, 0.9)... whatever the
+caller passes) as TWO kernels over the model's flat parameter / gradient buffers instead of ~430 per-tensor launches.
+
+    opt = FlatAdamW(model, lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, max_grad_norm=0.5)
+    loss.backward(); opt.step(); opt.zero_grad()
+
+`FlatAdamW` switches the model to flat-gradient mode: the training backward writes d loss / d parameter straight into one flat buffer
+that every `p.grad` is a view of, so nothing is copied between backward and step.  The update rule is torch.optim.AdamW's
+(decoupled weight decay, bias-corrected moments); tests/test_train.py checks it against torch step by step.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _native
+
+
+class FlatAdamW:
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None, device=None):
+        self.model, self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = model, lr, betas, eps, weight_decay, max_grad_norm
+        dev = torch.device(device) if device is not None else next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatAdamW works on the HIP device the model lives on")
+        self.device = dev
+        self.t = 0
+        self._state = None
+        self.last_grad_norm = None
+        model.enable_flat_grads(dev)
+
+    def _buffers(self):
+        flat, gflat = self.model.flat_buffers(self.device)
+        if self._state is None or self._state[0].data_ptr() != flat.data_ptr():
+            self._state = (flat, torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros(2 + 1024, dtype=torch.float32, device=self.device))
+        return flat, gflat, self._state[1], self._state[2], self._state[3]
+
+    @torch.no_grad()
+    def step(self):
+        lib = _native.load()
+        flat, gflat, m, v, aux = self._buffers()
+        self.t += 1
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):
+            clip = None
+            if self.max_grad_norm is not None:
+                _native.check(lib.escx_grad_norm_clip(p(gflat), gflat.numel(), float(self.max_grad_norm), p(aux), st))
+                clip = p(aux)
+                self.last_grad_norm = aux[0]
+            _native.check(lib.escx_adamw_step(p(flat), p(gflat), p(m), p(v), flat.numel(), self.t, float(self.lr), float(self.betas[0]),
+                                              float(self.betas[1]), float(self.eps), float(self.weight_decay), clip, st))
+        self.model.note_params_updated()
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.model.zero_flat_grads(self.device)
+
+    def state_dict(self):
+        flat, gflat, m, v, _ = self._buffers()
+        return {"step": self.t, "exp_avg": m.clone(), "exp_avg_sq": v.clone(), "lr": self.lr, "betas": self.betas, "eps": self.eps,
+                "weight_decay": self.weight_decay, "max_grad_norm": self.max_grad_norm}
+
+    def load_state_dict(self, sd):
+        flat, gflat, m, v, _ = self._buffers()
+        self.t = int(sd["step"]); m.copy_(sd["exp_avg"]); v.copy_(sd["exp_avg_sq"])
+        self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
+        self.max_grad_norm = sd.get("max_grad_norm")

@@ -216,7 +216,8 @@ def test_training_step_losses_and_every_gradient(name):
             worst = max(worst, (err / bound, k, err))
             assert err <= bound and err <= 1e-2, f"{tag}: gradient of {k} rel rms {err:.3e} vs fp64, reference fp32 noise floor {floor[k]:.3e}"
             gn = float(np.linalg.norm(np.asarray(grads[k], np.float64)))
-            assert abs(gn - rn) <= bound * max(rn, 1e-6 * scale) + 1e-12, f"{tag}: |grad {k}| = {gn} vs reference fixture {rn}"
+            # the fixture is the fp32 reference: both sides carry their own noise (HIP error + the reference's floor)
+            assert abs(gn - rn) <= 2.0 * bound * max(rn, 1e-6 * scale) + 1e-12, f"{tag}: |grad {k}| = {gn} vs reference fixture {rn}"
         print(f"[{tag}] vs fp64 oracle: HIP median rel rms {np.median(errs):.2e} max {max(errs):.2e}; reference-fp32 noise floor median {med:.2e} "
               f"max {max(floor.values()):.2e}; worst (error / bound) {worst[0]:.2f} at {worst[1]}")
         assert np.median(errs) <= 2.0 * med + 1e-5          # as a whole, the HIP gradients are as close to the truth as the fp32 reference's own
