@@ -45,6 +45,15 @@ TrainTape* tape_of(escx_handle_s* h) {
 
 inline unsigned blocks_for(long long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
 
+// fixed-order sum of `slices` partial tensors of n floats.  The variant depends on (slices, n) only - never on data - so results stay
+// run-to-run deterministic.
+void reduce_partials(const float* part, int slices, long long n, float* out, int accumulate, hipStream_t st) {
+    if (slices >= 32 && n * 4 <= ((long long)1 << 22))
+        hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3(blocks_for((n + 15) / 16 * 64)), dim3(256), 0, st, part, slices, n, out, accumulate);
+    else
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for(n)), dim3(256), 0, st, part, slices, n, out, accumulate);
+}
+
 // ---- GEMM helpers --------------------------------------------------------------------------------
 template <class Ld, class Epi>
 void gemm_any(const Ld& ld, const float* W, int M, int Np, int Kp, const Epi& ep, hipStream_t st, int force_bk = 0) {
@@ -77,24 +86,25 @@ int dw_launch(escx_handle_s* h, const LdA& la, const LdB& lb, int M, int Np, int
     float* bpart = part + (size_t)slices * Np * Kp;
     if (db) hipLaunchKernelGGL((gemm_dw_kernel<LdA, LdB, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
     else hipLaunchKernelGGL((gemm_dw_kernel<LdA, LdB, false>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for((long long)Np * Kp)), dim3(256), 0, st, part, slices, (long long)Np * Kp, dW, 0);
-    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for(Np)), dim3(256), 0, st, bpart, slices, (long long)Np, db, 0);
+    reduce_partials(part, slices, (long long)Np * Kp, dW, 0, st);
+    if (db) reduce_partials(bpart, slices, (long long)Np, db, 0, st);
     return 0;
 }
 
 // LayerNorm backward launcher; dgamma -> dg[SEGS*Cp], dbeta -> dbt[SEGS*Cp]
 int ln_bwd(int mode, const float* x, const float* dy, const float* gamma, const int* map, const float* add, float* dx, float* dg, float* dbt,
-           int rows_per_clip, int src_rows_per_clip, int dy_rows_per_clip, int total_rows, int C, int Cp, float* part, hipStream_t st) {
+           int rows_per_clip, int src_rows_per_clip, int dy_rows_per_clip, int total_rows, int C, int Cp, float* part, hipStream_t st,
+           float* dx_slots = nullptr, const int* slot_of = nullptr, int slots_per_clip = 0) {
     const int segs = mode == 2 ? 2 : 1;
     const int grid = (int)std::min<long long>(512, ((long long)total_rows + 15) / 16);
     const size_t shm = (size_t)16 * 2 * segs * Cp * sizeof(float);
     const int RW = segs * Cp;
-    if (mode == 0) hipLaunchKernelGGL((ln_bwd_kernel<1, 0>), dim3(grid), dim3(256), shm, st, x, dy, gamma, map, add, dx, part, rows_per_clip, src_rows_per_clip, dy_rows_per_clip, total_rows, C, Cp, 1e-5f);
-    else if (mode == 1) hipLaunchKernelGGL((ln_bwd_kernel<1, 1>), dim3(grid), dim3(256), shm, st, x, dy, gamma, map, add, dx, part, rows_per_clip, src_rows_per_clip, dy_rows_per_clip, total_rows, C, Cp, 1e-5f);
-    else hipLaunchKernelGGL((ln_bwd_kernel<2, 2>), dim3(grid), dim3(256), shm, st, x, dy, gamma, map, add, dx, part, rows_per_clip, src_rows_per_clip, dy_rows_per_clip, total_rows, C, Cp, 1e-5f);
+    if (mode == 0) hipLaunchKernelGGL((ln_bwd_kernel<1, 0>), dim3(grid), dim3(256), shm, st, x, dy, gamma, map, add, dx, part, rows_per_clip, src_rows_per_clip, dy_rows_per_clip, total_rows, C, Cp, 1e-5f, dx_slots, slot_of, slots_per_clip);
+    else if (mode == 1) hipLaunchKernelGGL((ln_bwd_kernel<1, 1>), dim3(grid), dim3(256), shm, st, x, dy, gamma, map, add, dx, part, rows_per_clip, src_rows_per_clip, dy_rows_per_clip, total_rows, C, Cp, 1e-5f, dx_slots, slot_of, slots_per_clip);
+    else hipLaunchKernelGGL((ln_bwd_kernel<2, 2>), dim3(grid), dim3(256), shm, st, x, dy, gamma, map, add, dx, part, rows_per_clip, src_rows_per_clip, dy_rows_per_clip, total_rows, C, Cp, 1e-5f, dx_slots, slot_of, slots_per_clip);
     // part: [grid][2][RW] -> reduce over grid (fixed order) into a [2][RW] row, then to the two destinations
     float* red = part + (size_t)grid * 2 * RW;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for(2 * RW)), dim3(256), 0, st, part, grid, (long long)2 * RW, red, 0);
+    reduce_partials(part, grid, (long long)2 * RW, red, 0, st);
     (void)hipMemcpyAsync(dg, red, (size_t)RW * sizeof(float), hipMemcpyDeviceToDevice, st);
     (void)hipMemcpyAsync(dbt, red + RW, (size_t)RW * sizeof(float), hipMemcpyDeviceToDevice, st);
     return 0;
@@ -111,7 +121,7 @@ int attn_bwd(const float* qkv, const float* bias, const float* dout, float* dqkv
         default: return -1;
     }
 #undef ESCX_ATB
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for((long long)nH * 256)), dim3(256), 0, st, part, gx, (long long)nH * 256, dbias, 0);
+    reduce_partials(part, gx, (long long)nH * 256, dbias, 0, st);
     return 0;
 }
 constexpr size_t ATT_PART_FLOATS = (size_t)512 * 64 * 256;
@@ -176,6 +186,7 @@ int layer_fwd(escx_handle_s* h, const Layer& L, LayerTape& LT, const float* x_in
     const double dM = M, dMs = Ms, dC = L.C, f4 = 4;
     LT.H = H;
     LT.blk.assign(L.blocks.size(), BlockTape());
+    const std::string tg = h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string();
     const float* x = x_in;
     int rc;
     for (size_t j = 0; j < L.blocks.size(); ++j) {
@@ -189,19 +200,19 @@ int layer_fwd(escx_handle_s* h, const Layer& L, LayerTape& LT, const float* x_in
         bt.x1 = tp.take((size_t)M * L.Cp); bt.xn2 = tp.take((size_t)M * L.Cp);
         bt.hpre = tp.take((size_t)M * L.hiddenP); bt.hact = tp.take((size_t)M * L.hiddenP); bt.x2 = tp.take((size_t)M * L.Cp);
         if (!bt.x2) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small");
-        PROF("T.ln1_gather", 0, (dM + dMs) * dC * f4, ln_rows(1, x, bt.xn1, bw.ln1_g, bw.ln1_b, map, slots, tokens, Ms, L.C, L.Cp, st));
-        PROF("T.gemm_qkv", 2 * dMs * dC * 3 * dC, dMs * 4 * dC * f4,
+        PROF("T.ln1_gather" + tg, 0, (dM + dMs) * dC * f4, ln_rows(1, x, bt.xn1, bw.ln1_g, bw.ln1_b, map, slots, tokens, Ms, L.C, L.Cp, st));
+        PROF("T.gemm_qkv" + tg, 2 * dMs * dC * 3 * dC, dMs * 4 * dC * f4,
              gemm_qkv(bt.xn1, L.Cp, Ms, bw.wqkv, L.Nqkv, L.Cp, bt.qkv, bw.bqkv, L.nH * L.hdp, 1.0f / std::sqrt((float)L.hd), st));
         int arc = 0;
-        PROF("T.window_attn", 4 * dMs * 16 * dC, dMs * 4 * dC * f4,
+        PROF("T.window_attn" + tg, 4 * dMs * 16 * dC, dMs * 4 * dC * f4,
              arc = window_attention(bt.qkv, bw.bias_tab, bt.obuf, Ms / 16, L.nH, L.hdp, L.Nqkv, L.Ko, Hp / 4, Wp / 4, shift > 0, st));
         if (arc) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "head_dim %d unsupported by the attention kernel", L.hd);
-        PROF("T.gemm_proj", 2 * dMs * dC * dC, (dMs * dC + 2 * dM * dC) * f4,
+        PROF("T.gemm_proj" + tg, 2 * dMs * dC * dC, (dMs * dC + 2 * dM * dC) * f4,
              gemm_proj_scatter(bt.obuf, L.Ko, Ms, bw.wproj, L.Cp, L.Ko, bt.x1, x, bw.bproj, map, slots, tokens, st));
-        PROF("T.ln2", 0, 2 * dM * dC * f4, ln_rows(0, bt.x1, bt.xn2, bw.ln2_g, bw.ln2_b, nullptr, tokens, tokens, M, L.C, L.Cp, st));
-        PROF("T.gemm_fc1_gelu", 2 * dM * dC * L.hidden, dM * (dC + 2 * L.hidden) * f4,
+        PROF("T.ln2" + tg, 0, 2 * dM * dC * f4, ln_rows(0, bt.x1, bt.xn2, bw.ln2_g, bw.ln2_b, nullptr, tokens, tokens, M, L.C, L.Cp, st));
+        PROF("T.gemm_fc1_gelu" + tg, 2 * dM * dC * L.hidden, dM * (dC + 2 * L.hidden) * f4,
              gemm_rows(bt.xn2, L.Cp, M, bw.w1, L.hiddenP, L.Cp, EpiGeluDual{bt.hpre, bt.hact, L.hiddenP, bw.b1}, st));
-        PROF("T.gemm_fc2_res", 2 * dM * dC * L.hidden, dM * (2 * dC + L.hidden) * f4,
+        PROF("T.gemm_fc2_res" + tg, 2 * dM * dC * L.hidden, dM * (2 * dC + L.hidden) * f4,
              gemm_residual(bt.hact, L.hiddenP, M, bw.w2, L.Cp, L.hiddenP, bt.x2, bw.b2, bt.x1, st));
         x = bt.x2;
     }
@@ -245,7 +256,7 @@ int quant_fwd(escx_handle_s* h, TrainTape& T, int sid, const float* enc, const f
     const double vec = (double)c.overlap * q.Hq * q.C;
     PROF("T.pvq_down", 2.0 * M * vec * q.d, (double)M * vec * (dec ? 2 : 1) * 4,
          gemm_pvq_down(enc, dec, B, q.Hq, W, q.Cp, c.overlap, q.wd, q.Nz, q.Kq, zpart, splits, st));
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for((long long)M * q.Nz)), dim3(256), 0, st, zpart, splits, (long long)M * q.Nz, Q.ze, 0);
+    reduce_partials(zpart, splits, (long long)M * q.Nz, Q.ze, 0, st);
     int src = 0;
     PROF("T.pvq_search", 2.0 * M * G * c.codebook_size * q.d, (double)G * c.codebook_size * q.d * 4,
          src = pvq_search(Q.ze, 1, M, q.Nz, q.cbn, q.c2, q.cbraw, G, c.codebook_size, q.d, q.dt, Tq, codes, bstride, nullptr, 0.f, c.l2norm, st));
@@ -421,6 +432,7 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
     float* attpart = sc.take(ATT_PART_FLOATS);
     float* dcur = sc.take((size_t)M * L.Cp);                 // gradient w.r.t. the current block output
     float* dx1 = sc.take((size_t)M * L.Cp);
+    float* dx1s = sc.take((size_t)Ms * L.Cp);                // the same gradient in window-slot order (pad slots zero)
     float* dxn = sc.take((size_t)std::max(M, Ms) * L.Cp);
     float* dhpre = sc.take((size_t)M * L.hiddenP);
     float* dqkv = sc.take((size_t)Ms * L.Nqkv);
@@ -429,6 +441,7 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
     float* dprev = sc.take((size_t)M * L.Cp);
     if (!dprev) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
     int rc;
+    const std::string tg = h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string();
     const float* x_last = LT.blk.back().x2;
     const float* dlast;                                     // gradient w.r.t. the last block's output
     if (L.scale == 1) {
@@ -461,36 +474,36 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
         if ((rc = get_map(h, H, W, shift, &map))) return rc;
         if ((rc = get_map(h, H, W, 10 + shift, &inv))) return rc;
         // ---- MLP: x2 = x1 + W2 gelu(W1 LN2(x1) + b1) + b2 ----
-        PROF("B.dw_fc2", 2.0 * M * L.C * L.hidden, 0,
+        PROF("B.dw_fc2" + tg, 2.0 * M * L.C * L.hidden, 0,
              rc = dw_launch(h, PlainA{dy, L.Cp, M}, PlainA{bt.hact, L.hiddenP, M}, M, L.Cp, L.hiddenP, G(h, bw.w2), G(h, bw.b2), part, st));
         if (rc) return rc;
-        PROF("B.dx_fc2", 2.0 * M * L.C * L.hidden, 0,
+        PROF("B.dx_fc2" + tg, 2.0 * M * L.C * L.hidden, 0,
              gemm_rows(dy, L.Cp, M, bw.w2T, L.hiddenP, L.Cp, EpiGeluBwd{dhpre, L.hiddenP, bt.hpre}, st));
-        PROF("B.dw_fc1", 2.0 * M * L.C * L.hidden, 0,
+        PROF("B.dw_fc1" + tg, 2.0 * M * L.C * L.hidden, 0,
              rc = dw_launch(h, PlainA{dhpre, L.hiddenP, M}, PlainA{bt.xn2, L.Cp, M}, M, L.hiddenP, L.Cp, G(h, bw.w1), G(h, bw.b1), part, st));
         if (rc) return rc;
-        PROF("B.dx_fc1", 2.0 * M * L.C * L.hidden, 0,
+        PROF("B.dx_fc1" + tg, 2.0 * M * L.C * L.hidden, 0,
              gemm_rows(dhpre, L.hiddenP, M, bw.w1T, L.Cp, L.hiddenP, EpiStore{dxn, L.Cp, nullptr}, st));
-        PROF("B.ln2", 0, 4.0 * M * L.C * 4,
-             ln_bwd(0, bt.x1, dxn, bw.ln2_g, nullptr, dy, dx1, G(h, bw.ln2_g), G(h, bw.ln2_b), tokens, tokens, tokens, M, L.C, L.Cp, lnpart, st));
+        if (slots != tokens) ESCX_HIP(hipMemsetAsync(dx1s, 0, (size_t)Ms * L.Cp * sizeof(float), st));      // pad slots carry no gradient
+        PROF("B.ln2" + tg, 0, 5.0 * M * L.C * 4,
+             ln_bwd(0, bt.x1, dxn, bw.ln2_g, nullptr, dy, dx1, G(h, bw.ln2_g), G(h, bw.ln2_b), tokens, tokens, tokens, M, L.C, L.Cp, lnpart, st, dx1s, inv, slots));
         // ---- attention: x1 = x0 + scatter(Wp attn(Wqkv gather(LN1(x0)))) ----
-        SlotGatherA gs{dx1, map, slots, tokens, L.Cp, Ms, FastDiv(slots)};
-        PROF("B.dw_proj", 2.0 * Ms * L.C * L.C, 0,
-             rc = dw_launch(h, gs, PlainA{bt.obuf, L.Ko, Ms}, Ms, L.Cp, L.Ko, G(h, bw.wproj), G(h, bw.bproj), part, st));
+        PROF("B.dw_proj" + tg, 2.0 * Ms * L.C * L.C, 0,
+             rc = dw_launch(h, PlainA{dx1s, L.Cp, Ms}, PlainA{bt.obuf, L.Ko, Ms}, Ms, L.Cp, L.Ko, G(h, bw.wproj), G(h, bw.bproj), part, st));
         if (rc) return rc;
-        PROF("B.dx_proj", 2.0 * Ms * L.C * L.C, 0, gemm_any(gs, bw.wprojT, Ms, L.Ko, L.Cp, EpiStore{dobuf, L.Ko, nullptr}, st));
+        PROF("B.dx_proj" + tg, 2.0 * Ms * L.C * L.C, 0, gemm_rows(dx1s, L.Cp, Ms, bw.wprojT, L.Ko, L.Cp, EpiStore{dobuf, L.Ko, nullptr}, st));
         int arc = 0;
-        PROF("B.attn_core", 10.0 * Ms * 16 * L.C, 0,
+        PROF("B.attn_core" + tg, 10.0 * Ms * 16 * L.C, 0,
              arc = attn_bwd(bt.qkv, bw.bias_tab, dobuf, dqkv, dbias, attpart, Ms / 16, L.nH, L.hdp, L.Nqkv, L.Ko, Hp / 4, Wp / 4, shift > 0,
                             1.0f / std::sqrt((float)L.hd), st));
         if (arc) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "head_dim %d unsupported by the attention backward kernel", L.hd);
         if (bw.tab_off >= 0)
             hipLaunchKernelGGL(bias_table_grad_kernel, dim3(blocks_for(49 * L.nH)), dim3(256), 0, st, dbias, gflat + bw.tab_off, L.nH);
-        PROF("B.dw_qkv", 2.0 * Ms * L.C * 3 * L.C, 0,
+        PROF("B.dw_qkv" + tg, 2.0 * Ms * L.C * 3 * L.C, 0,
              rc = dw_launch(h, PlainA{dqkv, L.Nqkv, Ms}, PlainA{bt.xn1, L.Cp, Ms}, Ms, L.Nqkv, L.Cp, G(h, bw.wqkv), G(h, bw.bqkv), part, st));
         if (rc) return rc;
-        PROF("B.dx_qkv", 2.0 * Ms * L.C * 3 * L.C, 0, gemm_rows(dqkv, L.Nqkv, Ms, bw.wqkvT, L.Cp, L.Nqkv, EpiStore{dxn, L.Cp, nullptr}, st));
-        PROF("B.ln1", 0, 4.0 * M * L.C * 4,
+        PROF("B.dx_qkv" + tg, 2.0 * Ms * L.C * 3 * L.C, 0, gemm_rows(dqkv, L.Nqkv, Ms, bw.wqkvT, L.Cp, L.Nqkv, EpiStore{dxn, L.Cp, nullptr}, st));
+        PROF("B.ln1" + tg, 0, 4.0 * M * L.C * 4,
              ln_bwd(1, bt.x0, dxn, bw.ln1_g, inv, dx1, dprev, G(h, bw.ln1_g), G(h, bw.ln1_b), tokens, tokens, slots, M, L.C, L.Cp, lnpart, st));
         std::swap(dcur, dprev);
         dy = dcur;

@@ -179,10 +179,11 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(LdA la, LdB lb, int M, int
 #pragma unroll
         for (int b = 0; b < DW_T; ++b) acc[a][b] = zero4(); }
 
-    // each lane moves 6 float4 per operand per chunk: element e -> (row e / 12, float4 column e % 12)
+    // each lane moves 6 float4 per operand per chunk: element e -> (row e / 12, float4 column e % 12).  The NEXT chunk's global loads are
+    // issued before the current chunk's MFMAs (register prefetch): one memory round trip per chunk is hidden behind 72 MFMAs.
     constexpr int V = DW_T * 4;          // float4 per staged row
-    for (int m0 = mbeg + wave * DW_MC; m0 < mend; m0 += 4 * DW_MC) {
-        f32x4 ra[6], rb[6];
+    f32x4 ra[6], rb[6];
+    auto fetch = [&](int m0) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int e = lane + 64 * j; const int row = e / V, c4 = e - row * V;
@@ -194,12 +195,17 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(LdA la, LdB lb, int M, int
             ra[j] = (n0 + col < Np) ? la.load4(ca, n0 + (col & ~15), col & 15) : zero4();
             rb[j] = (k0 + col < Kp) ? lb.load4(cb, k0 + (col & ~15), col & 15) : zero4();
         }
+    };
+    const int mfirst = mbeg + wave * DW_MC;
+    if (mfirst < mend) fetch(mfirst);
+    for (int m0 = mfirst; m0 < mend; m0 += 4 * DW_MC) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int e = lane + 64 * j; const int row = e / V, c4 = e - row * V;
             st4(As + row * DW_LD + 4 * c4, ra[j]);
             st4(Bs + row * DW_LD + 4 * c4, rb[j]);
         }
+        if (m0 + 4 * DW_MC < mend) fetch(m0 + 4 * DW_MC);
         // a wave only reads what it wrote itself: no workgroup barrier, the LDS queue is in order per wave
         __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
@@ -276,6 +282,20 @@ __global__ void reduce_partials_kernel(const float* __restrict__ part, int slice
     for (int k = 0; k < slices; ++k) s += part[(size_t)k * n + i];
     out[i] = s;
 }
+// The same for MANY slices of a SMALL output (a 48 x 48 weight gradient summed over ~2000 slices): a thread per output would walk its
+// slices as one long chain of dependent L2 loads (~1 ms); here a 64-lane wave owns 16 consecutive outputs, lane (q, j) adds slices
+// q, q+4, q+8, ... of output j (coalesced 64 B reads), then the 4 partial sums are joined in the fixed order ((0+1)+(2+3)).
+__global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* __restrict__ part, int slices, long long n, float* __restrict__ out,
+                                                                   int accumulate) {
+    const long long wv = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    const long long i = wv * 16 + j;
+    float s = 0.f;
+    if (i < n) for (int k = q; k < slices; k += 4) s += part[(size_t)k * n + i];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (i < n && q == 0) out[i] = (accumulate ? out[i] : 0.f) + s;
+}
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm backward.  Modes as in ln_rows_kernel; statistics are recomputed from the saved input.
@@ -289,7 +309,8 @@ template <int SEGS, int MODE>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
                                                      const int* __restrict__ map, const float* __restrict__ add, float* __restrict__ dx,
                                                      float* __restrict__ part, int rows_per_clip, int src_rows_per_clip, int dy_rows_per_clip,
-                                                     int total_rows, int C, int Cp, float eps) {
+                                                     int total_rows, int C, int Cp, float eps, float* __restrict__ dx_slots, const int* __restrict__ slot_of,
+                                                     int slots_per_clip) {
     constexpr int MAXV = 6;                       // float4 per thread per segment: Cp <= 384
     extern __shared__ float dyn[];                // [16 groups][2][SEGS*Cp]
     const int sub = threadIdx.x & 15, gl = threadIdx.x >> 4;
@@ -377,6 +398,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                     o[e] = (4 * v + e < C) ? o[e] + rstd * (g[e] * gm[e] - c1 - xh * c2) : 0.f;
                 }
                 st4(dp[s] + 4 * v, o);
+                // MODE 0 only: a second copy in window-slot order (token -> slot through slot_of), so that the projection's dW / dX GEMMs
+                // read plain rows instead of gathering through the window map
+                if (MODE == 0 && dx_slots) st4(dx_slots + ((size_t)b * slots_per_clip + slot_of[rr]) * Cp + 4 * v, o);
             }
         }
     }
