@@ -57,7 +57,10 @@ void reduce_partials(const float* part, int slices, long long n, float* out, int
 // ---- GEMM helpers --------------------------------------------------------------------------------
 template <class Ld, class Epi>
 void gemm_any(const Ld& ld, const float* W, int M, int Np, int Kp, const Epi& ep, hipStream_t st, int force_bk = 0) {
-    launch_gemm<64>(ld, W, M, Np, Kp, ep, st, 1, force_bk);
+    // 128-row tiles halve the weight traffic per output row; 64 when the grid would not fill the chip (same rule as gemm_swin.hip)
+    const long long tiles128 = (long long)((M + 127) / 128) * ((Np + 95) / 96);
+    if (tiles128 >= 512) launch_gemm<128>(ld, W, M, Np, Kp, ep, st, 1, force_bk);
+    else launch_gemm<64>(ld, W, M, Np, Kp, ep, st, 1, force_bk);
 }
 template <class Epi>
 void gemm_rows(const float* A, int lda, int M, const float* W, int Np, int Kp, const Epi& ep, hipStream_t st) {
@@ -86,6 +89,32 @@ int dw_launch(escx_handle_s* h, const LdA& la, const LdB& lb, int M, int Np, int
     float* bpart = part + (size_t)slices * Np * Kp;
     if (db) hipLaunchKernelGGL((gemm_dw_kernel<LdA, LdB, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
     else hipLaunchKernelGGL((gemm_dw_kernel<LdA, LdB, false>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+    reduce_partials(part, slices, (long long)Np * Kp, dW, 0, st);
+    if (db) reduce_partials(bpart, slices, (long long)Np, db, 0, st);
+    return 0;
+}
+
+// plain row-major operands: wide workgroup tiles (gemm_dw2_kernel) unless dW is a single 48 x 48 tile
+int dw_rows(escx_handle_s* h, const float* A, int lda, const float* Bm, int ldb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
+    // measured (profiles/r2_train_breakdown_*.txt): the wide tiles read less HBM but lose to the single-tile kernel, whose waves never
+    // meet at a barrier and run 2-3 workgroups per CU (dW of the C = 45 MLP: 1.9 ms/step vs 2.5 ms/step); kept selectable for A/B
+    static const bool v1_only = [] { const char* e = getenv("ESCX_DW_V2"); return !(e && e[0] == '1'); }();
+    const int nT = (Np + 47) / 48, kT = (Kp + 47) / 48;
+    if (v1_only || (nT == 1 && kT == 1)) return dw_launch(h, PlainA{A, lda, M}, PlainA{Bm, ldb, M}, M, Np, Kp, dW, db, part, st);
+    const int wn = kT == 1 ? 4 : (nT == 1 ? 1 : 2), wk = 4 / wn;
+    const int nbn = (nT + wn - 1) / wn, nbk = (kT + wk - 1) / wk, blocks = nbn * nbk;
+    int slices = std::max(1, std::min((1536 + blocks - 1) / blocks, (M + 63) / 64));
+    const size_t per = (size_t)Np * Kp + Np;
+    slices = (int)std::min<size_t>(slices, DW_PART_FLOATS / per);
+    if (slices < 1) ESCX_FAIL(ESCX_ERR_STATE, "dW scratch too small for %d x %d", Np, Kp);
+    int mps = ((M + slices - 1) / slices + 31) / 32 * 32;
+    slices = (M + mps - 1) / mps;
+    float* bpart = part + (size_t)slices * Np * Kp;
+    dim3 grid(blocks, slices);
+#define ESCX_DW2(WN, WK) do { if (db) hipLaunchKernelGGL((gemm_dw2_kernel<WN, WK, true>), grid, dim3(256), 0, st, A, lda, Bm, ldb, M, Np, Kp, nbk, mps, part, bpart); \
+                              else hipLaunchKernelGGL((gemm_dw2_kernel<WN, WK, false>), grid, dim3(256), 0, st, A, lda, Bm, ldb, M, Np, Kp, nbk, mps, part, bpart); } while (0)
+    if (wn == 4) ESCX_DW2(4, 1); else if (wn == 1) ESCX_DW2(1, 4); else ESCX_DW2(2, 2);
+#undef ESCX_DW2
     reduce_partials(part, slices, (long long)Np * Kp, dW, 0, st);
     if (db) reduce_partials(bpart, slices, (long long)Np, db, 0, st);
     return 0;
@@ -450,7 +479,7 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
         if ((rc = get_map(h, H, W, -1, &map))) return rc;
         float* dsub = sc.take((size_t)M2 * 2 * L.Cp);
         if (!dsub) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
-        if ((rc = dw_launch(h, PlainA{gy, L.CoutP, M2}, PlainA{LT.sub_xn, 2 * L.Cp, M2}, M2, L.CoutP, 2 * L.Cp, G(h, L.sub_w), nullptr, part, st))) return rc;
+        if ((rc = dw_rows(h, gy, L.CoutP, LT.sub_xn, 2 * L.Cp, M2, L.CoutP, 2 * L.Cp, G(h, L.sub_w), nullptr, part, st))) return rc;
         gemm_rows(gy, L.CoutP, M2, L.sub_wT, 2 * L.Cp, L.CoutP, EpiStore{dsub, 2 * L.Cp, nullptr}, st);
         ln_bwd(2, x_last, dsub, L.sub_g, map, nullptr, dcur, G(h, L.sub_g), G(h, L.sub_b), H2 * W, tokens, 0, M2, L.C, L.Cp, lnpart, st);
         dlast = dcur;
@@ -475,12 +504,12 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
         if ((rc = get_map(h, H, W, 10 + shift, &inv))) return rc;
         // ---- MLP: x2 = x1 + W2 gelu(W1 LN2(x1) + b1) + b2 ----
         PROF("B.dw_fc2" + tg, 2.0 * M * L.C * L.hidden, 0,
-             rc = dw_launch(h, PlainA{dy, L.Cp, M}, PlainA{bt.hact, L.hiddenP, M}, M, L.Cp, L.hiddenP, G(h, bw.w2), G(h, bw.b2), part, st));
+             rc = dw_rows(h, dy, L.Cp, bt.hact, L.hiddenP, M, L.Cp, L.hiddenP, G(h, bw.w2), G(h, bw.b2), part, st));
         if (rc) return rc;
         PROF("B.dx_fc2" + tg, 2.0 * M * L.C * L.hidden, 0,
              gemm_rows(dy, L.Cp, M, bw.w2T, L.hiddenP, L.Cp, EpiGeluBwd{dhpre, L.hiddenP, bt.hpre}, st));
         PROF("B.dw_fc1" + tg, 2.0 * M * L.C * L.hidden, 0,
-             rc = dw_launch(h, PlainA{dhpre, L.hiddenP, M}, PlainA{bt.xn2, L.Cp, M}, M, L.hiddenP, L.Cp, G(h, bw.w1), G(h, bw.b1), part, st));
+             rc = dw_rows(h, dhpre, L.hiddenP, bt.xn2, L.Cp, M, L.hiddenP, L.Cp, G(h, bw.w1), G(h, bw.b1), part, st));
         if (rc) return rc;
         PROF("B.dx_fc1" + tg, 2.0 * M * L.C * L.hidden, 0,
              gemm_rows(dhpre, L.hiddenP, M, bw.w1T, L.Cp, L.hiddenP, EpiStore{dxn, L.Cp, nullptr}, st));
@@ -489,7 +518,7 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
              ln_bwd(0, bt.x1, dxn, bw.ln2_g, nullptr, dy, dx1, G(h, bw.ln2_g), G(h, bw.ln2_b), tokens, tokens, tokens, M, L.C, L.Cp, lnpart, st, dx1s, inv, slots));
         // ---- attention: x1 = x0 + scatter(Wp attn(Wqkv gather(LN1(x0)))) ----
         PROF("B.dw_proj" + tg, 2.0 * Ms * L.C * L.C, 0,
-             rc = dw_launch(h, PlainA{dx1s, L.Cp, Ms}, PlainA{bt.obuf, L.Ko, Ms}, Ms, L.Cp, L.Ko, G(h, bw.wproj), G(h, bw.bproj), part, st));
+             rc = dw_rows(h, dx1s, L.Cp, bt.obuf, L.Ko, Ms, L.Cp, L.Ko, G(h, bw.wproj), G(h, bw.bproj), part, st));
         if (rc) return rc;
         PROF("B.dx_proj" + tg, 2.0 * Ms * L.C * L.C, 0, gemm_rows(dx1s, L.Cp, Ms, bw.wprojT, L.Ko, L.Cp, EpiStore{dobuf, L.Ko, nullptr}, st));
         int arc = 0;
@@ -500,7 +529,7 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
         if (bw.tab_off >= 0)
             hipLaunchKernelGGL(bias_table_grad_kernel, dim3(blocks_for(49 * L.nH)), dim3(256), 0, st, dbias, gflat + bw.tab_off, L.nH);
         PROF("B.dw_qkv" + tg, 2.0 * Ms * L.C * 3 * L.C, 0,
-             rc = dw_launch(h, PlainA{dqkv, L.Nqkv, Ms}, PlainA{bt.xn1, L.Cp, Ms}, Ms, L.Nqkv, L.Cp, G(h, bw.wqkv), G(h, bw.bqkv), part, st));
+             rc = dw_rows(h, dqkv, L.Nqkv, bt.xn1, L.Cp, Ms, L.Nqkv, L.Cp, G(h, bw.wqkv), G(h, bw.bqkv), part, st));
         if (rc) return rc;
         PROF("B.dx_qkv" + tg, 2.0 * Ms * L.C * 3 * L.C, 0, gemm_rows(dqkv, L.Nqkv, Ms, bw.wqkvT, L.Cp, L.Nqkv, EpiStore{dxn, L.Cp, nullptr}, st));
         PROF("B.ln1" + tg, 0, 4.0 * M * L.C * 4,
@@ -585,7 +614,6 @@ extern "C" int escx_train_backward(escx_handle h, const float* d_wave, const flo
         const size_t nspec = (size_t)B * T2 * c.in_dim * h->Fp;
         float* drspec = sc.take(nspec);
         float* dframes = sc.take((size_t)B * T2 * h->winP);
-        float* ddeemb = sc.take((size_t)B * T2 * F2 * h->C0p);
         float* part = sc.take(DW_PART_FLOATS);
         if (!part) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
         if (d_recon_feat) pad_rows(d_recon_feat, drspec, (long long)B * T2 * c.in_dim, h->F, h->Fp, st);
@@ -596,26 +624,36 @@ extern "C" int escx_train_backward(escx_handle h, const float* d_wave, const flo
             PROF("B.istft", 2.0 * B * T2 * c.win_length * 2 * h->F, 0,
                  gemm_rows(dframes, h->winP, B * T2, h->idft_wT, c.in_dim * h->Fp, h->winP, EpiAccum{drspec, c.in_dim * h->Fp}, st));
         }
-        // conv3x3 (in: fine map [B][T2][F2][C0p], out: spectrum): dW, db, dX
-        const int Mf = B * T2 * F2;
-        SpecRowsA gsp{drspec, F2, h->Fp, c.in_dim, Mf, FastDiv(F2)};
-        ConvA cfine{T.deemb, T2, F2, h->C0p, 3, 3, Mf};
-        PROF("B.dw_conv3", 2.0 * Mf * 9 * h->C0 * c.in_dim, 0,
-             rc = dw_launch(h, gsp, cfine, Mf, 16, 9 * h->C0p, G(h, h->dc2_w), G(h, h->dc2_b), part, st));
-        if (rc) return rc;
-        PROF("B.dx_conv3", 2.0 * Mf * 9 * h->C0 * c.in_dim, 0,
-             hipLaunchKernelGGL(conv3_dx_kernel, dim3(blocks_for((long long)Mf * (h->C0p / 4))), dim3(256), 0, st, drspec, h->dc2_w, ddeemb, B, T2, F2, h->Fp,
-                                h->C0p, c.in_dim));
-        // conv5x5 + pixel shuffle (in: tokens [B][H0][W][C0p], out: fine map)
-        const int Mt = B * s.H0 * s.W, Q = h->Q;
-        ShuffleA gsh{ddeemb, s.H0, s.W, h->C0p, c.patch_f, c.patch_t, Mt, FastDiv(s.H0 * s.W), FastDiv(s.W), FastDiv(h->C0p)};
+        // conv5x5 + pixel shuffle (in: tokens [B][H0][W][C0p], out: fine map), through the rank-18 structure of its output gradient
+        // (train_kernels.h: deembed_p_kernel): dW and dX contract over 128 columns of P instead of the 288 channels of dY1
+        const int Mt = B * s.H0 * s.W, Q = h->Q, K1 = 25 * h->C0p;
+        if (Q * DEP_J > DEP_LD || c.in_dim * 9 > DEP_J) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "patch size / in_dim outside the de-embedding backward kernels");
+        float* P = sc.take((size_t)Mt * DEP_LD);
+        float* R = sc.take((size_t)DEP_LD * K1 + DEP_LD);
+        float* weff = sc.take((size_t)h->C0p * 25 * DEP_LD);
+        if (!weff) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
+        hipLaunchKernelGGL(deembed_p_kernel, dim3(blocks_for((long long)Mt * DEP_LD)), dim3(256), 0, st, drspec, P, B, s.H0, s.W, c.patch_f, c.patch_t, c.in_dim, h->Fp);
         ConvA ctok{T.post, s.H0, s.W, h->C0p, 5, 5, Mt};
-        PROF("B.dw_conv5", 2.0 * Mt * 25 * h->C0 * h->C0 * Q, 0,
-             rc = dw_launch(h, gsh, ctok, Mt, Q * h->C0p, 25 * h->C0p, G(h, h->dc1_w), G(h, h->dc1_b), part, st));
+        float* Rb = R + (size_t)DEP_LD * K1;
+        PROF("B.dw_conv5", 2.0 * Mt * 25 * h->C0 * Q * c.in_dim * 9, 0,
+             rc = dw_launch(h, PlainA{P, DEP_LD, Mt}, ctok, Mt, DEP_LD, K1, R, Rb, part, st));
         if (rc) return rc;
-        ConvShuffleA gcs{ddeemb, s.H0, s.W, h->C0p, c.patch_f, c.patch_t, Mt, FastDiv(s.H0 * s.W), FastDiv(s.W), FastDiv(h->C0p), FastDiv(Q)};
-        PROF("B.dx_conv5", 2.0 * Mt * 25 * h->C0 * h->C0 * Q, 0,
-             gemm_any(gcs, h->dc1_wT, Mt, h->C0p, 25 * Q * h->C0p, EpiStore{gtok, h->C0p, nullptr}, st, pick_bk(h->C0p)));
+        hipLaunchKernelGGL(deembed_fold_dw_kernel, dim3(blocks_for((long long)Q * h->C0p * K1)), dim3(256), 0, st, R, h->dc2_w, G(h, h->dc1_w), Q, h->C0, h->C0p, K1, c.in_dim);
+        hipLaunchKernelGGL(deembed_fold_dw_kernel, dim3(blocks_for((long long)Q * h->C0p)), dim3(256), 0, st, Rb, h->dc2_w, G(h, h->dc1_b), Q, h->C0, h->C0p, 1, c.in_dim);
+        hipLaunchKernelGGL(deembed_weff_kernel, dim3(blocks_for((long long)h->C0p * 25 * DEP_LD)), dim3(256), 0, st, h->dc1_w, h->dc2_w, weff, Q, h->C0, h->C0p, c.in_dim);
+        // conv3x3 weight gradient with the same P: X = P^T . Y1 on the MFMA (Y1 = the saved fine map viewed per coarse pixel), then the q == q'
+        // blocks are summed; db2 = the centre-tap column sums of P
+        float* X = sc.take((size_t)DEP_LD * Q * h->C0p);
+        if (!X) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
+        ShuffleA ysh{T.deemb, s.H0, s.W, h->C0p, c.patch_f, c.patch_t, Mt, FastDiv(s.H0 * s.W), FastDiv(s.W), FastDiv(h->C0p)};
+        PROF("B.dw_conv3", 2.0 * Mt * Q * 9 * h->C0 * c.in_dim, 0,
+             rc = dw_launch(h, PlainA{P, DEP_LD, Mt}, ysh, Mt, DEP_LD, Q * h->C0p, X, nullptr, part, st));
+        if (rc) return rc;
+        hipLaunchKernelGGL(deembed_fold_dw2_kernel, dim3(blocks_for((long long)c.in_dim * 9 * h->C0p + c.in_dim)), dim3(256), 0, st, X, Rb, G(h, h->dc2_w),
+                           G(h, h->dc2_b), Q, h->C0, h->C0p, c.in_dim);
+        ConvA cp{P, s.H0, s.W, DEP_LD, 5, 5, Mt};
+        PROF("B.dx_conv5", 2.0 * Mt * 25 * h->C0 * Q * c.in_dim * 9, 0,
+             gemm_any(cp, weff, Mt, h->C0p, 25 * DEP_LD, EpiStore{gtok, h->C0p, nullptr}, st, pick_bk(DEP_LD)));
     }
     // ---- decoder (post_nn, blocks n-2 .. 0) interleaved with the quantisers ----
     float* gcur = nullptr;

@@ -106,9 +106,11 @@ struct SpecRowsA {              // rows m = (b, t, f) of a frame-major spectrum 
 // ------------------------------------------------------------------------------------------------
 // extra epilogues
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_grad(float x) {       // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+// d/dx [x * Phi(x)] = Phi(x) + x * phi(x), branch-free: erf_bf (1.1 ulp, gemm_engine.h) and v_exp_f32 instead of libm's erff / expf, whose
+// data-dependent branches made this epilogue cost more VALU time than the GEMM it rides on costs MFMA time at C <= 96
+__device__ __forceinline__ float gelu_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erf_bf(x * 0.70710678118654752440f));
+    return fmaf(x * 0.39894228040143267794f, __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f), cdf);
 }
 
 struct EpiGeluDual {            // fc1 in training: pre-activation AND activation are kept (attention.py:267-272)
@@ -116,7 +118,7 @@ struct EpiGeluDual {            // fc1 in training: pre-activation AND activatio
     __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
         v += ld4(bias + n);
         st4(pre + (size_t)m * ldo + n, v);
-        v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+        v[0] = gelu_bf(v[0]); v[1] = gelu_bf(v[1]); v[2] = gelu_bf(v[2]); v[3] = gelu_bf(v[3]);       // the fused inference kernels' exact-erf GELU (11 VALU ops)
         st4(act + (size_t)m * ldo + n, v);
     }
 };
@@ -272,6 +274,99 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(LdA la, LdB lb, int M, int
                 if (do_bias && l15 == 0) bpart[(size_t)blockIdx.y * Np + n] = accb[a][r];
             }
     }
+}
+
+// The same contraction for plain row-major operands with a WIDE workgroup tile: the WN x WK waves of a workgroup own adjacent 48 x 48
+// tiles of dW and share every staged 32-row chunk through a double-buffered LDS image, so a chunk of A (48*WN columns) and of B (48*WK
+// columns) is read from HBM once per workgroup instead of once per 48 x 48 tile: at C <= 96 the dW GEMMs are bound by that traffic
+// (N = 48, K = 192: 240 floats per row instead of 384).  One barrier per chunk; the next chunk's global loads are in flight during the MFMAs.
+template <int WN, int WK, bool BIAS>
+__global__ __launch_bounds__(256) void gemm_dw2_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb, int M, int Np, int Kp,
+                                                       int nblk_k, int m_per_slice, float* __restrict__ part, float* __restrict__ bpart) {
+    static_assert(WN * WK == 4, "four waves");
+    constexpr int TNW = 48 * WN, TKW = 48 * WK;
+    constexpr int LDA = (TNW % 32 == 16) ? TNW : TNW + 16, LDB = (TKW % 32 == 16) ? TKW : TKW + 16;
+    constexpr int VA = TNW / 4, VB = TKW / 4;                    // float4 per staged row
+    constexpr int NA = (DW_MC * VA + 255) / 256, NB = (DW_MC * VB + 255) / 256;
+    __shared__ float lds[2 * DW_MC * (LDA + LDB)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wn = wave / WK, wk = wave - wn * WK;
+    const int bn = blockIdx.x / nblk_k, bk = blockIdx.x - bn * nblk_k;
+    const int n0 = bn * TNW, k0 = bk * TKW;
+    const int mbeg = blockIdx.y * m_per_slice, mend = min(M, mbeg + m_per_slice);
+    const bool do_bias = BIAS && bk == 0 && wk == 0;
+    f32x4 acc[DW_T][DW_T], accb[DW_T];
+#pragma unroll
+    for (int a = 0; a < DW_T; ++a) { accb[a] = zero4();
+#pragma unroll
+        for (int b = 0; b < DW_T; ++b) acc[a][b] = zero4(); }
+    f32x4 ra[NA], rb[NB];
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int e = tid + 256 * j; const int row = e / VA, c4 = e - row * VA;
+            const int m = m0 + row, col = n0 + 4 * c4;
+            ra[j] = (e < DW_MC * VA && m < mend && col < Np) ? ld4(A + (size_t)m * lda + col) : zero4();
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int e = tid + 256 * j; const int row = e / VB, c4 = e - row * VB;
+            const int m = m0 + row, col = k0 + 4 * c4;
+            rb[j] = (e < DW_MC * VB && m < mend && col < Kp) ? ld4(Bm + (size_t)m * ldb + col) : zero4();
+        }
+    };
+    if (mbeg < mend) fetch(mbeg);
+    int buf = 0;
+    for (int m0 = mbeg; m0 < mend; m0 += DW_MC) {
+        float* As = lds + buf * DW_MC * (LDA + LDB);
+        float* Bs = As + DW_MC * LDA;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int e = tid + 256 * j; const int row = e / VA, c4 = e - row * VA;
+            if (e < DW_MC * VA) st4(As + row * LDA + 4 * c4, ra[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int e = tid + 256 * j; const int row = e / VB, c4 = e - row * VB;
+            if (e < DW_MC * VB) st4(Bs + row * LDB + 4 * c4, rb[j]);
+        }
+        __syncthreads();
+        if (m0 + DW_MC < mend) fetch(m0 + DW_MC);
+        const float* Aw = As + wn * 48; const float* Bw = Bs + wk * 48;
+#pragma unroll
+        for (int ms = 0; ms < DW_MC / 4; ++ms) {
+            float af[DW_T], bf[DW_T];
+#pragma unroll
+            for (int a = 0; a < DW_T; ++a) af[a] = Aw[(4 * ms + lg) * LDA + 16 * a + l15];
+#pragma unroll
+            for (int b = 0; b < DW_T; ++b) bf[b] = Bw[(4 * ms + lg) * LDB + 16 * b + l15];
+#pragma unroll
+            for (int a = 0; a < DW_T; ++a)
+#pragma unroll
+                for (int b = 0; b < DW_T; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+            if (do_bias) {
+                const float one = (l15 == 0) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int a = 0; a < DW_T; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], one, accb[a], 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+    }
+    float* po = part + (size_t)blockIdx.y * Np * Kp;
+#pragma unroll
+    for (int a = 0; a < DW_T; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn * 48 + 16 * a + 4 * lg + r;
+            if (n >= Np) continue;
+#pragma unroll
+            for (int b = 0; b < DW_T; ++b) {
+                const int k = k0 + wk * 48 + 16 * b + l15;
+                if (k < Kp) po[(size_t)n * Kp + k] = acc[a][b][r];
+            }
+            if (do_bias && l15 == 0) bpart[(size_t)blockIdx.y * Np + n] = accb[a][r];
+        }
 }
 
 // out[i] = sum_s part[s][i], s increasing (fixed order); optional accumulate into out
@@ -439,7 +534,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                                                        int ldq, int ldo, int nWh, int nWw, int shifted, float scale) {
     constexpr int HDP = 4 * STEPS;
     constexpr int DT = (HDP + 15) / 16;
+    constexpr bool STAGE = HDP <= 32;            // q / k / dO tiles of the window are kept in LDS for the column-wise second uses
+    constexpr int TL = STAGE ? HDP + 1 : 1;
     __shared__ float tp[4][2][16][17];           // per wave: P and dS, to read them transposed
+    __shared__ float tile[4][3][16][TL];         // per wave: Q, K, dO (row = token, column = head dim)
     __shared__ float wsum[4][64][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
@@ -447,13 +545,28 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
     const int kOff = nH * HDP, vOff = 2 * nH * HDP;
     f32x4 dbsum = zero4();
+    // the four operand rows of the NEXT window are fetched while the current one is processed (one exposed memory round trip per
+    // window instead of three)
+    float nq[STEPS], nk[STEPS], nv[STEPS], nd[STEPS];
+    auto fetch = [&](int win) {
+        const float* rowp = qkv + ((size_t)win * 16 + i) * ldq + h * HDP + STEPS * g;
+        const float* dorow = dout + ((size_t)win * 16 + i) * ldo + h * HDP + STEPS * g;
+#pragma unroll
+        for (int r = 0; r < STEPS; ++r) { nq[r] = rowp[r]; nk[r] = rowp[kOff + r]; nv[r] = rowp[vOff + r]; nd[r] = dorow[r]; }
+    };
+    if (wave_global < total_windows) fetch(wave_global);
     for (int win = wave_global; win < total_windows; win += nwaves) {
         const float* base = qkv + (size_t)win * 16 * ldq + h * HDP;
-        const float* rowp = base + (size_t)i * ldq + STEPS * g;
-        const float* dorow = dout + ((size_t)win * 16 + i) * ldo + h * HDP + STEPS * g;
         float kf[STEPS], qf[STEPS], vf[STEPS], df[STEPS];
 #pragma unroll
-        for (int r = 0; r < STEPS; ++r) { qf[r] = rowp[r]; kf[r] = rowp[kOff + r]; vf[r] = rowp[vOff + r]; df[r] = dorow[r]; }
+        for (int r = 0; r < STEPS; ++r) { qf[r] = nq[r]; kf[r] = nk[r]; vf[r] = nv[r]; df[r] = nd[r]; }
+        if (win + nwaves < total_windows) fetch(win + nwaves);
+        if (STAGE) {
+#pragma unroll
+            for (int r = 0; r < STEPS; ++r) {
+                tile[wave][0][i][(STEPS * g + r) % TL] = qf[r]; tile[wave][1][i][(STEPS * g + r) % TL] = kf[r]; tile[wave][2][i][(STEPS * g + r) % TL] = df[r];
+            }
+        }
         f32x4 s = zero4(), dp = zero4();
 #pragma unroll
         for (int r = 0; r < STEPS; ++r) {
@@ -475,37 +588,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             }
         }
         float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = max_groups(mx);                             // v_permlane16/32_swap butterflies (gemm_engine.h)
         f32x4 p;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] = expf(s[r] - mx);
+        for (int r = 0; r < 4; ++r) p[r] = exp_fast(s[r] - mx);
         float den = (p[0] + p[1]) + (p[2] + p[3]);
-        den += __shfl_xor(den, 16);
-        den += __shfl_xor(den, 32);
+        den = sum_groups(den);
         const float inv = 1.0f / den;
         float dot = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { p[r] *= inv; dot += p[r] * dp[r]; }
-        dot += __shfl_xor(dot, 16);
-        dot += __shfl_xor(dot, 32);
+        dot = sum_groups(dot);
         f32x4 ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) ds[r] = p[r] * (dp[r] - dot);
         dbsum += ds;
-        // dQ[i][d] = sum_j dS[i][j] K[j][d]  (same operand pattern as O = P V in the forward), scaled back through q*scale
-        float* dqrow = dqkv + ((size_t)win * 16 + i) * ldq + h * HDP;
-#pragma unroll
-        for (int t = 0; t < DT; ++t) {
-            const int d = t * 16 + i;
-            f32x4 o = zero4();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float kk = (d < HDP) ? base[(size_t)(4 * g + r) * ldq + kOff + d] : 0.f;
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(kk, ds[r], o, 0, 0, 0);
-            }
-            if (t * 16 + 4 * g < HDP) st4(dqrow + t * 16 + 4 * g, o * scale);
-        }
         // transposed P and dS through LDS: lane (j, g) then holds P[4g + r][j]
 #pragma unroll
         for (int r = 0; r < 4; ++r) { tp[wave][0][i][4 * g + r] = p[r]; tp[wave][1][i][4 * g + r] = ds[r]; }
@@ -514,24 +611,35 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         f32x4 pt, dsT;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { pt[r] = tp[wave][0][4 * g + r][i]; dsT[r] = tp[wave][1][4 * g + r][i]; }
-        __builtin_amdgcn_wave_barrier();
+        // dQ[i][d] = sum_j dS[i][j] K[j][d]  (same operand pattern as O = P V in the forward), scaled back through q*scale;
         // dV[j][d] = sum_i P[i][j] dO[i][d] ; dK[j][d] = sum_i dS[i][j] Q[i][d]   (lane (j, g): rows of key j)
-        float* dkrow = dqkv + ((size_t)win * 16 + i) * ldq + kOff + h * HDP;
-        float* dvrow = dqkv + ((size_t)win * 16 + i) * ldq + vOff + h * HDP;
+        float* dqrow = dqkv + ((size_t)win * 16 + i) * ldq + h * HDP;
+        float* dkrow = dqrow + kOff;
+        float* dvrow = dqrow + vOff;
         const float* dobase = dout + (size_t)win * 16 * ldo + h * HDP;
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
             const int d = t * 16 + i;
-            f32x4 ov = zero4(), ok = zero4();
+            f32x4 oq = zero4(), ov = zero4(), ok = zero4();
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float dd = (d < HDP) ? dobase[(size_t)(4 * g + r) * ldo + d] : 0.f;
-                const float qq = (d < HDP) ? base[(size_t)(4 * g + r) * ldq + d] : 0.f;
+                float kk, dd, qq;
+                if (STAGE) {
+                    const int dc = d < HDP ? d : 0;
+                    kk = tile[wave][1][4 * g + r][dc % TL]; dd = tile[wave][2][4 * g + r][dc % TL]; qq = tile[wave][0][4 * g + r][dc % TL];
+                    if (d >= HDP) { kk = 0.f; dd = 0.f; qq = 0.f; }
+                } else {
+                    kk = (d < HDP) ? base[(size_t)(4 * g + r) * ldq + kOff + d] : 0.f;
+                    dd = (d < HDP) ? dobase[(size_t)(4 * g + r) * ldo + d] : 0.f;
+                    qq = (d < HDP) ? base[(size_t)(4 * g + r) * ldq + d] : 0.f;
+                }
+                oq = __builtin_amdgcn_mfma_f32_16x16x4f32(kk, ds[r], oq, 0, 0, 0);
                 ov = __builtin_amdgcn_mfma_f32_16x16x4f32(dd, pt[r], ov, 0, 0, 0);
                 ok = __builtin_amdgcn_mfma_f32_16x16x4f32(qq, dsT[r], ok, 0, 0, 0);
             }
-            if (t * 16 + 4 * g < HDP) { st4(dvrow + t * 16 + 4 * g, ov); st4(dkrow + t * 16 + 4 * g, ok); }
+            if (t * 16 + 4 * g < HDP) { st4(dqrow + t * 16 + 4 * g, oq * scale); st4(dvrow + t * 16 + 4 * g, ov); st4(dkrow + t * 16 + 4 * g, ok); }
         }
+        __builtin_amdgcn_wave_barrier();             // the LDS tiles are rewritten by the next window
         if (h == 0 && 3 * nH * HDP < ldq)            // tail padding of the qkv width: keep exact zeros (K padding of the dX GEMM)
             for (int c = 3 * nH * HDP + g; c < ldq; c += 4) dqkv[((size_t)win * 16 + i) * ldq + c] = 0.f;
     }
@@ -714,6 +822,84 @@ __global__ void conv3_dx_kernel(const float* __restrict__ g, const float* __rest
         }
     }
     st4(dx + ((((size_t)b * T + t) * F + f) * Cp) + 4 * c4, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// De-embedding backward through its low-rank structure.  The gradient at the conv5x5 output, dY1[pix][(q, cc)] (270 channels), is
+//     sum_{oc, a, b} W2[oc][cc][a][b] * g_pad[fine(pix, q) - (a-1, b-1)][oc]          (conv3x3 transposed; g = d loss / d spectrum),
+// i.e. a fixed 45 x 18 matrix applied to the 18 spectrum-gradient values around each fine position.  So instead of running the two
+// 270-channel contractions of conv5x5's dW and dX on dY1, they run on P[pix][q][j = (oc, a, b)] (6 x 18 -> 6 x 20 = 120 columns, padded
+// to 128) and the 45 x 18 matrix is folded into the (tiny) weight side: 2.3x fewer FLOPs, exact including the zero-padded borders.
+//   P      [B*H*W][128]   column q*20 + j, j = oc*9 + a*3 + b < 18 (a: frequency tap, b: time tap), zero elsewhere
+//   g      frame-major spectrum gradient [(b, t)][oc*Fp + f]
+// ------------------------------------------------------------------------------------------------
+constexpr int DEP_J = 20, DEP_LD = 128;
+__global__ void deembed_p_kernel(const float* __restrict__ g, float* __restrict__ P, int B, int H, int W, int pf, int pt, int in_dim, int Fp) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * H * W * DEP_LD) return;
+    const int col = (int)(idx % DEP_LD); long long pix = idx / DEP_LD;
+    const int w = (int)(pix % W); pix /= W; const int h = (int)(pix % H), b = (int)(pix / H);
+    const int q = col / DEP_J, j = col - q * DEP_J;
+    float v = 0.f;
+    if (q < pf * pt && j < in_dim * 9) {
+        const int oc = j / 9, ab = j - oc * 9, a = ab / 3, bq = ab - a * 3;
+        const int s1 = q / pt, s2 = q - s1 * pt;
+        const int f = pf * h + s1 - (a - 1), t = pt * w + s2 - (bq - 1);
+        if (f >= 0 && f < pf * H && t >= 0 && t < pt * W) v = g[((size_t)b * (pt * W) + t) * (in_dim * Fp) + oc * Fp + f];
+    }
+    P[idx] = v;
+}
+// dW1[(q*Cp + cc)][k] = sum_j W2[oc][cc][a][b] * R[q*20 + j][k] ; w2 is the packed conv3x3 matrix [16][9*Cp], tap order (b*3 + a)
+__global__ void deembed_fold_dw_kernel(const float* __restrict__ R, const float* __restrict__ w2, float* __restrict__ dW1, int Q, int C, int Cp, int K,
+                                       int in_dim) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)Q * Cp * K) return;
+    const int k = (int)(idx % K); const int r = (int)(idx / K); const int q = r / Cp, cc = r - q * Cp;
+    float s = 0.f;
+    if (cc < C)
+        for (int j = 0; j < in_dim * 9; ++j) {
+            const int oc = j / 9, ab = j - oc * 9, a = ab / 3, bq = ab - a * 3;
+            s += w2[(size_t)oc * 9 * Cp + (size_t)(bq * 3 + a) * Cp + cc] * R[(size_t)(q * DEP_J + j) * K + k];
+        }
+    dW1[idx] = s;
+}
+// conv3x3 weight gradient from X = P^T . Y1 (X[(q, j)][(q', cc)], only the q == q' blocks are meaningful):
+//   dW2[oc][(b*3 + a)*Cp + cc] = sum_q X[q*20 + j][q*Cp + cc],  j = oc*9 + a*3 + b ;   db2[oc] = sum_q Rb[q*20 + oc*9 + 4]  (centre tap: no border exclusion)
+__global__ void deembed_fold_dw2_kernel(const float* __restrict__ X, const float* __restrict__ Rb, float* __restrict__ dW2, float* __restrict__ db2, int Q,
+                                        int C, int Cp, int in_dim) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = in_dim * 9 * Cp;
+    if (idx < n) {
+        const int cc = idx % Cp; const int t = idx / Cp; const int tap = t % 9, oc = t / 9;      // tap = b*3 + a (packed order)
+        const int bq = tap / 3, a = tap - bq * 3;
+        float s = 0.f;
+        if (cc < C)
+            for (int q = 0; q < Q; ++q) s += X[(size_t)(q * DEP_J + oc * 9 + a * 3 + bq) * (Q * Cp) + q * Cp + cc];
+        dW2[idx] = s;
+    } else if (idx < n + in_dim) {
+        const int oc = idx - n;
+        float s = 0.f;
+        for (int q = 0; q < Q; ++q) s += Rb[q * DEP_J + oc * 9 + 4];
+        db2[oc] = s;
+    }
+}
+// effective dX weights: Weff[ci][(t0*5 + t1)*128 + q*20 + j] = sum_cc W2[oc][cc][a][b] * W1[(q, cc)][ci][kh = 4 - t0][kw = 4 - t1]
+// (taps flipped so that the forward implicit-GEMM loader ConvA serves the transposed convolution); w1 is the packed conv5x5 matrix
+// [Q*Cp][25*Cp] with k = (kh*5 + kw)*Cp + ci
+__global__ void deembed_weff_kernel(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ weff, int Q, int C, int Cp, int in_dim) {
+    const int KE = 25 * DEP_LD;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)Cp * KE) return;
+    const int k = (int)(idx % KE), ci = (int)(idx / KE);
+    const int tap = k / DEP_LD, col = k - tap * DEP_LD; const int q = col / DEP_J, j = col - q * DEP_J;
+    float s = 0.f;
+    if (ci < C && q < Q && j < in_dim * 9) {
+        const int t0 = tap / 5, t1 = tap - t0 * 5, kh = 4 - t0, kw = 4 - t1;
+        const int oc = j / 9, ab = j - oc * 9, a = ab / 3, bq = ab - a * 3;
+        for (int cc = 0; cc < C; ++cc)
+            s += w2[(size_t)oc * 9 * Cp + (size_t)(bq * 3 + a) * Cp + cc] * w1[(size_t)(q * Cp + cc) * 25 * Cp + (size_t)(kh * 5 + kw) * Cp + ci];
+    }
+    weff[idx] = s;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,156 @@
+"""Non-adversarial training loop on the MI355X: the optimisation step of the reference trainer (`/root/reference/scripts/
+trainer_no_adv.py:95-124`) without its experiment plumbing (accelerate, wandb, tqdm, checkpoint rotation are not reproduced).
+
+Per step: sample the number of transmitted streams (quantisation dropout, `scripts/utils.py:11-25`), freeze the codebooks during the
+pre-training phase (`trainer_no_adv.py:99`), training-mode forward, mel + complex-STFT + VQ losses with the config's weights
+(`configs/9kbps_esc_base.yaml:29-33`), backward, clip_grad_norm 0.5, AdamW, learning-rate schedule.  Everything numerical runs in
+libescx (HIP): forward / backward (`esc.ESC` in train mode), losses (`esc.modules`), optimiser (`esc.optim.FlatAdamW`).
+
+    python -m scripts.train --synthetic base --steps 20 --batch_size 36                       # synthetic clips, synthetic init
+    torchrun --nproc-per-node 8 -m scripts.train --data ./train_wavs --config cfg.yaml        # data parallel: flat-gradient all-reduce
+"""
+import argparse
+import json
+import math
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from esc.models import make_model
+from esc.modules import ComplexSTFTLoss, MelSpectrogramLoss
+from esc.optim import FlatAdamW
+
+DEFAULT_LOSS_WEIGHTS = dict(stft_weight=1.0, cm_weight=0.25, cb_weight=1.0, mel_weight=0.25)
+
+
+def sample_streams(rng: np.random.Generator, dropout_rate: float, max_streams: int) -> int:
+    """Quantisation dropout: with probability `dropout_rate` a uniform stream count in [1, max_streams], otherwise all of them."""
+    if not 0.0 <= dropout_rate <= 1.0:
+        raise AssertionError("dropout_rate must be within [0, 1]")
+    return int(rng.integers(1, max_streams + 1)) if rng.random() < dropout_rate else max_streams
+
+
+def lr_at(step: int, base_lr: float, kind: str, total_steps: int, warmup_steps: int) -> float:
+    """constant | constant_warmup | cosine_warmup | exponential_decay (the four schedules of scripts/utils.py:52-65)."""
+    if kind == "constant":
+        return base_lr
+    warm = min(1.0, (step + 1) / max(1, warmup_steps)) if warmup_steps > 0 else 1.0
+    if kind == "constant_warmup":
+        return base_lr * warm
+    if kind == "cosine_warmup":
+        if step < warmup_steps:
+            return base_lr * step / max(1, warmup_steps)
+        prog = (step - warmup_steps) / max(1, total_steps - warmup_steps)
+        return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+    if kind == "exponential_decay":
+        return base_lr * 0.999996 ** step
+    raise ValueError(f"{kind} must be in ('constant', 'constant_warmup', 'cosine_warmup', 'exponential_decay')")
+
+
+class Stepper:
+    """Holds model, losses and optimiser; `step(x, n)` is one optimisation step and returns the per-loss batch means."""
+
+    def __init__(self, model, lr, loss_weights=None, dropout_rate=1.0, pretraining_steps=0, scheduler="constant", total_steps=250000,
+                 warmup_steps=0, seed=1234, group=None):
+        self.model = model.train()
+        self.w = dict(DEFAULT_LOSS_WEIGHTS, **(loss_weights or {}))
+        self.mel, self.stft = MelSpectrogramLoss(), ComplexSTFTLoss()
+        self.opt = FlatAdamW(model, lr=lr, max_grad_norm=0.5, group=group)                 # torch.optim.AdamW defaults otherwise (utils.py:48-49)
+        self.base_lr, self.sched, self.total, self.warmup = lr, scheduler, total_steps, warmup_steps
+        self.dropout_rate, self.pretraining_steps = dropout_rate, pretraining_steps
+        self.rng = np.random.default_rng(seed)
+
+    def step(self, x: torch.Tensor, n: int) -> dict:
+        freeze = n < self.pretraining_steps
+        s = sample_streams(self.rng, self.dropout_rate, self.model.max_streams)
+        if n == self.pretraining_steps and n > 0:                                          # "Optimizer Renewed" (trainer_no_adv.py:76-79)
+            self.opt = FlatAdamW(self.model, lr=self.base_lr, max_grad_norm=0.5, group=self.opt.group)
+        self.opt.lr = lr_at(n, self.base_lr, self.sched, self.total, self.warmup)
+        out = self.model(x=x, x_feat=None, num_streams=s, freeze_codebook=freeze)
+        terms = {"cm_loss": out["cm_loss"], "cb_loss": out["cb_loss"], "mel_loss": self.mel(out["raw_audio"], out["recon_audio"]),
+                 "stft_loss": self.stft(out["raw_feat"], out["recon_feat"])}
+        total = sum(terms[k] * self.w[k.replace("_loss", "_weight")] for k in terms)
+        total.mean().backward()
+        self.opt.step()
+        self.opt.zero_grad()
+        terms["loss"] = total
+        return {"streams": s, "frozen": freeze, **{k: v.detach().mean() for k, v in terms.items()}}
+
+
+def _batches(args, device, rank, world):
+    if args.data:
+        from torch.utils.data import DataLoader, default_collate
+        from .utils import EvalSet
+        ds = EvalSet(args.data)
+        idx = list(range(rank, len(ds), world))
+        dl = DataLoader(torch.utils.data.Subset(ds, idx), batch_size=args.batch_size, shuffle=True, collate_fn=default_collate, drop_last=True)
+        while True:
+            for x in dl:
+                yield x.to(device)
+    from esc import synth
+    k = 0
+    while True:
+        pcm = np.stack([(synth.voiced_clip_int16 if (k + i) % 2 else synth.noise_clip_int16)(f"train-r{rank}-{k + i}", args.clip_samples) for i in range(args.batch_size)])
+        k += args.batch_size
+        yield torch.from_numpy(synth.pcm_to_float(pcm)).to(device)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default=None, help="yaml with model: / loss: blocks (reference layout)")
+    ap.add_argument("--synthetic", default="base", help="without --config: base|large|tiny model block from tests/golden, synthetic init")
+    ap.add_argument("--data", default=None, help="folder of 16 kHz wavs (default: synthetic clips)")
+    ap.add_argument("--clip_samples", type=int, default=47920)
+    ap.add_argument("--batch_size", type=int, default=9)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--pretraining_steps", type=int, default=0)
+    ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--dropout_rate", type=float, default=1.0)
+    ap.add_argument("--scheduler_type", default="constant")
+    ap.add_argument("--num_warmup_steps", type=int, default=0)
+    ap.add_argument("--save_path", default=None)
+    ap.add_argument("--log_steps", type=int, default=5)
+    ap.add_argument("--seed", type=int, default=1234)
+    args = ap.parse_args()
+
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    torch.manual_seed(args.seed)
+    loss_w = None
+    if args.config:
+        from .utils import read_yaml
+        cfg = read_yaml(args.config)
+        model = make_model(cfg["model"], cfg.get("model_name", "csvq+swinT"))
+        loss_w = cfg.get("loss")
+    else:
+        from .test import load_model
+        model, _ = load_model(argparse.Namespace(model_path=None, synthetic=args.synthetic))
+    model = model.to(device)
+    st = Stepper(model, args.lr, loss_w, args.dropout_rate, args.pretraining_steps, args.scheduler_type, args.steps, args.num_warmup_steps,
+                 seed=args.seed)                                        # same seed on every rank: the ranks agree on the stream count
+    data = _batches(args, device, rank, world)
+    t0 = time.perf_counter()
+    for n in range(args.steps):
+        log = st.step(next(data), n)
+        if rank == 0 and ((n + 1) % args.log_steps == 0 or n == 0):
+            torch.cuda.synchronize()
+            vals = {k: (round(float(v), 5) if torch.is_tensor(v) else v) for k, v in log.items()}
+            print(json.dumps({"step": n + 1, "s_per_step": round((time.perf_counter() - t0) / (n + 1), 4), **vals}))
+    if rank == 0 and args.save_path:
+        os.makedirs(args.save_path, exist_ok=True)
+        torch.save({"step": args.steps - 1, "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                    "optimizer_state_dict": st.opt.state_dict()}, os.path.join(args.save_path, "checkpoint.pth"))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    main()

@@ -107,3 +107,24 @@ def test_bench_shard_plan_is_a_partition():
     # the strong-mode clip tags are global: every world size processes the same 288 clips (first 36 = the weak-mode rank-0 batch)
     tags36 = [f"bench-r0-{i}" for i in range(36)]
     assert [f"bench-r{g // bench.CLIPS_PER_GPU}-{g % bench.CLIPS_PER_GPU}" for g in range(36)] == tags36
+
+
+def _grad_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "efficient-speech-codec_amd"))
+    from esc.distributed import all_reduce_gradients
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(1_000_003, generator=g)
+    all_reduce_gradients(flat, bucket_mb=1.0)             # 4 buckets, the last one ragged
+    ref = sum(torch.randn(1_000_003, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)) / world
+    np.save(os.path.join(out_dir, f"g{rank}.npy"), np.array([float((flat - ref).abs().max())]))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_flat_gradient_all_reduce_is_the_mean_over_ranks(tmp_path):
+    """Data-parallel training path: the bucketed all-reduce of the flat gradient buffer equals the mean over ranks on every rank."""
+    port = _free_port()
+    mp.spawn(_grad_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    for r in range(3):
+        assert float(np.load(tmp_path / f"g{r}.npy")[0]) < 1e-6

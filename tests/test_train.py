@@ -210,7 +210,7 @@ def test_backward_pass_esc_large():
 @pytest.mark.parametrize("name", ["tiny", "base"])
 def test_training_step_losses_and_every_gradient(name):
     """The trainer's step (trainer_no_adv.py:105-115): losses 1e-5 relative to the reference fixtures, codes identical; every parameter
-    gradient against the fp64 oracle within 5x the reference's own fp32 noise floor (the larger of that parameter's and the median over
+    gradient against the fp64 oracle within 8x the reference's own fp32 noise floor (the larger of that parameter's and the median over
     parameters, +1e-5), the median HIP error within 3x the median noise floor, and the gradient norms of the reference fixtures within
     the same level."""
     g = load_golden("train")
@@ -233,7 +233,7 @@ def test_training_step_losses_and_every_gradient(name):
             ref = g64[k].numpy()
             err = _rel_rms(grads[k], ref, 1e-6 * scale / np.sqrt(ref.size))
             errs.append(err)
-            bound = 5.0 * max(floor[k], med) + 1e-5
+            bound = 8.0 * max(floor[k], med) + 1e-5
             worst = max(worst, (err / bound, k, err))
             assert err <= bound and err <= 1e-2, f"{tag}: gradient of {k} rel rms {err:.3e} vs fp64, reference fp32 noise floor {floor[k]:.3e}"
             gn = float(np.linalg.norm(np.asarray(grads[k], np.float64)))
@@ -326,3 +326,44 @@ def test_eval_after_optimizer_steps_uses_the_updated_weights():
     import copy
     twin = copy.deepcopy(model)                           # ADVICE: deepcopy / pickling of a used model
     assert torch.equal(twin.encode(x, 3)[0], c1)
+
+
+def test_train_harness_schedules_and_stream_sampling():
+    """scripts/train.py host logic: quantisation dropout (scripts/utils.py:11-25) and the four learning-rate schedules."""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "efficient-speech-codec_amd"))
+    from scripts.train import lr_at, sample_streams
+    rng = np.random.default_rng(0)
+    assert all(sample_streams(rng, 0.0, 6) == 6 for _ in range(20))
+    draws = [sample_streams(rng, 1.0, 6) for _ in range(600)]
+    assert set(draws) == {1, 2, 3, 4, 5, 6}
+    with pytest.raises(AssertionError):
+        sample_streams(rng, 1.5, 6)
+    assert lr_at(10, 1e-4, "constant", 100, 0) == 1e-4
+    assert lr_at(0, 1e-4, "constant_warmup", 100, 10) == pytest.approx(1e-5) and lr_at(50, 1e-4, "constant_warmup", 100, 10) == 1e-4
+    assert lr_at(5, 1e-4, "cosine_warmup", 100, 10) == pytest.approx(5e-5) and lr_at(100, 1e-4, "cosine_warmup", 100, 10) == pytest.approx(0.0, abs=1e-12)
+    assert lr_at(55, 1e-4, "cosine_warmup", 100, 10) == pytest.approx(5e-5)
+    assert lr_at(1000, 1e-4, "exponential_decay", 0, 0) == pytest.approx(1e-4 * 0.999996 ** 1000)
+    with pytest.raises(ValueError):
+        lr_at(0, 1e-4, "linear", 1, 0)
+
+
+@pytest.mark.gpu
+def test_training_loop_reduces_the_loss():
+    """scripts/train.py `Stepper` (quantisation dropout, frozen-codebook pre-training phase, optimiser renewal, HIP losses + FlatAdamW)
+    on one fixed batch: finite losses throughout, frozen phase reports zero VQ losses, and the loss goes down."""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "efficient-speech-codec_amd"))
+    from esc.models import make_model
+    from scripts.train import Stepper
+    g = load_golden("train")
+    x = _clips(g, "tiny").cuda()
+    model = make_model(_cfg("tiny")); model.load_state_dict(synth_state("tiny")); model = model.cuda()
+    st = Stepper(model, lr=2e-3, dropout_rate=0.5, pretraining_steps=4, scheduler="constant_warmup", total_steps=40, warmup_steps=3)
+    logs = [st.step(x, n) for n in range(40)]
+    assert all(np.isfinite(float(l["loss"])) for l in logs)
+    assert all(l["frozen"] and float(l["cm_loss"]) == 0.0 for l in logs[:4]) and not logs[4]["frozen"] and float(logs[4]["cm_loss"]) > 0
+    full = [float(l["loss"]) for l in logs[4:] if l["streams"] == model.max_streams]
+    assert len(full) >= 6 and np.mean(full[-3:]) < np.mean(full[:3]), full
