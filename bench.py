@@ -334,13 +334,24 @@ def main():
         flops_per_launch = dom["flops"] / dom["calls"]
         bytes_per_launch = dom["bytes"] / dom["calls"]
         mfma_bound = flops_per_launch / PEAK_F32_MFMA >= bytes_per_launch / PEAK_HBM
-        traffic = None
+        # HBM traffic of the dominant kernel: measured by tools/profile_round.sh (rocprofv3 --pmc passes, calibrated by tools/pmc_calib.py)
+        # and only reported when it was taken on THESE kernel sources (the file is stamped with a hash of csrc/)
+        traffic, traffic_note = None, "no PMC file"
         pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dom["name"])
-            except Exception:
-                traffic = None
+                import hashlib
+                pm = json.load(open(pmc))
+                hsh = hashlib.sha256()
+                cs = os.path.join(ROOT, "efficient-speech-codec_amd", "csrc")
+                for f in sorted(os.listdir(cs)):
+                    hsh.update(f.encode()); hsh.update(open(os.path.join(cs, f), "rb").read())
+                if pm.get("_csrc_sha256") == hsh.hexdigest():
+                    traffic, traffic_note = pm.get(dom["name"]), f"rocprofv3 PMC, calibration {pm.get('_calibration')}"
+                else:
+                    traffic_note = "profiles/pmc_dominant.json was measured on different kernel sources: not reported"
+            except Exception as e:
+                traffic_note = f"unreadable PMC file: {e}"
         if mfma_bound:
             ach = flops_per_launch / avg_s
             roofline = {"bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
@@ -354,7 +365,7 @@ def main():
                          "clips_per_launch": n_local // max(streams, 1),
                          "note": (f"{streams} streams: each launch covers 1/{streams} of the batch and overlaps with the other part's kernels, "
                                   "so the duration includes sharing the GPU (ESCX_PROF_SERIAL=1 isolates kernels)") if streams > 1 else "single stream",
-                         "share_of_gpu_time": round(dom["ms"] / tot, 4),
+                         "share_of_gpu_time": round(dom["ms"] / tot, 4), "traffic_source": traffic_note,
                          "executed_gflop_per_clip": round(sum(r["flops"] for r in recs) / args.profile_steps / n_local / 1e9, 2)})
         if not args.skip_isolated:
             # the same kernel timed alone on the GPU (batch parts back to back instead of overlapped)

@@ -1411,6 +1411,11 @@ extern "C" int escx_test_math(const float* x, float* y, int64_t n, int which, vo
     test_math(x, y, n, which, (hipStream_t)stream);
     return launch_ok("test_math");
 }
+extern "C" int escx_test_copy_rows(const float* src, float* dst, int64_t rows, int row_floats, void* stream) {
+    if (!src || !dst || rows < 1 || row_floats < 4 || row_floats % 4) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
+    test_copy_rows(src, dst, rows, row_floats, (hipStream_t)stream);
+    return launch_ok("test_copy_rows");
+}
 extern "C" int escx_codes_pack10(const int64_t* codes, uint8_t* out, int64_t n, void* stream) {
     if (!codes || !out || n < 0) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
     codes_pack10((const long long*)codes, out, n, (hipStream_t)stream);

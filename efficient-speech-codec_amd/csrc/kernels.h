@@ -410,6 +410,14 @@ __global__ void codes_unpack10_kernel(const unsigned char* __restrict__ in, long
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const long long i = q * 4 + j; if (i < n) out[i] = (long long)((v >> (10 * j)) & 1023); }
 }
+// Calibration kernel for the HBM counters (tools/pmc_calib.py): a copy with the fused kernels' access pattern - 16 lanes per row, one
+// 16-byte access per lane and step, rows of Cp floats (192 B at Cp = 48) - over buffers far larger than the 256 MiB Infinity Cache.
+__global__ __launch_bounds__(256) void test_copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long long rows, int Cp) {
+    const int sub = threadIdx.x & 15;
+    const long long grp = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4, ngrp = ((long long)gridDim.x * 256) >> 4;
+    for (long long r = grp; r < rows; r += ngrp)
+        for (int v = sub; v < Cp / 4; v += 16) st4(dst + r * Cp + 4 * v, ld4(src + r * Cp + 4 * v));
+}
 __global__ void test_math_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, int which) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

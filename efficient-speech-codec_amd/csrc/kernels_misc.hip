@@ -97,6 +97,9 @@ void codes_unpack10(const unsigned char* in, long long* out, long long n, hipStr
 void test_math(const float* x, float* y, long long n, int which, hipStream_t s) {
     hipLaunchKernelGGL(test_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n, which);
 }
+void test_copy_rows(const float* src, float* dst, long long rows, int Cp, hipStream_t s) {
+    hipLaunchKernelGGL(test_copy_rows_kernel, dim3(4096), dim3(256), 0, s, src, dst, rows, Cp);
+}
 void codes_narrow(const long long* in, short* out, long long n, hipStream_t s) {
     hipLaunchKernelGGL(codes_narrow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
 }

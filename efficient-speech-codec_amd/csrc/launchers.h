@@ -78,6 +78,7 @@ void unpad_rows(const float* src, float* dst, long long rows, int C, int Cp, hip
 void codes_pack10(const long long* in, unsigned char* out, long long n, hipStream_t s);
 void codes_unpack10(const unsigned char* in, long long* out, long long n, hipStream_t s);
 void test_math(const float* x, float* y, long long n, int which, hipStream_t s);
+void test_copy_rows(const float* src, float* dst, long long rows, int Cp, hipStream_t s);
 void codes_narrow(const long long* in, short* out, long long n, hipStream_t s);
 void codes_widen(const short* in, long long* out, long long n, hipStream_t s);
 

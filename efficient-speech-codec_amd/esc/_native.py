@@ -51,6 +51,7 @@ SIGNATURES = {
     "escx_debug_mlp_trace": (c_int, [c_void_p]),
     "escx_test_math": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "escx_test_fastdiv": (c_int, [c_int, c_int]),
+    "escx_test_copy_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "escx_codes_pack10": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "escx_codes_unpack10": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "escx_codes_narrow": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

@@ -142,6 +142,9 @@ const char* escx_profile_report(escx_handle h);
 /* Debug: per-wave cycle counters of the fused MLP main loop (kernel built with the trace flag, ESCX_MLP_VARIANT=164). */
 int escx_debug_mlp_trace(unsigned long long* dev_buf);
 int escx_test_math(const float* x_dev, float* y_dev, int64_t n, int which, void* stream);
+/* Counter calibration (tools/pmc_calib.py): copies `rows` rows of `row_floats` floats with the fused kernels' access pattern (16 lanes per
+ * row, 16 B per lane), so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be compared with a known byte count. */
+int escx_test_copy_rows(const float* src_dev, float* dst_dev, int64_t rows, int row_floats, void* stream);
 /* Host-side evaluation of the multiply-high division the gather loaders / scatter epilogues use on the device (gemm_engine.h FastDiv):
  * returns n / d for 0 <= n < 2^31, 1 <= d < 2^31 (no GPU needed; tests compare it with exact division). */
 int escx_test_fastdiv(int n, int d);

@@ -1,10 +1,10 @@
 #!/usr/bin/env python
 """FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc, separate runs) -> per-kernel HBM-side traffic per launch.
 
-usage: pmc_hbm.py <fetch_dir> <write_dir> <out_all.json> <out_dominant.json>
+usage: pmc_hbm.py <fetch_dir> <write_dir> <out_all.json> <out_dominant.json> [calibration.json from pmc_calib.py]
 The second file maps bench.py's per-launch event names (mlp_fused[C=..], attn_fused[C=..]) to bytes per launch.
 """
-import csv, glob, json, os, re, sys
+import csv, glob, hashlib, json, os, re, sys
 from collections import defaultdict
 
 CP_TO_C = {48: 45, 80: 72, 96: 96, 144: 144, 192: 192, 384: 384}
@@ -23,8 +23,19 @@ def load(d, counter):
     return acc
 
 
+def csrc_hash():
+    """sha256 over the kernel sources: bench.py refuses a traffic figure measured on other kernels."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "efficient-speech-codec_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        h.update(f.encode()); h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()
+
+
 def main():
     fd, wd, out_all, out_dom = sys.argv[1:5]
+    cal = json.load(open(sys.argv[5])) if len(sys.argv) > 5 and os.path.exists(sys.argv[5]) else {}
+    ff, wf = cal.get("fetch_factor") or 1.0, cal.get("write_factor") or 1.0
     fe, wr = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
     allk, dom = {}, {}
     for k in sorted(set(fe) | set(wr)):
@@ -35,11 +46,13 @@ def main():
         if m:
             ev = ("mlp_fused" if m.group(1).startswith("mlp") else "attn_fused") + f"[C={CP_TO_C.get(int(m.group(2)), int(m.group(2)))}]"
             tot = dom.setdefault(ev, [0, 0.0])
-            tot[0] += n; tot[1] += n * (f + w) * 1024
+            tot[0] += n; tot[1] += n * (f * ff + w * wf) * 1024
     dom = {k: int(v[1] / v[0]) for k, v in dom.items()}
-    dom["_note"] = ("bytes per launch = (FETCH_SIZE + WRITE_SIZE) KiB * 1024 from separate rocprofv3 --pmc passes of bench.py (2 streams: each launch covers 18 of "
-                    "the 36 clips), launch-weighted over the kernel variants behind one event name. FETCH_SIZE is used uncorrected: for these kernels (16 B/lane loads of "
-                    "64 B row segments) the raw value matches the expected byte count, unlike the 2x under-count the guide reports for wide streaming reads.")
+    dom["_note"] = ("bytes per launch = (FETCH_SIZE * fetch_factor + WRITE_SIZE * write_factor) KiB * 1024 from separate rocprofv3 --pmc passes of bench.py "
+                    "(2 streams: each launch covers 18 of the 36 clips), launch-weighted over the kernel variants behind one event name; the factors come "
+                    "from tools/pmc_calib.py (a copy with this library's access pattern over 1.5 GiB: true bytes / reported bytes).")
+    dom["_calibration"] = {"fetch_factor": ff, "write_factor": wf}
+    dom["_csrc_sha256"] = csrc_hash()
     json.dump(allk, open(out_all, "w"), indent=1)
     json.dump(dom, open(out_dom, "w"), indent=1)
     print(json.dumps(dom, indent=1))

@@ -16,7 +16,10 @@ tail -1 $O/prof.log | cut -c1-300 > $O/prof_bench_line.txt
 PC="python $R/bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline"
 timeout 900 rocprofv3 --pmc FETCH_SIZE -f csv -d $O/pmc_fetch -o f -- $PC > $O/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE -f csv -d $O/pmc_write -o w -- $PC > $O/pmc_write.log 2>&1
-python $R/tools/pmc_hbm.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm.json $O/pmc_dominant.json > /dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE -f csv -d $O/cal_fetch -o f -- python $R/tools/pmc_calib.py run > $O/cal_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE -f csv -d $O/cal_write -o w -- python $R/tools/pmc_calib.py run > $O/cal_write.log 2>&1
+python $R/tools/pmc_calib.py reduce $O/cal_fetch $O/cal_write $O/pmc_calibration.json > /dev/null
+python $R/tools/pmc_hbm.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm.json $O/pmc_dominant.json $O/pmc_calibration.json > /dev/null
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do
   i=$((i+1)); ESCX_STREAMS=1 timeout 900 rocprofv3 --pmc $set -f csv -d $O/pmc_sq/p$i -o p -- $PC > $O/pmc_sq_$i.log 2>&1
@@ -25,5 +28,15 @@ python $R/tools/pmc_agg.py $O/pmc_sq --json $O/sq_counters.json --top 16 > $O/sq
 cd $R
 ESCX_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_rccl_1rank.json
 timeout 900 python tools/bench_configs.py > $O/other_configs.json 2>$O/other_configs.err
-find $O -name "*.csv" ! -name "kernel_stats.csv" -delete; rm -rf $O/prof $O/pmc_fetch $O/pmc_write $O/pmc_sq
+# strong-scaling mode at N = 1 (BASELINE configs[3] on one GPU) and the training step (BASELINE configs[4], first slice)
+timeout 900 python bench.py --global-batch 288 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_strong_n1.json
+ESCX_BENCH_BREAKDOWN=1 timeout 900 python bench.py --mode train --steps 10 --warmup 3 2>$O/train.err | tail -1 > $O/bench_train.json; cut -c1-300 $O/bench_train.json
+grep "^#" $O/train.err | awk '!seen[$0]++' > $O/train_breakdown.txt
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_train -o p -- python $R/bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_train.log 2>&1
+cp $(find $O/prof_train -name "*kernel_stats.csv" | head -1) $O/train_kernel_stats.csv 2>/dev/null
+tail -1 $O/prof_train.log | cut -c1-300 > $O/prof_train_bench_line.txt
+rm -rf $O/prof_train
+cd $R
+find $O -name "*.csv" ! -name "kernel_stats.csv" -delete; rm -rf $O/prof $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/cal_fetch $O/cal_write
 ls -la $O
