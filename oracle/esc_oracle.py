@@ -540,3 +540,102 @@ def training_loss(out: dict, w: dict = LOSS_WEIGHTS) -> dict:
     stft = complex_stft_loss(out["raw_feat"], out["recon_feat"])
     total = out["cm_loss"] * w["cm_weight"] + out["cb_loss"] * w["cb_weight"] + mel * w["mel_weight"] + stft * w["stft_weight"]
     return {"mel_loss": mel, "stft_loss": stft, "loss": total, "scalar": total.mean()}
+
+
+# ----------------------------------------------------------------------------------------------
+# Adversarial training: DAC discriminator (esc/models/discriminator.py:31-221) and GAN losses (esc/modules/loss/gan_loss.py:5-50)
+# ----------------------------------------------------------------------------------------------
+DISC_BANDS = [(0.0, 0.1), (0.1, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0)]
+DISC_DEFAULT = dict(sample_rate=16000, rates=[], periods=[2, 3, 5, 7, 11], fft_sizes=[2048, 1024, 512], bands=DISC_BANDS)
+
+
+def wn_weight(sd, pfx: str) -> Tensor:
+    """torch.nn.utils.weight_norm (dim=0): w = g * v / ||v||, the norm over everything but the output channel."""
+    v, g = sd[pfx + "weight_v"], sd[pfx + "weight_g"]
+    return v * (g / v.flatten(1).norm(dim=1).view(-1, *([1] * (v.dim() - 1))))
+
+
+def wn_conv2d(x: Tensor, sd, pfx: str, stride, padding, act: bool = True) -> Tensor:
+    """WNConv2d (discriminator.py:23-28): weight-normalised conv, LeakyReLU(0.1) unless act=False."""
+    y = F.conv2d(x, wn_weight(sd, pfx), sd[pfx + "bias"], stride=stride, padding=padding)
+    return F.leaky_relu(y, 0.1) if act else y
+
+
+def disc_preprocess(y: Tensor) -> Tensor:
+    """discriminator.py:205-210: remove the DC offset, peak-normalise to 0.8."""
+    y = y - y.mean(dim=-1, keepdim=True)
+    return 0.8 * y / (y.abs().max(dim=-1, keepdim=True)[0] + 1e-9)
+
+
+def mpd_forward(x: Tensor, sd, pfx: str, period: int) -> List[Tensor]:
+    """MPD.forward (discriminator.py:31-66): x (B,1,L) -> list of 6 feature maps."""
+    t = x.shape[-1]
+    x = F.pad(x, (0, period - t % period), mode="reflect")
+    x = x.view(x.shape[0], 1, -1, period)
+    fmap = []
+    for i, st in enumerate([(3, 1)] * 4 + [(1, 1)]):
+        x = wn_conv2d(x, sd, f"{pfx}convs.{i}.0.", st, (2, 0))
+        fmap.append(x)
+    fmap.append(wn_conv2d(x, sd, f"{pfx}conv_post.", (1, 1), (1, 0), act=False))
+    return fmap
+
+
+def matched_stride_stft(x: Tensor, window_length: int) -> Tensor:
+    """audiotools AudioSignal.stft with STFTParams(window_length, hop = window_length // 4, match_stride=True) (discriminator.py:128-132),
+    restated from the audiotools source (not installed here: UNPINNED at this boundary): reflect-pad by ((wl - hop) / 2, (wl - hop) / 2 +
+    right_pad), right_pad = ceil(L / hop) * hop - L, torch.stft(center=True, hann), drop the first and last two frames.  (B,1,L) -> (B,2,T,F)."""
+    hop = window_length // 4
+    L = x.shape[-1]
+    right = math.ceil(L / hop) * hop - L
+    pad = (window_length - hop) // 2
+    xp = F.pad(x, (pad, pad + right), "reflect")
+    s = torch.stft(xp.reshape(-1, xp.shape[-1]), n_fft=window_length, hop_length=hop, window=torch.hann_window(window_length, dtype=x.dtype),
+                   return_complex=True, center=True)[..., 2:-2]
+    return torch.view_as_real(s).permute(0, 3, 2, 1)          # (B, F, T, 2) -> (B, 2, T, F)   ["b 1 f t c -> (b 1) c t f"]
+
+
+def mrd_forward(x: Tensor, sd, pfx: str, window_length: int, bands=DISC_BANDS) -> List[Tensor]:
+    """MRD.forward (discriminator.py:105-176): 5 band stacks of 5 convs, concatenated along frequency, conv_post."""
+    spec = matched_stride_stft(x, window_length)
+    n_fft = window_length // 2 + 1
+    fmap, outs = [], []
+    for bi, (lo, hi) in enumerate(bands):
+        band = spec[..., int(lo * n_fft):int(hi * n_fft)]
+        for j, (st, k) in enumerate([((1, 1), 9), ((1, 2), 9), ((1, 2), 9), ((1, 2), 9), ((1, 1), 3)]):
+            band = wn_conv2d(band, sd, f"{pfx}band_convs.{bi}.{j}.0.", st, (1, k // 2))
+            fmap.append(band)
+        outs.append(band)
+    fmap.append(wn_conv2d(torch.cat(outs, dim=-1), sd, f"{pfx}conv_post.", (1, 1), (1, 1), act=False))
+    return fmap
+
+
+def discriminator_forward(x: Tensor, sd, cfg: dict = DISC_DEFAULT) -> List[List[Tensor]]:
+    """Discriminator.forward (discriminator.py:212-215): x (B,1,L) -> one list of feature maps per sub-discriminator."""
+    assert not cfg.get("rates"), "MSD (rates) is not used by the ESC configurations"
+    x = disc_preprocess(x)
+    out = [mpd_forward(x, sd, f"discriminators.{i}.", p) for i, p in enumerate(cfg["periods"])]
+    n = len(cfg["periods"])
+    out += [mrd_forward(x, sd, f"discriminators.{n + i}.", w, cfg.get("bands", DISC_BANDS)) for i, w in enumerate(cfg["fft_sizes"])]
+    return out
+
+
+def gan_discriminator_loss(fake: Tensor, real: Tensor, sd, cfg: dict = DISC_DEFAULT) -> Tensor:
+    """GANLoss.discriminator_loss (gan_loss.py:29-36): least-squares GAN, per clip."""
+    d_fake, d_real = discriminator_forward(fake.detach().unsqueeze(1), sd, cfg), discriminator_forward(real.unsqueeze(1), sd, cfg)
+    loss = 0
+    for xf, xr in zip(d_fake, d_real):
+        loss = loss + torch.mean(xf[-1] ** 2, dim=[1, 2, 3]) + torch.mean((1 - xr[-1]) ** 2, dim=[1, 2, 3])
+    return loss
+
+
+def gan_generator_loss(fake: Tensor, real: Tensor, sd, cfg: dict = DISC_DEFAULT):
+    """GANLoss.generator_loss (gan_loss.py:38-50): adversarial term + L1 feature matching, per clip."""
+    d_fake, d_real = discriminator_forward(fake.unsqueeze(1), sd, cfg), discriminator_forward(real.unsqueeze(1), sd, cfg)
+    loss_g = 0
+    for xf in d_fake:
+        loss_g = loss_g + torch.mean((1 - xf[-1]) ** 2, dim=[1, 2, 3])
+    loss_f = 0
+    for df, dr in zip(d_fake, d_real):
+        for a, b in zip(df[:-1], dr[:-1]):
+            loss_f = loss_f + F.l1_loss(a, b.detach(), reduction="none").mean([1, 2, 3])
+    return loss_g, loss_f
