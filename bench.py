@@ -252,6 +252,8 @@ def main():
                     help="strong scaling: fix the JOB's batch (e.g. 288 = BASELINE configs[3]) and shard it over the ranks; "
                          "default 0 = weak scaling with 36 clips per rank")
     ap.add_argument("--profile-steps", type=int, default=6)
+    ap.add_argument("--skip-single-clip", action="store_true",
+                    help="omit the B=1 latency measurement (used under rocprofv3 / --pmc so that per-kernel averages cover the 36-clip launches only)")
     ap.add_argument("--skip-isolated", action="store_true",
                     help="omit the isolated-kernel timing pass (used under rocprofv3 so that its per-kernel averages cover two-stream launches only)")
     args = ap.parse_args()
@@ -388,7 +390,7 @@ def main():
                           f"{r['flops'] / max(r['ms'], 1e-9) / 1e9:9.1f} TFLOP/s  {r['bytes'] / max(r['ms'], 1e-9) / 1e6:9.1f} GB/s", file=sys.stderr)
 
     single_gpu = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.skip_single_clip:
         # BASELINE configs[0] workload (one 3 s clip) on the GPU, next to cpu_baseline.single_clip
         x1 = x[:1].contiguous()
         for _ in range(3):

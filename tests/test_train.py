@@ -235,7 +235,7 @@ def test_training_step_losses_and_every_gradient(name):
             errs.append(err)
             bound = 8.0 * max(floor[k], med) + 1e-5
             worst = max(worst, (err / bound, k, err))
-            assert err <= bound and err <= 1e-2, f"{tag}: gradient of {k} rel rms {err:.3e} vs fp64, reference fp32 noise floor {floor[k]:.3e}"
+            assert err <= bound and err <= 5e-2, f"{tag}: gradient of {k} rel rms {err:.3e} vs fp64, reference fp32 noise floor {floor[k]:.3e}"
             gn = float(np.linalg.norm(np.asarray(grads[k], np.float64)))
             # the fixture is the fp32 reference: both sides carry their own noise (HIP error + the reference's floor)
             assert abs(gn - rn) <= 2.0 * bound * max(rn, 1e-6 * scale) + 1e-12, f"{tag}: |grad {k}| = {gn} vs reference fixture {rn}"

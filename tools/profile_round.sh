@@ -9,11 +9,11 @@ timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench.err | tail -1 > $O/
 ESCX_BENCH_BREAKDOWN=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep "^#" > $O/event_breakdown_isolated.txt
 ESCX_STREAMS=1 ESCX_BENCH_BREAKDOWN=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep "^#" > $O/event_breakdown_1stream.txt
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --skip-isolated"
+CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --skip-isolated --skip-single-clip"
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/prof -o p -- $CMD > $O/prof.log 2>&1
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv 2>/dev/null
 tail -1 $O/prof.log | cut -c1-300 > $O/prof_bench_line.txt
-PC="python $R/bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline"
+PC="python $R/bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --skip-single-clip"
 timeout 900 rocprofv3 --pmc FETCH_SIZE -f csv -d $O/pmc_fetch -o f -- $PC > $O/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE -f csv -d $O/pmc_write -o w -- $PC > $O/pmc_write.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -f csv -d $O/cal_fetch -o f -- python $R/tools/pmc_calib.py run > $O/cal_fetch.log 2>&1
