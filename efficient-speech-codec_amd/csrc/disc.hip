@@ -1,0 +1,504 @@
+// DAC discriminator + GAN losses of the adversarial training step on MI355X (BASELINE configs[4]).
+// Reference: esc/models/discriminator.py:31-221 (MPD, MRD, Discriminator; MSD is unused by every ESC config: rates = []),
+// esc/modules/loss/gan_loss.py:5-50, scripts/trainer_adv.py:60-105.  fp32 like the reference.
+//
+// One handle = one Discriminator.  Parameters live in a flat fp32 device buffer owned by the caller (reference state_dict order of the
+// trainable entries: per convolution bias, weight_g, weight_v); the weight-normalised, packed GEMM operands are rebuilt from it at the start of
+// every forward (108 small kernels; the weights change every step anyway).  Feature maps are channels-last [B][D0][D1][Cp] buffers owned by
+// the caller (they ARE the autograd tape); backward takes the gradients of all feature maps and returns d loss / d parameters and / or
+// d loss / d waveform.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "escx_internal.h"
+#include "launchers.h"
+#include "train_kernels.h"
+#include "disc_kernels.h"
+
+using namespace escx;
+
+namespace {
+
+inline unsigned blk(long long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+struct DConv {
+    std::string prefix;
+    int Cin, Cout, CinP, CoutP, CinR, T0, T1, s0, s1, p0, p1, act;
+    int Kf, Kt;
+    size_t off_b = 0, off_g = 0, off_v = 0;
+    float *Wf = nullptr, *Wt = nullptr, *bias = nullptr, *scale = nullptr;
+};
+struct DSub {
+    int kind, arg;                       // 0: MPD(period), 1: MRD(window length)
+    std::vector<DConv> convs;            // MPD: 5 + post; MRD: nb * 5 (band-major) + post
+    std::vector<std::pair<int, int>> bands;
+    float *D = nullptr, *DT = nullptr;   // MRD: windowed DFT matrix [2Fq][w] and its transpose
+    int Fq = 0;
+};
+struct FmapShape { int sub, C, Cp, D0, D1, P1, off1; long long base; };     // off1/P1: slice of a concatenated buffer (MRD band tops); base: first fmap of the slice's buffer
+
+}  // namespace
+
+struct escx_disc_s {
+    int device = 0, sample_rate = 16000;
+    std::vector<DSub> subs;
+    std::vector<std::string> keys; std::vector<size_t> offs, numels;
+    size_t total = 0;
+    float* wbuf = nullptr; size_t wfloats = 0;
+    float* scratch = nullptr; size_t scratch_bytes = 0;
+};
+
+namespace {
+
+size_t pad64(size_t n) { return (n + 63) / 64 * 64; }
+
+DConv make_conv(const std::string& p, int Cin, int Cout, int T0, int T1, int s0, int s1, int p0, int p1, int act) {
+    DConv c; c.prefix = p; c.Cin = Cin; c.Cout = Cout; c.CinP = Cin < 16 ? 4 : rup(Cin, 16); c.CoutP = rup(Cout, 16); c.CinR = rup(c.CinP, 16);
+    c.T0 = T0; c.T1 = T1; c.s0 = s0; c.s1 = s1; c.p0 = p0; c.p1 = p1; c.act = act;
+    c.Kf = rup(T0 * T1 * c.CinP, 16); c.Kt = T0 * T1 * c.CoutP;
+    return c;
+}
+
+int out_dim(int D, int T, int s, int p) { return (D + 2 * p - T) / s + 1; }
+
+// per-sub-discriminator geometry for clips of L samples
+struct SubGeom { int D0, D1; std::vector<int> O0, O1; std::vector<int> bandF; int T = 0, catF = 0; };
+
+SubGeom geometry(const DSub& S, int L) {
+    SubGeom g;
+    if (S.kind == 0) {
+        const int p = S.arg;
+        g.D0 = (L + (p - L % p)) / p; g.D1 = p;
+        int d0 = g.D0;
+        for (const DConv& c : S.convs) { d0 = out_dim(d0, c.T0, c.s0, c.p0); g.O0.push_back(d0); g.O1.push_back(p); }
+    } else {
+        const int w = S.arg, hop = w / 4;
+        g.T = (L + hop - 1) / hop;
+        const int nb = (int)S.bands.size();
+        g.catF = 0;
+        for (int b = 0; b < nb; ++b) {
+            int f = S.bands[b].second - S.bands[b].first;
+            g.bandF.push_back(f);
+            for (int j = 0; j < 5; ++j) { const DConv& c = S.convs[b * 5 + j]; f = out_dim(f, c.T1, c.s1, c.p1); g.O0.push_back(g.T); g.O1.push_back(f); }
+            g.catF += f;
+        }
+        g.O0.push_back(g.T); g.O1.push_back(g.catF);
+    }
+    return g;
+}
+
+void fmap_shapes(escx_disc_s* d, int L, std::vector<FmapShape>* out) {
+    out->clear();
+    for (size_t si = 0; si < d->subs.size(); ++si) {
+        const DSub& S = d->subs[si];
+        const SubGeom g = geometry(S, L);
+        if (S.kind == 0) {
+            for (size_t j = 0; j < S.convs.size(); ++j) out->push_back({(int)si, S.convs[j].Cout, S.convs[j].CoutP, g.O0[j], g.O1[j], g.O1[j], 0, -1});
+        } else {
+            const int nb = (int)S.bands.size();
+            int off = 0;
+            for (int b = 0; b < nb; ++b)
+                for (int j = 0; j < 5; ++j) {
+                    const DConv& c = S.convs[b * 5 + j];
+                    const bool top = j == 4;
+                    out->push_back({(int)si, c.Cout, c.CoutP, g.O0[b * 5 + j], g.O1[b * 5 + j], top ? g.catF : g.O1[b * 5 + j], top ? off : 0, -1});
+                    if (top) off += g.O1[b * 5 + j];
+                }
+            const DConv& c = S.convs.back();
+            out->push_back({(int)si, c.Cout, c.CoutP, g.T, g.catF, g.catF, 0, -1});
+        }
+    }
+}
+
+TView view_of(float* base, const FmapShape& f) { return TView{base, f.D0, f.D1, f.P1, f.Cp}; }
+
+int pack_weights(escx_disc_s* d, const float* flat, hipStream_t st) {
+    for (DSub& S : d->subs)
+        for (DConv& c : S.convs)
+            hipLaunchKernelGGL(wn_pack_kernel, dim3(c.Cout), dim3(256), 0, st, flat + c.off_v, flat + c.off_g, flat + c.off_b, c.Wf, c.Wt, c.bias, c.scale,
+                               c.Cout, c.Cin, c.T0 * c.T1, c.CinP, c.CoutP, c.Kf, c.Kt);
+    return launch_ok("disc_pack_weights");
+}
+
+int ensure_scratch(escx_disc_s* d, size_t bytes) {
+    if (d->scratch_bytes >= bytes) return 0;
+    ESCX_HIP(hipDeviceSynchronize());
+    if (d->scratch) ESCX_HIP(hipFree(d->scratch));
+    d->scratch = nullptr; d->scratch_bytes = 0;
+    ESCX_HIP(hipMalloc((void**)&d->scratch, bytes));
+    d->scratch_bytes = bytes;
+    return 0;
+}
+
+template <class Ld, class Epi>
+void conv_gemm(const Ld& ld, const float* W, int M, int Np, int Kp, const Epi& ep, hipStream_t st) {
+    const long long tiles128 = (long long)((M + 127) / 128) * ((Np + 95) / 96);
+    if (tiles128 >= 512) launch_gemm<128>(ld, W, M, Np, Kp, ep, st);
+    else launch_gemm<64>(ld, W, M, Np, Kp, ep, st);
+}
+
+ConvS make_convs(const TView& x, const DConv& c, int O0, int O1, int B) {
+    ConvGeom g{c.T0, c.T1, c.s0, c.s1, c.p0, c.p1, O0, O1};
+    return ConvS{x, g, B * O0 * O1, FastDiv(O0 * O1), FastDiv(O1), FastDiv(x.Cp), FastDiv(c.T1)};
+}
+
+void conv_forward(const TView& x, const DConv& c, const TView& out, int B, hipStream_t st) {
+    ConvS ld = make_convs(x, c, out.D0, out.D1, B);
+    conv_gemm(ld, c.Wf, B * out.D0 * out.D1, c.CoutP, c.Kf, EpiConvOut{out, c.bias, c.act, FastDiv(out.D0 * out.D1), FastDiv(out.D1)}, st);
+}
+
+constexpr size_t DISC_DW_PART = (size_t)12 << 20;
+
+// dW partial-sum launch (same scheme as train.hip's dw_launch)
+template <class LdA, class LdB>
+int disc_dw(const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
+    const int nbn = (Np + 47) / 48, nbk = (Kp + 47) / 48, blocks = nbn * nbk;
+    int slices = std::max(1, std::min((2048 + blocks - 1) / blocks, (M + 127) / 128));
+    const size_t per = (size_t)Np * Kp + Np;
+    slices = (int)std::min<size_t>(slices, DISC_DW_PART / per);
+    if (slices < 1) ESCX_FAIL(ESCX_ERR_STATE, "discriminator dW scratch too small for %d x %d", Np, Kp);
+    int mps = ((M + slices - 1) / slices + 127) / 128 * 128;
+    slices = (M + mps - 1) / mps;
+    float* bpart = part + (size_t)slices * Np * Kp;
+    hipLaunchKernelGGL((gemm_dw_kernel<LdA, LdB, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+    const long long n = (long long)Np * Kp;
+    if (slices >= 32 && n * 4 <= ((long long)1 << 22)) hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3(blk((n + 15) / 16 * 64)), dim3(256), 0, st, part, slices, n, dW, 0);
+    else hipLaunchKernelGGL(reduce_partials_kernel, dim3(blk(n)), dim3(256), 0, st, part, slices, n, dW, 0);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blk(Np)), dim3(256), 0, st, bpart, slices, (long long)Np, db, 0);
+    return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int escx_disc_create(const escx_disc_config* cfg, int device, escx_disc* out) {
+    if (!cfg || !out) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null argument");
+    if (cfg->n_rates != 0) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "MSD (rates) is not implemented: every ESC configuration uses rates = []");
+    if (cfg->n_periods < 0 || cfg->n_periods > 8 || cfg->n_ffts < 0 || cfg->n_ffts > 8 || cfg->n_bands < 1 || cfg->n_bands > 8)
+        ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad discriminator configuration");
+    escx_disc_s* d = new escx_disc_s();
+    d->device = device; d->sample_rate = cfg->sample_rate;
+    int idx = 0;
+    for (int i = 0; i < cfg->n_periods; ++i, ++idx) {
+        DSub S; S.kind = 0; S.arg = cfg->periods[i];
+        if (S.arg < 1) { delete d; ESCX_FAIL(ESCX_ERR_INVALID_ARG, "period must be positive"); }
+        const std::string p = "discriminators." + std::to_string(idx) + ".";
+        const int ch[6] = {1, 32, 128, 512, 1024, 1024};
+        for (int j = 0; j < 5; ++j) S.convs.push_back(make_conv(p + "convs." + std::to_string(j) + ".0.", ch[j], ch[j + 1], 5, 1, j < 4 ? 3 : 1, 1, 2, 0, 1));
+        S.convs.push_back(make_conv(p + "conv_post.", 1024, 1, 3, 1, 1, 1, 1, 0, 0));
+        d->subs.push_back(S);
+    }
+    for (int i = 0; i < cfg->n_ffts; ++i, ++idx) {
+        DSub S; S.kind = 1; S.arg = cfg->fft_sizes[i];
+        if (S.arg < 16 || S.arg % 16) { delete d; ESCX_FAIL(ESCX_ERR_INVALID_ARG, "fft size must be a positive multiple of 16"); }
+        const int nf = S.arg / 2 + 1;
+        for (int b = 0; b < cfg->n_bands; ++b) S.bands.push_back({(int)(cfg->bands[b][0] * nf), (int)(cfg->bands[b][1] * nf)});
+        const std::string p = "discriminators." + std::to_string(idx) + ".";
+        for (int b = 0; b < cfg->n_bands; ++b)
+            for (int j = 0; j < 5; ++j) {
+                const int k1 = j < 4 ? 9 : 3, s1 = (j >= 1 && j <= 3) ? 2 : 1;
+                S.convs.push_back(make_conv(p + "band_convs." + std::to_string(b) + "." + std::to_string(j) + ".0.", j == 0 ? 2 : 32, 32, 3, k1, 1, s1, 1, k1 / 2, 1));
+            }
+        S.convs.push_back(make_conv(p + "conv_post.", 32, 1, 3, 3, 1, 1, 1, 1, 0));
+        S.Fq = rup(nf, 16);
+        d->subs.push_back(S);
+    }
+    // flat parameter layout: the reference's named_parameters() order = per conv (bias, weight_g, weight_v)
+    size_t off = 0, wf = 0;
+    for (DSub& S : d->subs) {
+        for (DConv& c : S.convs) {
+            const size_t nv = (size_t)c.Cout * c.Cin * c.T0 * c.T1;
+            c.off_b = off; d->keys.push_back(c.prefix + "bias"); d->offs.push_back(off); d->numels.push_back(c.Cout); off += c.Cout;
+            c.off_g = off; d->keys.push_back(c.prefix + "weight_g"); d->offs.push_back(off); d->numels.push_back(c.Cout); off += c.Cout;
+            c.off_v = off; d->keys.push_back(c.prefix + "weight_v"); d->offs.push_back(off); d->numels.push_back(nv); off += nv;
+            wf += pad64((size_t)c.CoutP * c.Kf) + pad64((size_t)c.CinR * c.Kt) + pad64(c.CoutP) + pad64(2 * c.Cout);
+        }
+        if (S.kind == 1) wf += 2 * pad64((size_t)2 * S.Fq * S.arg);
+    }
+    d->total = off;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { delete d; ESCX_FAIL(ESCX_ERR_HIP, "hipSetDevice failed"); }
+    if (hipMalloc((void**)&d->wbuf, wf * sizeof(float)) != hipSuccess) { delete d; ESCX_FAIL(ESCX_ERR_HIP, "hipMalloc of the discriminator weights failed"); }
+    (void)hipMemset(d->wbuf, 0, wf * sizeof(float));
+    d->wfloats = wf;
+    size_t cur = 0;
+    auto take = [&](size_t n) { float* p = d->wbuf + cur; cur += pad64(n); return p; };
+    for (DSub& S : d->subs) {
+        for (DConv& c : S.convs) { c.Wf = take((size_t)c.CoutP * c.Kf); c.Wt = take((size_t)c.CinR * c.Kt); c.bias = take(c.CoutP); c.scale = take(2 * c.Cout); }
+        if (S.kind == 1) {      // windowed DFT of AudioSignal.stft: periodic hann of the full window length
+            const int w = S.arg, nf = w / 2 + 1, Fq = S.Fq;
+            S.D = take((size_t)2 * Fq * w); S.DT = take((size_t)2 * Fq * w);
+            std::vector<float> hD((size_t)2 * Fq * w, 0.f), hT((size_t)2 * Fq * w, 0.f);
+            for (int f = 0; f < nf; ++f) for (int k = 0; k < w; ++k) {
+                const double win = 0.5 - 0.5 * std::cos(2.0 * M_PI * k / w);
+                const double ang = 2.0 * M_PI * (double)((long long)f * k % w) / w;
+                const float re = (float)(win * std::cos(ang)), im = (float)(-win * std::sin(ang));
+                hD[(size_t)f * w + k] = re; hD[(size_t)(Fq + f) * w + k] = im;
+                hT[(size_t)k * 2 * Fq + f] = re; hT[(size_t)k * 2 * Fq + Fq + f] = im;
+            }
+            (void)hipMemcpy(S.D, hD.data(), hD.size() * sizeof(float), hipMemcpyHostToDevice);
+            (void)hipMemcpy(S.DT, hT.data(), hT.size() * sizeof(float), hipMemcpyHostToDevice);
+        }
+    }
+    *out = d;
+    return ESCX_OK;
+}
+
+extern "C" void escx_disc_destroy(escx_disc d) {
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    if (d->wbuf) (void)hipFree(d->wbuf);
+    if (d->scratch) (void)hipFree(d->scratch);
+    delete d;
+}
+
+extern "C" int escx_disc_param_count(escx_disc d) { return d ? (int)d->keys.size() : 0; }
+extern "C" const char* escx_disc_param_key(escx_disc d, int i) { return (d && i >= 0 && i < (int)d->keys.size()) ? d->keys[i].c_str() : nullptr; }
+extern "C" int64_t escx_disc_param_offset(escx_disc d, int i) { return (d && i >= 0 && i < (int)d->offs.size()) ? (int64_t)d->offs[i] : -1; }
+extern "C" int64_t escx_disc_param_numel(escx_disc d, int i) { return (d && i >= 0 && i < (int)d->numels.size()) ? (int64_t)d->numels[i] : -1; }
+extern "C" int64_t escx_disc_param_total(escx_disc d) { return d ? (int64_t)d->total : 0; }
+
+// Feature maps of one forward for clips of n_samples: count, and for map i its sub-discriminator, channels, padded channels, extent (D0, D1), the
+// row pitch P1 and column offset of the buffer it lives in (the five band tops of an MRD are slices of one [T][sum F][32] buffer).
+extern "C" int escx_disc_num_fmaps(escx_disc d, int n_samples) {
+    if (!d) return 0;
+    std::vector<FmapShape> f; fmap_shapes(d, n_samples, &f);
+    return (int)f.size();
+}
+extern "C" int escx_disc_fmap_shape(escx_disc d, int n_samples, int i, int* sub, int* C, int* Cp, int* D0, int* D1, int* P1, int* off1) {
+    if (!d) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null handle");
+    std::vector<FmapShape> f; fmap_shapes(d, n_samples, &f);
+    if (i < 0 || i >= (int)f.size()) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "feature map index out of range");
+    if (sub) *sub = f[i].sub; if (C) *C = f[i].C; if (Cp) *Cp = f[i].Cp; if (D0) *D0 = f[i].D0; if (D1) *D1 = f[i].D1; if (P1) *P1 = f[i].P1; if (off1) *off1 = f[i].off1;
+    return ESCX_OK;
+}
+
+namespace {
+// scratch layout shared by forward and backward: pre-processed wave, per-sub input maps / spectrogram rows
+struct Front { float* y; float* stats; std::vector<float*> in; std::vector<float*> spec; size_t floats; };
+
+size_t front_floats(escx_disc_s* d, int B, int L) {
+    size_t n = pad64((size_t)B * L) + pad64((size_t)4 * B);
+    for (const DSub& S : d->subs) {
+        const SubGeom g = geometry(S, L);
+        if (S.kind == 0) n += pad64((size_t)B * g.D0 * g.D1 * 4);
+        else { n += pad64((size_t)B * g.T * 2 * S.Fq); for (int f : g.bandF) n += pad64((size_t)B * g.T * f * 4); }
+    }
+    return n;
+}
+
+// pre-process + build every sub-discriminator's input map (MPD: padded/reshaped wave; MRD: band slices of the matched-stride STFT)
+void build_front(escx_disc_s* d, const float* wave, int B, int L, float* base, std::vector<std::vector<float*>>* ins, std::vector<float*>* specs, float** y_out,
+                 float** stats_out, hipStream_t st) {
+    float* cur = base;
+    auto take = [&](size_t n) { float* p = cur; cur += pad64(n); return p; };
+    float* y = take((size_t)B * L); float* stats = take((size_t)4 * B);
+    hipLaunchKernelGGL(disc_preprocess_kernel, dim3(B), dim3(1024), 0, st, wave, y, stats, L);
+    ins->clear(); specs->clear();
+    for (const DSub& S : d->subs) {
+        const SubGeom g = geometry(S, L);
+        std::vector<float*> v;
+        if (S.kind == 0) {
+            float* in = take((size_t)B * g.D0 * g.D1 * 4);
+            hipLaunchKernelGGL(mpd_input_kernel, dim3(blk((long long)B * g.D0 * g.D1)), dim3(256), 0, st, y, in, B, L, g.D0, S.arg);
+            v.push_back(in); specs->push_back(nullptr);
+        } else {
+            const int w = S.arg, hop = w / 4;
+            float* spec = take((size_t)B * g.T * 2 * S.Fq);
+            gemm_frames(y, B, L, g.T, hop, -(w - hop) / 2, S.D, 2 * S.Fq, w, spec, st);
+            for (size_t b = 0; b < S.bands.size(); ++b) {
+                float* in = take((size_t)B * g.T * g.bandF[b] * 4);
+                hipLaunchKernelGGL(mrd_band_kernel, dim3(blk((long long)B * g.T * g.bandF[b])), dim3(256), 0, st, spec, in, (long long)B * g.T, S.Fq, S.bands[b].first, g.bandF[b]);
+                v.push_back(in);
+            }
+            specs->push_back(spec);
+        }
+        ins->push_back(v);
+    }
+    *y_out = y; *stats_out = stats;
+}
+}  // namespace
+
+// Discriminator.forward (discriminator.py:212-215).  fmaps: host array of escx_disc_num_fmaps() device pointers, each the BASE address of map i
+// (i.e. already offset to its column slice when it lives in a concatenated buffer), laid out [B][D0][P1][Cp].
+extern "C" int escx_disc_forward(escx_disc d, const float* flat_params, const float* wave, int B, int L, float* const* fmaps, void* stream) {
+    if (!d || !flat_params || !wave || !fmaps || B < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
+    ESCX_HIP(hipSetDevice(d->device));
+    hipStream_t st = (hipStream_t)stream;
+    int maxp = 1; for (const DSub& S : d->subs) if (S.kind == 0) maxp = std::max(maxp, S.arg);
+    if (L <= maxp + 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "clip too short for the reflect padding of the period discriminators");
+    std::vector<FmapShape> shp; fmap_shapes(d, L, &shp);
+    int rc = ensure_scratch(d, front_floats(d, B, L) * sizeof(float)); if (rc) return rc;
+    if ((rc = pack_weights(d, flat_params, st))) return rc;
+    std::vector<std::vector<float*>> ins; std::vector<float*> specs; float *y, *stats;
+    build_front(d, wave, B, L, d->scratch, &ins, &specs, &y, &stats, st);
+    int fi = 0;
+    for (size_t si = 0; si < d->subs.size(); ++si) {
+        const DSub& S = d->subs[si];
+        const SubGeom g = geometry(S, L);
+        if (S.kind == 0) {
+            TView x{ins[si][0], g.D0, g.D1, g.D1, 4};
+            for (size_t j = 0; j < S.convs.size(); ++j, ++fi) {
+                TView o = view_of(fmaps[fi], shp[fi]);
+                conv_forward(x, S.convs[j], o, B, st);
+                x = o;
+            }
+        } else {
+            const int nb = (int)S.bands.size();
+            float* cat_base = nullptr;
+            for (int b = 0; b < nb; ++b) {
+                TView x{ins[si][b], g.T, g.bandF[b], g.bandF[b], 4};
+                for (int j = 0; j < 5; ++j, ++fi) {
+                    TView o = view_of(fmaps[fi], shp[fi]);
+                    conv_forward(x, S.convs[b * 5 + j], o, B, st);
+                    x = o;
+                    if (j == 4 && b == 0) cat_base = fmaps[fi];
+                }
+            }
+            TView cat{cat_base, g.T, g.catF, g.catF, 32};
+            TView o = view_of(fmaps[fi], shp[fi]);
+            conv_forward(cat, S.convs.back(), o, B, st);
+            ++fi;
+        }
+    }
+    return launch_ok("disc_forward");
+}
+
+// Backward of the last forward on the same inputs.  d_fmaps[i]: gradient of map i with the SAME layout as fmaps[i] (NULL = zero).
+// grad_flat (optional): d loss / d parameters, overwritten.  d_wave (optional): d loss / d waveform (B, L), overwritten.
+extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, const float* wave, int B, int L, float* const* fmaps, const float* const* d_fmaps,
+                                  float* grad_flat, float* d_wave, void* stream) {
+    if (!d || !flat_params || !wave || !fmaps || !d_fmaps || B < 1 || (!grad_flat && !d_wave)) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
+    ESCX_HIP(hipSetDevice(d->device));
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<FmapShape> shp; fmap_shapes(d, L, &shp);
+    // scratch: front + gradient buffers of every feature-map BUFFER (concatenated buffers once) + input-map gradients + dW staging
+    const size_t front = front_floats(d, B, L);
+    size_t gfl = 0, max_w = 0, in_g = 0;
+    {
+        int fi = 0;
+        for (const DSub& S : d->subs) {
+            const SubGeom g = geometry(S, L);
+            for (size_t j = 0; j < S.convs.size(); ++j, ++fi) {
+                const FmapShape& f = shp[fi];
+                const bool slice = f.P1 != f.D1;
+                if (!slice) gfl += pad64((size_t)B * f.D0 * f.D1 * f.Cp);
+                else if (f.off1 == 0) gfl += pad64((size_t)B * f.D0 * f.P1 * f.Cp);
+                max_w = std::max(max_w, (size_t)S.convs[j].CoutP * S.convs[j].Kf + S.convs[j].CoutP);
+            }
+            if (S.kind == 0) in_g = std::max(in_g, (size_t)B * g.D0 * g.D1 * 4);
+            else { for (int f : g.bandF) in_g = std::max(in_g, (size_t)B * g.T * f * 4); in_g = std::max(in_g, (size_t)B * g.T * std::max(2 * S.Fq, S.arg)); }
+        }
+    }
+    const size_t total = front + gfl + 3 * pad64(in_g) + pad64(max_w) + pad64(DISC_DW_PART) + pad64((size_t)B * L) + 4096;
+    int rc = ensure_scratch(d, total * sizeof(float)); if (rc) return rc;
+    if ((rc = pack_weights(d, flat_params, st))) return rc;
+    std::vector<std::vector<float*>> ins; std::vector<float*> specs; float *y, *stats;
+    build_front(d, wave, B, L, d->scratch, &ins, &specs, &y, &stats, st);
+    float* cur = d->scratch + front;
+    auto take = [&](size_t n) { float* p = cur; cur += pad64(n); return p; };
+    // gradient views, one per feature map
+    std::vector<TView> gv(shp.size());
+    {
+        float* cat = nullptr;
+        for (size_t i = 0; i < shp.size(); ++i) {
+            const FmapShape& f = shp[i];
+            if (f.P1 == f.D1) gv[i] = TView{take((size_t)B * f.D0 * f.D1 * f.Cp), f.D0, f.D1, f.D1, f.Cp};
+            else { if (f.off1 == 0) cat = take((size_t)B * f.D0 * f.P1 * f.Cp); gv[i] = TView{cat + (size_t)f.off1 * f.Cp, f.D0, f.D1, f.P1, f.Cp}; }
+            TView src{const_cast<float*>(d_fmaps[i]), f.D0, f.D1, f.P1, f.Cp};
+            hipLaunchKernelGGL(view_copy_kernel, dim3(blk((long long)B * f.D0 * f.D1 * f.Cp / 4)), dim3(256), 0, st, gv[i], src, (long long)B * f.D0 * f.D1 * f.Cp / 4);
+        }
+    }
+    float* gin = take(in_g); float* gspec = take(in_g); float* gfr = take(in_g);
+    float* dWs = take(max_w); float* part = take(DISC_DW_PART); float* dy = take((size_t)B * L);
+    if (grad_flat) ESCX_HIP(hipMemsetAsync(grad_flat, 0, d->total * sizeof(float), st));
+    if (d_wave) ESCX_HIP(hipMemsetAsync(dy, 0, (size_t)B * L * sizeof(float), st));
+
+    auto layer_bwd = [&](const DConv& c, const TView& x, const TView& yv, const TView& g, const TView* gx, float* gx_plain) -> int {
+        const int M = B * yv.D0 * yv.D1;
+        if (c.act) hipLaunchKernelGGL(leaky_bwd_kernel, dim3(blk((long long)M * yv.Cp / 4)), dim3(256), 0, st, g, yv, (long long)M * yv.Cp / 4, B);
+        if (grad_flat) {
+            ViewRowsA la{g, M, FastDiv(yv.D0 * yv.D1), FastDiv(yv.D1)};
+            ConvS lb = make_convs(x, c, yv.D0, yv.D1, B);
+            int r = disc_dw(la, lb, M, c.CoutP, c.Kf, dWs, dWs + (size_t)c.CoutP * c.Kf, part, st);
+            if (r) return r;
+            hipLaunchKernelGGL(wn_bwd_kernel, dim3(c.Cout), dim3(256), 0, st, dWs, flat_params + c.off_v, c.scale, grad_flat + c.off_v, grad_flat + c.off_g, c.Cin,
+                               c.T0 * c.T1, c.CinP, c.Kf);
+            ESCX_HIP(hipMemcpyAsync(grad_flat + c.off_b, dWs + (size_t)c.CoutP * c.Kf, (size_t)c.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+        if (gx || gx_plain) {
+            ConvGeom cg{c.T0, c.T1, c.s0, c.s1, c.p0, c.p1, yv.D0, yv.D1};
+            const int Mi = B * x.D0 * x.D1;
+            ConvTS lt{g, cg, x.D0, x.D1, Mi, FastDiv(x.D0 * x.D1), FastDiv(x.D1), FastDiv(g.Cp), FastDiv(c.T1), FastDiv(c.s0), FastDiv(c.s1)};
+            if (gx) conv_gemm(lt, c.Wt, Mi, c.CinR, c.Kt, EpiAccumView{*gx, FastDiv(x.D0 * x.D1), FastDiv(x.D1)}, st);
+            else conv_gemm(lt, c.Wt, Mi, c.CinR, c.Kt, EpiStoreN{gx_plain, x.Cp, x.Cp}, st);
+        }
+        return 0;
+    };
+
+    int fi_end = (int)shp.size();
+    for (int si = (int)d->subs.size() - 1; si >= 0; --si) {
+        const DSub& S = d->subs[si];
+        const SubGeom g = geometry(S, L);
+        const int nconv = (int)S.convs.size();
+        const int f0 = fi_end - nconv;
+        if (S.kind == 0) {
+            for (int j = nconv - 1; j >= 0; --j) {
+                const int fi = f0 + j;
+                TView yv = view_of(fmaps[fi], shp[fi]);
+                TView x = j > 0 ? view_of(fmaps[fi - 1], shp[fi - 1]) : TView{ins[si][0], g.D0, g.D1, g.D1, 4};
+                if (j > 0) { if ((rc = layer_bwd(S.convs[j], x, yv, gv[fi], &gv[fi - 1], nullptr))) return rc; }
+                else { if ((rc = layer_bwd(S.convs[j], x, yv, gv[fi], nullptr, d_wave ? gin : nullptr))) return rc; }
+            }
+            if (d_wave) hipLaunchKernelGGL(mpd_input_bwd_kernel, dim3(blk((long long)B * L)), dim3(256), 0, st, gin, dy, B, L, g.D0, S.arg);
+        } else {
+            const int nb = (int)S.bands.size();
+            const int fpost = f0 + nconv - 1, ftop0 = f0 + 4;
+            TView cat_y{fmaps[ftop0], g.T, g.catF, g.catF, 32};
+            TView cat_g{gv[ftop0].p, g.T, g.catF, g.catF, 32};
+            if ((rc = layer_bwd(S.convs.back(), cat_y, view_of(fmaps[fpost], shp[fpost]), gv[fpost], &cat_g, nullptr))) return rc;
+            if (d_wave) ESCX_HIP(hipMemsetAsync(gspec, 0, (size_t)B * g.T * 2 * S.Fq * sizeof(float), st));
+            for (int b = nb - 1; b >= 0; --b) {
+                for (int j = 4; j >= 0; --j) {
+                    const int fi = f0 + b * 5 + j;
+                    TView yv = view_of(fmaps[fi], shp[fi]);
+                    TView x = j > 0 ? view_of(fmaps[fi - 1], shp[fi - 1]) : TView{ins[si][b], g.T, g.bandF[b], g.bandF[b], 4};
+                    if (j > 0) { if ((rc = layer_bwd(S.convs[b * 5 + j], x, yv, gv[fi], &gv[fi - 1], nullptr))) return rc; }
+                    else { if ((rc = layer_bwd(S.convs[b * 5 + j], x, yv, gv[fi], nullptr, d_wave ? gin : nullptr))) return rc; }
+                }
+                if (d_wave) hipLaunchKernelGGL(mrd_band_bwd_kernel, dim3(blk((long long)B * g.T * g.bandF[b])), dim3(256), 0, st, gin, gspec, (long long)B * g.T, S.Fq,
+                                               S.bands[b].first, g.bandF[b]);
+            }
+            if (d_wave) {
+                const int w = S.arg, hop = w / 4;
+                PlainA ld{gspec, 2 * S.Fq, B * g.T};
+                conv_gemm(ld, S.DT, B * g.T, w, 2 * S.Fq, EpiStore{gfr, w, nullptr}, st);
+                hipLaunchKernelGGL(frames_bwd_kernel, dim3(blk((long long)B * L)), dim3(256), 0, st, gfr, dy, B, L, g.T, hop, w, w, 1, (w - hop) / 2);
+            }
+        }
+        fi_end = f0;
+    }
+    if (d_wave) hipLaunchKernelGGL(disc_preprocess_bwd_kernel, dim3(B), dim3(1024), 0, st, dy, y, stats, d_wave, L);
+    return launch_ok("disc_backward");
+}
+
+// One GAN loss term over a feature map (gan_loss.py:29-50): loss_dev[b] (+)= mean over the map's real elements; grad (optional, same layout as x).
+//   mode 0: (target - x)^2 ; mode 1: |x - ref|
+extern "C" int escx_gan_term(const float* x, const float* ref, float* grad, int B, int C, int Cp, int D0, int D1, int P1, int mode, float target, float* loss_dev,
+                             int accumulate, void* stream) {
+    if (!x || !loss_dev || B < 1 || (mode == 1 && !ref) || mode < 0 || mode > 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    TView xv{const_cast<float*>(x), D0, D1, P1, Cp}, rv{const_cast<float*>(ref), D0, D1, P1, Cp}, gvw{grad, D0, D1, P1, Cp};
+    const long long per = (long long)D0 * D1 * Cp;
+    const int bpc = (int)std::min<long long>(64, (per + 255) / 256);
+    float* part = nullptr;
+    ESCX_HIP(hipMallocAsync((void**)&part, (size_t)B * bpc * sizeof(float), st));
+    hipLaunchKernelGGL(gan_term_kernel, dim3(bpc, B), dim3(256), 0, st, xv, rv, gvw, part, mode, target, C, bpc, 1.0f / ((float)C * D0 * D1));
+    hipLaunchKernelGGL(row_sum_kernel, dim3(blk(B, 64)), dim3(64), 0, st, part, bpc, loss_dev, B, accumulate, 1.0f);
+    ESCX_HIP(hipFreeAsync(part, st));
+    return launch_ok("gan_term");
+}

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void gemm_dw2_kernel(const float* __restrict__
 }
 
 // out[i] = sum_s part[s][i], s increasing (fixed order); optional accumulate into out
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int slices, long long n, float* __restrict__ out, int accumulate) {
+static __global__ void reduce_partials_kernel(const float* __restrict__ part, int slices, long long n, float* __restrict__ out, int accumulate) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = accumulate ? out[i] : 0.f;
@@ -380,7 +380,7 @@ __global__ void reduce_partials_kernel(const float* __restrict__ part, int slice
 // The same for MANY slices of a SMALL output (a 48 x 48 weight gradient summed over ~2000 slices): a thread per output would walk its
 // slices as one long chain of dependent L2 loads (~1 ms); here a 64-lane wave owns 16 consecutive outputs, lane (q, j) adds slices
 // q, q+4, q+8, ... of output j (coalesced 64 B reads), then the 4 partial sums are joined in the fixed order ((0+1)+(2+3)).
-__global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* __restrict__ part, int slices, long long n, float* __restrict__ out,
+static __global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* __restrict__ part, int slices, long long n, float* __restrict__ out,
                                                                    int accumulate) {
     const long long wv = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 }
 
 // table gradient: dtable[idx][h] = sum over the (i, j) pairs of the 4x4 window with relative index idx of dbias[h][i][j], fixed order
-__global__ void bias_table_grad_kernel(const float* __restrict__ dbias, float* __restrict__ dtable, int nH) {
+static __global__ void bias_table_grad_kernel(const float* __restrict__ dbias, float* __restrict__ dtable, int nH) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 49 * nH) return;
     const int idx = e / nH, h = e - idx * nH;
@@ -668,16 +668,16 @@ __global__ void bias_table_grad_kernel(const float* __restrict__ dbias, float* _
 // ------------------------------------------------------------------------------------------------
 // small element-wise helpers
 // ------------------------------------------------------------------------------------------------
-__global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n4) {
+static __global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n4) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n4) st4(dst + 4 * i, ld4(dst + 4 * i) + ld4(src + 4 * i));
 }
-__global__ void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ out, long long per_row, long long n) {
+static __global__ void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ out, long long per_row, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = x[i] * g[i / per_row];
 }
 // derived layouts refreshed on the device from the flat fp32 parameter buffer: arena[i] = flat[map[i] - 1] (map 0 = structural zero, < 0 = computed elsewhere)
-__global__ void gather_params_kernel(const float* __restrict__ flat, const int* __restrict__ map, float* __restrict__ arena, long long n) {
+static __global__ void gather_params_kernel(const float* __restrict__ flat, const int* __restrict__ map, float* __restrict__ arena, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int c = map[i];
@@ -685,14 +685,14 @@ __global__ void gather_params_kernel(const float* __restrict__ flat, const int* 
     else if (c == 0) arena[i] = 0.f;
 }
 // gradient of the packed layouts back to the flat reference layout (one-to-one on the regions it is launched on)
-__global__ void scatter_grads_kernel(const float* __restrict__ garena, const int* __restrict__ map, float* __restrict__ gflat, long long n) {
+static __global__ void scatter_grads_kernel(const float* __restrict__ garena, const int* __restrict__ map, float* __restrict__ gflat, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int c = map[i];
     if (c > 0) gflat[c - 1] = garena[i];
 }
 // F.normalize of the codebooks + squared norms (codebook.py:31-36), same summation order as the host packer
-__global__ void codebook_normalize_kernel(const float* __restrict__ raw, float* __restrict__ cbn, float* __restrict__ c2, int rows, int d, int dt, int l2norm) {
+static __global__ void codebook_normalize_kernel(const float* __restrict__ raw, float* __restrict__ cbn, float* __restrict__ c2, int rows, int d, int dt, int l2norm) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= rows) return;
     const float* r = raw + (size_t)k * dt;
@@ -710,7 +710,7 @@ __global__ void codebook_normalize_kernel(const float* __restrict__ raw, float* 
 //   zup [M][ldz]  what the up-projection sees: STE value z_e + (z_q - z_e), or with frozen codebooks (z_q_ste * 0 + z_e)
 //   terms[g*M + m] = sum_j (z_q - z_e)^2 * loss_scale   (commitment == codebook loss numerically; zero when frozen)
 // ------------------------------------------------------------------------------------------------
-__global__ void pvq_train_fwd_kernel(const float* __restrict__ ze, const long long* __restrict__ codes, long long bstride, const float* __restrict__ cbraw,
+static __global__ void pvq_train_fwd_kernel(const float* __restrict__ ze, const long long* __restrict__ codes, long long bstride, const float* __restrict__ cbraw,
                                      float* __restrict__ zup, float* __restrict__ terms, int M, int G, int Ksz, int d, int dt, int ldz, int Tq,
                                      float loss_scale, int freeze) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -735,7 +735,7 @@ __global__ void pvq_train_fwd_kernel(const float* __restrict__ ze, const long lo
 }
 
 // d z_e = d z_up (straight-through / frozen pass-through) + d(cm_loss) ;  gq = d(cb_loss) w.r.t. the selected code row (per vector)
-__global__ void pvq_train_bwd_kernel(const float* __restrict__ ze, const long long* __restrict__ codes, long long bstride, const float* __restrict__ cbraw,
+static __global__ void pvq_train_bwd_kernel(const float* __restrict__ ze, const long long* __restrict__ codes, long long bstride, const float* __restrict__ cbraw,
                                      const float* __restrict__ dzup, const float* __restrict__ dcm, const float* __restrict__ dcb, float* __restrict__ dze,
                                      float* __restrict__ gq, int M, int G, int Ksz, int d, int dt, int ldz, int Tq, float loss_scale, int freeze) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -757,7 +757,7 @@ __global__ void pvq_train_bwd_kernel(const float* __restrict__ ze, const long lo
 
 // embedding gradient without atomics: one wave per (group, code) scans the vectors 64 at a time and adds the rows of those that chose the
 // code in increasing vector order (lane j carries dimension j)
-__global__ __launch_bounds__(256) void codebook_grad_kernel(const long long* __restrict__ codes, long long bstride, const float* __restrict__ gq,
+static __global__ __launch_bounds__(256) void codebook_grad_kernel(const long long* __restrict__ codes, long long bstride, const float* __restrict__ gq,
                                                             float* __restrict__ dcb, int M, int G, int Ksz, int dt, int ldz, int Tq) {
     const int wv = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wv >= G * Ksz) return;
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256) void codebook_grad_kernel(const long long* __r
 // ------------------------------------------------------------------------------------------------
 // inverse-STFT backward: gradient of the windowed frames from the waveform gradient (istft_ola_kernel transposed)
 // ------------------------------------------------------------------------------------------------
-__global__ void istft_ola_bwd_kernel(const float* __restrict__ dwave, const float* __restrict__ win2, float* __restrict__ dframes, int B, int T,
+static __global__ void istft_ola_bwd_kernel(const float* __restrict__ dwave, const float* __restrict__ win2, float* __restrict__ dframes, int B, int T,
                                      int ldf, int win, int hop, int left, int half, int out_len) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)B * T * ldf) return;
@@ -801,7 +801,7 @@ __global__ void istft_ola_bwd_kernel(const float* __restrict__ dwave, const floa
 
 // conv3x3 dX on the fine time-major map: d_in[(b,t,f)][ci] = sum_{tap,oc} g[(b, t-(kw-1))][oc*Fp + f-(kh-1)] * w[oc][tap=(kw*3+kh)][ci]
 // (w is the packed [16][9*Cp] matrix of the forward implicit GEMM: tap order (t0 over time = kw, t1 over freq = kh))
-__global__ void conv3_dx_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dx, int B, int T, int F, int Fp, int Cp,
+static __global__ void conv3_dx_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dx, int B, int T, int F, int Fp, int Cp,
                                 int in_dim) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // one thread per (b,t,f, 4 channels)
     const int V = Cp / 4;
@@ -834,7 +834,7 @@ __global__ void conv3_dx_kernel(const float* __restrict__ g, const float* __rest
 //   g      frame-major spectrum gradient [(b, t)][oc*Fp + f]
 // ------------------------------------------------------------------------------------------------
 constexpr int DEP_J = 20, DEP_LD = 128;
-__global__ void deembed_p_kernel(const float* __restrict__ g, float* __restrict__ P, int B, int H, int W, int pf, int pt, int in_dim, int Fp) {
+static __global__ void deembed_p_kernel(const float* __restrict__ g, float* __restrict__ P, int B, int H, int W, int pf, int pt, int in_dim, int Fp) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)B * H * W * DEP_LD) return;
     const int col = (int)(idx % DEP_LD); long long pix = idx / DEP_LD;
@@ -850,7 +850,7 @@ __global__ void deembed_p_kernel(const float* __restrict__ g, float* __restrict_
     P[idx] = v;
 }
 // dW1[(q*Cp + cc)][k] = sum_j W2[oc][cc][a][b] * R[q*20 + j][k] ; w2 is the packed conv3x3 matrix [16][9*Cp], tap order (b*3 + a)
-__global__ void deembed_fold_dw_kernel(const float* __restrict__ R, const float* __restrict__ w2, float* __restrict__ dW1, int Q, int C, int Cp, int K,
+static __global__ void deembed_fold_dw_kernel(const float* __restrict__ R, const float* __restrict__ w2, float* __restrict__ dW1, int Q, int C, int Cp, int K,
                                        int in_dim) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)Q * Cp * K) return;
@@ -865,7 +865,7 @@ __global__ void deembed_fold_dw_kernel(const float* __restrict__ R, const float*
 }
 // conv3x3 weight gradient from X = P^T . Y1 (X[(q, j)][(q', cc)], only the q == q' blocks are meaningful):
 //   dW2[oc][(b*3 + a)*Cp + cc] = sum_q X[q*20 + j][q*Cp + cc],  j = oc*9 + a*3 + b ;   db2[oc] = sum_q Rb[q*20 + oc*9 + 4]  (centre tap: no border exclusion)
-__global__ void deembed_fold_dw2_kernel(const float* __restrict__ X, const float* __restrict__ Rb, float* __restrict__ dW2, float* __restrict__ db2, int Q,
+static __global__ void deembed_fold_dw2_kernel(const float* __restrict__ X, const float* __restrict__ Rb, float* __restrict__ dW2, float* __restrict__ db2, int Q,
                                         int C, int Cp, int in_dim) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = in_dim * 9 * Cp;
@@ -886,7 +886,7 @@ __global__ void deembed_fold_dw2_kernel(const float* __restrict__ X, const float
 // effective dX weights: Weff[ci][(t0*5 + t1)*128 + q*20 + j] = sum_cc W2[oc][cc][a][b] * W1[(q, cc)][ci][kh = 4 - t0][kw = 4 - t1]
 // (taps flipped so that the forward implicit-GEMM loader ConvA serves the transposed convolution); w1 is the packed conv5x5 matrix
 // [Q*Cp][25*Cp] with k = (kh*5 + kw)*Cp + ci
-__global__ void deembed_weff_kernel(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ weff, int Q, int C, int Cp, int in_dim) {
+static __global__ void deembed_weff_kernel(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ weff, int Q, int C, int Cp, int in_dim) {
     const int KE = 25 * DEP_LD;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)Cp * KE) return;
@@ -907,7 +907,7 @@ __global__ void deembed_weff_kernel(const float* __restrict__ w1, const float* _
 // pl(x) = sign(x) (|x| + 1e-10)^0.3.  Spectra are frame-major (B, T, in_dim, F).  part[b][block] partial sums; unit gradient optional.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float power_law(float x) { return (x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f)) * powf(fabsf(x) + 1e-10f, 0.3f); }
-__global__ __launch_bounds__(256) void stft_loss_kernel(const float* __restrict__ raw, const float* __restrict__ rec, float* __restrict__ part,
+static __global__ __launch_bounds__(256) void stft_loss_kernel(const float* __restrict__ raw, const float* __restrict__ rec, float* __restrict__ part,
                                                         float* __restrict__ grad, long long per_clip, int blocks_per_clip, float inv_n) {
     const int b = blockIdx.y;
     __shared__ float red[256];
@@ -927,7 +927,7 @@ __global__ __launch_bounds__(256) void stft_loss_kernel(const float* __restrict_
     if (threadIdx.x == 0) part[(size_t)b * blocks_per_clip + blockIdx.x] = red[0] * inv_n;
 }
 // out[b] (+)= sum_k part[b][k], fixed order
-__global__ void row_sum_kernel(const float* __restrict__ part, int n, float* __restrict__ out, int rows, int accumulate, float scale) {
+static __global__ void row_sum_kernel(const float* __restrict__ part, int n, float* __restrict__ out, int rows, int accumulate, float scale) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= rows) return;
     float s = 0.f;
@@ -938,7 +938,7 @@ __global__ void row_sum_kernel(const float* __restrict__ part, int n, float* __r
 // ------------------------------------------------------------------------------------------------
 // Mel loss pieces (generator_loss.py:37-74).  spec: [B*T][2*Fp] DFT rows (re | im) of raw and recon; mag = |S|.
 // ------------------------------------------------------------------------------------------------
-__global__ void complex_mag_kernel(const float* __restrict__ spec, float* __restrict__ mag, long long rows, int F, int Fp, int Fq) {
+static __global__ void complex_mag_kernel(const float* __restrict__ spec, float* __restrict__ mag, long long rows, int F, int Fp, int Fq) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * Fq) return;
     const long long r = idx / Fq; const int f = (int)(idx - r * Fq);
@@ -947,7 +947,7 @@ __global__ void complex_mag_kernel(const float* __restrict__ spec, float* __rest
     mag[idx] = v;
 }
 // per-clip mel terms: |x - y| / n  +  |log10(clamp(x)^2) - log10(clamp(y)^2)| / n ; gradient w.r.t. y (the reconstruction's mel)
-__global__ __launch_bounds__(256) void mel_l1_kernel(const float* __restrict__ xm, const float* __restrict__ ym, float* __restrict__ part,
+static __global__ __launch_bounds__(256) void mel_l1_kernel(const float* __restrict__ xm, const float* __restrict__ ym, float* __restrict__ part,
                                                      float* __restrict__ gy, int rows_per_clip, int n_mels, int ldm, int blocks_per_clip, float inv_n,
                                                      float clamp_eps) {
     const int b = blockIdx.y;
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(256) void mel_l1_kernel(const float* __restrict__ x
     if (threadIdx.x == 0) part[(size_t)b * blocks_per_clip + blockIdx.x] = red[0] * inv_n;
 }
 // d spec = d mag * S / |S|   (|.| of a complex number; zero gradient at S = 0)
-__global__ void complex_mag_bwd_kernel(const float* __restrict__ spec, const float* __restrict__ dmag, float* __restrict__ dspec, long long rows, int F,
+static __global__ void complex_mag_bwd_kernel(const float* __restrict__ spec, const float* __restrict__ dmag, float* __restrict__ dspec, long long rows, int F,
                                        int Fp, int Fq) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * Fp) return;
@@ -990,12 +990,12 @@ __global__ void complex_mag_bwd_kernel(const float* __restrict__ spec, const flo
 }
 // framing backward with reflect padding (torch.stft center=True): dwave[b][j] (+)= sum of dframes over every (frame, tap) that read sample j,
 // including the mirrored reads of the padded ends.  padded position i = t*hop + k, sample = reflect(i - pad).
-__global__ void frames_bwd_kernel(const float* __restrict__ dframes, float* __restrict__ dwave, int B, int L, int T, int hop, int n_fft, int ldf,
-                                  int accumulate) {
+static __global__ void frames_bwd_kernel(const float* __restrict__ dframes, float* __restrict__ dwave, int B, int L, int T, int hop, int n_fft, int ldf,
+                                  int accumulate, int pad_left = -1) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)B * L) return;
     const int b = (int)(idx / L), j = (int)(idx - (long long)b * L);
-    const int pad = n_fft / 2;
+    const int pad = pad_left >= 0 ? pad_left : n_fft / 2;      // samples of reflect padding in front of sample 0 (the right side is as long as the frames reach)
     auto gather = [&](int i) {                  // sum over frames covering padded position i
         float s = 0.f;
         if (i < 0) return s;
@@ -1005,14 +1005,14 @@ __global__ void frames_bwd_kernel(const float* __restrict__ dframes, float* __re
     };
     float s = gather(j + pad);
     if (j >= 1 && j <= pad) s += gather(pad - j);                              // left mirror: padded i < pad reads sample pad - i
-    if (j <= L - 2 && j >= L - 1 - pad) s += gather(pad + 2 * (L - 1) - j);      // right mirror: padded i - pad >= L reads 2(L-1) - (i - pad)
+    if (j <= L - 2) s += gather(pad + 2 * (L - 1) - j);                        // right mirror: padded i - pad >= L reads 2(L-1) - (i - pad); gather() is 0 past the last frame
     dwave[idx] = (accumulate ? dwave[idx] : 0.f) + s;
 }
 
 // ------------------------------------------------------------------------------------------------
 // optimiser: global-norm clipping + AdamW on flat buffers (trainer_no_adv.py:116-117; torch.optim.AdamW semantics)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
+static __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
     __shared__ float red[256];
     float acc = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc += x[i] * x[i];
@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 // norm_out[0] = sqrt(sum part) ; norm_out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))
-__global__ void clip_coef_kernel(const float* __restrict__ part, int n, float max_norm, float* __restrict__ norm_out) {
+static __global__ void clip_coef_kernel(const float* __restrict__ part, int n, float max_norm, float* __restrict__ norm_out) {
     if (threadIdx.x || blockIdx.x) return;
     float s = 0.f;
     for (int i = 0; i < n; ++i) s += part[i];
@@ -1031,7 +1031,7 @@ __global__ void clip_coef_kernel(const float* __restrict__ part, int n, float ma
     const float c = max_norm / (nrm + 1e-6f);
     norm_out[1] = c < 1.0f ? c : 1.0f;
 }
-__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+static __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
                              const float* __restrict__ coef, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

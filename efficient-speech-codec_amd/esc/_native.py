@@ -21,6 +21,11 @@ class EscxConfig(Structure):
     ]
 
 
+class EscxDiscConfig(Structure):
+    _fields_ = [("sample_rate", c_int32), ("n_rates", c_int32), ("n_periods", c_int32), ("periods", c_int32 * 8), ("n_ffts", c_int32),
+                ("fft_sizes", c_int32 * 8), ("n_bands", c_int32), ("bands", (c_float * 2) * 8)]
+
+
 # name -> (restype, argtypes); every symbol include/escx.h declares
 SIGNATURES = {
     "escx_last_error": (c_char_p, []),
@@ -70,6 +75,18 @@ SIGNATURES = {
     "escx_scale_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "escx_grad_norm_clip": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     "escx_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "escx_disc_create": (c_int, [POINTER(EscxDiscConfig), c_int, POINTER(c_void_p)]),
+    "escx_disc_destroy": (None, [c_void_p]),
+    "escx_disc_param_count": (c_int, [c_void_p]),
+    "escx_disc_param_key": (c_char_p, [c_void_p, c_int]),
+    "escx_disc_param_offset": (c_int64, [c_void_p, c_int]),
+    "escx_disc_param_numel": (c_int64, [c_void_p, c_int]),
+    "escx_disc_param_total": (c_int64, [c_void_p]),
+    "escx_disc_num_fmaps": (c_int, [c_void_p, c_int]),
+    "escx_disc_fmap_shape": (c_int, [c_void_p, c_int, c_int] + [POINTER(c_int)] * 7),
+    "escx_disc_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p), c_void_p]),
+    "escx_disc_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_void_p]),
+    "escx_gan_term": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "escx_set_rccl_library": (c_int, [c_char_p]),
     "escx_allgather_codes": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
 }

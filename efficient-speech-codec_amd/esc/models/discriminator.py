@@ -1,0 +1,211 @@
+"""DAC discriminator of the reference's adversarial trainer (`/root/reference/esc/models/discriminator.py:31-221`) on the MI355X.
+
+Same constructor (`rates, periods, fft_sizes, sample_rate, bands`), same parameter names (`discriminators.{i}.convs.{j}.0.{bias,weight_g,
+weight_v}`, `...band_convs.{b}.{j}.0...`, `...conv_post...`: reference checkpoints load with `load_state_dict`), same call:
+`disc(x)` with x (B, 1, L) returns one list of feature maps (B, C, D0, D1) per sub-discriminator, differentiable w.r.t. the parameters and
+the waveform.  The convolutions, weight normalisation, matched-stride STFT and all backward passes run in libescx (csrc/disc.hip); there
+is no PyTorch/CPU implementation here.  MSD (`rates`) is not implemented - no ESC configuration uses it.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from .. import _native
+from .codecs import _Node, _attach
+
+BANDS = [(0.0, 0.1), (0.1, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0)]
+
+
+def _conv_specs(periods, fft_sizes, n_bands):
+    """(prefix, Cout, Cin, T0, T1) of every convolution in the reference's construction order."""
+    out, idx = [], 0
+    for _ in periods:
+        p = f"discriminators.{idx}."
+        ch = [1, 32, 128, 512, 1024, 1024]
+        out += [(f"{p}convs.{j}.0.", ch[j + 1], ch[j], 5, 1) for j in range(5)] + [(f"{p}conv_post.", 1, 1024, 3, 1)]
+        idx += 1
+    for _ in fft_sizes:
+        p = f"discriminators.{idx}."
+        for b in range(n_bands):
+            out += [(f"{p}band_convs.{b}.{j}.0.", 32, 2 if j == 0 else 32, 3, 9 if j < 4 else 3) for j in range(5)]
+        out.append((f"{p}conv_post.", 1, 32, 3, 3))
+        idx += 1
+    return out
+
+
+class FeatureMaps(list):
+    """The reference's list of feature maps of one sub-discriminator, plus the channels-last buffers the HIP loss kernels read."""
+    entries: list        # per map: (buffer, C, Cp, D0, D1, P1, off1)
+
+
+class Discriminator(nn.Module):
+    def __init__(self, rates: list = [], periods: list = [2, 3, 5, 7, 11], fft_sizes: list = [2048, 1024, 512], sample_rate: int = 44100,
+                 bands: list = BANDS):
+        super().__init__()
+        if rates:
+            raise NotImplementedError("MSD (rates) is not implemented in the MI355X build; the ESC configurations use rates=[]")
+        self.cfg = dict(rates=list(rates), periods=list(periods), fft_sizes=list(fft_sizes), sample_rate=sample_rate, bands=[tuple(b) for b in bands])
+        for pfx, cout, cin, t0, t1 in _conv_specs(periods, fft_sizes, len(bands)):
+            fan_in = cin * t0 * t1
+            bound = 1.0 / math.sqrt(fan_in)
+            v = torch.empty(cout, cin, t0, t1).uniform_(-bound, bound)                   # nn.Conv2d default init, then weight_norm: g = ||v||
+            _attach(self, pfx + "bias", torch.empty(cout).uniform_(-bound, bound), False)
+            _attach(self, pfx + "weight_g", v.flatten(1).norm(dim=1).view(cout, 1, 1, 1).clone(), False)
+            _attach(self, pfx + "weight_v", v, False)
+        self._handles, self._flat = {}, {}
+
+    def _apply(self, fn, *a, **k):
+        self._drop()
+        return super()._apply(fn, *a, **k)
+
+    def _drop(self):
+        if getattr(self, "_handles", None):
+            lib = _native.load()
+            for hd in self._handles.values():
+                lib.escx_disc_destroy(hd)
+        self._handles, self._flat = {}, {}
+
+    def __del__(self):
+        try:
+            self._drop()
+        except Exception:
+            pass
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_handles"], st["_flat"] = {}, {}
+        return st
+
+    def _handle(self, device):
+        lib = _native.load()
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if idx not in self._handles:
+            c = self.cfg
+            cc = _native.EscxDiscConfig()
+            cc.sample_rate, cc.n_rates, cc.n_periods, cc.n_ffts, cc.n_bands = c["sample_rate"], 0, len(c["periods"]), len(c["fft_sizes"]), len(c["bands"])
+            for i, p in enumerate(c["periods"]):
+                cc.periods[i] = p
+            for i, w in enumerate(c["fft_sizes"]):
+                cc.fft_sizes[i] = w
+            for i, (lo, hi) in enumerate(c["bands"]):
+                cc.bands[i][0], cc.bands[i][1] = lo, hi
+            hd = ctypes.c_void_p()
+            _native.check(lib.escx_disc_create(ctypes.byref(cc), idx, ctypes.byref(hd)))
+            self._handles[idx] = hd
+        return lib, self._handles[idx]
+
+    def _ensure_flat(self, device, lib, hd):
+        """Flat fp32 parameter buffer in the library's order; the nn.Parameters are views of it (same scheme as esc.ESC)."""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        st = self._flat.get(idx)
+        params = dict(self.named_parameters())
+        if st is None:
+            n = lib.escx_disc_param_count(hd)
+            layout = [(lib.escx_disc_param_key(hd, i).decode(), int(lib.escx_disc_param_offset(hd, i)), int(lib.escx_disc_param_numel(hd, i))) for i in range(n)]
+            st = {"flat": torch.zeros(int(lib.escx_disc_param_total(hd)), dtype=torch.float32, device=device), "layout": layout}
+            self._flat[idx] = st
+        flat, base = st["flat"], st["flat"].data_ptr()
+        with torch.no_grad():
+            for key, off, n in st["layout"]:
+                p = params[key]
+                if p.data_ptr() != base + 4 * off:
+                    flat[off:off + n].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
+                    p.data = flat[off:off + n].view(p.shape)
+        return flat
+
+    def fmap_layout(self, device, n_samples):
+        lib, hd = self._handle(device)
+        out = []
+        ints = [ctypes.c_int() for _ in range(7)]
+        for i in range(lib.escx_disc_num_fmaps(hd, n_samples)):
+            _native.check(lib.escx_disc_fmap_shape(hd, n_samples, i, *[ctypes.byref(v) for v in ints]))
+            out.append(tuple(v.value for v in ints))          # (sub, C, Cp, D0, D1, P1, off1)
+        return out
+
+    def forward(self, x) -> List[FeatureMaps]:
+        if x.dim() != 3 or x.shape[1] != 1:
+            raise ValueError("x must have shape (B, 1, L)")
+        if not x.is_cuda:
+            raise RuntimeError("esc Discriminator (MI355X build): x must live on a HIP device; this package has no CPU implementation")
+        layout = self.fmap_layout(x.device, x.shape[-1])
+        bufs = _DiscFn.apply(self, x[:, 0].to(torch.float32).contiguous(), layout, *self.parameters())
+        out, bi = [], 0
+        n_sub = len(self.cfg["periods"]) + len(self.cfg["fft_sizes"])
+        per_sub = [FeatureMaps() for _ in range(n_sub)]
+        for fm in per_sub:
+            fm.entries = []
+        cat = None
+        for sub, C, Cp, D0, D1, P1, off1 in layout:
+            if P1 == D1:
+                buf = bufs[bi]; bi += 1
+            else:
+                if off1 == 0:
+                    cat = bufs[bi]; bi += 1
+                buf = cat
+            per_sub[sub].append(buf[:, :, off1:off1 + D1, :C].permute(0, 3, 1, 2))
+            per_sub[sub].entries.append((buf, C, Cp, D0, D1, P1, off1))
+        return per_sub
+
+
+def _buffer_plan(layout):
+    """Shapes of the distinct output buffers ([D0][P1][Cp], B prepended at allocation) and, per map, (buffer index, column offset)."""
+    shapes, where, cat = [], [], -1
+    for sub, C, Cp, D0, D1, P1, off1 in layout:
+        if P1 == D1:
+            shapes.append((D0, P1, Cp)); where.append((len(shapes) - 1, 0))
+        else:                                   # a column slice of the concatenated buffer, which is allocated with its first slice
+            if off1 == 0:
+                shapes.append((D0, P1, Cp)); cat = len(shapes) - 1
+            where.append((cat, off1))
+    return shapes, where
+
+
+class _DiscFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disc, wave, layout, *params):
+        dev = wave.device
+        lib, hd = disc._handle(dev)
+        flat = disc._ensure_flat(dev, lib, hd)
+        B, L = wave.shape
+        shapes, where = _buffer_plan(layout)
+        bufs = [torch.empty((B,) + s, dtype=torch.float32, device=dev) for s in shapes]
+        ptrs = (ctypes.c_void_p * len(layout))(*[bufs[bi].data_ptr() + 4 * off1 * layout[i][2] for i, (bi, off1) in enumerate(where)])
+        with torch.cuda.device(dev):
+            _native.check(lib.escx_disc_forward(hd, ctypes.c_void_p(flat.data_ptr()), ctypes.c_void_p(wave.data_ptr()), B, L, ptrs,
+                                                ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        ctx.disc, ctx.layout, ctx.where, ctx.wave, ctx.bufs, ctx.idx = disc, layout, where, wave, bufs, (dev.index if dev.index is not None else torch.cuda.current_device())
+        ctx.want_wave, ctx.want_params = ctx.needs_input_grad[1], any(ctx.needs_input_grad[3:])
+        return tuple(bufs)
+
+    @staticmethod
+    def backward(ctx, *dbufs):
+        disc, layout, where, wave, bufs = ctx.disc, ctx.layout, ctx.where, ctx.wave, ctx.bufs
+        dev = wave.device
+        lib, hd = disc._handle(dev)
+        st = disc._flat[ctx.idx]
+        flat = st["flat"]
+        B, L = wave.shape
+        dbufs = [None if g is None else g.to(torch.float32).contiguous() for g in dbufs]
+        n = len(layout)
+        fm = (ctypes.c_void_p * n)(*[bufs[bi].data_ptr() + 4 * off1 * layout[i][2] for i, (bi, off1) in enumerate(where)])
+        dfm = (ctypes.c_void_p * n)(*[(None if dbufs[bi] is None else dbufs[bi].data_ptr() + 4 * off1 * layout[i][2]) for i, (bi, off1) in enumerate(where)])
+        gflat = torch.empty_like(flat) if ctx.want_params else None
+        dwave = torch.empty_like(wave) if ctx.want_wave else None
+        if gflat is None and dwave is None:
+            return (None, None, None) + (None,) * (len(st["layout"]))
+        with torch.cuda.device(dev):
+            _native.check(lib.escx_disc_backward(hd, ctypes.c_void_p(flat.data_ptr()), ctypes.c_void_p(wave.data_ptr()), B, L, fm, dfm,
+                                                 None if gflat is None else ctypes.c_void_p(gflat.data_ptr()),
+                                                 None if dwave is None else ctypes.c_void_p(dwave.data_ptr()),
+                                                 ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        grads = (None,) * len(st["layout"])
+        if gflat is not None:
+            params = dict(disc.named_parameters())
+            by_id = {id(params[k]): gflat[off:off + n_].view(params[k].shape) for k, off, n_ in st["layout"]}
+            grads = tuple(by_id.get(id(p)) for p in disc.parameters())
+        return (None, dwave, None) + grads

@@ -107,3 +107,60 @@ class MelSpectrogramLoss(nn.Module):
 
     def forward(self, raw_audio, recon_audio):
         return self.weight * _MelLossFn.apply(raw_audio, recon_audio, SR)
+
+
+class _GanTermFn(torch.autograd.Function):
+    """One per-clip loss term over a channels-last feature-map buffer (escx_gan_term): mode 0 = mean (target - x)^2, mode 1 = mean |x - ref|."""
+
+    @staticmethod
+    def forward(ctx, buf, ref, meta, mode, target):
+        C, Cp, D0, D1, P1, off1 = meta
+        lib = _native.load()
+        B = buf.shape[0]
+        loss = torch.empty(B, dtype=torch.float32, device=buf.device)
+        need = ctx.needs_input_grad[0]
+        unit = torch.zeros_like(buf) if need else None          # zeros: a slice of a concatenated buffer only covers its own columns
+        off = 4 * off1 * Cp
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr() + off)
+        with torch.cuda.device(buf.device):
+            _native.check(lib.escx_gan_term(p(buf), p(ref), p(unit), B, C, Cp, D0, D1, P1, int(mode), float(target), _ptr(loss), 0, _stream(buf.device)))
+        ctx.unit = unit
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return (_scale_rows(ctx.unit, g) if ctx.unit is not None else None), None, None, None, None
+
+
+class GANLoss(nn.Module):
+    """Least-squares GAN + feature-matching losses of the adversarial trainer (`/root/reference/esc/modules/loss/gan_loss.py:5-50`)."""
+
+    def __init__(self, discriminator):
+        super().__init__()
+        self.discriminator = discriminator
+
+    def forward(self, fake, real):
+        if fake.dim() == 2:
+            fake = fake.unsqueeze(1)
+        if real.dim() == 2:
+            real = real.unsqueeze(1)
+        return self.discriminator(**dict(x=fake)), self.discriminator(**dict(x=real))
+
+    def discriminator_loss(self, fake, real):
+        d_fake, d_real = self.forward(fake.clone().detach(), real)
+        loss = 0
+        for xf, xr in zip(d_fake, d_real):
+            bf, *mf = xf.entries[-1]
+            br, *mr = xr.entries[-1]
+            loss = loss + _GanTermFn.apply(bf, None, tuple(mf), 0, 0.0) + _GanTermFn.apply(br, None, tuple(mr), 0, 1.0)
+        return loss
+
+    def generator_loss(self, fake, real):
+        d_fake, d_real = self.forward(fake, real)
+        loss_g, loss_f = 0, 0
+        for xf, xr in zip(d_fake, d_real):
+            bf, *mf = xf.entries[-1]
+            loss_g = loss_g + _GanTermFn.apply(bf, None, tuple(mf), 0, 1.0)
+            for (ba, *ma), (bb, *mb) in zip(xf.entries[:-1], xr.entries[:-1]):
+                loss_f = loss_f + _GanTermFn.apply(ba, bb.detach(), tuple(ma), 1, 0.0)
+        return loss_g, loss_f

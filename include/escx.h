@@ -196,6 +196,39 @@ int escx_grad_norm_clip(const float* grad_flat_dev, int64_t n, float max_norm, f
 int escx_adamw_step(float* param_flat_dev, const float* grad_flat_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, int step,
                     float lr, float beta1, float beta2, float eps, float weight_decay, const float* clip_dev, void* stream);
 
+/* ---- adversarial step: DAC discriminator + GAN losses (BASELINE configs[4]; scripts/trainer_adv.py:60-105) ---------------------------------
+ * Reference: esc/models/discriminator.py:31-221 (MPD :31-66, MRD :105-176, Discriminator :179-215; MSD is not used by any ESC config),
+ * esc/modules/loss/gan_loss.py:5-50.  Parameters: one flat fp32 device buffer in the order escx_disc_param_*() reports (the reference's
+ * named_parameters(): per convolution bias, weight_g, weight_v).  Feature maps are caller-owned channels-last buffers [B][D0][P1][Cp]
+ * (escx_disc_fmap_shape); the reference's (B, C, D0, D1) tensor of map i is buffer[:, :, off1 : off1 + D1, :C] permuted (0, 3, 1, 2). */
+typedef struct {
+    int32_t sample_rate;                 /* 16000                                                  */
+    int32_t n_rates;                     /* must be 0 (MSD unsupported)                            */
+    int32_t n_periods; int32_t periods[8];      /* 2, 3, 5, 7, 11                                  */
+    int32_t n_ffts; int32_t fft_sizes[8];       /* 2048, 1024, 512                                 */
+    int32_t n_bands; float bands[8][2];         /* (0, .1), (.1, .25), (.25, .5), (.5, .75), (.75, 1) */
+} escx_disc_config;
+typedef struct escx_disc_s* escx_disc;
+int escx_disc_create(const escx_disc_config* cfg, int device, escx_disc* out);
+void escx_disc_destroy(escx_disc d);
+int escx_disc_param_count(escx_disc d);
+const char* escx_disc_param_key(escx_disc d, int i);
+int64_t escx_disc_param_offset(escx_disc d, int i);
+int64_t escx_disc_param_numel(escx_disc d, int i);
+int64_t escx_disc_param_total(escx_disc d);
+int escx_disc_num_fmaps(escx_disc d, int n_samples);
+int escx_disc_fmap_shape(escx_disc d, int n_samples, int i, int* sub, int* C, int* Cp, int* D0, int* D1, int* P1, int* off1);
+/* Discriminator.forward: wave (B, L) -> every feature map (fmaps_dev: HOST array of device pointers, map i's own base address). */
+int escx_disc_forward(escx_disc d, const float* flat_params_dev, const float* wave_dev, int batch, int n_samples, float* const* fmaps_dev, void* stream);
+/* Backward of a forward on the same (params, wave, fmaps): d_fmaps_dev[i] (same layout, NULL = zero) -> grad_flat_dev (optional, overwritten)
+ * and / or d_wave_dev (optional, (B, L), overwritten). */
+int escx_disc_backward(escx_disc d, const float* flat_params_dev, const float* wave_dev, int batch, int n_samples, float* const* fmaps_dev,
+                       const float* const* d_fmaps_dev, float* grad_flat_dev, float* d_wave_dev, void* stream);
+/* One GAN loss term over a feature-map buffer (gan_loss.py:29-50): loss_dev[b] (+)= mean over the C x D0 x D1 real elements of
+ * (target - x)^2 (mode 0) or |x - ref| (mode 1); grad_dev (optional, layout of x) receives d term_b / d x. */
+int escx_gan_term(const float* x_dev, const float* ref_dev, float* grad_dev, int batch, int C, int Cp, int D0, int D1, int P1, int mode, float target,
+                  float* loss_dev, int accumulate, void* stream);
+
 /* ---- multi-GPU: the one exchange step of the sharded path (BASELINE configs[3]; SURVEY.md 8(b),(e)) ------------- */
 /* The reference has no inference-time collective (clips are independent end to end); batch shards exchange only the emitted codes.
  * codes_local_dev: n_local_codes int64 values of this rank (e.g. 36*S*G*T); codes_all_dev: world_size * n_local_codes, rank order.
