@@ -43,11 +43,11 @@ def base_config():
     return json.loads(str(g["config_json"]))
 
 
-def build_model(device):
+def build_model(device, name="base"):
     from esc import synth
     from esc.models import make_model
     from esc.models.codecs import state_manifest
-    cfg = base_config()
+    cfg = base_config() if name == "base" else json.loads(str(np.load(os.path.join(ROOT, "tests", "golden", f"{name}.npz"))["config_json"]))
     model = make_model(cfg)
     sd = {}
     for k, shp in state_manifest(model.cfg).items():
@@ -240,10 +240,71 @@ def run_train(args, rank, world, device, use_dist):
     print(json.dumps(out))
 
 
+def run_train_adv(args, rank, world, device, use_dist):
+    """--mode train_adv = BASELINE configs[4]: ESC-Large 9 kbps + the adversarial training step of scripts/trainer_adv.py:60-105 (generator update
+    with LS-GAN + feature-matching terms through the DAC discriminator, then the discriminator update), batch 36, one MI355X.  fp32: the reference
+    has no reduced-precision path (plain Accelerator()), so a bf16 number would be narrower than the reference's arithmetic."""
+    from esc import synth
+    from esc.models import Discriminator
+    from scripts.train import AdvStepper
+    model, cfg, sd = build_model(device, "large")
+    disc = Discriminator(sample_rate=16000).to(device)
+    bsz = int(os.environ.get("ESCX_BENCH_ADV_BATCH", CLIPS_PER_GPU))
+    pcm = np.stack([(synth.voiced_clip_int16 if i % 2 else synth.noise_clip_int16)(f"bench-r{rank}-{i}", TRAIN_SAMPLES) for i in range(bsz)])
+    x = torch.from_numpy(synth.pcm_to_float(pcm)).to(device)
+    st = AdvStepper(model, disc, lr=1e-4, dropout_rate=0.0)
+
+    def sync():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+    for n in range(args.warmup):
+        st.step(x, n)
+    sync()
+    t0 = time.perf_counter()
+    for n in range(args.steps):
+        log = st.step(x, args.warmup + n)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert all(bool(torch.isfinite(v).all()) for v in log.values() if torch.is_tensor(v))
+    if rank != 0:
+        return
+    n_gen, n_disc = sum(p.numel() for p in model.parameters()), sum(p.numel() for p in disc.parameters())
+    # convolution FLOPs of one discriminator pass per clip (2 x MACs), from the feature-map geometry
+    lay = disc.fmap_layout(device, TRAIN_SAMPLES)
+    from esc.models.discriminator import _conv_specs
+    specs = _conv_specs(disc.cfg["periods"], disc.cfg["fft_sizes"], len(disc.cfg["bands"]))
+    d_flops = sum(2.0 * D0 * D1 * cout * cin * t0 * t1 for (sub, C, Cp, D0, D1, P1, off1), (pfx, cout, cin, t0, t1) in zip(lay, specs))
+    # per step: generator step = 2 forward passes (fake, real) + input-gradient backward of the fake pass; discriminator step = 2 forward + 2 full backward
+    d_step_flops = d_flops * (2 + 1 + 2 + 2 * 2)
+    audio_s = bsz * world * args.steps * (TRAIN_SAMPLES / 16000.0)
+    out = {"metric": "audio-seconds/sec trained, adversarial step (generator + discriminator updates), ESC-Large 9kbps 3s@16kHz",
+           "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": f"BASELINE configs[4]: ESC-Large 9kbps + adversarial training step (scripts/trainer_adv.py:60-105), batch={bsz} clips of "
+                                  f"{TRAIN_SAMPLES} samples per GPU, num_streams=6, fp32 (the reference has no bf16 / AMP path)",
+                      "global_batch": bsz * world, "clip_samples": TRAIN_SAMPLES, "num_streams": NUM_STREAMS, "parallelism": f"dp{world}",
+                      "generator_params_M": round(n_gen / 1e6, 2), "discriminator_params_M": round(n_disc / 1e6, 2),
+                      "losses": {k: round(float(v), 5) for k, v in log.items() if torch.is_tensor(v)}},
+           "roofline": {"bound": "mfma", "achieved": round(d_step_flops * bsz / (elapsed / args.steps) / 1e12, 3), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                        "frac": round(d_step_flops * bsz / (elapsed / args.steps) / PEAK_F32_MFMA, 4), "traffic": None,
+                        "kernel": "discriminator convolutions (all launches of the step)",
+                        "note": "algorithmic discriminator-convolution FLOPs of the step (9 pass-equivalents of "
+                                f"{d_flops / 1e9:.1f} GFLOP per clip) over the WHOLE step time, generator included: a lower bound on the conv kernels' rate"},
+           "cpu_baseline": None}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", choices=["codec", "train"], default="codec",
-                    help="codec (default): encode+decode throughput, the BASELINE metric; train: one optimisation step (BASELINE configs[4], first slice)")
+    ap.add_argument("--mode", choices=["codec", "train", "train_adv"], default="codec",
+                    help="codec (default): encode+decode throughput, the BASELINE metric; train: the non-adversarial optimisation step (ESC-Base); "
+                         "train_adv: BASELINE configs[4] - ESC-Large + the adversarial step (generator and discriminator updates), fp32")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
@@ -272,6 +333,12 @@ def main():
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)
 
+    if args.mode == "train_adv":
+        run_train_adv(args, rank, world, device, use_dist)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.mode == "train":
         run_train(args, rank, world, device, use_dist)
         if use_dist:

@@ -58,6 +58,39 @@ class Discriminator(nn.Module):
             _attach(self, pfx + "weight_g", v.flatten(1).norm(dim=1).view(cout, 1, 1, 1).clone(), False)
             _attach(self, pfx + "weight_v", v, False)
         self._handles, self._flat = {}, {}
+        self._flat_grad_mode = False
+
+    # ---- flat-gradient mode (esc.optim.FlatAdamW), same contract as esc.ESC -------------------------------------------------
+    def enable_flat_grads(self, device):
+        device = torch.device(device)
+        lib, hd = self._handle(device)
+        flat = self._ensure_flat(device, lib, hd)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        st = self._flat[idx]
+        if "gflat" not in st:
+            st["gflat"], st["gfresh"] = torch.zeros_like(flat), True
+        params = dict(self.named_parameters())
+        for key, off, n in st["layout"]:
+            params[key].grad = st["gflat"][off:off + n].view(params[key].shape)
+        self._flat_grad_mode = True
+
+    def flat_buffers(self, device):
+        device = torch.device(device)
+        lib, hd = self._handle(device)
+        flat = self._ensure_flat(device, lib, hd)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if "gflat" not in self._flat[idx]:
+            self.enable_flat_grads(device)
+        return flat, self._flat[idx]["gflat"]
+
+    def zero_flat_grads(self, device):
+        idx = torch.device(device).index
+        st = self._flat.get(idx if idx is not None else torch.cuda.current_device())
+        if st is not None and "gflat" in st:
+            st["gfresh"] = True
+
+    def note_params_updated(self):
+        pass                                    # the packed weights are rebuilt from the flat buffer at every forward
 
     def _apply(self, fn, *a, **k):
         self._drop()
@@ -194,7 +227,8 @@ class _DiscFn(torch.autograd.Function):
         n = len(layout)
         fm = (ctypes.c_void_p * n)(*[bufs[bi].data_ptr() + 4 * off1 * layout[i][2] for i, (bi, off1) in enumerate(where)])
         dfm = (ctypes.c_void_p * n)(*[(None if dbufs[bi] is None else dbufs[bi].data_ptr() + 4 * off1 * layout[i][2]) for i, (bi, off1) in enumerate(where)])
-        gflat = torch.empty_like(flat) if ctx.want_params else None
+        flat_mode = disc._flat_grad_mode and "gflat" in st and ctx.want_params
+        gflat = (st["gflat"] if (flat_mode and st["gfresh"]) else torch.empty_like(flat)) if ctx.want_params else None
         dwave = torch.empty_like(wave) if ctx.want_wave else None
         if gflat is None and dwave is None:
             return (None, None, None) + (None,) * (len(st["layout"]))
@@ -204,7 +238,12 @@ class _DiscFn(torch.autograd.Function):
                                                  None if dwave is None else ctypes.c_void_p(dwave.data_ptr()),
                                                  ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         grads = (None,) * len(st["layout"])
-        if gflat is not None:
+        if flat_mode:                           # p.grad are views of st["gflat"]: written (or accumulated) in place
+            if st["gfresh"]:
+                st["gfresh"] = False
+            else:
+                st["gflat"].add_(gflat)
+        elif gflat is not None:
             params = dict(disc.named_parameters())
             by_id = {id(params[k]): gflat[off:off + n_].view(params[k].shape) for k, off, n_ in st["layout"]}
             grads = tuple(by_id.get(id(p)) for p in disc.parameters())

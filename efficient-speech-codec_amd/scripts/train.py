@@ -1,4 +1,4 @@
-"""Non-adversarial training loop on the MI355X: the optimisation step of the reference trainer (`/root/reference/scripts/
+"""Training loops on the MI355X (non-adversarial by default, `--adv` for the GAN step): the optimisation step of the reference trainer (`/root/reference/scripts/
 trainer_no_adv.py:95-124`) without its experiment plumbing (accelerate, wandb, tqdm, checkpoint rotation are not reproduced).
 
 Per step: sample the number of transmitted streams (quantisation dropout, `scripts/utils.py:11-25`), freeze the codebooks during the
@@ -24,6 +24,7 @@ from esc.modules import ComplexSTFTLoss, MelSpectrogramLoss
 from esc.optim import FlatAdamW
 
 DEFAULT_LOSS_WEIGHTS = dict(stft_weight=1.0, cm_weight=0.25, cb_weight=1.0, mel_weight=0.25)
+ADV_LOSS_WEIGHTS = dict(stft_weight=0.0, cm_weight=0.25, cb_weight=1.0, mel_weight=15.0, gen_weight=1.0, feat_weight=2.0)     # configs/9kbps_esc_base_adv.yaml:41-47
 
 
 def sample_streams(rng: np.random.Generator, dropout_rate: float, max_streams: int) -> int:
@@ -80,6 +81,46 @@ class Stepper:
         return {"streams": s, "frozen": freeze, **{k: v.detach().mean() for k, v in terms.items()}}
 
 
+class AdvStepper:
+    """The adversarial step of `/root/reference/scripts/trainer_adv.py:60-105`: generator update (VQ + mel [+ STFT] + LS-GAN + feature matching,
+    clip 1e3) followed by the discriminator update on the detached reconstruction (clip 10); during the frozen-codebook pre-training
+    phase the discriminator is not involved."""
+
+    def __init__(self, model, disc, lr, loss_weights=None, dropout_rate=1.0, pretraining_steps=0, seed=1234, group=None):
+        from esc.modules import GANLoss
+        self.model, self.disc = model.train(), disc.train()
+        self.w = dict(ADV_LOSS_WEIGHTS, **(loss_weights or {}))
+        self.mel, self.stft, self.gan = MelSpectrogramLoss(), ComplexSTFTLoss(), GANLoss(disc)
+        self.opt_g = FlatAdamW(model, lr=lr, max_grad_norm=1e3, group=group)
+        self.opt_d = FlatAdamW(disc, lr=lr, max_grad_norm=10.0, group=group)
+        self.dropout_rate, self.pretraining_steps = dropout_rate, pretraining_steps
+        self.rng = np.random.default_rng(seed)
+
+    def step(self, x: torch.Tensor, n: int) -> dict:
+        freeze = n < self.pretraining_steps
+        s = sample_streams(self.rng, self.dropout_rate, self.model.max_streams)
+        out = self.model(x=x, x_feat=None, num_streams=s, freeze_codebook=freeze)
+        terms = {"cm_loss": out["cm_loss"], "cb_loss": out["cb_loss"], "mel_loss": self.mel(out["raw_audio"], out["recon_audio"])}
+        if self.w["stft_weight"] != 0.0:
+            terms["stft_loss"] = self.stft(out["raw_feat"], out["recon_feat"])
+        if not freeze:
+            for p in self.disc.parameters():                        # the generator step needs d loss / d waveform only: skip the discriminator's dW
+                p.requires_grad_(False)
+            terms["gen_loss"], terms["feat_loss"] = self.gan.generator_loss(fake=out["recon_audio"], real=out["raw_audio"])
+            for p in self.disc.parameters():
+                p.requires_grad_(True)
+        total = sum(terms[k] * self.w[k.replace("_loss", "_weight")] for k in terms)
+        total.mean().backward()
+        self.opt_g.step(); self.opt_g.zero_grad()
+        log = {"streams": s, "frozen": freeze, **{k: v.detach().mean() for k, v in terms.items()}, "loss": total.detach().mean()}
+        if not freeze:
+            d_loss = self.gan.discriminator_loss(fake=out["recon_audio"], real=out["raw_audio"])
+            d_loss.mean().backward()
+            self.opt_d.step(); self.opt_d.zero_grad()
+            log["disc_loss"] = d_loss.detach().mean()
+        return log
+
+
 def _batches(args, device, rank, world):
     if args.data:
         from torch.utils.data import DataLoader, default_collate
@@ -111,6 +152,7 @@ def main():
     ap.add_argument("--dropout_rate", type=float, default=1.0)
     ap.add_argument("--scheduler_type", default="constant")
     ap.add_argument("--num_warmup_steps", type=int, default=0)
+    ap.add_argument("--adv", action="store_true", help="adversarial training (trainer_adv.py): adds the DAC discriminator and its update")
     ap.add_argument("--save_path", default=None)
     ap.add_argument("--log_steps", type=int, default=5)
     ap.add_argument("--seed", type=int, default=1234)
@@ -133,8 +175,14 @@ def main():
         from .test import load_model
         model, _ = load_model(argparse.Namespace(model_path=None, synthetic=args.synthetic))
     model = model.to(device)
-    st = Stepper(model, args.lr, loss_w, args.dropout_rate, args.pretraining_steps, args.scheduler_type, args.steps, args.num_warmup_steps,
-                 seed=args.seed)                                        # same seed on every rank: the ranks agree on the stream count
+    if args.adv:
+        from esc.models import Discriminator
+        dcfg = (cfg.get("discriminator") if args.config else None) or dict(sample_rate=16000)
+        disc = Discriminator(**dcfg).to(device)
+        st = AdvStepper(model, disc, args.lr, loss_w, args.dropout_rate, args.pretraining_steps, seed=args.seed)
+    else:
+        st = Stepper(model, args.lr, loss_w, args.dropout_rate, args.pretraining_steps, args.scheduler_type, args.steps, args.num_warmup_steps,
+                     seed=args.seed)                                    # same seed on every rank: the ranks agree on the stream count
     data = _batches(args, device, rank, world)
     t0 = time.perf_counter()
     for n in range(args.steps):
