@@ -31,6 +31,7 @@ struct DConv {
     int Kf, Kt;
     size_t off_b = 0, off_g = 0, off_v = 0;
     float *Wf = nullptr, *Wt = nullptr, *bias = nullptr, *scale = nullptr;
+    float* Wp = nullptr; size_t wp_floats = 0;      // strided layers: per-residue-class compact dX weights (disc_kernels.h ConvTSP)
 };
 struct DSub {
     int kind, arg;                       // 0: MPD(period), 1: MRD(window length)
@@ -60,6 +61,9 @@ DConv make_conv(const std::string& p, int Cin, int Cout, int T0, int T1, int s0,
     DConv c; c.prefix = p; c.Cin = Cin; c.Cout = Cout; c.CinP = Cin < 16 ? 4 : rup(Cin, 16); c.CoutP = rup(Cout, 16); c.CinR = rup(c.CinP, 16);
     c.T0 = T0; c.T1 = T1; c.s0 = s0; c.s1 = s1; c.p0 = p0; c.p1 = p1; c.act = act;
     c.Kf = rup(T0 * T1 * c.CinP, 16); c.Kt = T0 * T1 * c.CoutP;
+    if (s0 * s1 > 1)
+        for (int r0 = 0; r0 < s0; ++r0) for (int r1 = 0; r1 < s1; ++r1)
+            c.wp_floats += (size_t)c.CinR * phase_ntaps(r0, p0, s0, T0) * phase_ntaps(r1, p1, s1, T1) * c.CoutP;
     return c;
 }
 
@@ -120,7 +124,7 @@ int pack_weights(escx_disc_s* d, const float* flat, hipStream_t st) {
     for (DSub& S : d->subs)
         for (DConv& c : S.convs)
             hipLaunchKernelGGL(wn_pack_kernel, dim3(c.Cout), dim3(256), 0, st, flat + c.off_v, flat + c.off_g, flat + c.off_b, c.Wf, c.Wt, c.bias, c.scale,
-                               c.Cout, c.Cin, c.T0 * c.T1, c.CinP, c.CoutP, c.Kf, c.Kt);
+                               c.Cout, c.Cin, c.T0 * c.T1, c.CinP, c.CoutP, c.Kf, c.Kt, c.Wp, c.T0, c.T1, c.s0, c.s1, c.p0, c.p1, c.CinR);
     return launch_ok("disc_pack_weights");
 }
 
@@ -215,7 +219,7 @@ extern "C" int escx_disc_create(const escx_disc_config* cfg, int device, escx_di
             c.off_b = off; d->keys.push_back(c.prefix + "bias"); d->offs.push_back(off); d->numels.push_back(c.Cout); off += c.Cout;
             c.off_g = off; d->keys.push_back(c.prefix + "weight_g"); d->offs.push_back(off); d->numels.push_back(c.Cout); off += c.Cout;
             c.off_v = off; d->keys.push_back(c.prefix + "weight_v"); d->offs.push_back(off); d->numels.push_back(nv); off += nv;
-            wf += pad64((size_t)c.CoutP * c.Kf) + pad64((size_t)c.CinR * c.Kt) + pad64(c.CoutP) + pad64(2 * c.Cout);
+            wf += pad64((size_t)c.CoutP * c.Kf) + pad64((size_t)c.CinR * c.Kt) + pad64(c.CoutP) + pad64(2 * c.Cout) + pad64(c.wp_floats);
         }
         if (S.kind == 1) wf += 2 * pad64((size_t)2 * S.Fq * S.arg);
     }
@@ -228,7 +232,8 @@ extern "C" int escx_disc_create(const escx_disc_config* cfg, int device, escx_di
     size_t cur = 0;
     auto take = [&](size_t n) { float* p = d->wbuf + cur; cur += pad64(n); return p; };
     for (DSub& S : d->subs) {
-        for (DConv& c : S.convs) { c.Wf = take((size_t)c.CoutP * c.Kf); c.Wt = take((size_t)c.CinR * c.Kt); c.bias = take(c.CoutP); c.scale = take(2 * c.Cout); }
+        for (DConv& c : S.convs) { c.Wf = take((size_t)c.CoutP * c.Kf); c.Wt = take((size_t)c.CinR * c.Kt); c.bias = take(c.CoutP); c.scale = take(2 * c.Cout);
+                                   if (c.wp_floats) c.Wp = take(c.wp_floats); }
         if (S.kind == 1) {      // windowed DFT of AudioSignal.stft: periodic hann of the full window length
             const int w = S.arg, nf = w / 2 + 1, Fq = S.Fq;
             S.D = take((size_t)2 * Fq * w); S.DT = take((size_t)2 * Fq * w);
@@ -431,11 +436,28 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, const f
             ESCX_HIP(hipMemcpyAsync(grad_flat + c.off_b, dWs + (size_t)c.CoutP * c.Kf, (size_t)c.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
         }
         if (gx || gx_plain) {
-            ConvGeom cg{c.T0, c.T1, c.s0, c.s1, c.p0, c.p1, yv.D0, yv.D1};
-            const int Mi = B * x.D0 * x.D1;
-            ConvTS lt{g, cg, x.D0, x.D1, Mi, FastDiv(x.D0 * x.D1), FastDiv(x.D1), FastDiv(g.Cp), FastDiv(c.T1), FastDiv(c.s0), FastDiv(c.s1)};
-            if (gx) conv_gemm(lt, c.Wt, Mi, c.CinR, c.Kt, EpiAccumView{*gx, FastDiv(x.D0 * x.D1), FastDiv(x.D1)}, st);
-            else conv_gemm(lt, c.Wt, Mi, c.CinR, c.Kt, EpiStoreN{gx_plain, x.Cp, x.Cp}, st);
+            TView gxv = gx ? *gx : TView{gx_plain, x.D0, x.D1, x.D1, x.Cp};
+            if (gx_plain) ESCX_HIP(hipMemsetAsync(gx_plain, 0, (size_t)B * x.D0 * x.D1 * x.Cp * sizeof(float), st));
+            if (c.Wp) {                         // strided: one launch per residue class of input positions over its own taps
+                size_t off = 0;
+                for (int r0 = 0; r0 < c.s0; ++r0) for (int r1 = 0; r1 < c.s1; ++r1) {
+                    const int n0 = phase_ntaps(r0, c.p0, c.s0, c.T0), n1 = phase_ntaps(r1, c.p1, c.s1, c.T1);
+                    const int kp = n0 * n1 * c.CoutP;
+                    const int Q0 = x.D0 > r0 ? (x.D0 - r0 + c.s0 - 1) / c.s0 : 0, Q1 = x.D1 > r1 ? (x.D1 - r1 + c.s1 - 1) / c.s1 : 0;
+                    if (kp > 0 && Q0 > 0 && Q1 > 0) {
+                        PhaseGeom pg{r0, r1, n0, n1, (r0 + c.p0 - phase_tmin(r0, c.p0, c.s0)) / c.s0, (r1 + c.p1 - phase_tmin(r1, c.p1, c.s1)) / c.s1, Q0, Q1, c.s0, c.s1};
+                        const int Mi = B * Q0 * Q1;
+                        ConvTSP lt{g, pg, Mi, FastDiv(Q0 * Q1), FastDiv(Q1), FastDiv(g.Cp), FastDiv(n1)};
+                        conv_gemm(lt, c.Wp + off, Mi, c.CinR, kp, EpiAccumPhase{gxv, pg, FastDiv(Q0 * Q1), FastDiv(Q1)}, st);
+                    }
+                    off += (size_t)c.CinR * kp;
+                }
+            } else {
+                ConvGeom cg{c.T0, c.T1, c.s0, c.s1, c.p0, c.p1, yv.D0, yv.D1};
+                const int Mi = B * x.D0 * x.D1;
+                ConvTS lt{g, cg, x.D0, x.D1, Mi, FastDiv(x.D0 * x.D1), FastDiv(x.D1), FastDiv(g.Cp), FastDiv(c.T1), FastDiv(c.s0), FastDiv(c.s1)};
+                conv_gemm(lt, c.Wt, Mi, c.CinR, c.Kt, EpiAccumView{gxv, FastDiv(x.D0 * x.D1), FastDiv(x.D1)}, st);
+            }
         }
         return 0;
     };

@@ -60,6 +60,42 @@ struct ConvTS {
     }
 };
 
+// Strided convolutions: the input positions of one residue class (i0 = r0 + s0*q0, i1 = r1 + s1*q1) receive gradient from a fixed SUBSET of
+// the taps (t = tmin + a*s with tmin = (r + p) mod s), so dX is run once per class over compact tap sets instead of once over all taps with
+// (s0*s1 - 1)/(s0*s1) of the products structurally zero (the stride-3 layers of the period discriminators are where the FLOPs are).
+struct PhaseGeom { int r0, r1, n0, n1, c0, c1, Q0, Q1, s0, s1; };       // n: taps of this class per axis; o = q + c - a; Q: positions of the class
+__host__ __device__ inline int phase_tmin(int r, int p, int s) { return (r + p) % s; }
+__host__ __device__ inline int phase_ntaps(int r, int p, int s, int T) { const int tm = phase_tmin(r, p, s); return tm < T ? (T - tm + s - 1) / s : 0; }
+
+struct ConvTSP {                // A[(b, q0, q1)][k = (a*n1 + b1)*Cp + co] = dY(b, q0 + c0 - a, q1 + c1 - b1, co)
+    TView y; PhaseGeom g; int M; FastDiv dQ, dQ1, dCp, dN1;
+    struct Ctx { int b, q0, q1; };
+    __device__ __forceinline__ Ctx make_ctx(int m) const {
+        Ctx c; c.b = -1; c.q0 = 0; c.q1 = 0;
+        if (m < M) { c.b = dQ.div(m); const int r = m - c.b * g.Q0 * g.Q1; const int q0 = dQ1.div(r); c.q0 = q0 + g.c0; c.q1 = r - q0 * g.Q1 + g.c1; }
+        return c;
+    }
+    __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
+        if (c.b < 0) return zero4();
+        const int k = k0 + kin; const int tap = dCp.div(k), cc = k - tap * y.Cp;
+        if (tap >= g.n0 * g.n1) return zero4();
+        const int a = dN1.div(tap), b1 = tap - a * g.n1;
+        const int o0 = c.q0 - a, o1 = c.q1 - b1;
+        if (o0 < 0 || o0 >= y.D0 || o1 < 0 || o1 >= y.D1) return zero4();
+        return ld4(y.p + (((size_t)c.b * y.D0 + o0) * y.P1 + o1) * y.Cp + cc);
+    }
+};
+
+struct EpiAccumPhase {          // out(b, r0 + s0*q0, r1 + s1*q1, n..) += v
+    TView o; PhaseGeom g; FastDiv dQ, dQ1;
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        if (n >= o.Cp) return;
+        const int b = dQ.div(m), r = m - b * g.Q0 * g.Q1; const int q0 = dQ1.div(r), q1 = r - q0 * g.Q1;
+        float* q = o.p + (((size_t)b * o.D0 + g.r0 + g.s0 * q0) * o.P1 + g.r1 + g.s1 * q1) * o.Cp + n;
+        st4(q, ld4(q) + v);
+    }
+};
+
 struct ViewRowsA {              // rows m = (b, i0, i1) of a view as a plain matrix (dY operand of the dW contraction)
     TView v; int M; FastDiv dR, dD1;
     typedef const float* Ctx;
@@ -99,9 +135,11 @@ struct EpiAccumView {           // out(b, i0, i1, n..) += v   (dX of a layer add
 // weight norm (torch.nn.utils.weight_norm, dim 0): w = g * v / ||v||; one workgroup per output channel.
 //   v [Cout][Cin][T] (reference layout), Wf [CoutP][Kf] with k = t*CinP + ci, Wt [CinR][Kt] with k = t*CoutP + co
 // ------------------------------------------------------------------------------------------------
+//   Wp (strided layers only): per residue class (r0, r1) a compact [CinR][n0*n1*CoutP] matrix, classes stored back to back
 __global__ __launch_bounds__(256) void wn_pack_kernel(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ b,
                                                       float* __restrict__ Wf, float* __restrict__ Wt, float* __restrict__ bias, float* __restrict__ scale,
-                                                      int Cout, int Cin, int T, int CinP, int CoutP, int Kf, int Kt) {
+                                                      int Cout, int Cin, int T, int CinP, int CoutP, int Kf, int Kt, float* __restrict__ Wp, int T0, int T1,
+                                                      int s0, int s1, int p0, int p1, int CinR) {
     const int co = blockIdx.x;
     __shared__ float red[256];
     const float* vr = v + (size_t)co * Cin * T;
@@ -118,6 +156,19 @@ __global__ __launch_bounds__(256) void wn_pack_kernel(const float* __restrict__ 
         const float w = vr[i] * sc;
         Wf[(size_t)co * Kf + t * CinP + ci] = w;
         Wt[(size_t)ci * Kt + t * CoutP + co] = w;
+        if (Wp) {
+            const int t0 = t / T1, t1 = t - t0 * T1;
+            const int r0 = ((t0 - p0) % s0 + s0) % s0, r1 = ((t1 - p1) % s1 + s1) % s1;
+            const int a = (t0 - phase_tmin(r0, p0, s0)) / s0, b1 = (t1 - phase_tmin(r1, p1, s1)) / s1;
+            size_t off = 0;
+            for (int q0 = 0; q0 < s0; ++q0)
+                for (int q1 = 0; q1 < s1; ++q1) {
+                    if (q0 == r0 && q1 == r1) { q0 = s0; break; }
+                    off += (size_t)CinR * phase_ntaps(q0, p0, s0, T0) * phase_ntaps(q1, p1, s1, T1) * CoutP;
+                }
+            const int n1 = phase_ntaps(r1, p1, s1, T1), kp = phase_ntaps(r0, p0, s0, T0) * n1 * CoutP;
+            Wp[off + (size_t)ci * kp + (a * n1 + b1) * CoutP + co] = w;
+        }
     }
 }
 // gradient of (g, v) from the packed weight gradient dWf [CoutP][Kf]:  dg = <dW, v> / ||v|| ;  dv = (g/||v||) (dW - <dW, v> v / ||v||^2)

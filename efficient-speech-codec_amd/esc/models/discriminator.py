@@ -43,6 +43,15 @@ class FeatureMaps(list):
     entries: list        # per map: (buffer, C, Cp, D0, D1, P1, off1)
 
 
+class DiscOutput(list):
+    """What Discriminator.forward returns: the reference's list (one FeatureMaps per sub-discriminator) plus what a later native backward
+    needs (the pre-processed input waveform and the raw buffers), so that ONE forward pass can serve both the generator's and the
+    discriminator's update of an adversarial step."""
+    wave: torch.Tensor
+    bufs: tuple
+    layout: list
+
+
 class Discriminator(nn.Module):
     def __init__(self, rates: list = [], periods: list = [2, 3, 5, 7, 11], fft_sizes: list = [2048, 1024, 512], sample_rate: int = 44100,
                  bands: list = BANDS):
@@ -151,6 +160,38 @@ class Discriminator(nn.Module):
                     p.data = flat[off:off + n].view(p.shape)
         return flat
 
+    def accumulate_param_grads(self, out: "DiscOutput", dbufs):
+        """d loss / d parameters for gradients `dbufs` (one per buffer of `out`, None = zero) of a forward pass already done, added to the
+        parameters' .grad (flat-gradient mode: into the flat buffer).  No autograd involved: the discriminator update of an adversarial
+        step reuses the feature maps the generator update has just computed."""
+        dev = out.wave.device
+        lib, hd = self._handle(dev)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        flat = self._ensure_flat(dev, lib, hd)
+        st = self._flat[idx]
+        layout = out.layout
+        _, where = _buffer_plan(layout)
+        n = len(layout)
+        B, L = out.wave.shape
+        dbufs = [None if g is None else g.to(torch.float32).contiguous() for g in dbufs]
+        fm = (ctypes.c_void_p * n)(*[out.bufs[bi].data_ptr() + 4 * off1 * layout[i][2] for i, (bi, off1) in enumerate(where)])
+        dfm = (ctypes.c_void_p * n)(*[(None if dbufs[bi] is None else dbufs[bi].data_ptr() + 4 * off1 * layout[i][2]) for i, (bi, off1) in enumerate(where)])
+        flat_mode = self._flat_grad_mode and "gflat" in st
+        gnew = st["gflat"] if (flat_mode and st["gfresh"]) else torch.empty_like(flat)
+        with torch.cuda.device(dev):
+            _native.check(lib.escx_disc_backward(hd, ctypes.c_void_p(flat.data_ptr()), ctypes.c_void_p(out.wave.data_ptr()), B, L, fm, dfm,
+                                                 ctypes.c_void_p(gnew.data_ptr()), None, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        if flat_mode:
+            if st["gfresh"]:
+                st["gfresh"] = False
+            else:
+                st["gflat"].add_(gnew)
+            return
+        params = dict(self.named_parameters())
+        for k, off, n_ in st["layout"]:
+            g = gnew[off:off + n_].view(params[k].shape)
+            params[k].grad = g.clone() if params[k].grad is None else params[k].grad + g
+
     def fmap_layout(self, device, n_samples):
         lib, hd = self._handle(device)
         out = []
@@ -160,16 +201,19 @@ class Discriminator(nn.Module):
             out.append(tuple(v.value for v in ints))          # (sub, C, Cp, D0, D1, P1, off1)
         return out
 
-    def forward(self, x) -> List[FeatureMaps]:
+    def forward(self, x, detach_params: bool = False) -> List[FeatureMaps]:
+        """detach_params=True treats the parameters as constants (the generator's update needs d loss / d waveform only)."""
         if x.dim() != 3 or x.shape[1] != 1:
             raise ValueError("x must have shape (B, 1, L)")
         if not x.is_cuda:
             raise RuntimeError("esc Discriminator (MI355X build): x must live on a HIP device; this package has no CPU implementation")
         layout = self.fmap_layout(x.device, x.shape[-1])
-        bufs = _DiscFn.apply(self, x[:, 0].to(torch.float32).contiguous(), layout, *self.parameters())
+        wave = x[:, 0].to(torch.float32).contiguous()
+        bufs = _DiscFn.apply(self, wave, (layout, bool(detach_params)), *self.parameters())
         out, bi = [], 0
         n_sub = len(self.cfg["periods"]) + len(self.cfg["fft_sizes"])
-        per_sub = [FeatureMaps() for _ in range(n_sub)]
+        per_sub = DiscOutput(FeatureMaps() for _ in range(n_sub))
+        per_sub.wave, per_sub.bufs, per_sub.layout = wave.detach(), tuple(b.detach() for b in bufs), layout
         for fm in per_sub:
             fm.entries = []
         cat = None
@@ -200,7 +244,8 @@ def _buffer_plan(layout):
 
 class _DiscFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, disc, wave, layout, *params):
+    def forward(ctx, disc, wave, layout_flag, *params):
+        layout, detach_params = layout_flag
         dev = wave.device
         lib, hd = disc._handle(dev)
         flat = disc._ensure_flat(dev, lib, hd)
@@ -212,7 +257,7 @@ class _DiscFn(torch.autograd.Function):
             _native.check(lib.escx_disc_forward(hd, ctypes.c_void_p(flat.data_ptr()), ctypes.c_void_p(wave.data_ptr()), B, L, ptrs,
                                                 ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         ctx.disc, ctx.layout, ctx.where, ctx.wave, ctx.bufs, ctx.idx = disc, layout, where, wave, bufs, (dev.index if dev.index is not None else torch.cuda.current_device())
-        ctx.want_wave, ctx.want_params = ctx.needs_input_grad[1], any(ctx.needs_input_grad[3:])
+        ctx.want_wave, ctx.want_params = ctx.needs_input_grad[1], (any(ctx.needs_input_grad[3:]) and not detach_params)
         return tuple(bufs)
 
     @staticmethod

@@ -164,3 +164,49 @@ class GANLoss(nn.Module):
             for (ba, *ma), (bb, *mb) in zip(xf.entries[:-1], xr.entries[:-1]):
                 loss_f = loss_f + _GanTermFn.apply(ba, bb.detach(), tuple(ma), 1, 0.0)
         return loss_g, loss_f
+
+    # ---- one discriminator forward per signal and step (not in the reference, which runs them twice; the values are identical) --------
+    def adversarial_forward(self, fake, real):
+        """Feature maps of the reconstruction (differentiable w.r.t. the waveform, discriminator parameters held constant) and of the
+        real signal (no graph): everything both updates of an adversarial step need."""
+        if fake.dim() == 2:
+            fake = fake.unsqueeze(1)
+        if real.dim() == 2:
+            real = real.unsqueeze(1)
+        d_fake = self.discriminator(fake, detach_params=True)
+        with torch.no_grad():
+            d_real = self.discriminator(real)
+        return d_fake, d_real
+
+    def generator_loss_from(self, d_fake, d_real):
+        """gan_loss.py:38-50 on feature maps that are already there."""
+        loss_g, loss_f = 0, 0
+        for xf, xr in zip(d_fake, d_real):
+            bf, *mf = xf.entries[-1]
+            loss_g = loss_g + _GanTermFn.apply(bf, None, tuple(mf), 0, 1.0)
+            for (ba, *ma), (bb, *mb) in zip(xf.entries[:-1], xr.entries[:-1]):
+                loss_f = loss_f + _GanTermFn.apply(ba, bb.detach(), tuple(ma), 1, 0.0)
+        return loss_g, loss_f
+
+    @torch.no_grad()
+    def discriminator_backward_from(self, d_fake, d_real):
+        """gan_loss.py:29-36 + `disc_loss.mean().backward()` (trainer_adv.py:95-103) on the feature maps of adversarial_forward: returns the
+        per-clip discriminator loss and ADDS d mean(loss) / d parameter to the discriminator's gradients."""
+        lib = _native.load()
+        loss = None
+        for out, target in ((d_fake, 0.0), (d_real, 1.0)):
+            B = out.wave.shape[0]
+            dbufs = [None] * len(out.bufs)
+            scale = torch.full((B,), 1.0 / B, dtype=torch.float32, device=out.wave.device)
+            for sub in out:
+                buf, C, Cp, D0, D1, P1, off1 = sub.entries[-1]
+                buf = buf.detach()
+                term = torch.empty(B, dtype=torch.float32, device=buf.device)
+                unit = torch.zeros_like(buf)
+                with torch.cuda.device(buf.device):
+                    _native.check(lib.escx_gan_term(_ptr(buf), None, _ptr(unit), B, C, Cp, D0, D1, P1, 0, float(target), _ptr(term), 0, _stream(buf.device)))
+                loss = term if loss is None else loss + term
+                bi = next(i for i, b in enumerate(out.bufs) if b.data_ptr() == buf.data_ptr())
+                dbufs[bi] = _scale_rows(unit, scale)
+            self.discriminator.accumulate_param_grads(out, dbufs)
+        return loss

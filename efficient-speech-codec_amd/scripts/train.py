@@ -103,21 +103,17 @@ class AdvStepper:
         terms = {"cm_loss": out["cm_loss"], "cb_loss": out["cb_loss"], "mel_loss": self.mel(out["raw_audio"], out["recon_audio"])}
         if self.w["stft_weight"] != 0.0:
             terms["stft_loss"] = self.stft(out["raw_feat"], out["recon_feat"])
-        if not freeze:
-            for p in self.disc.parameters():                        # the generator step needs d loss / d waveform only: skip the discriminator's dW
-                p.requires_grad_(False)
-            terms["gen_loss"], terms["feat_loss"] = self.gan.generator_loss(fake=out["recon_audio"], real=out["raw_audio"])
-            for p in self.disc.parameters():
-                p.requires_grad_(True)
+        if not freeze:                                              # ONE discriminator pass per signal serves both updates of the step
+            d_fake, d_real = self.gan.adversarial_forward(fake=out["recon_audio"], real=out["raw_audio"])
+            terms["gen_loss"], terms["feat_loss"] = self.gan.generator_loss_from(d_fake, d_real)
         total = sum(terms[k] * self.w[k.replace("_loss", "_weight")] for k in terms)
         total.mean().backward()
         self.opt_g.step(); self.opt_g.zero_grad()
         log = {"streams": s, "frozen": freeze, **{k: v.detach().mean() for k, v in terms.items()}, "loss": total.detach().mean()}
-        if not freeze:
-            d_loss = self.gan.discriminator_loss(fake=out["recon_audio"], real=out["raw_audio"])
-            d_loss.mean().backward()
+        if not freeze:                                              # discriminator update on the (detached) reconstruction, trainer_adv.py:93-103
+            d_loss = self.gan.discriminator_backward_from(d_fake, d_real)
             self.opt_d.step(); self.opt_d.zero_grad()
-            log["disc_loss"] = d_loss.detach().mean()
+            log["disc_loss"] = d_loss.mean()
         return log
 
 

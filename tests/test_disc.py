@@ -177,3 +177,36 @@ def test_adversarial_training_loop():
     assert any(not torch.equal(v, d0[k]) for k, v in disc.state_dict().items())
     dl = [float(l["disc_loss"]) for l in logs]
     assert np.mean(dl[-3:]) < np.mean(dl[:3]), dl
+
+
+@pytest.mark.gpu
+def test_single_pass_adversarial_losses_equal_the_two_pass_reference_form():
+    """The step's discriminator forward passes are shared between the generator and the discriminator update (GANLoss.adversarial_forward /
+    generator_loss_from / discriminator_backward_from): losses and gradients must equal the reference's two-pass form (generator_loss,
+    discriminator_loss + backward) bit for bit on the values, and to rounding on the gradients."""
+    from esc.modules import GANLoss
+    g = load_golden("disc")
+    real, fake = clips(g)
+    disc, sd = _gpu_models()
+    gan = GANLoss(disc)
+    fg = fake.cuda().requires_grad_(True)
+    lg, lf = gan.generator_loss(fg, real.cuda())
+    (lg + 2.0 * lf).mean().backward()
+    ref_dfake = fg.grad.clone()
+    for p in disc.parameters():
+        p.grad = None
+    ld = gan.discriminator_loss(fake.cuda(), real.cuda())
+    ld.mean().backward()
+    ref_grads = {k: p.grad.clone() for k, p in disc.named_parameters()}
+    for p in disc.parameters():
+        p.grad = None
+    fg2 = fake.cuda().requires_grad_(True)
+    d_fake, d_real = gan.adversarial_forward(fg2, real.cuda())
+    lg2, lf2 = gan.generator_loss_from(d_fake, d_real)
+    (lg2 + 2.0 * lf2).mean().backward()
+    assert torch.equal(lg2, lg) and torch.equal(lf2, lf) and torch.equal(fg2.grad, ref_dfake)
+    assert all(p.grad is None for p in disc.parameters())
+    ld2 = gan.discriminator_backward_from(d_fake, d_real)
+    np.testing.assert_allclose(ld2.cpu().numpy(), ld.detach().cpu().numpy(), rtol=1e-6)      # the same terms, added in another order
+    for k, p in disc.named_parameters():
+        assert _rel(p.grad.cpu().numpy(), ref_grads[k].cpu().numpy()) < 1e-6, k
