@@ -51,6 +51,7 @@ struct escx_disc_s {
     size_t total = 0;
     float* wbuf = nullptr; size_t wfloats = 0;
     float* scratch = nullptr; size_t scratch_bytes = 0;
+    const float* packed_ptr = nullptr; long long packed_version = -1;      // which (buffer, version) the packed weights were derived from
 };
 
 namespace {
@@ -120,7 +121,11 @@ void fmap_shapes(escx_disc_s* d, int L, std::vector<FmapShape>* out) {
 
 TView view_of(float* base, const FmapShape& f) { return TView{base, f.D0, f.D1, f.P1, f.Cp}; }
 
-int pack_weights(escx_disc_s* d, const float* flat, hipStream_t st) {
+// params_version: any number that changes whenever the flat buffer's CONTENTS change (negative = unknown: always re-pack).  The weight-normalised
+// operands are rebuilt only then - an adversarial step makes five calls on the same weights, 108 pack launches each otherwise.
+int pack_weights(escx_disc_s* d, const float* flat, long long params_version, hipStream_t st) {
+    if (params_version >= 0 && params_version == d->packed_version && flat == d->packed_ptr) return 0;
+    d->packed_version = params_version; d->packed_ptr = flat;
     for (DSub& S : d->subs)
         for (DConv& c : S.convs)
             hipLaunchKernelGGL(wn_pack_kernel, dim3(c.Cout), dim3(256), 0, st, flat + c.off_v, flat + c.off_g, flat + c.off_b, c.Wf, c.Wt, c.bias, c.scale,
@@ -330,7 +335,7 @@ void build_front(escx_disc_s* d, const float* wave, int B, int L, float* base, s
 
 // Discriminator.forward (discriminator.py:212-215).  fmaps: host array of escx_disc_num_fmaps() device pointers, each the BASE address of map i
 // (i.e. already offset to its column slice when it lives in a concatenated buffer), laid out [B][D0][P1][Cp].
-extern "C" int escx_disc_forward(escx_disc d, const float* flat_params, const float* wave, int B, int L, float* const* fmaps, void* stream) {
+extern "C" int escx_disc_forward(escx_disc d, const float* flat_params, int64_t params_version, const float* wave, int B, int L, float* const* fmaps, void* stream) {
     if (!d || !flat_params || !wave || !fmaps || B < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
     ESCX_HIP(hipSetDevice(d->device));
     hipStream_t st = (hipStream_t)stream;
@@ -338,7 +343,7 @@ extern "C" int escx_disc_forward(escx_disc d, const float* flat_params, const fl
     if (L <= maxp + 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "clip too short for the reflect padding of the period discriminators");
     std::vector<FmapShape> shp; fmap_shapes(d, L, &shp);
     int rc = ensure_scratch(d, front_floats(d, B, L) * sizeof(float)); if (rc) return rc;
-    if ((rc = pack_weights(d, flat_params, st))) return rc;
+    if ((rc = pack_weights(d, flat_params, (long long)params_version, st))) return rc;
     std::vector<std::vector<float*>> ins; std::vector<float*> specs; float *y, *stats;
     build_front(d, wave, B, L, d->scratch, &ins, &specs, &y, &stats, st);
     int fi = 0;
@@ -375,8 +380,8 @@ extern "C" int escx_disc_forward(escx_disc d, const float* flat_params, const fl
 
 // Backward of the last forward on the same inputs.  d_fmaps[i]: gradient of map i with the SAME layout as fmaps[i] (NULL = zero).
 // grad_flat (optional): d loss / d parameters, overwritten.  d_wave (optional): d loss / d waveform (B, L), overwritten.
-extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, const float* wave, int B, int L, float* const* fmaps, const float* const* d_fmaps,
-                                  float* grad_flat, float* d_wave, void* stream) {
+extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t params_version, const float* wave, int B, int L, float* const* fmaps,
+                                  const float* const* d_fmaps, float* grad_flat, float* d_wave, void* stream) {
     if (!d || !flat_params || !wave || !fmaps || !d_fmaps || B < 1 || (!grad_flat && !d_wave)) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
     ESCX_HIP(hipSetDevice(d->device));
     hipStream_t st = (hipStream_t)stream;
@@ -401,7 +406,7 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, const f
     }
     const size_t total = front + gfl + 3 * pad64(in_g) + pad64(max_w) + pad64(DISC_DW_PART) + pad64((size_t)B * L) + 4096;
     int rc = ensure_scratch(d, total * sizeof(float)); if (rc) return rc;
-    if ((rc = pack_weights(d, flat_params, st))) return rc;
+    if ((rc = pack_weights(d, flat_params, (long long)params_version, st))) return rc;
     std::vector<std::vector<float*>> ins; std::vector<float*> specs; float *y, *stats;
     build_front(d, wave, B, L, d->scratch, &ins, &specs, &y, &stats, st);
     float* cur = d->scratch + front;

@@ -84,8 +84,8 @@ SIGNATURES = {
     "escx_disc_param_total": (c_int64, [c_void_p]),
     "escx_disc_num_fmaps": (c_int, [c_void_p, c_int]),
     "escx_disc_fmap_shape": (c_int, [c_void_p, c_int, c_int] + [POINTER(c_int)] * 7),
-    "escx_disc_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p), c_void_p]),
-    "escx_disc_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_void_p]),
+    "escx_disc_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, POINTER(c_void_p), c_void_p]),
+    "escx_disc_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_void_p]),
     "escx_gan_term": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "escx_set_rccl_library": (c_int, [c_char_p]),
     "escx_allgather_codes": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),

@@ -68,6 +68,7 @@ class Discriminator(nn.Module):
             _attach(self, pfx + "weight_v", v, False)
         self._handles, self._flat = {}, {}
         self._flat_grad_mode = False
+        self._native_updates = 0
 
     # ---- flat-gradient mode (esc.optim.FlatAdamW), same contract as esc.ESC -------------------------------------------------
     def enable_flat_grads(self, device):
@@ -99,7 +100,11 @@ class Discriminator(nn.Module):
             st["gfresh"] = True
 
     def note_params_updated(self):
-        pass                                    # the packed weights are rebuilt from the flat buffer at every forward
+        self._native_updates += 1               # a native kernel wrote the flat buffer: autograd's version counters did not move
+
+    def _version(self) -> int:
+        """Changes whenever a parameter changes (in-place torch updates bump autograd's counters, native optimiser steps bump ours)."""
+        return sum(p._version for p in self.parameters()) + (self._native_updates << 32)
 
     def _apply(self, fn, *a, **k):
         self._drop()
@@ -179,7 +184,7 @@ class Discriminator(nn.Module):
         flat_mode = self._flat_grad_mode and "gflat" in st
         gnew = st["gflat"] if (flat_mode and st["gfresh"]) else torch.empty_like(flat)
         with torch.cuda.device(dev):
-            _native.check(lib.escx_disc_backward(hd, ctypes.c_void_p(flat.data_ptr()), ctypes.c_void_p(out.wave.data_ptr()), B, L, fm, dfm,
+            _native.check(lib.escx_disc_backward(hd, ctypes.c_void_p(flat.data_ptr()), self._version(), ctypes.c_void_p(out.wave.data_ptr()), B, L, fm, dfm,
                                                  ctypes.c_void_p(gnew.data_ptr()), None, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         if flat_mode:
             if st["gfresh"]:
@@ -254,7 +259,7 @@ class _DiscFn(torch.autograd.Function):
         bufs = [torch.empty((B,) + s, dtype=torch.float32, device=dev) for s in shapes]
         ptrs = (ctypes.c_void_p * len(layout))(*[bufs[bi].data_ptr() + 4 * off1 * layout[i][2] for i, (bi, off1) in enumerate(where)])
         with torch.cuda.device(dev):
-            _native.check(lib.escx_disc_forward(hd, ctypes.c_void_p(flat.data_ptr()), ctypes.c_void_p(wave.data_ptr()), B, L, ptrs,
+            _native.check(lib.escx_disc_forward(hd, ctypes.c_void_p(flat.data_ptr()), disc._version(), ctypes.c_void_p(wave.data_ptr()), B, L, ptrs,
                                                 ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         ctx.disc, ctx.layout, ctx.where, ctx.wave, ctx.bufs, ctx.idx = disc, layout, where, wave, bufs, (dev.index if dev.index is not None else torch.cuda.current_device())
         ctx.want_wave, ctx.want_params = ctx.needs_input_grad[1], (any(ctx.needs_input_grad[3:]) and not detach_params)
@@ -278,7 +283,7 @@ class _DiscFn(torch.autograd.Function):
         if gflat is None and dwave is None:
             return (None, None, None) + (None,) * (len(st["layout"]))
         with torch.cuda.device(dev):
-            _native.check(lib.escx_disc_backward(hd, ctypes.c_void_p(flat.data_ptr()), ctypes.c_void_p(wave.data_ptr()), B, L, fm, dfm,
+            _native.check(lib.escx_disc_backward(hd, ctypes.c_void_p(flat.data_ptr()), disc._version(), ctypes.c_void_p(wave.data_ptr()), B, L, fm, dfm,
                                                  None if gflat is None else ctypes.c_void_p(gflat.data_ptr()),
                                                  None if dwave is None else ctypes.c_void_p(dwave.data_ptr()),
                                                  ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))

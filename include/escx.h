@@ -218,12 +218,15 @@ int64_t escx_disc_param_numel(escx_disc d, int i);
 int64_t escx_disc_param_total(escx_disc d);
 int escx_disc_num_fmaps(escx_disc d, int n_samples);
 int escx_disc_fmap_shape(escx_disc d, int n_samples, int i, int* sub, int* C, int* Cp, int* D0, int* D1, int* P1, int* off1);
-/* Discriminator.forward: wave (B, L) -> every feature map (fmaps_dev: HOST array of device pointers, map i's own base address). */
-int escx_disc_forward(escx_disc d, const float* flat_params_dev, const float* wave_dev, int batch, int n_samples, float* const* fmaps_dev, void* stream);
+/* Discriminator.forward: wave (B, L) -> every feature map (fmaps_dev: HOST array of device pointers, map i's own base address).
+ * params_version: a number that changes whenever the CONTENTS of the flat buffer change (negative: unknown); the weight-normalised GEMM operands
+ * are re-derived from the flat buffer only when (pointer, version) differs from the previous call. */
+int escx_disc_forward(escx_disc d, const float* flat_params_dev, int64_t params_version, const float* wave_dev, int batch, int n_samples,
+                      float* const* fmaps_dev, void* stream);
 /* Backward of a forward on the same (params, wave, fmaps): d_fmaps_dev[i] (same layout, NULL = zero) -> grad_flat_dev (optional, overwritten)
  * and / or d_wave_dev (optional, (B, L), overwritten). */
-int escx_disc_backward(escx_disc d, const float* flat_params_dev, const float* wave_dev, int batch, int n_samples, float* const* fmaps_dev,
-                       const float* const* d_fmaps_dev, float* grad_flat_dev, float* d_wave_dev, void* stream);
+int escx_disc_backward(escx_disc d, const float* flat_params_dev, int64_t params_version, const float* wave_dev, int batch, int n_samples,
+                       float* const* fmaps_dev, const float* const* d_fmaps_dev, float* grad_flat_dev, float* d_wave_dev, void* stream);
 /* One GAN loss term over a feature-map buffer (gan_loss.py:29-50): loss_dev[b] (+)= mean over the C x D0 x D1 real elements of
  * (target - x)^2 (mode 0) or |x - ref| (mode 1); grad_dev (optional, layout of x) receives d term_b / d x. */
 int escx_gan_term(const float* x_dev, const float* ref_dev, float* grad_dev, int batch, int C, int Cp, int D0, int D1, int P1, int mode, float target,
