@@ -279,8 +279,9 @@ def run_train_adv(args, rank, world, device, use_dist):
     from esc.models.discriminator import _conv_specs
     specs = _conv_specs(disc.cfg["periods"], disc.cfg["fft_sizes"], len(disc.cfg["bands"]))
     d_flops = sum(2.0 * D0 * D1 * cout * cin * t0 * t1 for (sub, C, Cp, D0, D1, P1, off1), (pfx, cout, cin, t0, t1) in zip(lay, specs))
-    # per step: generator step = 2 forward passes (fake, real) + input-gradient backward of the fake pass; discriminator step = 2 forward + 2 full backward
-    d_step_flops = d_flops * (2 + 1 + 2 + 2 * 2)
+    # per step (GANLoss.adversarial_forward shares the passes): 2 forward passes (fake, real) + the input-gradient backward of the fake pass for the
+    # generator + 2 full backward passes (dX + dW) for the discriminator
+    d_step_flops = d_flops * (2 + 1 + 2 * 2)
     audio_s = bsz * world * args.steps * (TRAIN_SAMPLES / 16000.0)
     out = {"metric": "audio-seconds/sec trained, adversarial step (generator + discriminator updates), ESC-Large 9kbps 3s@16kHz",
            "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -294,7 +295,7 @@ def run_train_adv(args, rank, world, device, use_dist):
            "roofline": {"bound": "mfma", "achieved": round(d_step_flops * bsz / (elapsed / args.steps) / 1e12, 3), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
                         "frac": round(d_step_flops * bsz / (elapsed / args.steps) / PEAK_F32_MFMA, 4), "traffic": None,
                         "kernel": "discriminator convolutions (all launches of the step)",
-                        "note": "algorithmic discriminator-convolution FLOPs of the step (9 pass-equivalents of "
+                        "note": "algorithmic discriminator-convolution FLOPs of the step (7 pass-equivalents of "
                                 f"{d_flops / 1e9:.1f} GFLOP per clip) over the WHOLE step time, generator included: a lower bound on the conv kernels' rate"},
            "cpu_baseline": None}
     print(json.dumps(out))

@@ -160,14 +160,32 @@ void conv_forward(const TView& x, const DConv& c, const TView& out, int B, hipSt
     conv_gemm(ld, c.Wf, B * out.D0 * out.D1, c.CoutP, c.Kf, EpiConvOut{out, c.bias, c.act, FastDiv(out.D0 * out.D1), FastDiv(out.D1)}, st);
 }
 
-constexpr size_t DISC_DW_PART = (size_t)12 << 20;
+constexpr size_t DISC_DW_PART = (size_t)48 << 20;          // floats: 192 MB of partial sums (8 slices of the 1024 x 5120 gradient)
 
 // dW partial-sum launch (same scheme as train.hip's dw_launch)
 template <class LdA, class LdB>
 int disc_dw(const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
+    const size_t per = (size_t)Np * Kp + Np;
+    static const bool wide_ok = [] { const char* e = getenv("ESCX_DW_WIDE"); return !(e && e[0] == '0'); }();
+    const bool big = Np >= 256 && Kp >= 256, narrow = Np == 32 && Kp >= 192;
+    if (wide_ok && (big || narrow)) {                         // wide workgroup tiles (gemm_dw3_kernel), ~5 rounds of 2 workgroups per CU
+        const int WA = big ? 128 : 32, WB = big ? 128 : 192;
+        const int nbn = (Np + WA - 1) / WA, nbk = (Kp + WB - 1) / WB, blocks = nbn * nbk;
+        int slices = std::max(1, std::min((2560 + blocks / 2) / blocks, (M + 255) / 256));
+        slices = (int)std::max<size_t>(1, std::min<size_t>(slices, DISC_DW_PART / per));
+        int mps = ((M + slices - 1) / slices + 31) / 32 * 32;
+        slices = (M + mps - 1) / mps;
+        float* bpart = part + (size_t)slices * Np * Kp;
+        if (big) hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, 4, 4, 2, 2, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+        else hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, 2, 3, 1, 4, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+        const long long n = (long long)Np * Kp;
+        if (slices >= 32 && n * 4 <= ((long long)1 << 22)) hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3(blk((n + 15) / 16 * 64)), dim3(256), 0, st, part, slices, n, dW, 0);
+        else hipLaunchKernelGGL(reduce_partials_kernel, dim3(blk(n)), dim3(256), 0, st, part, slices, n, dW, 0);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blk(Np)), dim3(256), 0, st, bpart, slices, (long long)Np, db, 0);
+        return 0;
+    }
     const int nbn = (Np + 47) / 48, nbk = (Kp + 47) / 48, blocks = nbn * nbk;
     int slices = std::max(1, std::min((2048 + blocks - 1) / blocks, (M + 127) / 128));
-    const size_t per = (size_t)Np * Kp + Np;
     slices = (int)std::min<size_t>(slices, DISC_DW_PART / per);
     if (slices < 1) ESCX_FAIL(ESCX_ERR_STATE, "discriminator dW scratch too small for %d x %d", Np, Kp);
     int mps = ((M + slices - 1) / slices + 127) / 128 * 128;
@@ -522,10 +540,9 @@ extern "C" int escx_gan_term(const float* x, const float* ref, float* grad, int 
     TView xv{const_cast<float*>(x), D0, D1, P1, Cp}, rv{const_cast<float*>(ref), D0, D1, P1, Cp}, gvw{grad, D0, D1, P1, Cp};
     const long long per = (long long)D0 * D1 * Cp;
     const int bpc = (int)std::min<long long>(64, (per + 255) / 256);
-    float* part = nullptr;
-    ESCX_HIP(hipMallocAsync((void**)&part, (size_t)B * bpc * sizeof(float), st));
+    float* part = stream_scratch(st, 0, (size_t)B * bpc);
+    if (!part) ESCX_FAIL(ESCX_ERR_HIP, "scratch allocation failed");
     hipLaunchKernelGGL(gan_term_kernel, dim3(bpc, B), dim3(256), 0, st, xv, rv, gvw, part, mode, target, C, bpc, 1.0f / ((float)C * D0 * D1));
     hipLaunchKernelGGL(row_sum_kernel, dim3(blk(B, 64)), dim3(64), 0, st, part, bpc, loss_dev, B, accumulate, 1.0f);
-    ESCX_HIP(hipFreeAsync(part, st));
     return launch_ok("gan_term");
 }

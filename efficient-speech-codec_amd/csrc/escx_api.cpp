@@ -6,6 +6,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 #include "escx_internal.h"
 #include "launchers.h"
@@ -892,6 +895,25 @@ struct TmpBuf {                      // test-path scratch for the stage-level en
     int alloc(size_t n_floats) { return hipMalloc((void**)&p, std::max<size_t>(n_floats, 1) * sizeof(float)) == hipSuccess ? 0 : -1; }
 };
 }  // namespace
+
+float* escx::stream_scratch(hipStream_t st, int slot, size_t floats) {
+    struct Buf { float* p = nullptr; size_t cap = 0; };
+    static std::mutex mu;
+    static std::map<std::tuple<int, hipStream_t, int>, Buf> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    Buf& b = bufs[std::make_tuple(dev, st, slot)];
+    if (b.cap < floats) {
+        (void)hipDeviceSynchronize();                                  // earlier work may still read the old buffer
+        if (b.p) (void)hipFree(b.p);
+        b.p = nullptr; b.cap = 0;
+        const size_t want = floats + floats / 8 + 1024;
+        if (hipMalloc((void**)&b.p, want * sizeof(float)) != hipSuccess) { b.p = nullptr; return nullptr; }
+        b.cap = want;
+    }
+    return b.p;
+}
 
 int escx::launch_ok(const char* what) {
     hipError_t e = hipGetLastError();

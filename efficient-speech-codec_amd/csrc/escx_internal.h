@@ -83,6 +83,10 @@ namespace escx {
 int make_shapes(escx_handle_s* h, int B, int T, Shapes* out);
 int get_map(escx_handle_s* h, int H, int W, int shift, const int** out);     // shift 0/2: slot -> token; -1: merge rows; 10/12: token -> slot
 int check_ready(escx_handle_s* h);
+// Grow-only device scratch for the stateless entry points (losses, GAN terms), one buffer per (device, stream, slot): hipMallocAsync /
+// hipFreeAsync cost ~1.6 ms of host time per call on this stack and were 40 % of the adversarial step's host time.  Work on one stream is
+// ordered, so consecutive calls may reuse the buffer; growing synchronises the device once.
+float* stream_scratch(hipStream_t st, int slot, size_t floats);
 int launch_ok(const char* what);
 int build_gather_map(escx_handle_s* h);
 }

@@ -722,11 +722,10 @@ extern "C" int escx_stft_loss(const float* raw_feat, const float* recon_feat, in
     hipStream_t st = (hipStream_t)stream;
     const long long per = (long long)per_clip;
     const int bpc = (int)std::min<long long>(64, (per + 255) / 256);
-    float* part = nullptr;
-    ESCX_HIP(hipMallocAsync((void**)&part, (size_t)B * bpc * sizeof(float), st));
+    float* part = stream_scratch(st, 0, (size_t)B * bpc);
+    if (!part) ESCX_FAIL(ESCX_ERR_HIP, "scratch allocation failed");
     hipLaunchKernelGGL(stft_loss_kernel, dim3(bpc, B), dim3(256), 0, st, raw_feat, recon_feat, part, d_recon, per, bpc, 1.0f / (float)per);
     hipLaunchKernelGGL(row_sum_kernel, dim3(blocks_for(B, 64)), dim3(64), 0, st, part, bpc, loss, B, 0, 1.0f);
-    ESCX_HIP(hipFreeAsync(part, st));
     return launch_ok("stft_loss");
 }
 
@@ -804,8 +803,8 @@ extern "C" int escx_mel_loss(const float* raw_wave, const float* recon_wave, int
     }
     const int bpc = 64;
     const size_t total = 2 * spec_max + 3 * mag_max + 3 * mel_max + fr_max + (size_t)B * bpc + 1024;
-    float* buf = nullptr;
-    ESCX_HIP(hipMallocAsync((void**)&buf, total * sizeof(float), st));
+    float* buf = stream_scratch(st, 1, total);
+    if (!buf) ESCX_FAIL(ESCX_ERR_HIP, "scratch allocation of %zu floats failed", total);
     float* spx = buf; float* spy = spx + spec_max; float* mgx = spy + spec_max; float* mgy = mgx + mag_max; float* dmg = mgy + mag_max;
     float* mlx = dmg + mag_max; float* mly = mlx + mel_max; float* gml = mly + mel_max; float* dfr = gml + mel_max; float* part = dfr + fr_max;
     for (int i = 0; i < 7; ++i) {
@@ -828,7 +827,6 @@ extern "C" int escx_mel_loss(const float* raw_wave, const float* recon_wave, int
             hipLaunchKernelGGL(frames_bwd_kernel, dim3(blocks_for((long long)B * L)), dim3(256), 0, st, dfr, d_recon, B, L, Tm, m.hop, m.w, m.w, i > 0);
         }
     }
-    ESCX_HIP(hipFreeAsync(buf, st));
     return launch_ok("mel_loss");
 }
 

@@ -369,6 +369,91 @@ __global__ __launch_bounds__(256) void gemm_dw2_kernel(const float* __restrict__
         }
 }
 
+// The contraction through arbitrary row loaders with a WIDE workgroup tile: WN x WK waves, each owning TA x TB accumulator tiles, share every
+// staged 32-row chunk through a double-buffered LDS image (one barrier per chunk, next chunk's loads in flight during the MFMAs).
+//   <4,4,2,2>  128 x 128 tile for large weight matrices (N, K >= 256: the 512 / 1024-channel convolutions of the discriminator): 256 floats
+//              staged per row for 16384 multiply-adds (the 48 x 48 kernel: 96 floats for 2304 - 2.7x the operand traffic and gather arithmetic)
+//   <2,3,1,4>   32 x 192 tile for N = 32 (the 32-channel band stacks of MRD): no padded third of the N side, dY staged once for four K tiles
+// Every thread owns ONE row of the chunk (8 threads per row): one make_ctx per operand per chunk.
+template <class LdA, class LdB, int TA, int TB, int WN, int WK, bool BIAS>
+__global__ __launch_bounds__(256) void gemm_dw3_kernel(LdA la, LdB lb, int M, int Np, int Kp, int nblk_k, int m_per_slice,
+                                                       float* __restrict__ part, float* __restrict__ bpart) {
+    static_assert(WN * WK == 4, "four waves");
+    constexpr int WA = 16 * TA * WN, WB = 16 * TB * WK;          // workgroup tile
+    static_assert(WA % 32 == 0 && WB % 32 == 0, "8 threads x float4 per row");
+    constexpr int LDA = WA + 16, LDB = WB + 16;                  // % 32 == 16: the 4 rows of an MFMA operand read hit different bank groups
+    constexpr int NA = WA / 32, NB = WB / 32;
+    __shared__ float lds[2 * DW_MC * (LDA + LDB)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wn = wave / WK, wk = wave - wn * WK;
+    const int bn = blockIdx.x / nblk_k, bk = blockIdx.x - bn * nblk_k;
+    const int n0 = bn * WA, k0 = bk * WB;
+    const int mbeg = blockIdx.y * m_per_slice, mend = min(M, mbeg + m_per_slice);
+    const bool do_bias = BIAS && bk == 0 && wk == 0;
+    const int frow = tid >> 3, fc = tid & 7;
+    f32x4 acc[TA][TB], accb[TA];
+#pragma unroll
+    for (int a = 0; a < TA; ++a) { accb[a] = zero4();
+#pragma unroll
+        for (int b = 0; b < TB; ++b) acc[a][b] = zero4(); }
+    f32x4 ra[NA], rb[NB];
+    auto fetch = [&](int m0) {
+        const int m = m0 + frow;
+        typename LdA::Ctx ca = la.make_ctx(m < mend ? m : M);
+        typename LdB::Ctx cb = lb.make_ctx(m < mend ? m : M);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) { const int col = 4 * (fc + 8 * j); ra[j] = (n0 + col < Np) ? la.load4(ca, n0 + (col & ~15), col & 15) : zero4(); }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { const int col = 4 * (fc + 8 * j); rb[j] = (k0 + col < Kp) ? lb.load4(cb, k0 + (col & ~15), col & 15) : zero4(); }
+    };
+    if (mbeg < mend) fetch(mbeg);
+    int buf = 0;
+    for (int m0 = mbeg; m0 < mend; m0 += DW_MC) {
+        float* As = lds + buf * (DW_MC * (LDA + LDB));
+        float* Bs = As + DW_MC * LDA;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) st4(As + frow * LDA + 4 * (fc + 8 * j), ra[j]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) st4(Bs + frow * LDB + 4 * (fc + 8 * j), rb[j]);
+        __syncthreads();                                         // one barrier per chunk: the other buffer was last read before the previous barrier
+        if (m0 + DW_MC < mend) fetch(m0 + DW_MC);
+        const float* Aw = As + wn * 16 * TA; const float* Bw = Bs + wk * 16 * TB;
+#pragma unroll
+        for (int ms = 0; ms < DW_MC / 4; ++ms) {
+            float af[TA], bf[TB];
+#pragma unroll
+            for (int a = 0; a < TA; ++a) af[a] = Aw[(4 * ms + lg) * LDA + 16 * a + l15];
+#pragma unroll
+            for (int b = 0; b < TB; ++b) bf[b] = Bw[(4 * ms + lg) * LDB + 16 * b + l15];
+#pragma unroll
+            for (int a = 0; a < TA; ++a)
+#pragma unroll
+                for (int b = 0; b < TB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+            if (do_bias) {
+                const float one = (l15 == 0) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int a = 0; a < TA; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], one, accb[a], 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+    }
+    float* po = part + (size_t)blockIdx.y * Np * Kp;
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn * 16 * TA + 16 * a + 4 * lg + r;
+            if (n >= Np) continue;
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                const int k = k0 + wk * 16 * TB + 16 * b + l15;
+                if (k < Kp) po[(size_t)n * Kp + k] = acc[a][b][r];
+            }
+            if (do_bias && l15 == 0) bpart[(size_t)blockIdx.y * Np + n] = accb[a][r];
+        }
+}
+
 // out[i] = sum_s part[s][i], s increasing (fixed order); optional accumulate into out
 static __global__ void reduce_partials_kernel(const float* __restrict__ part, int slices, long long n, float* __restrict__ out, int accumulate) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -136,14 +136,29 @@ def _smooth_probe(name, x):
     return A, R, 0.7, 1.3
 
 
-def _noise_floor(name, S, freeze, x):
-    """Per-parameter relative RMS distance between the oracle's fp32 and fp64 gradients of the trainer's loss = how well an fp32
-    evaluation of the reference determines each gradient at all."""
-    _, _, g32 = _oracle_step(name, S, freeze, x)
+def _noise_floor(name, S, freeze, x, draws=3):
+    """Per-parameter relative RMS distance between fp32 evaluations of the reference restatement and its fp64 gradients of the trainer's
+    loss = how well ANY fp32 evaluation determines each gradient.  One fp32 run is a single draw of that noise and draws differ by up to 10x
+    (measured on base, S=3: medians 1.0e-3 / 3.1e-3 / 5.6e-3 / 1.2e-2 for the default run, two runs with every input sample moved by one
+    ulp, and a single-threaded run - tools/grad_noise_diag.py), so the floor is the envelope over `draws` realisations: the default run, the
+    inputs moved by one ulp with random signs, and the default inputs summed single-threaded."""
     _, _, g64 = _oracle_step(name, S, freeze, x, dtype=torch.float64)
     scale = float(np.sqrt(sum(float((v.double() ** 2).sum()) for v in g64.values())))
-    floor = {k: _rel_rms(g32[k].numpy(), g64[k].numpy(), 1e-6 * scale / np.sqrt(g64[k].numel())) for k in g64}
-    return g64, floor, scale
+    gen = torch.Generator().manual_seed(5)
+    floor, medians = {k: 0.0 for k in g64}, []
+    for d in range(draws):
+        nt = torch.get_num_threads()
+        xd = x if d != 1 else x * (1 + (torch.randint(0, 2, x.shape, generator=gen).float() * 2 - 1) * 2.0 ** -23)
+        if d == 2:
+            torch.set_num_threads(1)
+        try:
+            _, _, g32 = _oracle_step(name, S, freeze, xd)
+        finally:
+            torch.set_num_threads(nt)
+        e = {k: _rel_rms(g32[k].numpy(), g64[k].numpy(), 1e-6 * scale / np.sqrt(g64[k].numel())) for k in g64}
+        medians.append(float(np.median(list(e.values()))))
+        floor = {k: max(floor[k], e[k]) for k in g64}
+    return g64, floor, scale, max(medians)
 
 
 def test_reference_fp32_gradient_noise_floor():
@@ -151,9 +166,8 @@ def test_reference_fp32_gradient_noise_floor():
     vs fp64, same codes, differs by more than that on most parameters - while the VQ-loss path alone is good to 1e-6."""
     g = load_golden("train")
     x = _clips(g, "tiny")
-    _, floor, _ = _noise_floor("tiny", 3, False, x)
-    med = float(np.median(list(floor.values())))
-    assert 2e-5 < med < 2e-3, med
+    _, floor, _, med = _noise_floor("tiny", 3, False, x)
+    assert 2e-5 < med < 2e-2, med
     _, _, a = _oracle_step("tiny", 3, False, x, smooth=(torch.zeros_like(x), torch.zeros(2, 2, 48, 64), 0.7, 1.3))
     _, _, b = _oracle_step("tiny", 3, False, x, dtype=torch.float64, smooth=(torch.zeros_like(x), torch.zeros(2, 2, 48, 64), 0.7, 1.3))
     errs = [_rel_rms(a[k].numpy(), b[k].numpy(), 1e-9) for k in b if float(b[k].abs().max()) > 0]
@@ -210,9 +224,9 @@ def test_backward_pass_esc_large():
 @pytest.mark.parametrize("name", ["tiny", "base"])
 def test_training_step_losses_and_every_gradient(name):
     """The trainer's step (trainer_no_adv.py:105-115): losses 1e-5 relative to the reference fixtures, codes identical; every parameter
-    gradient against the fp64 oracle within 8x the reference's own fp32 noise floor (the larger of that parameter's and the median over
-    parameters, +1e-5), the median HIP error within 3x the median noise floor, and the gradient norms of the reference fixtures within
-    the same level."""
+    gradient against the fp64 oracle within 4x the reference restatement's own fp32 noise floor (envelope over three fp32 realisations, see
+    _noise_floor; the larger of that parameter's and the median over parameters, +1e-5), the median HIP error within 2x the median noise
+    floor, and the gradient norms of the reference fixtures within the same level."""
     g = load_golden("train")
     w = json.loads(str(g["weights_json"]))
     keys = json.loads(str(g[f"{name}_keys"]))
@@ -226,22 +240,21 @@ def test_training_step_losses_and_every_gradient(name):
         for k in ("cm", "cb", "mel", "stft", "loss"):
             np.testing.assert_allclose(losses[k], g[f"{tag}_{k}"], rtol=LOSS_RTOL, atol=1e-7, err_msg=f"{tag} {k}")
         assert np.array_equal(out["codes"].cpu().numpy(), g[f"{tag}_codes"].astype(np.int64))
-        g64, floor, scale = _noise_floor(name, S, freeze, x)
-        med = float(np.median(list(floor.values())))          # one parameter's floor is a single random draw: never trust less than the median
+        g64, floor, scale, med = _noise_floor(name, S, freeze, x)       # envelope over three fp32 realisations; med = their largest median
         worst, errs = (0.0, "", 0.0), []
         for k, rn in zip(keys, g[f"{tag}_gnorm"]):
             ref = g64[k].numpy()
             err = _rel_rms(grads[k], ref, 1e-6 * scale / np.sqrt(ref.size))
             errs.append(err)
-            bound = 8.0 * max(floor[k], med) + 1e-5
+            bound = 4.0 * max(floor[k], med) + 1e-5
             worst = max(worst, (err / bound, k, err))
-            assert err <= bound and err <= 5e-2, f"{tag}: gradient of {k} rel rms {err:.3e} vs fp64, reference fp32 noise floor {floor[k]:.3e}"
+            assert err <= bound and err <= max(5e-2, 2.0 * floor[k]), f"{tag}: gradient of {k} rel rms {err:.3e} vs fp64, reference fp32 noise floor {floor[k]:.3e}"
             gn = float(np.linalg.norm(np.asarray(grads[k], np.float64)))
             # the fixture is the fp32 reference: both sides carry their own noise (HIP error + the reference's floor)
             assert abs(gn - rn) <= 2.0 * bound * max(rn, 1e-6 * scale) + 1e-12, f"{tag}: |grad {k}| = {gn} vs reference fixture {rn}"
         print(f"[{tag}] vs fp64 oracle: HIP median rel rms {np.median(errs):.2e} max {max(errs):.2e}; reference-fp32 noise floor median {med:.2e} "
               f"max {max(floor.values()):.2e}; worst (error / bound) {worst[0]:.2f} at {worst[1]}")
-        assert np.median(errs) <= 3.0 * med + 1e-5          # as a whole, the HIP gradients sit at the fp32 reference's own distance from the truth
+        assert np.median(errs) <= 2.0 * med + 1e-5          # as a whole, the HIP gradients sit at the fp32 reference's own distance from the truth
 
 
 @pytest.mark.gpu
