@@ -412,11 +412,9 @@ def main():
             try:
                 import hashlib
                 pm = json.load(open(pmc))
-                hsh = hashlib.sha256()
-                cs = os.path.join(ROOT, "efficient-speech-codec_amd", "csrc")
-                for f in sorted(os.listdir(cs)):
-                    hsh.update(f.encode()); hsh.update(open(os.path.join(cs, f), "rb").read())
-                if pm.get("_csrc_sha256") == hsh.hexdigest():
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from pmc_hbm import csrc_hash                   # sha256 over the sources of the kernels this bench launches
+                if pm.get("_csrc_sha256") == csrc_hash():
                     traffic, traffic_note = pm.get(dom["name"]), f"rocprofv3 PMC, calibration {pm.get('_calibration')}"
                 else:
                     traffic_note = "profiles/pmc_dominant.json was measured on different kernel sources: not reported"

@@ -23,11 +23,16 @@ def load(d, counter):
     return acc
 
 
+CODEC_KERNEL_SOURCES = ("fused_attn.h", "fused_deembed.h", "fused_mlp.h", "fused_rowgemm.h", "fused_swin.hip", "gemm_engine.h", "gemm_misc.hip",
+                        "gemm_swin.hip", "kernels.h", "kernels_misc.hip", "launchers.h")
+
+
 def csrc_hash():
-    """sha256 over the kernel sources: bench.py refuses a traffic figure measured on other kernels."""
+    """sha256 over the sources of the kernels the codec bench launches (the training / discriminator / collective files and the host launch
+    sequence do not change what those kernels read or write): bench.py refuses a traffic figure measured on other kernels."""
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "efficient-speech-codec_amd", "csrc")
     h = hashlib.sha256()
-    for f in sorted(os.listdir(root)):
+    for f in CODEC_KERNEL_SOURCES:
         h.update(f.encode()); h.update(open(os.path.join(root, f), "rb").read())
     return h.hexdigest()
 
