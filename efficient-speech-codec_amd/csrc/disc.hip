@@ -121,6 +121,22 @@ void fmap_shapes(escx_disc_s* d, int L, std::vector<FmapShape>* out) {
 
 TView view_of(float* base, const FmapShape& f) { return TView{base, f.D0, f.D1, f.P1, f.Cp}; }
 
+// ESCX_DISC_TRACE=1: per-launch-group timing (events + a stream sync after each group: a diagnostic, not a mode to run in)
+struct DTrace {
+    static bool on() { static const bool v = [] { const char* e = getenv("ESCX_DISC_TRACE"); return e && e[0] == '1'; }(); return v; }
+    hipStream_t st; hipEvent_t a = nullptr, b = nullptr; const char* what; const char* name; double flops; int M, N, K;
+    DTrace(hipStream_t s, const char* w, const char* nm, int M_, int N_, int K_) : st(s), what(w), name(nm), flops(2.0 * M_ * N_ * K_), M(M_), N(N_), K(K_) {
+        if (on()) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
+    }
+    ~DTrace() {
+        if (!a) return;
+        (void)hipEventRecord(b, st); (void)hipEventSynchronize(b);
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, a, b);
+        fprintf(stderr, "[disc] %-4s %-44s M %8d N %5d K %5d  %8.3f ms  %6.1f TFLOP/s\n", what, name, M, N, K, ms, flops / (ms * 1e9));
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    }
+};
+
 // params_version: any number that changes whenever the flat buffer's CONTENTS change (negative = unknown: always re-pack).  The weight-normalised
 // operands are rebuilt only then - an adversarial step makes five calls on the same weights, 108 pack launches each otherwise.
 int pack_weights(escx_disc_s* d, const float* flat, long long params_version, hipStream_t st) {
@@ -146,8 +162,12 @@ int ensure_scratch(escx_disc_s* d, size_t bytes) {
 template <class Ld, class Epi>
 void conv_gemm(const Ld& ld, const float* W, int M, int Np, int Kp, const Epi& ep, hipStream_t st) {
     const long long tiles128 = (long long)((M + 127) / 128) * ((Np + 95) / 96);
-    if (tiles128 >= 512) launch_gemm<128>(ld, W, M, Np, Kp, ep, st);
-    else launch_gemm<64>(ld, W, M, Np, Kp, ep, st);
+    // K steps of 16: 18 KB of LDS per workgroup instead of 75 KB at the engine's default step of 80 for K = 5 x 1024 - twice the resident
+    // workgroups per CU; measured on the step's convolutions (tools/disc_trace.py): forward 73.5 -> 60.2 ms, dX 115.8 -> 99.0 ms
+    static const int env_bk = [] { const char* e = getenv("ESCX_CONV_BK"); return e ? atoi(e) : 16; }();
+    const int fbk = (env_bk > 0 && Kp % env_bk == 0) ? env_bk : 0;
+    if (tiles128 >= 512) launch_gemm<128>(ld, W, M, Np, Kp, ep, st, 1, fbk);
+    else launch_gemm<64>(ld, W, M, Np, Kp, ep, st, 1, fbk);
 }
 
 ConvS make_convs(const TView& x, const DConv& c, int O0, int O1, int B) {
@@ -156,6 +176,7 @@ ConvS make_convs(const TView& x, const DConv& c, int O0, int O1, int B) {
 }
 
 void conv_forward(const TView& x, const DConv& c, const TView& out, int B, hipStream_t st) {
+    DTrace tr(st, "fwd", c.prefix.c_str(), B * out.D0 * out.D1, c.CoutP, c.Kf);
     ConvS ld = make_convs(x, c, out.D0, out.D1, B);
     conv_gemm(ld, c.Wf, B * out.D0 * out.D1, c.CoutP, c.Kf, EpiConvOut{out, c.bias, c.act, FastDiv(out.D0 * out.D1), FastDiv(out.D1)}, st);
 }
@@ -178,10 +199,8 @@ int disc_dw(const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, floa
         float* bpart = part + (size_t)slices * Np * Kp;
         if (big) hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, 4, 4, 2, 2, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
         else hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, 2, 3, 1, 4, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
-        const long long n = (long long)Np * Kp;
-        if (slices >= 32 && n * 4 <= ((long long)1 << 22)) hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3(blk((n + 15) / 16 * 64)), dim3(256), 0, st, part, slices, n, dW, 0);
-        else hipLaunchKernelGGL(reduce_partials_kernel, dim3(blk(n)), dim3(256), 0, st, part, slices, n, dW, 0);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blk(Np)), dim3(256), 0, st, bpart, slices, (long long)Np, db, 0);
+        launch_reduce_partials(part, slices, (long long)Np * Kp, dW, 0, st);
+        launch_reduce_partials(bpart, slices, (long long)Np, db, 0, st);
         return 0;
     }
     const int nbn = (Np + 47) / 48, nbk = (Kp + 47) / 48, blocks = nbn * nbk;
@@ -192,10 +211,8 @@ int disc_dw(const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, floa
     slices = (M + mps - 1) / mps;
     float* bpart = part + (size_t)slices * Np * Kp;
     hipLaunchKernelGGL((gemm_dw_kernel<LdA, LdB, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
-    const long long n = (long long)Np * Kp;
-    if (slices >= 32 && n * 4 <= ((long long)1 << 22)) hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3(blk((n + 15) / 16 * 64)), dim3(256), 0, st, part, slices, n, dW, 0);
-    else hipLaunchKernelGGL(reduce_partials_kernel, dim3(blk(n)), dim3(256), 0, st, part, slices, n, dW, 0);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blk(Np)), dim3(256), 0, st, bpart, slices, (long long)Np, db, 0);
+    launch_reduce_partials(part, slices, (long long)Np * Kp, dW, 0, st);
+    launch_reduce_partials(bpart, slices, (long long)Np, db, 0, st);
     return 0;
 }
 
@@ -452,7 +469,8 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
         if (grad_flat) {
             ViewRowsA la{g, M, FastDiv(yv.D0 * yv.D1), FastDiv(yv.D1)};
             ConvS lb = make_convs(x, c, yv.D0, yv.D1, B);
-            int r = disc_dw(la, lb, M, c.CoutP, c.Kf, dWs, dWs + (size_t)c.CoutP * c.Kf, part, st);
+            int r;
+            { DTrace tr(st, "dW", c.prefix.c_str(), M, c.CoutP, c.Kf); r = disc_dw(la, lb, M, c.CoutP, c.Kf, dWs, dWs + (size_t)c.CoutP * c.Kf, part, st); }
             if (r) return r;
             hipLaunchKernelGGL(wn_bwd_kernel, dim3(c.Cout), dim3(256), 0, st, dWs, flat_params + c.off_v, c.scale, grad_flat + c.off_v, grad_flat + c.off_g, c.Cin,
                                c.T0 * c.T1, c.CinP, c.Kf);
@@ -460,6 +478,7 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
         }
         if (gx || gx_plain) {
             TView gxv = gx ? *gx : TView{gx_plain, x.D0, x.D1, x.D1, x.Cp};
+            DTrace tr(st, "dX", c.prefix.c_str(), B * x.D0 * x.D1, c.CinR, c.Wp ? c.Kt / (c.s0 * c.s1) : c.Kt);
             if (gx_plain) ESCX_HIP(hipMemsetAsync(gx_plain, 0, (size_t)B * x.D0 * x.D1 * x.Cp * sizeof(float), st));
             if (c.Wp) {                         // strided: one launch per residue class of input positions over its own taps
                 size_t off = 0;

@@ -45,13 +45,8 @@ TrainTape* tape_of(escx_handle_s* h) {
 
 inline unsigned blocks_for(long long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
 
-// fixed-order sum of `slices` partial tensors of n floats.  The variant depends on (slices, n) only - never on data - so results stay
-// run-to-run deterministic.
 void reduce_partials(const float* part, int slices, long long n, float* out, int accumulate, hipStream_t st) {
-    if (slices >= 32 && n * 4 <= ((long long)1 << 22))
-        hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3(blocks_for((n + 15) / 16 * 64)), dim3(256), 0, st, part, slices, n, out, accumulate);
-    else
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for(n)), dim3(256), 0, st, part, slices, n, out, accumulate);
+    launch_reduce_partials(part, slices, n, out, accumulate, st);
 }
 
 // ---- GEMM helpers --------------------------------------------------------------------------------
@@ -59,6 +54,9 @@ template <class Ld, class Epi>
 void gemm_any(const Ld& ld, const float* W, int M, int Np, int Kp, const Epi& ep, hipStream_t st, int force_bk = 0) {
     // 128-row tiles halve the weight traffic per output row; 64 when the grid would not fill the chip (same rule as gemm_swin.hip)
     const long long tiles128 = (long long)((M + 127) / 128) * ((Np + 95) / 96);
+    // K steps of 16 keep the workgroup's LDS image small (more resident workgroups): 98.0 -> 96.1 ms/step over the engine's default steps
+    static const int env_bk = [] { const char* e = getenv("ESCX_TRAIN_BK"); return e ? atoi(e) : 16; }();
+    if (!force_bk && env_bk > 0 && Kp % env_bk == 0) force_bk = env_bk;
     if (tiles128 >= 512) launch_gemm<128>(ld, W, M, Np, Kp, ep, st, 1, force_bk);
     else launch_gemm<64>(ld, W, M, Np, Kp, ep, st, 1, force_bk);
 }
@@ -74,7 +72,7 @@ struct Scratch {                              // bump allocator over the free ta
     float* take(size_t n) { return a->take(n); }
 };
 
-constexpr size_t DW_PART_FLOATS = (size_t)10 << 20;      // partial-sum scratch of one dW launch (40 MB)
+constexpr size_t DW_PART_FLOATS = (size_t)40 << 20;      // partial-sum scratch of one dW launch (160 MB)
 
 // dW[Np][Kp] (+ db[Np]) = sum over M rows; la: gradient rows (columns n), lb: saved input rows (columns k)
 template <class LdA, class LdB>
@@ -89,6 +87,23 @@ int dw_launch(escx_handle_s* h, const LdA& la, const LdB& lb, int M, int Np, int
     float* bpart = part + (size_t)slices * Np * Kp;
     if (db) hipLaunchKernelGGL((gemm_dw_kernel<LdA, LdB, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
     else hipLaunchKernelGGL((gemm_dw_kernel<LdA, LdB, false>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+    reduce_partials(part, slices, (long long)Np * Kp, dW, 0, st);
+    if (db) reduce_partials(bpart, slices, (long long)Np, db, 0, st);
+    return 0;
+}
+
+// the same through 128 x 128 workgroup tiles (gemm_dw3_kernel) for large weight matrices: operands staged once per workgroup
+template <class LdA, class LdB>
+int dw_launch_wide(escx_handle_s* h, const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
+    const int nbn = (Np + 127) / 128, nbk = (Kp + 127) / 128, blocks = nbn * nbk;
+    int slices = std::max(1, std::min((2560 + blocks / 2) / blocks, (M + 255) / 256));
+    const size_t per = (size_t)Np * Kp + Np;
+    slices = (int)std::max<size_t>(1, std::min<size_t>(slices, DW_PART_FLOATS / per));
+    int mps = ((M + slices - 1) / slices + 31) / 32 * 32;
+    slices = (M + mps - 1) / mps;
+    float* bpart = part + (size_t)slices * Np * Kp;
+    if (db) hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, 4, 4, 2, 2, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+    else hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, 4, 4, 2, 2, false>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
     reduce_partials(part, slices, (long long)Np * Kp, dW, 0, st);
     if (db) reduce_partials(bpart, slices, (long long)Np, db, 0, st);
     return 0;
@@ -202,7 +217,7 @@ size_t tape_bytes(escx_handle_s* h, const Shapes& s) {
     add((size_t)B * T2 * c.in_dim * h->Fp);                          // rspec
     // backward scratch (upper bounds): activations-sized gradients, dW partials, LN / attention partials, frames
     const size_t fine = (size_t)B * T2 * F2 * h->C0p;
-    tot += 12 * pad256(act_max) + 2 * pad256(hid_max) + 2 * pad256(qkv_max) + pad256(zp_max) + 2 * pad256(fine) + pad256(DW_PART_FLOATS) +
+    tot += 12 * pad256(act_max) + 2 * pad256(hid_max) + 2 * pad256(qkv_max) + pad256(zp_max) + 2 * pad256(fine) + 2 * pad256(DW_PART_FLOATS) +
            pad256(LN_PART_FLOATS) + pad256(ATT_PART_FLOATS) + 3 * pad256((size_t)B * T2 * std::max(h->winP, c.in_dim * h->Fp)) + (size_t)n * pad256(act_max) + (64 << 20);
     return tot;
 }
@@ -636,18 +651,20 @@ extern "C" int escx_train_backward(escx_handle h, const float* d_wave, const flo
         ConvA ctok{T.post, s.H0, s.W, h->C0p, 5, 5, Mt};
         float* Rb = R + (size_t)DEP_LD * K1;
         PROF("B.dw_conv5", 2.0 * Mt * 25 * h->C0 * Q * c.in_dim * 9, 0,
-             rc = dw_launch(h, PlainA{P, DEP_LD, Mt}, ctok, Mt, DEP_LD, K1, R, Rb, part, st));
+             rc = dw_launch_wide(h, PlainA{P, DEP_LD, Mt}, ctok, Mt, DEP_LD, K1, R, Rb, part, st));
         if (rc) return rc;
         hipLaunchKernelGGL(deembed_fold_dw_kernel, dim3(blocks_for((long long)Q * h->C0p * K1)), dim3(256), 0, st, R, h->dc2_w, G(h, h->dc1_w), Q, h->C0, h->C0p, K1, c.in_dim);
         hipLaunchKernelGGL(deembed_fold_dw_kernel, dim3(blocks_for((long long)Q * h->C0p)), dim3(256), 0, st, Rb, h->dc2_w, G(h, h->dc1_b), Q, h->C0, h->C0p, 1, c.in_dim);
         hipLaunchKernelGGL(deembed_weff_kernel, dim3(blocks_for((long long)h->C0p * 25 * DEP_LD)), dim3(256), 0, st, h->dc1_w, h->dc2_w, weff, Q, h->C0, h->C0p, c.in_dim);
-        // conv3x3 weight gradient with the same P: X = P^T . Y1 on the MFMA (Y1 = the saved fine map viewed per coarse pixel), then the q == q'
-        // blocks are summed; db2 = the centre-tap column sums of P
-        float* X = sc.take((size_t)DEP_LD * Q * h->C0p);
+        // conv3x3 weight gradient with the same P: only the Q diagonal blocks of P^T . Y1 (Y1 = the saved fine map viewed per coarse pixel) are
+        // needed - one 20 x C0p contraction per sub-pixel q instead of the full 128 x Q*C0p product; db2 = the centre-tap column sums of P
+        float* X = sc.take((size_t)Q * DEP_J * h->C0p);
         if (!X) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
         ShuffleA ysh{T.deemb, s.H0, s.W, h->C0p, c.patch_f, c.patch_t, Mt, FastDiv(s.H0 * s.W), FastDiv(s.W), FastDiv(h->C0p)};
-        PROF("B.dw_conv3", 2.0 * Mt * Q * 9 * h->C0 * c.in_dim, 0,
-             rc = dw_launch(h, PlainA{P, DEP_LD, Mt}, ysh, Mt, DEP_LD, Q * h->C0p, X, nullptr, part, st));
+        PROF("B.dw_conv3", 2.0 * Mt * Q * 9 * h->C0 * c.in_dim, 0, {
+             for (int q = 0; q < Q && !rc; ++q)
+                 rc = dw_launch(h, ColOffset<PlainA>{PlainA{P, DEP_LD, Mt}, q * DEP_J}, ColOffset<ShuffleA>{ysh, q * h->C0p}, Mt, DEP_J, h->C0p,
+                                X + (size_t)q * DEP_J * h->C0p, nullptr, part, st); });
         if (rc) return rc;
         hipLaunchKernelGGL(deembed_fold_dw2_kernel, dim3(blocks_for((long long)c.in_dim * 9 * h->C0p + c.in_dim)), dim3(256), 0, st, X, Rb, G(h, h->dc2_w),
                            G(h, h->dc2_b), Q, h->C0, h->C0p, c.in_dim);

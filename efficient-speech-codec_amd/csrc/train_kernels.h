@@ -65,6 +65,14 @@ struct ShuffleA {               // inverse of the de-embedding pixel shuffle: A[
     }
 };
 
+template <class Ld>
+struct ColOffset {              // columns [off, off + width) of another loader's rows (the diagonal blocks of a block-structured contraction)
+    Ld ld; int off;
+    typedef typename Ld::Ctx Ctx;
+    __device__ __forceinline__ Ctx make_ctx(int m) const { return ld.make_ctx(m); }
+    __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const { return ld.load4(c, k0 + off, kin); }
+};
+
 struct ConvShuffleA {           // conv5x5 dX: A[(b,h,w)][k = (tap, q, c)] = dY1[(b, h-dh, w-dw)][q*Cp+c] with dY1 = ShuffleA(g); tap = (kh,kw), dh = kh-2
     const float* g; int H, W, Cp, pf, pt, M; FastDiv dHW, dW, dCp, dQ;
     struct Ctx { int b, h, w; };
@@ -475,6 +483,44 @@ static __global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const 
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
     if (i < n && q == 0) out[i] = (accumulate ? out[i] : 0.f) + s;
+}
+
+// For MANY slices (>= 128): 16 outputs x 16 slice lanes per workgroup - lane (q, j) adds slices q, q+16, ... of output j, the 16 partial sums
+// are then added in the order 0..15 by lane q = 0.  Four times the loads in flight of the wave-per-16-outputs form above, which still walked
+// ~500 dependent L2 loads per lane for the 48-channel weight gradients (2000 slices) and the 512-slice bias gradients of the discriminator.
+static __global__ __launch_bounds__(256) void reduce_partials_tree_kernel(const float* __restrict__ part, int slices, long long n, float* __restrict__ out,
+                                                                   int accumulate) {
+    __shared__ float red[16][17];
+    const int j = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const long long i = (long long)blockIdx.x * 16 + j;
+    float s = 0.f;
+    if (i < n) {
+        int k = q;
+        for (; k + 48 < slices; k += 64) {                     // four independent loads per round trip
+            const float a = part[(size_t)k * n + i], b = part[(size_t)(k + 16) * n + i], c = part[(size_t)(k + 32) * n + i], d = part[(size_t)(k + 48) * n + i];
+            s += a; s += b; s += c; s += d;
+        }
+        for (; k < slices; k += 16) s += part[(size_t)k * n + i];
+    }
+    red[q][j] = s;
+    __syncthreads();
+    if (q == 0 && i < n) {
+        float t = red[0][j];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) t += red[r][j];
+        out[i] = (accumulate ? out[i] : 0.f) + t;
+    }
+}
+// fixed-order sum of `slices` partial tensors of n floats.  The variant depends on (slices, n) only - never on data - so results stay
+// run-to-run deterministic.
+static inline void launch_reduce_partials(const float* part, int slices, long long n, float* out, int accumulate, hipStream_t st) {
+    auto nb = [](long long v) { return (unsigned)((v + 255) / 256); };
+    if (slices >= 128 && n <= ((long long)1 << 18))
+        hipLaunchKernelGGL(reduce_partials_tree_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, slices, n, out, accumulate);
+    else if (slices >= 32 && n * 4 <= ((long long)1 << 22))
+        hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3(nb((n + 15) / 16 * 64)), dim3(256), 0, st, part, slices, n, out, accumulate);
+    else
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(nb(n)), dim3(256), 0, st, part, slices, n, out, accumulate);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -948,8 +994,8 @@ static __global__ void deembed_fold_dw_kernel(const float* __restrict__ R, const
         }
     dW1[idx] = s;
 }
-// conv3x3 weight gradient from X = P^T . Y1 (X[(q, j)][(q', cc)], only the q == q' blocks are meaningful):
-//   dW2[oc][(b*3 + a)*Cp + cc] = sum_q X[q*20 + j][q*Cp + cc],  j = oc*9 + a*3 + b ;   db2[oc] = sum_q Rb[q*20 + oc*9 + 4]  (centre tap: no border exclusion)
+// conv3x3 weight gradient from the Q diagonal blocks X[q][j][cc] = sum_pix P[pix][q*20 + j] * Y1[pix][q*Cp + cc]:
+//   dW2[oc][(b*3 + a)*Cp + cc] = sum_q X[q][j][cc],  j = oc*9 + a*3 + b ;   db2[oc] = sum_q Rb[q*20 + oc*9 + 4]  (centre tap: no border exclusion)
 static __global__ void deembed_fold_dw2_kernel(const float* __restrict__ X, const float* __restrict__ Rb, float* __restrict__ dW2, float* __restrict__ db2, int Q,
                                         int C, int Cp, int in_dim) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -959,7 +1005,7 @@ static __global__ void deembed_fold_dw2_kernel(const float* __restrict__ X, cons
         const int bq = tap / 3, a = tap - bq * 3;
         float s = 0.f;
         if (cc < C)
-            for (int q = 0; q < Q; ++q) s += X[(size_t)(q * DEP_J + oc * 9 + a * 3 + bq) * (Q * Cp) + q * Cp + cc];
+            for (int q = 0; q < Q; ++q) s += X[((size_t)q * DEP_J + oc * 9 + a * 3 + bq) * Cp + cc];
         dW2[idx] = s;
     } else if (idx < n + in_dim) {
         const int oc = idx - n;
