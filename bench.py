@@ -156,6 +156,39 @@ def train_cpu_baseline(cfg, sd, x_cpu):
                       "no optimiser step"}
 
 
+def train_adv_cpu_baseline(cfg, sd, disc_sd, x_cpu, weights):
+    """One adversarial step of the oracle as the reference runs it (trainer_adv.py:60-105: generator forward, four discriminator passes, two
+    backward passes; no optimiser steps) on the host cores: bounded sample of 1 clip."""
+    from oracle import esc_oracle as O
+    avail = os.cpu_count() or 1
+    thr = min(avail, 16)
+    torch.set_num_threads(thr)
+    xs = x_cpu[:1]
+
+    def once():
+        leaf = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not k.endswith(".window")) else v) for k, v in sd.items()}
+        dleaf = {k: v.clone().requires_grad_(True) for k, v in disc_sd.items()}
+        orc = O.EscOracle(cfg, leaf, keep_graph=True)
+        t0 = time.perf_counter()
+        out = orc.forward_train(xs, NUM_STREAMS, False)
+        lg, lf = O.gan_generator_loss(out["recon_audio"], out["raw_audio"], dleaf)
+        total = (out["cm_loss"] * weights["cm_weight"] + out["cb_loss"] * weights["cb_weight"] + O.mel_spectrogram_loss(out["raw_audio"], out["recon_audio"]) * weights["mel_weight"]
+                 + lg * weights["gen_weight"] + lf * weights["feat_weight"])
+        total.mean().backward()
+        O.gan_discriminator_loss(out["recon_audio"].detach(), out["raw_audio"], dleaf).mean().backward()
+        return time.perf_counter() - t0
+    once()
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        once(); reps += 1
+        el = time.perf_counter() - t0
+        if el > 15.0 or reps >= 4:
+            break
+    return {"value": round(reps * 1 * (TRAIN_SAMPLES / 16000.0) / el, 3), "unit": "audio-seconds/sec", "cores": thr, "kind": "port",
+            "sample": f"{reps} x (generator forward, 4 discriminator passes, generator + discriminator backward) of 1 clip, oracle/esc_oracle.py under torch "
+                      f"autograd, CPU fp32, {thr} of {avail} host threads; no optimiser steps"}
+
+
 def run_train(args, rank, world, device, use_dist):
     """--mode train: the step of scripts/trainer_no_adv.py:95-118 (training forward, mel + complex-STFT + VQ losses, backward, clip 0.5,
     AdamW) on 36 clips per GPU, ESC-Base, fp32 like the reference (it has no AMP path).  Single-GPU measurement; with N > 1 every rank
@@ -297,7 +330,8 @@ def run_train_adv(args, rank, world, device, use_dist):
                         "kernel": "discriminator convolutions (all launches of the step)",
                         "note": "algorithmic discriminator-convolution FLOPs of the step (7 pass-equivalents of "
                                 f"{d_flops / 1e9:.1f} GFLOP per clip) over the WHOLE step time, generator included: a lower bound on the conv kernels' rate"},
-           "cpu_baseline": None}
+           "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else
+                           train_adv_cpu_baseline(cfg, sd, {k: v.detach().cpu() for k, v in disc.state_dict().items()}, x.cpu(), st.w)}
     print(json.dumps(out))
 
 

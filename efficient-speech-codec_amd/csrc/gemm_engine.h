@@ -14,6 +14,7 @@
 //  * 256 threads = 4 waves stacked along M; each wave owns (BM/4) x BN of the block tile.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 namespace escx {
 
@@ -457,7 +458,11 @@ struct EpiPartial {             // split-K partial sums, reduced in a fixed orde
 // ------------------------------------------------------------------------------------------------
 // Host-side tile selection and launch.
 // ------------------------------------------------------------------------------------------------
-inline int pick_bk(int Kp) { return Kp % 48 == 0 ? 48 : (Kp % 80 == 0 ? 80 : (Kp % 32 == 0 ? 32 : 16)); }     // 80: the C = 72 maps (a 16-wide step there means 5x the K steps)
+inline int pick_bk(int Kp) {
+    static const int env_bk = [] { const char* e = getenv("ESCX_BK"); return e ? atoi(e) : 0; }();          // tuning aid (results are identical for every step size)
+    if (env_bk > 0 && Kp % env_bk == 0) return env_bk;
+    return Kp % 48 == 0 ? 48 : (Kp % 80 == 0 ? 80 : (Kp % 32 == 0 ? 32 : 16));
+}     // 80: the C = 72 maps (a 16-wide step there means 5x the K steps)
 inline int pick_bn(int Np) {
     // padded width, with a mild preference for wide tiles (every N tile re-stages the A tile)
     const int cands[4] = {96, 48, 32, 16};
