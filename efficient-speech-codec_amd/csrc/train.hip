@@ -92,47 +92,51 @@ int dw_launch(escx_handle_s* h, const LdA& la, const LdB& lb, int M, int Np, int
     return 0;
 }
 
-// the same through 128 x 128 workgroup tiles (gemm_dw3_kernel) for large weight matrices: operands staged once per workgroup
-template <class LdA, class LdB>
+// the same through wide workgroup tiles (gemm_dw3_kernel, 2 x 2 waves of TA x TB accumulator tiles): operands staged once per workgroup
+template <int TA, int TB, class LdA, class LdB>
 int dw_launch_wide(escx_handle_s* h, const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
-    const int nbn = (Np + 127) / 128, nbk = (Kp + 127) / 128, blocks = nbn * nbk;
+    constexpr int WA = 32 * TA, WB = 32 * TB;
+    const int nbn = (Np + WA - 1) / WA, nbk = (Kp + WB - 1) / WB, blocks = nbn * nbk;
     int slices = std::max(1, std::min((2560 + blocks / 2) / blocks, (M + 255) / 256));
     const size_t per = (size_t)Np * Kp + Np;
     slices = (int)std::max<size_t>(1, std::min<size_t>(slices, DW_PART_FLOATS / per));
     int mps = ((M + slices - 1) / slices + 31) / 32 * 32;
     slices = (M + mps - 1) / mps;
     float* bpart = part + (size_t)slices * Np * Kp;
-    if (db) hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, 4, 4, 2, 2, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
-    else hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, 4, 4, 2, 2, false>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+    if (db) hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, TA, TB, 2, 2, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+    else hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, TA, TB, 2, 2, false>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
     reduce_partials(part, slices, (long long)Np * Kp, dW, 0, st);
     if (db) reduce_partials(bpart, slices, (long long)Np, db, 0, st);
     return 0;
 }
 
-// plain row-major operands: wide workgroup tiles (gemm_dw2_kernel) unless dW is a single 48 x 48 tile
+// plain row-major operands (the linear layers): the workgroup tile (128 / 96 / 64 per side) with the least padding, wide tiles preferred;
+// the 48 x 48 kernel where none fits within 15 % (C = 45, 72, 144: multiples of 48) or the matrix is small
 int dw_rows(escx_handle_s* h, const float* A, int lda, const float* Bm, int ldb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
-    // measured (profiles/r2_train_breakdown_*.txt): the wide tiles read less HBM but lose to the single-tile kernel, whose waves never
-    // meet at a barrier and run 2-3 workgroups per CU (dW of the C = 45 MLP: 1.9 ms/step vs 2.5 ms/step); kept selectable for A/B
-    static const bool v1_only = [] { const char* e = getenv("ESCX_DW_V2"); return !(e && e[0] == '1'); }();
-    const int nT = (Np + 47) / 48, kT = (Kp + 47) / 48;
-    if (v1_only || (nT == 1 && kT == 1)) return dw_launch(h, PlainA{A, lda, M}, PlainA{Bm, ldb, M}, M, Np, Kp, dW, db, part, st);
-    const int wn = kT == 1 ? 4 : (nT == 1 ? 1 : 2), wk = 4 / wn;
-    const int nbn = (nT + wn - 1) / wn, nbk = (kT + wk - 1) / wk, blocks = nbn * nbk;
-    int slices = std::max(1, std::min((1536 + blocks - 1) / blocks, (M + 63) / 64));
-    const size_t per = (size_t)Np * Kp + Np;
-    slices = (int)std::min<size_t>(slices, DW_PART_FLOATS / per);
-    if (slices < 1) ESCX_FAIL(ESCX_ERR_STATE, "dW scratch too small for %d x %d", Np, Kp);
-    int mps = ((M + slices - 1) / slices + 31) / 32 * 32;
-    slices = (M + mps - 1) / mps;
-    float* bpart = part + (size_t)slices * Np * Kp;
-    dim3 grid(blocks, slices);
-#define ESCX_DW2(WN, WK) do { if (db) hipLaunchKernelGGL((gemm_dw2_kernel<WN, WK, true>), grid, dim3(256), 0, st, A, lda, Bm, ldb, M, Np, Kp, nbk, mps, part, bpart); \
-                              else hipLaunchKernelGGL((gemm_dw2_kernel<WN, WK, false>), grid, dim3(256), 0, st, A, lda, Bm, ldb, M, Np, Kp, nbk, mps, part, bpart); } while (0)
-    if (wn == 4) ESCX_DW2(4, 1); else if (wn == 1) ESCX_DW2(1, 4); else ESCX_DW2(2, 2);
-#undef ESCX_DW2
-    reduce_partials(part, slices, (long long)Np * Kp, dW, 0, st);
-    if (db) reduce_partials(bpart, slices, (long long)Np, db, 0, st);
-    return 0;
+    static const bool wide_ok = [] { const char* e = getenv("ESCX_DW_WIDE"); return !(e && e[0] == '0'); }();
+    const PlainA la{A, lda, M}, lb{Bm, ldb, M};
+    int bestA = 0, bestB = 0; double best = 1e30;
+    if (wide_ok && Np >= 96 && Kp >= 96 && (long long)Np * Kp >= 96 * 288) {
+        const int cand[3] = {128, 96, 64};
+        for (int wa : cand) for (int wb : cand) {
+            const double padded = (double)((Np + wa - 1) / wa * wa) * ((Kp + wb - 1) / wb * wb);
+            if (padded > 1.15 * Np * Kp) continue;
+            const double cost = padded * (1.0 + 24.0 / wa + 24.0 / wb);          // MFMA work + a charge for operand re-staging
+            if (cost < best) { best = cost; bestA = wa; bestB = wb; }
+        }
+    }
+    switch (bestA * 1000 + bestB) {
+        case 128128: return dw_launch_wide<4, 4>(h, la, lb, M, Np, Kp, dW, db, part, st);
+        case 128096: return dw_launch_wide<4, 3>(h, la, lb, M, Np, Kp, dW, db, part, st);
+        case 128064: return dw_launch_wide<4, 2>(h, la, lb, M, Np, Kp, dW, db, part, st);
+        case 96128: return dw_launch_wide<3, 4>(h, la, lb, M, Np, Kp, dW, db, part, st);
+        case 96096: return dw_launch_wide<3, 3>(h, la, lb, M, Np, Kp, dW, db, part, st);
+        case 96064: return dw_launch_wide<3, 2>(h, la, lb, M, Np, Kp, dW, db, part, st);
+        case 64128: return dw_launch_wide<2, 4>(h, la, lb, M, Np, Kp, dW, db, part, st);
+        case 64096: return dw_launch_wide<2, 3>(h, la, lb, M, Np, Kp, dW, db, part, st);
+        case 64064: return dw_launch_wide<2, 2>(h, la, lb, M, Np, Kp, dW, db, part, st);
+        default: return dw_launch(h, la, lb, M, Np, Kp, dW, db, part, st);
+    }
 }
 
 // LayerNorm backward launcher; dgamma -> dg[SEGS*Cp], dbeta -> dbt[SEGS*Cp]
@@ -651,7 +655,7 @@ extern "C" int escx_train_backward(escx_handle h, const float* d_wave, const flo
         ConvA ctok{T.post, s.H0, s.W, h->C0p, 5, 5, Mt};
         float* Rb = R + (size_t)DEP_LD * K1;
         PROF("B.dw_conv5", 2.0 * Mt * 25 * h->C0 * Q * c.in_dim * 9, 0,
-             rc = dw_launch_wide(h, PlainA{P, DEP_LD, Mt}, ctok, Mt, DEP_LD, K1, R, Rb, part, st));
+             rc = (dw_launch_wide<4, 4>(h, PlainA{P, DEP_LD, Mt}, ctok, Mt, DEP_LD, K1, R, Rb, part, st)));
         if (rc) return rc;
         hipLaunchKernelGGL(deembed_fold_dw_kernel, dim3(blocks_for((long long)Q * h->C0p * K1)), dim3(256), 0, st, R, h->dc2_w, G(h, h->dc1_w), Q, h->C0, h->C0p, K1, c.in_dim);
         hipLaunchKernelGGL(deembed_fold_dw_kernel, dim3(blocks_for((long long)Q * h->C0p)), dim3(256), 0, st, Rb, h->dc2_w, G(h, h->dc1_b), Q, h->C0, h->C0p, 1, c.in_dim);

@@ -284,99 +284,6 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(LdA la, LdB lb, int M, int
     }
 }
 
-// The same contraction for plain row-major operands with a WIDE workgroup tile: the WN x WK waves of a workgroup own adjacent 48 x 48
-// tiles of dW and share every staged 32-row chunk through a double-buffered LDS image, so a chunk of A (48*WN columns) and of B (48*WK
-// columns) is read from HBM once per workgroup instead of once per 48 x 48 tile: at C <= 96 the dW GEMMs are bound by that traffic
-// (N = 48, K = 192: 240 floats per row instead of 384).  One barrier per chunk; the next chunk's global loads are in flight during the MFMAs.
-template <int WN, int WK, bool BIAS>
-__global__ __launch_bounds__(256) void gemm_dw2_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb, int M, int Np, int Kp,
-                                                       int nblk_k, int m_per_slice, float* __restrict__ part, float* __restrict__ bpart) {
-    static_assert(WN * WK == 4, "four waves");
-    constexpr int TNW = 48 * WN, TKW = 48 * WK;
-    constexpr int LDA = (TNW % 32 == 16) ? TNW : TNW + 16, LDB = (TKW % 32 == 16) ? TKW : TKW + 16;
-    constexpr int VA = TNW / 4, VB = TKW / 4;                    // float4 per staged row
-    constexpr int NA = (DW_MC * VA + 255) / 256, NB = (DW_MC * VB + 255) / 256;
-    __shared__ float lds[2 * DW_MC * (LDA + LDB)];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, lg = lane >> 4;
-    const int wn = wave / WK, wk = wave - wn * WK;
-    const int bn = blockIdx.x / nblk_k, bk = blockIdx.x - bn * nblk_k;
-    const int n0 = bn * TNW, k0 = bk * TKW;
-    const int mbeg = blockIdx.y * m_per_slice, mend = min(M, mbeg + m_per_slice);
-    const bool do_bias = BIAS && bk == 0 && wk == 0;
-    f32x4 acc[DW_T][DW_T], accb[DW_T];
-#pragma unroll
-    for (int a = 0; a < DW_T; ++a) { accb[a] = zero4();
-#pragma unroll
-        for (int b = 0; b < DW_T; ++b) acc[a][b] = zero4(); }
-    f32x4 ra[NA], rb[NB];
-    auto fetch = [&](int m0) {
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int e = tid + 256 * j; const int row = e / VA, c4 = e - row * VA;
-            const int m = m0 + row, col = n0 + 4 * c4;
-            ra[j] = (e < DW_MC * VA && m < mend && col < Np) ? ld4(A + (size_t)m * lda + col) : zero4();
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int e = tid + 256 * j; const int row = e / VB, c4 = e - row * VB;
-            const int m = m0 + row, col = k0 + 4 * c4;
-            rb[j] = (e < DW_MC * VB && m < mend && col < Kp) ? ld4(Bm + (size_t)m * ldb + col) : zero4();
-        }
-    };
-    if (mbeg < mend) fetch(mbeg);
-    int buf = 0;
-    for (int m0 = mbeg; m0 < mend; m0 += DW_MC) {
-        float* As = lds + buf * DW_MC * (LDA + LDB);
-        float* Bs = As + DW_MC * LDA;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int e = tid + 256 * j; const int row = e / VA, c4 = e - row * VA;
-            if (e < DW_MC * VA) st4(As + row * LDA + 4 * c4, ra[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int e = tid + 256 * j; const int row = e / VB, c4 = e - row * VB;
-            if (e < DW_MC * VB) st4(Bs + row * LDB + 4 * c4, rb[j]);
-        }
-        __syncthreads();
-        if (m0 + DW_MC < mend) fetch(m0 + DW_MC);
-        const float* Aw = As + wn * 48; const float* Bw = Bs + wk * 48;
-#pragma unroll
-        for (int ms = 0; ms < DW_MC / 4; ++ms) {
-            float af[DW_T], bf[DW_T];
-#pragma unroll
-            for (int a = 0; a < DW_T; ++a) af[a] = Aw[(4 * ms + lg) * LDA + 16 * a + l15];
-#pragma unroll
-            for (int b = 0; b < DW_T; ++b) bf[b] = Bw[(4 * ms + lg) * LDB + 16 * b + l15];
-#pragma unroll
-            for (int a = 0; a < DW_T; ++a)
-#pragma unroll
-                for (int b = 0; b < DW_T; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[b], acc[a][b], 0, 0, 0);
-            if (do_bias) {
-                const float one = (l15 == 0) ? 1.0f : 0.0f;
-#pragma unroll
-                for (int a = 0; a < DW_T; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], one, accb[a], 0, 0, 0);
-            }
-        }
-        buf ^= 1;
-    }
-    float* po = part + (size_t)blockIdx.y * Np * Kp;
-#pragma unroll
-    for (int a = 0; a < DW_T; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + wn * 48 + 16 * a + 4 * lg + r;
-            if (n >= Np) continue;
-#pragma unroll
-            for (int b = 0; b < DW_T; ++b) {
-                const int k = k0 + wk * 48 + 16 * b + l15;
-                if (k < Kp) po[(size_t)n * Kp + k] = acc[a][b][r];
-            }
-            if (do_bias && l15 == 0) bpart[(size_t)blockIdx.y * Np + n] = accb[a][r];
-        }
-}
-
 // The contraction through arbitrary row loaders with a WIDE workgroup tile: WN x WK waves, each owning TA x TB accumulator tiles, share every
 // staged 32-row chunk through a double-buffered LDS image (one barrier per chunk, next chunk's loads in flight during the MFMAs).
 //   <4,4,2,2>  128 x 128 tile for large weight matrices (N, K >= 256: the 512 / 1024-channel convolutions of the discriminator): 256 floats
