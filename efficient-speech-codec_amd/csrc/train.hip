@@ -584,7 +584,7 @@ int quant_bwd(escx_handle_s* h, TrainTape& T, int sid, const float* gref, float*
     const float scale = 1.0f / ((float)Tq * q.d * Gr);
     hipLaunchKernelGGL(pvq_train_bwd_kernel, dim3(blocks_for((long long)M * Gr)), dim3(256), 0, st, Q.ze, codes, bstride, q.cbraw, dzup, dcm, dcb, dze, gq,
                        M, Gr, c.codebook_size, q.d, q.dt, q.Nz, Tq, scale, T.freeze);
-    hipLaunchKernelGGL(codebook_grad_kernel, dim3(blocks_for((long long)Gr * c.codebook_size * 64)), dim3(256), 0, st, codes, bstride, gq, G(h, q.cbraw), M,
+    hipLaunchKernelGGL(codebook_grad_kernel, dim3(Gr * ((c.codebook_size + CBG_CODES - 1) / CBG_CODES)), dim3(256), 0, st, codes, bstride, gq, G(h, q.cbraw), M,
                        Gr, c.codebook_size, q.dt, q.Nz, Tq);
     // down-projection: ze = residual_frames . Wd^T   (Wd packed [Nz][Kq])
     ResidualGatherA rfr{Q.enc, Q.dec, q.Hq, W, q.Cp, Tq, c.overlap, M, FastDiv(Tq), FastDiv(q.Cp), FastDiv(q.Hq)};

@@ -189,8 +189,13 @@ def main():
             print(json.dumps({"step": n + 1, "s_per_step": round((time.perf_counter() - t0) / (n + 1), 4), **vals}))
     if rank == 0 and args.save_path:
         os.makedirs(args.save_path, exist_ok=True)
-        torch.save({"step": args.steps - 1, "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
-                    "optimizer_state_dict": st.opt.state_dict()}, os.path.join(args.save_path, "checkpoint.pth"))
+        ck = {"step": args.steps - 1, "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()}}
+        if args.adv:                                                    # trainer_adv.py keeps the discriminator and both optimisers in the checkpoint
+            ck.update(disc_state_dict={k: v.detach().cpu() for k, v in disc.state_dict().items()},
+                      optimizer_state_dict=st.opt_g.state_dict(), disc_optimizer_state_dict=st.opt_d.state_dict())
+        else:
+            ck["optimizer_state_dict"] = st.opt.state_dict()
+        torch.save(ck, os.path.join(args.save_path, "checkpoint.pth"))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
 
