@@ -157,7 +157,7 @@ def train_cpu_baseline(cfg, sd, x_cpu):
 
 
 def train_adv_cpu_baseline(cfg, sd, disc_sd, x_cpu, weights):
-    """One adversarial step of the oracle as the reference runs it (trainer_adv.py:60-105: generator forward, four discriminator passes, two
+    """One adversarial step of the oracle as the reference runs it (trainer_adv.py:61-107: generator forward, four discriminator passes, two
     backward passes; no optimiser steps) on the host cores: bounded sample of 1 clip."""
     from oracle import esc_oracle as O
     avail = os.cpu_count() or 1
@@ -274,7 +274,7 @@ def run_train(args, rank, world, device, use_dist):
 
 
 def run_train_adv(args, rank, world, device, use_dist):
-    """--mode train_adv = BASELINE configs[4]: ESC-Large 9 kbps + the adversarial training step of scripts/trainer_adv.py:60-105 (generator update
+    """--mode train_adv = BASELINE configs[4]: ESC-Large 9 kbps + the adversarial training step of scripts/trainer_adv.py:61-107 (generator update
     with LS-GAN + feature-matching terms through the DAC discriminator, then the discriminator update), batch 36, one MI355X.  fp32: the reference
     has no reduced-precision path (plain Accelerator()), so a bf16 number would be narrower than the reference's arithmetic."""
     from esc import synth
@@ -320,7 +320,7 @@ def run_train_adv(args, rank, world, device, use_dist):
            "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
-           "config": {"workload": f"BASELINE configs[4]: ESC-Large 9kbps + adversarial training step (scripts/trainer_adv.py:60-105), batch={bsz} clips of "
+           "config": {"workload": f"BASELINE configs[4]: ESC-Large 9kbps + adversarial training step (scripts/trainer_adv.py:61-107), batch={bsz} clips of "
                                   f"{TRAIN_SAMPLES} samples per GPU, num_streams=6, fp32 (the reference has no bf16 / AMP path)",
                       "global_batch": bsz * world, "clip_samples": TRAIN_SAMPLES, "num_streams": NUM_STREAMS, "parallelism": f"dp{world}",
                       "generator_params_M": round(n_gen / 1e6, 2), "discriminator_params_M": round(n_disc / 1e6, 2),

@@ -1,6 +1,6 @@
 // DAC discriminator + GAN losses of the adversarial training step on MI355X (BASELINE configs[4]).
 // Reference: esc/models/discriminator.py:31-221 (MPD, MRD, Discriminator; MSD is unused by every ESC config: rates = []),
-// esc/modules/loss/gan_loss.py:5-50, scripts/trainer_adv.py:60-105.  fp32 like the reference.
+// esc/modules/loss/gan_loss.py:5-51, scripts/trainer_adv.py:61-107.  fp32 like the reference.
 //
 // One handle = one Discriminator.  Parameters live in a flat fp32 device buffer owned by the caller (reference state_dict order of the
 // trainable entries: per convolution bias, weight_g, weight_v); the weight-normalised, packed GEMM operands are rebuilt from it at the start of
@@ -368,7 +368,7 @@ void build_front(escx_disc_s* d, const float* wave, int B, int L, float* base, s
 }
 }  // namespace
 
-// Discriminator.forward (discriminator.py:212-215).  fmaps: host array of escx_disc_num_fmaps() device pointers, each the BASE address of map i
+// Discriminator.forward (discriminator.py:218-221).  fmaps: host array of escx_disc_num_fmaps() device pointers, each the BASE address of map i
 // (i.e. already offset to its column slice when it lives in a concatenated buffer), laid out [B][D0][P1][Cp].
 extern "C" int escx_disc_forward(escx_disc d, const float* flat_params, int64_t params_version, const float* wave, int B, int L, float* const* fmaps, void* stream) {
     if (!d || !flat_params || !wave || !fmaps || B < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
@@ -550,7 +550,7 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
     return launch_ok("disc_backward");
 }
 
-// One GAN loss term over a feature map (gan_loss.py:29-50): loss_dev[b] (+)= mean over the map's real elements; grad (optional, same layout as x).
+// One GAN loss term over a feature map (gan_loss.py:30-51): loss_dev[b] (+)= mean over the map's real elements; grad (optional, same layout as x).
 //   mode 0: (target - x)^2 ; mode 1: |x - ref|
 extern "C" int escx_gan_term(const float* x, const float* ref, float* grad, int B, int C, int Cp, int D0, int D1, int P1, int mode, float target, float* loss_dev,
                              int accumulate, void* stream) {

@@ -1,6 +1,6 @@
 // Device code of the adversarial step (BASELINE configs[4]): the DAC discriminator of the reference
 // (esc/models/discriminator.py:31-221: multi-period + multi-resolution-spectrogram discriminators, weight-normalised convolutions with
-// LeakyReLU(0.1)) and the least-squares GAN / feature-matching losses (esc/modules/loss/gan_loss.py:5-50).
+// LeakyReLU(0.1)) and the least-squares GAN / feature-matching losses (esc/modules/loss/gan_loss.py:5-51).
 //
 // Every convolution is an implicit GEMM on the fp32 MFMA engine of gemm_engine.h over channels-last activations:
 //   tensor view  T(b, i0, i1, c) = p[((b * D0 + i0) * P1 + i1) * Cp + c]      (P1 >= D1: row pitch, so that the five band stacks of an MRD
@@ -107,7 +107,7 @@ struct ViewRowsA {              // rows m = (b, i0, i1) of a view as a plain mat
     __device__ __forceinline__ f32x4 load4(Ctx c, int k0, int kin) const { return (c && k0 + kin < v.Cp) ? ld4(c + k0 + kin) : zero4(); }
 };
 
-struct EpiConvOut {             // out(b, o0, o1, n..n+3) = act(v + bias[n]) ; act = LeakyReLU(0.1) (discriminator.py:19, 28)
+struct EpiConvOut {             // out(b, o0, o1, n..n+3) = act(v + bias[n]) ; act = LeakyReLU(0.1) (discriminator.py:28, 28)
     TView o; const float* bias; int act; FastDiv dR, dD1;
     __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
         if (n >= o.Cp) return;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ d
 }
 
 // ------------------------------------------------------------------------------------------------
-// Discriminator.preprocess (discriminator.py:205-210): y = 0.8 (x - mean) / (max|x - mean| + 1e-9), one workgroup per clip.
+// Discriminator.preprocess (discriminator.py:211-216): y = 0.8 (x - mean) / (max|x - mean| + 1e-9), one workgroup per clip.
 // stats[b] = {mean, max|z|, argmax, sign(z_argmax)} for the backward.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void disc_preprocess_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ stats, int L) {
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(1024) void disc_preprocess_bwd_kernel(const float* 
 // ------------------------------------------------------------------------------------------------
 // input builders
 // ------------------------------------------------------------------------------------------------
-// MPD (discriminator.py:48-59): right reflect-pad to a multiple of the period (a whole period when it already is one), view (L/p, p); Cp = 4
+// MPD (discriminator.py:48-57): right reflect-pad to a multiple of the period (a whole period when it already is one), view (L/p, p); Cp = 4
 __global__ void mpd_input_kernel(const float* __restrict__ y, float* __restrict__ out, int B, int L, int D0, int p) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)B * D0 * p) return;
@@ -299,7 +299,7 @@ __global__ void view_copy_kernel(TView dst, TView src, long long n4) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// GAN losses on feature-map views (gan_loss.py:29-50).  per clip: mean over the C real channels x D0 x D1.
+// GAN losses on feature-map views (gan_loss.py:30-51).  per clip: mean over the C real channels x D0 x D1.
 //   mode 0: (target - x)^2          d/dx = -2 (target - x) / n         (least-squares GAN terms)
 //   mode 1: |x - ref|               d/dx = sign(x - ref) / n           (feature matching; ref is detached)
 // part[b][block]; gradient written to a view shaped like x (pad channels zero).

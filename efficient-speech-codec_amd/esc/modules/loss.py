@@ -133,7 +133,7 @@ class _GanTermFn(torch.autograd.Function):
 
 
 class GANLoss(nn.Module):
-    """Least-squares GAN + feature-matching losses of the adversarial trainer (`/root/reference/esc/modules/loss/gan_loss.py:5-50`)."""
+    """Least-squares GAN + feature-matching losses of the adversarial trainer (`/root/reference/esc/modules/loss/gan_loss.py:5-51`)."""
 
     def __init__(self, discriminator):
         super().__init__()
@@ -179,7 +179,7 @@ class GANLoss(nn.Module):
         return d_fake, d_real
 
     def generator_loss_from(self, d_fake, d_real):
-        """gan_loss.py:38-50 on feature maps that are already there."""
+        """gan_loss.py:39-51 on feature maps that are already there."""
         loss_g, loss_f = 0, 0
         for xf, xr in zip(d_fake, d_real):
             bf, *mf = xf.entries[-1]
@@ -190,7 +190,7 @@ class GANLoss(nn.Module):
 
     @torch.no_grad()
     def discriminator_backward_from(self, d_fake, d_real):
-        """gan_loss.py:29-36 + `disc_loss.mean().backward()` (trainer_adv.py:95-103) on the feature maps of adversarial_forward: returns the
+        """gan_loss.py:30-37 + `disc_loss.mean().backward()` (trainer_adv.py:96-105) on the feature maps of adversarial_forward: returns the
         per-clip discriminator loss and ADDS d mean(loss) / d parameter to the discriminator's gradients."""
         lib = _native.load()
         loss = None

@@ -82,7 +82,7 @@ class Stepper:
 
 
 class AdvStepper:
-    """The adversarial step of `/root/reference/scripts/trainer_adv.py:60-105`: generator update (VQ + mel [+ STFT] + LS-GAN + feature matching,
+    """The adversarial step of `/root/reference/scripts/trainer_adv.py:61-107`: generator update (VQ + mel [+ STFT] + LS-GAN + feature matching,
     clip 1e3) followed by the discriminator update on the detached reconstruction (clip 10); during the frozen-codebook pre-training
     phase the discriminator is not involved."""
 
@@ -110,7 +110,7 @@ class AdvStepper:
         total.mean().backward()
         self.opt_g.step(); self.opt_g.zero_grad()
         log = {"streams": s, "frozen": freeze, **{k: v.detach().mean() for k, v in terms.items()}, "loss": total.detach().mean()}
-        if not freeze:                                              # discriminator update on the (detached) reconstruction, trainer_adv.py:93-103
+        if not freeze:                                              # discriminator update on the (detached) reconstruction, trainer_adv.py:96-105
             d_loss = self.gan.discriminator_backward_from(d_fake, d_real)
             self.opt_d.step(); self.opt_d.zero_grad()
             log["disc_loss"] = d_loss.mean()

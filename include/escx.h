@@ -196,9 +196,9 @@ int escx_grad_norm_clip(const float* grad_flat_dev, int64_t n, float max_norm, f
 int escx_adamw_step(float* param_flat_dev, const float* grad_flat_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, int step,
                     float lr, float beta1, float beta2, float eps, float weight_decay, const float* clip_dev, void* stream);
 
-/* ---- adversarial step: DAC discriminator + GAN losses (BASELINE configs[4]; scripts/trainer_adv.py:60-105) ---------------------------------
+/* ---- adversarial step: DAC discriminator + GAN losses (BASELINE configs[4]; scripts/trainer_adv.py:61-107) ---------------------------------
  * Reference: esc/models/discriminator.py:31-221 (MPD :31-66, MRD :105-176, Discriminator :179-215; MSD is not used by any ESC config),
- * esc/modules/loss/gan_loss.py:5-50.  Parameters: one flat fp32 device buffer in the order escx_disc_param_*() reports (the reference's
+ * esc/modules/loss/gan_loss.py:5-51.  Parameters: one flat fp32 device buffer in the order escx_disc_param_*() reports (the reference's
  * named_parameters(): per convolution bias, weight_g, weight_v).  Feature maps are caller-owned channels-last buffers [B][D0][P1][Cp]
  * (escx_disc_fmap_shape); the reference's (B, C, D0, D1) tensor of map i is buffer[:, :, off1 : off1 + D1, :C] permuted (0, 3, 1, 2). */
 typedef struct {
@@ -227,7 +227,7 @@ int escx_disc_forward(escx_disc d, const float* flat_params_dev, int64_t params_
  * and / or d_wave_dev (optional, (B, L), overwritten). */
 int escx_disc_backward(escx_disc d, const float* flat_params_dev, int64_t params_version, const float* wave_dev, int batch, int n_samples,
                        float* const* fmaps_dev, const float* const* d_fmaps_dev, float* grad_flat_dev, float* d_wave_dev, void* stream);
-/* One GAN loss term over a feature-map buffer (gan_loss.py:29-50): loss_dev[b] (+)= mean over the C x D0 x D1 real elements of
+/* One GAN loss term over a feature-map buffer (gan_loss.py:30-51): loss_dev[b] (+)= mean over the C x D0 x D1 real elements of
  * (target - x)^2 (mode 0) or |x - ref| (mode 1); grad_dev (optional, layout of x) receives d term_b / d x. */
 int escx_gan_term(const float* x_dev, const float* ref_dev, float* grad_dev, int batch, int C, int Cp, int D0, int D1, int P1, int mode, float target,
                   float* loss_dev, int accumulate, void* stream);

@@ -543,7 +543,7 @@ def training_loss(out: dict, w: dict = LOSS_WEIGHTS) -> dict:
 
 
 # ----------------------------------------------------------------------------------------------
-# Adversarial training: DAC discriminator (esc/models/discriminator.py:31-221) and GAN losses (esc/modules/loss/gan_loss.py:5-50)
+# Adversarial training: DAC discriminator (esc/models/discriminator.py:31-221) and GAN losses (esc/modules/loss/gan_loss.py:5-51)
 # ----------------------------------------------------------------------------------------------
 DISC_BANDS = [(0.0, 0.1), (0.1, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0)]
 DISC_DEFAULT = dict(sample_rate=16000, rates=[], periods=[2, 3, 5, 7, 11], fft_sizes=[2048, 1024, 512], bands=DISC_BANDS)
@@ -562,7 +562,7 @@ def wn_conv2d(x: Tensor, sd, pfx: str, stride, padding, act: bool = True) -> Ten
 
 
 def disc_preprocess(y: Tensor) -> Tensor:
-    """discriminator.py:205-210: remove the DC offset, peak-normalise to 0.8."""
+    """discriminator.py:211-216: remove the DC offset, peak-normalise to 0.8."""
     y = y - y.mean(dim=-1, keepdim=True)
     return 0.8 * y / (y.abs().max(dim=-1, keepdim=True)[0] + 1e-9)
 
@@ -581,7 +581,7 @@ def mpd_forward(x: Tensor, sd, pfx: str, period: int) -> List[Tensor]:
 
 
 def matched_stride_stft(x: Tensor, window_length: int) -> Tensor:
-    """audiotools AudioSignal.stft with STFTParams(window_length, hop = window_length // 4, match_stride=True) (discriminator.py:128-132),
+    """audiotools AudioSignal.stft with STFTParams(window_length, hop = window_length // 4, match_stride=True) (discriminator.py:129-133),
     restated from the audiotools source (not installed here: UNPINNED at this boundary): reflect-pad by ((wl - hop) / 2, (wl - hop) / 2 +
     right_pad), right_pad = ceil(L / hop) * hop - L, torch.stft(center=True, hann), drop the first and last two frames.  (B,1,L) -> (B,2,T,F)."""
     hop = window_length // 4
@@ -610,7 +610,7 @@ def mrd_forward(x: Tensor, sd, pfx: str, window_length: int, bands=DISC_BANDS) -
 
 
 def discriminator_forward(x: Tensor, sd, cfg: dict = DISC_DEFAULT) -> List[List[Tensor]]:
-    """Discriminator.forward (discriminator.py:212-215): x (B,1,L) -> one list of feature maps per sub-discriminator."""
+    """Discriminator.forward (discriminator.py:218-221): x (B,1,L) -> one list of feature maps per sub-discriminator."""
     assert not cfg.get("rates"), "MSD (rates) is not used by the ESC configurations"
     x = disc_preprocess(x)
     out = [mpd_forward(x, sd, f"discriminators.{i}.", p) for i, p in enumerate(cfg["periods"])]
@@ -620,7 +620,7 @@ def discriminator_forward(x: Tensor, sd, cfg: dict = DISC_DEFAULT) -> List[List[
 
 
 def gan_discriminator_loss(fake: Tensor, real: Tensor, sd, cfg: dict = DISC_DEFAULT) -> Tensor:
-    """GANLoss.discriminator_loss (gan_loss.py:29-36): least-squares GAN, per clip."""
+    """GANLoss.discriminator_loss (gan_loss.py:30-37): least-squares GAN, per clip."""
     d_fake, d_real = discriminator_forward(fake.detach().unsqueeze(1), sd, cfg), discriminator_forward(real.unsqueeze(1), sd, cfg)
     loss = 0
     for xf, xr in zip(d_fake, d_real):
@@ -629,7 +629,7 @@ def gan_discriminator_loss(fake: Tensor, real: Tensor, sd, cfg: dict = DISC_DEFA
 
 
 def gan_generator_loss(fake: Tensor, real: Tensor, sd, cfg: dict = DISC_DEFAULT):
-    """GANLoss.generator_loss (gan_loss.py:38-50): adversarial term + L1 feature matching, per clip."""
+    """GANLoss.generator_loss (gan_loss.py:39-51): adversarial term + L1 feature matching, per clip."""
     d_fake, d_real = discriminator_forward(fake.unsqueeze(1), sd, cfg), discriminator_forward(real.unsqueeze(1), sd, cfg)
     loss_g = 0
     for xf in d_fake:

@@ -1,4 +1,4 @@
-"""Adversarial step (trainer_adv.py:60-105): the DAC discriminator and the GAN losses.
+"""Adversarial step (trainer_adv.py:61-107): the DAC discriminator and the GAN losses.
 
 Fixtures: tests/golden/disc.npz = the REAL reference Discriminator + GANLoss on name-keyed synthetic weights (oracle/gen_disc_golden.py;
 audiotools' matched-stride STFT is shimmed: unpinned at that boundary).  CPU: the oracle restatement is pinned to them.  GPU: the HIP
@@ -106,7 +106,7 @@ def test_discriminator_feature_maps_against_the_oracle():
 @pytest.mark.gpu
 def test_gan_losses_and_gradients():
     """Discriminator step (gradients of every discriminator parameter) and generator step (gradient of the fake waveform) of
-    trainer_adv.py:75-105 against the reference fixtures and the oracle's autograd."""
+    trainer_adv.py:75-107 against the reference fixtures and the oracle's autograd."""
     from oracle import esc_oracle as O
     from esc.modules import GANLoss
     g = load_golden("disc")
@@ -155,7 +155,7 @@ def test_gan_losses_and_gradients():
 
 @pytest.mark.gpu
 def test_adversarial_training_loop():
-    """scripts/train.py AdvStepper (trainer_adv.py:60-105) on the tiny generator + the full discriminator: frozen pre-training steps leave the
+    """scripts/train.py AdvStepper (trainer_adv.py:61-107) on the tiny generator + the full discriminator: frozen pre-training steps leave the
     discriminator untouched, afterwards both networks are updated, every logged loss stays finite, and the discriminator loss goes down on a
     fixed batch."""
     import sys
