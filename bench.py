@@ -191,8 +191,8 @@ def train_adv_cpu_baseline(cfg, sd, disc_sd, x_cpu, weights):
 
 def run_train(args, rank, world, device, use_dist):
     """--mode train: the step of scripts/trainer_no_adv.py:95-118 (training forward, mel + complex-STFT + VQ losses, backward, clip 0.5,
-    AdamW) on 36 clips per GPU, ESC-Base, fp32 like the reference (it has no AMP path).  Single-GPU measurement; with N > 1 every rank
-    runs its own replica of the step (no gradient exchange is implemented yet: reported as such)."""
+    AdamW) on 36 clips per GPU, ESC-Base, fp32 like the reference (it has no AMP path).  With N > 1 the step is data-parallel: FlatAdamW
+    averages the flat gradient buffer over the ranks (bucketed RCCL all-reduce, esc/distributed.py) before clipping, as DDP does for the reference."""
     from esc.modules import ComplexSTFTLoss, MelSpectrogramLoss
     from esc.optim import FlatAdamW
     model, cfg, sd = build_model(device)
