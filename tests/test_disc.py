@@ -210,3 +210,64 @@ def test_single_pass_adversarial_losses_equal_the_two_pass_reference_form():
     np.testing.assert_allclose(ld2.cpu().numpy(), ld.detach().cpu().numpy(), rtol=1e-6)      # the same terms, added in another order
     for k, p in disc.named_parameters():
         assert _rel(p.grad.cpu().numpy(), ref_grads[k].cpu().numpy()) < 1e-6, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,B,L", [
+    (dict(periods=[2, 3], fft_sizes=[512], bands=[(0.0, 0.25), (0.25, 1.0)]), 1, 4099),        # one clip, prime length, two bands
+    (dict(periods=[7], fft_sizes=[1024, 256], bands=[(0.0, 0.1), (0.1, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0)]), 3, 6001),
+    (dict(periods=[11, 5], fft_sizes=[], bands=[(0.0, 1.0)]), 2, 2500),                       # period discriminators only
+])
+def test_other_discriminator_configurations_and_lengths(cfg, B, L):
+    """Configurations, batch sizes and clip lengths the fixture does not hold (lengths that are no multiple of a period or a hop, one clip,
+    other band splits): feature maps, both losses, every parameter gradient and the waveform gradient against the oracle (fp64)."""
+    from oracle import esc_oracle as O
+    from esc.models import Discriminator
+    from esc.modules import GANLoss
+    torch.manual_seed(3)
+    disc = Discriminator(sample_rate=16000, **cfg).cuda()
+    ocfg = dict(O.DISC_DEFAULT, **cfg)
+    sd = {k: v.detach().cpu() for k, v in disc.state_dict().items()}
+    real = torch.from_numpy(synth.pcm_to_float(np.stack([synth.voiced_clip_int16(f"dcfg-real-{i}", L) for i in range(B)])))
+    fake = 0.7 * real + torch.from_numpy(synth.pcm_to_float(np.stack([synth.noise_clip_int16(f"dcfg-fake-{i}", L, amp=0.03) for i in range(B)])))
+    with torch.no_grad():
+        fm = disc(fake.cuda().unsqueeze(1))
+    ref = O.discriminator_forward(fake.unsqueeze(1), sd, ocfg)
+    assert [[tuple(t.shape) for t in f] for f in fm] == [[tuple(t.shape) for t in f] for f in ref]
+    worst = max(_rel(x.cpu().numpy(), y.numpy()) for a, b in zip(fm, ref) for x, y in zip(a, b))
+    assert worst < 2e-5, worst
+    gan = GANLoss(disc)
+    # discriminator update
+    ld = gan.discriminator_loss(fake.cuda(), real.cuda())
+    ld.mean().backward()
+    osd = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
+    old = O.gan_discriminator_loss(fake.double(), real.double(), osd, ocfg)
+    old.mean().backward()
+    np.testing.assert_allclose(ld.detach().cpu().numpy(), old.detach().numpy(), rtol=2e-5)
+    o32 = {k: v.clone().requires_grad_(True) for k, v in sd.items()}                  # the fp32 evaluation's own distance from fp64 = the floor
+    O.gan_discriminator_loss(fake, real, o32, ocfg).mean().backward()
+    scale = float(np.sqrt(sum(float((v.grad ** 2).sum()) for v in osd.values())))
+    errs = {}
+    for k, p in disc.named_parameters():
+        r = osd[k].grad.numpy()
+        den = max(np.sqrt((r ** 2).mean()), 1e-6 * scale / np.sqrt(r.size))
+        errs[k] = float(np.sqrt(((p.grad.cpu().numpy().astype(np.float64) - r) ** 2).mean()) / den)
+        floor = float(np.sqrt(((o32[k].grad.double().numpy() - r) ** 2).mean()) / den)
+        assert errs[k] < max(5e-4, 3.0 * floor), f"gradient of {k} rel rms {errs[k]:.3e} vs the fp64 oracle (fp32 oracle: {floor:.3e})"
+    assert float(np.median(list(errs.values()))) < 2e-5
+    # generator update: losses and d loss / d fake
+    disc.zero_grad()
+    fk = fake.cuda().clone().requires_grad_(True)
+    lg, lf = gan.generator_loss(fk, real.cuda())
+    (lg + 2.0 * lf).mean().backward()
+    of = fake.double().clone().requires_grad_(True)
+    olg, olf = O.gan_generator_loss(of, real.double(), {k: v.detach() for k, v in osd.items()}, ocfg)
+    (olg + 2.0 * olf).mean().backward()
+    np.testing.assert_allclose(lg.detach().cpu().numpy(), olg.detach().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(lf.detach().cpu().numpy(), olf.detach().numpy(), rtol=2e-5)
+    of32 = fake.clone().requires_grad_(True)
+    a32, b32 = O.gan_generator_loss(of32, real, sd, ocfg)
+    (a32 + 2.0 * b32).mean().backward()
+    assert _rel(fk.grad.cpu().numpy(), of.grad.numpy()) < max(1e-4, 3.0 * _rel(of32.grad.numpy(), of.grad.numpy()))
+    print(f"[disc cfg {cfg['periods']}/{cfg['fft_sizes']} B={B} L={L}] fmaps {worst:.2e}, gradients median {np.median(list(errs.values())):.2e} "
+          f"max {max(errs.values()):.2e}, d_fake {_rel(fk.grad.cpu().numpy(), of.grad.numpy()):.2e}")
