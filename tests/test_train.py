@@ -200,6 +200,27 @@ def test_backward_pass_every_gradient_well_conditioned(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,B,L,S,freeze", [("tiny", 3, 1180, 3, False), ("tiny", 1, 1180, 2, True), ("base", 1, 3440, 6, False), ("base", 3, 5040, 4, False)])
+def test_backward_pass_padded_windows_and_other_batches(name, B, L, S, freeze):
+    """Clip lengths whose token maps are NOT a multiple of the 4 x 4 window (W % 4 == 2: the Swin blocks pad after the norm, padded
+    slots take part as keys and carry no gradient back), one-clip and three-clip batches: same well-conditioned probe, every gradient."""
+    pcm = np.stack([(synth.voiced_clip_int16 if i % 2 else synth.noise_clip_int16)(f"train-pad-{name}-{i}", L) for i in range(B)])
+    x = torch.from_numpy(synth.pcm_to_float(pcm))
+    probe = _smooth_probe(name, x)
+    model, out, losses, grads = _product_step(name, S, freeze, x, None, smooth=probe)
+    oout, ols, ograds = _oracle_step(name, S, freeze, x, smooth=probe)
+    assert torch.equal(out["codes"].cpu(), oout["codes"])
+    np.testing.assert_allclose(losses["loss"], ols["loss"].detach().numpy(), rtol=LOSS_RTOL)
+    scale = float(np.sqrt(sum(float((v.double() ** 2).sum()) for v in ograds.values())))
+    worst = (0.0, "")
+    for k, ref in ograds.items():
+        err = _rel_rms(grads[k], ref.numpy(), 1e-6 * scale / np.sqrt(ref.numel()))
+        worst = max(worst, (err, k))
+        assert err <= GRAD_TOL, f"{name} B={B} L={L}: gradient of {k} rel rms {err:.3e}"
+    print(f"[smooth {name} B={B} L={L} S={S} freeze={int(freeze)}] worst gradient rel rms {worst[0]:.2e} ({worst[1]})")
+
+
+@pytest.mark.gpu
 def test_backward_pass_esc_large():
     """ESC-Large (swin_depth 4, BASELINE configs[4]'s model): the same well-conditioned probe, one case, every parameter gradient."""
     g = load_golden("train")
