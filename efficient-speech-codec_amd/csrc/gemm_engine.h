@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <type_traits>
 
 namespace escx {
 
@@ -25,6 +26,12 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 
 // ------------------------------------------------------------------------------------------------
+// An epilogue with `static constexpr bool ROWWISE = true` gets the accumulators of its wave instead of per-fragment store() calls:
+//   template <int TN, int TM> void finish(f32x4 (&acc)[TN][TM], int wave_row0, int lane, int M) const
+// lane (l15, lg) holds D[row = wave_row0 + 16*b + l15][col = 16*a + 4*lg + r] in acc[a][b][r].  The launch must use one workgroup column.
+template <class E, class = void> struct epi_is_rowwise : std::false_type {};
+template <class E> struct epi_is_rowwise<E, std::enable_if_t<E::ROWWISE>> : std::true_type {};
+
 template <int BM, int BN, int BK, class Loader, class Epi>
 __global__ __launch_bounds__(256) void gemm_kernel(Loader ld, const float* __restrict__ Wt, int M, int Np,
                                                    int Kp, int k_per_z, Epi ep) {
@@ -112,6 +119,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(Loader ld, const float* __res
         __syncthreads();
     }
 
+    // row epilogues (Epi::ROWWISE): the workgroup tile spans the whole output row (Np <= BN), so the epilogue can reduce over it in registers
+    if constexpr (epi_is_rowwise<Epi>::value) {
+        ep.template finish<TN, TM>(acc, m0 + wave * (BM / 4), lane, M);
+        return;
+    }
     // lane holds D[n = 4*lg + r][m = l15] of every 16x16 tile: 4 consecutive output features of one row
 #pragma unroll
     for (int b = 0; b < TM; ++b) {

@@ -78,7 +78,8 @@ constexpr size_t DW_PART_FLOATS = (size_t)40 << 20;      // partial-sum scratch 
 template <class LdA, class LdB>
 int dw_launch(escx_handle_s* h, const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
     const int nbn = (Np + 47) / 48, nbk = (Kp + 47) / 48, blocks = nbn * nbk;
-    int slices = std::max(1, std::min((2048 + blocks - 1) / blocks, (M + 127) / 128));
+    static const int target = [] { const char* e = getenv("ESCX_DW_TARGET"); return e ? atoi(e) : 2048; }();        // workgroups per launch (tuning aid)
+    int slices = std::max(1, std::min((target + blocks - 1) / blocks, (M + 127) / 128));
     const size_t per = (size_t)Np * Kp + Np;
     slices = (int)std::min<size_t>(slices, DW_PART_FLOATS / per);
     if (slices < 1) ESCX_FAIL(ESCX_ERR_STATE, "dW scratch too small for %d x %d", Np, Kp);
@@ -158,6 +159,21 @@ int ln_bwd(int mode, const float* x, const float* dy, const float* gamma, const 
     return 0;
 }
 constexpr size_t LN_PART_FLOATS = (size_t)513 * 2 * 2 * 384;
+
+// dx_fc1 GEMM with the LayerNorm backward as its row epilogue (EpiLnBwdRows; Cp <= 96): out = add + LNbwd(dh . W; x), dgamma / dbeta.
+// `part` needs ceil(M / 64) * 4 * 2 * Cp floats (+ 2 * Cp for the reduced row): the dW partial-sum scratch is used.
+void gemm_ln_bwd_rows(const float* A, int lda, int M, const float* Wt, int Cp, int Kp, const float* x, const float* gamma, const float* add, float* dx,
+                      float* dx_slots, const int* slot_of, int rows_per_clip, int slots_per_clip, int C, float* dg, float* dbt, float* part, hipStream_t st) {
+    EpiLnBwdRows ep{x, gamma, add, dx, dx_slots, slot_of, part, C, Cp, rows_per_clip, slots_per_clip, 1e-5f};
+    const bool big = (long long)((M + 127) / 128) >= 512;
+    const int rows = (big ? (M + 127) / 128 : (M + 63) / 64) * 4;
+    if (big) launch_gemm<128>(PlainA{A, lda, M}, Wt, M, Cp, Kp, ep, st, 1, 16);
+    else launch_gemm<64>(PlainA{A, lda, M}, Wt, M, Cp, Kp, ep, st, 1, 16);
+    float* red = part + (size_t)rows * 2 * Cp;
+    launch_reduce_partials(part, rows, (long long)2 * Cp, red, 0, st, red + 2 * Cp);
+    (void)hipMemcpyAsync(dg, red, (size_t)Cp * sizeof(float), hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(dbt, red + Cp, (size_t)Cp * sizeof(float), hipMemcpyDeviceToDevice, st);
+}
 
 int attn_bwd(const float* qkv, const float* bias, const float* dout, float* dqkv, float* dbias, float* part, int total_windows, int nH, int hdp, int ldq,
              int ldo, int nWh, int nWw, int shifted, float scale, hipStream_t st) {
@@ -530,11 +546,18 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
         PROF("B.dw_fc1" + tg, 2.0 * M * L.C * L.hidden, 0,
              rc = dw_rows(h, dhpre, L.hiddenP, bt.xn2, L.Cp, M, L.hiddenP, L.Cp, G(h, bw.w1), G(h, bw.b1), part, st));
         if (rc) return rc;
-        PROF("B.dx_fc1" + tg, 2.0 * M * L.C * L.hidden, 0,
-             gemm_rows(dhpre, L.hiddenP, M, bw.w1T, L.Cp, L.hiddenP, EpiStore{dxn, L.Cp, nullptr}, st));
         if (slots != tokens) ESCX_HIP(hipMemsetAsync(dx1s, 0, (size_t)Ms * L.Cp * sizeof(float), st));      // pad slots carry no gradient
-        PROF("B.ln2" + tg, 0, 5.0 * M * L.C * 4,
-             ln_bwd(0, bt.x1, dxn, bw.ln2_g, nullptr, dy, dx1, G(h, bw.ln2_g), G(h, bw.ln2_b), tokens, tokens, tokens, M, L.C, L.Cp, lnpart, st, dx1s, inv, slots));
+        static const bool ln_fused = [] { const char* e = getenv("ESCX_LN_FUSED"); return !(e && e[0] == '0'); }();
+        if (ln_fused && L.Cp <= 96) {       // narrow maps: LN2's backward rides in the epilogue of the GEMM that produces its upstream gradient
+            PROF("B.dx_fc1+ln2" + tg, 2.0 * M * L.C * L.hidden, 0,
+                 gemm_ln_bwd_rows(dhpre, L.hiddenP, M, bw.w1T, L.Cp, L.hiddenP, bt.x1, bw.ln2_g, dy, dx1, dx1s, inv, tokens, slots, L.C, G(h, bw.ln2_g),
+                                  G(h, bw.ln2_b), part, st));
+        } else {
+            PROF("B.dx_fc1" + tg, 2.0 * M * L.C * L.hidden, 0,
+                 gemm_rows(dhpre, L.hiddenP, M, bw.w1T, L.Cp, L.hiddenP, EpiStore{dxn, L.Cp, nullptr}, st));
+            PROF("B.ln2" + tg, 0, 5.0 * M * L.C * 4,
+                 ln_bwd(0, bt.x1, dxn, bw.ln2_g, nullptr, dy, dx1, G(h, bw.ln2_g), G(h, bw.ln2_b), tokens, tokens, tokens, M, L.C, L.Cp, lnpart, st, dx1s, inv, slots));
+        }
         // ---- attention: x1 = x0 + scatter(Wp attn(Wqkv gather(LN1(x0)))) ----
         PROF("B.dw_proj" + tg, 2.0 * Ms * L.C * L.C, 0,
              rc = dw_rows(h, dx1s, L.Cp, bt.obuf, L.Ko, Ms, L.Cp, L.Ko, G(h, bw.wproj), G(h, bw.bproj), part, st));

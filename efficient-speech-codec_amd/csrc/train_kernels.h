@@ -160,6 +160,92 @@ struct EpiPvqGrad {             // gradient of the framed residual back on the t
     }
 };
 
+// LayerNorm backward as the ROW EPILOGUE of the GEMM that produces its upstream gradient (dx_fc1: d LN2(x1) = d h_pre . W1), for maps whose
+// channel count fits one workgroup tile (Cp <= 96): out = add + LNbwd(acc; x), written in token order and - through slot_of - in window-slot
+// order; the standalone pass re-read the GEMM's output, x and add and was HBM-bound.  dgamma / dbeta leave as one partial row per wave
+// (part[(workgroup*4 + wave)][2][Cp]), added in a fixed order by reduce_partials.
+struct EpiLnBwdRows {
+    static constexpr bool ROWWISE = true;
+    const float* x; const float* gamma; const float* add; float* dx; float* dx_slots; const int* slot_of; float* part;
+    int C, Cp, rows_per_clip, slots_per_clip; float eps;
+    __device__ __forceinline__ void store(int, int, f32x4, int) const {}
+    template <int TN, int TM>
+    __device__ __forceinline__ void finish(f32x4 (&acc)[TN][TM], int row0, int lane, int M) const {
+        const int l15 = lane & 15, lg = lane >> 4;
+        const float invC = 1.0f / (float)C;
+        f32x4 gm[TN], ag[TN], ab[TN];
+#pragma unroll
+        for (int a = 0; a < TN; ++a) { const int n = 16 * a + 4 * lg; gm[a] = n < Cp ? ld4(gamma + n) : zero4(); ag[a] = zero4(); ab[a] = zero4(); }
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const int m = row0 + 16 * b + l15;
+            const bool live = m < M;
+            f32x4 xv[TN];
+            float s = 0.f;
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int n = 16 * a + 4 * lg;
+                xv[a] = (live && n < Cp) ? ld4(x + (size_t)m * Cp + n) : zero4();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (n + e < C) s += xv[a][e];
+            }
+            const float mean = sum_groups(s) * invC;
+            float var = 0.f;
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (16 * a + 4 * lg + e < C) { const float d = xv[a][e] - mean; var += d * d; }
+            const float rstd = 1.0f / sqrtf(sum_groups(var) * invC + eps);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (16 * a + 4 * lg + e < C) {
+                        const float xh = (xv[a][e] - mean) * rstd, g = acc[a][b][e], t = g * gm[a][e];
+                        s1 += t; s2 += t * xh;
+                        if (live) { ag[a][e] += g * xh; ab[a][e] += g; }
+                    }
+            const float c1 = sum_groups(s1) * invC, c2 = sum_groups(s2) * invC;
+            if (live) {
+                const int bi = m / rows_per_clip, rr = m - bi * rows_per_clip;
+                float* ds = dx_slots ? dx_slots + ((size_t)bi * slots_per_clip + slot_of[rr]) * Cp : nullptr;
+#pragma unroll
+                for (int a = 0; a < TN; ++a) {
+                    const int n = 16 * a + 4 * lg;
+                    if (n >= Cp) continue;
+                    f32x4 o = add ? ld4(add + (size_t)m * Cp + n) : zero4();
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (xv[a][e] - mean) * rstd;
+                        o[e] = (n + e < C) ? o[e] + rstd * (acc[a][b][e] * gm[a][e] - c1 - xh * c2) : 0.f;
+                    }
+                    st4(dx + (size_t)m * Cp + n, o);
+                    if (ds) st4(ds + n, o);
+                }
+            }
+        }
+        // column sums over this wave's rows: the 16 lanes of a lane group hold 16 different rows of the same columns
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float u = ag[a][e], w = ab[a][e];
+#pragma unroll
+                for (int o = 8; o >= 1; o >>= 1) { u += __shfl_xor(u, o, 16); w += __shfl_xor(w, o, 16); }
+                ag[a][e] = u; ab[a][e] = w;
+            }
+        if (l15 == 0) {
+            float* pr = part + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 * Cp;
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int n = 16 * a + 4 * lg;
+                if (n < Cp) { st4(pr + n, ag[a]); st4(pr + Cp + n, ab[a]); }
+            }
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // dW[n][k] = sum_m A[m][n] * B[m][k]   (A = upstream gradient rows, B = saved input rows), optional db[n] = sum_m A[m][n].
 // One workgroup = one 48 x 48 output tile and one slice of M; its 4 waves take alternate 32-row chunks, stage them in their own LDS
@@ -420,8 +506,31 @@ static __global__ __launch_bounds__(256) void reduce_partials_tree_kernel(const 
 }
 // fixed-order sum of `slices` partial tensors of n floats.  The variant depends on (slices, n) only - never on data - so results stay
 // run-to-run deterministic.
-static inline void launch_reduce_partials(const float* part, int slices, long long n, float* out, int accumulate, hipStream_t st) {
+// slices [g*per, (g+1)*per) of a [slices][n] tensor -> tmp[g][n]   (first stage of the two-stage reduction below; grid = (n/16, groups))
+static __global__ __launch_bounds__(256) void reduce_partials_stage_kernel(const float* __restrict__ part, int slices, int per, long long n, float* __restrict__ tmp) {
+    __shared__ float red[16][17];
+    const int j = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const long long i = (long long)blockIdx.x * 16 + j;
+    const int k0 = blockIdx.y * per, k1 = min(slices, k0 + per);
+    float s = 0.f;
+    if (i < n) for (int k = k0 + q; k < k1; k += 16) s += part[(size_t)k * n + i];
+    red[q][j] = s;
+    __syncthreads();
+    if (q == 0 && i < n) {
+        float t = red[0][j];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) t += red[r][j];
+        tmp[(size_t)blockIdx.y * n + i] = t;
+    }
+}
+static inline void launch_reduce_partials(const float* part, int slices, long long n, float* out, int accumulate, hipStream_t st, float* tmp = nullptr) {
     auto nb = [](long long v) { return (unsigned)((v + 255) / 256); };
+    if (tmp && slices >= 2048 && n <= 4096) {                  // very many slices of a short row: 64 groups first (tmp: 64 * n floats), then the 64
+        const int groups = 64, per = (slices + groups - 1) / groups;
+        hipLaunchKernelGGL(reduce_partials_stage_kernel, dim3((unsigned)((n + 15) / 16), groups), dim3(256), 0, st, part, slices, per, n, tmp);
+        hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3(nb((n + 15) / 16 * 64)), dim3(256), 0, st, tmp, (slices + per - 1) / per, n, out, accumulate);
+        return;
+    }
     if (slices >= 128 && n <= ((long long)1 << 18))
         hipLaunchKernelGGL(reduce_partials_tree_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, slices, n, out, accumulate);
     else if (slices >= 32 && n * 4 <= ((long long)1 << 22))
