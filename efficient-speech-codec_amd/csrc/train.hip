@@ -163,8 +163,9 @@ constexpr size_t LN_PART_FLOATS = (size_t)513 * 2 * 2 * 384;
 // dx_fc1 GEMM with the LayerNorm backward as its row epilogue (EpiLnBwdRows; Cp <= 96): out = add + LNbwd(dh . W; x), dgamma / dbeta.
 // `part` needs ceil(M / 64) * 4 * 2 * Cp floats (+ 2 * Cp for the reduced row): the dW partial-sum scratch is used.
 void gemm_ln_bwd_rows(const float* A, int lda, int M, const float* Wt, int Cp, int Kp, const float* x, const float* gamma, const float* add, float* dx,
-                      float* dx_slots, const int* slot_of, int rows_per_clip, int slots_per_clip, int C, float* dg, float* dbt, float* part, hipStream_t st) {
-    EpiLnBwdRows ep{x, gamma, add, dx, dx_slots, slot_of, part, C, Cp, rows_per_clip, slots_per_clip, 1e-5f};
+                      float* dx_slots, const int* slot_of, int rows_per_clip, int slots_per_clip, int C, float* dg, float* dbt, float* part, hipStream_t st,
+                      const int* row_map = nullptr) {
+    EpiLnBwdRows ep{x, gamma, add, dx, dx_slots, slot_of, part, C, Cp, rows_per_clip, slots_per_clip, 1e-5f, row_map};
     const bool big = (long long)((M + 127) / 128) >= 512;
     const int rows = (big ? (M + 127) / 128 : (M + 63) / 64) * 4;
     if (big) launch_gemm<128>(PlainA{A, lda, M}, Wt, M, Cp, Kp, ep, st, 1, 16);
@@ -573,9 +574,15 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
         PROF("B.dw_qkv" + tg, 2.0 * Ms * L.C * 3 * L.C, 0,
              rc = dw_rows(h, dqkv, L.Nqkv, bt.xn1, L.Cp, Ms, L.Nqkv, L.Cp, G(h, bw.wqkv), G(h, bw.bqkv), part, st));
         if (rc) return rc;
-        PROF("B.dx_qkv" + tg, 2.0 * Ms * L.C * 3 * L.C, 0, gemm_rows(dqkv, L.Nqkv, Ms, bw.wqkvT, L.Cp, L.Nqkv, EpiStore{dxn, L.Cp, nullptr}, st));
-        PROF("B.ln1" + tg, 0, 4.0 * M * L.C * 4,
-             ln_bwd(1, bt.x0, dxn, bw.ln1_g, inv, dx1, dprev, G(h, bw.ln1_g), G(h, bw.ln1_b), tokens, tokens, slots, M, L.C, L.Cp, lnpart, st));
+        if (ln_fused && L.Cp <= 96) {       // LN1's backward in the epilogue of the QKV dX GEMM: its rows are window slots, map = slot -> token
+            PROF("B.dx_qkv+ln1" + tg, 2.0 * Ms * L.C * 3 * L.C, 0,
+                 gemm_ln_bwd_rows(dqkv, L.Nqkv, Ms, bw.wqkvT, L.Cp, L.Nqkv, bt.x0, bw.ln1_g, dx1, dprev, nullptr, nullptr, tokens, slots, L.C, G(h, bw.ln1_g),
+                                  G(h, bw.ln1_b), part, st, map));
+        } else {
+            PROF("B.dx_qkv" + tg, 2.0 * Ms * L.C * 3 * L.C, 0, gemm_rows(dqkv, L.Nqkv, Ms, bw.wqkvT, L.Cp, L.Nqkv, EpiStore{dxn, L.Cp, nullptr}, st));
+            PROF("B.ln1" + tg, 0, 4.0 * M * L.C * 4,
+                 ln_bwd(1, bt.x0, dxn, bw.ln1_g, inv, dx1, dprev, G(h, bw.ln1_g), G(h, bw.ln1_b), tokens, tokens, slots, M, L.C, L.Cp, lnpart, st));
+        }
         std::swap(dcur, dprev);
         dy = dcur;
     }

@@ -168,6 +168,8 @@ struct EpiLnBwdRows {
     static constexpr bool ROWWISE = true;
     const float* x; const float* gamma; const float* add; float* dx; float* dx_slots; const int* slot_of; float* part;
     int C, Cp, rows_per_clip, slots_per_clip; float eps;
+    const int* row_map;         // optional: the GEMM's rows are window SLOTS (LN1: the upstream gradient comes out of the QKV GEMM in slot order);
+                                // row_map[slot] = token of the clip or -1 for a pad slot, x / add / dx are indexed by token
     __device__ __forceinline__ void store(int, int, f32x4, int) const {}
     template <int TN, int TM>
     __device__ __forceinline__ void finish(f32x4 (&acc)[TN][TM], int row0, int lane, int M) const {
@@ -178,8 +180,12 @@ struct EpiLnBwdRows {
         for (int a = 0; a < TN; ++a) { const int n = 16 * a + 4 * lg; gm[a] = n < Cp ? ld4(gamma + n) : zero4(); ag[a] = zero4(); ab[a] = zero4(); }
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
-            const int m = row0 + 16 * b + l15;
-            const bool live = m < M;
+            int m = row0 + 16 * b + l15;
+            bool live = m < M;
+            if (row_map && live) {
+                const int bi = m / slots_per_clip; const int tok = row_map[m - bi * slots_per_clip];
+                live = tok >= 0; m = bi * rows_per_clip + tok;
+            }
             f32x4 xv[TN];
             float s = 0.f;
 #pragma unroll
