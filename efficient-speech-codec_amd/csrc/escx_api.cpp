@@ -155,6 +155,7 @@ extern "C" void escx_destroy(escx_handle h) {
     if (h->coll_buf) (void)hipFree(h->coll_buf);
     if (h->gmap) (void)hipFree(h->gmap);
     if (h->garena) (void)hipFree(h->garena);
+    if (h->grad_seg) (void)hipFree(h->grad_seg);
     if (h->tape.base) (void)hipFree(h->tape.base);
     delete h;
 }
@@ -588,6 +589,7 @@ extern "C" int escx_finalize_params(escx_handle h) {
     ESCX_HIP(hipMemcpy(h->wts.base, image.data(), bytes, hipMemcpyHostToDevice));
     for (auto& f : fix) *f.first = reinterpret_cast<float*>(h->wts.base) + f.second;
     h->grad_regions = grads;
+    if (h->grad_seg) { (void)hipFree(h->grad_seg); h->grad_seg = nullptr; }      // rebuilt by the next training backward
     h->finalized = true;
     build_flat_layout(h);
     for (Layer& L : h->layers)

@@ -124,6 +124,7 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     int* gmap = nullptr;                         // per arena float: flat index + 1, 0 = zero padding, -1 = computed elsewhere
     float* garena = nullptr;                     // gradients of the packed layouts, same offsets as the weight arena
     std::vector<std::pair<size_t, size_t>> grad_regions;     // (offset, n) of the primary training layouts inside the arena
+    long long* grad_seg = nullptr; int grad_nseg = 0; long long grad_seg_total = 0;     // device table [nseg][2] = (first element, arena offset) for the one-launch scatter
     escx::Arena tape;                            // activations kept between escx_train_forward and escx_train_backward
     void* train_state = nullptr;                 // TrainTape* (train.hip)
     bool composed_stale = false;                 // weights were refreshed on the device: the fp64-folded de-embedding of the inference path is out of date

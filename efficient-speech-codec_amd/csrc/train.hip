@@ -759,9 +759,17 @@ extern "C" int escx_train_backward(escx_handle h, const float* d_wave, const flo
         if ((rc = dw_launch(h, PlainA{dpre, h->C0p, Mt}, pa, Mt, h->C0p, h->Kpe, G(h, h->pe_w), G(h, h->pe_b), part, st))) return rc;
     }
     // ---- packed gradients -> flat reference layout ----
-    for (auto& r : h->grad_regions)
-        hipLaunchKernelGGL(scatter_grads_kernel, dim3(blocks_for((long long)r.second)), dim3(256), 0, st, h->garena + r.first, h->gmap + r.first, grad_flat,
-                           (long long)r.second);
+    if (!h->grad_seg && !h->grad_regions.empty()) {              // one table for all primary layouts (344 launches per step before)
+        std::vector<long long> seg;
+        long long tot = 0;
+        for (auto& r : h->grad_regions) { seg.push_back(tot); seg.push_back((long long)r.first); tot += (long long)r.second; }
+        ESCX_HIP(hipMalloc((void**)&h->grad_seg, seg.size() * sizeof(long long)));
+        ESCX_HIP(hipMemcpy(h->grad_seg, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice));
+        h->grad_nseg = (int)h->grad_regions.size(); h->grad_seg_total = tot;
+    }
+    if (h->grad_seg)
+        hipLaunchKernelGGL(scatter_grads_kernel, dim3(blocks_for(h->grad_seg_total)), dim3(256), 0, st, h->garena, h->gmap, grad_flat, h->grad_seg, h->grad_nseg,
+                           h->grad_seg_total);
     return launch_ok("train_backward");
 }
 

@@ -838,11 +838,17 @@ static __global__ void gather_params_kernel(const float* __restrict__ flat, cons
     else if (c == 0) arena[i] = 0.f;
 }
 // gradient of the packed layouts back to the flat reference layout (one-to-one on the regions it is launched on)
-static __global__ void scatter_grads_kernel(const float* __restrict__ garena, const int* __restrict__ map, float* __restrict__ gflat, long long n) {
+// packed gradients -> flat reference layout, all primary layouts in ONE launch: seg[s] = (first element of segment s in the concatenation,
+// arena offset of the segment); element i belongs to the last segment whose first element is <= i (binary search over ~350 entries)
+static __global__ void scatter_grads_kernel(const float* __restrict__ garena, const int* __restrict__ map, float* __restrict__ gflat,
+                                            const long long* __restrict__ seg, int nseg, long long total) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = map[i];
-    if (c > 0) gflat[c - 1] = garena[i];
+    if (i >= total) return;
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (seg[2 * mid] <= i) lo = mid; else hi = mid - 1; }
+    const long long a = seg[2 * lo + 1] + (i - seg[2 * lo]);
+    const int c = map[a];
+    if (c > 0) gflat[c - 1] = garena[a];
 }
 // F.normalize of the codebooks + squared norms (codebook.py:31-36), same summation order as the host packer
 static __global__ void codebook_normalize_kernel(const float* __restrict__ raw, float* __restrict__ cbn, float* __restrict__ c2, int rows, int d, int dt, int l2norm) {
