@@ -3,6 +3,7 @@
 Tolerances: integer codes bit-exact; audio <= 1e-4 RMS (north_star); intermediate fp32 activations are compared
 relative to their own RMS at 2e-5 (pure fp32 re-association noise)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -751,3 +752,31 @@ def test_allgather_codes_through_the_c_abi_one_rank_rccl(base):
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.environ.get("ESCX_PARITY_SWEEP"), reason="opt-in: ESCX_PARITY_SWEEP=<clips per family> (minutes of host time for the oracle)")
+def test_parity_sweep_many_clips(base):
+    """Opt-in sweep (its log is committed under profiles/): N noise + N voiced clips in batches of 36 against the oracle, every code; a
+    difference must sit on a reference near-tie (margin < 2e-6) in the earliest differing stream of its clip."""
+    model, orc, g, cfg = base
+    Trace = __import__("oracle.esc_oracle", fromlist=["Trace"]).Trace
+    n = int(os.environ["ESCX_PARITY_SWEEP"])
+    tot = dict(clips=0, exact=0, codes=0, diff=0, under_1e5=0, under_2e6=0)
+    min_margin = 1.0
+    for fam, fn in (("noise", synth.noise_clip_int16), ("voiced", synth.voiced_clip_int16)):
+        for lo in range(0, n, 36):
+            k = min(36, n - lo)
+            pcm = np.stack([fn(f"sweep-{fam}-{lo + i}", 48000) for i in range(k)])
+            x = torch.from_numpy(synth.pcm_to_float(pcm))
+            codes, shape = model.encode(x.cuda(), 6)
+            tr = Trace()
+            oc, _ = orc.encode(x, 6, trace=tr)
+            m = torch.stack(tr.margins, dim=1).numpy()
+            got, ref = codes.cpu().numpy(), oc.numpy()
+            bad = unattributable(got, ref, m)
+            assert not bad, f"{fam} clips {lo}..{lo + k}: " + "\n".join(bad[:10])
+            tot["clips"] += k; tot["exact"] += int((got == ref).reshape(k, -1).all(1).sum()); tot["codes"] += got.size; tot["diff"] += int((got != ref).sum())
+            tot["under_1e5"] += int((m < 1e-5).sum()); tot["under_2e6"] += int((m < 2e-6).sum()); min_margin = min(min_margin, float(m.min()))
+            print(f"[sweep {fam} {lo}..{lo + k}] exact {tot['exact']}/{tot['clips']} clips, smallest reference margin so far {min_margin:.2e}", flush=True)
+    print(f"[sweep] {tot}; smallest reference margin {min_margin:.2e}")
