@@ -756,10 +756,11 @@ def test_allgather_codes_through_the_c_abi_one_rank_rccl(base):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.environ.get("ESCX_PARITY_SWEEP"), reason="opt-in: ESCX_PARITY_SWEEP=<clips per family> (minutes of host time for the oracle)")
-def test_parity_sweep_many_clips(base):
+def test_parity_sweep_many_clips():
     """Opt-in sweep (its log is committed under profiles/): N noise + N voiced clips in batches of 36 against the oracle, every code; a
-    difference must sit on a reference near-tie (margin < 2e-6) in the earliest differing stream of its clip."""
-    model, orc, g, cfg = base
+    difference must sit on a reference near-tie (margin < 2e-6) in the earliest differing stream of its clip.  ESCX_PARITY_SWEEP_MODEL=large
+    sweeps ESC-Large instead of ESC-Base."""
+    model, orc, g, cfg = build_models(os.environ.get("ESCX_PARITY_SWEEP_MODEL", "base"))
     Trace = __import__("oracle.esc_oracle", fromlist=["Trace"]).Trace
     n = int(os.environ["ESCX_PARITY_SWEEP"])
     tot = dict(clips=0, exact=0, codes=0, diff=0, under_1e5=0, under_2e6=0)
