@@ -102,6 +102,9 @@ def cpu_baseline(cfg, sd, x_cpu):
         if best_t is None or t < best_t:
             best_t, best_thr = t, thr
     torch.set_num_threads(best_thr)
+    # the timed sample is the SAME workload the GPU number is quoted on: the whole 36-clip batch (about 10-20 s of host time per pass)
+    n = min(CLIPS_PER_GPU, x_cpu.shape[0])
+    xs = x_cpu[:n]
     reps, t0 = 0, time.perf_counter()
     while True:
         once()
@@ -122,7 +125,7 @@ def cpu_baseline(cfg, sd, x_cpu):
             "single_clip": {"ms": round(t1 * 1e3, 1), "audio_s_per_s": round(3.0 / t1, 2),
                             "what": "BASELINE configs[0]: one 3 s clip, num_streams=6, encode+decode, oracle on the host cores"},
             "sample": f"{reps} x encode+decode of {n} clips (3 s each), oracle/esc_oracle.py, torch {torch.__version__} CPU fp32, "
-                      f"{best_thr} of {avail} host threads (best of a 8/16/32/64 sweep)"}
+                      f"{best_thr} of {avail} host threads (best of a 8/16/32/64 sweep on 4 clips)"}
 
 
 TRAIN_SAMPLES = 47920              # 3 s minus one hop: an even frame count, so that raw and reconstructed spectra have the same T (the trainers' clips)
