@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--num_warmup_steps", type=int, default=0)
     ap.add_argument("--adv", action="store_true", help="adversarial training (trainer_adv.py): adds the DAC discriminator and its update")
     ap.add_argument("--save_path", default=None)
+    ap.add_argument("--resume", default=None, help="checkpoint.pth written by --save_path: continues at its step with the optimiser state (accel.load_state in the reference)")
     ap.add_argument("--log_steps", type=int, default=5)
     ap.add_argument("--seed", type=int, default=1234)
     args = ap.parse_args()
@@ -180,13 +181,25 @@ def main():
         st = Stepper(model, args.lr, loss_w, args.dropout_rate, args.pretraining_steps, args.scheduler_type, args.steps, args.num_warmup_steps,
                      seed=args.seed)                                    # same seed on every rank: the ranks agree on the stream count
     data = _batches(args, device, rank, world)
+    first = 0
+    if args.resume:
+        ck = torch.load(args.resume, map_location="cpu", weights_only=False)
+        model.load_state_dict(ck["model_state_dict"])
+        first = int(ck["step"]) + 1
+        if args.adv:
+            disc.load_state_dict(ck["disc_state_dict"])
+            st.opt_g.load_state_dict(ck["optimizer_state_dict"]); st.opt_d.load_state_dict(ck["disc_optimizer_state_dict"])
+        else:
+            st.opt.load_state_dict(ck["optimizer_state_dict"])
+        for _ in range(first):                                          # the stream sampler and the data order continue where they stopped
+            sample_streams(st.rng, st.dropout_rate, model.max_streams); next(data)
     t0 = time.perf_counter()
-    for n in range(args.steps):
+    for n in range(first, args.steps):
         log = st.step(next(data), n)
         if rank == 0 and ((n + 1) % args.log_steps == 0 or n == 0):
             torch.cuda.synchronize()
             vals = {k: (round(float(v), 5) if torch.is_tensor(v) else v) for k, v in log.items()}
-            print(json.dumps({"step": n + 1, "s_per_step": round((time.perf_counter() - t0) / (n + 1), 4), **vals}))
+            print(json.dumps({"step": n + 1, "s_per_step": round((time.perf_counter() - t0) / (n + 1 - first), 4), **vals}))
     if rank == 0 and args.save_path:
         os.makedirs(args.save_path, exist_ok=True)
         ck = {"step": args.steps - 1, "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()}}
