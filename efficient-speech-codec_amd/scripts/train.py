@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--num_warmup_steps", type=int, default=0)
     ap.add_argument("--adv", action="store_true", help="adversarial training (trainer_adv.py): adds the DAC discriminator and its update")
     ap.add_argument("--save_path", default=None)
+    ap.add_argument("--val_data", default=None, help="folder of 16 kHz wavs: every --eval_every steps the model is evaluated at max_streams (trainer_no_adv.py:132-145)")
+    ap.add_argument("--eval_every", type=int, default=0)
     ap.add_argument("--resume", default=None, help="checkpoint.pth written by --save_path: continues at its step with the optimiser state (accel.load_state in the reference)")
     ap.add_argument("--log_steps", type=int, default=5)
     ap.add_argument("--seed", type=int, default=1234)
@@ -193,9 +195,25 @@ def main():
             st.opt.load_state_dict(ck["optimizer_state_dict"])
         for _ in range(first):                                          # the stream sampler and the data order continue where they stopped
             sample_streams(st.rng, st.dropout_rate, model.max_streams); next(data)
+    evaluate = None
+    if args.val_data and args.eval_every > 0 and rank == 0:              # the reference's evaluate(): eval_epoch at the full bitrate, no PESQ here
+        from torch.utils.data import DataLoader, default_collate
+        from .metrics import EntropyCounter, MelSpectrogramDistance, SISDR
+        from .test import eval_epoch
+        from .utils import EvalSet
+        val_dl = DataLoader(EvalSet(args.val_data), batch_size=args.batch_size, shuffle=False, collate_fn=default_collate)
+        mfs = {"MelDistance": MelSpectrogramDistance().to(device), "SISDR": SISDR().to(device)}
+        mc = model.cfg
+        ec = EntropyCounter(mc["codebook_size"], num_streams=mc["max_streams"], num_groups=mc["group_size"], device=device)
+
+        def evaluate(step):
+            perf = eval_epoch(model, val_dl, mfs, ec, device, bps_per_stream=1.5, num_streams=model.max_streams, verbose=False)
+            print(json.dumps({"step": step, "eval": {k: v[0] for k, v in perf.items()}}))
     t0 = time.perf_counter()
     for n in range(first, args.steps):
         log = st.step(next(data), n)
+        if evaluate and (n + 1) % args.eval_every == 0:
+            evaluate(n + 1)
         if rank == 0 and ((n + 1) % args.log_steps == 0 or n == 0):
             torch.cuda.synchronize()
             vals = {k: (round(float(v), 5) if torch.is_tensor(v) else v) for k, v in log.items()}

@@ -422,6 +422,15 @@ def test_train_cli_checkpoint_and_resume(tmp_path):
     assert [l["step"] for l in rest] == [4, 5, 6]
     for a, b in zip(full[3:], rest):
         assert a["streams"] == b["streams"] and a["loss"] == b["loss"], (a, b)
+    # periodic evaluation on a validation folder (the reference's evaluate(): eval_epoch at max_streams) leaves training untouched
+    from scipy.io import wavfile
+    os.makedirs(tmp_path / "val")
+    for i in range(3):
+        wavfile.write(tmp_path / "val" / f"v{i}.wav", 16000, synth.voiced_clip_int16(f"val-{i}", 15980))          # EvalSet drops 80 samples: 795 hops of the tiny model, an even frame count
+    ev = run(["--steps", "6", "--val_data", str(tmp_path / "val"), "--eval_every", "3"])
+    evals = [l for l in ev if "eval" in l]
+    assert [l["step"] for l in evals] == [3, 6] and all(np.isfinite(l["eval"]["SISDR"]) and 0 < l["eval"]["utilization"] <= 1 for l in evals)
+    assert [l["loss"] for l in ev if "loss" in l] == [l["loss"] for l in full]
     wa = torch.load(tmp_path / "a" / "checkpoint.pth", weights_only=False)["model_state_dict"]
     wc = torch.load(tmp_path / "c" / "checkpoint.pth", weights_only=False)["model_state_dict"]
     assert all(torch.equal(wa[k], wc[k]) for k in wa)
