@@ -434,3 +434,30 @@ def test_train_cli_checkpoint_and_resume(tmp_path):
     wa = torch.load(tmp_path / "a" / "checkpoint.pth", weights_only=False)["model_state_dict"]
     wc = torch.load(tmp_path / "c" / "checkpoint.pth", weights_only=False)["model_state_dict"]
     assert all(torch.equal(wa[k], wc[k]) for k in wa)
+
+
+@pytest.mark.gpu
+def test_training_step_is_run_to_run_deterministic():
+    """No atomics anywhere in the backward (fixed-order partial sums): the same step twice gives bit-identical losses and gradients, for the
+    generator (base, two clips) and for the discriminator."""
+    from esc.models import Discriminator
+    from esc.modules import GANLoss
+    g = load_golden("train")
+    w = json.loads(str(g["weights_json"]))
+    x = _clips(g, "base")
+    runs = []
+    for _ in range(2):
+        model, out, losses, grads = _product_step("base", 6, False, x, w)
+        runs.append((losses, grads))
+    assert all(np.array_equal(runs[0][0][k], runs[1][0][k]) for k in runs[0][0])
+    assert all(np.array_equal(runs[0][1][k], runs[1][1][k]) for k in runs[0][1])
+    torch.manual_seed(0)
+    disc = Discriminator(sample_rate=16000).cuda()
+    gan = GANLoss(disc)
+    real = x[:, :8000].cuda(); fake = (0.9 * x[:, :8000] + 0.01).cuda()
+    dg = []
+    for _ in range(2):
+        disc.zero_grad()
+        gan.discriminator_loss(fake, real).mean().backward()
+        dg.append({k: p.grad.detach().clone() for k, p in disc.named_parameters()})
+    assert all(torch.equal(dg[0][k], dg[1][k]) for k in dg[0])
