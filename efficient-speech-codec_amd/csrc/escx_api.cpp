@@ -129,7 +129,7 @@ extern "C" int escx_create(const escx_config* cfg, int device, escx_handle* out)
     { const char* e = getenv("ESCX_MLP_VARIANT"); if (e && e[0]) h->mlp_variant = atoi(e); }
     { const char* e = getenv("ESCX_MLP_HS"); if (e && e[0]) h->mlp_hs = atoi(e); }
     { const char* e = getenv("ESCX_ATTN_GS"); if (e && e[0]) h->attn_gs = atoi(e); }
-    { const char* e = getenv("ESCX_STREAMS"); if (e && e[0]) h->parts = std::min(std::max(atoi(e), 1), (int)escx_handle_s::MAX_PARTS); }
+    { const char* e = getenv("ESCX_STREAMS"); if (e && e[0]) { h->parts = std::min(std::max(atoi(e), 1), (int)escx_handle_s::MAX_PARTS); h->parts_forced = true; } }
     { const char* e = getenv("ESCX_DEEMBED_TWO_STAGE"); h->deembed_two_stage = (e && e[0] == '1'); }
     { const char* e = getenv("ESCX_DEEMBED_GEMM"); h->deembed_halo = !(e && e[0] == '1'); }
     { const char* e = getenv("ESCX_ATTN_NW"); if (e && e[0]) h->attn_nw = atoi(e); }
@@ -719,7 +719,10 @@ extern "C" int64_t escx_workspace_bytes(escx_handle h) {
 
 static void use_set(escx_handle_s* h, int i) { static_cast<WsFields&>(*h) = h->sets[i]; }
 // number of parts a batch of B clips is split into, and the clips one workspace set must hold
-static int n_parts(escx_handle_s* h, int B) { return std::max(1, std::min(h->parts, B)); }
+// Batches under 6 clips run as ONE part: splitting 2 - 4 clips over two streams costs more in per-launch efficiency than the overlap of the
+// parts' tails returns (measured, tools/small_batch.py: B = 2 4.52 -> 4.12 ms, B = 4 4.96 -> 4.67 ms; from B = 8 up two parts win).  The
+// arithmetic of a clip does not depend on how the batch is split, so the codes stay identical either way.
+static int n_parts(escx_handle_s* h, int B) { return std::max(1, std::min((h->parts_forced || B >= 6) ? h->parts : 1, B)); }
 static int set_clips(escx_handle_s* h, int B) { const int k = n_parts(h, B); return (B + k - 1) / k; }
 
 static bool ws_fits(escx_handle_s* h, int B, int T) {
@@ -733,9 +736,11 @@ static bool ws_fits(escx_handle_s* h, int B, int T) {
     return true;
 }
 
-static int reserve_frames(escx_handle_s* h, int Btotal, int T) {
+// set_clips_min / sets_min: lower bounds carried over from the existing workspace when it grows (the clips a part holds are NOT monotone in
+// the batch: 5 clips run as one part of 5, 8 clips as two parts of 4)
+static int reserve_frames(escx_handle_s* h, int Btotal, int T, int set_clips_min = 0, int sets_min = 0) {
     ESCX_HIP(hipSetDevice(h->device));
-    const int B = set_clips(h, Btotal), sets = n_parts(h, Btotal);
+    const int B = std::max(set_clips(h, Btotal), set_clips_min), sets = std::max(n_parts(h, Btotal), sets_min);
     Shapes s;
     int rc = make_shapes(h, B, T, &s);
     if (rc) return rc;
@@ -755,11 +760,11 @@ static int reserve_frames(escx_handle_s* h, int Btotal, int T) {
     }
     if (ws_fits(h, Btotal, T)) return ESCX_OK;
     // grow only: keep the largest batch and clip length seen so far, so that callers alternating between shapes do not thrash
-    if (h->sets[0].ws.base) {
-        const int Bt = std::max(Btotal, h->cap_clips), Tt = std::max(T, h->sets[0].shp.T);
-        if (Bt != Btotal || Tt != T) {
+    if (h->sets[0].ws.base && !(set_clips_min || sets_min)) {
+        const int Bs = std::max(B, h->sets[0].shp.B), ns = std::max(sets, h->n_sets), Tt = std::max(T, h->sets[0].shp.T);
+        if (Bs != B || ns != sets || Tt != T) {
             Shapes s2;
-            if (make_shapes(h, set_clips(h, Bt), Tt, &s2) == 0) return reserve_frames(h, Bt, Tt);
+            if (make_shapes(h, Bs, Tt, &s2) == 0) return reserve_frames(h, Btotal, Tt, Bs, ns);
         }
     }
     if (!h->ev_fork) ESCX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));

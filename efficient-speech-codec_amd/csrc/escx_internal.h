@@ -137,6 +137,7 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     int n_sets = 1;
     int cap_clips = 0;               // total clips (over all parts) the current workspace was reserved for
     int parts = 2;                   // ESCX_STREAMS=k (1..4): batch split into k parts on k streams; 1 = single stream
+    bool parts_forced = false;       // ESCX_STREAMS given: use it for every batch size
     hipStream_t sx[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};   // extra streams (part 0 runs on the caller's stream)
     hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
 

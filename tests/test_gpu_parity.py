@@ -781,3 +781,18 @@ def test_parity_sweep_many_clips():
             tot["under_1e5"] += int((m < 1e-5).sum()); tot["under_2e6"] += int((m < 2e-6).sum()); min_margin = min(min_margin, float(m.min()))
             print(f"[sweep {fam} {lo}..{lo + k}] exact {tot['exact']}/{tot['clips']} clips, smallest reference margin so far {min_margin:.2e}", flush=True)
     print(f"[sweep] {tot}; smallest reference margin {min_margin:.2e}")
+
+
+@pytest.mark.gpu
+def test_batch_sizes_alternating_between_one_and_two_parts():
+    """Batches under 6 clips run as one part, larger ones as two parts on two streams: the clips a part holds are not monotone in the batch
+    (8 -> 2 x 4, 5 -> 1 x 5), the workspace has to grow per part; every clip keeps its codes and its audio in every batch it appears in."""
+    model, orc, g, cfg = build_models("base")
+    pcm = np.stack([synth.noise_clip_int16(f"parts-{i}", 24000) for i in range(12)])
+    x = torch.from_numpy(synth.pcm_to_float(pcm)).cuda()
+    ref_c, shape = model.encode(x, 6)
+    ref_w = model.decode(ref_c, shape)
+    for B in (8, 5, 4, 7, 1, 6, 3, 12, 2):
+        c, shp = model.encode(x[:B].contiguous(), 6)
+        w = model.decode(c, shp)
+        assert torch.equal(c, ref_c[:B]) and torch.equal(w, ref_w[:B]), B
