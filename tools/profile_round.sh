@@ -39,7 +39,7 @@ tail -1 $O/prof_train.log | cut -c1-300 > $O/prof_train_bench_line.txt
 rm -rf $O/prof_train
 # adversarial step (ESC-Large generator + discriminator): bench line and kernel stats
 cd $R
-timeout 900 python bench.py --mode train_adv --steps 4 --warmup 2 --no-cpu-baseline 2>$O/train_adv.err | tail -1 > $O/bench_train_adv.json; cut -c1-300 $O/bench_train_adv.json
+timeout 900 python bench.py --mode train_adv --steps 4 --warmup 2 2>$O/train_adv.err | tail -1 > $O/bench_train_adv.json; cut -c1-300 $O/bench_train_adv.json
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_adv -o p -- python $R/bench.py --mode train_adv --steps 4 --warmup 1 --no-cpu-baseline > $O/prof_adv.log 2>&1
 cp $(find $O/prof_adv -name "*kernel_stats.csv" | head -1) $O/train_adv_kernel_stats.csv 2>/dev/null
