@@ -344,7 +344,8 @@ def main():
                     help="codec (default): encode+decode throughput, the BASELINE metric; train: the non-adversarial optimisation step (ESC-Base); "
                          "train_adv: BASELINE configs[4] - ESC-Large + the adversarial step (generator and discriminator updates), fp32")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 200 for the codec = 3 s of GPU work, enough for a utilisation sampler to see it; 20 for train, 6 for train_adv)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--global-batch", type=int, default=0,
@@ -356,6 +357,8 @@ def main():
     ap.add_argument("--skip-isolated", action="store_true",
                     help="omit the isolated-kernel timing pass (used under rocprofv3 so that its per-kernel averages cover two-stream launches only)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"codec": 200, "train": 20, "train_adv": 6}[args.mode]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
