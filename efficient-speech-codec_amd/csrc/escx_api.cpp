@@ -987,10 +987,21 @@ static int attn_cap(int Cp, int tmw) { const int v = Cp * tmw; return v <= 96 ? 
 // The partial sums live in the (otherwise unused) hidden-activation buffer of the unfused path: needs hiddenP >= 3 * Cp.
 static int mlp_hs_for(int tokens_per_clip, int HT, int Cp) { return (tokens_per_clip <= 1200 && HT % 3 == 0 && HT * 16 >= 3 * Cp) ? 3 : 1; }
 // The same split over the head groups of the fused attention (partials share the buffer; an MLP always follows on the same
-// stream).  Measured: -19 % on the isolated C = 384 kernel but neutral end to end with two parts in flight, so it is off unless
-// ESCX_ATTN_GS_TOKENS raises the limit (single-clip latency is where it pays).
-static int attn_gs_for(int tokens_per_clip, int n_groups, int hiddenP, int Cp) { static const int lim = [] { const char* e = getenv("ESCX_ATTN_GS_TOKENS"); return e && e[0] ? atoi(e) : 0; }(); return (tokens_per_clip <= lim && n_groups % 3 == 0 && hiddenP >= 3 * Cp) ? 3 : 1; }
+// stream), for maps of up to 600 tokens per clip (the C = 384 scale of a 3 s clip; ESCX_ATTN_GS_TOKENS overrides, 0 = off).  Like the hidden
+// split it depends on the clip's geometry only, never on the batch.  Measured (tools/small_batch.py): one clip 3.52 -> 3.12 ms, 4 clips
+// 4.30 -> 3.90 ms, 8 clips 5.56 -> 5.19 ms; 36 clips 15.73 -> 15.86 ms (a wave holds one window pair and is MFMA-bound on its own: with
+// three workgroups per pair a small grid uses three times the CUs, a full grid gains nothing and pays the combine).
+static int attn_gs_for(int tokens_per_clip, int n_groups, int hiddenP, int Cp) { static const int lim = [] { const char* e = getenv("ESCX_ATTN_GS_TOKENS"); return e && e[0] ? atoi(e) : 600; }(); return (tokens_per_clip <= lim && n_groups % 3 == 0 && hiddenP >= 3 * Cp) ? 3 : 1; }
 static int mlp_variant_for(int M, int Cp) { return pick_nw((M + 15) / 16, 1, mlp_cap(Cp)) == 8 ? 3 : 1; }     // fused_swin.hip: 1 = (TM 1, NW 4), 3 = (TM 1, NW 8)
+// The hidden-split MLP at C >= 384: 8-wave workgroups when that fills one dispatch round anyway (36-clip batches: 255 workgroups, half the
+// weight DMA per wave), 4-wave ones for small grids - with 8 waves two waves share every SIMD's MFMA pipe and a 15-workgroup launch takes
+// as long as a 255-workgroup one (single clip: 197 us; 4 waves: one wave per SIMD).  A wave's rows and arithmetic are the same either way.
+// Measured (tools/small_batch.py, ms per encode+decode, 8-wave -> rule): B = 1 3.88 -> 3.52, B = 4 4.67 -> 4.30, B = 8 5.96 -> 5.60, B = 12 6.79 -> 6.64;
+// at 8 clips per part (225 four-wave workgroups) the two forms cross over.
+static int mlp_split_nw(int M, int hs) {
+    const long long tiles = (M + 15) / 16;
+    return ((tiles + 3) / 4) * hs <= 192 ? 4 : 8;
+}
 
 // One TransformerLayer on padded token maps.  x_in is read-only; y receives (B, H'*W, CoutP).
 // attention.py:48-91 (layer), 129-178 (block): LN1 -> pad -> roll -> windows -> attention -> reverse -> residual -> MLP.
@@ -1039,7 +1050,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             static const int tm2_max = [] { const char* e = getenv("ESCX_MLP_TM2_MAXCP"); return e && e[0] ? atoi(e) : 0; }();
             static const int tm2_nw8 = [] { const char* e = getenv("ESCX_MLP_TM2_NW8"); return e && e[0] == '1'; }();
             int hs = (h->mlp_hs > 0 && L.hiddenP >= h->mlp_hs * L.Cp) ? h->mlp_hs : mlp_hs_for(tokens, L.hiddenP / 16, L.Cp);
-            const int variant = h->mlp_variant >= 0 ? h->mlp_variant : (hs > 1 ? (L.Cp >= hs_nw8_cp ? 3 : 1) : (L.Cp <= tm2_max ? (tm2_nw8 ? 5 : 4) : mlp_variant_for(M, L.Cp)));
+            const int variant = h->mlp_variant >= 0 ? h->mlp_variant : (hs > 1 ? ((L.Cp >= hs_nw8_cp && mlp_split_nw(M, hs) == 8) ? 3 : 1) : (L.Cp <= tm2_max ? (tm2_nw8 ? 5 : 4) : mlp_variant_for(M, L.Cp)));
             PROF("mlp_fused" + tag, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
                  frc = mlp_fused(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP, variant, &hs, h->hid, st));
             if (frc == 0 && hs > 1)
