@@ -987,11 +987,13 @@ static int attn_cap(int Cp, int tmw) { const int v = Cp * tmw; return v <= 96 ? 
 // The partial sums live in the (otherwise unused) hidden-activation buffer of the unfused path: needs hiddenP >= 3 * Cp.
 static int mlp_hs_for(int tokens_per_clip, int HT, int Cp) { return (tokens_per_clip <= 1200 && HT % 3 == 0 && HT * 16 >= 3 * Cp) ? 3 : 1; }
 // The same split over the head groups of the fused attention (partials share the buffer; an MLP always follows on the same
-// stream), for maps of up to 600 tokens per clip (the C = 384 scale of a 3 s clip; ESCX_ATTN_GS_TOKENS overrides, 0 = off).  Like the hidden
-// split it depends on the clip's geometry only, never on the batch.  Measured (tools/small_batch.py): one clip 3.52 -> 3.12 ms, 4 clips
-// 4.30 -> 3.90 ms, 8 clips 5.56 -> 5.19 ms; 36 clips 15.73 -> 15.86 ms (a wave holds one window pair and is MFMA-bound on its own: with
-// three workgroups per pair a small grid uses three times the CUs, a full grid gains nothing and pays the combine).
-static int attn_gs_for(int tokens_per_clip, int n_groups, int hiddenP, int Cp) { static const int lim = [] { const char* e = getenv("ESCX_ATTN_GS_TOKENS"); return e && e[0] ? atoi(e) : 600; }(); return (tokens_per_clip <= lim && n_groups % 3 == 0 && hiddenP >= 3 * Cp) ? 3 : 1; }
+// stream).  Like the hidden split it would have to depend on the clip's geometry only, never on the batch (it re-associates the projection
+// sum).  Measured with ESCX_ATTN_GS_TOKENS=600 (the C = 384 scale of a 3 s clip; tools/small_batch.py): one clip 3.52 -> 3.12 ms, 4 clips
+// 4.30 -> 3.90, 8 clips 5.56 -> 5.19 ms, but 36 clips 15.73 -> 15.86 ms and 288 clips 121.3 -> 123.3 ms (a wave holds one window pair and is
+// MFMA-bound on its own: three workgroups per pair put a small grid on three times the CUs, a full grid gains nothing and pays the
+// combine).  The throughput configurations are the ones BASELINE quotes, so the split is OFF by default; all parity tests and the
+// 576-clip sweep are bit-exact with it on, a latency-bound deployment can switch it on.
+static int attn_gs_for(int tokens_per_clip, int n_groups, int hiddenP, int Cp) { static const int lim = [] { const char* e = getenv("ESCX_ATTN_GS_TOKENS"); return e && e[0] ? atoi(e) : 0; }(); return (tokens_per_clip <= lim && n_groups % 3 == 0 && hiddenP >= 3 * Cp) ? 3 : 1; }
 static int mlp_variant_for(int M, int Cp) { return pick_nw((M + 15) / 16, 1, mlp_cap(Cp)) == 8 ? 3 : 1; }     // fused_swin.hip: 1 = (TM 1, NW 4), 3 = (TM 1, NW 8)
 // The hidden-split MLP at C >= 384: 8-wave workgroups when that fills one dispatch round anyway (36-clip batches: 255 workgroups, half the
 // weight DMA per wave), 4-wave ones for small grids - with 8 waves two waves share every SIMD's MFMA pipe and a 15-workgroup launch takes
