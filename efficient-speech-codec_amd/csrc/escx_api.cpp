@@ -989,7 +989,7 @@ static int mlp_hs_for(int tokens_per_clip, int HT, int Cp) { return (tokens_per_
 // The same split over the head groups of the fused attention (partials share the buffer; an MLP always follows on the same
 // stream).  Like the hidden split it would have to depend on the clip's geometry only, never on the batch (it re-associates the projection
 // sum).  Measured with ESCX_ATTN_GS_TOKENS=600 (the C = 384 scale of a 3 s clip; tools/small_batch.py): one clip 3.52 -> 3.12 ms, 4 clips
-// 4.30 -> 3.90, 8 clips 5.56 -> 5.19 ms, but 36 clips 15.73 -> 15.86 ms and 288 clips 121.3 -> 123.3 ms (a wave holds one window pair and is
+// 4.30 -> 3.90, 8 clips 5.56 -> 5.19 ms, but 36 clips +0.2 .. 0.8 % and 288 clips 121.4 -> 123.5 ms in same-box A/B runs (a wave holds one window pair and is
 // MFMA-bound on its own: three workgroups per pair put a small grid on three times the CUs, a full grid gains nothing and pays the
 // combine).  The throughput configurations are the ones BASELINE quotes, so the split is OFF by default; all parity tests and the
 // 576-clip sweep are bit-exact with it on, a latency-bound deployment can switch it on.
