@@ -21,8 +21,8 @@ sys.path.insert(0, HERE)
 import gen_golden as gg  # noqa: E402
 
 WEIGHTS = dict(cm_weight=0.25, cb_weight=1.0, mel_weight=0.25, stft_weight=1.0)        # configs/9kbps_esc_base.yaml:29-33
-CASES = {"tiny": [(1, False), (2, False), (3, False), (3, True)], "base": [(1, False), (3, False), (6, False), (6, True)]}
-N_SAMPLES = {"tiny": 1260, "base": 47920}            # even frame count: raw_feat and recon_feat have the same T (the trainers' clips are cut that way)
+CASES = {"tiny": [(1, False), (2, False), (3, False), (3, True)], "base": [(1, False), (3, False), (6, False), (6, True)], "large": [(6, False)]}
+N_SAMPLES = {"tiny": 1260, "base": 47920, "large": 47920}            # even frame count: raw_feat and recon_feat have the same T (the trainers' clips are cut that way)
 FULL_GRADS = {   # parameters whose whole gradient is stored (small ones from every kind of layer)
     "tiny": ["quantizers.1.vqs.0.embedding.weight", "quantizers.0.down_projs.1.weight", "quantizers.2.up_projs.2.weight",
              "encoder.patch_embed.proj.weight", "encoder.pre_nn.swint_blocks.1.attn.relative_position_bias_table",
@@ -32,6 +32,7 @@ FULL_GRADS = {   # parameters whose whole gradient is stored (small ones from ev
     "base": ["quantizers.5.vqs.1.embedding.weight", "encoder.patch_embed.proj.weight", "encoder.pre_nn.swint_blocks.1.attn.relative_position_bias_table",
              "encoder.blocks.4.swint_blocks.0.attn.qkv.bias", "decoder.blocks.2.swint_blocks.1.norm2.weight", "decoder.patch_deembed.de_proj2.weight",
              "decoder.post_nn.swint_blocks.0.mlp.linear_1.bias", "quantizers.3.down_projs.0.weight"],
+    "large": ["encoder.patch_embed.proj.weight", "decoder.patch_deembed.de_proj2.weight", "quantizers.0.down_projs.0.weight"],       # ESC-Large: the adversarial trainer's generator
 }
 
 
@@ -43,8 +44,10 @@ def main():
     losses = importlib.import_module("esc.modules")
     mel_fn, stft_fn = losses.MelSpectrogramLoss(), losses.ComplexSTFTLoss()
     out = {"weights_json": np.array(json.dumps(WEIGHTS)), "cases_json": np.array(json.dumps(CASES)), "n_samples_json": np.array(json.dumps(N_SAMPLES))}
-    for name in ("tiny", "base"):
-        cfg = gg.TINY_CFG if name == "tiny" else yaml.safe_load(open(f"{gg.ref_shims.REFERENCE_ROOT}/configs/9kbps_esc_base.yaml"))["model"]
+    only = sys.argv[1:]                     # e.g. `python oracle/gen_train_golden.py large`: add / refresh these configurations, keep the rest of the file
+    old = dict(np.load(os.path.join(gg.GOLD, "train.npz"))) if only and os.path.exists(os.path.join(gg.GOLD, "train.npz")) else {}
+    for name in (only or ("tiny", "base", "large")):
+        cfg = gg.TINY_CFG if name == "tiny" else yaml.safe_load(open(f"{gg.ref_shims.REFERENCE_ROOT}/configs/9kbps_esc_{name}.yaml"))["model"]
         model, manifest = gg.build_reference(ref_models, cfg)
         model.train()
         tags = [f"train-{name}-0", f"train-{name}-1"]
@@ -75,7 +78,7 @@ def main():
                 out[f"{tag}_g::{k}"] = (torch.zeros_like(params[k]) if g is None else g).numpy().astype(np.float32)
             print(tag, "loss", out[f"{tag}_loss"], "cm", out[f"{tag}_cm"], "mel", out[f"{tag}_mel"], "stft", out[f"{tag}_stft"],
                   "total grad norm", float(np.sqrt((out[f"{tag}_gnorm"] ** 2).sum())))
-    np.savez_compressed(os.path.join(gg.GOLD, "train.npz"), **out)
+    np.savez_compressed(os.path.join(gg.GOLD, "train.npz"), **{**old, **out})
 
 
 if __name__ == "__main__":

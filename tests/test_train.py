@@ -79,7 +79,7 @@ def _check_against_fixture(g, tag, keys, losses, codes, grads, grad_tol):
 
 
 # ------------------------------------------------------------------------------------------------ CPU: the oracle is pinned
-@pytest.mark.parametrize("name,cases", [("tiny", None), ("base", [(3, False)])])
+@pytest.mark.parametrize("name,cases", [("tiny", None), ("base", [(3, False)]), ("large", None)])
 def test_oracle_training_step_matches_reference(name, cases):
     g = load_golden("train")
     keys = json.loads(str(g[f"{name}_keys"]))
@@ -95,7 +95,7 @@ def test_oracle_training_step_matches_reference(name, cases):
 def test_train_fixture_covers_every_parameter():
     g = load_golden("train")
     from esc.models import make_model
-    for name in ("tiny", "base"):
+    for name in ("tiny", "base", "large"):
         keys = json.loads(str(g[f"{name}_keys"]))
         model = make_model(_cfg(name))
         assert keys == [k for k, _ in model.named_parameters()] or set(keys) == {k for k, _ in model.named_parameters()}
@@ -242,7 +242,7 @@ def test_backward_pass_esc_large():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["tiny", "base"])
+@pytest.mark.parametrize("name", ["tiny", "base", "large"])
 def test_training_step_losses_and_every_gradient(name):
     """The trainer's step (trainer_no_adv.py:105-115): losses 1e-5 relative to the reference fixtures, codes identical; every parameter
     gradient against the fp64 oracle within 4x the reference restatement's own fp32 noise floor (envelope over three fp32 realisations, see
