@@ -271,3 +271,91 @@ def test_other_discriminator_configurations_and_lengths(cfg, B, L):
     assert _rel(fk.grad.cpu().numpy(), of.grad.numpy()) < max(1e-4, 3.0 * _rel(of32.grad.numpy(), of.grad.numpy()))
     print(f"[disc cfg {cfg['periods']}/{cfg['fft_sizes']} B={B} L={L}] fmaps {worst:.2e}, gradients median {np.median(list(errs.values())):.2e} "
           f"max {max(errs.values()):.2e}, d_fake {_rel(fk.grad.cpu().numpy(), of.grad.numpy()):.2e}")
+
+
+# ------------------------------------------------------------------------------------------------ the whole adversarial step vs the reference
+def _adv_setup():
+    """Fixture of ONE adversarial step of the real reference (oracle/gen_adv_golden.py -> tests/golden/adv.npz: trainer_adv.py:61-107 with its own
+    four discriminator passes): configurations, name-keyed synthetic weights of generator and discriminator, the two clips."""
+    from esc.models.codecs import state_manifest
+    from esc.models import make_model
+    g = load_golden("adv")
+    cfg, dcfg, w = json.loads(str(g["model_cfg_json"])), json.loads(str(g["disc_cfg_json"])), json.loads(str(g["weights_json"]))
+    model = make_model(cfg)
+    sd = {}
+    for k, shp in state_manifest(model.cfg).items():
+        v = synth.synth_tensor(k, shp)
+        if k.endswith(".window"):
+            v = torch.hann_window(shp[0]).numpy()
+        sd[k] = torch.from_numpy(np.ascontiguousarray(v))
+    model.load_state_dict(sd, strict=True)
+    L = int(g["n_samples"]); tags = json.loads(str(g["tags_json"]))
+    x = torch.from_numpy(synth.pcm_to_float(np.stack([synth.noise_clip_int16(tags[0], L), synth.voiced_clip_int16(tags[1], L)])))
+    return g, cfg, dcfg, w, model, sd, disc_state(), x
+
+
+def _gnorm_check(got, ref, what, rel):
+    """Per-parameter gradient norms against the fixture; `rel` of the parameter's own norm or of the typical norm, whichever is larger
+    (the adversarial losses inherit the fp32 conditioning of the spectral losses, tests/test_train.py)."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    floor = float(np.sqrt((ref ** 2).mean()))
+    bad = np.abs(got - ref) > rel * np.maximum(ref, 0.05 * floor)
+    worst = float((np.abs(got - ref) / np.maximum(ref, 0.05 * floor)).max())
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {len(ref)} gradient norms off, worst rel {worst:.3e}"
+    np.testing.assert_allclose(np.sqrt((got ** 2).sum()), np.sqrt((ref ** 2).sum()), rtol=rel)
+    print(f"[adversarial step, {what}] {len(ref)} gradient norms vs the reference: worst rel {worst:.2e}, total norm rel "
+          f"{abs(np.sqrt((got ** 2).sum()) / np.sqrt((ref ** 2).sum()) - 1):.2e}")
+
+
+def test_oracle_adversarial_step_matches_reference():
+    from oracle import esc_oracle as O
+    g, cfg, dcfg, w, model, sd, dsd, x = _adv_setup()
+    leaf = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not k.endswith(".window")) else v) for k, v in sd.items()}
+    dleaf = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
+    ocfg = dict(O.DISC_DEFAULT, **{k: v for k, v in dcfg.items() if k != "sample_rate"})
+    out = O.EscOracle(cfg, leaf, keep_graph=True).forward_train(x, int(g["streams"]), False)
+    mel = O.mel_spectrogram_loss(out["raw_audio"], out["recon_audio"])
+    lg, lf = O.gan_generator_loss(out["recon_audio"], out["raw_audio"], dleaf, ocfg)
+    total = out["cm_loss"] * w["cm_weight"] + out["cb_loss"] * w["cb_weight"] + mel * w["mel_weight"] + lg * w["gen_weight"] + lf * w["feat_weight"]
+    total.mean().backward()
+    assert np.array_equal(out["codes"].numpy(), g["codes"].astype(np.int64))
+    for name, val in (("cm", out["cm_loss"]), ("mel", mel), ("gen", lg), ("feat", lf), ("loss", total)):
+        np.testing.assert_allclose(val.detach().numpy(), g[name], rtol=2e-5, err_msg=name)
+    gk = json.loads(str(g["gen_keys_json"]))
+    _gnorm_check([0.0 if leaf[k].grad is None else float(leaf[k].grad.double().norm()) for k in gk], g["gen_gnorm"], "generator", 2e-4)
+    for v in dleaf.values():
+        v.grad = None
+    dl = O.gan_discriminator_loss(out["recon_audio"].detach(), out["raw_audio"], dleaf, ocfg)
+    dl.mean().backward()
+    np.testing.assert_allclose(dl.detach().numpy(), g["disc_loss"], rtol=2e-5)
+    dk = json.loads(str(g["disc_keys_json"]))
+    _gnorm_check([float(dleaf[k].grad.double().norm()) for k in dk], g["disc_gnorm"], "discriminator", 2e-4)
+
+
+@pytest.mark.gpu
+def test_adversarial_step_with_shared_passes_equals_the_references_four_pass_step():
+    """The product runs the discriminator twice per step and serves both updates from those passes (GANLoss.adversarial_forward); the
+    reference runs it four times (trainer_adv.py:76-78, 98-100).  Same losses (1e-5) and the same gradients as the reference's step."""
+    from esc.models import Discriminator
+    from esc.modules import GANLoss, MelSpectrogramLoss
+    g, cfg, dcfg, w, model, sd, dsd, x = _adv_setup()
+    model = model.cuda().train()
+    disc = Discriminator(**dcfg).cuda().train()
+    disc.load_state_dict(dsd)
+    gan = GANLoss(disc)
+    out = model(**dict(x=x.cuda(), x_feat=None, num_streams=int(g["streams"]), freeze_codebook=False))
+    mel = MelSpectrogramLoss()(out["raw_audio"], out["recon_audio"])
+    d_fake, d_real = gan.adversarial_forward(fake=out["recon_audio"], real=out["raw_audio"])
+    lg, lf = gan.generator_loss_from(d_fake, d_real)
+    total = out["cm_loss"] * w["cm_weight"] + out["cb_loss"] * w["cb_weight"] + mel * w["mel_weight"] + lg * w["gen_weight"] + lf * w["feat_weight"]
+    total.mean().backward()
+    assert np.array_equal(out["codes"].cpu().numpy(), g["codes"].astype(np.int64))
+    for name, val in (("cm", out["cm_loss"]), ("mel", mel), ("gen", lg), ("feat", lf), ("loss", total)):
+        np.testing.assert_allclose(val.detach().cpu().numpy(), g[name], rtol=2e-5, err_msg=name)
+    gp = dict(model.named_parameters())
+    _gnorm_check([0.0 if gp[k].grad is None else float(gp[k].grad.double().norm()) for k in json.loads(str(g["gen_keys_json"]))], g["gen_gnorm"], "generator", 1e-3)          # measured 6e-6
+    assert all(p.grad is None for p in disc.parameters()), "the generator update must not leave discriminator gradients behind"
+    dl = gan.discriminator_backward_from(d_fake, d_real)
+    np.testing.assert_allclose(dl.cpu().numpy(), g["disc_loss"], rtol=2e-5)
+    dp = dict(disc.named_parameters())
+    _gnorm_check([float(dp[k].grad.double().norm()) for k in json.loads(str(g["disc_keys_json"]))], g["disc_gnorm"], "discriminator", 2e-3)      # measured 6e-5
