@@ -359,3 +359,78 @@ def test_adversarial_step_with_shared_passes_equals_the_references_four_pass_ste
     np.testing.assert_allclose(dl.cpu().numpy(), g["disc_loss"], rtol=2e-5)
     dp = dict(disc.named_parameters())
     _gnorm_check([float(dp[k].grad.double().norm()) for k in json.loads(str(g["disc_keys_json"]))], g["disc_gnorm"], "discriminator", 2e-3)      # measured 6e-5
+
+
+# ------------------------------------------------------------------------------------------------ a second configuration from the real reference
+def _alt_setup():
+    g = load_golden("disc_alt")
+    cfg = json.loads(str(g["cfg_json"]))
+    man = json.loads(str(g["manifest_json"]))
+    out = {}
+    for k, shp in man.items():
+        u = synth.hashed_uniform(k, int(np.prod(shp))).reshape(shp)
+        if k.endswith("weight_v"):
+            out[k] = (u / math.sqrt(int(np.prod(shp[1:])))).astype(np.float32)
+        elif k.endswith("bias"):
+            out[k] = (0.05 * u).astype(np.float32)
+    for k, shp in man.items():
+        if k.endswith("weight_g"):
+            v = out[k[:-1] + "v"]
+            nrm = np.sqrt((v.reshape(shp[0], -1).astype(np.float64) ** 2).sum(1)).reshape(shp)
+            out[k] = (nrm * (1.0 + 0.5 * synth.hashed_uniform(k, int(np.prod(shp))).reshape(shp))).astype(np.float32)
+    sd = {k: torch.from_numpy(out[k]) for k in man}
+    L, B = int(g["n_samples"]), int(g["batch"])
+    real = torch.from_numpy(synth.pcm_to_float(np.stack([synth.voiced_clip_int16(f"dalt-real-{i}", L) for i in range(B)])))
+    fake = 0.7 * real + torch.from_numpy(synth.pcm_to_float(np.stack([synth.noise_clip_int16(f"dalt-fake-{i}", L, amp=0.03) for i in range(B)])))
+    return g, cfg, sd, real, fake
+
+
+def _alt_check(g, ld, lg, lf, d_fake, gnorm, fm_rms, tol_g):
+    np.testing.assert_allclose(ld, g["disc_loss"], rtol=2e-5); np.testing.assert_allclose(lg, g["gen_loss"], rtol=2e-5); np.testing.assert_allclose(lf, g["feat_loss"], rtol=2e-5)
+    assert _rel(d_fake, g["d_fake"]) < 2e-4
+    ref = g["disc_gnorm"]; floor = float(np.sqrt((ref ** 2).mean()))
+    assert float((np.abs(np.asarray(gnorm) - ref) / np.maximum(ref, 0.05 * floor)).max()) < tol_g
+    for i, row in enumerate(fm_rms):
+        np.testing.assert_allclose(row, g["fmap_rms"][i][: len(row)], rtol=1e-4)
+
+
+def test_oracle_second_discriminator_configuration_matches_reference():
+    """periods [3, 7], windows [512, 256], two bands, three clips of 6001 samples - from the REAL reference (oracle/gen_disc_alt_golden.py)."""
+    from oracle import esc_oracle as O
+    g, cfg, sd, real, fake = _alt_setup()
+    ocfg = dict(O.DISC_DEFAULT, **{k: v for k, v in cfg.items() if k != "sample_rate"})
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ld = O.gan_discriminator_loss(fake, real, leaf, ocfg)
+    ld.mean().backward()
+    gn = [float(leaf[k].grad.double().norm()) for k in json.loads(str(g["keys_json"]))]
+    fk = fake.clone().requires_grad_(True)
+    lg, lf = O.gan_generator_loss(fk, real, {k: v.detach() for k, v in leaf.items()}, ocfg)
+    (lg + 2.0 * lf).mean().backward()
+    fm = O.discriminator_forward(fake.unsqueeze(1), sd, ocfg)
+    assert [[list(t.shape) for t in f] for f in fm] == json.loads(str(g["fmap_shapes_json"]))
+    _alt_check(g, ld.detach().numpy(), lg.detach().numpy(), lf.detach().numpy(), fk.grad.numpy(), gn,
+               [[float(t.double().pow(2).mean().sqrt()) for t in f] for f in fm], 2e-3)
+
+
+@pytest.mark.gpu
+def test_second_discriminator_configuration_against_the_reference_fixture():
+    from esc.models import Discriminator
+    from esc.modules import GANLoss
+    g, cfg, sd, real, fake = _alt_setup()
+    disc = Discriminator(**{**cfg, "bands": [tuple(b) for b in cfg["bands"]]}).cuda()
+    assert set(sd) == set(disc.state_dict())
+    disc.load_state_dict(sd)
+    gan = GANLoss(disc)
+    ld = gan.discriminator_loss(fake.cuda(), real.cuda())
+    ld.mean().backward()
+    dp = dict(disc.named_parameters())
+    gn = [float(dp[k].grad.double().norm()) for k in json.loads(str(g["keys_json"]))]
+    disc.zero_grad()
+    fk = fake.cuda().clone().requires_grad_(True)
+    lg, lf = gan.generator_loss(fk, real.cuda())
+    (lg + 2.0 * lf).mean().backward()
+    with torch.no_grad():
+        fm = disc(fake.cuda().unsqueeze(1))
+    assert [[list(t.shape) for t in f] for f in fm] == json.loads(str(g["fmap_shapes_json"]))
+    _alt_check(g, ld.detach().cpu().numpy(), lg.detach().cpu().numpy(), lf.detach().cpu().numpy(), fk.grad.cpu().numpy(), gn,
+               [[float(t.double().pow(2).mean().sqrt()) for t in f] for f in fm], 5e-3)
