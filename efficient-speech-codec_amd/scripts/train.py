@@ -38,9 +38,8 @@ def lr_at(step: int, base_lr: float, kind: str, total_steps: int, warmup_steps: 
     """constant | constant_warmup | cosine_warmup | exponential_decay (the four schedules of scripts/utils.py:52-65)."""
     if kind == "constant":
         return base_lr
-    warm = min(1.0, (step + 1) / max(1, warmup_steps)) if warmup_steps > 0 else 1.0
-    if kind == "constant_warmup":
-        return base_lr * warm
+    if kind == "constant_warmup":               # transformers.get_constant_schedule_with_warmup: step / warmup while step < warmup (0 at the first step)
+        return base_lr * (step / max(1, warmup_steps) if step < warmup_steps else 1.0)
     if kind == "cosine_warmup":
         if step < warmup_steps:
             return base_lr * step / max(1, warmup_steps)

@@ -375,12 +375,24 @@ def test_train_harness_schedules_and_stream_sampling():
     with pytest.raises(AssertionError):
         sample_streams(rng, 1.5, 6)
     assert lr_at(10, 1e-4, "constant", 100, 0) == 1e-4
-    assert lr_at(0, 1e-4, "constant_warmup", 100, 10) == pytest.approx(1e-5) and lr_at(50, 1e-4, "constant_warmup", 100, 10) == 1e-4
+    assert lr_at(1, 1e-4, "constant_warmup", 100, 10) == pytest.approx(1e-5) and lr_at(50, 1e-4, "constant_warmup", 100, 10) == 1e-4
     assert lr_at(5, 1e-4, "cosine_warmup", 100, 10) == pytest.approx(5e-5) and lr_at(100, 1e-4, "cosine_warmup", 100, 10) == pytest.approx(0.0, abs=1e-12)
     assert lr_at(55, 1e-4, "cosine_warmup", 100, 10) == pytest.approx(5e-5)
     assert lr_at(1000, 1e-4, "exponential_decay", 0, 0) == pytest.approx(1e-4 * 0.999996 ** 1000)
     with pytest.raises(ValueError):
         lr_at(0, 1e-4, "linear", 1, 0)
+    # the schedulers the reference builds (scripts/utils.py:52-65: transformers' schedules and ExponentialLR), stepped once per optimiser step
+    transformers = pytest.importorskip("transformers")
+    for kind, total, warm in (("constant", 50, 0), ("constant_warmup", 50, 7), ("cosine_warmup", 60, 9), ("exponential_decay", 50, 0)):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], 3e-4)
+        sch = {"constant": lambda: transformers.get_constant_schedule(opt),
+               "constant_warmup": lambda: transformers.get_constant_schedule_with_warmup(opt, num_warmup_steps=warm),
+               "cosine_warmup": lambda: transformers.get_cosine_schedule_with_warmup(opt, num_warmup_steps=warm, num_training_steps=total),
+               "exponential_decay": lambda: torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.999996)}[kind]()
+        for n in range(total):
+            assert opt.param_groups[0]["lr"] == pytest.approx(lr_at(n, 3e-4, kind, total, warm), rel=1e-9, abs=1e-15), (kind, n)
+            opt.step(); sch.step()
 
 
 @pytest.mark.gpu
