@@ -2,13 +2,18 @@
 """ESC-Base 9 kbps encode+decode throughput on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8                      # launches its own 8 ranks (re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = ESC.encode (STFT -> encoder -> 6 cross-scale VQ streams) + [N>1: all-gather of the codes over RCCL] +
-ESC.decode (de-quantise -> decoder -> ISTFT) on 36 synthetic 3 s / 16 kHz clips per GPU (BASELINE configs[1]; at N=8
-this is configs[3]: 288 clips).  Default = weak scaling: per-GPU work is fixed.  `--global-batch 288` is the STRONG-scaling mode
-of SURVEY 8(d) config 4: the batch is fixed, rank r takes shard_bounds(288, N, r) clips, "scaling": "strong"; at N=1 it is the
-whole 288-clip batch on one GPU.  Inputs are resident in HBM before the timed region.
+ESC.decode (de-quantise -> decoder -> ISTFT).
+  N = 1 (default): 36 synthetic 3 s / 16 kHz clips = BASELINE configs[1], the configuration the metric is quoted on.
+  N > 1 (default): the FIXED 288-clip job of BASELINE configs[3] / SURVEY 8(d) config 4, rank r takes shard_bounds(288, N, r)
+         clips, "scaling": "strong" (the >= 6x target at 8 GPUs is stated on this job; at N = 8 every rank holds 36 clips).
+  --weak: 36 clips per rank at any N ("scaling": "weak");  --global-batch B: any fixed job size (also at N = 1).
+`--gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself; it refuses to run when the node has fewer
+than N devices, and `n_gpus` in the JSON line is the size of the communicator, never the flag.
+Inputs are resident in HBM before the timed region.
 Weights are the deterministic name-keyed synthetic ESC-Base weights (no checkpoints exist offline); fp32 throughout.
 """
 import argparse
@@ -31,6 +36,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 CLIPS_PER_GPU = 36
+NODE_BATCH = 288                   # BASELINE configs[3] / SURVEY 8(d) config 4: the fixed job of the strong-scaling curve
 N_SAMPLES = 48000
 NUM_STREAMS = 6
 FLOP_PER_CLIP = 56.75e9            # BASELINE.md section 3 (2xMAC over linear/bmm/conv, S=6)
@@ -77,6 +83,77 @@ def shard_plan(global_batch, world, rank):
     counts = [shard_bounds(global_batch, world, r)[1] - shard_bounds(global_batch, world, r)[0] for r in range(world)]
     lo, hi = shard_bounds(global_batch, world, rank)
     return lo, hi - lo, counts
+
+
+def resolve_job(world, global_batch=0, weak=False):
+    """(strong?, clips of the whole job).  One GPU: BASELINE configs[1] (36 clips).  Several GPUs: the fixed 288-clip job of configs[3]
+    unless --weak (36 clips per rank) or an explicit --global-batch."""
+    if weak and global_batch > 0:
+        raise SystemExit("bench.py: --weak and --global-batch exclude each other")
+    if global_batch > 0:
+        return True, int(global_batch)
+    if weak or world == 1:
+        return False, CLIPS_PER_GPU * world
+    return True, NODE_BATCH
+
+
+def launcher_command(argv, n, port):
+    """The command line the driver itself uses for N > 1: one rank per GPU of ONE node, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks ourselves.  Never shrinks the job
+    silently: fewer than N devices on the node is an error (exit status 1)."""
+    import subprocess
+    have = args.gpus if args.dry_run else (torch.cuda.device_count() if torch.cuda.is_available() else 0)
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {have} HIP device(s); refusing to run a {args.gpus}-GPU job on fewer "
+                         "devices (one process per GPU, no oversubscription)")
+    cmd = launcher_command(argv, args.gpus, _free_port())
+    print("# bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.run(cmd).returncode)
+
+
+def run_dry(args, rank, world):
+    """--dry-run: launcher, job resolution, shard plan and the code all-gather on CPU ranks (gloo), no model and no timing claim: the
+    "codes" of clip g are a function of g, so that every rank can check the gathered batch.  Test infrastructure (tests/test_bench_launch.py)."""
+    from esc.distributed import all_gather_codes
+    strong, total = resolve_job(world, args.global_batch, args.weak)
+    if strong:
+        first, n_local, counts = shard_plan(total, world, rank)
+    else:
+        first, n_local, counts = rank * CLIPS_PER_GPU, CLIPS_PER_GPU, [CLIPS_PER_GPU] * world
+    if n_local < 1:
+        raise SystemExit(f"--global-batch {total} leaves rank {rank} of {world} without clips")
+    fake = lambda lo, n: ((torch.arange(lo, lo + n).view(n, 1, 1, 1) * 7 + torch.arange(NUM_STREAMS * 3 * 150).view(1, NUM_STREAMS, 3, 150)) % 1024).to(torch.int64)
+    allc = all_gather_codes(fake(first, n_local), force=world > 1, counts=counts)
+    assert torch.equal(allc, fake(0, total) if world > 1 else fake(first, n_local)), "gathered codes are not the whole batch in rank order"
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "audio-seconds/sec encode+decode, ESC-Base 9kbps 3s@16kHz", "value": None, "unit": "audio-seconds/sec",
+                          "n_gpus": dist.get_world_size(), "steps": 0, "warmup": 0, "scaling": "strong" if strong else "weak", "dry_run": True,
+                          "config": {"workload": workload_name(strong, total, world, counts), "global_batch": total,
+                                     "clips_per_rank": counts, "parallelism": f"dp{world}" + (" + all_gather(codes int16)" if world > 1 else "")}}))
+
+
+def workload_name(strong, total, world, counts):
+    if strong:
+        tag = "BASELINE configs[3], fixed batch" if total == NODE_BATCH else "fixed batch"
+        return (f"ESC-Base 9kbps, batch={total} 3-sec 16kHz clips sharded over {world} GPU(s) ({min(counts)}-{max(counts)} per rank), "
+                f"num_streams=6, encode+decode ({tag})")
+    return (f"ESC-Base 9kbps, batch={CLIPS_PER_GPU} 3-sec 16kHz clips per GPU, num_streams=6, encode+decode "
+            f"(BASELINE configs[{1 if world == 1 else 3}])")
 
 
 def cpu_baseline(cfg, sd, x_cpu):
@@ -206,6 +283,7 @@ def run_train(args, rank, world, device, use_dist):
     x = x_cpu.to(device)
     mel_fn, stft_fn = MelSpectrogramLoss(), ComplexSTFTLoss()
     opt = FlatAdamW(model, lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, max_grad_norm=0.5, device=device)
+    opt.force_allreduce = use_dist        # ESCX_BENCH_FORCE_DIST=1 with one rank: the flat-gradient all-reduce still goes through RCCL
     w = TRAIN_WEIGHTS
 
     def step():
@@ -262,13 +340,13 @@ def run_train(args, rank, world, device, use_dist):
     audio_s = CLIPS_PER_GPU * world * args.steps * (TRAIN_SAMPLES / 16000.0)
     roofline["whole_step_frac_executed_flops"] = round(roofline["executed_gflop_per_clip"] * 1e9 * CLIPS_PER_GPU * args.steps / elapsed / PEAK_F32_MFMA, 4)
     out = {"metric": "audio-seconds/sec trained (forward + mel/STFT/VQ losses + backward + clip + AdamW), ESC-Base 9kbps 3s@16kHz",
-           "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": (dist.get_world_size() if use_dist else 1), "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
            "config": {"workload": f"ESC-Base training step (scripts/trainer_no_adv.py:95-118, non-adversarial), batch={CLIPS_PER_GPU} clips of {TRAIN_SAMPLES} samples per GPU, "
                                   "num_streams=6, fp32 (the reference has no AMP); first slice of BASELINE configs[4]",
                       "global_batch": CLIPS_PER_GPU * world, "clip_samples": TRAIN_SAMPLES, "num_streams": NUM_STREAMS,
-                      "parallelism": f"dp{world}" + (" (independent replicas: no gradient all-reduce yet)" if world > 1 else ""),
+                      "parallelism": f"dp{world}" + (" (flat-gradient all-reduce over RCCL before the clip, esc.distributed.all_reduce_gradients)" if use_dist else ""),
                       "optimizer": "AdamW (flat, 2 kernels) + clip_grad_norm 0.5", "tape_gb": round(lib.escx_train_tape_bytes(hd) / 2 ** 30, 2),
                       "steps_per_sec": round(args.steps / elapsed, 3)},
            "roofline": roofline,
@@ -320,7 +398,7 @@ def run_train_adv(args, rank, world, device, use_dist):
     d_step_flops = d_flops * (2 + 1 + 2 * 2)
     audio_s = bsz * world * args.steps * (TRAIN_SAMPLES / 16000.0)
     out = {"metric": "audio-seconds/sec trained, adversarial step (generator + discriminator updates), ESC-Large 9kbps 3s@16kHz",
-           "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": (dist.get_world_size() if use_dist else 1), "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
            "config": {"workload": f"BASELINE configs[4]: ESC-Large 9kbps + adversarial training step (scripts/trainer_adv.py:61-107), batch={bsz} clips of "
@@ -349,8 +427,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--global-batch", type=int, default=0,
-                    help="strong scaling: fix the JOB's batch (e.g. 288 = BASELINE configs[3]) and shard it over the ranks; "
-                         "default 0 = weak scaling with 36 clips per rank")
+                    help="strong scaling: fix the JOB's batch and shard it over the ranks; default 0 = 36 clips (BASELINE configs[1]) on one GPU, "
+                         "the fixed 288-clip job of BASELINE configs[3] on several")
+    ap.add_argument("--weak", action="store_true", help="36 clips per rank at any N (weak scaling) instead of the fixed 288-clip job")
+    ap.add_argument("--dry-run", action="store_true", help="CPU ranks over gloo: launcher + job resolution + shard plan + code all-gather, no model (tests)")
     ap.add_argument("--profile-steps", type=int, default=6)
     ap.add_argument("--skip-single-clip", action="store_true",
                     help="omit the B=1 latency measurement (used under rocprofv3 / --pmc so that per-kernel averages cover the 36-clip launches only)")
@@ -360,11 +440,27 @@ def main():
     if args.steps is None:
         args.steps = {"codec": 200, "train": 20, "train_adv": 6}[args.mode]
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("ESCX_BENCH_SELF_LAUNCH") == "1"):
+        self_launch(args, sys.argv[1:])                                      # does not return (ESCX_BENCH_SELF_LAUNCH=1: also for one rank, tests)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the flag and the launcher disagree")
+    if args.dry_run:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()) if world == 1 else "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group(backend="gloo")
+        run_dry(args, rank, world)
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU implementation")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} (local rank {local_rank}) has no device: the node exposes {torch.cuda.device_count()} HIP device(s)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("ESCX_BENCH_FORCE_DIST") == "1"     # the latter: exercise RCCL with one rank
@@ -387,23 +483,38 @@ def main():
             dist.destroy_process_group()
         return
 
-    from esc.distributed import all_gather_codes
+    from esc.distributed import AbiCodesGather, all_gather_codes
     model, cfg, sd = build_model(device)
-    strong = args.global_batch > 0
+    n_ranks = dist.get_world_size() if use_dist else 1                       # what the JSON line reports: the communicator, not the flag
+    assert n_ranks == world
+    strong, total_clips = resolve_job(world, args.global_batch, args.weak)
     if strong:
-        first, n_local, counts = shard_plan(args.global_batch, world, rank)
+        first, n_local, counts = shard_plan(total_clips, world, rank)
         if n_local < 1:
-            raise SystemExit(f"--global-batch {args.global_batch} leaves rank {rank} of {world} without clips")
+            raise SystemExit(f"--global-batch {total_clips} leaves rank {rank} of {world} without clips")
     else:
         first, n_local, counts = None, CLIPS_PER_GPU, [CLIPS_PER_GPU] * world
-    total_clips = sum(counts)
+    assert total_clips == sum(counts)
     x_cpu = synth_batch(n_local, rank, first)
     x = x_cpu.to(device)
     model.reserve(n_local, N_SAMPLES, device)
+    # ESCX_BENCH_ABI_COLLECTIVE=1: the exchange step goes through the C ABI (escx_allgather_codes on a communicator of its own, created
+    # on the RCCL instance libescx resolves) instead of torch.distributed; equal shards only (one ncclAllGather, no padding protocol)
+    abi_gather = None
+    if use_dist and os.environ.get("ESCX_BENCH_ABI_COLLECTIVE") == "1":
+        if len(set(counts)) != 1:
+            raise SystemExit("ESCX_BENCH_ABI_COLLECTIVE=1 needs equal shards (escx_allgather_codes is one ncclAllGather)")
+        abi_gather = AbiCodesGather(model, device)
+    gather_on = use_dist and not os.environ.get("ESCX_BENCH_SKIP_GATHER")
 
     def step():
         codes, shape = model.encode(x, NUM_STREAMS)
-        allc = all_gather_codes(codes, force=use_dist, counts=counts) if (use_dist and not os.environ.get("ESCX_BENCH_SKIP_GATHER")) else codes
+        if not gather_on:
+            allc = codes
+        elif abi_gather is not None:
+            allc = abi_gather(codes)
+        else:
+            allc = all_gather_codes(codes, force=use_dist, counts=counts)
         wave = model.decode(codes, shape)
         return allc, wave
 
@@ -513,16 +624,12 @@ def main():
         audio_s = total_clips * args.steps * (N_SAMPLES / 16000.0)
         out = {
             "metric": "audio-seconds/sec encode+decode, ESC-Base 9kbps 3s@16kHz",
-            "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
+            "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": n_ranks, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"ESC-Base 9kbps, batch={total_clips} 3-sec 16kHz clips sharded over {world} GPU(s) "
-                                    f"({min(counts)}-{max(counts)} per rank), num_streams=6, encode+decode (BASELINE configs[3], fixed batch)")
-                                   if strong else
-                                   (f"ESC-Base 9kbps, batch={CLIPS_PER_GPU} 3-sec 16kHz clips per GPU, num_streams=6, "
-                                    f"encode+decode (BASELINE configs[{1 if world == 1 else 3}])"),
+            "config": {"workload": workload_name(strong, total_clips, world, counts),
                        "global_batch": total_clips, "clip_samples": N_SAMPLES, "num_streams": NUM_STREAMS,
-                       "parallelism": f"dp{world}" + (" + all_gather(codes int16)" if world > 1 else ""),
+                       "parallelism": f"dp{world}" + ((" + all_gather(codes int16" + (", escx_allgather_codes C ABI)" if abi_gather is not None else ", torch.distributed)")) if gather_on else ""),
                        "weights": "deterministic name-keyed synthetic (esc/synth.py)",
                        "frames_per_sec": round(audio_s / elapsed * 200.0, 1),
                        "single_clip_gpu": single_gpu},
@@ -539,6 +646,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+    if abi_gather is not None:
+        abi_gather.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -80,6 +80,66 @@ def all_gather_codes(codes_local: torch.Tensor, group: Optional[dist.ProcessGrou
     return widen_codes(torch.cat([p.view(torch.int16)[:c] for p, c in zip(parts, counts)], dim=0))
 
 
+class AbiCodesGather:
+    """The exchange step through the C ABI: `escx_allgather_codes` (csrc/collective.cpp) on an RCCL communicator of its own.
+
+    torch.distributed does not hand out its ncclComm_t, so the communicator is created here on the SAME RCCL instance libescx resolves
+    (`escx_set_rccl_library` is pointed at the library this class loaded): rank 0 draws the unique id, the id travels over the existing
+    torch.distributed group (bootstrap only), every rank calls ncclCommInitRank.  Equal shards only - it is one ncclAllGather."""
+
+    _NAMES = ("librccl.so.1", "librccl.so")
+
+    def __init__(self, model, device, group: Optional[dist.ProcessGroup] = None):
+        import os
+        from . import _native
+        self.lib, self.hd = model._handle(torch.device(device))
+        self.device = torch.device(device)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.rccl, tried = None, []
+        for name in self._NAMES + (os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so.1"):
+            try:
+                self.rccl = ctypes.CDLL(name)
+                rc = self.lib.escx_set_rccl_library(name.encode())
+                if rc not in (0, _native.ESCX_ERR_STATE):              # ERR_STATE: already resolved by an earlier collective (same search order)
+                    _native.check(rc)
+                break
+            except OSError as e:
+                tried.append(f"{name}: {e}")
+        if self.rccl is None:
+            raise ImportError("no RCCL library found: " + "; ".join(tried))
+
+        class UniqueId(ctypes.Structure):
+            _fields_ = [("internal", ctypes.c_char * 128)]
+        uid = UniqueId()
+        if self.rank == 0 and self.rccl.ncclGetUniqueId(ctypes.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        box = [bytes(bytearray(uid)) if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ctypes.memmove(ctypes.byref(uid), box[0], 128)
+        self.comm = ctypes.c_void_p()
+        self.rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+        with torch.cuda.device(self.device):
+            rc = self.rccl.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank)
+        if rc != 0:
+            raise RuntimeError(f"ncclCommInitRank failed with {rc}")
+
+    def __call__(self, codes_local: torch.Tensor) -> torch.Tensor:
+        from . import _native
+        c = codes_local.contiguous()
+        out = torch.empty((self.world * c.shape[0],) + tuple(c.shape[1:]), dtype=torch.int64, device=c.device)
+        with torch.cuda.device(self.device):
+            _native.check(self.lib.escx_allgather_codes(self.hd, ctypes.c_void_p(c.data_ptr()), c.numel(), ctypes.c_void_p(out.data_ptr()), self.world,
+                                                        self.comm, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        return out
+
+    def close(self):
+        if self.comm:
+            torch.cuda.synchronize(self.device)
+            self.rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            self.rccl.ncclCommDestroy(self.comm)
+            self.comm = ctypes.c_void_p()
+
+
 def encode_sharded(model, x_local: torch.Tensor, num_streams: int = 6, group: Optional[dist.ProcessGroup] = None,
                    counts: Optional[Sequence[int]] = None):
     """Each rank encodes its own clips; returns (codes of the WHOLE batch on every rank, local codes, feat_shape)."""
@@ -88,12 +148,12 @@ def encode_sharded(model, x_local: torch.Tensor, num_streams: int = 6, group: Op
 
 
 # ---- data-parallel training: gradient exchange ----------------------------------------------------------------------------
-def all_reduce_gradients(grad_flat: torch.Tensor, group: Optional[dist.ProcessGroup] = None, bucket_mb: float = 16.0) -> torch.Tensor:
+def all_reduce_gradients(grad_flat: torch.Tensor, group: Optional[dist.ProcessGroup] = None, bucket_mb: float = 16.0, force: bool = False) -> torch.Tensor:
     """Mean of the flat gradient buffer over the ranks, in place (what DDP does for `accel.backward`, /root/reference/scripts/
     trainer_no_adv.py:115).  The training backward leaves ALL gradients in one flat fp32 buffer (35 MB for ESC-Base, 62 MB for Large),
     so the exchange is a handful of large ring all-reduces instead of one per parameter: buckets of `bucket_mb` (xGMI is point-to-point,
     ~153 GB/s per link: 16 MB keeps every ring step well above the latency floor) issued asynchronously and awaited together."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):      # force: run the collective even with one rank (tests)
         return grad_flat
     world = dist.get_world_size(group)
     n = grad_flat.numel()

@@ -22,6 +22,7 @@ class FlatAdamW:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None, device=None, group=None):
         self.model, self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = model, lr, betas, eps, weight_decay, max_grad_norm
         self.group = group                   # data-parallel process group: gradients are averaged over it before clipping (DDP semantics)
+        self.force_allreduce = False         # run the gradient all-reduce even on a one-rank group (exercises RCCL on a 1-GPU box)
         dev = torch.device(device) if device is not None else next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("FlatAdamW works on the HIP device the model lives on")
@@ -42,7 +43,7 @@ class FlatAdamW:
         lib = _native.load()
         flat, gflat, m, v, aux = self._buffers()
         from .distributed import all_reduce_gradients
-        all_reduce_gradients(gflat, self.group)          # no-op unless torch.distributed is initialised with more than one rank
+        all_reduce_gradients(gflat, self.group, force=self.force_allreduce)     # no-op unless torch.distributed is initialised with more than one rank
         self.t += 1
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
