@@ -157,6 +157,7 @@ extern "C" void escx_destroy(escx_handle h) {
     if (h->garena) (void)hipFree(h->garena);
     if (h->grad_seg) (void)hipFree(h->grad_seg);
     if (h->tape.base) (void)hipFree(h->tape.base);
+    free_train_state(h);
     delete h;
 }
 
@@ -696,13 +697,9 @@ int escx::get_map(escx_handle_s* h, int H, int W, int shift, const int** out) {
             m[((size_t)h2 * W + w) * 2 + 1] = (2 * h2 + 1 < H) ? (2 * h2 + 1) * W + w : -1;
         }
     }
-    // Bounded cache: a caller that streams clips of many different lengths (scripts/test.py on a real data set) would otherwise
-    // grow device memory without limit.  Dropping every map needs the kernels that read them to have finished.
-    if (h->maps.size() >= 768) {
-        ESCX_HIP(hipDeviceSynchronize());
-        for (auto& kv : h->maps) (void)hipFree(kv.second);
-        h->maps.clear();
-    }
+    // The cache is bounded (a caller that streams clips of many different lengths, scripts/test.py on a real data set, would otherwise grow
+    // device memory without limit), but nothing is evicted HERE: a launch sequence may hold several maps at once (train.hip fetches a map and
+    // its inverse back to back).  Eviction happens at entry-point boundaries only: check_ready() -> trim_maps().
     int* d = nullptr;
     ESCX_HIP(hipMalloc((void**)&d, m.size() * sizeof(int)));
     ESCX_HIP(hipMemcpy(d, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -845,11 +842,31 @@ extern "C" int escx_reserve(escx_handle h, int B, int L) {
 // ------------------------------------------------------------------------------------------------
 // launch sequences
 // ------------------------------------------------------------------------------------------------
+// Called at the start of every entry point, i.e. when no launch sequence of this handle holds a map pointer on the host side.  Dropping every
+// map needs the kernels that read them to have finished.
+static int trim_maps(escx_handle_s* h) {
+    if (h->maps.size() < 768) return 0;
+    ESCX_HIP(hipDeviceSynchronize());
+    for (auto& kv : h->maps) (void)hipFree(kv.second);
+    h->maps.clear();
+    return 0;
+}
+
 int escx::check_ready(escx_handle_s* h) {
     if (!h) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null handle");
     if (!h->finalized) ESCX_FAIL(ESCX_ERR_STATE, "parameters not finalised (call escx_finalize_params)");
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) ESCX_FAIL(ESCX_ERR_HIP, "hipSetDevice failed");
+    return trim_maps(h);
+}
+
+// Entry points that run the fp64-folded de-embedding of the inference path: after a device-side weight refresh (escx_train_forward with a flat
+// buffer, escx_load_flat_params(full = 0)) that host-side product is out of date and the call would silently decode with the OLD weights.
+int escx::check_infer_ready(escx_handle_s* h) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (h->composed_stale)
+        ESCX_FAIL(ESCX_ERR_STATE, "weights were refreshed on the device (training step): call escx_load_flat_params(handle, flat, /*full=*/1, stream) "
+                                  "before decoding, so that the folded de-embedding is rebuilt from the current values");
     return 0;
 }
 
@@ -1258,7 +1275,7 @@ static int run_csvq_decode(escx_handle_s* h, const long long* codes, int B, int 
 
 extern "C" int escx_decode(escx_handle h, const int64_t* codes, int B, int S, int fh, int fw, float* wave_out, float* recon_feat,
                            void* stream) {
-    int rc = check_ready(h); if (rc) return rc;
+    int rc = check_infer_ready(h); if (rc) return rc;
     if (!codes || !wave_out) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
     const escx_config& c = h->cfg;
     if (S < 1 || S > c.max_streams) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "codes.size(1)=%d outside [1, %d]", S, c.max_streams);
@@ -1281,7 +1298,7 @@ extern "C" int escx_decode(escx_handle h, const int64_t* codes, int B, int S, in
 // permuted to frame-major) is given; with `feat` the STFT is skipped (codecs.py:33-34).
 static int forward_impl(escx_handle h, const float* wave, const float* feat, int B, int L, int T, int S, int64_t* codes, float* wave_out,
                         float* raw_feat, float* recon_feat, float* cm_loss, void* stream) {
-    int rc = check_ready(h); if (rc) return rc;
+    int rc = check_infer_ready(h); if (rc) return rc;
     if ((!wave && !feat) || !codes || !wave_out) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
     const escx_config& c = h->cfg;
     if (S < 1 || S > c.max_streams) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "num_streams=%d outside [1, %d]", S, c.max_streams);
@@ -1438,7 +1455,7 @@ extern "C" int escx_pvq_decode(escx_handle h, int sid, const int64_t* codes, int
 }
 
 extern "C" int escx_patch_deembed(escx_handle h, const float* tokens, int B, int W, float* spec, void* stream) {
-    int rc = check_ready(h); if (rc) return rc;
+    int rc = check_infer_ready(h); if (rc) return rc;
     Shapes s; if ((rc = stage_ws_for_w(h, B, W, &s))) return rc;
     hipStream_t st = (hipStream_t)stream;
     pad_rows(tokens, h->stageA, (long long)B * s.H0 * W, h->C0, h->C0p, st);

@@ -81,6 +81,8 @@ struct WsFields {                    // one workspace: every scratch buffer of t
 struct escx_handle_s;
 namespace escx {
 int make_shapes(escx_handle_s* h, int B, int T, Shapes* out);
+int check_infer_ready(escx_handle_s* h);     // check_ready + the folded inference layouts are current (see escx_api.cpp)
+void free_train_state(escx_handle_s* h);     // train.hip: deletes the TrainTape bookkeeping object
 int get_map(escx_handle_s* h, int H, int W, int shift, const int** out);     // shift 0/2: slot -> token; -1: merge rows; 10/12: token -> slot
 int check_ready(escx_handle_s* h);
 // Grow-only device scratch for the stateless entry points (losses, GAN terms), one buffer per (device, stream, slot): hipMallocAsync /

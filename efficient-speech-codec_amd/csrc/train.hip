@@ -27,6 +27,7 @@ struct LayerTape { std::vector<BlockTape> blk; float* sub_xn = nullptr; float* y
 struct QuantTape { bool transmit = false; float *ze = nullptr, *zup = nullptr; const float* enc = nullptr; const float* dec = nullptr; float* out = nullptr; };
 struct TrainTape {
     bool valid = false;
+    long long generation = 0;                // counts escx_train_forward calls: a backward must belong to the LAST forward
     int B = 0, L = 0, S = 0, freeze = 0;
     Shapes shp;
     float *spec = nullptr, *pe_pre = nullptr, *tok0 = nullptr, *deemb = nullptr, *rspec = nullptr, *terms = nullptr;
@@ -38,6 +39,12 @@ struct TrainTape {
     size_t fwd_mark = 0;
 };
 
+}  // namespace
+void escx::free_train_state(escx_handle_s* h) {
+    delete static_cast<TrainTape*>(h->train_state);
+    h->train_state = nullptr;
+}
+namespace {
 TrainTape* tape_of(escx_handle_s* h) {
     if (!h->train_state) h->train_state = new TrainTape();
     return static_cast<TrainTape*>(h->train_state);
@@ -381,6 +388,7 @@ extern "C" int escx_load_flat_params(escx_handle h, const float* flat_dev, int f
 }
 
 extern "C" int64_t escx_train_tape_bytes(escx_handle h) { return h ? (int64_t)h->tape.cap : 0; }
+extern "C" int64_t escx_train_tape_generation(escx_handle h) { return (h && h->train_state) ? (int64_t)static_cast<TrainTape*>(h->train_state)->generation : 0; }
 
 extern "C" int escx_train_forward(escx_handle h, const float* flat_dev, const float* wave, int B, int L, int S, int freeze, int64_t* codes_out,
                                   float* wave_out, float* raw_feat, float* recon_feat, float* cm_loss, float* cb_loss, void* stream) {
@@ -395,6 +403,7 @@ extern "C" int escx_train_forward(escx_handle h, const float* flat_dev, const fl
     if ((rc = build_gather_map(h))) return rc;
     TrainTape& T = *tape_of(h);
     T.valid = false;
+    ++T.generation;
     Shapes s;
     if ((rc = make_shapes(h, B, 1 + L / c.hop_length, &s))) return rc;
     const size_t need = tape_bytes(h, s);
@@ -912,8 +921,9 @@ extern "C" int escx_grad_norm_clip(const float* grad_flat, int64_t n, float max_
 extern "C" int escx_adamw_step(float* param_flat, const float* grad_flat, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr, float beta1,
                                float beta2, float eps, float weight_decay, const float* clip_dev, void* stream) {
     if (!param_flat || !grad_flat || !exp_avg || !exp_avg_sq || n < 1 || step < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
-    const float bc1 = 1.0f - std::pow(beta1, (float)step), bc2 = 1.0f - std::pow(beta2, (float)step);
+    // torch.optim.AdamW evaluates the bias corrections, lr / bc1 and sqrt(bc2) in double (python floats) and hands the kernel two fp32 scalars
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks_for((long long)n)), dim3(256), 0, (hipStream_t)stream, param_flat, grad_flat, exp_avg, exp_avg_sq, (long long)n,
-                       clip_dev, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
+                       clip_dev, lr, beta1, beta2, eps, weight_decay, (float)((double)lr / bc1), (float)std::sqrt(bc2));
     return launch_ok("adamw_step");
 }

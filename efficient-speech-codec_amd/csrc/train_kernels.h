@@ -1212,7 +1212,7 @@ static __global__ void clip_coef_kernel(const float* __restrict__ part, int n, f
     norm_out[1] = c < 1.0f ? c : 1.0f;
 }
 static __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
-                             const float* __restrict__ coef, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2) {
+                             const float* __restrict__ coef, float lr, float beta1, float beta2, float eps, float wd, float step_size, float bc2_sqrt) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float gi = g[i] * (coef ? coef[1] : 1.0f);
@@ -1220,7 +1220,7 @@ static __global__ void adamw_kernel(float* __restrict__ p, const float* __restri
     const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
     const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
     m[i] = mi; v[i] = vi;
-    pi -= (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+    pi -= step_size * mi / (sqrtf(vi) / bc2_sqrt + eps);
     p[i] = pi;
 }
 

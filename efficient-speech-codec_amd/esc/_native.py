@@ -70,6 +70,7 @@ SIGNATURES = {
     "escx_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "escx_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "escx_train_tape_bytes": (c_int64, [c_void_p]),
+    "escx_train_tape_generation": (c_int64, [c_void_p]),
     "escx_stft_loss": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
     "escx_mel_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "escx_scale_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),

@@ -163,6 +163,7 @@ class ESC(nn.Module):
         self._packed_version: Dict[int, int] = {}        # parameter fingerprint the packed device layouts were derived from
         self._dirty = True
         self._flat_grad_mode = False
+        self._carry: Dict[int, tuple] = {}               # flat gradient buffers that survive a handle rebuild (see _handle)
 
     # ---- weight management ------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -247,8 +248,11 @@ class ESC(nn.Module):
         idx = device.index if device.index is not None else torch.cuda.current_device()
         st = self._flat[idx]
         if "gflat" not in st:
-            st["gflat"] = torch.zeros_like(flat)
-            st["gfresh"] = True
+            old = self._carry.pop(idx, None)             # a rebuild (model.to(), load_state_dict) keeps pending gradients: same layout, same buffer
+            if old is not None and old[0].shape == flat.shape and old[0].device == flat.device:
+                st["gflat"], st["gfresh"] = old
+            else:
+                st["gflat"], st["gfresh"] = torch.zeros_like(flat), True
         params = self._named_params()
         for key, off, n in st["layout"]:
             params[key].grad = st["gflat"][off:off + n].view(params[key].shape)
@@ -280,6 +284,9 @@ class ESC(nn.Module):
         if self._dirty:
             for hd in self._handles.values():
                 lib.escx_destroy(hd)
+            # flat-gradient mode outlives the rebuild: the gradient buffer (and with it every p.grad view and whatever a backward has already
+            # accumulated) is carried over, so that a live FlatAdamW keeps stepping on real gradients
+            self._carry = {i: (st["gflat"], st["gfresh"]) for i, st in self._flat.items() if "gflat" in st}
             self._handles, self._flat, self._packed_version = {}, {}, {}
             self._dirty = False
         if idx not in self._handles:
@@ -299,6 +306,9 @@ class ESC(nn.Module):
                 raise
             self._handles[idx] = hd
             self._packed_version[idx] = self._param_version()
+            if self._flat_grad_mode and idx in self._carry:
+                self._flat_grad_mode = False             # (guards the re-entry through enable_flat_grads -> _handle)
+                self.enable_flat_grads(device)
         hd = self._handles[idx]
         if not for_training and self._packed_version.get(idx) != self._param_version():
             # parameters were updated in place since the last pack (optimizer steps, manual edits): rebuild every derived layout,
@@ -312,7 +322,8 @@ class ESC(nn.Module):
     def __getstate__(self):
         """copy.deepcopy / torch.save of the whole module: native handles are per-process device resources and are rebuilt lazily."""
         state = self.__dict__.copy()
-        state["_handles"], state["_flat"], state["_packed_version"], state["_dirty"] = {}, {}, {}, True
+        state["_handles"], state["_flat"], state["_packed_version"], state["_dirty"], state["_carry"] = {}, {}, {}, True, {}
+        state["_flat_grad_mode"] = False
         return state
 
     def __del__(self):
@@ -504,6 +515,7 @@ class _TrainStep(torch.autograd.Function):
                                                  ctypes.c_void_p(recon_fm.data_ptr()), ctypes.c_void_p(cm.data_ptr()), ctypes.c_void_p(cb.data_ptr()),
                                                  model._stream(dev)))
         ctx.model, ctx.dev, ctx.idx = model, dev, idx
+        ctx.tape_generation = int(lib.escx_train_tape_generation(hd))
         ctx.mark_non_differentiable(raw_fm, codes)
         return recon, recon_fm, raw_fm, cm, cb, codes
 
@@ -511,6 +523,9 @@ class _TrainStep(torch.autograd.Function):
     def backward(ctx, d_recon, d_recon_fm, _d_raw, d_cm, d_cb, _d_codes):
         model, dev = ctx.model, ctx.dev
         lib, hd = model._handle(dev, for_training=True)
+        if int(lib.escx_train_tape_generation(hd)) != ctx.tape_generation:
+            raise RuntimeError("esc.ESC backward: the model ran another training forward after the one this graph belongs to; the library keeps ONE "
+                               "activation tape per model (backward before the next forward, or use a second model instance)")
         st = model._flat[ctx.idx]
         flat_mode = model._flat_grad_mode and "gflat" in st
         gflat = st["gflat"] if (flat_mode and st["gfresh"]) else torch.empty_like(st["flat"])

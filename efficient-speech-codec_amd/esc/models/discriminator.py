@@ -66,7 +66,7 @@ class Discriminator(nn.Module):
             _attach(self, pfx + "bias", torch.empty(cout).uniform_(-bound, bound), False)
             _attach(self, pfx + "weight_g", v.flatten(1).norm(dim=1).view(cout, 1, 1, 1).clone(), False)
             _attach(self, pfx + "weight_v", v, False)
-        self._handles, self._flat = {}, {}
+        self._handles, self._flat, self._carry = {}, {}, {}
         self._flat_grad_mode = False
         self._native_updates = 0
 
@@ -78,7 +78,8 @@ class Discriminator(nn.Module):
         idx = device.index if device.index is not None else torch.cuda.current_device()
         st = self._flat[idx]
         if "gflat" not in st:
-            st["gflat"], st["gfresh"] = torch.zeros_like(flat), True
+            old = self._carry.pop(idx, None)             # a rebuild keeps the gradient buffer and what it holds (same contract as esc.ESC)
+            st["gflat"], st["gfresh"] = old if (old is not None and old[0].shape == flat.shape and old[0].device == flat.device) else (torch.zeros_like(flat), True)
         params = dict(self.named_parameters())
         for key, off, n in st["layout"]:
             params[key].grad = st["gflat"][off:off + n].view(params[key].shape)
@@ -115,6 +116,7 @@ class Discriminator(nn.Module):
             lib = _native.load()
             for hd in self._handles.values():
                 lib.escx_disc_destroy(hd)
+        self._carry = {i: (st["gflat"], st["gfresh"]) for i, st in getattr(self, "_flat", {}).items() if "gflat" in st}
         self._handles, self._flat = {}, {}
 
     def __del__(self):
@@ -125,7 +127,7 @@ class Discriminator(nn.Module):
 
     def __getstate__(self):
         st = self.__dict__.copy()
-        st["_handles"], st["_flat"] = {}, {}
+        st["_handles"], st["_flat"], st["_carry"], st["_flat_grad_mode"] = {}, {}, {}, False
         return st
 
     def _handle(self, device):
@@ -144,6 +146,9 @@ class Discriminator(nn.Module):
             hd = ctypes.c_void_p()
             _native.check(lib.escx_disc_create(ctypes.byref(cc), idx, ctypes.byref(hd)))
             self._handles[idx] = hd
+            if self._flat_grad_mode and idx in self._carry:
+                self._flat_grad_mode = False             # (guards the re-entry through enable_flat_grads -> _handle)
+                self.enable_flat_grads(device)
         return lib, self._handles[idx]
 
     def _ensure_flat(self, device, lib, hd):

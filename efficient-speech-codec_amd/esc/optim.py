@@ -34,8 +34,14 @@ class FlatAdamW:
 
     def _buffers(self):
         flat, gflat = self.model.flat_buffers(self.device)
-        if self._state is None or self._state[0].data_ptr() != flat.data_ptr():
+        if self._state is None:
             self._state = (flat, torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros(2 + 1024, dtype=torch.float32, device=self.device))
+        elif self._state[0].data_ptr() != flat.data_ptr():
+            # the model rebuilt its flat buffer (model.to(), load_state_dict): the moments are indexed by the library's layout, which depends on
+            # the configuration only, so they stay valid; a different size means a different model
+            if self._state[1].shape != flat.shape or self._state[1].device != flat.device:
+                raise RuntimeError("the model's flat parameter buffer changed size or device under a live FlatAdamW; build a new optimiser")
+            self._state = (flat,) + self._state[1:]
         return flat, gflat, self._state[1], self._state[2], self._state[3]
 
     @torch.no_grad()
@@ -60,13 +66,57 @@ class FlatAdamW:
     def zero_grad(self, set_to_none: bool = False):
         self.model.zero_flat_grads(self.device)
 
+    # ---- checkpoint interchange: torch.optim.AdamW's state_dict layout (what the reference's trainers save and load) --------------------
+    def _param_slices(self):
+        """[(offset, numel, shape)] in `model.parameters()` order = the parameter indices of a torch optimiser built from them."""
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._buffers()
+        where = {k: (off, n) for k, off, n in self.model._flat[idx]["layout"]}
+        return [(where[k] + (tuple(p.shape),)) if k in where else None for k, p in self.model.named_parameters()]
+
     def state_dict(self):
+        """`torch.optim.AdamW(model.parameters(), ...).state_dict()` layout: per-parameter `step` / `exp_avg` / `exp_avg_sq` cut out of the flat
+        moment buffers, one param group.  A reference trainer's `optimizer.load_state_dict` reads it (trainer_no_adv.py:62, trainer_adv.py:118)."""
         flat, gflat, m, v, _ = self._buffers()
-        return {"step": self.t, "exp_avg": m.clone(), "exp_avg_sq": v.clone(), "lr": self.lr, "betas": self.betas, "eps": self.eps,
-                "weight_decay": self.weight_decay, "max_grad_norm": self.max_grad_norm}
+        slices = self._param_slices()
+        state = {}
+        if self.t > 0:
+            for i, sl in enumerate(slices):
+                if sl is not None:
+                    off, n, shp = sl
+                    state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": m[off:off + n].view(shp).clone(), "exp_avg_sq": v[off:off + n].view(shp).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(slices))),
+                 "max_grad_norm": self.max_grad_norm}            # extra key: torch ignores what it does not know
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
+        """Accepts the torch AdamW layout (a reference checkpoint's `optimizer_state_dict`) and the flat layout earlier builds of this package wrote."""
         flat, gflat, m, v, _ = self._buffers()
-        self.t = int(sd["step"]); m.copy_(sd["exp_avg"]); v.copy_(sd["exp_avg_sq"])
-        self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
-        self.max_grad_norm = sd.get("max_grad_norm")
+        if "param_groups" not in sd:                        # flat layout {step, exp_avg, exp_avg_sq, lr, ...}
+            self.t = int(sd["step"]); m.copy_(sd["exp_avg"]); v.copy_(sd["exp_avg_sq"])
+            self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
+            self.max_grad_norm = sd.get("max_grad_norm")
+            return
+        groups = sd["param_groups"]
+        slices = self._param_slices()
+        ids = [i for g in groups for i in g["params"]]
+        if len(ids) != len(slices):
+            raise ValueError(f"optimizer state has {len(ids)} parameters, the model has {len(slices)}")
+        if len({(g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]) for g in groups}) != 1 or any(g.get("amsgrad") for g in groups):
+            raise NotImplementedError("FlatAdamW holds ONE hyper-parameter set (the reference builds AdamW(params, lr) with a single group, no amsgrad)")
+        g0 = groups[0]
+        self.lr, self.betas, self.eps, self.weight_decay = g0["lr"], tuple(g0["betas"]), g0["eps"], g0["weight_decay"]
+        self.max_grad_norm = g0.get("max_grad_norm", self.max_grad_norm)
+        m.zero_(); v.zero_()
+        steps = set()
+        for pos, pid in enumerate(ids):                    # torch maps saved ids to parameters by position
+            st = sd["state"].get(pid)
+            if st is None or slices[pos] is None:
+                continue
+            off, n, shp = slices[pos]
+            m[off:off + n].copy_(st["exp_avg"].reshape(-1)); v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise NotImplementedError(f"per-parameter step counts differ ({sorted(steps)}): the flat update applies one bias correction")
+        self.t = steps.pop() if steps else 0

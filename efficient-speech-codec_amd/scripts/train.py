@@ -50,6 +50,32 @@ def lr_at(step: int, base_lr: float, kind: str, total_steps: int, warmup_steps: 
     raise ValueError(f"{kind} must be in ('constant', 'constant_warmup', 'cosine_warmup', 'exponential_decay')")
 
 
+def scheduler_state(kind: str, base_lr: float, n_done: int, total_steps: int, warmup_steps: int) -> dict:
+    """`scheduler_state_dict` of a checkpoint written after `n_done` scheduler steps: the fields torch's LRScheduler.state_dict() carries that
+    determine the schedule's position (the learning rate here is a pure function of the step, `lr_at`)."""
+    return {"base_lrs": [base_lr], "last_epoch": n_done, "_step_count": n_done + 1, "_last_lr": [lr_at(n_done, base_lr, kind, total_steps, warmup_steps)],
+            "scheduler_type": kind, "num_training_steps": total_steps, "num_warmup_steps": warmup_steps}
+
+
+class _Schedule:
+    """Learning rate of the generator optimiser at step n, as the reference's loop produces it: `scheduler.step()` after every optimiser step
+    (trainer_no_adv.py:118, trainer_adv.py:92), and once the optimiser is renewed after the frozen-codebook phase (at step
+    pretraining_steps + 1, trainer_no_adv.py:76-79 / trainer_adv.py:140-143) the NEW optimiser runs at the constant base rate - the scheduler
+    stays bound to the discarded one."""
+
+    def __init__(self, base_lr, kind, total_steps, warmup_steps, pretraining_steps):
+        lr_at(0, base_lr, kind, total_steps, warmup_steps)                              # unknown kinds raise here, not at step n
+        self.base_lr, self.kind, self.total, self.warmup, self.pre = base_lr, kind, total_steps, warmup_steps, pretraining_steps
+
+    def renew_at(self, n: int) -> bool:
+        return self.pre > 0 and n == self.pre + 1
+
+    def lr(self, n: int) -> float:
+        if self.pre > 0 and n > self.pre:
+            return self.base_lr
+        return lr_at(n, self.base_lr, self.kind, self.total, self.warmup)
+
+
 class Stepper:
     """Holds model, losses and optimiser; `step(x, n)` is one optimisation step and returns the per-loss batch means."""
 
@@ -59,16 +85,16 @@ class Stepper:
         self.w = dict(DEFAULT_LOSS_WEIGHTS, **(loss_weights or {}))
         self.mel, self.stft = MelSpectrogramLoss(), ComplexSTFTLoss()
         self.opt = FlatAdamW(model, lr=lr, max_grad_norm=0.5, group=group)                 # torch.optim.AdamW defaults otherwise (utils.py:48-49)
-        self.base_lr, self.sched, self.total, self.warmup = lr, scheduler, total_steps, warmup_steps
+        self.base_lr, self.schedule = lr, _Schedule(lr, scheduler, total_steps, warmup_steps, pretraining_steps)
         self.dropout_rate, self.pretraining_steps = dropout_rate, pretraining_steps
         self.rng = np.random.default_rng(seed)
 
     def step(self, x: torch.Tensor, n: int) -> dict:
         freeze = n < self.pretraining_steps
         s = sample_streams(self.rng, self.dropout_rate, self.model.max_streams)
-        if n == self.pretraining_steps and n > 0:                                          # "Optimizer Renewed" (trainer_no_adv.py:76-79)
+        if self.schedule.renew_at(n):                                                      # "Optimizer Renewed" (trainer_no_adv.py:76-79)
             self.opt = FlatAdamW(self.model, lr=self.base_lr, max_grad_norm=0.5, group=self.opt.group)
-        self.opt.lr = lr_at(n, self.base_lr, self.sched, self.total, self.warmup)
+        self.opt.lr = self.schedule.lr(n)
         out = self.model(x=x, x_feat=None, num_streams=s, freeze_codebook=freeze)
         terms = {"cm_loss": out["cm_loss"], "cb_loss": out["cb_loss"], "mel_loss": self.mel(out["raw_audio"], out["recon_audio"]),
                  "stft_loss": self.stft(out["raw_feat"], out["recon_feat"])}
@@ -85,19 +111,24 @@ class AdvStepper:
     clip 1e3) followed by the discriminator update on the detached reconstruction (clip 10); during the frozen-codebook pre-training
     phase the discriminator is not involved."""
 
-    def __init__(self, model, disc, lr, loss_weights=None, dropout_rate=1.0, pretraining_steps=0, seed=1234, group=None):
+    def __init__(self, model, disc, lr, loss_weights=None, dropout_rate=1.0, pretraining_steps=0, seed=1234, group=None, scheduler="constant",
+                 total_steps=250000, warmup_steps=0, lr_disc=None):
         from esc.modules import GANLoss
         self.model, self.disc = model.train(), disc.train()
         self.w = dict(ADV_LOSS_WEIGHTS, **(loss_weights or {}))
         self.mel, self.stft, self.gan = MelSpectrogramLoss(), ComplexSTFTLoss(), GANLoss(disc)
         self.opt_g = FlatAdamW(model, lr=lr, max_grad_norm=1e3, group=group)
-        self.opt_d = FlatAdamW(disc, lr=lr, max_grad_norm=10.0, group=group)
+        self.opt_d = FlatAdamW(disc, lr=lr if lr_disc is None else lr_disc, max_grad_norm=10.0, group=group)   # constant: the scheduler drives opt_g only (trainer_adv.py:43-48)
+        self.base_lr, self.schedule = lr, _Schedule(lr, scheduler, total_steps, warmup_steps, pretraining_steps)
         self.dropout_rate, self.pretraining_steps = dropout_rate, pretraining_steps
         self.rng = np.random.default_rng(seed)
 
     def step(self, x: torch.Tensor, n: int) -> dict:
         freeze = n < self.pretraining_steps
         s = sample_streams(self.rng, self.dropout_rate, self.model.max_streams)
+        if self.schedule.renew_at(n):                               # "Generator's Optimizer Renewed" (trainer_adv.py:140-143): fresh Adam moments
+            self.opt_g = FlatAdamW(self.model, lr=self.base_lr, max_grad_norm=1e3, group=self.opt_g.group)
+        self.opt_g.lr = self.schedule.lr(n)                         # scheduler.step() after opt_g.step() (trainer_adv.py:92)
         out = self.model(x=x, x_feat=None, num_streams=s, freeze_codebook=freeze)
         terms = {"cm_loss": out["cm_loss"], "cb_loss": out["cb_loss"], "mel_loss": self.mel(out["raw_audio"], out["recon_audio"])}
         if self.w["stft_weight"] != 0.0:
@@ -114,6 +145,25 @@ class AdvStepper:
             self.opt_d.step(); self.opt_d.zero_grad()
             log["disc_loss"] = d_loss.mean()
         return log
+
+
+def _cpu(sd):
+    return {k: (_cpu(v) if isinstance(v, dict) else (v.detach().cpu() if torch.is_tensor(v) else v)) for k, v in sd.items()}
+
+
+def checkpoint(st, step: int, scheduler: str, total_steps: int, warmup_steps: int, best_perf=-1) -> dict:
+    """The reference's checkpoint dictionary, key for key (trainer_no_adv.py:155-163; with a discriminator trainer_adv.py:159-168): optimiser
+    states in torch.optim.AdamW's own layout, so the reference's `--pretrain_ckp` loader reads a checkpoint written here and vice versa."""
+    adv = isinstance(st, AdvStepper)
+    ck = {"step": step, "model_state_dict": _cpu(st.model.state_dict())}
+    if adv:
+        ck["model_disc_state_dict"] = _cpu(st.disc.state_dict())
+    ck["optimizer_state_dict"] = _cpu((st.opt_g if adv else st.opt).state_dict())
+    if adv:
+        ck["optimizer_disc_state_dict"] = _cpu(st.opt_d.state_dict())
+    ck["scheduler_state_dict"] = scheduler_state(scheduler, st.base_lr, step + 1, total_steps, warmup_steps)
+    ck["best_perf"] = best_perf
+    return ck
 
 
 def _batches(args, device, rank, world):
@@ -177,21 +227,27 @@ def main():
         from esc.models import Discriminator
         dcfg = (cfg.get("discriminator") if args.config else None) or dict(sample_rate=16000)
         disc = Discriminator(**dcfg).to(device)
-        st = AdvStepper(model, disc, args.lr, loss_w, args.dropout_rate, args.pretraining_steps, seed=args.seed)
+        st = AdvStepper(model, disc, args.lr, loss_w, args.dropout_rate, args.pretraining_steps, seed=args.seed, scheduler=args.scheduler_type,
+                        total_steps=args.steps, warmup_steps=args.num_warmup_steps)
     else:
         st = Stepper(model, args.lr, loss_w, args.dropout_rate, args.pretraining_steps, args.scheduler_type, args.steps, args.num_warmup_steps,
                      seed=args.seed)                                    # same seed on every rank: the ranks agree on the stream count
     data = _batches(args, device, rank, world)
     first = 0
     if args.resume:
+        # the reference's checkpoint layout (trainer_no_adv.py:155-163, trainer_adv.py:159-168): a checkpoint written by either loads here
         ck = torch.load(args.resume, map_location="cpu", weights_only=False)
         model.load_state_dict(ck["model_state_dict"])
         first = int(ck["step"]) + 1
         if args.adv:
-            disc.load_state_dict(ck["disc_state_dict"])
-            st.opt_g.load_state_dict(ck["optimizer_state_dict"]); st.opt_d.load_state_dict(ck["disc_optimizer_state_dict"])
+            if "model_disc_state_dict" in ck:
+                disc.load_state_dict(ck["model_disc_state_dict"])
+                st.opt_d.load_state_dict(ck["optimizer_disc_state_dict"])
+            st.opt_g.load_state_dict(ck["optimizer_state_dict"])      # a non-adversarial checkpoint = the reference's --pretrain_ckp start
         else:
             st.opt.load_state_dict(ck["optimizer_state_dict"])
+        if "scheduler_state_dict" in ck and int(ck["scheduler_state_dict"].get("last_epoch", first)) != first:
+            raise ValueError(f"checkpoint step {first - 1} and scheduler position {ck['scheduler_state_dict'].get('last_epoch')} disagree")
         for _ in range(first):                                          # the stream sampler and the data order continue where they stopped
             sample_streams(st.rng, st.dropout_rate, model.max_streams); next(data)
     evaluate = None
@@ -219,13 +275,7 @@ def main():
             print(json.dumps({"step": n + 1, "s_per_step": round((time.perf_counter() - t0) / (n + 1 - first), 4), **vals}))
     if rank == 0 and args.save_path:
         os.makedirs(args.save_path, exist_ok=True)
-        ck = {"step": args.steps - 1, "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()}}
-        if args.adv:                                                    # trainer_adv.py keeps the discriminator and both optimisers in the checkpoint
-            ck.update(disc_state_dict={k: v.detach().cpu() for k, v in disc.state_dict().items()},
-                      optimizer_state_dict=st.opt_g.state_dict(), disc_optimizer_state_dict=st.opt_d.state_dict())
-        else:
-            ck["optimizer_state_dict"] = st.opt.state_dict()
-        torch.save(ck, os.path.join(args.save_path, "checkpoint.pth"))
+        torch.save(checkpoint(st, args.steps - 1, args.scheduler_type, args.steps, args.num_warmup_steps), os.path.join(args.save_path, "checkpoint.pth"))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
 

@@ -181,6 +181,10 @@ int escx_train_forward(escx_handle h, const float* flat_params_dev, const float*
 int escx_train_backward(escx_handle h, const float* d_wave_dev, const float* d_recon_feat_dev, const float* d_cm_loss_dev,
                         const float* d_cb_loss_dev, float* grad_flat_dev, void* stream);
 int64_t escx_train_tape_bytes(escx_handle h);
+/* Number of escx_train_forward calls on this handle so far.  The handle holds ONE tape: escx_train_backward consumes the activations of the
+ * LAST forward.  A caller that interleaves several forwards (autograd graphs alive at the same time) records this value after its forward
+ * and compares it before its backward; a mismatch means the tape belongs to a later forward (esc/models/codecs.py raises). */
+int64_t escx_train_tape_generation(escx_handle h);
 /* ComplexSTFTLoss (generator_loss.py:12-35): per-clip loss (B,) = mean over the clip's `per_clip` spectrum values (any layout, the
  * same for both inputs) of (pl(raw) - pl(recon))^2, pl = power-law compression; optionally d loss_b / d recon_feat. */
 int escx_stft_loss(const float* raw_feat_dev, const float* recon_feat_dev, int batch, int64_t per_clip, float* loss_dev,

@@ -362,6 +362,68 @@ def test_eval_after_optimizer_steps_uses_the_updated_weights():
     assert torch.equal(twin.encode(x, 3)[0], c1)
 
 
+@pytest.mark.gpu
+def test_flat_gradients_and_adam_moments_survive_a_handle_rebuild():
+    """load_state_dict / model.to() between backward and optimiser step rebuilds the native handle and the flat parameter buffer.
+    The flat gradient buffer (with what the backward accumulated) and FlatAdamW's moments must carry over: the run with a rebuild in the
+    middle of every step equals the undisturbed run bit for bit."""
+    from esc.models import make_model
+    from esc.modules import ComplexSTFTLoss, MelSpectrogramLoss
+    from esc.optim import FlatAdamW
+    g = load_golden("train")
+    x = _clips(g, "tiny").cuda()
+    mel, stft = MelSpectrogramLoss(), ComplexSTFTLoss()
+    runs = []
+    for disturb in (False, True):
+        model = make_model(_cfg("tiny")); model.load_state_dict(synth_state("tiny")); model = model.cuda().train()
+        opt = FlatAdamW(model, lr=1e-3, max_grad_norm=0.5)
+        for n in range(3):
+            out = model(x=x, x_feat=None, num_streams=3, freeze_codebook=False)
+            (out["cm_loss"] + out["cb_loss"] + mel(out["raw_audio"], out["recon_audio"]) + stft(out["raw_feat"], out["recon_feat"])).mean().backward()
+            if disturb:
+                model.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})        # dirty: handle + flat buffer are rebuilt lazily
+                model.to("cuda")
+            opt.step(); opt.zero_grad()
+        assert opt.t == 3 and float(opt.last_grad_norm) > 0
+        runs.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+    assert all(torch.equal(runs[0][k], runs[1][k]) for k in runs[0])
+    init = synth_state("tiny")
+    assert sum(not torch.equal(v.cpu(), init[k]) for k, v in runs[0].items() if v.is_floating_point() and not k.endswith(".window")) > 50      # it did train
+
+
+@pytest.mark.gpu
+def test_native_state_guards_of_the_training_path():
+    """ADVICE r2, C-ABI level: (1) after a device-side weight refresh (a training forward) the inference entry points that run the fp64-folded
+    de-embedding refuse with ESCX_ERR_STATE until escx_load_flat_params(full=1) - they do not decode with stale weights; (2) the handle keeps ONE
+    tape: a backward that belongs to an earlier forward raises instead of consuming the later forward's activations."""
+    import ctypes
+    from esc import _native
+    from esc.models import make_model
+    g = load_golden("train")
+    x = _clips(g, "tiny").cuda()
+    model = make_model(_cfg("tiny")); model.load_state_dict(synth_state("tiny")); model = model.cuda().eval()
+    codes, shape = model.encode(x, 3)
+    model.train()
+    out_a = model(x=x, x_feat=None, num_streams=3, freeze_codebook=False)
+    lib, hd = model._handle(x.device, for_training=True)
+    wave = torch.empty((x.shape[0], model.hop_length * (2 * shape[1] - 1)), device="cuda")
+    rc = lib.escx_decode(hd, codes.data_ptr(), codes.shape[0], 3, shape[0], shape[1], wave.data_ptr(), None, None)
+    assert rc == _native.ESCX_ERR_STATE and b"escx_load_flat_params" in lib.escx_last_error()
+    flat, _ = model.flat_buffers(x.device)
+    _native.check(lib.escx_load_flat_params(hd, ctypes.c_void_p(flat.data_ptr()), 1, None))
+    assert lib.escx_decode(hd, codes.data_ptr(), codes.shape[0], 3, shape[0], shape[1], wave.data_ptr(), None, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(wave, model.eval().decode(codes, shape))
+    # (2) two graphs alive at once
+    model.train()
+    out_a = model(x=x, x_feat=None, num_streams=3, freeze_codebook=False)
+    out_b = model(x=x, x_feat=None, num_streams=2, freeze_codebook=False)
+    with pytest.raises(RuntimeError, match="another training forward"):
+        out_a["recon_audio"].sum().backward()
+    out_b["recon_audio"].sum().backward()                      # the last forward's graph is fine
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
 def test_train_harness_schedules_and_stream_sampling():
     """scripts/train.py host logic: quantisation dropout (scripts/utils.py:11-25) and the four learning-rate schedules."""
     import os, sys
@@ -393,6 +455,83 @@ def test_train_harness_schedules_and_stream_sampling():
         for n in range(total):
             assert opt.param_groups[0]["lr"] == pytest.approx(lr_at(n, 3e-4, kind, total, warm), rel=1e-9, abs=1e-15), (kind, n)
             opt.step(); sch.step()
+
+
+def test_generator_schedule_follows_the_reference_loop():
+    """the generator's learning rate follows the scheduler in BOTH trainers (trainer_no_adv.py:118, trainer_adv.py:92); the optimiser is
+    renewed at step pretraining_steps + 1 (trainer_no_adv.py:76-79, trainer_adv.py:140-143) and the renewed one runs at the constant base rate
+    (the scheduler stays bound to the discarded optimiser).  Replayed against the reference's own loop structure with torch objects."""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "efficient-speech-codec_amd"))
+    from scripts.train import _Schedule, scheduler_state
+    transformers = pytest.importorskip("transformers")
+    base, total, warm, pre = 2e-4, 30, 6, 4
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], base)
+    sch = transformers.get_cosine_schedule_with_warmup(opt, num_warmup_steps=warm, num_training_steps=total)     # stays bound to the FIRST optimiser
+    mine = _Schedule(base, "cosine_warmup", total, warm, pre)
+    for n in range(total):                                    # the reference's loop body: renew, step, scheduler.step()
+        renewed = pre > 0 and n == pre + 1
+        if renewed:
+            opt = torch.optim.AdamW([p], base)
+        assert mine.renew_at(n) == renewed
+        assert mine.lr(n) == pytest.approx(opt.param_groups[0]["lr"], rel=1e-9, abs=1e-15), n
+        opt.step(); sch.step()
+    assert not any(_Schedule(base, "constant", total, 0, 0).renew_at(n) for n in range(5))
+    with pytest.raises(ValueError):
+        _Schedule(base, "linear", total, 0, 0)
+    st = scheduler_state("cosine_warmup", base, 10, total, warm)
+    assert st["last_epoch"] == 10 and st["base_lrs"] == [base] and st["_last_lr"][0] == pytest.approx(sch.state_dict()["base_lrs"][0] * 0.5 * (1 + np.cos(np.pi * 4 / 24)))
+
+
+@pytest.mark.gpu
+def test_checkpoint_layout_is_the_reference_trainers():
+    """a checkpoint written by scripts/train.py has the reference's keys (trainer_adv.py:159-168) and its optimiser states are
+    torch.optim.AdamW state_dicts: a REAL torch AdamW over model.parameters() loads them (what the reference's --pretrain_ckp path does,
+    trainer_adv.py:118) and continues exactly like FlatAdamW; a torch-written state loads back into FlatAdamW."""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "efficient-speech-codec_amd"))
+    from esc.models import Discriminator, make_model
+    from esc.optim import FlatAdamW
+    from scripts.train import AdvStepper, checkpoint
+    g = load_golden("train")
+    x = _clips(g, "tiny").cuda()
+    model = make_model(_cfg("tiny")); model.load_state_dict(synth_state("tiny")); model = model.cuda()
+    disc = Discriminator(sample_rate=16000, periods=[2], fft_sizes=[256]).cuda()
+    st = AdvStepper(model, disc, lr=1e-3, dropout_rate=0.0, scheduler="constant_warmup", warmup_steps=2, total_steps=10)
+    for n in range(3):
+        st.step(x, n)
+    ck = checkpoint(st, 2, "constant_warmup", 10, 2)
+    assert list(ck) == ["step", "model_state_dict", "model_disc_state_dict", "optimizer_state_dict", "optimizer_disc_state_dict", "scheduler_state_dict", "best_perf"]
+    assert ck["step"] == 2 and ck["scheduler_state_dict"]["last_epoch"] == 3 and ck["best_perf"] == -1
+    for net, key in ((model, "optimizer_state_dict"), (disc, "optimizer_disc_state_dict")):
+        osd = ck[key]
+        n_params = len(list(net.parameters()))
+        assert sorted(osd["state"]) == list(range(n_params)) and osd["param_groups"][0]["params"] == list(range(n_params))
+        assert all(v["exp_avg"].shape == p.shape and float(v["step"]) == 3.0 for v, p in zip(osd["state"].values(), net.parameters()))
+    # a real torch AdamW takes the state and makes the same next step as FlatAdamW (same gradients, no clipping)
+    twin = make_model(_cfg("tiny")); twin.load_state_dict(ck["model_state_dict"]); twin = twin.cuda().train()
+    topt = torch.optim.AdamW(twin.parameters(), lr=1e-3)
+    topt.load_state_dict(ck["optimizer_state_dict"])
+    gen = torch.Generator().manual_seed(5)
+    grads = [torch.randn(p.shape, generator=gen).cuda() * 1e-2 for p in model.parameters()]
+    st.opt_g.max_grad_norm = None
+    st.opt_g.lr = 1e-3
+    for p, q, gr in zip(model.parameters(), twin.parameters(), grads):
+        p.grad.copy_(gr); q.grad = gr.clone()
+    st.opt_g.step(); topt.step()
+    worst = max(float((p - q).abs().max()) for p, q in zip(model.parameters(), twin.parameters()))
+    assert worst < 2e-7, worst
+    # and back: torch's state (after its step) into a fresh FlatAdamW
+    back = FlatAdamW(twin, lr=1e-3)
+    back.load_state_dict(topt.state_dict())
+    assert back.t == 4
+    for (_, a), (_, b) in zip(sorted(back.state_dict()["state"].items()), sorted(st.opt_g.state_dict()["state"].items())):
+        assert float((a["exp_avg"] - b["exp_avg"]).abs().max()) < 1e-7 and float((a["exp_avg_sq"] - b["exp_avg_sq"]).abs().max()) < 1e-9
+    with pytest.raises(ValueError):
+        back.load_state_dict({"state": {}, "param_groups": [dict(osd["param_groups"][0], params=[0, 1])]})
 
 
 @pytest.mark.gpu
