@@ -3,7 +3,9 @@ oracle/ref_shims.py): scripts/trainer_adv.py:61-107 without the optimisers - gen
 generator's GAN losses through the reference Discriminator (its own two passes), the weighted sum of configs/9kbps_esc_base_adv.yaml,
 `loss.mean().backward()`; then `discriminator_loss` (its own two passes on the detached reconstruction) and its backward.
 
-    python oracle/gen_adv_golden.py        # writes tests/golden/adv.npz
+    python oracle/gen_adv_golden.py        # writes tests/golden/adv.npz        (ESC-Base generator: configs/9kbps_esc_base_adv.yaml as it stands)
+    python oracle/gen_adv_golden.py large  # writes tests/golden/adv_large.npz  (BASELINE configs[4]: the `model:` block of configs/9kbps_esc_large.yaml
+                                           #  under the adversarial yaml's loss / discriminator blocks - the reference ships no large_adv yaml)
 
 Stored: per-clip losses of both updates, the gradient norm of every generator parameter (through the discriminator) and of every
 discriminator parameter.  The product shares the discriminator passes between the two updates (two instead of four): this fixture is what
@@ -25,6 +27,7 @@ STREAMS = 6
 
 
 def main():
+    large = len(sys.argv) > 1 and sys.argv[1] == "large"
     torch.manual_seed(0); torch.set_num_threads(8)
     ref_models = gg.ref_shims.load_reference()
     gd.install_audiotools()
@@ -35,6 +38,8 @@ def main():
     losses = importlib.import_module("esc.modules")
     ycfg = yaml.safe_load(open(f"{gg.ref_shims.REFERENCE_ROOT}/configs/9kbps_esc_base_adv.yaml"))
     w = {k: float(v) for k, v in ycfg["loss"].items()}
+    if large:
+        ycfg["model"] = yaml.safe_load(open(f"{gg.ref_shims.REFERENCE_ROOT}/configs/9kbps_esc_large.yaml"))["model"]
     model, manifest = gg.build_reference(ref_models, ycfg["model"])
     model.train()
     disc = D.Discriminator(**{**ycfg.get("discriminator", {}), "sample_rate": 16000}) if "discriminator" in ycfg else D.Discriminator(sample_rate=16000)
@@ -42,7 +47,7 @@ def main():
     disc.load_state_dict({k: torch.from_numpy(v) for k, v in gd.synth_disc_state(dman).items()})
     gan = G.GANLoss(disc)
     mel_fn, stft_fn = losses.MelSpectrogramLoss(), losses.ComplexSTFTLoss()
-    tags = ["adv-0", "adv-1"]
+    tags = ["advL-0", "advL-1"] if large else ["adv-0", "adv-1"]
     pcm = np.stack([gg.synth.noise_clip_int16(tags[0], N_SAMPLES), gg.synth.voiced_clip_int16(tags[1], N_SAMPLES)])
     x = torch.from_numpy(gg.synth.pcm_to_float(pcm))
     # ---- generator update (trainer_adv.py:70-91)
@@ -72,7 +77,7 @@ def main():
     out.update(disc_keys_json=np.array(json.dumps(dkeys)), disc_loss=dl.detach().numpy(), disc_gnorm=np.array([float(dp[k].grad.double().norm()) for k in dkeys]))
     print("loss", out["loss"], "gen", out["gen"], "feat", out["feat"], "disc", out["disc_loss"], "|g gen|", float(np.sqrt((out["gen_gnorm"] ** 2).sum())),
           "|g disc|", float(np.sqrt((out["disc_gnorm"] ** 2).sum())))
-    np.savez_compressed(os.path.join(gg.GOLD, "adv.npz"), **out)
+    np.savez_compressed(os.path.join(gg.GOLD, "adv_large.npz" if large else "adv.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -274,12 +274,13 @@ def test_other_discriminator_configurations_and_lengths(cfg, B, L):
 
 
 # ------------------------------------------------------------------------------------------------ the whole adversarial step vs the reference
-def _adv_setup():
+def _adv_setup(which="adv"):
     """Fixture of ONE adversarial step of the real reference (oracle/gen_adv_golden.py -> tests/golden/adv.npz: trainer_adv.py:61-107 with its own
-    four discriminator passes): configurations, name-keyed synthetic weights of generator and discriminator, the two clips."""
+    four discriminator passes): configurations, name-keyed synthetic weights of generator and discriminator, the two clips.  `adv_large` =
+    BASELINE configs[4]'s networks: the ESC-Large generator (configs/9kbps_esc_large.yaml) under the adversarial yaml's discriminator / loss blocks."""
     from esc.models.codecs import state_manifest
     from esc.models import make_model
-    g = load_golden("adv")
+    g = load_golden(which)
     cfg, dcfg, w = json.loads(str(g["model_cfg_json"])), json.loads(str(g["disc_cfg_json"])), json.loads(str(g["weights_json"]))
     model = make_model(cfg)
     sd = {}
@@ -307,9 +308,10 @@ def _gnorm_check(got, ref, what, rel):
           f"{abs(np.sqrt((got ** 2).sum()) / np.sqrt((ref ** 2).sum()) - 1):.2e}")
 
 
-def test_oracle_adversarial_step_matches_reference():
+@pytest.mark.parametrize("which", ["adv", "adv_large"])
+def test_oracle_adversarial_step_matches_reference(which):
     from oracle import esc_oracle as O
-    g, cfg, dcfg, w, model, sd, dsd, x = _adv_setup()
+    g, cfg, dcfg, w, model, sd, dsd, x = _adv_setup(which)
     leaf = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not k.endswith(".window")) else v) for k, v in sd.items()}
     dleaf = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
     ocfg = dict(O.DISC_DEFAULT, **{k: v for k, v in dcfg.items() if k != "sample_rate"})
@@ -333,12 +335,14 @@ def test_oracle_adversarial_step_matches_reference():
 
 
 @pytest.mark.gpu
-def test_adversarial_step_with_shared_passes_equals_the_references_four_pass_step():
+@pytest.mark.parametrize("which", ["adv", "adv_large"])
+def test_adversarial_step_with_shared_passes_equals_the_references_four_pass_step(which):
     """The product runs the discriminator twice per step and serves both updates from those passes (GANLoss.adversarial_forward); the
-    reference runs it four times (trainer_adv.py:76-78, 98-100).  Same losses (1e-5) and the same gradients as the reference's step."""
+    reference runs it four times (trainer_adv.py:76-78, 98-100).  Same losses (1e-5) and the same gradients as the reference's step.
+    `adv_large` is BASELINE configs[4] as ONE workload: ESC-Large generator x full discriminator x adversarial step."""
     from esc.models import Discriminator
     from esc.modules import GANLoss, MelSpectrogramLoss
-    g, cfg, dcfg, w, model, sd, dsd, x = _adv_setup()
+    g, cfg, dcfg, w, model, sd, dsd, x = _adv_setup(which)
     model = model.cuda().train()
     disc = Discriminator(**dcfg).cuda().train()
     disc.load_state_dict(dsd)
@@ -359,6 +363,72 @@ def test_adversarial_step_with_shared_passes_equals_the_references_four_pass_ste
     np.testing.assert_allclose(dl.cpu().numpy(), g["disc_loss"], rtol=2e-5)
     dp = dict(disc.named_parameters())
     _gnorm_check([float(dp[k].grad.double().norm()) for k in json.loads(str(g["disc_keys_json"]))], g["disc_gnorm"], "discriminator", 2e-3)      # measured 6e-5
+
+
+@pytest.mark.gpu
+def test_configs4_at_full_size_large_generator_discriminator_adversarial_step():
+    """BASELINE configs[4] as ONE workload at its full size: ESC-Large generator x the full discriminator x the adversarial step on 36 clips of
+    3 s.  The oracle cannot run this in test time, so size-independent properties: everything finite; the step is run-to-run deterministic bit
+    for bit (losses, every generator and discriminator gradient); and the product's two shared discriminator passes equal the reference's
+    four-pass form (generator_loss + discriminator_loss evaluated separately, trainer_adv.py:76-78, 98-100) - loss values bit for bit, gradients
+    to fp32 rounding.  The small-size pin of the same networks is `adv_large` above."""
+    from esc.models import Discriminator
+    from esc.modules import GANLoss, MelSpectrogramLoss
+    g, cfg, dcfg, w, model, sd, dsd, _ = _adv_setup("adv_large")
+    B, L = 36, 47920
+    pcm = np.stack([(synth.voiced_clip_int16 if i % 2 else synth.noise_clip_int16)(f"c4-{i}", L) for i in range(B)])
+    x = torch.from_numpy(synth.pcm_to_float(pcm)).cuda()
+    model = model.cuda().train()
+    disc = Discriminator(**dcfg).cuda().train()
+    disc.load_state_dict(dsd)
+    gan, mel_fn = GANLoss(disc), MelSpectrogramLoss()
+
+    def weighted(out, mel, lg, lf):
+        return out["cm_loss"] * w["cm_weight"] + out["cb_loss"] * w["cb_weight"] + mel * w["mel_weight"] + lg * w["gen_weight"] + lf * w["feat_weight"]
+
+    def grads(net):
+        return torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+
+    def clear():
+        for p in list(model.parameters()) + list(disc.parameters()):
+            p.grad = None
+
+    def shared_step():
+        clear()
+        out = model(**dict(x=x, x_feat=None, num_streams=6, freeze_codebook=False))
+        mel = mel_fn(out["raw_audio"], out["recon_audio"])
+        d_fake, d_real = gan.adversarial_forward(fake=out["recon_audio"], real=out["raw_audio"])
+        lg, lf = gan.generator_loss_from(d_fake, d_real)
+        total = weighted(out, mel, lg, lf)
+        total.mean().backward()
+        gg_ = grads(model)
+        assert all(p.grad is None for p in disc.parameters())
+        dl = gan.discriminator_backward_from(d_fake, d_real)
+        return dict(total=total.detach().clone(), lg=lg.detach().clone(), lf=lf.detach().clone(), dl=dl.detach().clone(), codes=out["codes"].clone(), gg=gg_, dg=grads(disc))
+
+    a, b = shared_step(), shared_step()
+    for k in a:
+        assert torch.isfinite(a[k].float()).all(), k
+        assert torch.equal(a[k], b[k]), f"{k}: the step is not run-to-run deterministic"
+    assert float(a["gg"].abs().max()) > 0 and float(a["dg"].abs().max()) > 0 and a["codes"].shape[:3] == (B, 6, 3)
+    # the reference's form: two discriminator passes for the generator update, two more for the discriminator update
+    clear()
+    out = model(**dict(x=x, x_feat=None, num_streams=6, freeze_codebook=False))
+    mel = mel_fn(out["raw_audio"], out["recon_audio"])
+    lg, lf = gan.generator_loss(fake=out["recon_audio"], real=out["raw_audio"])
+    total = weighted(out, mel, lg, lf)
+    total.mean().backward()
+    gg4 = grads(model)
+    for p in disc.parameters():
+        p.grad = None
+    dl = gan.discriminator_loss(fake=out["recon_audio"].detach(), real=out["raw_audio"])
+    dl.mean().backward()
+    dg4 = grads(disc)
+    assert torch.equal(out["codes"], a["codes"]) and torch.equal(lg.detach(), a["lg"]) and torch.equal(lf.detach(), a["lf"]) and torch.equal(total.detach(), a["total"])
+    np.testing.assert_allclose(dl.detach().cpu().numpy(), a["dl"].cpu().numpy(), rtol=1e-6)
+    rg = float((gg4 - a["gg"]).double().norm() / a["gg"].double().norm()); rd = float((dg4 - a["dg"]).double().norm() / a["dg"].double().norm())
+    print(f"[configs[4] full size] B={B}: loss {float(total.mean()):.4f}, disc loss {float(dl.mean()):.4f}; four-pass vs shared-pass gradients: generator {rg:.2e}, discriminator {rd:.2e}")
+    assert rg < 1e-6 and rd < 1e-5
 
 
 # ------------------------------------------------------------------------------------------------ a second configuration from the real reference
