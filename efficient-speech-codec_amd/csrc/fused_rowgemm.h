@@ -5,6 +5,12 @@
 // 16-row tiles stream through a double-buffered LDS ring (fragment order, global_load_lds).  Each accumulator tile is
 // stored as soon as it is complete (16 B per lane) -- plain rows for PatchMerge, pixel-shuffled rows for PatchSplit.
 // The normalised tensor never goes to memory (the unfused path writes and re-reads it).
+//
+// Grid = row blocks x OUTPUT-COLUMN chunks.  At the deep scales a 36-clip batch has fewer 16-row tiles than the chip has SIMDs
+// (C = 384: 675 per half batch), and a wave that walks all 24 output tiles alone on its SIMD exposes every DMA wait and barrier
+// (34 % MFMA-busy, 110 us for a 20 us contraction).  Splitting the OUTPUT columns over workgroups multiplies the waves without touching
+// any reduction: every output element is still one k-ordered fmaf chain, so results are bit-identical for every chunking; the cost is
+// the re-done row gather + LayerNorm (K loads per row per chunk), chosen on the host (launch_rowgemm).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gemm_engine.h"
@@ -20,6 +26,7 @@ struct RowGemmArgs {
     int M, rows_per_clip, src_rows_per_clip, C, Cp, NT;     // NT = output tiles of 16
     int split, H, W, C2p;       // split != 0: out[(b, 2h+s, w)][c] with n = s*C2p + c ; else out[m][n], row stride 16*NT
     float eps;
+    int nt_chunk;               // output tiles per workgroup column: blockIdx.y owns tiles [y * nt_chunk, (y + 1) * nt_chunk)
 };
 
 template <int KP, int SEGS, int TM, int NW, int UT>
@@ -30,11 +37,12 @@ __global__ __launch_bounds__(64 * NW) void rowgemm_fused_kernel(RowGemmArgs a) {
     const int l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: keeps the DMA issue loop scalar
     const int m0 = (blockIdx.x * NW + wave) * (16 * TM);
-    const int n_stages = (a.NT + UT - 1) / UT;
+    const int nt_lo = blockIdx.y * a.nt_chunk, nt_hi = min(a.NT, nt_lo + a.nt_chunk);
+    const int n_stages = (nt_hi - nt_lo + UT - 1) / UT;
 
     auto issue = [&](int st, int buf) {
-        const int cnt = min(UT, a.NT - st * UT) * KK;
-        const f32x4* src = a.wf + (size_t)st * UT * KK * 64 + lane;
+        const int cnt = min(UT, nt_hi - nt_lo - st * UT) * KK;
+        const f32x4* src = a.wf + (size_t)(nt_lo + st * UT) * KK * 64 + lane;
         for (int c = wave; c < cnt; c += NW)
             __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(&wbuf[buf][c * 64]), 16, 0, 0);
     };
@@ -103,8 +111,8 @@ __global__ __launch_bounds__(64 * NW) void rowgemm_fused_kernel(RowGemmArgs a) {
         __syncthreads();
         if (st + 1 < n_stages) issue(st + 1, (st + 1) & 1);
         const f32x4* wb = &wbuf[st & 1][lane];
-        const int nt_end = min(a.NT, (st + 1) * UT);
-        for (int nt = st * UT; nt < nt_end; ++nt, wb += KK * 64) {
+        const int nt_end = min(nt_hi, nt_lo + (st + 1) * UT);
+        for (int nt = nt_lo + st * UT; nt < nt_end; ++nt, wb += KK * 64) {
             f32x4 acc[TM], acc2[TM];
 #pragma unroll
             for (int t = 0; t < TM; ++t) { acc[t] = zero4(); acc2[t] = zero4(); }

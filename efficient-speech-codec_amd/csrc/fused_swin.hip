@@ -118,13 +118,24 @@ static void launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
     constexpr int TM = KP <= 192 ? 2 : 1;
     constexpr int NW = 4;
     const int rows = 16 * TM * NW;
-    hipLaunchKernelGGL((rowgemm_fused_kernel<KP, SEGS, TM, NW, UT>), dim3((a.M + rows - 1) / rows), dim3(64 * NW), 0, s, a);
+    // Output-column chunks (fused_rowgemm.h), bit-identical for every chunking.  MEASURED (round 3, B = 36): targets of 3072 / 6144 waves make the
+    // merge + split kernels 3 % / 8 % SLOWER alone (1.333 -> 1.379 / 1.452 ms per step) and the step 2 - 2.6 % slower: these kernels are not short of
+    // waves, the re-done gather + LayerNorm costs more than the extra occupancy returns.  Off by default (ESCX_ROWGEMM_WAVES = target to try it).
+    static const int target = [] { const char* e = getenv("ESCX_ROWGEMM_WAVES"); return e ? atoi(e) : 0; }();
+    RowGemmArgs b = a;
+    const int waves = (a.M + 16 * TM - 1) / (16 * TM);
+    int chunks = target > 0 ? (target + waves - 1) / waves : 1;
+    chunks = std::max(1, std::min(chunks, a.NT / std::max(2 * UT, 2)));
+    b.nt_chunk = (a.NT + chunks - 1) / chunks;
+    b.nt_chunk = (b.nt_chunk + UT - 1) / UT * UT;                 // whole stages
+    chunks = (a.NT + b.nt_chunk - 1) / b.nt_chunk;
+    hipLaunchKernelGGL((rowgemm_fused_kernel<KP, SEGS, TM, NW, UT>), dim3((a.M + rows - 1) / rows, chunks), dim3(64 * NW), 0, s, b);
 }
 
 int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, const float* beta, const float* wf, const int* map, int M,
                   int rows_per_clip, int src_rows_per_clip, int C, int Cp, int Np, int split, int H, int W, int C2p, hipStream_t s) {
     RowGemmArgs a{x, out, gamma, beta, reinterpret_cast<const f32x4*>(wf), map, M, rows_per_clip, src_rows_per_clip, C, Cp, Np / 16,
-                  split, H, W, C2p, 1e-5f};
+                  split, H, W, C2p, 1e-5f, Np / 16};
     const int KP = segs * Cp;
     if (segs == 1) {
         switch (KP) {

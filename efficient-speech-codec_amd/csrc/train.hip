@@ -17,6 +17,7 @@
 #include "escx_internal.h"
 #include "launchers.h"
 #include "train_kernels.h"
+#include "train_mlp_fused.h"
 
 using namespace escx;
 
@@ -200,6 +201,31 @@ constexpr size_t ATT_PART_FLOATS = (size_t)512 * 64 * 256;
 
 inline float* G(escx_handle_s* h, const float* w) { return h->garena + (w - reinterpret_cast<const float*>(h->wts.base)); }
 
+// The wide token maps (C = 45: 12 hidden tiles = the 12 waves of one workgroup) run the MLP fused in both directions: forward = the inference
+// path's kernel (only x1 stays on the tape), backward = train_mlp_fused.h (hidden tile recomputed on the fly).  ESCX_TRAIN_MLP_FUSED=0: unfused.
+inline bool mlp_train_fused(const Layer& L) {
+    static const bool on = [] { const char* e = getenv("ESCX_TRAIN_MLP_FUSED"); return !(e && e[0] == '0'); }();
+    return on && L.Cp == 48 && L.hiddenP == 192;
+}
+
+// one workgroup per CU (~150 KB of LDS), persistent over the row tiles; `part` holds grid x (2 * hiddenP * Cp + hiddenP + Cp) floats + the reduced E
+int mlp_bwd_fused(escx_handle_s* h, const Layer& L, const BlockW& bw, const float* x1, const float* dy, float* dx1, float* dx1s, const int* slot_of,
+                  int tokens, int slots, int M, float* part, hipStream_t st) {
+    const int ntiles = (M + 15) / 16;
+    const int grid = std::min(ntiles, 256);
+    const int n1 = L.hiddenP * L.Cp;
+    const size_t per = 2 * (size_t)n1 + L.hiddenP + L.Cp;
+    if ((size_t)grid * per + n1 > DW_PART_FLOATS) ESCX_FAIL(ESCX_ERR_STATE, "dW scratch too small for the fused MLP backward");
+    MlpBwdArgs a{x1, dy, dx1, dx1s, slot_of, bw.ln2_g, bw.ln2_b, bw.w1, bw.b1, bw.w2T, bw.w1T, part, M, L.C, L.hiddenP, tokens, slots, 1e-5f};
+    hipLaunchKernelGGL((mlp_bwd_fused_kernel<48, 12>), dim3(grid), dim3(64 * 15), 0, st, a);
+    float* Etot = part + (size_t)grid * per;
+    hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, part, grid, n1, L.hiddenP, L.Cp, Etot, G(h, bw.w2),
+                       G(h, bw.b1), G(h, bw.b2));
+    hipLaunchKernelGGL(mlp_bwd_finish_kernel, dim3(1), dim3(1024), 0, st, Etot, G(h, bw.b1), bw.w1, bw.ln2_g, bw.ln2_b, G(h, bw.w1), G(h, bw.ln2_g),
+                       G(h, bw.ln2_b), L.hiddenP, L.Cp);
+    return 0;
+}
+
 // ---- tape sizing -----------------------------------------------------------------------------------
 int layer_H(escx_handle_s* h, const Shapes& s, int li) {
     const int n = h->n;
@@ -223,7 +249,8 @@ size_t tape_bytes(escx_handle_s* h, const Shapes& s) {
         const int H = layer_H(h, s, li);
         const size_t M = (size_t)B * H * s.W, Ms = (size_t)B * rup(H, 4) * rup(s.W, 4);
         for (size_t j = 0; j < L.blocks.size(); ++j) {
-            add(Ms * L.Cp); add(Ms * L.Nqkv); add(Ms * L.Ko); add(M * L.Cp); add(M * L.Cp); add(M * L.hiddenP); add(M * L.hiddenP); add(M * L.Cp);
+            add(Ms * L.Cp); add(Ms * L.Nqkv); add(Ms * L.Ko); add(M * L.Cp); add(M * L.Cp);
+            if (!mlp_train_fused(L)) { add(M * L.Cp); add(M * L.hiddenP); add(M * L.hiddenP); }       // xn2, h_pre, gelu(h_pre): not kept by the fused MLP
         }
         if (L.scale == 1) { const size_t M2 = (size_t)B * ((H + 1) / 2) * s.W; add(M2 * 2 * L.Cp); add(M2 * L.CoutP); }
         else if (L.scale == 2) { add(M * L.Cp); add(2 * M * L.CoutP); }
@@ -269,8 +296,11 @@ int layer_fwd(escx_handle_s* h, const Layer& L, LayerTape& LT, const float* x_in
         if ((rc = get_map(h, H, W, shift, &map))) return rc;
         bt.x0 = const_cast<float*>(x);
         bt.xn1 = tp.take((size_t)Ms * L.Cp); bt.qkv = tp.take((size_t)Ms * L.Nqkv); bt.obuf = tp.take((size_t)Ms * L.Ko);
-        bt.x1 = tp.take((size_t)M * L.Cp); bt.xn2 = tp.take((size_t)M * L.Cp);
-        bt.hpre = tp.take((size_t)M * L.hiddenP); bt.hact = tp.take((size_t)M * L.hiddenP); bt.x2 = tp.take((size_t)M * L.Cp);
+        const bool fmlp = mlp_train_fused(L);
+        bt.x1 = tp.take((size_t)M * L.Cp);
+        bt.xn2 = bt.hpre = bt.hact = nullptr;
+        if (!fmlp) { bt.xn2 = tp.take((size_t)M * L.Cp); bt.hpre = tp.take((size_t)M * L.hiddenP); bt.hact = tp.take((size_t)M * L.hiddenP); }
+        bt.x2 = tp.take((size_t)M * L.Cp);
         if (!bt.x2) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small");
         PROF("T.ln1_gather" + tg, 0, (dM + dMs) * dC * f4, ln_rows(1, x, bt.xn1, bw.ln1_g, bw.ln1_b, map, slots, tokens, Ms, L.C, L.Cp, st));
         PROF("T.gemm_qkv" + tg, 2 * dMs * dC * 3 * dC, dMs * 4 * dC * f4,
@@ -281,6 +311,15 @@ int layer_fwd(escx_handle_s* h, const Layer& L, LayerTape& LT, const float* x_in
         if (arc) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "head_dim %d unsupported by the attention kernel", L.hd);
         PROF("T.gemm_proj" + tg, 2 * dMs * dC * dC, (dMs * dC + 2 * dM * dC) * f4,
              gemm_proj_scatter(bt.obuf, L.Ko, Ms, bw.wproj, L.Cp, L.Ko, bt.x1, x, bw.bproj, map, slots, tokens, st));
+        if (fmlp) {       // LN2 + fc1 + GELU + fc2 + residual in one kernel, in place on a copy of x1 (x1 itself is what the backward recomputes from)
+            ESCX_HIP(hipMemcpyAsync(bt.x2, bt.x1, (size_t)M * L.Cp * sizeof(float), hipMemcpyDeviceToDevice, st));
+            int hs = 1, frc = 0;
+            PROF("T.mlp_fused" + tg, 4 * dM * dC * L.hidden, 4 * dM * dC * f4,
+                 frc = mlp_fused(bt.x2, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP, 3, &hs, nullptr, st));
+            if (frc) ESCX_FAIL(ESCX_ERR_STATE, "fused MLP not instantiated for Cp = %d", L.Cp);
+            x = bt.x2;
+            continue;
+        }
         PROF("T.ln2" + tg, 0, 2 * dM * dC * f4, ln_rows(0, bt.x1, bt.xn2, bw.ln2_g, bw.ln2_b, nullptr, tokens, tokens, M, L.C, L.Cp, st));
         PROF("T.gemm_fc1_gelu" + tg, 2 * dM * dC * L.hidden, dM * (dC + 2 * L.hidden) * f4,
              gemm_rows(bt.xn2, L.Cp, M, bw.w1, L.hiddenP, L.Cp, EpiGeluDual{bt.hpre, bt.hact, L.hiddenP, bw.b1}, st));
@@ -548,6 +587,14 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
         if ((rc = get_map(h, H, W, shift, &map))) return rc;
         if ((rc = get_map(h, H, W, 10 + shift, &inv))) return rc;
         // ---- MLP: x2 = x1 + W2 gelu(W1 LN2(x1) + b1) + b2 ----
+        const bool fmlp = mlp_train_fused(L);
+        static const bool ln_fused = [] { const char* e = getenv("ESCX_LN_FUSED"); return !(e && e[0] == '0'); }();
+        if (fmlp) {
+            if (slots != tokens) ESCX_HIP(hipMemsetAsync(dx1s, 0, (size_t)Ms * L.Cp * sizeof(float), st));      // pad slots carry no gradient
+            PROF("B.mlp_fused" + tg, 10.0 * M * L.C * L.hidden, 0,
+                 rc = mlp_bwd_fused(h, L, bw, bt.x1, dy, dx1, dx1s, inv, tokens, slots, M, part, st));
+            if (rc) return rc;
+        } else {
         PROF("B.dw_fc2" + tg, 2.0 * M * L.C * L.hidden, 0,
              rc = dw_rows(h, dy, L.Cp, bt.hact, L.hiddenP, M, L.Cp, L.hiddenP, G(h, bw.w2), G(h, bw.b2), part, st));
         if (rc) return rc;
@@ -557,7 +604,6 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
              rc = dw_rows(h, dhpre, L.hiddenP, bt.xn2, L.Cp, M, L.hiddenP, L.Cp, G(h, bw.w1), G(h, bw.b1), part, st));
         if (rc) return rc;
         if (slots != tokens) ESCX_HIP(hipMemsetAsync(dx1s, 0, (size_t)Ms * L.Cp * sizeof(float), st));      // pad slots carry no gradient
-        static const bool ln_fused = [] { const char* e = getenv("ESCX_LN_FUSED"); return !(e && e[0] == '0'); }();
         if (ln_fused && L.Cp <= 96) {       // narrow maps: LN2's backward rides in the epilogue of the GEMM that produces its upstream gradient
             PROF("B.dx_fc1+ln2" + tg, 2.0 * M * L.C * L.hidden, 0,
                  gemm_ln_bwd_rows(dhpre, L.hiddenP, M, bw.w1T, L.Cp, L.hiddenP, bt.x1, bw.ln2_g, dy, dx1, dx1s, inv, tokens, slots, L.C, G(h, bw.ln2_g),
@@ -567,6 +613,7 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
                  gemm_rows(dhpre, L.hiddenP, M, bw.w1T, L.Cp, L.hiddenP, EpiStore{dxn, L.Cp, nullptr}, st));
             PROF("B.ln2" + tg, 0, 5.0 * M * L.C * 4,
                  ln_bwd(0, bt.x1, dxn, bw.ln2_g, nullptr, dy, dx1, G(h, bw.ln2_g), G(h, bw.ln2_b), tokens, tokens, tokens, M, L.C, L.Cp, lnpart, st, dx1s, inv, slots));
+        }
         }
         // ---- attention: x1 = x0 + scatter(Wp attn(Wqkv gather(LN1(x0)))) ----
         PROF("B.dw_proj" + tg, 2.0 * Ms * L.C * L.C, 0,
@@ -918,12 +965,14 @@ extern "C" int escx_grad_norm_clip(const float* grad_flat, int64_t n, float max_
     return launch_ok("grad_norm_clip");
 }
 // torch.optim.AdamW step t (1-based) on flat parameter / gradient / moment buffers; clip_dev (optional) = output of escx_grad_norm_clip
-extern "C" int escx_adamw_step(float* param_flat, const float* grad_flat, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr, float beta1,
-                               float beta2, float eps, float weight_decay, const float* clip_dev, void* stream) {
+extern "C" int escx_adamw_step(float* param_flat, const float* grad_flat, float* exp_avg, float* exp_avg_sq, int64_t n, int step, double lr, double beta1,
+                               double beta2, double eps, double weight_decay, const float* clip_dev, void* stream) {
     if (!param_flat || !grad_flat || !exp_avg || !exp_avg_sq || n < 1 || step < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
-    // torch.optim.AdamW evaluates the bias corrections, lr / bc1 and sqrt(bc2) in double (python floats) and hands the kernel two fp32 scalars
-    const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    // torch.optim.AdamW evaluates the bias corrections, lr / bc1, sqrt(bc2), 1 - beta and 1 - lr * wd in double (python floats) and hands its
+    // kernels fp32 scalars: the same here (fp32 1 - 0.999f alone is off by 1.3e-5 relative)
+    const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks_for((long long)n)), dim3(256), 0, (hipStream_t)stream, param_flat, grad_flat, exp_avg, exp_avg_sq, (long long)n,
-                       clip_dev, lr, beta1, beta2, eps, weight_decay, (float)((double)lr / bc1), (float)std::sqrt(bc2));
+                       clip_dev, (float)(1.0 - lr * weight_decay), (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                       (float)(lr / bc1), (float)std::sqrt(bc2));
     return launch_ok("adamw_step");
 }

@@ -1,0 +1,326 @@
+// Fused backward of the Swin block's MLP for the wide token maps of the training step (C = 45: 19 200 tokens per 3 s clip).
+//
+//   x2 = x1 + W2 gelu(W1 LN2(x1) + b1) + b2          (attention.py:267-272 inside attention.py:168-176)
+//
+// The unfused backward (train.hip) is four launches that are HBM-bound on hidden-sized tensors: the forward writes h_pre and gelu(h_pre)
+// (tokens x 4C each), dW_fc2 reads the activation, dX_fc2 reads h_pre and writes d h_pre, dW_fc1 and dX_fc1 read d h_pre - seven passes over
+// a 530 MB tensor per block at 36 clips.  Here NOTHING hidden-sized exists in memory: the forward is the inference path's fused kernel
+// (fused_mlp.h: only x1 stays on the tape) and this kernel recomputes the hidden tile from x1 on the fly.
+//
+// Work split (one workgroup = NW waves = the NW hidden tiles of 16 units; workgroups are persistent and stride over 16-row tiles):
+//   * wave w OWNS hidden tile w: its slices of W1 (two operand layouts) and W2 live in registers for the whole kernel, and so do its
+//     accumulators of dW1[16w..16w+15][:] and dW2[:][16w..16w+15] - the weight gradients are contracted over ALL rows the workgroup
+//     visits without ever leaving the register file;
+//   * per row tile every wave computes, for its hidden tile:  h_pre = xn W1^T + b1,  d h_act = dy W2,  d h_pre = d h_act * gelu'(h_pre),
+//     dW1 += d h_pre^T xn,  dW2 += dy^T gelu(h_pre),  and its share of  d xn = d h_pre W1  (16 x C partial sums);
+//   * the NW partial sums of d xn meet in LDS and ONE wave (the role rotates) adds them in wave order, applies the LayerNorm backward
+//     and writes dx1 = dy + LN2'(d xn) (token order, and window-slot order for the attention backward).  That wave is on the critical path of
+//     the iteration (everybody meets it at the next barrier), so it does nothing else: the LayerNorm's parameter gradients are NOT column
+//     sums over the rows here (a first version did that with 108 cross-lane shuffles per tile: 1.69 ms per launch, 33 TFLOP/s) but algebra:
+//     with E = d h_pre^T xhat (what the wave accumulates instead of dW1; xhat = the normalised rows before the affine map),
+//        dW1 = E diag(gamma) + d b1 beta^T,    d gamma = colsum(W1 * E),    d beta = W1^T d b1      (mlp_bwd_finish_kernel, exact identities);
+//   * the row tile (LayerNorm applied once) is staged in LDS by two other waves one iteration ahead, in both operand layouts
+//     (row-major for the contractions over channels, transposed for the contractions over rows), so no wave ever waits on global memory.
+// One barrier per row tile.  No atomics: per-workgroup partial sums of every parameter gradient are reduced in a fixed order by the caller
+// (reduce_partials), so the step stays run-to-run deterministic.
+//
+// MFMA operand conventions (v_mfma_f32_16x16x4_f32, lane = (g = lane >> 4, b = lane & 15)): A-operand register = A[i = b][k-slot g],
+// B-operand register = B[k-slot g][j = b], D register r = D[i = 4g + r][j = b].  A D tile is therefore directly the B operand of a
+// contraction over its ROW index (k-slot g <-> rows 4g + r at step r); a contraction over its COLUMN index needs the transposed tile
+// (one 16 x 16 transpose of d h_pre per tile through a private LDS scratch).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gemm_engine.h"
+#include "train_kernels.h"
+
+namespace escx {
+
+struct MlpBwdArgs {
+    const float* x1;            // [M][CP]   input of LN2 (kept on the tape)
+    const float* dy;            // [M][CP]   gradient w.r.t. the block output x2
+    float* dx1;                 // [M][CP]   out: dy + LN2 backward
+    float* dx1s;                // [B*slots][CP] the same rows in window-slot order (nullptr: not written)
+    const int* slot_of;         // token -> slot (per clip)
+    const float* gamma; const float* beta;      // LN2 [CP]
+    const float* w1;            // [hiddenP][CP]
+    const float* b1;            // [hiddenP]
+    const float* w2T;           // [hiddenP][CP]   (w2T[h][c] = W2[c][h])
+    const float* w1T;           // [CP][hiddenP]
+    float* part;                // per-workgroup partial sums, regions [grid][n]: E = d h_pre^T xhat (hiddenP*CP) | dW2 (CP*hiddenP) | db1 (hiddenP) | db2 (CP)
+    int M, C, hiddenP, tokens, slots;
+    float eps;
+};
+
+// NC compute waves (= hidden tiles) + 3 service waves: wave NC stages x1 (LayerNorm), wave NC + 1 stages dy, wave NC + 2 finishes the PREVIOUS
+// tile (cross-wave sum of the d xn partials, LayerNorm backward, stores).  A first version rotated these roles over the compute waves: with
+// one barrier per tile everybody then waits for the wave that had the extra role (0.92 ms per launch); with dedicated waves the compute waves
+// all do the same work between two barriers and a service wave has a whole iteration (~6000 cycles) for a few hundred cycles of work.
+template <int CP, int NC>
+__global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs a) {
+    constexpr int KC = CP / 16;                 // channel tiles
+    constexpr int SLD = CP + 4, TLD = 20;       // row strides (dwords) of the row-major / transposed staged copies
+    struct Stage { float xn[16 * SLD]; float xh[16 * SLD]; float dy[16 * SLD]; float xhT[CP * TLD]; float dyT[CP * TLD]; float rstd[16]; };
+    __shared__ Stage stg[3];
+    __shared__ float red[2][NC][16 * SLD];
+    __shared__ float tr[NC][16 * TLD];
+    __shared__ float gam_s[CP], bet_s[CP];
+
+    const int lane = threadIdx.x & 63, b = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntiles = (a.M + 15) / 16;
+    const int n_it = (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const float invC = 1.0f / (float)a.C;
+    if (threadIdx.x < CP) { gam_s[threadIdx.x] = a.gamma[threadIdx.x]; bet_s[threadIdx.x] = a.beta[threadIdx.x]; }
+    __syncthreads();
+    auto tile_row = [&](int t) { return ((int)blockIdx.x + t * (int)gridDim.x) * 16 + b; };
+
+    if (wave == NC) {
+        // ---- stager of x1: LayerNorm once per row, both operand layouts; global loads run two tiles ahead of the consumers ----
+        f32x4 pre[KC];
+        auto load = [&](int t) {
+            const int row = tile_row(t);
+#pragma unroll
+            for (int ct = 0; ct < KC; ++ct) pre[ct] = (t < n_it && row < a.M) ? ld4(a.x1 + (size_t)row * CP + 16 * ct + 4 * g) : zero4();
+        };
+        auto store = [&](Stage& S, int t) {
+            const bool live = tile_row(t) < a.M;
+            float s = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < KC; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (16 * ct + 4 * g + e < a.C) s += pre[ct][e];
+            const float mean = sum_groups(s) * invC;
+            float var = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < KC; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (16 * ct + 4 * g + e < a.C) { const float d = pre[ct][e] - mean; var += d * d; }
+            const float rstd = 1.0f / sqrtf(sum_groups(var) * invC + a.eps);
+#pragma unroll
+            for (int ct = 0; ct < KC; ++ct) {
+                const f32x4 bt = ld4(&bet_s[16 * ct + 4 * g]), gm = ld4(&gam_s[16 * ct + 4 * g]);
+                f32x4 xh, xn;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = live && (16 * ct + 4 * g + e < a.C);
+                    xh[e] = in ? (pre[ct][e] - mean) * rstd : 0.f;
+                    xn[e] = in ? xh[e] * gm[e] + bt[e] : 0.f;
+                    S.xhT[(16 * ct + 4 * g + e) * TLD + b] = xh[e];
+                }
+                st4(&S.xh[b * SLD + 16 * ct + 4 * g], xh);
+                st4(&S.xn[b * SLD + 16 * ct + 4 * g], xn);
+            }
+            if (g == 0) S.rstd[b] = live ? rstd : 0.f;
+        };
+        load(0); store(stg[0], 0); load(1);
+        __syncthreads();
+        int snext = 1;
+        for (int it = 0; it < n_it; ++it) {
+            if (it + 1 < n_it) { store(stg[snext], it + 1); load(it + 2); }
+            snext = snext == 2 ? 0 : snext + 1;
+            __syncthreads();
+        }
+    } else if (wave == NC + 1) {
+        // ---- stager of dy ----
+        f32x4 pre[KC];
+        auto load = [&](int t) {
+            const int row = tile_row(t);
+#pragma unroll
+            for (int ct = 0; ct < KC; ++ct) pre[ct] = (t < n_it && row < a.M) ? ld4(a.dy + (size_t)row * CP + 16 * ct + 4 * g) : zero4();
+        };
+        f32x4 sdy[KC];                           // d b2 = column sums of dy: this lane's row of every tile (rows beyond M are loaded as zeros)
+#pragma unroll
+        for (int ct = 0; ct < KC; ++ct) sdy[ct] = zero4();
+        auto store = [&](Stage& S) {
+#pragma unroll
+            for (int ct = 0; ct < KC; ++ct) {
+                sdy[ct] += pre[ct];
+                st4(&S.dy[b * SLD + 16 * ct + 4 * g], pre[ct]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S.dyT[(16 * ct + 4 * g + e) * TLD + b] = pre[ct][e];
+            }
+        };
+        load(0); store(stg[0]); load(1);
+        __syncthreads();
+        int snext = 1;
+        for (int it = 0; it < n_it; ++it) {
+            if (it + 1 < n_it) { store(stg[snext]); load(it + 2); }
+            snext = snext == 2 ? 0 : snext + 1;
+            __syncthreads();
+        }
+        float* Pd = a.part + (size_t)gridDim.x * (2 * (size_t)a.hiddenP * CP + a.hiddenP) + (size_t)blockIdx.x * CP;
+#pragma unroll
+        for (int ct = 0; ct < KC; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float u = sdy[ct][e];
+#pragma unroll
+                for (int sh = 8; sh >= 1; sh >>= 1) u += __shfl_xor(u, sh, 16);
+                if (b == 0) Pd[16 * ct + 4 * g + e] = u;
+            }
+    } else if (wave == NC + 2) {
+        // ---- finisher: during iteration it it completes tile it - 1 (the partial sums were published by the barrier that ended it - 1) ----
+        auto finish = [&](int t, const Stage& S) {
+            const int row = tile_row(t);
+            const bool live = row < a.M;
+            const float* rp = &red[t & 1][0][0];
+            f32x4 gv[KC], xh[KC];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < KC; ++ct) {
+                const int o4 = b * SLD + 16 * ct + 4 * g;
+                f32x4 tt = ld4(rp + o4);
+#pragma unroll
+                for (int w = 1; w < NC; ++w) tt += ld4(rp + w * 16 * SLD + o4);           // wave order: fixed
+                xh[ct] = ld4(&S.xh[o4]);
+                tt *= ld4(&gam_s[16 * ct + 4 * g]);                                       // gamma = 0 in the pad channels
+                gv[ct] = tt;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1 += tt[e]; s2 += tt[e] * xh[ct][e]; }
+            }
+            const float c1 = sum_groups(s1) * invC, c2 = sum_groups(s2) * invC;
+            const float rstd = S.rstd[b];
+            if (live) {
+                float* ds = nullptr;
+                if (a.dx1s) { const int bi = row / a.tokens, rr = row - bi * a.tokens; ds = a.dx1s + ((size_t)bi * a.slots + a.slot_of[rr]) * CP; }
+#pragma unroll
+                for (int ct = 0; ct < KC; ++ct) {
+                    const f32x4 dyv = ld4(&S.dy[b * SLD + 16 * ct + 4 * g]);
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (16 * ct + 4 * g + e < a.C) ? dyv[e] + rstd * (gv[ct][e] - c1 - xh[ct][e] * c2) : 0.f;
+                    st4(a.dx1 + (size_t)row * CP + 16 * ct + 4 * g, o);
+                    if (ds) st4(ds + 16 * ct + 4 * g, o);
+                }
+            }
+        };
+        __syncthreads();
+        int sprev = 2;                           // (it - 1) % 3
+        for (int it = 0; it < n_it; ++it) {
+            if (it > 0) finish(it - 1, stg[sprev]);
+            sprev = sprev == 2 ? 0 : sprev + 1;
+            __syncthreads();
+        }
+        if (n_it > 0) finish(n_it - 1, stg[sprev]);
+    } else {
+        // ---- compute wave w: hidden tile w ----
+        f32x4 W1a[KC], W2c[KC], W1e[KC], dW1T[KC], dW2[KC];
+#pragma unroll
+        for (int ct = 0; ct < KC; ++ct) {
+            W1a[ct] = ld4(a.w1 + (size_t)(16 * wave + b) * CP + 16 * ct + 4 * g);
+            W2c[ct] = ld4(a.w2T + (size_t)(16 * wave + b) * CP + 16 * ct + 4 * g);
+            W1e[ct] = ld4(a.w1T + (size_t)(16 * ct + b) * a.hiddenP + 16 * wave + 4 * g);
+            dW1T[ct] = zero4(); dW2[ct] = zero4();
+        }
+        const float bias1 = a.b1[16 * wave + b];
+        float db1 = 0.f;
+        float* trw = &tr[wave][0];
+        __syncthreads();
+        int sidx = 0;
+        for (int it = 0; it < n_it; ++it) {
+            const Stage& S = stg[sidx];
+            f32x4 hp = {bias1, bias1, bias1, bias1}, dh = zero4();
+#pragma unroll
+            for (int ct = 0; ct < KC; ++ct) {
+                const f32x4 xa = ld4(&S.xn[b * SLD + 16 * ct + 4 * g]);
+                const f32x4 da = ld4(&S.dy[b * SLD + 16 * ct + 4 * g]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    hp = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[r], W1a[ct][r], hp, 0, 0, 0);        // h_pre[row 4g+r'][hid b]
+                    dh = __builtin_amdgcn_mfma_f32_16x16x4f32(da[r], W2c[ct][r], dh, 0, 0, 0);        // d h_act
+                }
+            }
+            // the row-contraction operands are fetched BEFORE the GELU arithmetic so that their LDS latency hides under it (all waves of the
+            // workgroup run in lockstep behind the per-tile barrier: an exposed LDS round trip is paid by every SIMD at the same time)
+            f32x4 xt[KC], dt[KC];
+#pragma unroll
+            for (int ct = 0; ct < KC; ++ct) {
+                xt[ct] = ld4(&S.xhT[(16 * ct + b) * TLD + 4 * g]);
+                dt[ct] = ld4(&S.dyT[(16 * ct + b) * TLD + 4 * g]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 hact, dhp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { float ac, gr; gelu_pair(hp[r], ac, gr); hact[r] = ac; dhp[r] = dh[r] * gr; }
+            db1 += (dhp[0] + dhp[1]) + (dhp[2] + dhp[3]);
+            // transpose d h_pre through the wave's private scratch: written [hid b][rows 4g..4g+3], read [hid 4g+r][row b]
+            st4(trw + b * TLD + 4 * g, dhp);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            f32x4 dhT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dhT[r] = trw[(4 * g + r) * TLD + b];
+            __builtin_amdgcn_sched_barrier(0);
+            // weight gradients: contractions over the 16 rows (k-slot g <-> rows 4g + r)
+#pragma unroll
+            for (int ct = 0; ct < KC; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dW1T[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[ct][r], dhp[r], dW1T[ct], 0, 0, 0);   // E[hid b][c 16ct+4g+r'] = sum_rows d h_pre * xhat
+                    dW2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dt[ct][r], hact[r], dW2[ct], 0, 0, 0);    // dW2[c 16ct+4g+r'][hid b]
+                }
+            // this tile's share of d xn = d h_pre W1: D[c 16ct+4g+r'][row b]; the KC accumulators are independent chains
+            f32x4 dx[KC];
+#pragma unroll
+            for (int ct = 0; ct < KC; ++ct) dx[ct] = zero4();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ct = 0; ct < KC; ++ct) dx[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(W1e[ct][r], dhT[r], dx[ct], 0, 0, 0);
+            float* rp = &red[it & 1][wave][0];
+#pragma unroll
+            for (int ct = 0; ct < KC; ++ct) st4(rp + b * SLD + 16 * ct + 4 * g, dx[ct]);
+            sidx = sidx == 2 ? 0 : sidx + 1;
+            __syncthreads();
+        }
+        // per-workgroup partial sums of the parameter gradients
+        const size_t n1 = (size_t)a.hiddenP * CP;
+        float* P1 = a.part + (size_t)blockIdx.x * n1;
+        float* P2 = a.part + (size_t)gridDim.x * n1 + (size_t)blockIdx.x * n1;
+        float* Pb = a.part + (size_t)gridDim.x * 2 * n1 + (size_t)blockIdx.x * a.hiddenP;
+#pragma unroll
+        for (int ct = 0; ct < KC; ++ct) {
+            st4(P1 + (size_t)(16 * wave + b) * CP + 16 * ct + 4 * g, dW1T[ct]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P2[(size_t)(16 * ct + 4 * g + r) * a.hiddenP + 16 * wave + b] = dW2[ct][r];
+        }
+        const float sb = sum_groups(db1);
+        if (g == 0) Pb[16 * wave + b] = sb;
+    }
+}
+
+// Fixed-order sum of the per-workgroup partials (slice-major regions E | dW2 | db1 | db2) in ONE launch: thread i owns output element i and adds
+// the `slices` values in slice order (consecutive threads read consecutive addresses of a slice: coalesced).  dW2, db1 and db2 are final; E
+// and db1 feed mlp_bwd_finish_kernel.
+static __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(const float* __restrict__ part, int slices, int n1, int hiddenP, int Cp,
+                                                                    float* __restrict__ E, float* __restrict__ dW2, float* __restrict__ db1, float* __restrict__ db2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int total = 2 * n1 + hiddenP + Cp;
+    if (i >= total) return;
+    const float* src; float* dst; int n, j;
+    if (i < n1) { src = part; dst = E; n = n1; j = i; }
+    else if (i < 2 * n1) { src = part + (size_t)slices * n1; dst = dW2; n = n1; j = i - n1; }
+    else if (i < 2 * n1 + hiddenP) { src = part + (size_t)slices * 2 * n1; dst = db1; n = hiddenP; j = i - 2 * n1; }
+    else { src = part + (size_t)slices * (2 * n1 + hiddenP); dst = db2; n = Cp; j = i - 2 * n1 - hiddenP; }
+    float t = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < slices; ++k) t += src[(size_t)k * n + j];
+    dst[j] = t;
+}
+
+// dW1 = E diag(gamma) + d b1 beta^T ;  d gamma[c] = sum_h W1[h][c] E[h][c] ;  d beta[c] = sum_h W1[h][c] d b1[h]   (fixed summation order)
+static __global__ void mlp_bwd_finish_kernel(const float* __restrict__ E, const float* __restrict__ db1, const float* __restrict__ w1,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dW1,
+                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int hiddenP, int Cp) {
+    for (int i = threadIdx.x; i < hiddenP * Cp; i += blockDim.x) {
+        const int hh = i / Cp, c = i - hh * Cp;
+        dW1[i] = E[i] * gamma[c] + db1[hh] * beta[c];
+    }
+    for (int c = threadIdx.x; c < Cp; c += blockDim.x) {
+        float sg = 0.f, sb = 0.f;
+        for (int hh = 0; hh < hiddenP; ++hh) { const float w = w1[(size_t)hh * Cp + c]; sg += w * E[(size_t)hh * Cp + c]; sb += w * db1[hh]; }
+        dgamma[c] = sg; dbeta[c] = sb;
+    }
+}
+
+}  // namespace escx

@@ -5,7 +5,7 @@ import of this module (or the first call) fails loudly.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int16, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int16, c_int32, c_int64, c_void_p
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libescx.so")
 MAX_SCALES = 8
@@ -75,7 +75,7 @@ SIGNATURES = {
     "escx_mel_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "escx_scale_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "escx_grad_norm_clip": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p]),
-    "escx_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "escx_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p, c_void_p]),
     "escx_disc_create": (c_int, [POINTER(EscxDiscConfig), c_int, POINTER(c_void_p)]),
     "escx_disc_destroy": (None, [c_void_p]),
     "escx_disc_param_count": (c_int, [c_void_p]),

@@ -197,8 +197,10 @@ int escx_mel_loss(const float* raw_wave_dev, const float* recon_wave_dev, int ba
 int escx_scale_rows(const float* x_dev, const float* g_dev, float* out_dev, int rows, int64_t per_row, void* stream);   /* out[r][:] = x[r][:] * g[r] */
 /* clip_grad_norm_ + AdamW on flat buffers (trainer_no_adv.py:116-117).  norm_out_dev: 2 + 1024 floats ([0] = norm, [1] = clip coefficient). */
 int escx_grad_norm_clip(const float* grad_flat_dev, int64_t n, float max_norm, float* norm_out_dev, void* stream);
+/* Hyper-parameters are doubles, as torch.optim.AdamW holds them (python floats): 1 - beta, lr / (1 - beta1^t), sqrt(1 - beta2^t) and 1 - lr * wd are
+ * evaluated in double on the host and reach the kernel as fp32 scalars, exactly as torch's single-tensor path does. */
 int escx_adamw_step(float* param_flat_dev, const float* grad_flat_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n, int step,
-                    float lr, float beta1, float beta2, float eps, float weight_decay, const float* clip_dev, void* stream);
+                    double lr, double beta1, double beta2, double eps, double weight_decay, const float* clip_dev, void* stream);
 
 /* ---- adversarial step: DAC discriminator + GAN losses (BASELINE configs[4]; scripts/trainer_adv.py:61-107) ---------------------------------
  * Reference: esc/models/discriminator.py:31-221 (MPD :31-66, MRD :105-176, Discriminator :179-215; MSD is not used by any ESC config),

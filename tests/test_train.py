@@ -522,14 +522,16 @@ def test_checkpoint_layout_is_the_reference_trainers():
     for p, q, gr in zip(model.parameters(), twin.parameters(), grads):
         p.grad.copy_(gr); q.grad = gr.clone()
     st.opt_g.step(); topt.step()
-    worst = max(float((p - q).abs().max()) for p, q in zip(model.parameters(), twin.parameters()))
+    worst = max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(model.parameters(), twin.parameters()))
     assert worst < 2e-7, worst
     # and back: torch's state (after its step) into a fresh FlatAdamW
     back = FlatAdamW(twin, lr=1e-3)
     back.load_state_dict(topt.state_dict())
     assert back.t == 4
     for (_, a), (_, b) in zip(sorted(back.state_dict()["state"].items()), sorted(st.opt_g.state_dict()["state"].items())):
-        assert float((a["exp_avg"] - b["exp_avg"]).abs().max()) < 1e-7 and float((a["exp_avg_sq"] - b["exp_avg_sq"]).abs().max()) < 1e-9
+        # torch's lerp_ and the flat kernel's beta * m + (1 - beta) * g round differently in the last bit
+        assert float((a["exp_avg"] - b["exp_avg"]).abs().max()) <= 1e-6 * float(b["exp_avg"].abs().max()) + 1e-12
+        assert float((a["exp_avg_sq"] - b["exp_avg_sq"]).abs().max()) <= 1e-6 * float(b["exp_avg_sq"].abs().max()) + 1e-15
     with pytest.raises(ValueError):
         back.load_state_dict({"state": {}, "param_groups": [dict(osd["param_groups"][0], params=[0, 1])]})
 
