@@ -216,7 +216,8 @@ int mlp_bwd_fused(escx_handle_s* h, const Layer& L, const BlockW& bw, const floa
     const int n1 = L.hiddenP * L.Cp;
     const size_t per = 2 * (size_t)n1 + L.hiddenP + L.Cp;
     if ((size_t)grid * per + n1 > DW_PART_FLOATS) ESCX_FAIL(ESCX_ERR_STATE, "dW scratch too small for the fused MLP backward");
-    MlpBwdArgs a{x1, dy, dx1, dx1s, slot_of, bw.ln2_g, bw.ln2_b, bw.w1, bw.b1, bw.w2T, bw.w1T, part, M, L.C, L.hiddenP, tokens, slots, 1e-5f};
+    MlpBwdArgs a{x1, dy, dx1, dx1s, slot_of, bw.ln2_g, bw.ln2_b, bw.w1, bw.b1, bw.w2T, bw.w1T, part, M, L.C, L.hiddenP, tokens, slots, 1e-5f, 0};
+    { static const int dbg = [] { const char* e = getenv("ESCX_MLPBWD_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     hipLaunchKernelGGL((mlp_bwd_fused_kernel<48, 12>), dim3(grid), dim3(64 * 15), 0, st, a);
     float* Etot = part + (size_t)grid * per;
     hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, part, grid, n1, L.hiddenP, L.Cp, Etot, G(h, bw.w2),

@@ -49,12 +49,18 @@ struct MlpBwdArgs {
     float* part;                // per-workgroup partial sums, regions [grid][n]: E = d h_pre^T xhat (hiddenP*CP) | dW2 (CP*hiddenP) | db1 (hiddenP) | db2 (CP)
     int M, C, hiddenP, tokens, slots;
     float eps;
+    int dbg;                    // timing experiments only (ESCX_MLPBWD_DBG): 1 = finisher idle, 2 = stagers stage only the first tile, 4 = compute waves skip the partial-sum writes
 };
 
 // NC compute waves (= hidden tiles) + 3 service waves: wave NC stages x1 (LayerNorm), wave NC + 1 stages dy, wave NC + 2 finishes the PREVIOUS
 // tile (cross-wave sum of the d xn partials, LayerNorm backward, stores).  A first version rotated these roles over the compute waves: with
 // one barrier per tile everybody then waits for the wave that had the extra role (0.92 ms per launch); with dedicated waves the compute waves
 // all do the same work between two barriers and a service wave has a whole iteration (~6000 cycles) for a few hundred cycles of work.
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also drains the vector-memory counter (s_waitcnt vmcnt(0)): the staging waves
+// would then wait at every tile for the global loads they have just issued for the tile after next (HBM latency per iteration: 745 us per launch
+// instead of ~480), and the finishing wave for its stores.  The data exchanged between waves here lives in LDS; global loads stay in flight.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int CP, int NC>
 __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs a) {
     constexpr int KC = CP / 16;                 // channel tiles
@@ -74,6 +80,10 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
     __syncthreads();
     auto tile_row = [&](int t) { return ((int)blockIdx.x + t * (int)gridDim.x) * 16 + b; };
 
+    // The service waves are the youngest of the workgroup: at equal priority the SIMD's arbiter hands them only the issue slots the three compute
+    // waves leave over, and their short per-tile chains then take longer than the compute waves' tile (measured: the finisher +120 us, the stagers
+    // +73 us per launch on a 530 us compute loop).  They issue a few hundred instructions per tile, so they go first.
+    if (wave >= NC) __builtin_amdgcn_s_setprio(3);
     if (wave == NC) {
         // ---- stager of x1: LayerNorm once per row, both operand layouts; global loads run two tiles ahead of the consumers ----
         f32x4 pre[KC];
@@ -113,12 +123,12 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
             if (g == 0) S.rstd[b] = live ? rstd : 0.f;
         };
         load(0); store(stg[0], 0); load(1);
-        __syncthreads();
+        lds_barrier();
         int snext = 1;
         for (int it = 0; it < n_it; ++it) {
-            if (it + 1 < n_it) { store(stg[snext], it + 1); load(it + 2); }
+            if (it + 1 < n_it && !(a.dbg & 2)) { store(stg[snext], it + 1); load(it + 2); }
             snext = snext == 2 ? 0 : snext + 1;
-            __syncthreads();
+            lds_barrier();
         }
     } else if (wave == NC + 1) {
         // ---- stager of dy ----
@@ -141,12 +151,12 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
             }
         };
         load(0); store(stg[0]); load(1);
-        __syncthreads();
+        lds_barrier();
         int snext = 1;
         for (int it = 0; it < n_it; ++it) {
-            if (it + 1 < n_it) { store(stg[snext]); load(it + 2); }
+            if (it + 1 < n_it && !(a.dbg & 2)) { store(stg[snext]); load(it + 2); }
             snext = snext == 2 ? 0 : snext + 1;
-            __syncthreads();
+            lds_barrier();
         }
         float* Pd = a.part + (size_t)gridDim.x * (2 * (size_t)a.hiddenP * CP + a.hiddenP) + (size_t)blockIdx.x * CP;
 #pragma unroll
@@ -194,12 +204,12 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
                 }
             }
         };
-        __syncthreads();
+        lds_barrier();
         int sprev = 2;                           // (it - 1) % 3
         for (int it = 0; it < n_it; ++it) {
-            if (it > 0) finish(it - 1, stg[sprev]);
+            if (it > 0 && !(a.dbg & 1)) finish(it - 1, stg[sprev]);
             sprev = sprev == 2 ? 0 : sprev + 1;
-            __syncthreads();
+            lds_barrier();
         }
         if (n_it > 0) finish(n_it - 1, stg[sprev]);
     } else {
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
         const float bias1 = a.b1[16 * wave + b];
         float db1 = 0.f;
         float* trw = &tr[wave][0];
-        __syncthreads();
+        lds_barrier();
         int sidx = 0;
         for (int it = 0; it < n_it; ++it) {
             const Stage& S = stg[sidx];
@@ -269,9 +279,9 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
                 for (int ct = 0; ct < KC; ++ct) dx[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(W1e[ct][r], dhT[r], dx[ct], 0, 0, 0);
             float* rp = &red[it & 1][wave][0];
 #pragma unroll
-            for (int ct = 0; ct < KC; ++ct) st4(rp + b * SLD + 16 * ct + 4 * g, dx[ct]);
+            for (int ct = 0; ct < KC; ++ct) if (!(a.dbg & 4) || it == 0) st4(rp + b * SLD + 16 * ct + 4 * g, dx[ct]);
             sidx = sidx == 2 ? 0 : sidx + 1;
-            __syncthreads();
+            lds_barrier();
         }
         // per-workgroup partial sums of the parameter gradients
         const size_t n1 = (size_t)a.hiddenP * CP;
@@ -309,17 +319,26 @@ static __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(const float*
 }
 
 // dW1 = E diag(gamma) + d b1 beta^T ;  d gamma[c] = sum_h W1[h][c] E[h][c] ;  d beta[c] = sum_h W1[h][c] d b1[h]   (fixed summation order)
-static __global__ void mlp_bwd_finish_kernel(const float* __restrict__ E, const float* __restrict__ db1, const float* __restrict__ w1,
+static __global__ __launch_bounds__(1024) void mlp_bwd_finish_kernel(const float* __restrict__ E, const float* __restrict__ db1, const float* __restrict__ w1,
                                              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dW1,
                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int hiddenP, int Cp) {
+    __shared__ float pg[16][100], pb[16][100];
     for (int i = threadIdx.x; i < hiddenP * Cp; i += blockDim.x) {
         const int hh = i / Cp, c = i - hh * Cp;
         dW1[i] = E[i] * gamma[c] + db1[hh] * beta[c];
     }
-    for (int c = threadIdx.x; c < Cp; c += blockDim.x) {
+    // 16 threads per column, each a strided subset of the hidden units in increasing order; the 16 partial sums are then added in order
+    const int c = threadIdx.x % 64, k = threadIdx.x / 64;       // Cp <= 64 columns x 16 parts
+    if (c < Cp) {
         float sg = 0.f, sb = 0.f;
-        for (int hh = 0; hh < hiddenP; ++hh) { const float w = w1[(size_t)hh * Cp + c]; sg += w * E[(size_t)hh * Cp + c]; sb += w * db1[hh]; }
-        dgamma[c] = sg; dbeta[c] = sb;
+        for (int hh = k; hh < hiddenP; hh += 16) { const float w = w1[(size_t)hh * Cp + c]; sg += w * E[(size_t)hh * Cp + c]; sb += w * db1[hh]; }
+        pg[k][c] = sg; pb[k][c] = sb;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < Cp) {
+        float sg = pg[0][threadIdx.x], sb = pb[0][threadIdx.x];
+        for (int j = 1; j < 16; ++j) { sg += pg[j][threadIdx.x]; sb += pb[j][threadIdx.x]; }
+        dgamma[threadIdx.x] = sg; dbeta[threadIdx.x] = sb;
     }
 }
 
