@@ -34,6 +34,7 @@ struct MlpArgs {
     // row-blocks x HS and workgroup (rb, hs) walks hidden tiles [hs*HT/HS, (hs+1)*HT/HS); the fc2 partial sums go to
     // partial[hs][M][CP] and mlp_combine_kernel adds them in fixed order (deterministic, no atomics).
     int HS; float* partial;
+    float* out;                 // nullptr: in place; otherwise x is left untouched and x + mlp(x) goes to out (training forward: x1 stays on the tape)
 };
 
 template <int CP, int TM>
@@ -130,12 +131,13 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
     for (int t = 0; t < TM; ++t) {
         const int row = m0 + t * 16 + l15;
         if (row >= a.M) continue;
-        float* xr = a.x + (size_t)row * CP + 4 * lg;
+        const float* xr = a.x + (size_t)row * CP + 4 * lg;
+        float* orow = (a.out ? a.out : a.x) + (size_t)row * CP + 4 * lg;
         f32x4 res[KK];
 #pragma unroll
         for (int o = 0; o < KK; ++o) { res[o] = ld4(xr + 16 * o); acc[o][t] += ld4(a.b2 + 16 * o + 4 * lg); }
 #pragma unroll
-        for (int o = 0; o < KK; ++o) st4(xr + 16 * o, res[o] + acc[o][t]);
+        for (int o = 0; o < KK; ++o) st4(orow + 16 * o, res[o] + acc[o][t]);
     }
 }
 
@@ -348,12 +350,13 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
     for (int t = 0; t < TM; ++t) {
         const int row = m0 + t * 16 + l15;
         if (row >= a.M) continue;
-        float* xr = a.x + (size_t)row * CP + 4 * lg;
+        const float* xr = a.x + (size_t)row * CP + 4 * lg;
+        float* orow = (a.out ? a.out : a.x) + (size_t)row * CP + 4 * lg;
         f32x4 res[KK];
 #pragma unroll
         for (int o = 0; o < KK; ++o) { res[o] = ld4(xr + 16 * o); acc[o][t] += ld4(a.b2 + 16 * o + 4 * lg); }
 #pragma unroll
-        for (int o = 0; o < KK; ++o) st4(xr + 16 * o, res[o] + acc[o][t]);
+        for (int o = 0; o < KK; ++o) st4(orow + 16 * o, res[o] + acc[o][t]);
     }
 }
 

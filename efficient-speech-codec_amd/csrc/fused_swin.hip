@@ -49,13 +49,14 @@ void rows_combine(float* dst, const float* src, const float* partial, const floa
 
 // *hs: requested hidden split in, split actually used out (> 1: x is untouched, partial[hs][M][Cp] is filled, the caller runs rows_combine)
 int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* w1f, const float* b1,
-              const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, int* hs_io, float* partial, hipStream_t s) {
+              const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, int* hs_io, float* partial, hipStream_t s, float* out) {
     int hs = hs_io ? *hs_io : 1;
     const bool lds_width = Cp == 48 || Cp == 80 || Cp == 96 || Cp == 144 || Cp == 192 || Cp == 384;
     if (hs > 1 && (variant <= 0 || variant >= 100 || variant > 3 || !lds_width || !partial || (hiddenP / 16) % hs)) hs = 1;
     if (hs_io) *hs_io = hs;
     MlpArgs a{x, gamma, beta, reinterpret_cast<const f32x4*>(w1f), b1, reinterpret_cast<const f32x4*>(w2f), b2,
-              reinterpret_cast<const f32x4*>(wcf), M, C, hiddenP / 16, 1e-5f, g_mlp_trace, hs, partial};
+              reinterpret_cast<const f32x4*>(wcf), M, C, hiddenP / 16, 1e-5f, g_mlp_trace, hs, partial, out};
+    if (out && (hs > 1 || variant >= 100)) return -1;       // a separate output: plain epilogues only (no hidden split, no ablation builds)
     if (variant >= 100) {      // timing-only ablations: variant = 100 + ABL bits
         const int abl = variant - 100;
         if (Cp == 192) {

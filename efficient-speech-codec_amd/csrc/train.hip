@@ -312,11 +312,10 @@ int layer_fwd(escx_handle_s* h, const Layer& L, LayerTape& LT, const float* x_in
         if (arc) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "head_dim %d unsupported by the attention kernel", L.hd);
         PROF("T.gemm_proj" + tg, 2 * dMs * dC * dC, (dMs * dC + 2 * dM * dC) * f4,
              gemm_proj_scatter(bt.obuf, L.Ko, Ms, bw.wproj, L.Cp, L.Ko, bt.x1, x, bw.bproj, map, slots, tokens, st));
-        if (fmlp) {       // LN2 + fc1 + GELU + fc2 + residual in one kernel, in place on a copy of x1 (x1 itself is what the backward recomputes from)
-            ESCX_HIP(hipMemcpyAsync(bt.x2, bt.x1, (size_t)M * L.Cp * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (fmlp) {       // LN2 + fc1 + GELU + fc2 + residual in one kernel: x1 -> x2 (x1 itself is what the backward recomputes from)
             int hs = 1, frc = 0;
-            PROF("T.mlp_fused" + tg, 4 * dM * dC * L.hidden, 4 * dM * dC * f4,
-                 frc = mlp_fused(bt.x2, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP, 3, &hs, nullptr, st));
+            PROF("T.mlp_fused" + tg, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
+                 frc = mlp_fused(bt.x1, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP, 3, &hs, nullptr, st, bt.x2));
             if (frc) ESCX_FAIL(ESCX_ERR_STATE, "fused MLP not instantiated for Cp = %d", L.Cp);
             x = bt.x2;
             continue;

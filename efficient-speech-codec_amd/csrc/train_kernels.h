@@ -962,10 +962,18 @@ static __global__ __launch_bounds__(256) void codebook_grad_kernel(const long lo
             for (int m0 = 0; m0 < mcnt; m0 += 64) {
                 const bool hit = (m0 + lane < mcnt) && lc[m0 + lane] == (short)k;
                 unsigned long long mask = __ballot(hit);
+                // four hits per trip: their row loads are independent and in flight together, the adds stay in vector order (a missing hit adds
+                // 0.0f, which leaves the sum bitwise unchanged).  One load + dependent add per hit cost a memory round trip each: with a skewed
+                // code usage (a few codes chosen by hundreds of vectors - every untrained codebook) that chain WAS the kernel: 320 us per stream.
                 while (mask) {
-                    const int l = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    if (lane < dt) acc[c] += gq[(size_t)(mbase + m0 + l) * ldz + g * dt + lane];
+                    int l[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { l[u] = mask ? __ffsll((long long)mask) - 1 : -1; mask &= mask - 1; }
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = (l[u] >= 0 && lane < dt) ? gq[(size_t)(mbase + m0 + l[u]) * ldz + g * dt + lane] : 0.0f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[c] += v[u];
                 }
             }
         }
