@@ -334,7 +334,10 @@ class EscOracle:
                                  c["window_size"], "up")
 
     # -- csrvq.py:131-158
-    def csvq_encode(self, enc_hs, num_streams: int, feat_shape, trace: Optional[Trace] = None) -> Tensor:
+    def csvq_encode(self, enc_hs, num_streams: int, feat_shape, trace: Optional[Trace] = None, force: Optional[Tensor] = None) -> Tensor:
+        """`force` (B, S, G, T) int64, -1 = free: codes imposed on the search (test infrastructure: when the device path resolved a reference
+        near-tie the other way, the oracle is CONTINUED from the device's choice so that the later streams - which see a different residual -
+        can still be compared code for code; tests/gpu_util.attribute_with_continuation)."""
         c = self.cfg
         H, W = feat_shape
         mg = [] if trace is not None else None
@@ -344,6 +347,9 @@ class EscOracle:
             code = pvq_encode(z, groups=c["group_size"], l2norm=c["l2norm"], margins=m, **self._q(i))
             if mg is not None:
                 mg.append(torch.stack(m, dim=1))
+            if force is not None:
+                f = force[:, i]
+                code = torch.where(f >= 0, f, code)
             return code
 
         codes = [enc(0, enc_hs[-1])]
@@ -381,12 +387,12 @@ class EscOracle:
 
     # -- codecs.py:68-94
     @torch.no_grad()
-    def encode(self, x: Tensor, num_streams: int = 6, trace: Optional[Trace] = None):
+    def encode(self, x: Tensor, num_streams: int = 6, trace: Optional[Trace] = None, force: Optional[Tensor] = None):
         feat = spec_transform(x, self.cfg, self.sd.get("ft.window"))
         enc_hs, shape = self.encoder(feat)
         if trace is not None:
             trace.feat, trace.enc_hs = feat, enc_hs
-        return self.csvq_encode(enc_hs, num_streams, shape, trace), shape
+        return self.csvq_encode(enc_hs, num_streams, shape, trace, force), shape
 
     @torch.no_grad()
     def decode(self, codes: Tensor, feat_shape=(2, 1000), trace: Optional[Trace] = None) -> Tensor:

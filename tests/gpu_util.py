@@ -76,3 +76,48 @@ def mismatch_summary(got, ref, margins):
     bad = np.argwhere(got != ref)
     clips = sorted(set(int(i) for i in bad[:, 0]))
     return f"{len(bad)} differing codes in clips {clips}; " + code_report(got, ref, margins)
+
+
+def attribute_with_continuation(orc, x, got, ref, margins, num_streams, tol=NEAR_TIE, max_rounds=8):
+    """`unattributable` judges only the EARLIEST differing stream of a clip: once a near-tie has been resolved the other way, every later stream sees
+    a different residual and its codes legitimately differ.  This closes that gap: for every clip with an attributed flip the
+    oracle is re-run with the device's choice FORCED at the flipped positions (EscOracle.encode(force=...)), and the comparison continues on the next
+    streams - again code for code, again only near-ties may differ.  Returns (findings, n_forced_codes, clips_continued); findings empty = every code
+    of every stream is either identical to the reference or identical to the reference continued from an attributed near-tie."""
+    import torch
+    from oracle.esc_oracle import Trace
+    got = np.asarray(got); ref = np.asarray(ref).copy(); margins = np.asarray(margins).copy()
+    B = got.shape[0]
+    force = np.full(got.shape, -1, dtype=np.int64)
+    findings, n_forced, continued = [], 0, set()
+    for _ in range(max_rounds):
+        redo = []
+        for b in range(B):
+            bad = np.argwhere(got[b] != ref[b])
+            if len(bad) == 0:
+                continue
+            s0 = bad[:, 0].min()
+            first = bad[bad[:, 0] == s0]
+            ok = True
+            for s, g, t in first:
+                m = float(margins[b, s, g, t])
+                if not m < tol:
+                    findings.append(f"clip {b} stream {s} group {g} frame {t}: got {got[b, s, g, t]} ref {ref[b, s, g, t]} margin {m:.3e}"
+                                    + (" (after continuation)" if b in continued else ""))
+                    ok = False
+            if ok:
+                for s, g, t in first:
+                    if force[b, s, g, t] < 0:
+                        n_forced += 1
+                    force[b, s, g, t] = got[b, s, g, t]
+                redo.append(b)
+        if findings or not redo:
+            break
+        continued.update(redo)
+        tr = Trace()
+        rc, _ = orc.encode(x[redo], num_streams, trace=tr, force=torch.from_numpy(force[redo]))
+        ref[redo] = rc.numpy()
+        margins[redo] = torch.stack(tr.margins, dim=1).numpy()
+    else:
+        findings.append("continuation did not converge")
+    return findings, n_forced, sorted(continued)

@@ -1,6 +1,7 @@
 """Pins the oracle (oracle/esc_oracle.py) to golden vectors produced by the real reference
 (oracle/gen_golden.py).  CPU only."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -133,3 +134,39 @@ def test_unfiltered_reference_clips(name):
     np.testing.assert_allclose(m, u[f"{name}_margins"][: len(sel)], atol=1e-5)
     a = orc.decode(codes, shape).numpy()
     assert _rms(a[:, ::16], u[f"{name}_audio_sub"][: len(sel)]) <= 1e-6
+
+
+def test_oracle_continuation_from_a_forced_code():
+    """Test infrastructure of the GPU parity sweeps (tests/gpu_util.attribute_with_continuation): a "device" that resolves one stream-0 decision the
+    other way and then continues consistently is accepted with exactly that one code forced (when the decision counts as a near-tie), is reported when
+    it does not, and an unrelated corruption in a later stream is reported even after the continuation."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from gpu_util import attribute_with_continuation
+    from oracle.esc_oracle import EscOracle, Trace
+    g = load_golden("tiny")
+    cfg = json.loads(str(g["config_json"]))
+    orc = EscOracle(cfg, synth_state("tiny"))
+    x = torch.from_numpy(synth.pcm_to_float(g["L1280_pcm"]))
+    tr = Trace()
+    ref, _ = orc.encode(x, 3, trace=tr)
+    margins = torch.stack(tr.margins, dim=1).numpy()
+    # the "device": second-best code at one stream-0 position of clip 0, everything downstream follows from it
+    b, gi, t = 0, 1, 5
+    flip = int(ref[b, 0, gi, t]) ^ 1
+    force = torch.full_like(ref, -1); force[b, 0, gi, t] = flip
+    got, _ = orc.encode(x, 3, force=force)
+    assert got[b, 0, gi, t] == flip and not torch.equal(got[b, 1:], ref[b, 1:]), "the flip must change later streams for this test to mean anything"
+    bad, n_forced, cont = attribute_with_continuation(orc, x, got.numpy(), ref.numpy(), margins, 3, tol=float("inf"))
+    assert bad == [] and n_forced == 1 and cont == [0]
+    bad, _, _ = attribute_with_continuation(orc, x, got.numpy(), ref.numpy(), margins, 3, tol=1e-12)
+    assert len(bad) == 1 and "stream 0" in bad[0]
+    wrong = got.clone(); wrong[b, 2, 0, 3] = (int(wrong[b, 2, 0, 3]) + 7) % cfg["codebook_size"]
+    bad, _, _ = attribute_with_continuation(orc, x, wrong.numpy(), ref.numpy(), margins, 3, tol=float("inf"))
+    assert bad == [], "with an unbounded tolerance every difference is a 'near-tie': the helper keeps forcing"
+    near = float(margins[b, 0, gi, t]) * 1.0001          # a tolerance that admits ONLY the stream-0 flip
+    tr2 = Trace(); ref2, _ = orc.encode(x, 3, trace=tr2, force=force)
+    m2 = float(torch.stack(tr2.margins, dim=1)[b, 2, 0, 3])
+    if m2 >= near:                                           # the corrupted position is not itself a near-tie under this tolerance
+        bad, _, cont = attribute_with_continuation(orc, x, wrong.numpy(), ref.numpy(), margins, 3, tol=near)
+        assert cont == [0] and len(bad) == 1 and "after continuation" in bad[0] and "stream 2" in bad[0]
