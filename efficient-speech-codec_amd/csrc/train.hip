@@ -86,7 +86,12 @@ constexpr size_t DW_PART_FLOATS = (size_t)40 << 20;      // partial-sum scratch 
 template <class LdA, class LdB>
 int dw_launch(escx_handle_s* h, const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
     const int nbn = (Np + 47) / 48, nbk = (Kp + 47) / 48, blocks = nbn * nbk;
-    static const int target = [] { const char* e = getenv("ESCX_DW_TARGET"); return e ? atoi(e) : 2048; }();        // workgroups per launch (tuning aid)
+    // Workgroups per launch.  A workgroup's fixed cost (cold first chunk, cross-wave add of 9 accumulator tiles, 9 KB partial tile that the reduction reads
+    // back) is paid per slice, so the narrow matrices - few output tiles, i.e. many slices each - want FEWER, longer slices even if that leaves slots empty
+    // (measured, B = 36, ESCX_DW_TARGET sweep in profiles/r3_dw_target_sweep.txt: dw_proj[C=45] (1 tile) 0.631 / 0.535 / 0.444 ms at 2048 / 1024 / 512,
+    // dw_qkv[C=45] (3 tiles) 1.218 / 1.137 / 1.026; from 10 tiles up 2048 wins: dw_fc1[C=72] 1.275 / 1.270 / 1.793).  ESCX_DW_TARGET overrides (tuning aid).
+    static const int env_target = [] { const char* e = getenv("ESCX_DW_TARGET"); return e ? atoi(e) : 0; }();
+    const int target = env_target > 0 ? env_target : (blocks <= 3 ? 512 : (blocks <= 4 ? 1024 : 2048));
     int slices = std::max(1, std::min((target + blocks - 1) / blocks, (M + 127) / 128));
     const size_t per = (size_t)Np * Kp + Np;
     slices = (int)std::min<size_t>(slices, DW_PART_FLOATS / per);

@@ -43,7 +43,7 @@ for S in range(1, 7):
     codes, shape = base.encode(x64, S)
     td = timeit(lambda: base.decode(codes, shape))
     out[f"base_B64_S{S}"] = {"encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2), "audio_s_per_s": round(64 * 3 / (te + td), 1)}
-for B in (1, 8, 288):
+for B in (1, 2, 4, 8, 288):
     x = bench.synth_batch(min(B, 36), 3).to(dev)
     if B > 36: x = x.repeat(B // 36, 1)
     base.reserve(B, 48000, dev)
