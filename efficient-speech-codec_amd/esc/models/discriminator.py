@@ -51,6 +51,16 @@ class DiscOutput(list):
     bufs: tuple
     layout: list
 
+    def clips(self, lo: int, hi: int) -> "DiscOutput":
+        """The same pass restricted to clips [lo, hi): views, no copies (every buffer is batch-major).  `whole` keeps the pass it came from, so that
+        one discriminator pass over [reconstruction | real signal] can serve an adversarial step (esc.modules.GANLoss.adversarial_forward)."""
+        out = DiscOutput(FeatureMaps(m[lo:hi] for m in fm) for fm in self)
+        for fm, src in zip(out, self):
+            fm.entries = [(e[0][lo:hi],) + tuple(e[1:]) for e in src.entries]
+        out.wave, out.bufs, out.layout = self.wave[lo:hi], tuple(b[lo:hi] for b in self.bufs), self.layout
+        out.whole, out.lo, out.hi = self, lo, hi
+        return out
+
 
 class Discriminator(nn.Module):
     def __init__(self, rates: list = [], periods: list = [2, 3, 5, 7, 11], fft_sizes: list = [2048, 1024, 512], sample_rate: int = 44100,
@@ -211,15 +221,17 @@ class Discriminator(nn.Module):
             out.append(tuple(v.value for v in ints))          # (sub, C, Cp, D0, D1, P1, off1)
         return out
 
-    def forward(self, x, detach_params: bool = False) -> List[FeatureMaps]:
-        """detach_params=True treats the parameters as constants (the generator's update needs d loss / d waveform only)."""
+    def forward(self, x, detach_params: bool = False, grad_clips: int = 0) -> List[FeatureMaps]:
+        """detach_params=True treats the parameters as constants (the generator's update needs d loss / d waveform only).
+        grad_clips = n > 0: only the first n clips of the batch can receive gradient (the rest is a constant, e.g. the real signals batched behind the
+        reconstructions): the backward then runs on those n clips only."""
         if x.dim() != 3 or x.shape[1] != 1:
             raise ValueError("x must have shape (B, 1, L)")
         if not x.is_cuda:
             raise RuntimeError("esc Discriminator (MI355X build): x must live on a HIP device; this package has no CPU implementation")
         layout = self.fmap_layout(x.device, x.shape[-1])
         wave = x[:, 0].to(torch.float32).contiguous()
-        bufs = _DiscFn.apply(self, wave, (layout, bool(detach_params)), *self.parameters())
+        bufs = _DiscFn.apply(self, wave, (layout, bool(detach_params), int(grad_clips)), *self.parameters())
         out, bi = [], 0
         n_sub = len(self.cfg["periods"]) + len(self.cfg["fft_sizes"])
         per_sub = DiscOutput(FeatureMaps() for _ in range(n_sub))
@@ -255,7 +267,8 @@ def _buffer_plan(layout):
 class _DiscFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, disc, wave, layout_flag, *params):
-        layout, detach_params = layout_flag
+        layout, detach_params, grad_clips = layout_flag
+        ctx.grad_clips = grad_clips
         dev = wave.device
         lib, hd = disc._handle(dev)
         flat = disc._ensure_flat(dev, lib, hd)
@@ -284,7 +297,13 @@ class _DiscFn(torch.autograd.Function):
         dfm = (ctypes.c_void_p * n)(*[(None if dbufs[bi] is None else dbufs[bi].data_ptr() + 4 * off1 * layout[i][2]) for i, (bi, off1) in enumerate(where)])
         flat_mode = disc._flat_grad_mode and "gflat" in st and ctx.want_params
         gflat = (st["gflat"] if (flat_mode and st["gfresh"]) else torch.empty_like(flat)) if ctx.want_params else None
-        dwave = torch.empty_like(wave) if ctx.want_wave else None
+        if ctx.grad_clips and ctx.grad_clips < B:       # every buffer is batch-major: the first clips of the pass ARE a pass (same base pointers)
+            if ctx.want_params:
+                raise RuntimeError("grad_clips restricts the backward to the leading clips: parameter gradients of the whole pass are not available")
+            dwave = torch.zeros_like(wave) if ctx.want_wave else None
+            B = ctx.grad_clips
+        else:
+            dwave = torch.empty_like(wave) if ctx.want_wave else None
         if gflat is None and dwave is None:
             return (None, None, None) + (None,) * (len(st["layout"]))
         with torch.cuda.device(dev):

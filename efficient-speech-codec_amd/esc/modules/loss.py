@@ -7,6 +7,7 @@ loss together with d loss_b / d reconstruction; backward only scales that by the
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -173,10 +174,18 @@ class GANLoss(nn.Module):
             fake = fake.unsqueeze(1)
         if real.dim() == 2:
             real = real.unsqueeze(1)
-        d_fake = self.discriminator(fake, detach_params=True)
-        with torch.no_grad():
-            d_real = self.discriminator(real)
-        return d_fake, d_real
+        # ONE pass over [reconstructions | real signals] (round 3): the discriminator's weights are the same for both, so the two passes of round 2
+        # become launches of twice the rows (half the launches, half the partial-sum reductions of the weight gradients); a clip's feature maps do
+        # not depend on the batch it is in (every output element is one k-ordered contraction), so the loss values are bit for bit those of two
+        # passes.  Only the leading clips (the reconstructions) can receive gradient.  ESCX_GAN_TWO_PASSES=1: the round-2 form.
+        if os.environ.get("ESCX_GAN_TWO_PASSES") == "1" or fake.shape != real.shape:
+            d_fake = self.discriminator(fake, detach_params=True)
+            with torch.no_grad():
+                d_real = self.discriminator(real)
+            return d_fake, d_real
+        B = fake.shape[0]
+        both = self.discriminator(torch.cat([fake, real.detach().to(fake.dtype)], dim=0), detach_params=True, grad_clips=B)
+        return both.clips(0, B), both.clips(B, 2 * B)
 
     def generator_loss_from(self, d_fake, d_real):
         """gan_loss.py:39-51 on feature maps that are already there."""
@@ -193,6 +202,28 @@ class GANLoss(nn.Module):
         """gan_loss.py:30-37 + `disc_loss.mean().backward()` (trainer_adv.py:96-105) on the feature maps of adversarial_forward: returns the
         per-clip discriminator loss and ADDS d mean(loss) / d parameter to the discriminator's gradients."""
         lib = _native.load()
+        whole = getattr(d_fake, "whole", None)
+        if whole is not None and whole is getattr(d_real, "whole", None) and d_fake.lo == 0 and d_real.lo == d_fake.hi:
+            # both halves of ONE pass: LS-GAN terms per half (targets 0 / 1), then one backward (dX chain + weight gradients) over all 2B clips
+            B = d_fake.hi
+            dbufs = [None] * len(whole.bufs)
+            scale = torch.full((2 * B,), 1.0 / B, dtype=torch.float32, device=whole.wave.device)      # d mean_b(term_fake_b + term_real_b)
+            loss = None
+            for sub in whole:
+                buf, C, Cp, D0, D1, P1, off1 = sub.entries[-1]
+                buf = buf.detach()
+                term = torch.empty(2 * B, dtype=torch.float32, device=buf.device)
+                unit = torch.zeros_like(buf)
+                with torch.cuda.device(buf.device):
+                    for lo, target in ((0, 0.0), (B, 1.0)):
+                        _native.check(lib.escx_gan_term(_ptr(buf[lo:lo + B]), None, _ptr(unit[lo:lo + B]), B, C, Cp, D0, D1, P1, 0, float(target), _ptr(term[lo:lo + B]), 0,
+                                                        _stream(buf.device)))
+                t = term[:B] + term[B:]
+                loss = t if loss is None else loss + t
+                bi = next(i for i, b in enumerate(whole.bufs) if b.data_ptr() == buf.data_ptr())
+                dbufs[bi] = _scale_rows(unit, scale)
+            self.discriminator.accumulate_param_grads(whole, dbufs)
+            return loss
         loss = None
         for out, target in ((d_fake, 0.0), (d_real, 1.0)):
             B = out.wave.shape[0]
