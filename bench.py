@@ -387,14 +387,38 @@ def run_train_adv(args, rank, world, device, use_dist):
     assert all(bool(torch.isfinite(v).all()) for v in log.values() if torch.is_tensor(v))
     if rank != 0:
         return
+    # per-kernel pass (diagnostic mode: events + a sync around every discriminator launch group, events around every generator launch): the launch
+    # group with the largest share of the step, its rate against the fp32 MFMA peak, and the ten largest groups
+    from esc import _native
+    lib = _native.load()
+    glib, ghd = model._handle(device, for_training=True)
+    lib.escx_disc_profile_enable(1); glib.escx_profile_enable(ghd, 1)
+    psteps = 2
+    for n in range(psteps):
+        st.step(x, args.warmup + args.steps + n)
+    torch.cuda.synchronize(device)
+    lib.escx_disc_profile_enable(0); glib.escx_profile_enable(ghd, 0)
+    recs = json.loads(lib.escx_disc_profile_report().decode()) + json.loads(glib.escx_profile_report(ghd).decode())
+    recs = [r for r in recs if r["flops"] > 0 and r["ms"] > 0]
+    recs.sort(key=lambda r: -r["ms"])
+    ptot = sum(r["ms"] for r in recs)
+    dom = recs[0]
+    kern_roof = {"kernel": dom["name"], "avg_us": round(dom["ms"] / dom["calls"] * 1e3, 1), "launches_per_step": dom["calls"] // psteps,
+                 "achieved": round(dom["flops"] / dom["ms"] / 1e9, 2), "frac": round(dom["flops"] / dom["ms"] / 1e9 / (PEAK_F32_MFMA / 1e12), 4),
+                 "share_of_profiled_gemm_time": round(dom["ms"] / ptot, 4), "profiled_gemm_ms_per_step": round(ptot / psteps, 2),
+                 "profiled_gemm_tflops": round(sum(r["flops"] for r in recs) / ptot / 1e9, 2),
+                 "top": [{"name": r["name"], "ms_per_step": round(r["ms"] / psteps, 3), "tflops": round(r["flops"] / r["ms"] / 1e9, 1)} for r in recs[:10]]}
+    if os.environ.get("ESCX_BENCH_BREAKDOWN"):
+        for r in recs:
+            print(f"# {r['name']:60s} calls {r['calls']:4d}  {r['ms'] / psteps:9.3f} ms/step  {r['flops'] / r['ms'] / 1e9:9.1f} TFLOP/s", file=sys.stderr)
     n_gen, n_disc = sum(p.numel() for p in model.parameters()), sum(p.numel() for p in disc.parameters())
     # convolution FLOPs of one discriminator pass per clip (2 x MACs), from the feature-map geometry
     lay = disc.fmap_layout(device, TRAIN_SAMPLES)
     from esc.models.discriminator import _conv_specs
     specs = _conv_specs(disc.cfg["periods"], disc.cfg["fft_sizes"], len(disc.cfg["bands"]))
     d_flops = sum(2.0 * D0 * D1 * cout * cin * t0 * t1 for (sub, C, Cp, D0, D1, P1, off1), (pfx, cout, cin, t0, t1) in zip(lay, specs))
-    # per step (GANLoss.adversarial_forward shares the passes): 2 forward passes (fake, real) + the input-gradient backward of the fake pass for the
-    # generator + 2 full backward passes (dX + dW) for the discriminator
+    # per step (GANLoss.adversarial_forward: ONE pass over [fake | real] = 2 pass-equivalents) + the input-gradient backward of the fake half for the
+    # generator + the full backward (dX + dW) over both halves for the discriminator (2 x 2 pass-equivalents)
     d_step_flops = d_flops * (2 + 1 + 2 * 2)
     audio_s = bsz * world * args.steps * (TRAIN_SAMPLES / 16000.0)
     out = {"metric": "audio-seconds/sec trained, adversarial step (generator + discriminator updates), ESC-Large 9kbps 3s@16kHz",
@@ -410,7 +434,8 @@ def run_train_adv(args, rank, world, device, use_dist):
                         "frac": round(d_step_flops * bsz / (elapsed / args.steps) / PEAK_F32_MFMA, 4), "traffic": None,
                         "kernel": "discriminator convolutions (all launches of the step)",
                         "note": "algorithmic discriminator-convolution FLOPs of the step (7 pass-equivalents of "
-                                f"{d_flops / 1e9:.1f} GFLOP per clip) over the WHOLE step time, generator included: a lower bound on the conv kernels' rate"},
+                                f"{d_flops / 1e9:.1f} GFLOP per clip) over the WHOLE step time, generator included: a lower bound on the conv kernels' rate",
+                        "dominant_launch_group": kern_roof},
            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else
                            train_adv_cpu_baseline(cfg, sd, {k: v.detach().cpu() for k, v in disc.state_dict().items()}, x.cpu(), st.w)}
     print(json.dumps(out))

@@ -8,6 +8,9 @@
 // the caller (they ARE the autograd tape); backward takes the gradients of all feature maps and returns d loss / d parameters and / or
 // d loss / d waveform.
 #include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
+#include <string>
 
 #include <algorithm>
 #include <cmath>
@@ -121,9 +124,18 @@ void fmap_shapes(escx_disc_s* d, int L, std::vector<FmapShape>* out) {
 
 TView view_of(float* base, const FmapShape& f) { return TView{base, f.D0, f.D1, f.P1, f.Cp}; }
 
-// ESCX_DISC_TRACE=1: per-launch-group timing (events + a stream sync after each group: a diagnostic, not a mode to run in)
+// Per-launch-group timing of the convolutions (events + a stream sync after each group: a diagnostic, not a mode to run in).
+// ESCX_DISC_TRACE=1 prints every group; escx_disc_profile_enable(1) accumulates them per (kind, layer) for escx_disc_profile_report() - what
+// bench.py --mode train_adv quotes its per-kernel roofline from.
+struct DProfAgg { int calls = 0; double ms = 0, flops = 0; };
+static std::mutex g_dprof_mu;
+static bool g_dprof_on = false;
+static std::map<std::string, DProfAgg> g_dprof;
+static std::vector<std::string> g_dprof_order;
+static std::string g_dprof_json;
 struct DTrace {
-    static bool on() { static const bool v = [] { const char* e = getenv("ESCX_DISC_TRACE"); return e && e[0] == '1'; }(); return v; }
+    static bool print() { static const bool v = [] { const char* e = getenv("ESCX_DISC_TRACE"); return e && e[0] == '1'; }(); return v; }
+    static bool on() { return print() || g_dprof_on; }
     hipStream_t st; hipEvent_t a = nullptr, b = nullptr; const char* what; const char* name; double flops; int M, N, K;
     DTrace(hipStream_t s, const char* w, const char* nm, int M_, int N_, int K_) : st(s), what(w), name(nm), flops(2.0 * M_ * N_ * K_), M(M_), N(N_), K(K_) {
         if (on()) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
@@ -132,7 +144,13 @@ struct DTrace {
         if (!a) return;
         (void)hipEventRecord(b, st); (void)hipEventSynchronize(b);
         float ms = 0.f; (void)hipEventElapsedTime(&ms, a, b);
-        fprintf(stderr, "[disc] %-4s %-44s M %8d N %5d K %5d  %8.3f ms  %6.1f TFLOP/s\n", what, name, M, N, K, ms, flops / (ms * 1e9));
+        if (print()) fprintf(stderr, "[disc] %-4s %-44s M %8d N %5d K %5d  %8.3f ms  %6.1f TFLOP/s\n", what, name, M, N, K, ms, flops / (ms * 1e9));
+        if (g_dprof_on) {
+            std::lock_guard<std::mutex> lk(g_dprof_mu);
+            const std::string key = std::string("D.") + what + "[" + name + "]";
+            if (!g_dprof.count(key)) g_dprof_order.push_back(key);
+            DProfAgg& g = g_dprof[key]; g.calls++; g.ms += ms; g.flops += flops;
+        }
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     }
 };
@@ -564,4 +582,24 @@ extern "C" int escx_gan_term(const float* x, const float* ref, float* grad, int 
     hipLaunchKernelGGL(gan_term_kernel, dim3(bpc, B), dim3(256), 0, st, xv, rv, gvw, part, mode, target, C, bpc, 1.0f / ((float)C * D0 * D1));
     hipLaunchKernelGGL(row_sum_kernel, dim3(blk(B, 64)), dim3(64), 0, st, part, bpc, loss_dev, B, accumulate, 1.0f);
     return launch_ok("gan_term");
+}
+
+extern "C" int escx_disc_profile_enable(int enable) {
+    std::lock_guard<std::mutex> lk(g_dprof_mu);
+    if (enable) { g_dprof.clear(); g_dprof_order.clear(); }
+    g_dprof_on = enable != 0;
+    return ESCX_OK;
+}
+
+extern "C" const char* escx_disc_profile_report() {
+    std::lock_guard<std::mutex> lk(g_dprof_mu);
+    std::string js = "[";
+    char buf[512];
+    for (size_t i = 0; i < g_dprof_order.size(); ++i) {
+        const DProfAgg& g = g_dprof[g_dprof_order[i]];
+        snprintf(buf, sizeof(buf), "%s{\"name\":\"%s\",\"calls\":%d,\"ms\":%.6f,\"flops\":%.6e,\"bytes\":0}", i ? "," : "", g_dprof_order[i].c_str(), g.calls, g.ms, g.flops);
+        js += buf;
+    }
+    g_dprof_json = js + "]";
+    return g_dprof_json.c_str();
 }

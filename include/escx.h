@@ -237,6 +237,11 @@ int escx_disc_backward(escx_disc d, const float* flat_params_dev, int64_t params
  * (target - x)^2 (mode 0) or |x - ref| (mode 1); grad_dev (optional, layout of x) receives d term_b / d x. */
 int escx_gan_term(const float* x_dev, const float* ref_dev, float* grad_dev, int batch, int C, int Cp, int D0, int D1, int P1, int mode, float target,
                   float* loss_dev, int accumulate, void* stream);
+/* Per-layer timing of the discriminator's convolutions (diagnostic: HIP events and a stream sync around every launch group while enabled, so the step
+ * itself runs slower).  escx_disc_profile_enable(1) clears and starts, (0) stops; the report is a JSON array of {"name": "D.<fwd|dX|dW>[<layer>]",
+ * "calls", "ms", "flops"} - the same record format as escx_profile_report.  Process-wide (not per handle). */
+int escx_disc_profile_enable(int enable);
+const char* escx_disc_profile_report(void);
 
 /* ---- multi-GPU: the one exchange step of the sharded path (BASELINE configs[3]; SURVEY.md 8(b),(e)) ------------- */
 /* The reference has no inference-time collective (clips are independent end to end); batch shards exchange only the emitted codes.
