@@ -128,13 +128,14 @@ int dw_launch_wide(escx_handle_s* h, const LdA& la, const LdB& lb, int M, int Np
 // the 48 x 48 kernel where none fits within 15 % (C = 45, 72, 144: multiples of 48) or the matrix is small
 int dw_rows(escx_handle_s* h, const float* A, int lda, const float* Bm, int ldb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
     static const bool wide_ok = [] { const char* e = getenv("ESCX_DW_WIDE"); return !(e && e[0] == '0'); }();
+    static const double pad_limit = [] { const char* e = getenv("ESCX_DW_WIDE_PAD"); return e ? atof(e) : 1.15; }();      // tile padding a wide tile may add
     const PlainA la{A, lda, M}, lb{Bm, ldb, M};
     int bestA = 0, bestB = 0; double best = 1e30;
     if (wide_ok && Np >= 96 && Kp >= 96 && (long long)Np * Kp >= 96 * 288) {
         const int cand[3] = {128, 96, 64};
         for (int wa : cand) for (int wb : cand) {
             const double padded = (double)((Np + wa - 1) / wa * wa) * ((Kp + wb - 1) / wb * wb);
-            if (padded > 1.15 * Np * Kp) continue;
+            if (padded > pad_limit * Np * Kp) continue;
             const double cost = padded * (1.0 + 24.0 / wa + 24.0 / wb);          // MFMA work + a charge for operand re-staging
             if (cost < best) { best = cost; bestA = wa; bestB = wb; }
         }
@@ -192,6 +193,7 @@ void gemm_ln_bwd_rows(const float* A, int lda, int M, const float* Wt, int Cp, i
 int attn_bwd(const float* qkv, const float* bias, const float* dout, float* dqkv, float* dbias, float* part, int total_windows, int nH, int hdp, int ldq,
              int ldo, int nWh, int nWw, int shifted, float scale, hipStream_t st) {
     const int gx = (int)std::min<long long>(512, ((long long)total_windows + 3) / 4);
+    if ((unsigned long long)(total_windows + 4 * gx) * 16ull * (unsigned long long)std::max(ldq, ldo) >= (1ull << 32)) return -2;    // 32-bit element offsets in the kernel
     dim3 grid(gx, nH);
 #define ESCX_ATB(S) case S: hipLaunchKernelGGL((attn_bwd_kernel<S>), grid, dim3(256), 0, st, qkv, bias, dout, dqkv, part, total_windows, nH, ldq, ldo, nWh, nWw, shifted, scale); break;
     switch (hdp / 4) {
@@ -629,7 +631,7 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
         PROF("B.attn_core" + tg, 10.0 * Ms * 16 * L.C, 0,
              arc = attn_bwd(bt.qkv, bw.bias_tab, dobuf, dqkv, dbias, attpart, Ms / 16, L.nH, L.hdp, L.Nqkv, L.Ko, Hp / 4, Wp / 4, shift > 0,
                             1.0f / std::sqrt((float)L.hd), st));
-        if (arc) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "head_dim %d unsupported by the attention backward kernel", L.hd);
+        if (arc) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, arc == -2 ? "batch too large for the attention backward kernel's 32-bit offsets (head_dim %d)" : "head_dim %d unsupported by the attention backward kernel", L.hd);
         if (bw.tab_off >= 0)
             hipLaunchKernelGGL(bias_table_grad_kernel, dim3(blocks_for(49 * L.nH)), dim3(256), 0, st, dbias, gflat + bw.tab_off, L.nH);
         PROF("B.dw_qkv" + tg, 2.0 * Ms * L.C * 3 * L.C, 0,

@@ -721,19 +721,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     // the four operand rows of the NEXT window are fetched while the current one is processed (one exposed memory round trip per
     // window instead of three)
     float nq[STEPS], nk[STEPS], nv[STEPS], nd[STEPS];
-    auto fetch = [&](int win) {
-        const float* rowp = qkv + ((size_t)win * 16 + i) * ldq + h * HDP + STEPS * g;
-        const float* dorow = dout + ((size_t)win * 16 + i) * ldo + h * HDP + STEPS * g;
+    // element offsets as 32-bit running values (the launcher guarantees total_windows * 16 * ld < 2^32): the per-window 64-bit multiplies and
+    // shifts of the address arithmetic were a third of this kernel's VALU instructions (31 v_lshl_add_u64 + 16 v_mul_lo_u32 per 20 MFMAs)
+    const unsigned rowq = (unsigned)i * ldq + h * HDP, rowo = (unsigned)i * ldo + h * HDP;
+    unsigned wq = (unsigned)wave_global * 16u * ldq, wo = (unsigned)wave_global * 16u * ldo;
+    const unsigned stepq = (unsigned)nwaves * 16u * ldq, stepo = (unsigned)nwaves * 16u * ldo;
+    auto fetch = [&](unsigned fq, unsigned fo) {
+        const float* rowp = qkv + (fq + rowq + STEPS * g);
+        const float* dorow = dout + (fo + rowo + STEPS * g);
 #pragma unroll
         for (int r = 0; r < STEPS; ++r) { nq[r] = rowp[r]; nk[r] = rowp[kOff + r]; nv[r] = rowp[vOff + r]; nd[r] = dorow[r]; }
     };
-    if (wave_global < total_windows) fetch(wave_global);
-    for (int win = wave_global; win < total_windows; win += nwaves) {
-        const float* base = qkv + (size_t)win * 16 * ldq + h * HDP;
+    if (wave_global < total_windows) fetch(wq, wo);
+    for (int win = wave_global; win < total_windows; win += nwaves, wq += stepq, wo += stepo) {
+        const float* base = qkv + (wq + h * HDP);
         float kf[STEPS], qf[STEPS], vf[STEPS], df[STEPS];
 #pragma unroll
         for (int r = 0; r < STEPS; ++r) { qf[r] = nq[r]; kf[r] = nk[r]; vf[r] = nv[r]; df[r] = nd[r]; }
-        if (win + nwaves < total_windows) fetch(win + nwaves);
+        if (win + nwaves < total_windows) fetch(wq + stepq, wo + stepo);
         if (STAGE) {
 #pragma unroll
             for (int r = 0; r < STEPS; ++r) {
@@ -786,10 +791,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         for (int r = 0; r < 4; ++r) { pt[r] = tp[wave][0][4 * g + r][i]; dsT[r] = tp[wave][1][4 * g + r][i]; }
         // dQ[i][d] = sum_j dS[i][j] K[j][d]  (same operand pattern as O = P V in the forward), scaled back through q*scale;
         // dV[j][d] = sum_i P[i][j] dO[i][d] ; dK[j][d] = sum_i dS[i][j] Q[i][d]   (lane (j, g): rows of key j)
-        float* dqrow = dqkv + ((size_t)win * 16 + i) * ldq + h * HDP;
+        float* dqrow = dqkv + (wq + rowq);
         float* dkrow = dqrow + kOff;
         float* dvrow = dqrow + vOff;
-        const float* dobase = dout + (size_t)win * 16 * ldo + h * HDP;
+        const float* dobase = dout + (wo + h * HDP);
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
             const int d = t * 16 + i;
@@ -814,7 +819,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         }
         __builtin_amdgcn_wave_barrier();             // the LDS tiles are rewritten by the next window
         if (h == 0 && 3 * nH * HDP < ldq)            // tail padding of the qkv width: keep exact zeros (K padding of the dX GEMM)
-            for (int c = 3 * nH * HDP + g; c < ldq; c += 4) dqkv[((size_t)win * 16 + i) * ldq + c] = 0.f;
+            for (int c = 3 * nH * HDP + g; c < ldq; c += 4) dqkv[wq + (unsigned)i * ldq + c] = 0.f;
     }
     // relative-position bias gradient: sum the four waves in fixed order, one partial [16][16] per (workgroup, head)
     st4(&wsum[wave][lane][0], dbsum);
