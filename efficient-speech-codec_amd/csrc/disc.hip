@@ -184,6 +184,12 @@ void conv_gemm(const Ld& ld, const float* W, int M, int Np, int Kp, const Epi& e
     // workgroups per CU; measured on the step's convolutions (tools/disc_trace.py): forward 73.5 -> 60.2 ms, dX 115.8 -> 99.0 ms
     static const int env_bk = [] { const char* e = getenv("ESCX_CONV_BK"); return e ? atoi(e) : 16; }();
     const int fbk = (env_bk > 0 && Kp % env_bk == 0) ? env_bk : 0;
+    // Narrow outputs (the 32-channel MRD stacks, the first MPD layers): a 128-row tile gives a wave 2 x 2 accumulator tiles - 16 MFMAs per four LDS
+    // fragment reads and per K step; 256 rows double the MFMAs per weight fragment and per barrier.  MEASURED SLOWER (round 3, adversarial step at 36
+    // clips): MRD band convolutions forward 79 -> 67 TFLOP/s, dX 68 -> 63, step 399.6 -> 402.0 ms (half the workgroups, 4 gather contexts per
+    // thread).  Kept as an A/B switch only: ESCX_CONV_BM256=1.
+    static const bool bm256 = [] { const char* e = getenv("ESCX_CONV_BM256"); return e && e[0] == '1'; }();
+    if (bm256 && Np <= 48 && (long long)((M + 255) / 256) * ((Np + 47) / 48) >= 1024) { launch_gemm<256>(ld, W, M, Np, Kp, ep, st, 1, fbk); return; }
     if (tiles128 >= 512) launch_gemm<128>(ld, W, M, Np, Kp, ep, st, 1, fbk);
     else launch_gemm<64>(ld, W, M, Np, Kp, ep, st, 1, fbk);
 }
