@@ -38,3 +38,20 @@ def test_rocprof_summary_of_the_same_command_is_committed_and_agrees():
     calls = sum(int(r["Calls"]) for r in match)
     avg_us = sum(float(r["TotalDurationNs"]) for r in match) / calls / 1e3
     assert abs(avg_us - under["roofline"]["avg_us"]) / avg_us < 0.10, (avg_us, under["roofline"]["avg_us"])
+
+
+def test_round3_bench_lines_are_committed_with_roofline_traffic_and_cpu_baseline():
+    """Round 3: the codec line (with the PMC traffic of the dominant kernel, taken on the committed kernel sources), the training line and the
+    adversarial line (BASELINE configs[4]) with its per-kernel block."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_default_with_traffic.json")))
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and "configs[1]" in d["config"]["workload"] and d["dtype"] == "f32"
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["traffic"] and r["traffic"] > 1e8 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["value"] > 100 * d["cpu_baseline"]["value"]
+    assert abs(d["value"] - 36 * 3.0 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    t = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_train.json")))
+    assert t["config"]["tape_gb"] < 40 and t["roofline"]["frac"] > 0 and t["cpu_baseline"]["kind"] == "port"
+    a = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_train_adv.json")))
+    assert "configs[4]" in a["config"]["workload"] and a["ms_per_step"] < 420
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r3_kernel_stats.csv"))))
+    assert any("mlp_fused_lds_kernel" in r["Name"] for r in rows) and any("attn_" in r["Name"] for r in rows)
