@@ -212,25 +212,35 @@ inline float* G(escx_handle_s* h, const float* w) { return h->garena + (w - rein
 // path's kernel (only x1 stays on the tape), backward = train_mlp_fused.h (hidden tile recomputed on the fly).  ESCX_TRAIN_MLP_FUSED=0: unfused.
 inline bool mlp_train_fused(const Layer& L) {
     static const bool on = [] { const char* e = getenv("ESCX_TRAIN_MLP_FUSED"); return !(e && e[0] == '0'); }();
-    return on && L.Cp == 48 && L.hiddenP == 192;
+    static const bool on72 = [] { const char* e = getenv("ESCX_TRAIN_MLP_FUSED_C72"); return !(e && e[0] == '0'); }();
+    return on && ((L.Cp == 48 && L.hiddenP == 192) || (on72 && L.Cp == 80 && L.hiddenP == 288));
 }
 
-// one workgroup per CU (~150 KB of LDS), persistent over the row tiles; `part` holds grid x (2 * hiddenP * Cp + hiddenP + Cp) floats + the reduced E
+// One workgroup per CU (~150 KB of LDS), persistent over the row tiles.  C = 45: 12 hidden tiles = 12 compute waves, LayerNorm backward inside.
+// C = 72: 18 hidden tiles as 2 x 9 (grid.y = 2): the workgroups write d xn partial slabs (`slabs`: 2 * M * Cp floats), which are summed into `dxn`
+// and go through the stand-alone LayerNorm backward.  `part`: grid.x x (2 * hiddenP * Cp + hiddenP + Cp) floats + the reduced E.
 int mlp_bwd_fused(escx_handle_s* h, const Layer& L, const BlockW& bw, const float* x1, const float* dy, float* dx1, float* dx1s, const int* slot_of,
-                  int tokens, int slots, int M, float* part, hipStream_t st) {
+                  int tokens, int slots, int M, float* part, float* dxn, float* slabs, float* lnpart, hipStream_t st) {
     const int ntiles = (M + 15) / 16;
-    const int grid = std::min(ntiles, 256);
+    const bool split = L.Cp == 80;
+    const int grid = std::min(ntiles, split ? 128 : 256);
     const int n1 = L.hiddenP * L.Cp;
     const size_t per = 2 * (size_t)n1 + L.hiddenP + L.Cp;
     if ((size_t)grid * per + n1 > DW_PART_FLOATS) ESCX_FAIL(ESCX_ERR_STATE, "dW scratch too small for the fused MLP backward");
-    MlpBwdArgs a{x1, dy, dx1, dx1s, slot_of, bw.ln2_g, bw.ln2_b, bw.w1, bw.b1, bw.w2T, bw.w1T, part, M, L.C, L.hiddenP, tokens, slots, 1e-5f, 0};
+    MlpBwdArgs a{x1, dy, dx1, dx1s, slot_of, bw.ln2_g, bw.ln2_b, bw.w1, bw.b1, bw.w2T, bw.w1T, part, slabs, M, L.C, L.hiddenP, tokens, slots, 1e-5f, 0};
     { static const int dbg = [] { const char* e = getenv("ESCX_MLPBWD_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
-    hipLaunchKernelGGL((mlp_bwd_fused_kernel<48, 12>), dim3(grid), dim3(64 * 15), 0, st, a);
+    if (split) hipLaunchKernelGGL((mlp_bwd_fused_kernel<80, 9, 2>), dim3(grid, 2), dim3(64 * 12), 0, st, a);
+    else hipLaunchKernelGGL((mlp_bwd_fused_kernel<48, 12, 1>), dim3(grid), dim3(64 * 15), 0, st, a);
     float* Etot = part + (size_t)grid * per;
     hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, part, grid, n1, L.hiddenP, L.Cp, Etot, G(h, bw.w2),
                        G(h, bw.b1), G(h, bw.b2));
-    hipLaunchKernelGGL(mlp_bwd_finish_kernel, dim3(1), dim3(1024), 0, st, Etot, G(h, bw.b1), bw.w1, bw.ln2_g, bw.ln2_b, G(h, bw.w1), G(h, bw.ln2_g),
-                       G(h, bw.ln2_b), L.hiddenP, L.Cp);
+    hipLaunchKernelGGL(mlp_bwd_finish_kernel, dim3(1), dim3(1024), 0, st, Etot, G(h, bw.b1), bw.w1, bw.ln2_g, bw.ln2_b, G(h, bw.w1),
+                       split ? nullptr : G(h, bw.ln2_g), split ? nullptr : G(h, bw.ln2_b), L.hiddenP, L.Cp);
+    if (split) {
+        const long long n4 = (long long)M * L.Cp / 4;
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, slabs, 2, n4, dxn);
+        ln_bwd(0, x1, dxn, bw.ln2_g, nullptr, dy, dx1, G(h, bw.ln2_g), G(h, bw.ln2_b), tokens, tokens, tokens, M, L.C, L.Cp, lnpart, st, dx1s, slot_of, slots);
+    }
     return 0;
 }
 
@@ -599,7 +609,7 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
         if (fmlp) {
             if (slots != tokens) ESCX_HIP(hipMemsetAsync(dx1s, 0, (size_t)Ms * L.Cp * sizeof(float), st));      // pad slots carry no gradient
             PROF("B.mlp_fused" + tg, 10.0 * M * L.C * L.hidden, 0,
-                 rc = mlp_bwd_fused(h, L, bw, bt.x1, dy, dx1, dx1s, inv, tokens, slots, M, part, st));
+                 rc = mlp_bwd_fused(h, L, bw, bt.x1, dy, dx1, dx1s, inv, tokens, slots, M, part, dxn, dhpre, lnpart, st));
             if (rc) return rc;
         } else {
         PROF("B.dw_fc2" + tg, 2.0 * M * L.C * L.hidden, 0,

@@ -46,7 +46,8 @@ struct MlpBwdArgs {
     const float* b1;            // [hiddenP]
     const float* w2T;           // [hiddenP][CP]   (w2T[h][c] = W2[c][h])
     const float* w1T;           // [CP][hiddenP]
-    float* part;                // per-workgroup partial sums, regions [grid][n]: E = d h_pre^T xhat (hiddenP*CP) | dW2 (CP*hiddenP) | db1 (hiddenP) | db2 (CP)
+    float* part;                // per-workgroup partial sums, regions [grid.x][n]: E = d h_pre^T xhat (hiddenP*CP) | dW2 (CP*hiddenP) | db1 (hiddenP) | db2 (CP)
+    float* dxn_part;            // hidden split (grid.y = HS > 1): slab [HS][M][CP] of d xn partial sums; the LayerNorm backward then runs as a separate pass
     int M, C, hiddenP, tokens, slots;
     float eps;
     int dbg;                    // timing experiments only (ESCX_MLPBWD_DBG): 1 = finisher idle, 2 = stagers stage only the first tile, 4 = compute waves skip the partial-sum writes
@@ -61,12 +62,18 @@ struct MlpBwdArgs {
 // instead of ~480), and the finishing wave for its stores.  The data exchanged between waves here lives in LDS; global loads stay in flight.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int CP, int NC>
+// HS > 1 (grid.y = HS; C = 72: 18 hidden tiles do not fit the 16 waves of a workgroup): workgroup (x, y) owns hidden tiles [y * NC, (y + 1) * NC); its d xn is
+// then a partial sum over a part of the hidden units, so the finisher only adds its NC waves' shares and writes them to slab y - the caller sums the HS slabs and runs
+// the stand-alone LayerNorm backward.  The finisher then reads nothing of the staged tile, the ring needs two slots instead of three, and the normalised rows are not
+// staged row-major (LDS: 156 KB at C = 72 with NC = 9).  W1's second operand layout is re-read from L1 per tile there instead of living in 20 registers.
+template <int CP, int NC, int HS>
 __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs a) {
     constexpr int KC = CP / 16;                 // channel tiles
     constexpr int SLD = CP + 4, TLD = 20;       // row strides (dwords) of the row-major / transposed staged copies
-    struct Stage { float xn[16 * SLD]; float xh[16 * SLD]; float dy[16 * SLD]; float xhT[CP * TLD]; float dyT[CP * TLD]; float rstd[16]; };
-    __shared__ Stage stg[3];
+    constexpr int NSTG = HS > 1 ? 2 : 3;
+    constexpr bool W1E_REG = CP <= 48;
+    struct Stage { float xn[16 * SLD]; float xh[HS > 1 ? 4 : 16 * SLD]; float dy[16 * SLD]; float xhT[CP * TLD]; float dyT[CP * TLD]; float rstd[16]; };
+    __shared__ Stage stg[NSTG];
     __shared__ float red[2][NC][16 * SLD];
     __shared__ float tr[NC][16 * TLD];
     __shared__ float gam_s[CP], bet_s[CP];
@@ -79,6 +86,7 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
     if (threadIdx.x < CP) { gam_s[threadIdx.x] = a.gamma[threadIdx.x]; bet_s[threadIdx.x] = a.beta[threadIdx.x]; }
     __syncthreads();
     auto tile_row = [&](int t) { return ((int)blockIdx.x + t * (int)gridDim.x) * 16 + b; };
+    auto ring_next = [&](int i) { return i + 1 == NSTG ? 0 : i + 1; };
 
     // The service waves are the youngest of the workgroup: at equal priority the SIMD's arbiter hands them only the issue slots the three compute
     // waves leave over, and their short per-tile chains then take longer than the compute waves' tile (measured: the finisher +120 us, the stagers
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
                     xn[e] = in ? xh[e] * gm[e] + bt[e] : 0.f;
                     S.xhT[(16 * ct + 4 * g + e) * TLD + b] = xh[e];
                 }
-                st4(&S.xh[b * SLD + 16 * ct + 4 * g], xh);
+                if (HS == 1) st4(&S.xh[b * SLD + 16 * ct + 4 * g], xh);
                 st4(&S.xn[b * SLD + 16 * ct + 4 * g], xn);
             }
             if (g == 0) S.rstd[b] = live ? rstd : 0.f;
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
         int snext = 1;
         for (int it = 0; it < n_it; ++it) {
             if (it + 1 < n_it && !(a.dbg & 2)) { store(stg[snext], it + 1); load(it + 2); }
-            snext = snext == 2 ? 0 : snext + 1;
+            snext = ring_next(snext);
             lds_barrier();
         }
     } else if (wave == NC + 1) {
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
         int snext = 1;
         for (int it = 0; it < n_it; ++it) {
             if (it + 1 < n_it && !(a.dbg & 2)) { store(stg[snext]); load(it + 2); }
-            snext = snext == 2 ? 0 : snext + 1;
+            snext = ring_next(snext);
             lds_barrier();
         }
         float* Pd = a.part + (size_t)gridDim.x * (2 * (size_t)a.hiddenP * CP + a.hiddenP) + (size_t)blockIdx.x * CP;
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
                 float u = sdy[ct][e];
 #pragma unroll
                 for (int sh = 8; sh >= 1; sh >>= 1) u += __shfl_xor(u, sh, 16);
-                if (b == 0) Pd[16 * ct + 4 * g + e] = u;
+                if (b == 0 && blockIdx.y == 0) Pd[16 * ct + 4 * g + e] = u;
             }
     } else if (wave == NC + 2) {
         // ---- finisher: during iteration it it completes tile it - 1 (the partial sums were published by the barrier that ended it - 1) ----
@@ -174,6 +182,19 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
             const int row = tile_row(t);
             const bool live = row < a.M;
             const float* rp = &red[t & 1][0][0];
+            if constexpr (HS > 1) {
+                // partial sum over this workgroup's hidden tiles -> slab blockIdx.y (the other workgroups of the row block hold the rest)
+                float* dst = a.dxn_part + ((size_t)blockIdx.y * a.M + row) * CP;
+#pragma unroll
+                for (int ct = 0; ct < KC; ++ct) {
+                    const int o4 = b * SLD + 16 * ct + 4 * g;
+                    f32x4 tt = ld4(rp + o4);
+#pragma unroll
+                    for (int w = 1; w < NC; ++w) tt += ld4(rp + w * 16 * SLD + o4);           // wave order: fixed
+                    if (live) st4(dst + 16 * ct + 4 * g, tt);
+                }
+                return;
+            }
             f32x4 gv[KC], xh[KC];
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -205,24 +226,26 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
             }
         };
         lds_barrier();
-        int sprev = 2;                           // (it - 1) % 3
+        int sprev = NSTG - 1;                    // (it - 1) % NSTG (HS > 1: the finisher does not read the stage)
         for (int it = 0; it < n_it; ++it) {
             if (it > 0 && !(a.dbg & 1)) finish(it - 1, stg[sprev]);
-            sprev = sprev == 2 ? 0 : sprev + 1;
+            sprev = ring_next(sprev);
             lds_barrier();
         }
         if (n_it > 0) finish(n_it - 1, stg[sprev]);
     } else {
         // ---- compute wave w: hidden tile w ----
-        f32x4 W1a[KC], W2c[KC], W1e[KC], dW1T[KC], dW2[KC];
+        const int ht = (int)blockIdx.y * NC + wave;                      // this wave's hidden tile
+        f32x4 W1a[KC], W2c[KC], W1e[W1E_REG ? KC : 1], dW1T[KC], dW2[KC];
 #pragma unroll
         for (int ct = 0; ct < KC; ++ct) {
-            W1a[ct] = ld4(a.w1 + (size_t)(16 * wave + b) * CP + 16 * ct + 4 * g);
-            W2c[ct] = ld4(a.w2T + (size_t)(16 * wave + b) * CP + 16 * ct + 4 * g);
-            W1e[ct] = ld4(a.w1T + (size_t)(16 * ct + b) * a.hiddenP + 16 * wave + 4 * g);
+            W1a[ct] = ld4(a.w1 + (size_t)(16 * ht + b) * CP + 16 * ct + 4 * g);
+            W2c[ct] = ld4(a.w2T + (size_t)(16 * ht + b) * CP + 16 * ct + 4 * g);
+            if (W1E_REG) W1e[ct] = ld4(a.w1T + (size_t)(16 * ct + b) * a.hiddenP + 16 * ht + 4 * g);
             dW1T[ct] = zero4(); dW2[ct] = zero4();
         }
-        const float bias1 = a.b1[16 * wave + b];
+        const float* w1e_src = a.w1T + (size_t)b * a.hiddenP + 16 * ht + 4 * g;    // + 16 * ct * hiddenP per channel tile
+        const float bias1 = a.b1[16 * ht + b];
         float db1 = 0.f;
         float* trw = &tr[wave][0];
         lds_barrier();
@@ -242,11 +265,14 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
             }
             // the row-contraction operands are fetched BEFORE the GELU arithmetic so that their LDS latency hides under it (all waves of the
             // workgroup run in lockstep behind the per-tile barrier: an exposed LDS round trip is paid by every SIMD at the same time)
-            f32x4 xt[KC], dt[KC];
+            constexpr bool PREFETCH_T = KC <= 3;            // wider maps: fetched tile by tile inside the contraction (registers)
+            f32x4 xt[PREFETCH_T ? KC : 1], dt[PREFETCH_T ? KC : 1];
+            if constexpr (PREFETCH_T) {
 #pragma unroll
-            for (int ct = 0; ct < KC; ++ct) {
-                xt[ct] = ld4(&S.xhT[(16 * ct + b) * TLD + 4 * g]);
-                dt[ct] = ld4(&S.dyT[(16 * ct + b) * TLD + 4 * g]);
+                for (int ct = 0; ct < KC; ++ct) {
+                    xt[ct] = ld4(&S.xhT[(16 * ct + b) * TLD + 4 * g]);
+                    dt[ct] = ld4(&S.dyT[(16 * ct + b) * TLD + 4 * g]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             f32x4 hact, dhp;
@@ -263,24 +289,38 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
             __builtin_amdgcn_sched_barrier(0);
             // weight gradients: contractions over the 16 rows (k-slot g <-> rows 4g + r)
 #pragma unroll
-            for (int ct = 0; ct < KC; ++ct)
+            for (int ct = 0; ct < KC; ++ct) {
+                f32x4 xq, dq;
+                if constexpr (PREFETCH_T) { xq = xt[ct]; dq = dt[ct]; }
+                else { xq = ld4(&S.xhT[(16 * ct + b) * TLD + 4 * g]); dq = ld4(&S.dyT[(16 * ct + b) * TLD + 4 * g]); }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    dW1T[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[ct][r], dhp[r], dW1T[ct], 0, 0, 0);   // E[hid b][c 16ct+4g+r'] = sum_rows d h_pre * xhat
-                    dW2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dt[ct][r], hact[r], dW2[ct], 0, 0, 0);    // dW2[c 16ct+4g+r'][hid b]
+                    dW1T[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[r], dhp[r], dW1T[ct], 0, 0, 0);   // E[hid b][c 16ct+4g+r'] = sum_rows d h_pre * xhat
+                    dW2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dq[r], hact[r], dW2[ct], 0, 0, 0);    // dW2[c 16ct+4g+r'][hid b]
                 }
+            }
             // this tile's share of d xn = d h_pre W1: D[c 16ct+4g+r'][row b]; the KC accumulators are independent chains
             f32x4 dx[KC];
 #pragma unroll
             for (int ct = 0; ct < KC; ++ct) dx[ct] = zero4();
+            if constexpr (W1E_REG) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int ct = 0; ct < KC; ++ct) dx[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(W1e[ct][r], dhT[r], dx[ct], 0, 0, 0);
+                    for (int ct = 0; ct < KC; ++ct) dx[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(W1e[ct][r], dhT[r], dx[ct], 0, 0, 0);
+            } else {
+                f32x4 we[KC];
+#pragma unroll
+                for (int ct = 0; ct < KC; ++ct) we[ct] = ld4(w1e_src + (size_t)16 * ct * a.hiddenP);      // L1-resident: the same 5 KB every tile
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ct = 0; ct < KC; ++ct) dx[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(we[ct][r], dhT[r], dx[ct], 0, 0, 0);
+            }
             float* rp = &red[it & 1][wave][0];
 #pragma unroll
             for (int ct = 0; ct < KC; ++ct) if (!(a.dbg & 4) || it == 0) st4(rp + b * SLD + 16 * ct + 4 * g, dx[ct]);
-            sidx = sidx == 2 ? 0 : sidx + 1;
+            sidx = ring_next(sidx);
             lds_barrier();
         }
         // per-workgroup partial sums of the parameter gradients
@@ -290,12 +330,12 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
         float* Pb = a.part + (size_t)gridDim.x * 2 * n1 + (size_t)blockIdx.x * a.hiddenP;
 #pragma unroll
         for (int ct = 0; ct < KC; ++ct) {
-            st4(P1 + (size_t)(16 * wave + b) * CP + 16 * ct + 4 * g, dW1T[ct]);
+            st4(P1 + (size_t)(16 * ht + b) * CP + 16 * ct + 4 * g, dW1T[ct]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) P2[(size_t)(16 * ct + 4 * g + r) * a.hiddenP + 16 * wave + b] = dW2[ct][r];
+            for (int r = 0; r < 4; ++r) P2[(size_t)(16 * ct + 4 * g + r) * a.hiddenP + 16 * ht + b] = dW2[ct][r];
         }
         const float sb = sum_groups(db1);
-        if (g == 0) Pb[16 * wave + b] = sb;
+        if (g == 0) Pb[16 * ht + b] = sb;
     }
 }
 
@@ -318,6 +358,15 @@ static __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(const float*
     dst[j] = t;
 }
 
+// d xn = slab 0 + slab 1 + ... (fixed order) of the hidden-split form
+static __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int n_slabs, long long n4, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 v = ld4(slabs + 4 * i);
+    for (int k = 1; k < n_slabs; ++k) v += ld4(slabs + (size_t)k * 4 * n4 + 4 * i);
+    st4(out + 4 * i, v);
+}
+
 // dW1 = E diag(gamma) + d b1 beta^T ;  d gamma[c] = sum_h W1[h][c] E[h][c] ;  d beta[c] = sum_h W1[h][c] d b1[h]   (fixed summation order)
 static __global__ __launch_bounds__(1024) void mlp_bwd_finish_kernel(const float* __restrict__ E, const float* __restrict__ db1, const float* __restrict__ w1,
                                              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dW1,
@@ -329,6 +378,7 @@ static __global__ __launch_bounds__(1024) void mlp_bwd_finish_kernel(const float
     }
     // 16 threads per column, each a strided subset of the hidden units in increasing order; the 16 partial sums are then added in order
     const int c = threadIdx.x % 64, k = threadIdx.x / 64;       // Cp <= 64 columns x 16 parts
+    if (!dgamma) return;                        // hidden-split form: the stand-alone LayerNorm backward produces d gamma / d beta
     if (c < Cp) {
         float sg = 0.f, sb = 0.f;
         for (int hh = k; hh < hiddenP; hh += 16) { const float w = w1[(size_t)hh * Cp + c]; sg += w * E[(size_t)hh * Cp + c]; sb += w * db1[hh]; }
