@@ -470,7 +470,37 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
     build_front(d, wave, B, L, d->scratch, &ins, &specs, &y, &stats, st);
     float* cur = d->scratch + front;
     auto take = [&](size_t n) { float* p = cur; cur += pad64(n); return p; };
-    // gradient views, one per feature map
+    // fused[i]: the dX launches of map i's consumer cover every position of the map exactly once, so their epilogue writes the final pre-activation
+    // gradient (loss gradient + dX, times the LeakyReLU mask) in one pass; otherwise copy the loss gradient first, accumulate, mask in place.
+    static const bool fuse_on = !(getenv("ESCX_DISC_FUSED_GRAD") && atoi(getenv("ESCX_DISC_FUSED_GRAD")) == 0);
+    auto dx_covers = [&](const DConv& c) {
+        if (!fuse_on) return false;
+        if (!c.Wp) return true;
+        for (int r0 = 0; r0 < c.s0; ++r0) for (int r1 = 0; r1 < c.s1; ++r1)
+            if (phase_ntaps(r0, c.p0, c.s0, c.T0) * phase_ntaps(r1, c.p1, c.s1, c.T1) == 0) return false;
+        return true;
+    };
+    std::vector<char> fused(shp.size(), 0);
+    {
+        int f0 = 0;
+        for (const DSub& S : d->subs) {
+            const int nconv = (int)S.convs.size();
+            if (S.kind == 0) { for (int j = 0; j + 1 < nconv; ++j) fused[f0 + j] = dx_covers(S.convs[j + 1]); }
+            else {
+                const int nb = (int)S.bands.size();
+                for (int b = 0; b < nb; ++b) for (int j = 0; j < 4; ++j) fused[f0 + b * 5 + j] = dx_covers(S.convs[b * 5 + j + 1]);
+                bool cat_ok = dx_covers(S.convs.back());        // the band tops are one concatenated map for conv_post: their loss gradients must be too
+                const float* base = d_fmaps[f0 + 4];
+                for (int b = 0; b < nb && cat_ok; ++b) {
+                    const int fi = f0 + b * 5 + 4;
+                    cat_ok = base ? d_fmaps[fi] == base + (size_t)shp[fi].off1 * shp[fi].Cp : d_fmaps[fi] == nullptr;
+                }
+                for (int b = 0; b < nb; ++b) fused[f0 + b * 5 + 4] = cat_ok;
+            }
+            f0 += nconv;
+        }
+    }
+    // gradient views, one per feature map (same layout as the map)
     std::vector<TView> gv(shp.size());
     {
         float* cat = nullptr;
@@ -478,6 +508,7 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
             const FmapShape& f = shp[i];
             if (f.P1 == f.D1) gv[i] = TView{take((size_t)B * f.D0 * f.D1 * f.Cp), f.D0, f.D1, f.D1, f.Cp};
             else { if (f.off1 == 0) cat = take((size_t)B * f.D0 * f.P1 * f.Cp); gv[i] = TView{cat + (size_t)f.off1 * f.Cp, f.D0, f.D1, f.P1, f.Cp}; }
+            if (fused[i]) continue;
             TView src{const_cast<float*>(d_fmaps[i]), f.D0, f.D1, f.P1, f.Cp};
             hipLaunchKernelGGL(view_copy_kernel, dim3(blk((long long)B * f.D0 * f.D1 * f.Cp / 4)), dim3(256), 0, st, gv[i], src, (long long)B * f.D0 * f.D1 * f.Cp / 4);
         }
@@ -487,9 +518,12 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
     if (grad_flat) ESCX_HIP(hipMemsetAsync(grad_flat, 0, d->total * sizeof(float), st));
     if (d_wave) ESCX_HIP(hipMemsetAsync(dy, 0, (size_t)B * L * sizeof(float), st));
 
-    auto layer_bwd = [&](const DConv& c, const TView& x, const TView& yv, const TView& g, const TView* gx, float* gx_plain) -> int {
+    // g: gradient of the layer's output map (g_pre: already the pre-activation gradient).  gx: gradient view of its input map; fin = 1 writes it
+    // finally as (init + dX) * LeakyReLU'(xact) (see GradOut).  gx_plain: dense gradient of a network input (no loss gradient, no activation).
+    auto layer_bwd = [&](const DConv& c, const TView& x, const TView& yv, const TView& g, bool g_pre, const TView* gx, float* gx_plain, bool fin, const float* init,
+                         const float* xact) -> int {
         const int M = B * yv.D0 * yv.D1;
-        if (c.act) hipLaunchKernelGGL(leaky_bwd_kernel, dim3(blk((long long)M * yv.Cp / 4)), dim3(256), 0, st, g, yv, (long long)M * yv.Cp / 4, B);
+        if (c.act && !g_pre) hipLaunchKernelGGL(leaky_bwd_kernel, dim3(blk((long long)M * yv.Cp / 4)), dim3(256), 0, st, g, yv, (long long)M * yv.Cp / 4, B);
         if (grad_flat) {
             ViewRowsA la{g, M, FastDiv(yv.D0 * yv.D1), FastDiv(yv.D1)};
             ConvS lb = make_convs(x, c, yv.D0, yv.D1, B);
@@ -503,7 +537,9 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
         if (gx || gx_plain) {
             TView gxv = gx ? *gx : TView{gx_plain, x.D0, x.D1, x.D1, x.Cp};
             DTrace tr(st, "dX", c.prefix.c_str(), B * x.D0 * x.D1, c.CinR, c.Wp ? c.Kt / (c.s0 * c.s1) : c.Kt);
-            if (gx_plain) ESCX_HIP(hipMemsetAsync(gx_plain, 0, (size_t)B * x.D0 * x.D1 * x.Cp * sizeof(float), st));
+            if (gx_plain) { fin = dx_covers(c); init = nullptr; xact = nullptr; }
+            if (gx_plain && !fin) ESCX_HIP(hipMemsetAsync(gx_plain, 0, (size_t)B * x.D0 * x.D1 * x.Cp * sizeof(float), st));
+            const GradOut go{gxv, init, xact, fin ? 1 : 0};
             if (c.Wp) {                         // strided: one launch per residue class of input positions over its own taps
                 size_t off = 0;
                 for (int r0 = 0; r0 < c.s0; ++r0) for (int r1 = 0; r1 < c.s1; ++r1) {
@@ -514,7 +550,7 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
                         PhaseGeom pg{r0, r1, n0, n1, (r0 + c.p0 - phase_tmin(r0, c.p0, c.s0)) / c.s0, (r1 + c.p1 - phase_tmin(r1, c.p1, c.s1)) / c.s1, Q0, Q1, c.s0, c.s1};
                         const int Mi = B * Q0 * Q1;
                         ConvTSP lt{g, pg, Mi, FastDiv(Q0 * Q1), FastDiv(Q1), FastDiv(g.Cp), FastDiv(n1)};
-                        conv_gemm(lt, c.Wp + off, Mi, c.CinR, kp, EpiAccumPhase{gxv, pg, FastDiv(Q0 * Q1), FastDiv(Q1)}, st);
+                        conv_gemm(lt, c.Wp + off, Mi, c.CinR, kp, EpiAccumPhase{go, pg, FastDiv(Q0 * Q1), FastDiv(Q1)}, st);
                     }
                     off += (size_t)c.CinR * kp;
                 }
@@ -522,7 +558,7 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
                 ConvGeom cg{c.T0, c.T1, c.s0, c.s1, c.p0, c.p1, yv.D0, yv.D1};
                 const int Mi = B * x.D0 * x.D1;
                 ConvTS lt{g, cg, x.D0, x.D1, Mi, FastDiv(x.D0 * x.D1), FastDiv(x.D1), FastDiv(g.Cp), FastDiv(c.T1), FastDiv(c.s0), FastDiv(c.s1)};
-                conv_gemm(lt, c.Wt, Mi, c.CinR, c.Kt, EpiAccumView{gxv, FastDiv(x.D0 * x.D1), FastDiv(x.D1)}, st);
+                conv_gemm(lt, c.Wt, Mi, c.CinR, c.Kt, EpiAccumView{go, FastDiv(x.D0 * x.D1), FastDiv(x.D1)}, st);
             }
         }
         return 0;
@@ -539,8 +575,10 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
                 const int fi = f0 + j;
                 TView yv = view_of(fmaps[fi], shp[fi]);
                 TView x = j > 0 ? view_of(fmaps[fi - 1], shp[fi - 1]) : TView{ins[si][0], g.D0, g.D1, g.D1, 4};
-                if (j > 0) { if ((rc = layer_bwd(S.convs[j], x, yv, gv[fi], &gv[fi - 1], nullptr))) return rc; }
-                else { if ((rc = layer_bwd(S.convs[j], x, yv, gv[fi], nullptr, d_wave ? gin : nullptr))) return rc; }
+                if (j > 0) {
+                    if ((rc = layer_bwd(S.convs[j], x, yv, gv[fi], fused[fi], &gv[fi - 1], nullptr, fused[fi - 1], d_fmaps[fi - 1], S.convs[j - 1].act ? fmaps[fi - 1] : nullptr)))
+                        return rc;
+                } else { if ((rc = layer_bwd(S.convs[j], x, yv, gv[fi], fused[fi], nullptr, d_wave ? gin : nullptr, false, nullptr, nullptr))) return rc; }
             }
             if (d_wave) hipLaunchKernelGGL(mpd_input_bwd_kernel, dim3(blk((long long)B * L)), dim3(256), 0, st, gin, dy, B, L, g.D0, S.arg);
         } else {
@@ -548,15 +586,20 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
             const int fpost = f0 + nconv - 1, ftop0 = f0 + 4;
             TView cat_y{fmaps[ftop0], g.T, g.catF, g.catF, 32};
             TView cat_g{gv[ftop0].p, g.T, g.catF, g.catF, 32};
-            if ((rc = layer_bwd(S.convs.back(), cat_y, view_of(fmaps[fpost], shp[fpost]), gv[fpost], &cat_g, nullptr))) return rc;
+            if ((rc = layer_bwd(S.convs.back(), cat_y, view_of(fmaps[fpost], shp[fpost]), gv[fpost], fused[fpost], &cat_g, nullptr, fused[ftop0], d_fmaps[ftop0],
+                                S.convs[4].act ? fmaps[ftop0] : nullptr)))
+                return rc;
             if (d_wave) ESCX_HIP(hipMemsetAsync(gspec, 0, (size_t)B * g.T * 2 * S.Fq * sizeof(float), st));
             for (int b = nb - 1; b >= 0; --b) {
                 for (int j = 4; j >= 0; --j) {
                     const int fi = f0 + b * 5 + j;
                     TView yv = view_of(fmaps[fi], shp[fi]);
                     TView x = j > 0 ? view_of(fmaps[fi - 1], shp[fi - 1]) : TView{ins[si][b], g.T, g.bandF[b], g.bandF[b], 4};
-                    if (j > 0) { if ((rc = layer_bwd(S.convs[b * 5 + j], x, yv, gv[fi], &gv[fi - 1], nullptr))) return rc; }
-                    else { if ((rc = layer_bwd(S.convs[b * 5 + j], x, yv, gv[fi], nullptr, d_wave ? gin : nullptr))) return rc; }
+                    if (j > 0) {
+                        if ((rc = layer_bwd(S.convs[b * 5 + j], x, yv, gv[fi], fused[fi], &gv[fi - 1], nullptr, fused[fi - 1], d_fmaps[fi - 1],
+                                            S.convs[b * 5 + j - 1].act ? fmaps[fi - 1] : nullptr)))
+                            return rc;
+                    } else { if ((rc = layer_bwd(S.convs[b * 5 + j], x, yv, gv[fi], fused[fi], nullptr, d_wave ? gin : nullptr, false, nullptr, nullptr))) return rc; }
                 }
                 if (d_wave) hipLaunchKernelGGL(mrd_band_bwd_kernel, dim3(blk((long long)B * g.T * g.bandF[b])), dim3(256), 0, st, gin, gspec, (long long)B * g.T, S.Fq,
                                                S.bands[b].first, g.bandF[b]);

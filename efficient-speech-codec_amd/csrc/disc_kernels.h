@@ -86,13 +86,30 @@ struct ConvTSP {                // A[(b, q0, q1)][k = (a*n1 + b1)*Cp + co] = dY(
     }
 };
 
-struct EpiAccumPhase {          // out(b, r0 + s0*q0, r1 + s1*q1, n..) += v
-    TView o; PhaseGeom g; FastDiv dQ, dQ1;
+// dX epilogues.  mode 0: out += v.  mode 1 (every position of the map is covered by exactly one dX launch): the FINAL pre-activation
+// gradient of the input map in one write, out = (init + v) * LeakyReLU'(y): init = the loss gradient of that map (NULL = 0), y = the map itself
+// (NULL = its producer has no activation); init and y share out's layout.  Same arithmetic as view_copy + accumulate + leaky_bwd_kernel.
+struct GradOut {
+    TView o; const float* init; const float* y; int final_;
+    __device__ __forceinline__ void put(size_t off, f32x4 v) const {
+        float* q = o.p + off;
+        if (!final_) { st4(q, ld4(q) + v); return; }
+        if (init) v = ld4(init + off) + v;
+        if (y) {
+            const f32x4 a = ld4(y + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = a[e] > 0.f ? v[e] : 0.1f * v[e];
+        }
+        st4(q, v);
+    }
+};
+struct EpiAccumPhase {          // out(b, r0 + s0*q0, r1 + s1*q1, n..)
+    GradOut w; PhaseGeom g; FastDiv dQ, dQ1;
     __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        const TView& o = w.o;
         if (n >= o.Cp) return;
         const int b = dQ.div(m), r = m - b * g.Q0 * g.Q1; const int q0 = dQ1.div(r), q1 = r - q0 * g.Q1;
-        float* q = o.p + (((size_t)b * o.D0 + g.r0 + g.s0 * q0) * o.P1 + g.r1 + g.s1 * q1) * o.Cp + n;
-        st4(q, ld4(q) + v);
+        w.put((((size_t)b * o.D0 + g.r0 + g.s0 * q0) * o.P1 + g.r1 + g.s1 * q1) * o.Cp + n, v);
     }
 };
 
@@ -121,13 +138,13 @@ struct EpiConvOut {             // out(b, o0, o1, n..n+3) = act(v + bias[n]) ; a
     }
 };
 
-struct EpiAccumView {           // out(b, i0, i1, n..) += v   (dX of a layer added to the gradient of its input map)
-    TView o; FastDiv dR, dD1;
+struct EpiAccumView {           // out(b, i0, i1, n..): dX of a layer into the gradient of its input map
+    GradOut w; FastDiv dR, dD1;
     __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {
+        const TView& o = w.o;
         if (n >= o.Cp) return;
         const int b = dR.div(m), r = m - b * o.D0 * o.D1; const int i0 = dD1.div(r), i1 = r - i0 * o.D1;
-        float* q = o.p + (((size_t)b * o.D0 + i0) * o.P1 + i1) * o.Cp + n;
-        st4(q, ld4(q) + v);
+        w.put((((size_t)b * o.D0 + i0) * o.P1 + i1) * o.Cp + n, v);
     }
 };
 
