@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -192,14 +193,38 @@ void gemm_ln_bwd_rows(const float* A, int lda, int M, const float* Wt, int Cp, i
 
 int attn_bwd(const float* qkv, const float* bias, const float* dout, float* dqkv, float* dbias, float* part, int total_windows, int nH, int hdp, int ldq,
              int ldo, int nWh, int nWw, int shifted, float scale, hipStream_t st) {
-    const int gx = (int)std::min<long long>(512, ((long long)total_windows + 3) / 4);
-    if ((unsigned long long)(total_windows + 4 * gx) * 16ull * (unsigned long long)std::max(ldq, ldo) >= (1ull << 32)) return -2;    // 32-bit element offsets in the kernel
-    dim3 grid(gx, nH);
-#define ESCX_ATB(S) case S: hipLaunchKernelGGL((attn_bwd_kernel<S>), grid, dim3(256), 0, st, qkv, bias, dout, dqkv, part, total_windows, nH, ldq, ldo, nWh, nWw, shifted, scale); break;
+    // Persistent waves striding over the windows, each doing HPW heads per window (the heads of a window share its rows: in one wave every cache line is
+    // fetched once).  Grid: ONE workgroup per CU in total - measured at 36 clips (profiles/r3_attn_bwd_grid_sweep.txt): the kernel moves 1.06 GB per launch
+    // at C = 45 and runs at 5.0 TB/s with 256 workgroups, 4.1 TB/s with 384 and 3.0 TB/s with the chip full (1 536, one head per wave): more concurrent row
+    // streams only cost DRAM efficiency, there is no latency left to hide.  ESCX_ATTN_BWD_GX = n: n window chunks; ESCX_ATTN_BWD_HPW=1: one head per wave.
+    static const int gx_env = [] { const char* e = getenv("ESCX_ATTN_BWD_GX"); return e ? atoi(e) : 0; }();
+    static const int hpw_env = [] { const char* e = getenv("ESCX_ATTN_BWD_HPW"); return e ? atoi(e) : 3; }();
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n;
+    }();
+    const int hpw = (hpw_env == 3 && nH % 3 == 0) ? 3 : 1;
+    const int gy = nH / hpw;
+    int gx = (int)std::min<long long>(512, ((long long)total_windows + 3) / 4);
+    if (gx_env > 0) gx = std::min(gx, gx_env);
+    else {
+        int cap = std::max(1, cus / gy);
+        if (cap >= 16) cap &= ~7;                            // the chunks of one window range land on the same XCD for every head group (workgroup id mod 8)
+        gx = std::min(gx, cap);
+    }
+    auto launch = [&](auto kern) {
+        if ((unsigned long long)(total_windows + 4 * gx) * 16ull * (unsigned long long)std::max(ldq, ldo) >= (1ull << 32)) return -2;    // 32-bit element offsets in the kernel
+        hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), 0, st, qkv, bias, dout, dqkv, part, total_windows, nH, ldq, ldo, nWh, nWw, shifted, scale);
+        return 0;
+    };
+    int lrc = -1;
+#define ESCX_ATB(S) case S: lrc = hpw == 3 ? launch(attn_bwd_kernel<S, 3>) : launch(attn_bwd_kernel<S, 1>); break;
     switch (hdp / 4) {
         ESCX_ATB(1) ESCX_ATB(2) ESCX_ATB(3) ESCX_ATB(4) ESCX_ATB(5) ESCX_ATB(6) ESCX_ATB(7) ESCX_ATB(8) ESCX_ATB(12) ESCX_ATB(16)
         default: return -1;
     }
+    if (lrc) return lrc;
 #undef ESCX_ATB
     reduce_partials(part, gx, (long long)nH * 256, dbias, 0, st);
     return 0;

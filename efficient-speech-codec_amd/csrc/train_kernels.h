@@ -699,9 +699,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 //   qkv  : [B*nW*16][ldq]  saved forward tensor (q already scaled)       dout : [B*nW*16][ldo]  gradient of the head-concatenated output
 //   dqkv : [B*nW*16][ldq]  gradient w.r.t. the UNSCALED qkv linear output (q columns are multiplied by `scale` here)
 //   dbias_part : [gridDim.x][nH][16][16]  per-workgroup sums of dS (relative-position bias gradient), reduced afterwards in fixed order
-// grid = (window chunks, nH): a wave keeps ONE head, so that its dS sum stays in registers across the windows it walks.
+// grid = (window chunks, nH / HPW): a wave walks windows and, on each, its HPW heads one after the other (their dS sums stay in registers).  Heads that
+// share the rows of a window in different workgroups re-fetch the same cache lines whenever they drift apart (measured: 3.0 TB/s of 1-pass traffic with one
+// head per wave and the chip full, 4.9 TB/s with a third of the waves); with the heads of a window in ONE wave every line is fetched once.
 // ------------------------------------------------------------------------------------------------
-template <int STEPS>
+template <int STEPS, int HPW>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ bias, const float* __restrict__ dout,
                                                        float* __restrict__ dqkv, float* __restrict__ dbias_part, int total_windows, int nH,
                                                        int ldq, int ldo, int nWh, int nWw, int shifted, float scale) {
@@ -714,31 +716,37 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     __shared__ float wsum[4][64][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y;
+    const int h0 = blockIdx.y * HPW;             // this wave's heads: h0 .. h0 + HPW - 1, one after the other on the same window
     const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
     const int kOff = nH * HDP, vOff = 2 * nH * HDP;
-    f32x4 dbsum = zero4();
-    // the four operand rows of the NEXT window are fetched while the current one is processed (one exposed memory round trip per
+    f32x4 dbsum[HPW];
+#pragma unroll
+    for (int hh = 0; hh < HPW; ++hh) dbsum[hh] = zero4();
+    // the four operand rows of the NEXT (window, head) are fetched while the current one is processed (one exposed memory round trip per
     // window instead of three)
     float nq[STEPS], nk[STEPS], nv[STEPS], nd[STEPS];
     // element offsets as 32-bit running values (the launcher guarantees total_windows * 16 * ld < 2^32): the per-window 64-bit multiplies and
     // shifts of the address arithmetic were a third of this kernel's VALU instructions (31 v_lshl_add_u64 + 16 v_mul_lo_u32 per 20 MFMAs)
-    const unsigned rowq = (unsigned)i * ldq + h * HDP, rowo = (unsigned)i * ldo + h * HDP;
+    const unsigned rowq = (unsigned)i * ldq + h0 * HDP, rowo = (unsigned)i * ldo + h0 * HDP;
     unsigned wq = (unsigned)wave_global * 16u * ldq, wo = (unsigned)wave_global * 16u * ldo;
     const unsigned stepq = (unsigned)nwaves * 16u * ldq, stepo = (unsigned)nwaves * 16u * ldo;
-    auto fetch = [&](unsigned fq, unsigned fo) {
-        const float* rowp = qkv + (fq + rowq + STEPS * g);
-        const float* dorow = dout + (fo + rowo + STEPS * g);
+    auto fetch = [&](unsigned fq, unsigned fo, int hh) {
+        const float* rowp = qkv + (fq + rowq + hh * HDP + STEPS * g);
+        const float* dorow = dout + (fo + rowo + hh * HDP + STEPS * g);
 #pragma unroll
         for (int r = 0; r < STEPS; ++r) { nq[r] = rowp[r]; nk[r] = rowp[kOff + r]; nv[r] = rowp[vOff + r]; nd[r] = dorow[r]; }
     };
-    if (wave_global < total_windows) fetch(wq, wo);
+    if (wave_global < total_windows) fetch(wq, wo, 0);
     for (int win = wave_global; win < total_windows; win += nwaves, wq += stepq, wo += stepo) {
+#pragma unroll
+        for (int hh = 0; hh < HPW; ++hh) {
+        const int h = h0 + hh;
         const float* base = qkv + (wq + h * HDP);
         float kf[STEPS], qf[STEPS], vf[STEPS], df[STEPS];
 #pragma unroll
         for (int r = 0; r < STEPS; ++r) { qf[r] = nq[r]; kf[r] = nk[r]; vf[r] = nv[r]; df[r] = nd[r]; }
-        if (win + nwaves < total_windows) fetch(wq + stepq, wo + stepo);
+        if (hh + 1 < HPW) fetch(wq, wo, hh + 1);
+        else if (win + nwaves < total_windows) fetch(wq + stepq, wo + stepo, 0);
         if (STAGE) {
 #pragma unroll
             for (int r = 0; r < STEPS; ++r) {
@@ -780,7 +788,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         f32x4 ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) ds[r] = p[r] * (dp[r] - dot);
-        dbsum += ds;
+        dbsum[hh] += ds;
         // transposed P and dS through LDS: lane (j, g) then holds P[4g + r][j]
 #pragma unroll
         for (int r = 0; r < 4; ++r) { tp[wave][0][i][4 * g + r] = p[r]; tp[wave][1][i][4 * g + r] = ds[r]; }
@@ -791,7 +799,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         for (int r = 0; r < 4; ++r) { pt[r] = tp[wave][0][4 * g + r][i]; dsT[r] = tp[wave][1][4 * g + r][i]; }
         // dQ[i][d] = sum_j dS[i][j] K[j][d]  (same operand pattern as O = P V in the forward), scaled back through q*scale;
         // dV[j][d] = sum_i P[i][j] dO[i][d] ; dK[j][d] = sum_i dS[i][j] Q[i][d]   (lane (j, g): rows of key j)
-        float* dqrow = dqkv + (wq + rowq);
+        float* dqrow = dqkv + (wq + (unsigned)i * ldq + h * HDP);
         float* dkrow = dqrow + kOff;
         float* dvrow = dqrow + vOff;
         const float* dobase = dout + (wo + h * HDP);
@@ -820,14 +828,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         __builtin_amdgcn_wave_barrier();             // the LDS tiles are rewritten by the next window
         if (h == 0 && 3 * nH * HDP < ldq)            // tail padding of the qkv width: keep exact zeros (K padding of the dX GEMM)
             for (int c = 3 * nH * HDP + g; c < ldq; c += 4) dqkv[wq + (unsigned)i * ldq + c] = 0.f;
+        }
     }
     // relative-position bias gradient: sum the four waves in fixed order, one partial [16][16] per (workgroup, head)
-    st4(&wsum[wave][lane][0], dbsum);
-    __syncthreads();
-    if (wave == 0) {
-        f32x4 t = ld4(&wsum[0][lane][0]);
-        t += ld4(&wsum[1][lane][0]); t += ld4(&wsum[2][lane][0]); t += ld4(&wsum[3][lane][0]);
-        st4(dbias_part + (((size_t)blockIdx.x * nH + h) * 16 + i) * 16 + 4 * g, t);
+#pragma unroll
+    for (int hh = 0; hh < HPW; ++hh) {
+        if (hh) __syncthreads();
+        st4(&wsum[wave][lane][0], dbsum[hh]);
+        __syncthreads();
+        if (wave == 0) {
+            f32x4 t = ld4(&wsum[0][lane][0]);
+            t += ld4(&wsum[1][lane][0]); t += ld4(&wsum[2][lane][0]); t += ld4(&wsum[3][lane][0]);
+            st4(dbias_part + (((size_t)blockIdx.x * nH + h0 + hh) * 16 + i) * 16 + 4 * g, t);
+        }
     }
 }
 
