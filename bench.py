@@ -327,7 +327,8 @@ def run_train(args, rank, world, device, use_dist):
     recs.sort(key=lambda r: -r["ms"])
     if os.environ.get("ESCX_BENCH_BREAKDOWN"):
         for r in recs:
-            print(f"# {r['name']:24s} calls {r['calls']:4d}  {r['ms'] / psteps:9.3f} ms/step  {r['flops'] / max(r['ms'], 1e-9) / 1e9:9.1f} TFLOP/s", file=sys.stderr)
+            print(f"# {r['name']:24s} calls {r['calls']:4d}  {r['ms'] / psteps:9.3f} ms/step  {r['flops'] / max(r['ms'], 1e-9) / 1e9:9.1f} TFLOP/s"
+                  f"  {r.get('bytes', 0) / max(r['ms'], 1e-9) / 1e6:9.1f} GB/s", file=sys.stderr)
     dom = next((r for r in recs if r["flops"] > 0), recs[0])
     avg_s = dom["ms"] / dom["calls"] * 1e-3
     fl = dom["flops"] / dom["calls"]

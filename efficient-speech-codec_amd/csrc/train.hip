@@ -112,7 +112,11 @@ template <int TA, int TB, class LdA, class LdB>
 int dw_launch_wide(escx_handle_s* h, const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
     constexpr int WA = 32 * TA, WB = 32 * TB;
     const int nbn = (Np + WA - 1) / WA, nbk = (Kp + WB - 1) / WB, blocks = nbn * nbk;
-    int slices = std::max(1, std::min((2560 + blocks / 2) / blocks, (M + 255) / 256));
+    static const int env_target = [] { const char* e = getenv("ESCX_DW_WIDE_TARGET"); return e ? atoi(e) : 0; }();
+    // ONE round of resident workgroups (2 per CU at 65-74 KB of LDS each): a partly filled extra round costs a whole slice time, and every further slice
+    // another partial tile (up to 64 KB) written and read back (ESCX_DW_WIDE_TARGET sweep, 36 clips: 512 -> 79.6 ms/step, 768 -> 80.9, 2560 -> 80.4)
+    const int target = env_target > 0 ? env_target : 512;
+    int slices = std::max(1, std::min(target / blocks, (M + 255) / 256));
     const size_t per = (size_t)Np * Kp + Np;
     slices = (int)std::max<size_t>(1, std::min<size_t>(slices, DW_PART_FLOATS / per));
     int mps = ((M + slices - 1) / slices + 31) / 32 * 32;
@@ -633,51 +637,51 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
         static const bool ln_fused = [] { const char* e = getenv("ESCX_LN_FUSED"); return !(e && e[0] == '0'); }();
         if (fmlp) {
             if (slots != tokens) ESCX_HIP(hipMemsetAsync(dx1s, 0, (size_t)Ms * L.Cp * sizeof(float), st));      // pad slots carry no gradient
-            PROF("B.mlp_fused" + tg, 10.0 * M * L.C * L.hidden, 0,
+            PROF("B.mlp_fused" + tg, 10.0 * M * L.C * L.hidden, (3.0 * M + Ms) * L.Cp * 4,
                  rc = mlp_bwd_fused(h, L, bw, bt.x1, dy, dx1, dx1s, inv, tokens, slots, M, part, dxn, dhpre, lnpart, st));
             if (rc) return rc;
         } else {
-        PROF("B.dw_fc2" + tg, 2.0 * M * L.C * L.hidden, 0,
+        PROF("B.dw_fc2" + tg, 2.0 * M * L.C * L.hidden, (double)M * (L.Cp + L.hiddenP) * 4,
              rc = dw_rows(h, dy, L.Cp, bt.hact, L.hiddenP, M, L.Cp, L.hiddenP, G(h, bw.w2), G(h, bw.b2), part, st));
         if (rc) return rc;
-        PROF("B.dx_fc2" + tg, 2.0 * M * L.C * L.hidden, 0,
+        PROF("B.dx_fc2" + tg, 2.0 * M * L.C * L.hidden, (double)M * (L.Cp + 2 * L.hiddenP) * 4,
              gemm_rows(dy, L.Cp, M, bw.w2T, L.hiddenP, L.Cp, EpiGeluBwd{dhpre, L.hiddenP, bt.hpre}, st));
-        PROF("B.dw_fc1" + tg, 2.0 * M * L.C * L.hidden, 0,
+        PROF("B.dw_fc1" + tg, 2.0 * M * L.C * L.hidden, (double)M * (L.Cp + L.hiddenP) * 4,
              rc = dw_rows(h, dhpre, L.hiddenP, bt.xn2, L.Cp, M, L.hiddenP, L.Cp, G(h, bw.w1), G(h, bw.b1), part, st));
         if (rc) return rc;
         if (slots != tokens) ESCX_HIP(hipMemsetAsync(dx1s, 0, (size_t)Ms * L.Cp * sizeof(float), st));      // pad slots carry no gradient
         if (ln_fused && L.Cp <= 96) {       // narrow maps: LN2's backward rides in the epilogue of the GEMM that produces its upstream gradient
-            PROF("B.dx_fc1+ln2" + tg, 2.0 * M * L.C * L.hidden, 0,
+            PROF("B.dx_fc1+ln2" + tg, 2.0 * M * L.C * L.hidden, ((double)M * (L.hiddenP + 3 * L.Cp) + (double)Ms * L.Cp) * 4,
                  gemm_ln_bwd_rows(dhpre, L.hiddenP, M, bw.w1T, L.Cp, L.hiddenP, bt.x1, bw.ln2_g, dy, dx1, dx1s, inv, tokens, slots, L.C, G(h, bw.ln2_g),
                                   G(h, bw.ln2_b), part, st));
         } else {
-            PROF("B.dx_fc1" + tg, 2.0 * M * L.C * L.hidden, 0,
+            PROF("B.dx_fc1" + tg, 2.0 * M * L.C * L.hidden, (double)M * (L.hiddenP + L.Cp) * 4,
                  gemm_rows(dhpre, L.hiddenP, M, bw.w1T, L.Cp, L.hiddenP, EpiStore{dxn, L.Cp, nullptr}, st));
             PROF("B.ln2" + tg, 0, 5.0 * M * L.C * 4,
                  ln_bwd(0, bt.x1, dxn, bw.ln2_g, nullptr, dy, dx1, G(h, bw.ln2_g), G(h, bw.ln2_b), tokens, tokens, tokens, M, L.C, L.Cp, lnpart, st, dx1s, inv, slots));
         }
         }
         // ---- attention: x1 = x0 + scatter(Wp attn(Wqkv gather(LN1(x0)))) ----
-        PROF("B.dw_proj" + tg, 2.0 * Ms * L.C * L.C, 0,
+        PROF("B.dw_proj" + tg, 2.0 * Ms * L.C * L.C, (double)Ms * (L.Cp + L.Ko) * 4,
              rc = dw_rows(h, dx1s, L.Cp, bt.obuf, L.Ko, Ms, L.Cp, L.Ko, G(h, bw.wproj), G(h, bw.bproj), part, st));
         if (rc) return rc;
-        PROF("B.dx_proj" + tg, 2.0 * Ms * L.C * L.C, 0, gemm_rows(dx1s, L.Cp, Ms, bw.wprojT, L.Ko, L.Cp, EpiStore{dobuf, L.Ko, nullptr}, st));
+        PROF("B.dx_proj" + tg, 2.0 * Ms * L.C * L.C, (double)Ms * (L.Cp + L.Ko) * 4, gemm_rows(dx1s, L.Cp, Ms, bw.wprojT, L.Ko, L.Cp, EpiStore{dobuf, L.Ko, nullptr}, st));
         int arc = 0;
-        PROF("B.attn_core" + tg, 10.0 * Ms * 16 * L.C, 0,
+        PROF("B.attn_core" + tg, 10.0 * Ms * 16 * L.C, (double)Ms * (2 * L.Nqkv + L.Ko) * 4,
              arc = attn_bwd(bt.qkv, bw.bias_tab, dobuf, dqkv, dbias, attpart, Ms / 16, L.nH, L.hdp, L.Nqkv, L.Ko, Hp / 4, Wp / 4, shift > 0,
                             1.0f / std::sqrt((float)L.hd), st));
         if (arc) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, arc == -2 ? "batch too large for the attention backward kernel's 32-bit offsets (head_dim %d)" : "head_dim %d unsupported by the attention backward kernel", L.hd);
         if (bw.tab_off >= 0)
             hipLaunchKernelGGL(bias_table_grad_kernel, dim3(blocks_for(49 * L.nH)), dim3(256), 0, st, dbias, gflat + bw.tab_off, L.nH);
-        PROF("B.dw_qkv" + tg, 2.0 * Ms * L.C * 3 * L.C, 0,
+        PROF("B.dw_qkv" + tg, 2.0 * Ms * L.C * 3 * L.C, (double)Ms * (L.Nqkv + L.Cp) * 4,
              rc = dw_rows(h, dqkv, L.Nqkv, bt.xn1, L.Cp, Ms, L.Nqkv, L.Cp, G(h, bw.wqkv), G(h, bw.bqkv), part, st));
         if (rc) return rc;
         if (ln_fused && L.Cp <= 96) {       // LN1's backward in the epilogue of the QKV dX GEMM: its rows are window slots, map = slot -> token
-            PROF("B.dx_qkv+ln1" + tg, 2.0 * Ms * L.C * 3 * L.C, 0,
+            PROF("B.dx_qkv+ln1" + tg, 2.0 * Ms * L.C * 3 * L.C, ((double)Ms * L.Nqkv + 3.0 * M * L.Cp) * 4,
                  gemm_ln_bwd_rows(dqkv, L.Nqkv, Ms, bw.wqkvT, L.Cp, L.Nqkv, bt.x0, bw.ln1_g, dx1, dprev, nullptr, nullptr, tokens, slots, L.C, G(h, bw.ln1_g),
                                   G(h, bw.ln1_b), part, st, map));
         } else {
-            PROF("B.dx_qkv" + tg, 2.0 * Ms * L.C * 3 * L.C, 0, gemm_rows(dqkv, L.Nqkv, Ms, bw.wqkvT, L.Cp, L.Nqkv, EpiStore{dxn, L.Cp, nullptr}, st));
+            PROF("B.dx_qkv" + tg, 2.0 * Ms * L.C * 3 * L.C, (double)Ms * (L.Nqkv + L.Cp) * 4, gemm_rows(dqkv, L.Nqkv, Ms, bw.wqkvT, L.Cp, L.Nqkv, EpiStore{dxn, L.Cp, nullptr}, st));
             PROF("B.ln1" + tg, 0, 4.0 * M * L.C * 4,
                  ln_bwd(1, bt.x0, dxn, bw.ln1_g, inv, dx1, dprev, G(h, bw.ln1_g), G(h, bw.ln1_b), tokens, tokens, slots, M, L.C, L.Cp, lnpart, st));
         }
