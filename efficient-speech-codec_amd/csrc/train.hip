@@ -108,22 +108,23 @@ int dw_launch(escx_handle_s* h, const LdA& la, const LdB& lb, int M, int Np, int
 }
 
 // the same through wide workgroup tiles (gemm_dw3_kernel, 2 x 2 waves of TA x TB accumulator tiles): operands staged once per workgroup
-template <int TA, int TB, class LdA, class LdB>
+template <int TA, int TB, int WN = 2, int WK = 2, class LdA, class LdB>
 int dw_launch_wide(escx_handle_s* h, const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
-    constexpr int WA = 32 * TA, WB = 32 * TB;
+    constexpr int WA = 16 * TA * WN, WB = 16 * TB * WK;
     const int nbn = (Np + WA - 1) / WA, nbk = (Kp + WB - 1) / WB, blocks = nbn * nbk;
     static const int env_target = [] { const char* e = getenv("ESCX_DW_WIDE_TARGET"); return e ? atoi(e) : 0; }();
     // ONE round of resident workgroups (2 per CU at 65-74 KB of LDS each): a partly filled extra round costs a whole slice time, and every further slice
     // another partial tile (up to 64 KB) written and read back (ESCX_DW_WIDE_TARGET sweep, 36 clips: 512 -> 79.6 ms/step, 768 -> 80.9, 2560 -> 80.4)
-    const int target = env_target > 0 ? env_target : 512;
+    constexpr int LDS_BYTES = 2 * 32 * ((WA % 32 == 0 ? WA + 16 : WA) + (WB % 32 == 0 ? WB + 16 : WB)) * 4;
+    const int target = env_target > 0 ? env_target : 256 * std::max(1, std::min(2, 163840 / LDS_BYTES));
     int slices = std::max(1, std::min(target / blocks, (M + 255) / 256));
     const size_t per = (size_t)Np * Kp + Np;
     slices = (int)std::max<size_t>(1, std::min<size_t>(slices, DW_PART_FLOATS / per));
     int mps = ((M + slices - 1) / slices + 31) / 32 * 32;
     slices = (M + mps - 1) / mps;
     float* bpart = part + (size_t)slices * Np * Kp;
-    if (db) hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, TA, TB, 2, 2, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
-    else hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, TA, TB, 2, 2, false>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+    if (db) hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, TA, TB, WN, WK, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+    else hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, TA, TB, WN, WK, false>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
     reduce_partials(part, slices, (long long)Np * Kp, dW, 0, st);
     if (db) reduce_partials(bpart, slices, (long long)Np, db, 0, st);
     return 0;
@@ -135,6 +136,14 @@ int dw_rows(escx_handle_s* h, const float* A, int lda, const float* Bm, int ldb,
     static const bool wide_ok = [] { const char* e = getenv("ESCX_DW_WIDE"); return !(e && e[0] == '0'); }();
     static const double pad_limit = [] { const char* e = getenv("ESCX_DW_WIDE_PAD"); return e ? atof(e) : 1.15; }();      // tile padding a wide tile may add
     const PlainA la{A, lda, M}, lb{Bm, ldb, M};
+    // the 144- and 80-wide maps (C = 144, 72) fit none of the 32-multiple tiles: one side of the workgroup tile IS the map width (9 or 5 accumulator tiles per
+    // wave, all four waves along the other side).  ESCX_DW_ODD=0: the 48 x 48 kernel as before.
+    static const bool odd_ok = [] { const char* e = getenv("ESCX_DW_ODD"); return !(e && e[0] == '0'); }();
+    if (wide_ok && odd_ok) {
+        if (Kp == 144 && Np >= 256) return dw_launch_wide<2, 9, 4, 1>(h, la, lb, M, Np, Kp, dW, db, part, st);         // 128 x 144
+        if (Np == 144 && Kp >= 256) return dw_launch_wide<9, 2, 1, 4>(h, la, lb, M, Np, Kp, dW, db, part, st);         // 144 x 128
+        if (Kp == 80 && Np > 192 && Np <= 256) return dw_launch_wide<4, 5, 4, 1>(h, la, lb, M, Np, Kp, dW, db, part, st);      // 256 x 80: the whole QKV gradient of C = 72
+    }
     int bestA = 0, bestB = 0; double best = 1e30;
     if (wide_ok && Np >= 96 && Kp >= 96 && (long long)Np * Kp >= 96 * 288) {
         const int cand[3] = {128, 96, 64};

@@ -406,10 +406,9 @@ template <class LdA, class LdB, int TA, int TB, int WN, int WK, bool BIAS>
 __global__ __launch_bounds__(256) void gemm_dw3_kernel(LdA la, LdB lb, int M, int Np, int Kp, int nblk_k, int m_per_slice,
                                                        float* __restrict__ part, float* __restrict__ bpart) {
     static_assert(WN * WK == 4, "four waves");
-    constexpr int WA = 16 * TA * WN, WB = 16 * TB * WK;          // workgroup tile
-    static_assert(WA % 32 == 0 && WB % 32 == 0, "8 threads x float4 per row");
-    constexpr int LDA = WA + 16, LDB = WB + 16;                  // % 32 == 16: the 4 rows of an MFMA operand read hit different bank groups
-    constexpr int NA = WA / 32, NB = WB / 32;
+    constexpr int WA = 16 * TA * WN, WB = 16 * TB * WK;          // workgroup tile (sides are multiples of 16: 144 and 80 for the C = 144 / 72 maps)
+    constexpr int LDA = WA % 32 == 0 ? WA + 16 : WA, LDB = WB % 32 == 0 ? WB + 16 : WB;      // % 32 == 16: the 4 rows of an MFMA operand read hit different bank groups
+    constexpr int NA = (WA + 31) / 32, NB = (WB + 31) / 32;      // float4 per thread per row (8 threads per row; the last one partly masked when the side is not a multiple of 32)
     __shared__ float lds[2 * DW_MC * (LDA + LDB)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -430,9 +429,9 @@ __global__ __launch_bounds__(256) void gemm_dw3_kernel(LdA la, LdB lb, int M, in
         typename LdA::Ctx ca = la.make_ctx(m < mend ? m : M);
         typename LdB::Ctx cb = lb.make_ctx(m < mend ? m : M);
 #pragma unroll
-        for (int j = 0; j < NA; ++j) { const int col = 4 * (fc + 8 * j); ra[j] = (n0 + col < Np) ? la.load4(ca, n0 + (col & ~15), col & 15) : zero4(); }
+        for (int j = 0; j < NA; ++j) { const int col = 4 * (fc + 8 * j); ra[j] = (col < WA && n0 + col < Np) ? la.load4(ca, n0 + (col & ~15), col & 15) : zero4(); }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { const int col = 4 * (fc + 8 * j); rb[j] = (k0 + col < Kp) ? lb.load4(cb, k0 + (col & ~15), col & 15) : zero4(); }
+        for (int j = 0; j < NB; ++j) { const int col = 4 * (fc + 8 * j); rb[j] = (col < WB && k0 + col < Kp) ? lb.load4(cb, k0 + (col & ~15), col & 15) : zero4(); }
     };
     if (mbeg < mend) fetch(mbeg);
     int buf = 0;
@@ -440,9 +439,9 @@ __global__ __launch_bounds__(256) void gemm_dw3_kernel(LdA la, LdB lb, int M, in
         float* As = lds + buf * (DW_MC * (LDA + LDB));
         float* Bs = As + DW_MC * LDA;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) st4(As + frow * LDA + 4 * (fc + 8 * j), ra[j]);
+        for (int j = 0; j < NA; ++j) if (WA % 32 == 0 || 4 * (fc + 8 * j) < WA) st4(As + frow * LDA + 4 * (fc + 8 * j), ra[j]);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) st4(Bs + frow * LDB + 4 * (fc + 8 * j), rb[j]);
+        for (int j = 0; j < NB; ++j) if (WB % 32 == 0 || 4 * (fc + 8 * j) < WB) st4(Bs + frow * LDB + 4 * (fc + 8 * j), rb[j]);
         __syncthreads();                                         // one barrier per chunk: the other buffer was last read before the previous barrier
         if (m0 + DW_MC < mend) fetch(m0 + DW_MC);
         const float* Aw = As + wn * 16 * TA; const float* Bw = Bs + wk * 16 * TB;
