@@ -196,8 +196,10 @@ void gemm_ln_bwd_rows(const float* A, int lda, int M, const float* Wt, int Cp, i
     EpiLnBwdRows ep{x, gamma, add, dx, dx_slots, slot_of, part, C, Cp, rows_per_clip, slots_per_clip, 1e-5f, row_map};
     const bool big = (long long)((M + 127) / 128) >= 512;
     const int rows = (big ? (M + 127) / 128 : (M + 63) / 64) * 4;
-    if (big) launch_gemm<128>(PlainA{A, lda, M}, Wt, M, Cp, Kp, ep, st, 1, 16);
-    else launch_gemm<64>(PlainA{A, lda, M}, Wt, M, Cp, Kp, ep, st, 1, 16);
+    static const int env_bk = [] { const char* e = getenv("ESCX_LNBWD_BK"); return e ? atoi(e) : 16; }();
+    const int bk = (env_bk > 0 && Kp % env_bk == 0) ? env_bk : 16;
+    if (big) launch_gemm<128>(PlainA{A, lda, M}, Wt, M, Cp, Kp, ep, st, 1, bk);
+    else launch_gemm<64>(PlainA{A, lda, M}, Wt, M, Cp, Kp, ep, st, 1, bk);
     float* red = part + (size_t)rows * 2 * Cp;
     launch_reduce_partials(part, rows, (long long)2 * Cp, red, 0, st, red + 2 * Cp);
     (void)hipMemcpyAsync(dg, red, (size_t)Cp * sizeof(float), hipMemcpyDeviceToDevice, st);
