@@ -628,9 +628,22 @@ extern "C" int escx_gan_term(const float* x, const float* ref, float* grad, int 
     const int bpc = (int)std::min<long long>(64, (per + 255) / 256);
     float* part = stream_scratch(st, 0, (size_t)B * bpc);
     if (!part) ESCX_FAIL(ESCX_ERR_HIP, "scratch allocation failed");
-    hipLaunchKernelGGL(gan_term_kernel, dim3(bpc, B), dim3(256), 0, st, xv, rv, gvw, part, mode, target, C, bpc, 1.0f / ((float)C * D0 * D1));
+    hipLaunchKernelGGL(gan_term_kernel, dim3(bpc, B), dim3(256), 0, st, xv, rv, gvw, part, mode, target, C, bpc, 1.0f / ((float)C * D0 * D1), (const float*)nullptr);
     hipLaunchKernelGGL(row_sum_kernel, dim3(blk(B, 64)), dim3(64), 0, st, part, bpc, loss_dev, B, accumulate, 1.0f);
     return launch_ok("gan_term");
+}
+
+// Backward of escx_gan_term with the upstream gradient folded in: grad (layout of x) = g[b] * d term_b / d x, nothing else read or written.
+// The forward then keeps no gradient buffer: the term is re-evaluated here (x and ref are still there), one pass instead of store + scale.
+extern "C" int escx_gan_term_grad(const float* x, const float* ref, const float* g, float* grad, int B, int C, int Cp, int D0, int D1, int P1, int mode, float target,
+                                  void* stream) {
+    if (!x || !g || !grad || B < 1 || (mode == 1 && !ref) || mode < 0 || mode > 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    TView xv{const_cast<float*>(x), D0, D1, P1, Cp}, rv{const_cast<float*>(ref), D0, D1, P1, Cp}, gvw{grad, D0, D1, P1, Cp};
+    const long long per = (long long)D0 * D1 * Cp;
+    const int bpc = (int)std::min<long long>(64, (per + 255) / 256);
+    hipLaunchKernelGGL(gan_term_kernel, dim3(bpc, B), dim3(256), 0, st, xv, rv, gvw, (float*)nullptr, mode, target, C, bpc, 1.0f / ((float)C * D0 * D1), g);
+    return launch_ok("gan_term_grad");
 }
 
 extern "C" int escx_disc_profile_enable(int enable) {

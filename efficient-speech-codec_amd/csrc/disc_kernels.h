@@ -322,10 +322,11 @@ __global__ void view_copy_kernel(TView dst, TView src, long long n4) {
 // part[b][block]; gradient written to a view shaped like x (pad channels zero).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gan_term_kernel(TView x, TView ref, TView grad, float* __restrict__ part, int mode, float target, int C,
-                                                       int blocks_per_clip, float inv_n) {
+                                                       int blocks_per_clip, float inv_n, const float* __restrict__ gscale) {
     const int b = blockIdx.y;
     __shared__ float red[256];
     const long long per = (long long)x.D0 * x.D1 * x.Cp;
+    const float gs = gscale ? gscale[b] * inv_n : inv_n;         // d (g_b * term_b) / d x: the upstream per-clip gradient folded in (backward-only launches)
     float acc = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long long)blocks_per_clip * 256) {
         const int c = (int)(i % x.Cp); long long r = i / x.Cp; const int i1 = (int)(r % x.D1); const int i0 = (int)(r / x.D1);
@@ -333,11 +334,12 @@ __global__ __launch_bounds__(256) void gan_term_kernel(TView x, TView ref, TView
         float gv = 0.f;
         if (c < C) {
             const float xv = x.p[ox];
-            if (mode == 0) { const float d = target - xv; acc += d * d; gv = -2.f * d * inv_n; }
-            else { const float d = xv - ref.p[(((size_t)b * ref.D0 + i0) * ref.P1 + i1) * ref.Cp + c]; acc += fabsf(d); gv = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv_n; }
+            if (mode == 0) { const float d = target - xv; acc += d * d; gv = -2.f * d * gs; }
+            else { const float d = xv - ref.p[(((size_t)b * ref.D0 + i0) * ref.P1 + i1) * ref.Cp + c]; acc += fabsf(d); gv = (d > 0.f ? gs : (d < 0.f ? -gs : 0.f)); }
         }
         if (grad.p) grad.p[(((size_t)b * grad.D0 + i0) * grad.P1 + i1) * grad.Cp + c] = gv;
     }
+    if (!part) return;
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }

@@ -111,26 +111,58 @@ class MelSpectrogramLoss(nn.Module):
 
 
 class _GanTermFn(torch.autograd.Function):
-    """One per-clip loss term over a channels-last feature-map buffer (escx_gan_term): mode 0 = mean (target - x)^2, mode 1 = mean |x - ref|."""
+    """Per-clip loss over the feature maps that live in ONE channels-last buffer (escx_gan_term): mode 0 = mean (target - x)^2, mode 1 = mean |x - ref|,
+    summed over the buffer's maps (`metas`: one (C, Cp, D0, D1, P1, off1) per map; a concatenated buffer holds several column slices).
+    The forward stores no gradient: the backward re-evaluates each term with the upstream per-clip gradient folded in (escx_gan_term_grad), so a
+    buffer's gradient is written once, in one pass, and never zero-filled, scaled or added afterwards (the maps of a buffer tile it completely)."""
 
     @staticmethod
-    def forward(ctx, buf, ref, meta, mode, target):
-        C, Cp, D0, D1, P1, off1 = meta
+    def forward(ctx, buf, ref, metas, mode, target, lo=0, n=None):
+        """Clips [lo, lo + n) of `buf` (default: all); `ref` already holds just those clips.  Taking the clip range here instead of a sliced tensor keeps
+        autograd from materialising a zero-filled full-size gradient per slice (a pass over [reconstruction | real] hands out its first half)."""
         lib = _native.load()
-        B = buf.shape[0]
-        loss = torch.empty(B, dtype=torch.float32, device=buf.device)
-        need = ctx.needs_input_grad[0]
-        unit = torch.zeros_like(buf) if need else None          # zeros: a slice of a concatenated buffer only covers its own columns
-        off = 4 * off1 * Cp
-        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr() + off)
+        n = buf.shape[0] - lo if n is None else n
+        loss = torch.empty(n, dtype=torch.float32, device=buf.device)
+        base = lo * buf.stride(0) * 4
         with torch.cuda.device(buf.device):
-            _native.check(lib.escx_gan_term(p(buf), p(ref), p(unit), B, C, Cp, D0, D1, P1, int(mode), float(target), _ptr(loss), 0, _stream(buf.device)))
-        ctx.unit = unit
+            for k, (C, Cp, D0, D1, P1, off1) in enumerate(metas):
+                off = 4 * off1 * Cp
+                _native.check(lib.escx_gan_term(ctypes.c_void_p(buf.data_ptr() + base + off), None if ref is None else ctypes.c_void_p(ref.data_ptr() + off), None,
+                                                n, C, Cp, D0, D1, P1, int(mode), float(target), _ptr(loss), int(k > 0), _stream(buf.device)))
+        ctx.save_for_backward(buf, ref)
+        ctx.metas, ctx.mode, ctx.target, ctx.lo, ctx.n = metas, int(mode), float(target), lo, n
+        ctx.tiles = all(m[4] == metas[0][4] for m in metas) and sum(m[3] for m in metas) == metas[0][4]      # the slices cover every column of the buffer
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        return (_scale_rows(ctx.unit, g) if ctx.unit is not None else None), None, None, None, None
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 7
+        buf, ref = ctx.saved_tensors
+        lib = _native.load()
+        lo, n = ctx.lo, ctx.n
+        g = g.to(torch.float32).contiguous()
+        if ctx.tiles:
+            grad = torch.empty_like(buf, memory_format=torch.contiguous_format)
+            grad[:lo].zero_()
+            grad[lo + n:].zero_()
+        else:
+            grad = torch.zeros_like(buf, memory_format=torch.contiguous_format)
+        base = lo * grad.stride(0) * 4
+        with torch.cuda.device(buf.device):
+            for C, Cp, D0, D1, P1, off1 in ctx.metas:
+                off = 4 * off1 * Cp
+                _native.check(lib.escx_gan_term_grad(ctypes.c_void_p(buf.data_ptr() + lo * buf.stride(0) * 4 + off), None if ref is None else ctypes.c_void_p(ref.data_ptr() + off),
+                                                     _ptr(g), ctypes.c_void_p(grad.data_ptr() + base + off), n, C, Cp, D0, D1, P1, ctx.mode, ctx.target, _stream(buf.device)))
+        return (grad,) + (None,) * 6
+
+
+def _by_buffer(entries):
+    """[(buffer, [meta, ...])] of feature-map entries (buffer, C, Cp, D0, D1, P1, off1), grouped by buffer in first-seen order."""
+    groups = {}
+    for buf, *meta in entries:
+        groups.setdefault(buf.data_ptr(), (buf, []))[1].append(tuple(meta))
+    return list(groups.values())
 
 
 class GANLoss(nn.Module):
@@ -153,7 +185,7 @@ class GANLoss(nn.Module):
         for xf, xr in zip(d_fake, d_real):
             bf, *mf = xf.entries[-1]
             br, *mr = xr.entries[-1]
-            loss = loss + _GanTermFn.apply(bf, None, tuple(mf), 0, 0.0) + _GanTermFn.apply(br, None, tuple(mr), 0, 1.0)
+            loss = loss + _GanTermFn.apply(bf, None, (tuple(mf),), 0, 0.0) + _GanTermFn.apply(br, None, (tuple(mr),), 0, 1.0)
         return loss
 
     def generator_loss(self, fake, real):
@@ -161,9 +193,9 @@ class GANLoss(nn.Module):
         loss_g, loss_f = 0, 0
         for xf, xr in zip(d_fake, d_real):
             bf, *mf = xf.entries[-1]
-            loss_g = loss_g + _GanTermFn.apply(bf, None, tuple(mf), 0, 1.0)
-            for (ba, *ma), (bb, *mb) in zip(xf.entries[:-1], xr.entries[:-1]):
-                loss_f = loss_f + _GanTermFn.apply(ba, bb.detach(), tuple(ma), 1, 0.0)
+            loss_g = loss_g + _GanTermFn.apply(bf, None, (tuple(mf),), 0, 1.0)
+            for (ba, metas), (bb, _) in zip(_by_buffer(xf.entries[:-1]), _by_buffer(xr.entries[:-1])):
+                loss_f = loss_f + _GanTermFn.apply(ba, bb.detach(), tuple(metas), 1, 0.0)
         return loss_g, loss_f
 
     # ---- one discriminator forward per signal and step (not in the reference, which runs them twice; the values are identical) --------
@@ -190,11 +222,20 @@ class GANLoss(nn.Module):
     def generator_loss_from(self, d_fake, d_real):
         """gan_loss.py:39-51 on feature maps that are already there."""
         loss_g, loss_f = 0, 0
+        whole = getattr(d_fake, "whole", None)
+        if whole is not None:                   # clips [lo, hi) of a larger pass: hand the terms the pass's own buffers and the clip range
+            lo, n = d_fake.lo, d_fake.hi - d_fake.lo
+            for xw, xr in zip(whole, d_real):
+                bf, *mf = xw.entries[-1]
+                loss_g = loss_g + _GanTermFn.apply(bf, None, (tuple(mf),), 0, 1.0, lo, n)
+                for (ba, metas), (bb, _) in zip(_by_buffer(xw.entries[:-1]), _by_buffer(xr.entries[:-1])):
+                    loss_f = loss_f + _GanTermFn.apply(ba, bb.detach(), tuple(metas), 1, 0.0, lo, n)
+            return loss_g, loss_f
         for xf, xr in zip(d_fake, d_real):
             bf, *mf = xf.entries[-1]
-            loss_g = loss_g + _GanTermFn.apply(bf, None, tuple(mf), 0, 1.0)
-            for (ba, *ma), (bb, *mb) in zip(xf.entries[:-1], xr.entries[:-1]):
-                loss_f = loss_f + _GanTermFn.apply(ba, bb.detach(), tuple(ma), 1, 0.0)
+            loss_g = loss_g + _GanTermFn.apply(bf, None, (tuple(mf),), 0, 1.0)
+            for (ba, metas), (bb, _) in zip(_by_buffer(xf.entries[:-1]), _by_buffer(xr.entries[:-1])):
+                loss_f = loss_f + _GanTermFn.apply(ba, bb.detach(), tuple(metas), 1, 0.0)
         return loss_g, loss_f
 
     @torch.no_grad()
@@ -213,15 +254,17 @@ class GANLoss(nn.Module):
                 buf, C, Cp, D0, D1, P1, off1 = sub.entries[-1]
                 buf = buf.detach()
                 term = torch.empty(2 * B, dtype=torch.float32, device=buf.device)
-                unit = torch.zeros_like(buf)
+                grad = torch.empty_like(buf)                     # the last map of a sub-discriminator is a buffer of its own
                 with torch.cuda.device(buf.device):
                     for lo, target in ((0, 0.0), (B, 1.0)):
-                        _native.check(lib.escx_gan_term(_ptr(buf[lo:lo + B]), None, _ptr(unit[lo:lo + B]), B, C, Cp, D0, D1, P1, 0, float(target), _ptr(term[lo:lo + B]), 0,
+                        _native.check(lib.escx_gan_term(_ptr(buf[lo:lo + B]), None, None, B, C, Cp, D0, D1, P1, 0, float(target), _ptr(term[lo:lo + B]), 0,
                                                         _stream(buf.device)))
+                        _native.check(lib.escx_gan_term_grad(_ptr(buf[lo:lo + B]), None, _ptr(scale[lo:lo + B]), _ptr(grad[lo:lo + B]), B, C, Cp, D0, D1, P1, 0, float(target),
+                                                             _stream(buf.device)))
                 t = term[:B] + term[B:]
                 loss = t if loss is None else loss + t
                 bi = next(i for i, b in enumerate(whole.bufs) if b.data_ptr() == buf.data_ptr())
-                dbufs[bi] = _scale_rows(unit, scale)
+                dbufs[bi] = grad
             self.discriminator.accumulate_param_grads(whole, dbufs)
             return loss
         loss = None
@@ -233,11 +276,12 @@ class GANLoss(nn.Module):
                 buf, C, Cp, D0, D1, P1, off1 = sub.entries[-1]
                 buf = buf.detach()
                 term = torch.empty(B, dtype=torch.float32, device=buf.device)
-                unit = torch.zeros_like(buf)
+                grad = torch.empty_like(buf)
                 with torch.cuda.device(buf.device):
-                    _native.check(lib.escx_gan_term(_ptr(buf), None, _ptr(unit), B, C, Cp, D0, D1, P1, 0, float(target), _ptr(term), 0, _stream(buf.device)))
+                    _native.check(lib.escx_gan_term(_ptr(buf), None, None, B, C, Cp, D0, D1, P1, 0, float(target), _ptr(term), 0, _stream(buf.device)))
+                    _native.check(lib.escx_gan_term_grad(_ptr(buf), None, _ptr(scale), _ptr(grad), B, C, Cp, D0, D1, P1, 0, float(target), _stream(buf.device)))
                 loss = term if loss is None else loss + term
                 bi = next(i for i, b in enumerate(out.bufs) if b.data_ptr() == buf.data_ptr())
-                dbufs[bi] = _scale_rows(unit, scale)
+                dbufs[bi] = grad
             self.discriminator.accumulate_param_grads(out, dbufs)
         return loss

@@ -237,6 +237,10 @@ int escx_disc_backward(escx_disc d, const float* flat_params_dev, int64_t params
  * (target - x)^2 (mode 0) or |x - ref| (mode 1); grad_dev (optional, layout of x) receives d term_b / d x. */
 int escx_gan_term(const float* x_dev, const float* ref_dev, float* grad_dev, int batch, int C, int Cp, int D0, int D1, int P1, int mode, float target,
                   float* loss_dev, int accumulate, void* stream);
+/* Backward of escx_gan_term with the upstream per-clip gradient folded in (what autograd does with `loss.mean().backward()` in trainer_adv.py:77-105):
+ * grad_dev (layout of x) = g_dev[b] * d term_b / d x.  The forward keeps no per-map gradient buffer; x (and ref) are re-read here. */
+int escx_gan_term_grad(const float* x_dev, const float* ref_dev, const float* g_dev, float* grad_dev, int batch, int C, int Cp, int D0, int D1, int P1, int mode,
+                       float target, void* stream);
 /* Per-layer timing of the discriminator's convolutions (diagnostic: HIP events and a stream sync around every launch group while enabled, so the step
  * itself runs slower).  escx_disc_profile_enable(1) clears and starts, (0) stops; the report is a JSON array of {"name": "D.<fwd|dX|dW>[<layer>]",
  * "calls", "ms", "flops"} - the same record format as escx_profile_report.  Process-wide (not per handle). */
