@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/round; rm -rf $O; mkdir -p $O
 cd $R
-timeout 1200 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
+timeout 2700 python -m pytest tests -x -q -m gpu --durations=8 > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
 timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench.err | tail -1 > $O/bench.json; cut -c1-400 $O/bench.json
 ESCX_BENCH_BREAKDOWN=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep "^#" > $O/event_breakdown_isolated.txt
 ESCX_STREAMS=1 ESCX_BENCH_BREAKDOWN=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep "^#" > $O/event_breakdown_1stream.txt
