@@ -55,6 +55,7 @@ struct escx_disc_s {
     float* wbuf = nullptr; size_t wfloats = 0;
     float* scratch = nullptr; size_t scratch_bytes = 0;
     const float* packed_ptr = nullptr; long long packed_version = -1;      // which (buffer, version) the packed weights were derived from
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};    // extra streams: the sub-discriminators are independent of each other
 };
 
 namespace {
@@ -165,6 +166,38 @@ int pack_weights(escx_disc_s* d, const float* flat, long long params_version, hi
             hipLaunchKernelGGL(wn_pack_kernel, dim3(c.Cout), dim3(256), 0, st, flat + c.off_v, flat + c.off_g, flat + c.off_b, c.Wf, c.Wt, c.bias, c.scale,
                                c.Cout, c.Cin, c.T0 * c.T1, c.CinP, c.CoutP, c.Kf, c.Kt, c.Wp, c.T0, c.T1, c.s0, c.s1, c.p0, c.p1, c.CinR);
     return launch_ok("disc_pack_weights");
+}
+
+// Multi-stream schedule over the sub-discriminators (they share nothing but the input): the launches of one sub-discriminator fill the dispatch tails and the
+// small-grid layers of another.  ESCX_DISC_STREAMS = n (1..4, default 2; 1 = everything on the caller's stream, also while the per-layer profile is on: its
+// events bracket single launches).  Sub-discriminator si runs on stream ESCX_DISC_STREAM_MAP[si] (a digit string, default si mod n); stream 0 is the caller's.
+int disc_streams() {
+    static const int n = [] { const char* e = getenv("ESCX_DISC_STREAMS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    return DTrace::on() ? 1 : n;
+}
+int disc_stream_of(int si, int n) {
+    static const std::string map = [] { const char* e = getenv("ESCX_DISC_STREAM_MAP"); return std::string(e ? e : ""); }();
+    const int q = si < (int)map.size() && map[si] >= '0' && map[si] <= '3' ? map[si] - '0' : si % n;
+    return q < n ? q : si % n;
+}
+int disc_fork(escx_disc_s* d, hipStream_t st, int n) {
+    if (!d->ev_fork) ESCX_HIP(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
+    ESCX_HIP(hipEventRecord(d->ev_fork, st));
+    for (int i = 0; i + 1 < n; ++i) {
+        if (!d->aux[i]) {
+            ESCX_HIP(hipStreamCreateWithFlags(&d->aux[i], hipStreamNonBlocking));
+            ESCX_HIP(hipEventCreateWithFlags(&d->ev_join[i], hipEventDisableTiming));
+        }
+        ESCX_HIP(hipStreamWaitEvent(d->aux[i], d->ev_fork, 0));
+    }
+    return 0;
+}
+int disc_join(escx_disc_s* d, hipStream_t st, int n) {
+    for (int i = 0; i + 1 < n; ++i) {
+        ESCX_HIP(hipEventRecord(d->ev_join[i], d->aux[i]));
+        ESCX_HIP(hipStreamWaitEvent(st, d->ev_join[i], 0));
+    }
+    return 0;
 }
 
 int ensure_scratch(escx_disc_s* d, size_t bytes) {
@@ -322,6 +355,11 @@ extern "C" void escx_disc_destroy(escx_disc d) {
     (void)hipSetDevice(d->device);
     if (d->wbuf) (void)hipFree(d->wbuf);
     if (d->scratch) (void)hipFree(d->scratch);
+    for (int i = 0; i < 3; ++i) {
+        if (d->aux[i]) { (void)hipStreamSynchronize(d->aux[i]); (void)hipStreamDestroy(d->aux[i]); }
+        if (d->ev_join[i]) (void)hipEventDestroy(d->ev_join[i]);
+    }
+    if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
     delete d;
 }
 
@@ -405,10 +443,14 @@ extern "C" int escx_disc_forward(escx_disc d, const float* flat_params, int64_t 
     if ((rc = pack_weights(d, flat_params, (long long)params_version, st))) return rc;
     std::vector<std::vector<float*>> ins; std::vector<float*> specs; float *y, *stats;
     build_front(d, wave, B, L, d->scratch, &ins, &specs, &y, &stats, st);
+    const int nq = disc_streams();
+    if (nq > 1 && (rc = disc_fork(d, st, nq))) return rc;
+    const hipStream_t st0 = st;
     int fi = 0;
     for (size_t si = 0; si < d->subs.size(); ++si) {
         const DSub& S = d->subs[si];
         const SubGeom g = geometry(S, L);
+        { const int q = disc_stream_of((int)si, nq); st = q ? d->aux[q - 1] : st0; }
         if (S.kind == 0) {
             TView x{ins[si][0], g.D0, g.D1, g.D1, 4};
             for (size_t j = 0; j < S.convs.size(); ++j, ++fi) {
@@ -434,6 +476,8 @@ extern "C" int escx_disc_forward(escx_disc d, const float* flat_params, int64_t 
             ++fi;
         }
     }
+    st = st0;
+    if (nq > 1 && (rc = disc_join(d, st, nq))) return rc;
     return launch_ok("disc_forward");
 }
 
@@ -463,7 +507,8 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
             else { for (int f : g.bandF) in_g = std::max(in_g, (size_t)B * g.T * f * 4); in_g = std::max(in_g, (size_t)B * g.T * std::max(2 * S.Fq, S.arg)); }
         }
     }
-    const size_t total = front + gfl + 3 * pad64(in_g) + pad64(max_w) + pad64(DISC_DW_PART) + pad64((size_t)B * L) + 4096;
+    const int nq = disc_streams();                              // per-stream copies of the per-layer scratch
+    const size_t total = front + gfl + nq * (3 * pad64(in_g) + pad64(max_w) + pad64(DISC_DW_PART) + pad64((size_t)B * L)) + 4096;
     int rc = ensure_scratch(d, total * sizeof(float)); if (rc) return rc;
     if ((rc = pack_weights(d, flat_params, (long long)params_version, st))) return rc;
     std::vector<std::vector<float*>> ins; std::vector<float*> specs; float *y, *stats;
@@ -513,10 +558,16 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
             hipLaunchKernelGGL(view_copy_kernel, dim3(blk((long long)B * f.D0 * f.D1 * f.Cp / 4)), dim3(256), 0, st, gv[i], src, (long long)B * f.D0 * f.D1 * f.Cp / 4);
         }
     }
-    float* gin = take(in_g); float* gspec = take(in_g); float* gfr = take(in_g);
-    float* dWs = take(max_w); float* part = take(DISC_DW_PART); float* dy = take((size_t)B * L);
+    float *gin_q[4], *gspec_q[4], *gfr_q[4], *dWs_q[4], *part_q[4], *dy_q[4];
+    for (int q = 0; q < nq; ++q) {
+        gin_q[q] = take(in_g); gspec_q[q] = take(in_g); gfr_q[q] = take(in_g);
+        dWs_q[q] = take(max_w); part_q[q] = take(DISC_DW_PART); dy_q[q] = take((size_t)B * L);
+    }
     if (grad_flat) ESCX_HIP(hipMemsetAsync(grad_flat, 0, d->total * sizeof(float), st));
-    if (d_wave) ESCX_HIP(hipMemsetAsync(dy, 0, (size_t)B * L * sizeof(float), st));
+    if (d_wave) for (int q = 0; q < nq; ++q) ESCX_HIP(hipMemsetAsync(dy_q[q], 0, (size_t)B * L * sizeof(float), st));
+    if (nq > 1 && (rc = disc_fork(d, st, nq))) return rc;
+    const hipStream_t st0 = st;
+    float *gin = gin_q[0], *gspec = gspec_q[0], *gfr = gfr_q[0], *dWs = dWs_q[0], *part = part_q[0], *dy = dy_q[0];      // re-pointed per sub-discriminator
 
     // g: gradient of the layer's output map (g_pre: already the pre-activation gradient).  gx: gradient view of its input map; fin = 1 writes it
     // finally as (init + dX) * LeakyReLU'(xact) (see GradOut).  gx_plain: dense gradient of a network input (no loss gradient, no activation).
@@ -570,6 +621,9 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
         const SubGeom g = geometry(S, L);
         const int nconv = (int)S.convs.size();
         const int f0 = fi_end - nconv;
+        const int q = disc_stream_of(si, nq);
+        st = q ? d->aux[q - 1] : st0;
+        gin = gin_q[q]; gspec = gspec_q[q]; gfr = gfr_q[q]; dWs = dWs_q[q]; part = part_q[q]; dy = dy_q[q];
         if (S.kind == 0) {
             for (int j = nconv - 1; j >= 0; --j) {
                 const int fi = f0 + j;
@@ -612,6 +666,12 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
             }
         }
         fi_end = f0;
+    }
+    st = st0; dy = dy_q[0];
+    if (nq > 1) {
+        if ((rc = disc_join(d, st, nq))) return rc;
+        // the waveform gradients of the streams' sub-discriminators, added in a fixed order
+        if (d_wave) for (int q = 1; q < nq; ++q) hipLaunchKernelGGL(add_into_kernel, dim3(blk((long long)B * L)), dim3(256), 0, st, dy, dy_q[q], (long long)B * L);
     }
     if (d_wave) hipLaunchKernelGGL(disc_preprocess_bwd_kernel, dim3(B), dim3(1024), 0, st, dy, y, stats, d_wave, L);
     return launch_ok("disc_backward");

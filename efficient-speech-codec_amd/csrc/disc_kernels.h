@@ -303,6 +303,10 @@ __global__ void leaky_bwd_kernel(TView dy, TView y, long long n4, int B) {
     for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.1f * g[e];
     st4(dy.p + od, g);
 }
+__global__ void add_into_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
 // dst view <- src view (or zero when src.p == nullptr)
 __global__ void view_copy_kernel(TView dst, TView src, long long n4) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
