@@ -41,16 +41,41 @@ struct TrainTape {
     size_t fwd_mark = 0;
 };
 
+// Everything a training pass keeps between forward and backward.  Clips are independent in the training step too (per-clip losses, no batch statistics), so a
+// large batch runs as TWO parts on two streams, like the inference path's run_halves: each part has its own tape arena, packed-gradient arena and flat
+// gradient buffer; the parts' flat gradients are added in a fixed order after the join.  One part's launches fill the dispatch tails and small grids of the other.
+struct TrainRoot {
+    TrainTape single;                        // the one-part form (small batches, profiling, ESCX_TRAIN_PARTS=1)
+    TrainTape part[2];
+    TrainTape* cur = &single;
+    escx::Arena arena[2];                    // tapes of the two parts (the handle's own arena serves the one-part form)
+    float* garena[2] = {nullptr, nullptr};   // [0] unused (part 0 writes the handle's)
+    float* gflat1 = nullptr;                 // part 1's flat gradient
+    hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int parts = 1, B0 = 0;                   // of the last forward
+    bool valid = false;
+    long long generation = 0;
+};
+
 }  // namespace
 void escx::free_train_state(escx_handle_s* h) {
-    delete static_cast<TrainTape*>(h->train_state);
+    TrainRoot* r = static_cast<TrainRoot*>(h->train_state);
+    if (r) {
+        for (int p = 0; p < 2; ++p) { if (r->arena[p].base) (void)hipFree(r->arena[p].base); if (r->garena[p]) (void)hipFree(r->garena[p]); }
+        if (r->gflat1) (void)hipFree(r->gflat1);
+        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamDestroy(r->aux); }
+        if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
+        if (r->ev_join) (void)hipEventDestroy(r->ev_join);
+    }
+    delete r;
     h->train_state = nullptr;
 }
 namespace {
-TrainTape* tape_of(escx_handle_s* h) {
-    if (!h->train_state) h->train_state = new TrainTape();
-    return static_cast<TrainTape*>(h->train_state);
+TrainRoot* root_of(escx_handle_s* h) {
+    if (!h->train_state) h->train_state = new TrainRoot();
+    return static_cast<TrainRoot*>(h->train_state);
 }
+TrainTape* tape_of(escx_handle_s* h) { return root_of(h)->cur; }
 
 inline unsigned blocks_for(long long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
 
@@ -483,20 +508,20 @@ extern "C" int escx_load_flat_params(escx_handle h, const float* flat_dev, int f
     return rc;
 }
 
-extern "C" int64_t escx_train_tape_bytes(escx_handle h) { return h ? (int64_t)h->tape.cap : 0; }
-extern "C" int64_t escx_train_tape_generation(escx_handle h) { return (h && h->train_state) ? (int64_t)static_cast<TrainTape*>(h->train_state)->generation : 0; }
+extern "C" int64_t escx_train_tape_bytes(escx_handle h) {
+    if (!h) return 0;
+    const TrainRoot* r = static_cast<TrainRoot*>(h->train_state);
+    if (r && r->parts == 2) return (int64_t)(r->arena[0].cap + r->arena[1].cap);
+    return (int64_t)h->tape.cap;
+}
+extern "C" int64_t escx_train_tape_generation(escx_handle h) { return (h && h->train_state) ? (int64_t)static_cast<TrainRoot*>(h->train_state)->generation : 0; }
 
-extern "C" int escx_train_forward(escx_handle h, const float* flat_dev, const float* wave, int B, int L, int S, int freeze, int64_t* codes_out,
-                                  float* wave_out, float* raw_feat, float* recon_feat, float* cm_loss, float* cb_loss, void* stream) {
-    int rc = check_ready(h); if (rc) return rc;
-    if (!wave || !codes_out || !wave_out) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
+namespace {
+// one pass over B clips on stream st, tape = tape_of(h) in the arena h->tape (the caller points both at the part it wants)
+int train_forward_impl(escx_handle_s* h, const float* wave, int B, int L, int S, int freeze, int64_t* codes_out, float* wave_out, float* raw_feat,
+                       float* recon_feat, float* cm_loss, float* cb_loss, hipStream_t st) {
+    int rc = 0;
     const escx_config& c = h->cfg;
-    if (B < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "batch must be positive");
-    if (S < 1 || S > c.max_streams) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "num_streams=%d outside [1, %d]", S, c.max_streams);
-    if (L <= h->n_fft / 2) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_samples=%d too short for reflect padding of %d", L, h->n_fft / 2);
-    hipStream_t st = (hipStream_t)stream;
-    if (flat_dev && (rc = refresh_from_flat(h, flat_dev, st))) return rc;
-    if ((rc = build_gather_map(h))) return rc;
     TrainTape& T = *tape_of(h);
     T.valid = false;
     ++T.generation;
@@ -588,6 +613,65 @@ extern "C" int escx_train_forward(escx_handle h, const float* flat_dev, const fl
     T.fwd_mark = tp.used;
     T.valid = true;
     return launch_ok("train_forward");
+}
+
+int train_parts_for(escx_handle_s* h, int B) {
+    const char* e = getenv("ESCX_TRAIN_PARTS");                 // read per call: tests switch it
+    const int want = e ? atoi(e) : 2;
+    static const int min_b = [] { const char* m = getenv("ESCX_TRAIN_PARTS_MIN_BATCH"); return m ? atoi(m) : 8; }();
+    return (want >= 2 && B >= std::max(2, min_b) && !h->prof) ? 2 : 1;
+}
+}  // namespace
+
+extern "C" int escx_train_forward(escx_handle h, const float* flat_dev, const float* wave, int B, int L, int S, int freeze, int64_t* codes_out,
+                                  float* wave_out, float* raw_feat, float* recon_feat, float* cm_loss, float* cb_loss, void* stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!wave || !codes_out || !wave_out) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
+    const escx_config& c = h->cfg;
+    if (B < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "batch must be positive");
+    if (S < 1 || S > c.max_streams) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "num_streams=%d outside [1, %d]", S, c.max_streams);
+    if (L <= h->n_fft / 2) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_samples=%d too short for reflect padding of %d", L, h->n_fft / 2);
+    hipStream_t st = (hipStream_t)stream;
+    if (flat_dev && (rc = refresh_from_flat(h, flat_dev, st))) return rc;
+    if ((rc = build_gather_map(h))) return rc;
+    TrainRoot& R = *root_of(h);
+    R.valid = false;
+    ++R.generation;
+    R.parts = train_parts_for(h, B);
+    if (R.parts == 1) {
+        R.cur = &R.single;
+        rc = train_forward_impl(h, wave, B, L, S, freeze, codes_out, wave_out, raw_feat, recon_feat, cm_loss, cb_loss, st);
+        R.valid = rc == 0;
+        return rc;
+    }
+    if (!R.aux) {
+        ESCX_HIP(hipStreamCreateWithFlags(&R.aux, hipStreamNonBlocking));
+        ESCX_HIP(hipEventCreateWithFlags(&R.ev_fork, hipEventDisableTiming));
+        ESCX_HIP(hipEventCreateWithFlags(&R.ev_join, hipEventDisableTiming));
+    }
+    ESCX_HIP(hipEventRecord(R.ev_fork, st));
+    ESCX_HIP(hipStreamWaitEvent(R.aux, R.ev_fork, 0));
+    Shapes s0;
+    if ((rc = make_shapes(h, 1, 1 + L / c.hop_length, &s0))) return rc;
+    const size_t per_codes = (size_t)c.max_streams * c.group_size * s0.Tq;
+    const size_t per_wave_out = (size_t)c.hop_length * (c.patch_t * s0.W - 1);
+    const size_t per_raw = (size_t)s0.T * c.in_dim * h->F, per_recon = (size_t)c.patch_t * s0.W * c.in_dim * h->F;
+    R.B0 = (B + 1) / 2;
+    for (int p = 0; p < 2; ++p) {
+        const int b0 = p ? R.B0 : 0, nb = p ? B - R.B0 : R.B0;
+        std::swap(h->tape, R.arena[p]);
+        R.cur = &R.part[p];
+        rc = train_forward_impl(h, wave + (size_t)b0 * L, nb, L, S, freeze, codes_out + b0 * per_codes, wave_out + b0 * per_wave_out,
+                                raw_feat ? raw_feat + b0 * per_raw : nullptr, recon_feat ? recon_feat + b0 * per_recon : nullptr,
+                                cm_loss ? cm_loss + b0 : nullptr, cb_loss ? cb_loss + b0 : nullptr, p ? R.aux : st);
+        std::swap(h->tape, R.arena[p]);
+        R.cur = &R.single;
+        if (rc) return rc;
+    }
+    ESCX_HIP(hipEventRecord(R.ev_join, R.aux));
+    ESCX_HIP(hipStreamWaitEvent(st, R.ev_join, 0));
+    R.valid = true;
+    return ESCX_OK;
 }
 
 namespace {
@@ -742,16 +826,14 @@ void add_inplace(float* dst, const float* src, size_t n, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int escx_train_backward(escx_handle h, const float* d_wave, const float* d_recon_feat, const float* d_cm, const float* d_cb,
-                                   float* grad_flat, void* stream) {
-    int rc = check_ready(h); if (rc) return rc;
-    if (!grad_flat) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null gradient buffer");
+namespace {
+int train_backward_impl(escx_handle_s* h, const float* d_wave, const float* d_recon_feat, const float* d_cm, const float* d_cb, float* grad_flat, hipStream_t st) {
+    int rc = 0;
     TrainTape& T = *tape_of(h);
     if (!T.valid) ESCX_FAIL(ESCX_ERR_STATE, "escx_train_backward without a preceding escx_train_forward");
     T.valid = false;                                             // the tape is consumed (scratch overwrites nothing of it, but one backward per forward)
     const escx_config& c = h->cfg;
     const Shapes& s = T.shp;
-    hipStream_t st = (hipStream_t)stream;
     Arena& tp = h->tape;
     tp.used = T.fwd_mark;
     const int n = h->n, B = T.B;
@@ -883,6 +965,43 @@ extern "C" int escx_train_backward(escx_handle h, const float* d_wave, const flo
     if (h->grad_seg)
         hipLaunchKernelGGL(scatter_grads_kernel, dim3(blocks_for(h->grad_seg_total)), dim3(256), 0, st, h->garena, h->gmap, grad_flat, h->grad_seg, h->grad_nseg,
                            h->grad_seg_total);
+    return launch_ok("train_backward");
+}
+}  // namespace
+
+extern "C" int escx_train_backward(escx_handle h, const float* d_wave, const float* d_recon_feat, const float* d_cm, const float* d_cb,
+                                   float* grad_flat, void* stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!grad_flat) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null gradient buffer");
+    TrainRoot& R = *root_of(h);
+    if (!R.valid) ESCX_FAIL(ESCX_ERR_STATE, "escx_train_backward without a preceding escx_train_forward");
+    R.valid = false;
+    hipStream_t st = (hipStream_t)stream;
+    if (R.parts == 1) { R.cur = &R.single; return train_backward_impl(h, d_wave, d_recon_feat, d_cm, d_cb, grad_flat, st); }
+    const escx_config& c = h->cfg;
+    const Shapes& s1 = R.part[0].shp;
+    const size_t per_wave = (size_t)c.hop_length * (c.patch_t * s1.W - 1), per_recon = (size_t)c.patch_t * s1.W * c.in_dim * h->F;
+    if (!R.garena[1]) ESCX_HIP(hipMalloc((void**)&R.garena[1], h->wts.cap));
+    if (!R.gflat1) ESCX_HIP(hipMalloc((void**)&R.gflat1, h->flat_total * sizeof(float)));
+    ESCX_HIP(hipEventRecord(R.ev_fork, st));
+    ESCX_HIP(hipStreamWaitEvent(R.aux, R.ev_fork, 0));
+    for (int p = 0; p < 2; ++p) {
+        const int b0 = p ? R.B0 : 0;
+        std::swap(h->tape, R.arena[p]);
+        if (p) std::swap(h->garena, R.garena[1]);
+        R.cur = &R.part[p];
+        rc = train_backward_impl(h, d_wave ? d_wave + b0 * per_wave : nullptr, d_recon_feat ? d_recon_feat + b0 * per_recon : nullptr, d_cm ? d_cm + b0 : nullptr,
+                                 d_cb ? d_cb + b0 : nullptr, p ? R.gflat1 : grad_flat, p ? R.aux : st);
+        std::swap(h->tape, R.arena[p]);
+        if (p) std::swap(h->garena, R.garena[1]);
+        R.cur = &R.single;
+        if (rc) return rc;
+    }
+    ESCX_HIP(hipEventRecord(R.ev_join, R.aux));
+    ESCX_HIP(hipStreamWaitEvent(st, R.ev_join, 0));
+    // d loss / d parameter = part 0 + part 1 (fixed order)
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks_for((long long)h->flat_total / 4 + 1)), dim3(256), 0, st, grad_flat, R.gflat1, (long long)(h->flat_total / 4));
+    if (h->flat_total % 4) hipLaunchKernelGGL(add_tail_kernel, dim3(1), dim3(4), 0, st, grad_flat, R.gflat1, (long long)(h->flat_total / 4 * 4), (long long)h->flat_total);
     return launch_ok("train_backward");
 }
 

@@ -862,6 +862,10 @@ static __global__ void add_inplace_kernel(float* __restrict__ dst, const float* 
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n4) st4(dst + 4 * i, ld4(dst + 4 * i) + ld4(src + 4 * i));
 }
+static __global__ void add_tail_kernel(float* __restrict__ dst, const float* __restrict__ src, long long from, long long n) {
+    const long long i = from + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
 static __global__ void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ out, long long per_row, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = x[i] * g[i / per_row];
