@@ -618,7 +618,8 @@ int train_forward_impl(escx_handle_s* h, const float* wave, int B, int L, int S,
 int train_parts_for(escx_handle_s* h, int B) {
     const char* e = getenv("ESCX_TRAIN_PARTS");                 // read per call: tests switch it
     const int want = e ? atoi(e) : 2;
-    static const int min_b = [] { const char* m = getenv("ESCX_TRAIN_PARTS_MIN_BATCH"); return m ? atoi(m) : 8; }();
+    const char* m = getenv("ESCX_TRAIN_PARTS_MIN_BATCH");
+    const int min_b = m ? atoi(m) : 8;
     return (want >= 2 && B >= std::max(2, min_b) && !h->prof) ? 2 : 1;
 }
 }  // namespace

@@ -614,3 +614,26 @@ def test_training_step_is_run_to_run_deterministic():
         gan.discriminator_loss(fake, real).mean().backward()
         dg.append({k: p.grad.detach().clone() for k, p in disc.named_parameters()})
     assert all(torch.equal(dg[0][k], dg[1][k]) for k in dg[0])
+
+
+@pytest.mark.gpu
+def test_two_part_training_pass_equals_the_one_part_pass(monkeypatch):
+    """Large batches run as two parts on two streams (train.hip: TrainRoot): own tapes and gradient arenas, flat gradients added in a fixed order.
+    Clips are independent in the training step, so the forward outputs (losses, codes) are bit for bit those of the one-part pass and the gradients
+    differ by summation order only; the two-part form is itself run-to-run deterministic."""
+    g = load_golden("train")
+    w = json.loads(str(g["weights_json"]))
+    x = _clips(g, "base")
+    x = torch.cat([x, 0.5 * x.flip(0)], dim=0)                    # 4 clips -> parts of 2 + 2
+    monkeypatch.setenv("ESCX_TRAIN_PARTS", "1")
+    _, _, l1, g1 = _product_step("base", 6, False, x, w)
+    monkeypatch.setenv("ESCX_TRAIN_PARTS", "2")
+    monkeypatch.setenv("ESCX_TRAIN_PARTS_MIN_BATCH", "2")
+    runs = [_product_step("base", 6, False, x, w)[2:] for _ in range(2)]
+    l2, g2 = runs[0]
+    assert all(np.array_equal(l2[k], runs[1][0][k]) for k in l2) and all(np.array_equal(g2[k], runs[1][1][k]) for k in g2)
+    for k in l1:
+        np.testing.assert_allclose(l2[k], l1[k], rtol=1e-6, atol=1e-7, err_msg=k)
+    num = sum(float(((g2[k].astype(np.float64) - g1[k]) ** 2).sum()) for k in g1)
+    den = sum(float((g1[k].astype(np.float64) ** 2).sum()) for k in g1)
+    assert (num / den) ** 0.5 < 1e-5, (num / den) ** 0.5
