@@ -45,14 +45,15 @@ struct TrainTape {
 // large batch runs as TWO parts on two streams, like the inference path's run_halves: each part has its own tape arena, packed-gradient arena and flat
 // gradient buffer; the parts' flat gradients are added in a fixed order after the join.  One part's launches fill the dispatch tails and small grids of the other.
 struct TrainRoot {
+    static constexpr int MAXP = 4;
     TrainTape single;                        // the one-part form (small batches, profiling, ESCX_TRAIN_PARTS=1)
-    TrainTape part[2];
+    TrainTape part[MAXP];
     TrainTape* cur = &single;
-    escx::Arena arena[2];                    // tapes of the two parts (the handle's own arena serves the one-part form)
-    float* garena[2] = {nullptr, nullptr};   // [0] unused (part 0 writes the handle's)
-    float* gflat1 = nullptr;                 // part 1's flat gradient
-    hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int parts = 1, B0 = 0;                   // of the last forward
+    escx::Arena arena[MAXP];                 // tapes of the parts (the handle's own arena serves the one-part form)
+    float* garena[MAXP] = {};                // [0] unused (part 0 writes the handle's)
+    float* gflat[MAXP] = {};                 // [0] unused (part 0 writes the caller's buffer)
+    hipStream_t aux[MAXP] = {}; hipEvent_t ev_fork = nullptr, ev_join[MAXP] = {};      // [0] unused (part 0 runs on the caller's stream)
+    int parts = 1, first[MAXP + 1] = {};     // of the last forward: part p = clips [first[p], first[p + 1])
     bool valid = false;
     long long generation = 0;
 };
@@ -61,11 +62,14 @@ struct TrainRoot {
 void escx::free_train_state(escx_handle_s* h) {
     TrainRoot* r = static_cast<TrainRoot*>(h->train_state);
     if (r) {
-        for (int p = 0; p < 2; ++p) { if (r->arena[p].base) (void)hipFree(r->arena[p].base); if (r->garena[p]) (void)hipFree(r->garena[p]); }
-        if (r->gflat1) (void)hipFree(r->gflat1);
-        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamDestroy(r->aux); }
+        for (int p = 0; p < TrainRoot::MAXP; ++p) {
+            if (r->arena[p].base) (void)hipFree(r->arena[p].base);
+            if (r->garena[p]) (void)hipFree(r->garena[p]);
+            if (r->gflat[p]) (void)hipFree(r->gflat[p]);
+            if (r->aux[p]) { (void)hipStreamSynchronize(r->aux[p]); (void)hipStreamDestroy(r->aux[p]); }
+            if (r->ev_join[p]) (void)hipEventDestroy(r->ev_join[p]);
+        }
         if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
-        if (r->ev_join) (void)hipEventDestroy(r->ev_join);
     }
     delete r;
     h->train_state = nullptr;
@@ -511,7 +515,7 @@ extern "C" int escx_load_flat_params(escx_handle h, const float* flat_dev, int f
 extern "C" int64_t escx_train_tape_bytes(escx_handle h) {
     if (!h) return 0;
     const TrainRoot* r = static_cast<TrainRoot*>(h->train_state);
-    if (r && r->parts == 2) return (int64_t)(r->arena[0].cap + r->arena[1].cap);
+    if (r && r->parts > 1) { int64_t t = 0; for (int p = 0; p < r->parts; ++p) t += (int64_t)r->arena[p].cap; return t; }
     return (int64_t)h->tape.cap;
 }
 extern "C" int64_t escx_train_tape_generation(escx_handle h) { return (h && h->train_state) ? (int64_t)static_cast<TrainRoot*>(h->train_state)->generation : 0; }
@@ -620,7 +624,8 @@ int train_parts_for(escx_handle_s* h, int B) {
     const int want = e ? atoi(e) : 2;
     const char* m = getenv("ESCX_TRAIN_PARTS_MIN_BATCH");
     const int min_b = m ? atoi(m) : 8;
-    return (want >= 2 && B >= std::max(2, min_b) && !h->prof) ? 2 : 1;
+    if (want < 2 || B < std::max(2, min_b) || h->prof) return 1;
+    return std::min(std::min(want, TrainRoot::MAXP), B);
 }
 }  // namespace
 
@@ -645,32 +650,36 @@ extern "C" int escx_train_forward(escx_handle h, const float* flat_dev, const fl
         R.valid = rc == 0;
         return rc;
     }
-    if (!R.aux) {
-        ESCX_HIP(hipStreamCreateWithFlags(&R.aux, hipStreamNonBlocking));
-        ESCX_HIP(hipEventCreateWithFlags(&R.ev_fork, hipEventDisableTiming));
-        ESCX_HIP(hipEventCreateWithFlags(&R.ev_join, hipEventDisableTiming));
-    }
+    if (!R.ev_fork) ESCX_HIP(hipEventCreateWithFlags(&R.ev_fork, hipEventDisableTiming));
     ESCX_HIP(hipEventRecord(R.ev_fork, st));
-    ESCX_HIP(hipStreamWaitEvent(R.aux, R.ev_fork, 0));
+    for (int p = 1; p < R.parts; ++p) {
+        if (!R.aux[p]) {
+            ESCX_HIP(hipStreamCreateWithFlags(&R.aux[p], hipStreamNonBlocking));
+            ESCX_HIP(hipEventCreateWithFlags(&R.ev_join[p], hipEventDisableTiming));
+        }
+        ESCX_HIP(hipStreamWaitEvent(R.aux[p], R.ev_fork, 0));
+    }
     Shapes s0;
     if ((rc = make_shapes(h, 1, 1 + L / c.hop_length, &s0))) return rc;
     const size_t per_codes = (size_t)c.max_streams * c.group_size * s0.Tq;
     const size_t per_wave_out = (size_t)c.hop_length * (c.patch_t * s0.W - 1);
     const size_t per_raw = (size_t)s0.T * c.in_dim * h->F, per_recon = (size_t)c.patch_t * s0.W * c.in_dim * h->F;
-    R.B0 = (B + 1) / 2;
-    for (int p = 0; p < 2; ++p) {
-        const int b0 = p ? R.B0 : 0, nb = p ? B - R.B0 : R.B0;
+    for (int p = 0; p <= R.parts; ++p) R.first[p] = (int)((long long)B * p / R.parts);
+    for (int p = 0; p < R.parts; ++p) {
+        const int b0 = R.first[p], nb = R.first[p + 1] - b0;
         std::swap(h->tape, R.arena[p]);
         R.cur = &R.part[p];
         rc = train_forward_impl(h, wave + (size_t)b0 * L, nb, L, S, freeze, codes_out + b0 * per_codes, wave_out + b0 * per_wave_out,
                                 raw_feat ? raw_feat + b0 * per_raw : nullptr, recon_feat ? recon_feat + b0 * per_recon : nullptr,
-                                cm_loss ? cm_loss + b0 : nullptr, cb_loss ? cb_loss + b0 : nullptr, p ? R.aux : st);
+                                cm_loss ? cm_loss + b0 : nullptr, cb_loss ? cb_loss + b0 : nullptr, p ? R.aux[p] : st);
         std::swap(h->tape, R.arena[p]);
         R.cur = &R.single;
         if (rc) return rc;
     }
-    ESCX_HIP(hipEventRecord(R.ev_join, R.aux));
-    ESCX_HIP(hipStreamWaitEvent(st, R.ev_join, 0));
+    for (int p = 1; p < R.parts; ++p) {
+        ESCX_HIP(hipEventRecord(R.ev_join[p], R.aux[p]));
+        ESCX_HIP(hipStreamWaitEvent(st, R.ev_join[p], 0));
+    }
     R.valid = true;
     return ESCX_OK;
 }
@@ -982,27 +991,31 @@ extern "C" int escx_train_backward(escx_handle h, const float* d_wave, const flo
     const escx_config& c = h->cfg;
     const Shapes& s1 = R.part[0].shp;
     const size_t per_wave = (size_t)c.hop_length * (c.patch_t * s1.W - 1), per_recon = (size_t)c.patch_t * s1.W * c.in_dim * h->F;
-    if (!R.garena[1]) ESCX_HIP(hipMalloc((void**)&R.garena[1], h->wts.cap));
-    if (!R.gflat1) ESCX_HIP(hipMalloc((void**)&R.gflat1, h->flat_total * sizeof(float)));
     ESCX_HIP(hipEventRecord(R.ev_fork, st));
-    ESCX_HIP(hipStreamWaitEvent(R.aux, R.ev_fork, 0));
-    for (int p = 0; p < 2; ++p) {
-        const int b0 = p ? R.B0 : 0;
+    for (int p = 1; p < R.parts; ++p) {
+        if (!R.garena[p]) ESCX_HIP(hipMalloc((void**)&R.garena[p], h->wts.cap));
+        if (!R.gflat[p]) ESCX_HIP(hipMalloc((void**)&R.gflat[p], h->flat_total * sizeof(float)));
+        ESCX_HIP(hipStreamWaitEvent(R.aux[p], R.ev_fork, 0));
+    }
+    for (int p = 0; p < R.parts; ++p) {
+        const int b0 = R.first[p];
         std::swap(h->tape, R.arena[p]);
-        if (p) std::swap(h->garena, R.garena[1]);
+        if (p) std::swap(h->garena, R.garena[p]);
         R.cur = &R.part[p];
         rc = train_backward_impl(h, d_wave ? d_wave + b0 * per_wave : nullptr, d_recon_feat ? d_recon_feat + b0 * per_recon : nullptr, d_cm ? d_cm + b0 : nullptr,
-                                 d_cb ? d_cb + b0 : nullptr, p ? R.gflat1 : grad_flat, p ? R.aux : st);
+                                 d_cb ? d_cb + b0 : nullptr, p ? R.gflat[p] : grad_flat, p ? R.aux[p] : st);
         std::swap(h->tape, R.arena[p]);
-        if (p) std::swap(h->garena, R.garena[1]);
+        if (p) std::swap(h->garena, R.garena[p]);
         R.cur = &R.single;
         if (rc) return rc;
     }
-    ESCX_HIP(hipEventRecord(R.ev_join, R.aux));
-    ESCX_HIP(hipStreamWaitEvent(st, R.ev_join, 0));
-    // d loss / d parameter = part 0 + part 1 (fixed order)
-    hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks_for((long long)h->flat_total / 4 + 1)), dim3(256), 0, st, grad_flat, R.gflat1, (long long)(h->flat_total / 4));
-    if (h->flat_total % 4) hipLaunchKernelGGL(add_tail_kernel, dim3(1), dim3(4), 0, st, grad_flat, R.gflat1, (long long)(h->flat_total / 4 * 4), (long long)h->flat_total);
+    // d loss / d parameter = ((part 0 + part 1) + part 2) + ... (fixed order)
+    for (int p = 1; p < R.parts; ++p) {
+        ESCX_HIP(hipEventRecord(R.ev_join[p], R.aux[p]));
+        ESCX_HIP(hipStreamWaitEvent(st, R.ev_join[p], 0));
+        hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks_for((long long)h->flat_total / 4 + 1)), dim3(256), 0, st, grad_flat, R.gflat[p], (long long)(h->flat_total / 4));
+        if (h->flat_total % 4) hipLaunchKernelGGL(add_tail_kernel, dim3(1), dim3(4), 0, st, grad_flat, R.gflat[p], (long long)(h->flat_total / 4 * 4), (long long)h->flat_total);
+    }
     return launch_ok("train_backward");
 }
 
