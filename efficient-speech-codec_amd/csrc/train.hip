@@ -211,8 +211,7 @@ int ln_bwd(int mode, const float* x, const float* dy, const float* gamma, const 
     // part: [grid][2][RW] -> reduce over grid (fixed order) into a [2][RW] row, then to the two destinations
     float* red = part + (size_t)grid * 2 * RW;
     reduce_partials(part, grid, (long long)2 * RW, red, 0, st);
-    (void)hipMemcpyAsync(dg, red, (size_t)RW * sizeof(float), hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(dbt, red + RW, (size_t)RW * sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(copy2_kernel, dim3(blocks_for(2 * RW)), dim3(256), 0, st, red, dg, dbt, RW);          // one launch instead of two copy-engine packets (~7 us each)
     return 0;
 }
 constexpr size_t LN_PART_FLOATS = (size_t)513 * 2 * 2 * 384;
@@ -231,8 +230,7 @@ void gemm_ln_bwd_rows(const float* A, int lda, int M, const float* Wt, int Cp, i
     else launch_gemm<64>(PlainA{A, lda, M}, Wt, M, Cp, Kp, ep, st, 1, bk);
     float* red = part + (size_t)rows * 2 * Cp;
     launch_reduce_partials(part, rows, (long long)2 * Cp, red, 0, st, red + 2 * Cp);
-    (void)hipMemcpyAsync(dg, red, (size_t)Cp * sizeof(float), hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(dbt, red + Cp, (size_t)Cp * sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(copy2_kernel, dim3(blocks_for(2 * Cp)), dim3(256), 0, st, red, dg, dbt, Cp);
 }
 
 int attn_bwd(const float* qkv, const float* bias, const float* dout, float* dqkv, float* dbias, float* part, int total_windows, int nH, int hdp, int ldq,

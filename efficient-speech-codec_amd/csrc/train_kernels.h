@@ -862,6 +862,12 @@ static __global__ void add_inplace_kernel(float* __restrict__ dst, const float* 
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n4) st4(dst + 4 * i, ld4(dst + 4 * i) + ld4(src + 4 * i));
 }
+// src[0..n) -> a, src[n..2n) -> b
+static __global__ void copy2_kernel(const float* __restrict__ src, float* __restrict__ a, float* __restrict__ b, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = src[i];
+    else if (i < 2 * n) b[i - n] = src[i];
+}
 static __global__ void add_tail_kernel(float* __restrict__ dst, const float* __restrict__ src, long long from, long long n) {
     const long long i = from + threadIdx.x;
     if (i < n) dst[i] += src[i];
