@@ -606,14 +606,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
             sp[0] = x + (size_t)row * Cp; dp[0] = dx + (size_t)row * Cp;
             gp = (MODE == 1) ? dy + ((size_t)b * dy_rows_per_clip + map[rr]) * Cp : dy + (size_t)row * Cp;
         }
+        // the row (input and upstream gradient) is read ONCE into registers: the four passes below (mean, variance, the two projections, dx) walked it
+        // four times through L1 before (2.2 TB/s of algorithmic bytes at C = 144)
+        f32x4 xr[SEGS][MAXV], gr[SEGS][MAXV];
+#pragma unroll
+        for (int s = 0; s < SEGS; ++s)
+#pragma unroll
+            for (int q = 0; q < MAXV; ++q) {
+                const int v = sub + 16 * q;
+                xr[s][q] = (v < V && sp[s]) ? ld4(sp[s] + 4 * v) : zero4();
+                gr[s][q] = (v < V) ? ld4(gp + s * Cp + 4 * v) : zero4();
+            }
         float sum = 0.f;
 #pragma unroll
         for (int s = 0; s < SEGS; ++s)
             if (sp[s])
-                for (int v = sub; v < V; v += 16) {
-                    const f32x4 xv = ld4(sp[s] + 4 * v);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (4 * v + e < C) sum += xv[e];
+                for (int q = 0; q < MAXV; ++q) {
+                    const int v = sub + 16 * q;
+                    if (v < V) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (4 * v + e < C) sum += xr[s][q][e];
+                    }
                 }
 #pragma unroll
         for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 16);
@@ -621,10 +635,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         float var = 0.f;
 #pragma unroll
         for (int s = 0; s < SEGS; ++s)
-            for (int v = sub; v < V; v += 16) {
-                const f32x4 xv = sp[s] ? ld4(sp[s] + 4 * v) : zero4();
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (4 * v + e < C) { const float d = xv[e] - mean; var += d * d; }
+            for (int q = 0; q < MAXV; ++q) {
+                const int v = sub + 16 * q;
+                if (v < V) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (4 * v + e < C) { const float d = xr[s][q][e] - mean; var += d * d; }
+                }
             }
 #pragma unroll
         for (int o = 8; o >= 1; o >>= 1) var += __shfl_xor(var, o, 16);
@@ -637,8 +654,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
             for (int q = 0; q < MAXV; ++q) {
                 const int v = sub + 16 * q;
                 if (v < V) {
-                    const f32x4 xv = sp[s] ? ld4(sp[s] + 4 * v) : zero4();
-                    const f32x4 g = ld4(gp + s * Cp + 4 * v), gm = ld4(gamma + s * Cp + 4 * v);
+                    const f32x4 xv = xr[s][q];
+                    const f32x4 g = gr[s][q], gm = ld4(gamma + s * Cp + 4 * v);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (4 * v + e < C) {
@@ -655,9 +672,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int s = 0; s < SEGS; ++s) {
             if (!dp[s]) continue;
-            for (int v = sub; v < V; v += 16) {
-                const f32x4 xv = ld4(sp[s] + 4 * v);
-                const f32x4 g = ld4(gp + s * Cp + 4 * v), gm = ld4(gamma + s * Cp + 4 * v);
+#pragma unroll
+            for (int q = 0; q < MAXV; ++q) {
+                const int v = sub + 16 * q;
+                if (v >= V) continue;
+                const f32x4 xv = xr[s][q];
+                const f32x4 g = gr[s][q], gm = ld4(gamma + s * Cp + 4 * v);
                 f32x4 o = (MODE != 2 && add) ? ld4(add + (size_t)row * Cp + 4 * v) : zero4();
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
