@@ -200,6 +200,13 @@ int disc_join(escx_disc_s* d, hipStream_t st, int n) {
     return 0;
 }
 
+// the convolution loaders address a feature map with 32-bit element offsets
+int check_map_sizes(const std::vector<FmapShape>& shp, int B) {
+    for (const FmapShape& f : shp)
+        if ((unsigned long long)B * f.D0 * f.P1 * f.Cp >= (1ull << 32)) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "feature map of %d x %d x %d x %d elements: batch too large for one discriminator pass", B, f.D0, f.P1, f.Cp);
+    return 0;
+}
+
 int ensure_scratch(escx_disc_s* d, size_t bytes) {
     if (d->scratch_bytes >= bytes) return 0;
     ESCX_HIP(hipDeviceSynchronize());
@@ -439,7 +446,8 @@ extern "C" int escx_disc_forward(escx_disc d, const float* flat_params, int64_t 
     int maxp = 1; for (const DSub& S : d->subs) if (S.kind == 0) maxp = std::max(maxp, S.arg);
     if (L <= maxp + 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "clip too short for the reflect padding of the period discriminators");
     std::vector<FmapShape> shp; fmap_shapes(d, L, &shp);
-    int rc = ensure_scratch(d, front_floats(d, B, L) * sizeof(float)); if (rc) return rc;
+    int rc = check_map_sizes(shp, B); if (rc) return rc;
+    if ((rc = ensure_scratch(d, front_floats(d, B, L) * sizeof(float)))) return rc;
     if ((rc = pack_weights(d, flat_params, (long long)params_version, st))) return rc;
     std::vector<std::vector<float*>> ins; std::vector<float*> specs; float *y, *stats;
     build_front(d, wave, B, L, d->scratch, &ins, &specs, &y, &stats, st);
@@ -509,7 +517,8 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
     }
     const int nq = disc_streams();                              // per-stream copies of the per-layer scratch
     const size_t total = front + gfl + nq * (3 * pad64(in_g) + pad64(max_w) + pad64(DISC_DW_PART) + pad64((size_t)B * L)) + 4096;
-    int rc = ensure_scratch(d, total * sizeof(float)); if (rc) return rc;
+    int rc = check_map_sizes(shp, B); if (rc) return rc;
+    if ((rc = ensure_scratch(d, total * sizeof(float)))) return rc;
     if ((rc = pack_weights(d, flat_params, (long long)params_version, st))) return rc;
     std::vector<std::vector<float*>> ins; std::vector<float*> specs; float *y, *stats;
     build_front(d, wave, B, L, d->scratch, &ins, &specs, &y, &stats, st);

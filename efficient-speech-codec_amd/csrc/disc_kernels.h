@@ -18,45 +18,74 @@ struct TView { float* p; int D0, D1, P1, Cp; };           // see above; batch st
 
 struct ConvGeom { int T0, T1, s0, s1, p0, p1, O0, O1; };  // taps, strides, pads, output extent
 
+// Loader cost matters here: the engine calls load4 twice per thread per 16-wide K step, next to 48 MFMAs per wave.  The straightforward form (tap and channel
+// from k by two divisions, a 64-bit (b, i0, i1, c) address product) is ~30 VALU instructions per call = 15 % of the MFMA time of the 1024-channel layers.
+// Here the row context carries a 32-bit element offset of the row's tap-(0, 0) position (wrapping arithmetic: out-of-range taps are masked by the bounds
+// test), and the tap index is derived from k0 ALONE - in the engine k0 is wave-uniform, so the two divisions and the tap offset run on the scalar unit;
+// a K step that straddles taps (Cp < 16: the one-channel input layers) takes the general path.  Feature maps hold < 2^32 elements (checked by the host).
+
 // forward gather: A[(b, o0, o1)][k = (t0*T1 + t1)*Cp + c] = X(b, o0*s0 + t0 - p0, o1*s1 + t1 - p1, c)
 struct ConvS {
     TView x; ConvGeom g; int M; FastDiv dO, dO1, dCp, dT1;
-    struct Ctx { int b, i0, i1; };
+    struct Ctx { int ok, i0, i1; unsigned base; };
     __device__ __forceinline__ Ctx make_ctx(int m) const {
-        Ctx c; c.b = -1; c.i0 = 0; c.i1 = 0;
-        if (m < M) { c.b = dO.div(m); const int r = m - c.b * g.O0 * g.O1; const int o0 = dO1.div(r), o1 = r - o0 * g.O1; c.i0 = o0 * g.s0 - g.p0; c.i1 = o1 * g.s1 - g.p1; }
+        Ctx c; c.ok = 0; c.i0 = 0; c.i1 = 0; c.base = 0;
+        if (m < M) {
+            const int b = dO.div(m); const int r = m - b * g.O0 * g.O1; const int o0 = dO1.div(r), o1 = r - o0 * g.O1;
+            c.ok = 1; c.i0 = o0 * g.s0 - g.p0; c.i1 = o1 * g.s1 - g.p1;
+            c.base = (((unsigned)b * (unsigned)x.D0 + (unsigned)c.i0) * (unsigned)x.P1 + (unsigned)c.i1) * (unsigned)x.Cp;
+        }
         return c;
     }
-    __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
-        if (c.b < 0) return zero4();
-        const int k = k0 + kin; const int tap = dCp.div(k), cc = k - tap * x.Cp;
+    __device__ __forceinline__ f32x4 at(const Ctx& c, int tap, int cc) const {
         if (tap >= g.T0 * g.T1) return zero4();
         const int t0 = dT1.div(tap), t1 = tap - t0 * g.T1;
-        const int i0 = c.i0 + t0, i1 = c.i1 + t1;
-        if (i0 < 0 || i0 >= x.D0 || i1 < 0 || i1 >= x.D1) return zero4();
-        return ld4(x.p + (((size_t)c.b * x.D0 + i0) * x.P1 + i1) * x.Cp + cc);
+        if ((unsigned)(c.i0 + t0) >= (unsigned)x.D0 || (unsigned)(c.i1 + t1) >= (unsigned)x.D1) return zero4();
+        return ld4(x.p + (c.base + (unsigned)((t0 * x.P1 + t1) * x.Cp) + (unsigned)cc));
+    }
+    __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
+        if (!c.ok) return zero4();
+        const int tap = dCp.div(k0);                    // functions of k0 only: scalar in the engine
+        const int cc = k0 - tap * x.Cp + kin;
+        if (cc < x.Cp) return at(c, tap, cc);
+        const int e = dCp.div(cc);
+        return at(c, tap + e, cc - e * x.Cp);
     }
 };
 
 // transposed gather for dX: A[(b, i0, i1)][k = (t0*T1 + t1)*Cp + co] = dY(b, (i0 + p0 - t0) / s0, (i1 + p1 - t1) / s1, co) where divisible
 struct ConvTS {
     TView y; ConvGeom g; int D0, D1, M; FastDiv dI, dI1, dCp, dT1, dS0, dS1;     // D0, D1: extent of the INPUT map the rows walk
-    struct Ctx { int b, i0, i1; };
+    struct Ctx { int ok, i0, i1; unsigned base; };
     __device__ __forceinline__ Ctx make_ctx(int m) const {
-        Ctx c; c.b = -1; c.i0 = 0; c.i1 = 0;
-        if (m < M) { c.b = dI.div(m); const int r = m - c.b * D0 * D1; const int i0 = dI1.div(r); c.i0 = i0 + g.p0; c.i1 = r - i0 * D1 + g.p1; }
+        Ctx c; c.ok = 0; c.i0 = 0; c.i1 = 0; c.base = 0;
+        if (m < M) {
+            const int b = dI.div(m); const int r = m - b * D0 * D1; const int i0 = dI1.div(r);
+            c.ok = 1; c.i0 = i0 + g.p0; c.i1 = r - i0 * D1 + g.p1;
+            c.base = (unsigned)b * (unsigned)y.D0 * (unsigned)y.P1 * (unsigned)y.Cp;           // of the clip; unit strides add (i0, i1) below
+        }
         return c;
     }
-    __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
-        if (c.b < 0) return zero4();
-        const int k = k0 + kin; const int tap = dCp.div(k), cc = k - tap * y.Cp;
+    __device__ __forceinline__ f32x4 at(const Ctx& c, int tap, int cc) const {
         if (tap >= g.T0 * g.T1) return zero4();
         const int t0 = dT1.div(tap), t1 = tap - t0 * g.T1;
         const int a0 = c.i0 - t0, a1 = c.i1 - t1;
         if (a0 < 0 || a1 < 0) return zero4();
-        const int o0 = dS0.div(a0), o1 = dS1.div(a1);
-        if (o0 * g.s0 != a0 || o1 * g.s1 != a1 || o0 >= y.D0 || o1 >= y.D1) return zero4();
-        return ld4(y.p + (((size_t)c.b * y.D0 + o0) * y.P1 + o1) * y.Cp + cc);
+        int o0 = a0, o1 = a1;
+        if (g.s0 != 1 || g.s1 != 1) {                   // (strided layers normally take the residue-class form below)
+            o0 = dS0.div(a0); o1 = dS1.div(a1);
+            if (o0 * g.s0 != a0 || o1 * g.s1 != a1) return zero4();
+        }
+        if (o0 >= y.D0 || o1 >= y.D1) return zero4();
+        return ld4(y.p + (c.base + (unsigned)((o0 * y.P1 + o1) * y.Cp) + (unsigned)cc));
+    }
+    __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
+        if (!c.ok) return zero4();
+        const int tap = dCp.div(k0);
+        const int cc = k0 - tap * y.Cp + kin;
+        if (cc < y.Cp) return at(c, tap, cc);
+        const int e = dCp.div(cc);
+        return at(c, tap + e, cc - e * y.Cp);
     }
 };
 
@@ -69,20 +98,29 @@ __host__ __device__ inline int phase_ntaps(int r, int p, int s, int T) { const i
 
 struct ConvTSP {                // A[(b, q0, q1)][k = (a*n1 + b1)*Cp + co] = dY(b, q0 + c0 - a, q1 + c1 - b1, co)
     TView y; PhaseGeom g; int M; FastDiv dQ, dQ1, dCp, dN1;
-    struct Ctx { int b, q0, q1; };
+    struct Ctx { int ok, q0, q1; unsigned base; };
     __device__ __forceinline__ Ctx make_ctx(int m) const {
-        Ctx c; c.b = -1; c.q0 = 0; c.q1 = 0;
-        if (m < M) { c.b = dQ.div(m); const int r = m - c.b * g.Q0 * g.Q1; const int q0 = dQ1.div(r); c.q0 = q0 + g.c0; c.q1 = r - q0 * g.Q1 + g.c1; }
+        Ctx c; c.ok = 0; c.q0 = 0; c.q1 = 0; c.base = 0;
+        if (m < M) {
+            const int b = dQ.div(m); const int r = m - b * g.Q0 * g.Q1; const int q0 = dQ1.div(r);
+            c.ok = 1; c.q0 = q0 + g.c0; c.q1 = r - q0 * g.Q1 + g.c1;
+            c.base = (((unsigned)b * (unsigned)y.D0 + (unsigned)c.q0) * (unsigned)y.P1 + (unsigned)c.q1) * (unsigned)y.Cp;
+        }
         return c;
     }
-    __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
-        if (c.b < 0) return zero4();
-        const int k = k0 + kin; const int tap = dCp.div(k), cc = k - tap * y.Cp;
+    __device__ __forceinline__ f32x4 at(const Ctx& c, int tap, int cc) const {
         if (tap >= g.n0 * g.n1) return zero4();
         const int a = dN1.div(tap), b1 = tap - a * g.n1;
-        const int o0 = c.q0 - a, o1 = c.q1 - b1;
-        if (o0 < 0 || o0 >= y.D0 || o1 < 0 || o1 >= y.D1) return zero4();
-        return ld4(y.p + (((size_t)c.b * y.D0 + o0) * y.P1 + o1) * y.Cp + cc);
+        if ((unsigned)(c.q0 - a) >= (unsigned)y.D0 || (unsigned)(c.q1 - b1) >= (unsigned)y.D1) return zero4();
+        return ld4(y.p + (c.base - (unsigned)((a * y.P1 + b1) * y.Cp) + (unsigned)cc));
+    }
+    __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
+        if (!c.ok) return zero4();
+        const int tap = dCp.div(k0);
+        const int cc = k0 - tap * y.Cp + kin;
+        if (cc < y.Cp) return at(c, tap, cc);
+        const int e = dCp.div(cc);
+        return at(c, tap + e, cc - e * y.Cp);
     }
 };
 
