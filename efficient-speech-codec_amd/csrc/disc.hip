@@ -241,7 +241,7 @@ ConvS make_convs(const TView& x, const DConv& c, int O0, int O1, int B) {
 
 void conv_forward(const TView& x, const DConv& c, const TView& out, int B, hipStream_t st) {
     DTrace tr(st, "fwd", c.prefix.c_str(), B * out.D0 * out.D1, c.CoutP, c.Kf);
-    ConvS ld = make_convs(x, c, out.D0, out.D1, B);
+    ConvSU ld; static_cast<ConvS&>(ld) = make_convs(x, c, out.D0, out.D1, B);
     conv_gemm(ld, c.Wf, B * out.D0 * out.D1, c.CoutP, c.Kf, EpiConvOut{out, c.bias, c.act, FastDiv(out.D0 * out.D1), FastDiv(out.D1)}, st);
 }
 
