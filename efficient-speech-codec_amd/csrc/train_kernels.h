@@ -293,13 +293,20 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(LdA la, LdB lb, int M, int
     const int mbeg = blockIdx.y * m_per_slice, mend = min(M, mbeg + m_per_slice);
     float* As = lds + wave * (2 * DW_MC * DW_LD);
     float* Bs = As + DW_MC * DW_LD;
+    // Bias gradient = column sums of the dY rows.  Rounds 1-3 had it ride on the MFMA (a column of ones as a fourth B tile, under `if (do_bias)`): the
+    // conditional matrix instructions inside the unrolled loop made the register allocator shuttle every accumulator between AGPRs and VGPRs - 2
+    // v_accvgpr copies per MFMA, 5x the VALU instructions of the bias-free instantiation (ISA counts in DESIGN 7a).  Now every lane adds the float4s it
+    // stages (its column group is the same in every chunk), and the lanes / waves are added in a fixed order through LDS at the end.
     const bool do_bias = BIAS && bk == 0;
 
-    f32x4 acc[DW_T][DW_T], accb[DW_T];
+    f32x4 acc[DW_T][DW_T];
 #pragma unroll
-    for (int a = 0; a < DW_T; ++a) { accb[a] = zero4();
+    for (int a = 0; a < DW_T; ++a)
 #pragma unroll
-        for (int b = 0; b < DW_T; ++b) acc[a][b] = zero4(); }
+        for (int b = 0; b < DW_T; ++b) acc[a][b] = zero4();
+    f32x4 sa[BIAS ? 6 : 1];
+#pragma unroll
+    for (int j = 0; j < (BIAS ? 6 : 1); ++j) sa[j] = zero4();
 
     // each lane moves 6 float4 per operand per chunk: element e -> (row e / 12, float4 column e % 12).  The NEXT chunk's global loads are
     // issued before the current chunk's MFMAs (register prefetch): one memory round trip per chunk is hidden behind 72 MFMAs.
@@ -326,6 +333,7 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(LdA la, LdB lb, int M, int
             const int e = lane + 64 * j; const int row = e / V, c4 = e - row * V;
             st4(As + row * DW_LD + 4 * c4, ra[j]);
             st4(Bs + row * DW_LD + 4 * c4, rb[j]);
+            if constexpr (BIAS) sa[j] += ra[j];          // rows beyond the slice were fetched as zeros
         }
         if (m0 + 4 * DW_MC < mend) fetch(m0 + 4 * DW_MC);
         // a wave only reads what it wrote itself: no workgroup barrier, the LDS queue is in order per wave
@@ -342,16 +350,30 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(LdA la, LdB lb, int M, int
             for (int a = 0; a < DW_T; ++a)
 #pragma unroll
                 for (int b = 0; b < DW_T; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[b], acc[a][b], 0, 0, 0);
-            if (do_bias) {
-                const float one = (l15 == 0) ? 1.0f : 0.0f;           // a column of ones appended to B: its product column is the bias gradient
-#pragma unroll
-                for (int a = 0; a < DW_T; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], one, accb[a], 0, 0, 0);
-            }
         }
         __builtin_amdgcn_wave_barrier();
     }
+    // column sums: every wave folds its 32 staged rows in its OWN staging area (rows in order), then the four waves are added in order
+    __shared__ float redb[4][16 * DW_T];
+    if constexpr (BIAS) {
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { const int e = lane + 64 * j; const int row = e / V, c4 = e - row * V; st4(As + row * DW_LD + 4 * c4, sa[j]); }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 16 * DW_T) {
+                float t = 0.f;
+                for (int r = 0; r < DW_MC; ++r) t += As[r * DW_LD + lane];
+                redb[wave][lane] = t;
+            }
+        }
+    }
     // add the four waves in the order 0,1,2,3 (fixed), wave 0 writes the slice's partial tile
     __syncthreads();
+    if constexpr (BIAS) {
+        if (do_bias && tid < 16 * DW_T && n0 + tid < Np)
+            bpart[(size_t)blockIdx.y * Np + n0 + tid] = ((redb[0][tid] + redb[1][tid]) + redb[2][tid]) + redb[3][tid];
+    }
     float* red = lds;                                                // [3 waves][9 tiles][64 lanes][4] = 27 KB of the 48 KB staging area
     if (wave > 0) {
         float* r = red + (size_t)(wave - 1) * 9 * 256;
@@ -360,12 +382,6 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(LdA la, LdB lb, int M, int
 #pragma unroll
             for (int b = 0; b < DW_T; ++b) st4(r + ((a * DW_T + b) * 64 + lane) * 4, acc[a][b]);
         }
-    }
-    // bias accumulators travel in a separate small region to keep the indexing simple
-    __shared__ float redb[3][DW_T][64][4];
-    if (BIAS && wave > 0) {
-#pragma unroll
-        for (int a = 0; a < DW_T; ++a) st4(&redb[wave - 1][a][lane][0], accb[a]);
     }
     __syncthreads();
     if (wave == 0) {
@@ -376,7 +392,6 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(LdA la, LdB lb, int M, int
             for (int a = 0; a < DW_T; ++a) {
 #pragma unroll
                 for (int b = 0; b < DW_T; ++b) acc[a][b] += ld4(r + ((a * DW_T + b) * 64 + lane) * 4);
-                if (BIAS) accb[a] += ld4(&redb[w][a][lane][0]);
             }
         }
         float* po = part + (size_t)blockIdx.y * Np * Kp;
@@ -391,7 +406,6 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(LdA la, LdB lb, int M, int
                     const int k = k0 + 16 * b + l15;
                     if (k < Kp) po[(size_t)n * Kp + k] = acc[a][b][r];
                 }
-                if (do_bias && l15 == 0) bpart[(size_t)blockIdx.y * Np + n] = accb[a][r];
             }
     }
 }
@@ -416,14 +430,17 @@ __global__ __launch_bounds__(256) void gemm_dw3_kernel(LdA la, LdB lb, int M, in
     const int bn = blockIdx.x / nblk_k, bk = blockIdx.x - bn * nblk_k;
     const int n0 = bn * WA, k0 = bk * WB;
     const int mbeg = blockIdx.y * m_per_slice, mend = min(M, mbeg + m_per_slice);
-    const bool do_bias = BIAS && bk == 0 && wk == 0;
+    const bool do_bias = BIAS && bk == 0;                       // bias gradient = column sums of the staged dY rows, on the VALU (see gemm_dw_kernel)
     const int frow = tid >> 3, fc = tid & 7;
-    f32x4 acc[TA][TB], accb[TA];
+    f32x4 acc[TA][TB];
 #pragma unroll
-    for (int a = 0; a < TA; ++a) { accb[a] = zero4();
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
-        for (int b = 0; b < TB; ++b) acc[a][b] = zero4(); }
+        for (int b = 0; b < TB; ++b) acc[a][b] = zero4();
     f32x4 ra[NA], rb[NB];
+    f32x4 sa[BIAS ? NA : 1];
+#pragma unroll
+    for (int j = 0; j < (BIAS ? NA : 1); ++j) sa[j] = zero4();
     auto fetch = [&](int m0) {
         const int m = m0 + frow;
         typename LdA::Ctx ca = la.make_ctx(m < mend ? m : M);
@@ -439,7 +456,7 @@ __global__ __launch_bounds__(256) void gemm_dw3_kernel(LdA la, LdB lb, int M, in
         float* As = lds + buf * (DW_MC * (LDA + LDB));
         float* Bs = As + DW_MC * LDA;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) if (WA % 32 == 0 || 4 * (fc + 8 * j) < WA) st4(As + frow * LDA + 4 * (fc + 8 * j), ra[j]);
+        for (int j = 0; j < NA; ++j) if (WA % 32 == 0 || 4 * (fc + 8 * j) < WA) { st4(As + frow * LDA + 4 * (fc + 8 * j), ra[j]); if constexpr (BIAS) sa[j] += ra[j]; }
 #pragma unroll
         for (int j = 0; j < NB; ++j) if (WB % 32 == 0 || 4 * (fc + 8 * j) < WB) st4(Bs + frow * LDB + 4 * (fc + 8 * j), rb[j]);
         __syncthreads();                                         // one barrier per chunk: the other buffer was last read before the previous barrier
@@ -456,13 +473,21 @@ __global__ __launch_bounds__(256) void gemm_dw3_kernel(LdA la, LdB lb, int M, in
             for (int a = 0; a < TA; ++a)
 #pragma unroll
                 for (int b = 0; b < TB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[b], acc[a][b], 0, 0, 0);
-            if (do_bias) {
-                const float one = (l15 == 0) ? 1.0f : 0.0f;
-#pragma unroll
-                for (int a = 0; a < TA; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], one, accb[a], 0, 0, 0);
-            }
         }
         buf ^= 1;
+    }
+    if constexpr (BIAS) {
+        if (do_bias) {                                           // uniform per workgroup: rows 0..31 of the thread grid in order
+            __syncthreads();                                     // every wave is done with the staging buffers
+#pragma unroll
+            for (int j = 0; j < NA; ++j) if (WA % 32 == 0 || 4 * (fc + 8 * j) < WA) st4(lds + frow * LDA + 4 * (fc + 8 * j), sa[j]);
+            __syncthreads();
+            for (int n = tid; n < WA; n += 256) {
+                float t = 0.f;
+                for (int r = 0; r < DW_MC; ++r) t += lds[r * LDA + n];
+                if (n0 + n < Np) bpart[(size_t)blockIdx.y * Np + n0 + n] = t;
+            }
+        }
     }
     float* po = part + (size_t)blockIdx.y * Np * Kp;
 #pragma unroll
@@ -476,7 +501,6 @@ __global__ __launch_bounds__(256) void gemm_dw3_kernel(LdA la, LdB lb, int M, in
                 const int k = k0 + wk * 16 * TB + 16 * b + l15;
                 if (k < Kp) po[(size_t)n * Kp + k] = acc[a][b][r];
             }
-            if (do_bias && l15 == 0) bpart[(size_t)blockIdx.y * Np + n] = accb[a][r];
         }
 }
 
