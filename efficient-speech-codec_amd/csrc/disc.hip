@@ -217,13 +217,25 @@ int ensure_scratch(escx_disc_s* d, size_t bytes) {
     return 0;
 }
 
+inline int conv_cp(const ConvS& l) { return l.x.Cp; }
+inline int conv_cp(const ConvTS& l) { return l.y.Cp; }
+inline int conv_cp(const ConvTSP& l) { return l.y.Cp; }
+inline int conv_cp(const PlainA&) { return 0; }
+
 template <class Ld, class Epi>
-void conv_gemm(const Ld& ld, const float* W, int M, int Np, int Kp, const Epi& ep, hipStream_t st) {
+void conv_gemm(const Ld& ld_in, const float* W, int M, int Np, int Kp, const Epi& ep, hipStream_t st) {
+    Ld ld = ld_in;
     const long long tiles128 = (long long)((M + 127) / 128) * ((Np + 95) / 96);
     // K steps of 16: 18 KB of LDS per workgroup instead of 75 KB at the engine's default step of 80 for K = 5 x 1024 - twice the resident
     // workgroups per CU; measured on the step's convolutions (tools/disc_trace.py): forward 73.5 -> 60.2 ms, dX 115.8 -> 99.0 ms
     static const int env_bk = [] { const char* e = getenv("ESCX_CONV_BK"); return e ? atoi(e) : 16; }();
-    const int fbk = (env_bk > 0 && Kp % env_bk == 0) ? env_bk : 0;
+    static const int env_bkn = [] { const char* e = getenv("ESCX_CONV_BK_NARROW"); return e ? atoi(e) : 0; }();       // K step of the <= 48-channel outputs (0: the same)
+    const int want_bk = (Np <= 48 && env_bkn > 0) ? env_bkn : env_bk;
+    const int fbk = (want_bk > 0 && Kp % want_bk == 0) ? want_bk : 0;
+    if constexpr (!std::is_same<Ld, PlainA>::value) {            // uniform-tap gathers only when no K step of the engine straddles a tap
+        const int bk = fbk ? fbk : pick_bk(Kp), cp = conv_cp(ld);
+        ld.fast = (cp > 0 && cp % bk == 0) ? 1 : 0;
+    }
     // Narrow outputs (the 32-channel MRD stacks, the first MPD layers): a 128-row tile gives a wave 2 x 2 accumulator tiles - 16 MFMAs per four LDS
     // fragment reads and per K step; 256 rows double the MFMAs per weight fragment and per barrier.  MEASURED SLOWER (round 3, adversarial step at 36
     // clips): MRD band convolutions forward 79 -> 67 TFLOP/s, dX 68 -> 63, step 399.6 -> 402.0 ms (half the workgroups, 4 gather contexts per

@@ -27,6 +27,7 @@ struct ConvGeom { int T0, T1, s0, s1, p0, p1, O0, O1; };  // taps, strides, pads
 // forward gather: A[(b, o0, o1)][k = (t0*T1 + t1)*Cp + c] = X(b, o0*s0 + t0 - p0, o1*s1 + t1 - p1, c)
 struct ConvS {
     TView x; ConvGeom g; int M; FastDiv dO, dO1, dCp, dT1;
+    int fast;                   // set by conv_gemm: the engine's K step divides the channel count, so no step straddles a tap (ConvSU only)
     struct Ctx { int ok, i0, i1; unsigned base; };
     __device__ __forceinline__ Ctx make_ctx(int m) const {
         Ctx c; c.ok = 0; c.i0 = 0; c.i1 = 0; c.base = 0;
@@ -57,7 +58,7 @@ struct ConvS {
 // two compares and the selects.  Measured on the 1024 -> 1024 period layer: forward 105 -> 110 TFLOP/s (the same form in ConvTS / ConvTSP: dX 98 -> 103, 86 -> 94).
 struct ConvSU : ConvS {
     __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
-        if ((x.Cp & 15) != 0) return ConvS::load4(c, k0, kin);
+        if (!fast) return ConvS::load4(c, k0, kin);
         const int tap = dCp.div(k0);
         const int t0 = dT1.div(tap), t1 = tap - t0 * g.T1;
         const unsigned toff = (unsigned)((t0 * x.P1 + t1) * x.Cp + (k0 - tap * x.Cp));
@@ -70,6 +71,7 @@ struct ConvSU : ConvS {
 // transposed gather for dX: A[(b, i0, i1)][k = (t0*T1 + t1)*Cp + co] = dY(b, (i0 + p0 - t0) / s0, (i1 + p1 - t1) / s1, co) where divisible
 struct ConvTS {
     TView y; ConvGeom g; int D0, D1, M; FastDiv dI, dI1, dCp, dT1, dS0, dS1;     // D0, D1: extent of the INPUT map the rows walk
+    int fast;                   // set by conv_gemm (see ConvS)
     struct Ctx { int ok, i0, i1; unsigned base; };
     __device__ __forceinline__ Ctx make_ctx(int m) const {
         Ctx c; c.ok = 0; c.i0 = 0; c.i1 = 0; c.base = 0;
@@ -94,7 +96,7 @@ struct ConvTS {
         return ld4(y.p + (c.base + (unsigned)((o0 * y.P1 + o1) * y.Cp) + (unsigned)cc));
     }
     __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
-        if ((y.Cp & 15) == 0 && g.s0 == 1 && g.s1 == 1) {          // the stride-1 layers (the strided ones take the residue-class form): branch-free
+        if (fast && g.s0 == 1 && g.s1 == 1) {                       // the stride-1 layers (the strided ones take the residue-class form): branch-free
             const int tap = dCp.div(k0);
             const int t0 = dT1.div(tap), t1 = tap - t0 * g.T1;
             const int o0 = c.i0 - t0, o1 = c.i1 - t1;
@@ -120,6 +122,7 @@ __host__ __device__ inline int phase_ntaps(int r, int p, int s, int T) { const i
 
 struct ConvTSP {                // A[(b, q0, q1)][k = (a*n1 + b1)*Cp + co] = dY(b, q0 + c0 - a, q1 + c1 - b1, co)
     TView y; PhaseGeom g; int M; FastDiv dQ, dQ1, dCp, dN1;
+    int fast;                   // set by conv_gemm (see ConvS)
     struct Ctx { int ok, q0, q1; unsigned base; };
     __device__ __forceinline__ Ctx make_ctx(int m) const {
         Ctx c; c.ok = 0; c.q0 = 0; c.q1 = 0; c.base = 0;
@@ -137,7 +140,7 @@ struct ConvTSP {                // A[(b, q0, q1)][k = (a*n1 + b1)*Cp + co] = dY(
         return ld4(y.p + (c.base - (unsigned)((a * y.P1 + b1) * y.Cp) + (unsigned)cc));
     }
     __device__ __forceinline__ f32x4 load4(const Ctx& c, int k0, int kin) const {
-        if ((y.Cp & 15) == 0) {
+        if (fast) {
             const int tap = dCp.div(k0);
             const int a = dN1.div(tap), b1 = tap - a * g.n1;
             const unsigned toff = (unsigned)((a * y.P1 + b1) * y.Cp - (k0 - tap * y.Cp));
