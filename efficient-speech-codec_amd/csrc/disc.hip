@@ -706,7 +706,7 @@ extern "C" int escx_gan_term(const float* x, const float* ref, float* grad, int 
     hipStream_t st = (hipStream_t)stream;
     TView xv{const_cast<float*>(x), D0, D1, P1, Cp}, rv{const_cast<float*>(ref), D0, D1, P1, Cp}, gvw{grad, D0, D1, P1, Cp};
     const long long per = (long long)D0 * D1 * Cp;
-    const int bpc = (int)std::min<long long>(64, (per + 255) / 256);
+    const int bpc = (int)std::min<long long>(64, (per / 4 + 255) / 256);
     float* part = stream_scratch(st, 0, (size_t)B * bpc);
     if (!part) ESCX_FAIL(ESCX_ERR_HIP, "scratch allocation failed");
     hipLaunchKernelGGL(gan_term_kernel, dim3(bpc, B), dim3(256), 0, st, xv, rv, gvw, part, mode, target, C, bpc, 1.0f / ((float)C * D0 * D1), (const float*)nullptr);
@@ -722,7 +722,7 @@ extern "C" int escx_gan_term_grad(const float* x, const float* ref, const float*
     hipStream_t st = (hipStream_t)stream;
     TView xv{const_cast<float*>(x), D0, D1, P1, Cp}, rv{const_cast<float*>(ref), D0, D1, P1, Cp}, gvw{grad, D0, D1, P1, Cp};
     const long long per = (long long)D0 * D1 * Cp;
-    const int bpc = (int)std::min<long long>(64, (per + 255) / 256);
+    const int bpc = (int)std::min<long long>(64, (per / 4 + 255) / 256);
     hipLaunchKernelGGL(gan_term_kernel, dim3(bpc, B), dim3(256), 0, st, xv, rv, gvw, (float*)nullptr, mode, target, C, bpc, 1.0f / ((float)C * D0 * D1), g);
     return launch_ok("gan_term_grad");
 }

@@ -400,19 +400,24 @@ __global__ __launch_bounds__(256) void gan_term_kernel(TView x, TView ref, TView
                                                        int blocks_per_clip, float inv_n, const float* __restrict__ gscale) {
     const int b = blockIdx.y;
     __shared__ float red[256];
-    const long long per = (long long)x.D0 * x.D1 * x.Cp;
+    const int V = x.Cp / 4;                                     // four channels per thread and trip (Cp is a multiple of 4)
+    const long long per4 = (long long)x.D0 * x.D1 * V;
     const float gs = gscale ? gscale[b] * inv_n : inv_n;         // d (g_b * term_b) / d x: the upstream per-clip gradient folded in (backward-only launches)
     float acc = 0.f;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long long)blocks_per_clip * 256) {
-        const int c = (int)(i % x.Cp); long long r = i / x.Cp; const int i1 = (int)(r % x.D1); const int i0 = (int)(r / x.D1);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per4; i += (long long)blocks_per_clip * 256) {
+        const int c = 4 * (int)(i % V); const long long r = i / V; const int i1 = (int)(r % x.D1); const int i0 = (int)(r / x.D1);
         const size_t ox = (((size_t)b * x.D0 + i0) * x.P1 + i1) * x.Cp + c;
-        float gv = 0.f;
-        if (c < C) {
-            const float xv = x.p[ox];
-            if (mode == 0) { const float d = target - xv; acc += d * d; gv = -2.f * d * gs; }
-            else { const float d = xv - ref.p[(((size_t)b * ref.D0 + i0) * ref.P1 + i1) * ref.Cp + c]; acc += fabsf(d); gv = (d > 0.f ? gs : (d < 0.f ? -gs : 0.f)); }
+        const f32x4 xv = ld4(x.p + ox);
+        f32x4 rv = zero4(), gv = zero4();
+        if (mode != 0) rv = ld4(ref.p + (((size_t)b * ref.D0 + i0) * ref.P1 + i1) * ref.Cp + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                            // same per-element arithmetic as the scalar form (a thread now owns float4 groups)
+            if (c + e < C) {
+                if (mode == 0) { const float d = target - xv[e]; acc += d * d; gv[e] = -2.f * d * gs; }
+                else { const float d = xv[e] - rv[e]; acc += fabsf(d); gv[e] = (d > 0.f ? gs : (d < 0.f ? -gs : 0.f)); }
+            }
         }
-        if (grad.p) grad.p[(((size_t)b * grad.D0 + i0) * grad.P1 + i1) * grad.Cp + c] = gv;
+        if (grad.p) st4(grad.p + (((size_t)b * grad.D0 + i0) * grad.P1 + i1) * grad.Cp + c, gv);
     }
     if (!part) return;
     red[threadIdx.x] = acc;
