@@ -5,6 +5,7 @@
 // ncclAllGather we call come from the SAME RCCL instance - in a PyTorch process that is torch's bundled librccl (already mapped,
 // found by SONAME), in a plain C/C++ host it is the system one.  escx_set_rccl_library() overrides the name.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 
 #include <mutex>
@@ -40,7 +41,13 @@ int resolve() {
 
 extern "C" int escx_set_rccl_library(const char* path) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_allgather) ESCX_FAIL(ESCX_ERR_STATE, "RCCL is already resolved; call escx_set_rccl_library before the first collective");
+    if (g_allgather) {              // name the bound instance so that a caller can verify its communicator comes from the same one
+        Dl_info info{};
+        char real[4096];
+        const char* bound = (dladdr((void*)g_allgather, &info) && info.dli_fname) ? info.dli_fname : "?";
+        if (bound[0] == '/' && realpath(bound, real)) bound = real;
+        ESCX_FAIL(ESCX_ERR_STATE, "RCCL is already resolved (bound: %s); call escx_set_rccl_library before the first collective", bound);
+    }
     g_name = path ? path : "";
     return ESCX_OK;
 }

@@ -1090,7 +1090,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         if ((rc = get_map(h, H, W, -1, &map))) return rc;
         int mrc = -1;
         if (h->use_fused)
-            PROF("merge_fused", 2.0 * B * H2 * W * 2 * L.C * L.Cout, ((double)M * L.C + (double)B * H2 * W * L.Cout) * 4,
+            PROF("merge_fused" + (h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string()), 2.0 * B * H2 * W * 2 * L.C * L.Cout, ((double)M * L.C + (double)B * H2 * W * L.Cout) * 4,
                  mrc = rowgemm_fused(2, cur, y, L.sub_g, L.sub_b, L.sub_wf, map, B * H2 * W, H2 * W, tokens, L.C, L.Cp, L.CoutP, 0, 0, 0, 0, st));
         if (mrc != 0) {
         PROF("merge_ln", 0, 2.0 * M * L.C * 4,
@@ -1102,7 +1102,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
     } else if (L.scale == 2) {
         int src2 = -1;
         if (h->use_fused)
-            PROF("split_fused", 2.0 * M * L.C * 2 * L.Cout, (double)M * (L.C + 2 * L.Cout) * 4,
+            PROF("split_fused" + (h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string()), 2.0 * M * L.C * 2 * L.Cout, (double)M * (L.C + 2 * L.Cout) * 4,
                  src2 = rowgemm_fused(1, cur, y, L.sub_g, L.sub_b, L.sub_wf, nullptr, M, tokens, tokens, L.C, L.Cp, 2 * L.CoutP, 1, H, W, L.CoutP, st));
         if (src2 != 0) {
         PROF("split_ln", 0, 2.0 * M * L.C * 4,

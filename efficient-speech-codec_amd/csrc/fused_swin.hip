@@ -112,8 +112,92 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
 }
 
 // ---- fused LN + linear for PatchMerge / PatchSplit ----
+// Weight-stationary persistent form (fused_rowgemm.h).  Chunking over output tiles never changes an output element's arithmetic, so it
+// may depend on the batch: the LDS budget bounds a chunk from above, and small grids (few row groups) take more, smaller chunks so that
+// every SIMD gets a wave.
+constexpr int rowgemm_ws_wps(int regs) { return regs <= 64 ? 8 : (regs <= 80 ? 6 : (regs <= 96 ? 5 : (regs <= 128 ? 4 : (regs <= 168 ? 3 : (regs <= 256 ? 2 : 1))))); }
+
+template <int KP, int SEGS, int NW, bool PF>
+static void launch_rowgemm_ws(const RowGemmArgs& a, hipStream_t s) {
+    constexpr int KK = KP / 16;
+    constexpr int TM = KP <= 192 ? 2 : 1;                       // as rowgemm_fused_kernel: the accumulator split (and with it every sum) is unchanged
+    constexpr int REGS = TM * KK * 4 * (PF ? 2 : 1) + 100;      // operand tile(s) + what hipcc measurably needs around them (ring, accumulators, addresses, LayerNorm temporaries)
+    constexpr int WPS0 = rowgemm_ws_wps(REGS);
+    constexpr int WPS = (WPS0 * 4 < NW) ? (NW / 4) : WPS0;        // one workgroup must fit a CU
+    auto kern = rowgemm_ws_kernel<KP, SEGS, TM, NW, WPS, PF>;
+    static const int lds_cap = [] { const char* e = getenv("ESCX_RG_LDS_KB"); return (e && e[0] ? atoi(e) : 144) * 1024; }();
+    const int tile_bytes = KK * 1024;
+    const int max_tiles = std::max(1, lds_cap / tile_bytes);
+    const int n_groups = (a.M + 16 * TM - 1) / (16 * TM);
+    int chunks = (a.NT + max_tiles - 1) / max_tiles;
+    while (chunks < a.NT && (long long)n_groups * chunks < 1024) ++chunks;         // small grids: a wave for every SIMD
+    RowGemmArgs b = a;
+    b.nt_chunk = (a.NT + chunks - 1) / chunks;
+    chunks = (a.NT + b.nt_chunk - 1) / b.nt_chunk;
+    const int lds = b.nt_chunk * tile_bytes;
+    const int by_lds = std::max(1, (160 * 1024) / lds), by_waves = std::max(1, std::min(32 / NW, WPS * 4 / NW));
+    const int wg_per_cu = std::min(by_lds, by_waves);
+    int gx = std::max(1, 256 * wg_per_cu / chunks);
+    gx = std::min(gx, (n_groups + NW - 1) / NW);
+    {   // every wave the same number of row groups: with `it` passes over gx * NW waves, shrink gx until the last pass is (nearly) full
+        const int it = (n_groups + gx * NW - 1) / (gx * NW);
+        gx = std::max(1, (n_groups + it * NW - 1) / (it * NW));
+    }
+    static thread_local int lds_set = 0;
+    if (lds > lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); lds_set = 160 * 1024; }
+    hipLaunchKernelGGL(kern, dim3(gx, chunks), dim3(64 * NW), lds, s, b);
+}
+
+template <int KP, int SEGS>
+static bool launch_rowgemm_ws_variant(const RowGemmArgs& a, hipStream_t s) {
+    // 0 (default): streaming kernel; 2..5: weight-stationary form with (NW, PF) = (4, no), (4, yes), (8, no), (8, yes).  MEASURED (round 4, B = 36,
+    // profiles/r4_rowgemm_ab.txt): alone on the GPU the new forms are 5-25 % faster per launch, but in the product's two-stream execution the step gets
+    // 0.1-0.2 ms SLOWER (the co-running MLP / attention launches stretch by more than these kernels shrink), so they stay opt-in.
+    static const int mode = [] { const char* e = getenv("ESCX_ROWGEMM_WS"); return e && e[0] ? atoi(e) : 0; }();
+    if (mode == 0) return false;
+    constexpr int KK = KP / 16;
+    switch (mode) {
+        case 2: launch_rowgemm_ws<KP, SEGS, 4, false>(a, s); return true;
+        case 3: launch_rowgemm_ws<KP, SEGS, 4, true>(a, s); return true;
+        case 4: launch_rowgemm_ws<KP, SEGS, 8, false>(a, s); return true;
+        case 5: launch_rowgemm_ws<KP, SEGS, 8, true>(a, s); return true;
+        default: return false;
+    }
+}
+
+// Shared-rows form for the deep scales (fused_rowgemm.h (B)): 3 row tiles per workgroup, 3 output tiles per wave.
+template <int KP, int SEGS, int NW>
+static void launch_rowgemm_xs(const RowGemmArgs& a, hipStream_t s) {
+    constexpr int KK = KP / 16, R = 3, NTW = 3;
+    constexpr int WPS0 = KP <= 192 ? 3 : 2;
+    constexpr int WPS = (WPS0 * 4 < NW) ? (NW / 4) : WPS0;
+    auto kern = rowgemm_xs_kernel<KP, SEGS, R, NW, NTW, WPS>;
+    const int lds = R * KK * 1024;
+    static thread_local bool lds_set = false;
+    if (lds > 64 * 1024 && !lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); lds_set = true; }
+    hipLaunchKernelGGL(kern, dim3((a.M + 16 * R - 1) / (16 * R)), dim3(64 * NW), lds, s, a);
+}
+
+template <int KP, int SEGS>
+static bool launch_rowgemm_xs_variant(const RowGemmArgs& a, hipStream_t s) {
+    if constexpr (KP >= 144) {
+        static const bool on = [] { const char* e = getenv("ESCX_ROWGEMM_XS"); return e && e[0] == '1'; }();      // opt-in, see launch_rowgemm_ws_variant
+        if (!on || a.NT * (KP / 16) < 96) return false;         // matrices under ~96 KB stay with the weight-stationary form
+        switch ((a.NT + 2) / 3) {
+            case 3: launch_rowgemm_xs<KP, SEGS, 3>(a, s); return true;
+            case 4: launch_rowgemm_xs<KP, SEGS, 4>(a, s); return true;
+            case 6: launch_rowgemm_xs<KP, SEGS, 6>(a, s); return true;
+            case 8: launch_rowgemm_xs<KP, SEGS, 8>(a, s); return true;
+            default: return false;
+        }
+    }
+    return false;
+}
+
 template <int KP, int SEGS>
 static void launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
+    if (launch_rowgemm_xs_variant<KP, SEGS>(a, s)) return;
+    if (launch_rowgemm_ws_variant<KP, SEGS>(a, s)) return;
     constexpr int KK = KP / 16;
     constexpr int UT = KK <= 6 ? 4 : (KK <= 12 ? 2 : 1);
     constexpr int TM = KP <= 192 ? 2 : 1;

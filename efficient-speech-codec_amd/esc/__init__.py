@@ -7,7 +7,9 @@ import os as _os
 
 # Batch halves run on two HIP streams; give the runtime enough hardware queues that they do not share one with
 # RCCL's / torch's streams (only effective if set before the first HIP call of the process -- see DESIGN.md section 5).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+from . import _native as _native_mod  # noqa: E402
+
+_native_mod.ensure_hw_queues()             # also called by _native.load(), i.e. by esc.distributed / scripts.* users that never import this module first
 
 from .models import ESC, make_model  # noqa: F401,E402
 

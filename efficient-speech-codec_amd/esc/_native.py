@@ -98,6 +98,33 @@ SIGNATURES = {
 ESCX_ERR_INVALID_ARG, ESCX_ERR_UNSUPPORTED, ESCX_ERR_HIP, ESCX_ERR_STATE, ESCX_ERR_ASSERT = -1, -2, -3, -4, -5
 
 _lib = None
+HW_QUEUES_ENV = "GPU_MAX_HW_QUEUES"
+HW_QUEUES_WANTED = "8"
+
+
+def ensure_hw_queues() -> str:
+    """The whole-path calls run batch halves on two HIP streams next to torch's and RCCL's.  With ROCm's default of 4 hardware queues
+    two of them land on one queue and the overlap turns into serialisation (measured 5420 -> 3900 audio-s/s with an RCCL communicator
+    alive).  The variable is only read when HIP initialises, so it is set here - every entry into the library goes
+    through load() - unless the user chose a value; if HIP is already up without it, say so instead of silently running slow.
+    Returns the value in effect ("default" when HIP initialised before anything set it)."""
+    cur = os.environ.get(HW_QUEUES_ENV)
+    if cur:
+        return cur
+    late = False
+    try:
+        import sys
+        tc = sys.modules.get("torch")
+        late = bool(tc is not None and tc.cuda.is_initialized())
+    except Exception:                                      # pragma: no cover - torch absent or half-imported
+        late = False
+    if late:
+        import warnings
+        warnings.warn(f"{HW_QUEUES_ENV} was not set before HIP initialised: the two-stream overlap of esc.ESC.encode/decode may serialise "
+                      f"next to RCCL (export {HW_QUEUES_ENV}={HW_QUEUES_WANTED}, or import esc before the first CUDA call)", RuntimeWarning, stacklevel=3)
+        return "default"
+    os.environ[HW_QUEUES_ENV] = HW_QUEUES_WANTED
+    return HW_QUEUES_WANTED
 
 
 def lib_path() -> str:
@@ -109,6 +136,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    ensure_hw_queues()
     if not os.path.exists(_LIB_PATH):
         raise ImportError(
             f"{_LIB_PATH} not found: the HIP library is the only implementation of esc.ESC.encode/decode. "

@@ -80,6 +80,21 @@ def all_gather_codes(codes_local: torch.Tensor, group: Optional[dist.ProcessGrou
     return widen_codes(torch.cat([p.view(torch.int16)[:c] for p, c in zip(parts, counts)], dim=0))
 
 
+def _mapped_path(cdll) -> Optional[str]:
+    """Real path of a loaded shared object (from /proc/self/maps), None when it cannot be told."""
+    import os
+    name = os.path.basename(getattr(cdll, "_name", "") or "")
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.split(None, 5)[-1].strip() if line.count(" ") >= 5 else ""
+                if path.startswith("/") and os.path.basename(path).startswith(name.split(".so")[0]):
+                    return os.path.realpath(path)
+    except OSError:
+        pass
+    return None
+
+
 class AbiCodesGather:
     """The exchange step through the C ABI: `escx_allgather_codes` (csrc/collective.cpp) on an RCCL communicator of its own.
 
@@ -92,15 +107,22 @@ class AbiCodesGather:
     def __init__(self, model, device, group: Optional[dist.ProcessGroup] = None):
         import os
         from . import _native
-        self.lib, self.hd = model._handle(torch.device(device))
+        self.model = model                       # the native handle is re-fetched per call: load_state_dict / .to() rebuild it
         self.device = torch.device(device)
+        self.lib, _ = model._handle(self.device)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.rccl, tried = None, []
         for name in self._NAMES + (os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so.1"):
             try:
                 self.rccl = ctypes.CDLL(name)
                 rc = self.lib.escx_set_rccl_library(name.encode())
-                if rc not in (0, _native.ESCX_ERR_STATE):              # ERR_STATE: already resolved by an earlier collective (same search order)
+                if rc == _native.ESCX_ERR_STATE:
+                    # libescx resolved its RCCL earlier (a previous collective).  A communicator from another RCCL instance must never reach
+                    # it, so the instance this class loaded has to be that very library: compare what the dynamic loader mapped.
+                    mine, theirs = _mapped_path(self.rccl), (self.lib.escx_last_error() or b"").decode("utf-8", "replace")
+                    if mine is None or mine not in theirs:
+                        raise RuntimeError(f"libescx already bound an RCCL library ({theirs!r}); refusing to create a communicator on {name} ({mine})")
+                else:
                     _native.check(rc)
                 break
             except OSError as e:
@@ -125,10 +147,15 @@ class AbiCodesGather:
 
     def __call__(self, codes_local: torch.Tensor) -> torch.Tensor:
         from . import _native
+        if codes_local.dtype != torch.int64:
+            raise TypeError(f"codes must be int64 (escx_allgather_codes reads n int64 values), got {codes_local.dtype}")
+        if not codes_local.is_cuda or codes_local.device != self.device:
+            raise ValueError(f"codes must live on {self.device}, got {codes_local.device}")
         c = codes_local.contiguous()
         out = torch.empty((self.world * c.shape[0],) + tuple(c.shape[1:]), dtype=torch.int64, device=c.device)
+        _, hd = self.model._handle(self.device)
         with torch.cuda.device(self.device):
-            _native.check(self.lib.escx_allgather_codes(self.hd, ctypes.c_void_p(c.data_ptr()), c.numel(), ctypes.c_void_p(out.data_ptr()), self.world,
+            _native.check(self.lib.escx_allgather_codes(hd, ctypes.c_void_p(c.data_ptr()), c.numel(), ctypes.c_void_p(out.data_ptr()), self.world,
                                                         self.comm, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         return out
 

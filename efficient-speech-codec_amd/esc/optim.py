@@ -27,7 +27,9 @@ class FlatAdamW:
         if dev.type != "cuda":
             raise RuntimeError("FlatAdamW works on the HIP device the model lives on")
         self.device = dev
-        self.t = 0
+        self.t = 0                           # number of step() calls (= every parameter's step unless a checkpoint or set_inactive() says otherwise)
+        self._steps = None                   # per-parameter step counts, model.parameters() order (torch.optim.AdamW keeps `step` per parameter)
+        self._inactive = set()               # parameter positions that currently have no gradient (torch: p.grad is None -> the parameter is skipped)
         self._state = None
         self.last_grad_norm = None
         model.enable_flat_grads(dev)
@@ -51,17 +53,54 @@ class FlatAdamW:
         from .distributed import all_reduce_gradients
         all_reduce_gradients(gflat, self.group, force=self.force_allreduce)     # no-op unless torch.distributed is initialised with more than one rank
         self.t += 1
-        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        p = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + 4 * off)
         st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         with torch.cuda.device(self.device):
             clip = None
             if self.max_grad_norm is not None:
+                # inactive parameters hold zero gradients in the flat buffer: they add nothing to the norm, as a None gradient adds nothing in torch
                 _native.check(lib.escx_grad_norm_clip(p(gflat), gflat.numel(), float(self.max_grad_norm), p(aux), st))
                 clip = p(aux)
                 self.last_grad_norm = aux[0]
-            _native.check(lib.escx_adamw_step(p(flat), p(gflat), p(m), p(v), flat.numel(), self.t, float(self.lr), float(self.betas[0]),
-                                              float(self.betas[1]), float(self.eps), float(self.weight_decay), clip, st))
+            for off, n, t in self._runs(flat.numel()):
+                _native.check(lib.escx_adamw_step(p(flat, off), p(gflat, off), p(m, off), p(v, off), n, t, float(self.lr), float(self.betas[0]),
+                                                  float(self.betas[1]), float(self.eps), float(self.weight_decay), clip, st))
         self.model.note_params_updated()
+
+    # ---- per-parameter step counts / gradient-less parameters (torch.optim.AdamW semantics) -----------------------------------------------
+    def set_inactive(self, names=()):
+        """Parameters that have NO gradient in the coming steps (torch: `p.grad is None`, e.g. a module left out of the graph): torch's AdamW
+        skips them entirely - no weight decay, no moment decay, `step` not advanced - and so does step() here.  The training backward of this
+        package writes a (possibly zero) gradient for every parameter, which is what the reference's graph produces too (masked streams are
+        multiplied by 0., csrvq.py:42-44), so nothing is inactive unless the caller says so; reference checkpoints written by other loops can
+        carry such parameters and load_state_dict() keeps their step counts."""
+        pos = {k: i for i, (k, _) in enumerate(self.model.named_parameters())}
+        self._inactive = {pos[k] for k in names}
+
+    def _runs(self, total):
+        """[(flat offset, numel, step to apply)] covering the active parameters: ONE launch when every parameter shares a step count."""
+        if self._steps is None and not self._inactive:
+            return [(0, total, self.t)]
+        slices = self._param_slices()
+        if self._steps is None:
+            self._steps = [self.t - 1] * len(slices)
+        items = []
+        for i, sl in enumerate(slices):
+            if sl is None or i in self._inactive:
+                continue
+            self._steps[i] += 1
+            items.append((sl[0], sl[1], self._steps[i]))
+        items.sort()
+        runs = []
+        for off, n, t in items:
+            if runs and runs[-1][2] == t and runs[-1][0] + runs[-1][1] == off:
+                runs[-1] = (runs[-1][0], runs[-1][1] + n, t)
+            else:
+                runs.append((off, n, t))
+        if not self._inactive and len({t for _, _, t in runs}) == 1 and sum(n for _, n, _ in runs) == total:
+            self._steps = None; self.t = runs[0][2]           # every parameter is level again: back to the one-launch form
+            return [(0, total, self.t)]
+        return runs
 
     def zero_grad(self, set_to_none: bool = False):
         self.model.zero_flat_grads(self.device)
@@ -80,11 +119,11 @@ class FlatAdamW:
         flat, gflat, m, v, _ = self._buffers()
         slices = self._param_slices()
         state = {}
-        if self.t > 0:
-            for i, sl in enumerate(slices):
-                if sl is not None:
-                    off, n, shp = sl
-                    state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": m[off:off + n].view(shp).clone(), "exp_avg_sq": v[off:off + n].view(shp).clone()}
+        for i, sl in enumerate(slices):
+            t = self.t if self._steps is None else self._steps[i]
+            if sl is not None and t > 0:                  # torch creates a parameter's state at its first step WITH a gradient
+                off, n, shp = sl
+                state[i] = {"step": torch.tensor(float(t)), "exp_avg": m[off:off + n].view(shp).clone(), "exp_avg_sq": v[off:off + n].view(shp).clone()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False,
                  "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(slices))),
                  "max_grad_norm": self.max_grad_norm}            # extra key: torch ignores what it does not know
@@ -94,7 +133,7 @@ class FlatAdamW:
         """Accepts the torch AdamW layout (a reference checkpoint's `optimizer_state_dict`) and the flat layout earlier builds of this package wrote."""
         flat, gflat, m, v, _ = self._buffers()
         if "param_groups" not in sd:                        # flat layout {step, exp_avg, exp_avg_sq, lr, ...}
-            self.t = int(sd["step"]); m.copy_(sd["exp_avg"]); v.copy_(sd["exp_avg_sq"])
+            self.t = int(sd["step"]); self._steps = None; m.copy_(sd["exp_avg"]); v.copy_(sd["exp_avg_sq"])
             self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
             self.max_grad_norm = sd.get("max_grad_norm")
             return
@@ -109,14 +148,14 @@ class FlatAdamW:
         self.lr, self.betas, self.eps, self.weight_decay = g0["lr"], tuple(g0["betas"]), g0["eps"], g0["weight_decay"]
         self.max_grad_norm = g0.get("max_grad_norm", self.max_grad_norm)
         m.zero_(); v.zero_()
-        steps = set()
-        for pos, pid in enumerate(ids):                    # torch maps saved ids to parameters by position
+        steps = [0] * len(slices)                          # a parameter without a state entry never saw a gradient: step 0, zero moments (torch
+        for pos, pid in enumerate(ids):                    # creates the entry lazily); torch maps saved ids to parameters by position
             st = sd["state"].get(pid)
             if st is None or slices[pos] is None:
                 continue
             off, n, shp = slices[pos]
             m[off:off + n].copy_(st["exp_avg"].reshape(-1)); v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
-            steps.add(int(float(st["step"])))
-        if len(steps) > 1:
-            raise NotImplementedError(f"per-parameter step counts differ ({sorted(steps)}): the flat update applies one bias correction")
-        self.t = steps.pop() if steps else 0
+            steps[pos] = int(float(st["step"]))
+        live = {t for t, sl in zip(steps, slices) if sl is not None}
+        self.t = max(live) if live else 0
+        self._steps = None if len(live) <= 1 else steps   # torch keeps `step` per parameter: differing counts get their own bias corrections

@@ -247,7 +247,12 @@ def main():
         else:
             st.opt.load_state_dict(ck["optimizer_state_dict"])
         if "scheduler_state_dict" in ck and int(ck["scheduler_state_dict"].get("last_epoch", first)) != first:
-            raise ValueError(f"checkpoint step {first - 1} and scheduler position {ck['scheduler_state_dict'].get('last_epoch')} disagree")
+            # legitimate in reference checkpoints: Accelerate steps a prepared scheduler num_processes times per optimiser step (an N-GPU
+            # checkpoint has last_epoch = N * (step + 1)), and trainer_adv.py restarts `step` at 0 on a pretrain checkpoint.  This loop keys
+            # its schedule on `step` (one advance per optimiser step on any world size), so it continues from `step` and says so.
+            import warnings
+            warnings.warn(f"checkpoint step {first - 1} and scheduler position {ck['scheduler_state_dict'].get('last_epoch')} differ; "
+                          f"continuing the schedule from step {first}")
         for _ in range(first):                                          # the stream sampler and the data order continue where they stopped
             sample_streams(st.rng, st.dropout_rate, model.max_streams); next(data)
     evaluate = None

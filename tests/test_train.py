@@ -537,6 +537,62 @@ def test_checkpoint_layout_is_the_reference_trainers():
 
 
 @pytest.mark.gpu
+def test_flat_adamw_continues_a_torch_state_with_gradient_less_parameters():
+    """torch.optim.AdamW keeps `step` PER PARAMETER and skips parameters whose grad is None (no decay, no state entry before the first
+    gradient).  A state written by such a loop - differing step counts, missing entries - loads into FlatAdamW, and the next steps (with the
+    same parameters still gradient-less) follow torch's trajectory: per-parameter bias corrections, untouched inactive parameters."""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "efficient-speech-codec_amd"))
+    from esc.models import make_model
+    from esc.optim import FlatAdamW
+    twin = make_model(_cfg("tiny")); twin.load_state_dict(synth_state("tiny")); twin = twin.cuda().train()
+    names = [k for k, _ in twin.named_parameters()]
+    late = {k for k in names if k.startswith("quantizers.2.")}          # first gradient arrives at the third torch step
+    never = {k for k in names if k.startswith("quantizers.1.vqs.")}      # never sees a gradient
+    assert late and never
+    topt = torch.optim.AdamW(twin.parameters(), lr=1e-3, betas=(0.8, 0.9), weight_decay=0.05)
+    gen = torch.Generator().manual_seed(11)
+    def grads():
+        return {k: torch.randn(p.shape, generator=gen).cuda() * 1e-2 for k, p in twin.named_parameters()}
+    for n in range(3):
+        g = grads()
+        for k, p in twin.named_parameters():
+            p.grad = None if (k in never or (k in late and n < 2)) else g[k]
+        topt.step()
+    tsd = topt.state_dict()
+    steps = {float(v["step"]) for v in tsd["state"].values()}
+    assert steps == {1.0, 3.0} and len(tsd["state"]) == len(names) - len(never)
+    model = make_model(_cfg("tiny")); model.load_state_dict(twin.state_dict()); model = model.cuda().train()
+    opt = FlatAdamW(model, lr=5e-4)
+    opt.load_state_dict(tsd)
+    assert (opt.lr, opt.betas, opt.weight_decay) == (1e-3, (0.8, 0.9), 0.05) and opt.t == 3
+    opt.set_inactive(never)
+    before = {k: p.detach().clone() for k, p in model.named_parameters() if k in never}
+    for n in range(2):
+        g = grads()
+        for (k, p), (_, q) in zip(model.named_parameters(), twin.named_parameters()):
+            p.grad.copy_(torch.zeros_like(g[k]) if k in never else g[k])
+            q.grad = None if k in never else g[k].clone()
+        opt.step(); topt.step()
+    worst = max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(model.parameters(), twin.parameters()))
+    assert worst < 3e-7, worst
+    assert all(torch.equal(dict(model.named_parameters())[k].detach(), v) for k, v in before.items())       # no decay on gradient-less parameters
+    back, ref = opt.state_dict(), topt.state_dict()
+    assert sorted(back["state"]) == sorted(ref["state"])
+    assert all(float(back["state"][i]["step"]) == float(ref["state"][i]["step"]) for i in ref["state"])
+    # once every parameter has a gradient again the never-seen ones start at step 1 (torch creates their state lazily) - still per parameter
+    opt.set_inactive(())
+    g = grads()
+    for (k, p), (_, q) in zip(model.named_parameters(), twin.named_parameters()):
+        p.grad.copy_(g[k]); q.grad = g[k].clone()
+    opt.step(); topt.step()
+    worst = max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(model.parameters(), twin.parameters()))
+    assert worst < 3e-7, worst
+    assert {float(v["step"]) for v in opt.state_dict()["state"].values()} == {1.0, 4.0, 6.0}
+
+
+@pytest.mark.gpu
 def test_training_loop_reduces_the_loss():
     """scripts/train.py `Stepper` (quantisation dropout, frozen-codebook pre-training phase, optimiser renewal, HIP losses + FlatAdamW)
     on one fixed batch: finite losses throughout, frozen phase reports zero VQ losses, and the loss goes down."""
