@@ -156,6 +156,19 @@ def workload_name(strong, total, world, counts):
             f"(BASELINE configs[{1 if world == 1 else 3}])")
 
 
+def kernel_symbol(group):
+    """Launch-group name of the library's profiler -> the kernel template it launches (how the same kernel appears in rocprofv3's
+    kernel_stats.csv); the trailing template arguments (waves per workgroup, ...) depend on the grid and are left open."""
+    import re
+    m = re.match(r"(\w+)\[C=(\d+)\]", group)
+    if not m:
+        return group
+    cp = (int(m.group(2)) + 15) // 16 * 16
+    fam = {"mlp_fused": "mlp_fused_lds_kernel", "attn_fused": "attn_packed_kernel" if cp == 384 else "attn_fused_kernel",
+           "mlp_combine": "rows_combine_kernel", "attn_combine": "rows_combine_kernel"}.get(m.group(1), m.group(1))
+    return f"escx::{fam}<{cp}, ...>"
+
+
 def cpu_baseline(cfg, sd, x_cpu):
     """The oracle (CPU restatement of the reference; the reference itself never travels) on the host cores.
     Eager ATen on these small ops scales badly past a few dozen threads, so a short sweep picks the thread count."""
@@ -269,7 +282,7 @@ def train_adv_cpu_baseline(cfg, sd, disc_sd, x_cpu, weights):
                       f"autograd, CPU fp32, {thr} of {avail} host threads; no optimiser steps"}
 
 
-def run_train(args, rank, world, device, use_dist):
+def run_train(args, rank, world, device, use_dist, emit=True):
     """--mode train: the step of scripts/trainer_no_adv.py:95-118 (training forward, mel + complex-STFT + VQ losses, backward, clip 0.5,
     AdamW) on 36 clips per GPU, ESC-Base, fp32 like the reference (it has no AMP path).  With N > 1 the step is data-parallel: FlatAdamW
     averages the flat gradient buffer over the ranks (bucketed RCCL all-reduce, esc/distributed.py) before clipping, as DDP does for the reference."""
@@ -352,10 +365,12 @@ def run_train(args, rank, world, device, use_dist):
                       "steps_per_sec": round(args.steps / elapsed, 3)},
            "roofline": roofline,
            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else train_cpu_baseline(cfg, sd, x_cpu)}
+    if not emit:
+        return out
     print(json.dumps(out))
 
 
-def run_train_adv(args, rank, world, device, use_dist):
+def run_train_adv(args, rank, world, device, use_dist, emit=True):
     """--mode train_adv = BASELINE configs[4]: ESC-Large 9 kbps + the adversarial training step of scripts/trainer_adv.py:61-107 (generator update
     with LS-GAN + feature-matching terms through the DAC discriminator, then the discriminator update), batch 36, one MI355X.  fp32: the reference
     has no reduced-precision path (plain Accelerator()), so a bf16 number would be narrower than the reference's arithmetic."""
@@ -439,7 +454,40 @@ def run_train_adv(args, rank, world, device, use_dist):
                         "dominant_launch_group": kern_roof},
            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else
                            train_adv_cpu_baseline(cfg, sd, {k: v.detach().cpu() for k, v in disc.state_dict().items()}, x.cpu(), st.w)}
+    if not emit:
+        return out
     print(json.dumps(out))
+
+
+def other_workloads(args, device):
+    """the driver runs ONE command (codec mode).  After its timed region, the training step (ESC-Base, non-adversarial) and
+    BASELINE configs[4] (ESC-Large + adversarial step) run for a few steps each and ride along in the JSON line, so that their numbers are
+    driver-observed too.  Same code paths as --mode train / --mode train_adv, fewer steps, no CPU baseline."""
+    import copy
+    res = {}
+    for name, fn, steps, warm in (("train", run_train, 5, 2), ("train_adv", run_train_adv, 3, 1)):
+        a = copy.copy(args)
+        a.steps, a.warmup, a.no_cpu_baseline, a.profile_steps = steps, warm, True, 2
+        t0 = time.perf_counter()
+        try:
+            full = fn(a, 0, 1, device, False, emit=False)
+            roof = full["roofline"]
+            res[name] = {"ms_per_step": full["ms_per_step"], "value": full["value"], "unit": full["unit"], "steps": steps, "warmup": warm,
+                         "config": full["config"]["workload"], "dtype": full["dtype"],
+                         "frac": roof.get("whole_step_frac_executed_flops", roof.get("frac")),
+                         "frac_of": ("executed FLOPs of the whole step over the step time / fp32 MFMA peak" if "whole_step_frac_executed_flops" in roof
+                                     else "algorithmic discriminator-convolution FLOPs of the step over the WHOLE step time / fp32 MFMA peak (lower bound)"),
+                         "dominant_kernel": {k: (roof.get("dominant_launch_group") or roof).get(k) for k in ("kernel", "avg_us", "achieved", "frac")},
+                         "wall_s": None}
+            if name == "train":
+                res[name]["tape_gb"] = full["config"].get("tape_gb")
+        except Exception as e:                          # the codec line must survive a failure of the riders
+            res[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.synchronize(device)
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        res[name]["wall_s"] = round(time.perf_counter() - t0, 1)
+    return res
 
 
 def main():
@@ -460,6 +508,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=6)
     ap.add_argument("--skip-single-clip", action="store_true",
                     help="omit the B=1 latency measurement (used under rocprofv3 / --pmc so that per-kernel averages cover the 36-clip launches only)")
+    ap.add_argument("--skip-other-workloads", action="store_true",
+                    help="codec mode on one GPU: do not append the short training / adversarial-step blocks (\"other_workloads\") - for rocprofv3 runs")
     ap.add_argument("--skip-isolated", action="store_true",
                     help="omit the isolated-kernel timing pass (used under rocprofv3 so that its per-kernel averages cover two-stream launches only)")
     args = ap.parse_args()
@@ -533,15 +583,21 @@ def main():
         abi_gather = AbiCodesGather(model, device)
     gather_on = use_dist and not os.environ.get("ESCX_BENCH_SKIP_GATHER")
 
+    overlap_gather = os.environ.get("ESCX_BENCH_SERIAL_GATHER") != "1"     # default: the exchange rides a side stream under the local decode
+
     def step():
         codes, shape = model.encode(x, NUM_STREAMS)
         if not gather_on:
-            allc = codes
+            pend = None; allc = codes
         elif abi_gather is not None:
-            allc = abi_gather(codes)
+            pend = abi_gather.start(codes) if overlap_gather else None
+            allc = None if overlap_gather else abi_gather(codes)
         else:
-            allc = all_gather_codes(codes, force=use_dist, counts=counts)
+            pend = all_gather_codes(codes, force=use_dist, counts=counts, async_op=True) if overlap_gather else None
+            allc = None if overlap_gather else all_gather_codes(codes, force=use_dist, counts=counts)
         wave = model.decode(codes, shape)
+        if pend is not None:
+            allc = pend.wait()              # joins the caller's stream with the collective: the step ends when BOTH are done
         return allc, wave
 
     def sync():
@@ -552,11 +608,21 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    # "median of >= 20 runs".  The contract's number (`value`, `ms_per_step`) stays the wall clock of the ONE bracket around all K
+    # steps; a HIP event recorded on the caller's stream after every step (no host synchronisation inside the region) gives the per-step
+    # durations, whose median / min / max ride along.
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         allc, wave = step()
+        marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_stats = {"median_ms": round(per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2]), 3),
+                  "min_ms": round(per_step[0], 3), "max_ms": round(per_step[-1], 3), "n": len(per_step),
+                  "what": "HIP events on the caller's stream after every step of the timed region (device time per step, rank 0)"}
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -576,7 +642,12 @@ def main():
         recs = json.loads(lib.escx_profile_report(hd).decode())
         tot = sum(r["ms"] for r in recs)
         recs.sort(key=lambda r: -r["ms"])
-        dom = recs[0]
+        # Headline kernel, chosen DETERMINISTICALLY: three launch groups (the C = 45, 144 and 384 MLPs) hold 8-9 % of the GPU
+        # time each and swap the top spot from run to run, so "largest share" alone names a different kernel per run.  Rule: among the groups
+        # within 15 % of the largest share, the one with the most algorithmic FLOPs per step; the three largest groups are always listed.
+        near_top = [r for r in recs if r["ms"] >= 0.85 * recs[0]["ms"]]
+        dom = max(near_top, key=lambda r: (r["flops"], r["name"]))
+        top3 = recs[:3]
         avg_s = dom["ms"] / dom["calls"] * 1e-3
         flops_per_launch = dom["flops"] / dom["calls"]
         bytes_per_launch = dom["bytes"] / dom["calls"]
@@ -611,6 +682,11 @@ def main():
                          "note": (f"{streams} streams: each launch covers 1/{streams} of the batch and overlaps with the other part's kernels, "
                                   "so the duration includes sharing the GPU (ESCX_PROF_SERIAL=1 isolates kernels)") if streams > 1 else "single stream",
                          "share_of_gpu_time": round(dom["ms"] / tot, 4), "traffic_source": traffic_note,
+                         "selection": "most algorithmic FLOPs per step among the launch groups within 15 % of the largest share of GPU time",
+                         "kernel_symbol": kernel_symbol(dom["name"]),
+                         "top3": [{"kernel": r["name"], "kernel_symbol": kernel_symbol(r["name"]), "share_of_gpu_time": round(r["ms"] / tot, 4),
+                                   "avg_us": round(r["ms"] / r["calls"] * 1e3, 2),
+                                   "frac": round(r["flops"] / max(r["ms"], 1e-9) / 1e9 / (PEAK_F32_MFMA / 1e12), 4)} for r in top3],
                          "executed_gflop_per_clip": round(sum(r["flops"] for r in recs) / args.profile_steps / n_local / 1e9, 2)})
         if not args.skip_isolated:
             # the same kernel timed alone on the GPU (batch parts back to back instead of overlapped)
@@ -621,6 +697,11 @@ def main():
             torch.cuda.synchronize(device)
             lib.escx_profile_enable(hd, 0)
             iso = {r["name"]: r for r in json.loads(lib.escx_profile_report(hd).decode())}
+            for t in roofline["top3"]:
+                if t["kernel"] in iso:
+                    ri = iso[t["kernel"]]
+                    t["isolated_avg_us"] = round(ri["ms"] / ri["calls"] * 1e3, 2)
+                    t["isolated_frac"] = round(ri["flops"] / max(ri["ms"], 1e-9) / 1e9 / (PEAK_F32_MFMA / 1e12), 4)
             if dom["name"] in iso:
                 r = iso[dom["name"]]
                 iso_s = r["ms"] / r["calls"] * 1e-3
@@ -651,13 +732,16 @@ def main():
         out = {
             "metric": "audio-seconds/sec encode+decode, ESC-Base 9kbps 3s@16kHz",
             "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": n_ranks, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_median": step_stats["median_ms"],
+            "per_step": step_stats, "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name(strong, total_clips, world, counts),
                        "global_batch": total_clips, "clip_samples": N_SAMPLES, "num_streams": NUM_STREAMS,
-                       "parallelism": f"dp{world}" + ((" + all_gather(codes int16" + (", escx_allgather_codes C ABI)" if abi_gather is not None else ", torch.distributed)")) if gather_on else ""),
+                       "parallelism": f"dp{world}" + ((" + all_gather(codes int16" + (", escx_allgather_codes C ABI" if abi_gather is not None else ", torch.distributed")
+                                                        + (", overlapped with the local decode)" if overlap_gather else ")")) if gather_on else ""),
                        "weights": "deterministic name-keyed synthetic (esc/synth.py)",
                        "frames_per_sec": round(audio_s / elapsed * 200.0, 1),
+                       "batch_parts_on_streams": int(os.environ.get("ESCX_STREAMS", "2")), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "single_clip_gpu": single_gpu},
             "roofline": roofline,
         }
@@ -671,6 +755,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, sd, x_cpu)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not use_dist and not args.skip_other_workloads:
+            del model, x, allc, wave
+            import gc
+            gc.collect(); torch.cuda.empty_cache()
+            out["other_workloads"] = other_workloads(args, device)
         print(json.dumps(out))
     if abi_gather is not None:
         abi_gather.close()

@@ -12,8 +12,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "esc", "lib")
-OBJ_DIR = os.path.join(HERE, "build")
-LIB = os.path.join(OUT_DIR, "libescx.so")
+# tuning builds: ESCX_BUILD_TAG=foo (with ESCX_EXTRA_CXXFLAGS) writes libescx_foo.so next to the product library; ESCX_LIB_TAG=foo makes esc/_native.py load it
+TAG = os.environ.get("ESCX_BUILD_TAG", "")
+OBJ_DIR = os.path.join(HERE, "build" + ("_" + TAG if TAG else ""))
+LIB = os.path.join(OUT_DIR, "libescx" + ("_" + TAG if TAG else "") + ".so")
 SOURCES = ["escx_api.cpp", "collective.cpp", "train.hip", "disc.hip", "gemm_swin.hip", "gemm_misc.hip", "kernels_misc.hip", "fused_swin.hip"]
 HEADERS = ["train_kernels.h", "train_mlp_fused.h", "disc_kernels.h", "gemm_engine.h", "kernels.h", "launchers.h", "escx_internal.h", "fused_mlp.h", "fused_attn.h", "fused_rowgemm.h", "fused_deembed.h", os.path.join("..", "..", "include", "escx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -83,6 +83,9 @@ template <int CP, int TMW> constexpr int attn_min_waves() { return (CP * TMW <= 
 
 template <int CP, int MODE, int UT, int TMW, int NW>
 __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fused_kernel(AttnArgs a) {
+#ifdef ESCX_ATTN_PRIO
+    __builtin_amdgcn_s_setprio(ESCX_ATTN_PRIO);     // tuning builds: static wave priority against co-running launches of the other batch part
+#endif
     constexpr int KK = CP / 16;
     constexpr int TPG = (MODE == 2) ? 8 : 4;    // weight tiles per head group
     constexpr int NB = (MODE == 2) ? 6 : 3;     // bias rows per group
@@ -454,6 +457,9 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
 // ------------------------------------------------------------------------------------------------
 template <int CP, int UT, int NW>
 __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packed_kernel(AttnArgs a) {
+#ifdef ESCX_ATTN_PRIO
+    __builtin_amdgcn_s_setprio(ESCX_ATTN_PRIO);
+#endif
     constexpr int KK = CP / 16;
     constexpr int TPG = 4;
     static_assert(TPG % UT == 0, "stage size must divide the tiles of a head group");

@@ -32,6 +32,7 @@ struct DeembedArgs {
 
 template <int CP>
 __global__ __launch_bounds__(512) void deembed7_kernel(DeembedArgs a) {
+    ESCX_SET_PRIO_SMALL();
     constexpr int KK = CP / 16, TH = 8, TW = 32, HH = TH + 6, HW = TW + 6, PS = CP + 4;     // PS: pixel stride in dwords
     constexpr int NW = 8, NP = 7 * KK, NPW = (NP + NW - 1) / NW;
     __shared__ float xs[HH * HW * PS];

@@ -156,6 +156,9 @@ template <int CP, int TM> constexpr int mlp_min_waves() { return (CP * TM <= ESC
 
 template <int CP, int TM, int NW, int ABL = 0>      // ABL: timing-only ablation bits (never used by the product path)
 __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_lds_kernel(MlpArgs a) {
+#ifdef ESCX_MLP_PRIO
+    __builtin_amdgcn_s_setprio(ESCX_MLP_PRIO);      // tuning builds: static wave priority against co-running launches of the other batch part
+#endif
     constexpr int KK = CP / 16;
     constexpr int CH = 2 * KK;                  // 1 KiB fragments per hidden tile: KK of fc1 then KK of fc2
     constexpr int PD = 3;                       // LDS -> register prefetch distance (fragments)
@@ -365,6 +368,7 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
 // Second pass of the hidden-split MLP and of the head-group-split attention (dst may alias src).
 __global__ __launch_bounds__(256) void rows_combine_kernel(float* dst, const float* src, const float* __restrict__ partial,
                                                            const float* __restrict__ bias, long long M, int CP, int n) {
+    ESCX_SET_PRIO_SMALL();
     const long long n4 = M * CP / 4;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;

@@ -31,6 +31,7 @@ struct RowGemmArgs {
 
 template <int KP, int SEGS, int TM, int NW, int UT>
 __global__ __launch_bounds__(64 * NW) void rowgemm_fused_kernel(RowGemmArgs a) {
+    ESCX_SET_PRIO_SMALL();
     constexpr int KK = KP / 16;
     __shared__ f32x4 wbuf[2][UT * KK * 64];
     const int lane = threadIdx.x & 63;

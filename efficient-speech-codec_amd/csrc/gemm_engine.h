@@ -17,6 +17,14 @@
 #include <cstdlib>
 #include <type_traits>
 
+// tuning builds (-DESCX_SMALL_PRIO=n): static wave priority of the short, latency-bound launches (GEMM engine, merge / split, PVQ search, combine,
+// de-embedding) against the MFMA-dense fused MLP / attention launches of the other batch part they share the GPU with
+#ifdef ESCX_SMALL_PRIO
+#define ESCX_SET_PRIO_SMALL() __builtin_amdgcn_s_setprio(ESCX_SMALL_PRIO)
+#else
+#define ESCX_SET_PRIO_SMALL()
+#endif
+
 namespace escx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -35,6 +43,7 @@ template <class E> struct epi_is_rowwise<E, std::enable_if_t<E::ROWWISE>> : std:
 template <int BM, int BN, int BK, class Loader, class Epi>
 __global__ __launch_bounds__(256) void gemm_kernel(Loader ld, const float* __restrict__ Wt, int M, int Np,
                                                    int Kp, int k_per_z, Epi ep) {
+    ESCX_SET_PRIO_SMALL();
     static_assert(BM % 64 == 0 && BN % 16 == 0 && BK % 16 == 0, "tile shape");
     constexpr int LDS_LD = BK + 4;             // +1 access width: rows land on different bank groups
     constexpr int TM = BM / 64;                // 16-row MFMA tiles per wave along M

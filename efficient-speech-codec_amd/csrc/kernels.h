@@ -178,6 +178,7 @@ __device__ __forceinline__ bool arg_better(float d1, int i1, float d2, int i2) {
 
 template <int STEPS>
 __global__ __launch_bounds__(256) void pvq_search_kernel(SearchArgs a) {
+    ESCX_SET_PRIO_SMALL();
     constexpr int DT = 4 * STEPS;
     __shared__ float zs[16][DT + 1];
     __shared__ float zn2[16][DT];

@@ -7,7 +7,8 @@ import ctypes
 import os
 from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int16, c_int32, c_int64, c_void_p
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libescx.so")
+_LIB_TAG = os.environ.get("ESCX_LIB_TAG", "")          # tuning builds only (build.py ESCX_BUILD_TAG); the product library has no tag
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libescx" + ("_" + _LIB_TAG if _LIB_TAG else "") + ".so")
 MAX_SCALES = 8
 
 

@@ -47,8 +47,22 @@ def widen_codes(codes16: torch.Tensor) -> torch.Tensor:
     return codes16.to(torch.int64)
 
 
+class PendingCodes:
+    """An all-gather of codes in flight (`all_gather_codes(..., async_op=True)`): the collective runs on the communicator's own stream,
+    the caller's stream carries on (the local decode does not depend on the other ranks' codes).  `wait()` orders the caller's CURRENT
+    stream behind the collective (no host synchronisation) and returns the gathered int64 codes."""
+
+    def __init__(self, finish):
+        self._finish, self._out = finish, None
+
+    def wait(self) -> torch.Tensor:
+        if self._finish is not None:
+            self._out, self._finish = self._finish(), None
+        return self._out
+
+
 def all_gather_codes(codes_local: torch.Tensor, group: Optional[dist.ProcessGroup] = None, force: bool = False,
-                     counts: Optional[Sequence[int]] = None) -> torch.Tensor:
+                     counts: Optional[Sequence[int]] = None, async_op: bool = False):
     """(B_local, S, G, T) int64 on every rank -> (sum B_local, S, G, T) int64 on every rank, rank order.
 
     No host synchronisation: shard sizes are never exchanged.  Equal shards (the default) use one
@@ -56,7 +70,7 @@ def all_gather_codes(codes_local: torch.Tensor, group: Optional[dist.ProcessGrou
     the per-link xGMI bandwidth.  Ragged shards pass `counts` (every rank can compute them with `shard_bounds`) and
     gather zero-padded shards.  Collectives move bytes: RCCL/gloo have no int16 type, so the payload is viewed as uint8."""
     if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
-        return codes_local
+        return PendingCodes(lambda: codes_local) if async_op else codes_local
     world = dist.get_world_size(group)
     small = narrow_codes(codes_local)
     if counts is None or len(set(counts)) == 1:
@@ -65,19 +79,28 @@ def all_gather_codes(codes_local: torch.Tensor, group: Optional[dist.ProcessGrou
         # the collective variant is chosen from the backend UP FRONT (never by catching an exception around a collective: ranks
         # that disagree on the fallback would deadlock)
         if str(dist.get_backend(group)).lower() == "nccl":
+            if async_op:            # RCCL runs on the process group's stream behind an event of ours; our stream waits only in wait()
+                work = dist.all_gather_into_tensor(out.view(torch.uint8), src8, group=group, async_op=True)
+
+                def finish(work=work, out=out, keep=(small, src8)):
+                    work.wait()     # stream-orders the current stream behind the collective, does not block the host
+                    return widen_codes(out)
+                return PendingCodes(finish)
             dist.all_gather_into_tensor(out.view(torch.uint8), src8, group=group)
         else:
             parts = [torch.empty_like(src8) for _ in range(world)]
             dist.all_gather(parts, src8, group=group)
             out = torch.cat(parts, dim=0).view(torch.int16)
-        return widen_codes(out)
+        res = widen_codes(out)
+        return PendingCodes(lambda: res) if async_op else res
     assert len(counts) == world and counts[dist.get_rank(group)] == small.shape[0]
     mx = max(counts)
     pad = torch.zeros((mx,) + tuple(small.shape[1:]), dtype=torch.int16, device=small.device)
     pad[: small.shape[0]] = small
     parts = [torch.empty_like(pad.view(torch.uint8)) for _ in range(world)]
     dist.all_gather(parts, pad.view(torch.uint8), group=group)
-    return widen_codes(torch.cat([p.view(torch.int16)[:c] for p, c in zip(parts, counts)], dim=0))
+    res = widen_codes(torch.cat([p.view(torch.int16)[:c] for p, c in zip(parts, counts)], dim=0))
+    return PendingCodes(lambda: res) if async_op else res
 
 
 def _mapped_path(cdll) -> Optional[str]:
@@ -159,6 +182,23 @@ class AbiCodesGather:
                                                         self.comm, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         return out
 
+    def start(self, codes_local: torch.Tensor) -> "PendingCodes":
+        """The same exchange on a side stream: ordered behind what the caller's stream has produced so far, joined in `wait()`."""
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            out = self(codes_local)
+            codes_local.record_stream(self._side)
+        done = torch.cuda.Event()
+        done.record(self._side)
+
+        def finish(out=out, done=done):
+            torch.cuda.current_stream(self.device).wait_event(done)
+            return out
+        return PendingCodes(finish)
+
     def close(self):
         if self.comm:
             torch.cuda.synchronize(self.device)
@@ -168,10 +208,12 @@ class AbiCodesGather:
 
 
 def encode_sharded(model, x_local: torch.Tensor, num_streams: int = 6, group: Optional[dist.ProcessGroup] = None,
-                   counts: Optional[Sequence[int]] = None):
-    """Each rank encodes its own clips; returns (codes of the WHOLE batch on every rank, local codes, feat_shape)."""
+                   counts: Optional[Sequence[int]] = None, async_op: bool = False):
+    """Each rank encodes its own clips; returns (codes of the WHOLE batch on every rank, local codes, feat_shape).
+    async_op=True: the first element is a `PendingCodes` - decode the local shard first, `wait()` when the whole batch is needed, and the
+    exchange over xGMI hides under the decode."""
     codes_local, shape = model.encode(x_local, num_streams)
-    return all_gather_codes(codes_local, group, counts=counts), codes_local, shape
+    return all_gather_codes(codes_local, group, counts=counts, async_op=async_op), codes_local, shape
 
 
 # ---- data-parallel training: gradient exchange ----------------------------------------------------------------------------

@@ -52,6 +52,8 @@ def _worker(rank, world, port, total, ragged, out_dir, use_bench_plan=False):
     local, _ = orc.encode(x[lo:hi], 3)
     counts = [shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)] if ragged else None
     full = all_gather_codes(local, counts=counts)
+    pending = all_gather_codes(local, counts=counts, async_op=True)         # the overlapped form: same bytes once wait() has joined
+    assert torch.equal(pending.wait(), full) and pending.wait() is pending.wait()
     if rank == 0:
         ref, _ = orc.encode(x[: (total if ragged else world * (total // world))], 3)
         np.save(os.path.join(out_dir, f"ok_{int(ragged)}.npy"), np.array([int(torch.equal(full, ref)), full.shape[0], int(full.dtype == torch.int64)]))

@@ -2,7 +2,7 @@
 # sample sclk / power while the bench loop runs: tools/clock_probe.sh NAME [ENV=VAL ...]
 R=${GRAFT_REPO_ROOT:-/root/repo}; NAME=$1; shift
 cd $R
-env "$@" python bench.py --steps 2500 --warmup 5 --no-cpu-baseline --skip-isolated --skip-single-clip > /tmp/cp_$NAME.log 2>&1 &
+env "$@" python bench.py --steps 2500 --warmup 5 --no-cpu-baseline --skip-isolated --skip-single-clip --skip-other-workloads > /tmp/cp_$NAME.log 2>&1 &
 PID=$!
 sleep 20
 for i in 1 2 3 4 5 6; do

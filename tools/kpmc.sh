@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; NAME=$1; shift
 O=$R/gpurun_out/kpmc_tmp_$NAME; rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-PC="python $R/bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --skip-isolated --skip-single-clip"
+PC="python $R/bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --skip-isolated --skip-single-clip --skip-other-workloads"
 env ESCX_STREAMS=1 "$@" timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE -f csv -d $O/p1 -o p -- $PC > $O/log1.txt 2>&1
 env ESCX_STREAMS=1 "$@" timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -f csv -d $O/p2 -o p -- $PC > $O/log2.txt 2>&1
 python $R/tools/pmc_agg.py $O --json $O/agg.json --top 0 > /dev/null

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; NAME=$1; shift
 O=$R/gpurun_out/kprof_tmp_$NAME; rm -rf $O; mkdir -p $O $R/gpurun_out
 cd /tmp; export TMPDIR=/tmp
-env ESCX_STREAMS=${KPROF_STREAMS:-1} "$@" timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O -o p -- python $R/bench.py --steps ${KPROF_STEPS:-6} --warmup 2 --no-cpu-baseline --skip-isolated --skip-single-clip > $O/log.txt 2>&1
+env ESCX_STREAMS=${KPROF_STREAMS:-1} "$@" timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O -o p -- python $R/bench.py --steps ${KPROF_STEPS:-6} --warmup 2 --no-cpu-baseline --skip-isolated --skip-single-clip --skip-other-workloads > $O/log.txt 2>&1
 cp $(find $O -name "*kernel_stats.csv" | head -1) $R/gpurun_out/kprof_$NAME.csv 2>/dev/null
 tail -1 $O/log.txt | cut -c1-200
 python - <<PY

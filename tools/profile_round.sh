@@ -6,14 +6,14 @@ O=$R/gpurun_out/round; rm -rf $O; mkdir -p $O
 cd $R
 timeout 2700 python -m pytest tests -x -q -m gpu --durations=8 > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
 timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench.err | tail -1 > $O/bench.json; cut -c1-400 $O/bench.json
-ESCX_BENCH_BREAKDOWN=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep "^#" > $O/event_breakdown_isolated.txt
-ESCX_STREAMS=1 ESCX_BENCH_BREAKDOWN=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep "^#" > $O/event_breakdown_1stream.txt
+ESCX_BENCH_BREAKDOWN=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --skip-other-workloads 2>&1 | grep "^#" > $O/event_breakdown_isolated.txt
+ESCX_STREAMS=1 ESCX_BENCH_BREAKDOWN=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --skip-other-workloads 2>&1 | grep "^#" > $O/event_breakdown_1stream.txt
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --skip-isolated --skip-single-clip"
+CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --skip-isolated --skip-single-clip --skip-other-workloads"
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/prof -o p -- $CMD > $O/prof.log 2>&1
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv 2>/dev/null
 tail -1 $O/prof.log | cut -c1-300 > $O/prof_bench_line.txt
-PC="python $R/bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --skip-single-clip"
+PC="python $R/bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --skip-single-clip --skip-other-workloads"
 timeout 900 rocprofv3 --pmc FETCH_SIZE -f csv -d $O/pmc_fetch -o f -- $PC > $O/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE -f csv -d $O/pmc_write -o w -- $PC > $O/pmc_write.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -f csv -d $O/cal_fetch -o f -- python $R/tools/pmc_calib.py run > $O/cal_fetch.log 2>&1
@@ -29,7 +29,7 @@ cd $R
 ESCX_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_rccl_1rank.json
 timeout 900 python tools/bench_configs.py > $O/other_configs.json 2>$O/other_configs.err
 # strong-scaling mode at N = 1 (BASELINE configs[3] on one GPU) and the training step (BASELINE configs[4], first slice)
-timeout 900 python bench.py --global-batch 288 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_strong_n1.json
+timeout 900 python bench.py --global-batch 288 --steps 10 --warmup 3 --no-cpu-baseline --skip-other-workloads 2>/dev/null | tail -1 > $O/bench_strong_n1.json
 ESCX_BENCH_BREAKDOWN=1 timeout 900 python bench.py --mode train --steps 10 --warmup 3 2>$O/train.err | tail -1 > $O/bench_train.json; cut -c1-300 $O/bench_train.json
 grep "^#" $O/train.err | awk '!seen[$0]++' > $O/train_breakdown.txt
 cd /tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # datapath utilisation per kernel (SQ_INSTS_MFMA / SQ_INSTS_VALU / GRBM_GUI_ACTIVE), single stream, written to gpurun_out/sq_util.txt
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/squ; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-PC="python $R/bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --skip-isolated --skip-single-clip"
+PC="python $R/bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --skip-isolated --skip-single-clip --skip-other-workloads"
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU"; do
   i=$((i+1)); ESCX_STREAMS=${SQ_STREAMS:-1} timeout 900 rocprofv3 --pmc $set -f csv -d $O/p$i -o p -- $PC > $O/log$i.txt 2>&1
