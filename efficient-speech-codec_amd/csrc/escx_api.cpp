@@ -804,7 +804,7 @@ static int reserve_frames(escx_handle_s* h, int Btotal, int T, int set_clips_min
     add(spec); for (int i = 0; i < n; ++i) add(ehs[i]);
     add(work); add(xn); add(qkv); add(ob); add(hid); add(dec); add(dec); add(zp); add(deemb); add(rspec); add(frames);
     const size_t lterms = (size_t)c.max_streams * c.group_size * B * s.Tq;
-    add(stage); add(stage); add(codes); add(B); add(lterms);
+    add(stage); add(stage); add(codes); add(B); add(lterms); add(WsFields::N_TICKETS);
 
     ESCX_HIP(hipDeviceSynchronize());
     for (int si = 0; si < escx_handle_s::MAX_PARTS; ++si) {
@@ -824,6 +824,7 @@ static int reserve_frames(escx_handle_s* h, int Btotal, int T, int set_clips_min
         S.stageA = S.ws.take(stage); S.stageB = S.ws.take(stage);
         S.codes_tmp = reinterpret_cast<long long*>(S.ws.take(codes));
         S.loss = S.ws.take(B); S.loss_terms = S.ws.take(lterms);
+        S.tickets = reinterpret_cast<int*>(S.ws.take(WsFields::N_TICKETS));     // zero from the hipMemset above; every launch leaves them zero
         if (!S.loss) ESCX_FAIL(ESCX_ERR_STATE, "workspace sizing bug");
         S.shp = s;
     }
@@ -1068,11 +1069,13 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             static const int hs_nw8_cp = [] { const char* e = getenv("ESCX_MLP_HS_NW8_CP"); return e && e[0] ? atoi(e) : 384; }();
             static const int tm2_max = [] { const char* e = getenv("ESCX_MLP_TM2_MAXCP"); return e && e[0] ? atoi(e) : 0; }();
             static const int tm2_nw8 = [] { const char* e = getenv("ESCX_MLP_TM2_NW8"); return e && e[0] == '1'; }();
+            bool combined = false;
             int hs = (h->mlp_hs > 0 && L.hiddenP >= h->mlp_hs * L.Cp) ? h->mlp_hs : mlp_hs_for(tokens, L.hiddenP / 16, L.Cp);
             const int variant = h->mlp_variant >= 0 ? h->mlp_variant : (hs > 1 ? ((L.Cp >= hs_nw8_cp && mlp_split_nw(M, hs) == 8) ? 3 : 1) : (L.Cp <= tm2_max ? (tm2_nw8 ? 5 : 4) : mlp_variant_for(M, L.Cp)));
             PROF("mlp_fused" + tag, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
-                 frc = mlp_fused(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP, variant, &hs, h->hid, st));
-            if (frc == 0 && hs > 1)
+                 frc = mlp_fused(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP, variant, &hs, h->hid, st, nullptr,
+                                 h->tickets, WsFields::N_TICKETS, &combined));
+            if (frc == 0 && hs > 1 && !combined)
                 PROF("mlp_combine" + tag, 0, (hs + 2) * dM * L.Cp * f4, rows_combine(cur, cur, h->hid, bw.b2, M, L.Cp, hs, st));
             if (frc == 0) { src = cur; continue; }
         }

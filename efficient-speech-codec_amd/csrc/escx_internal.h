@@ -72,6 +72,8 @@ struct WsFields {                    // one workspace: every scratch buffer of t
     float *decA = nullptr, *decB = nullptr, *zpart = nullptr, *deemb = nullptr, *rspec = nullptr, *frames = nullptr;
     float *stageA = nullptr, *stageB = nullptr, *loss = nullptr, *loss_terms = nullptr;     // loss_terms: [max_streams][G][B*Tq] per-vector commitment terms
     long long* codes_tmp = nullptr;
+    int* tickets = nullptr;          // arrival counters of the in-launch combine of the hidden-split MLP (fused_mlp.h): zero between launches
+    static constexpr int N_TICKETS = 16384;
     std::vector<float*> enc_hs;
     size_t zpart_cap = 0;
 };

@@ -35,7 +35,17 @@ struct MlpArgs {
     // partial[hs][M][CP] and mlp_combine_kernel adds them in fixed order (deterministic, no atomics).
     int HS; float* partial;
     float* out;                 // nullptr: in place; otherwise x is left untouched and x + mlp(x) goes to out (training forward: x1 stays on the tape)
+    // Hidden split with the combine INSIDE the launch (round 4): one arrival counter per row block (zero between launches).  Every workgroup
+    // publishes its slab write-through and takes a ticket; the LAST arriver adds the slabs in slab-index order - ((P0 + P1) + P2) + bias, then
+    // + x, the arithmetic of rows_combine_kernel - and writes x.  nullptr: slabs only, the caller runs rows_combine_kernel.
+    int* tickets;
 };
+
+// buffer descriptor over [p, p + bytes): raw (stride 0) addressing; for write-through (sc1) stores of hand-off data
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(p, (short)0, (int)bytes, 0x00020000);
+}
 
 template <int CP, int TM>
 __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
@@ -154,7 +164,10 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
 // hidden tile takes ~5600 cycles for 3072 cycles of MFMA work).
 template <int CP, int TM> constexpr int mlp_min_waves() { return (CP * TM <= ESCX_MLP_OCC4) ? 4 : ((CP * TM <= 192) ? 3 : 1); }
 
-template <int CP, int TM, int NW, int ABL = 0>      // ABL: timing-only ablation bits (never used by the product path)
+// FC: compile the in-launch combine of the hidden split (a.tickets).  A SEPARATE instantiation on purpose: with that code in the body, hipcc
+// allocates registers differently for the whole kernel and the plain (slabs + rows_combine_kernel) path of every hidden-split width gets
+// 10-12 % slower (measured, profiles/r4_mlp_combine_ab.txt).
+template <int CP, int TM, int NW, int ABL = 0, bool FC = false>      // ABL: timing-only ablation bits (never used by the product path)
 __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_lds_kernel(MlpArgs a) {
 #ifdef ESCX_MLP_PRIO
     __builtin_amdgcn_s_setprio(ESCX_MLP_PRIO);      // tuning builds: static wave priority against co-running launches of the other batch part
@@ -336,7 +349,7 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
     }
 #undef ESCX_TS
 
-    if (HS > 1) {               // raw fc2 partial sums; bias + residual are applied by mlp_combine_kernel
+    if (HS > 1 && (!FC || a.tickets == nullptr)) {       // raw fc2 partial sums; bias + residual are applied by rows_combine_kernel
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             const int row = m0 + t * 16 + l15;
@@ -344,6 +357,56 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
             float* pr = a.partial + ((size_t)hs * a.M + row) * CP + 4 * lg;
 #pragma unroll
             for (int o = 0; o < KK; ++o) st4(pr + 16 * o, acc[o][t]);
+        }
+        return;
+    }
+    if constexpr (FC) if (HS > 1) {
+        // ---- combine by the last arriver (MI355X_MICROARCH.md, splitk-seam / publish-large rows; cdna_hip_programming.md Guideline 16 R1) ----
+        // Publish: 16-byte sc1 (write-through) stores, so no release fence is needed; EVERY storing wave drains its stores, then ONE lane takes
+        // the ticket with an agent-scope atomic.  The slab bytes are out of this XCD's L2 and in memory before the ticket is visible.
+        const size_t slab = (size_t)a.M * CP;                   // floats per slab; HS * slab * 4 < 2^32 is checked by the launcher
+        const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.partial, (unsigned)((size_t)HS * slab * sizeof(float)));
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int row = m0 + t * 16 + l15;
+            if (row >= a.M) continue;
+            const unsigned off = (unsigned)((((size_t)hs * a.M + row) * CP + 4 * lg) * sizeof(float));
+#pragma unroll
+            for (int o = 0; o < KK; ++o) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, acc[o][t]), rsrc, off + 64 * o, 0, 16 /* sc1 */);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __shared__ int ticket_s;
+        __syncthreads();
+        if (threadIdx.x == 0) ticket_s = __hip_atomic_fetch_add(a.tickets + rb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (ticket_s != HS - 1) return;
+        // Last arriver: every other slab of this row block is complete in memory.  ONE agent-scope acquire drops this CU's L1 (nobody on this
+        // XCD has read these lines in this launch, and launch boundaries invalidate L2), then plain loads.  The counter goes back to zero for
+        // the next launch (stream-ordered).
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(a.tickets + rb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int row = m0 + t * 16 + l15;
+            if (row >= a.M) continue;
+            const float* xr = a.x + (size_t)row * CP + 4 * lg;
+            f32x4 res[KK], v[KK];
+#pragma unroll
+            for (int o = 0; o < KK; ++o) res[o] = ld4(xr + 16 * o);
+            for (int h2 = 0; h2 < HS; ++h2) {                   // slab-index order, NOT arrival order: bit-identical to rows_combine_kernel
+                const float* pr = a.partial + ((size_t)h2 * a.M + row) * CP + 4 * lg;
+#pragma unroll
+                for (int o = 0; o < KK; ++o) {
+                    const f32x4 p = (h2 == hs) ? acc[o][t] : ld4(pr + 16 * o);      // this workgroup's own slab is still in registers
+                    v[o] = h2 == 0 ? p : v[o] + p;
+                }
+            }
+            float* orow = a.x + (size_t)row * CP + 4 * lg;
+#pragma unroll
+            for (int o = 0; o < KK; ++o) { v[o] += ld4(a.b2 + 16 * o + 4 * lg); st4(orow + 16 * o, res[o] + v[o]); }
         }
         return;
     }

@@ -17,7 +17,11 @@ template <int CP, int TM, int NW>
 static void launch_mlp_lds(const MlpArgs& a, hipStream_t s) {
     const int rows = 16 * TM * NW;
     const int hs = a.HS > 1 ? a.HS : 1;
-    hipLaunchKernelGGL((mlp_fused_lds_kernel<CP, TM, NW>), dim3(((a.M + rows - 1) / rows) * hs), dim3(64 * NW), 0, s, a);
+    if constexpr (TM == 1 && (CP == 192 || CP == 384) && (NW == 4 || NW == 8)) {      // the widths that take the hidden split
+        if (a.tickets) { hipLaunchKernelGGL((mlp_fused_lds_kernel<CP, TM, NW, 0, true>), dim3(((a.M + rows - 1) / rows) * hs), dim3(64 * NW), 0, s, a); return; }
+    }
+    MlpArgs b = a; b.tickets = nullptr;
+    hipLaunchKernelGGL((mlp_fused_lds_kernel<CP, TM, NW>), dim3(((a.M + rows - 1) / rows) * hs), dim3(64 * NW), 0, s, b);
 }
 
 // variant: 0 = wave-autonomous; otherwise LDS-staged with (TM, NW) = 1:(1,4) 2:(1,6) 3:(1,8) 4:(2,4) 5:(2,8)
@@ -49,13 +53,24 @@ void rows_combine(float* dst, const float* src, const float* partial, const floa
 
 // *hs: requested hidden split in, split actually used out (> 1: x is untouched, partial[hs][M][Cp] is filled, the caller runs rows_combine)
 int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* w1f, const float* b1,
-              const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, int* hs_io, float* partial, hipStream_t s, float* out) {
+              const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, int* hs_io, float* partial, hipStream_t s, float* out,
+              int* tickets, int n_tickets, bool* combined) {
     int hs = hs_io ? *hs_io : 1;
     const bool lds_width = Cp == 48 || Cp == 80 || Cp == 96 || Cp == 144 || Cp == 192 || Cp == 384;
     if (hs > 1 && (variant <= 0 || variant >= 100 || variant > 3 || !lds_width || !partial || (hiddenP / 16) % hs)) hs = 1;
     if (hs_io) *hs_io = hs;
+    // combine inside the launch (fused_mlp.h): needs a zeroed arrival counter per row block and slab offsets that fit the 32-bit buffer addressing
+    // OPT-IN (ESCX_MLP_FUSED_COMBINE=1).  MEASURED (round 4, B = 36, profiles/r4_mlp_combine_ab.txt): bit-identical to the two-launch form, but the
+    // last arriver's serial tail (drain of the write-through stores, ticket, acquire, two slab reads from memory) costs more than the combine launches
+    // it removes - mlp C = 192 / 384 +0.44 / +0.36 ms per step against 0.30 ms of combine launches, whole step 16.06 -> 16.45 ms.
+    static const bool fuse_combine = [] { const char* e = getenv("ESCX_MLP_FUSED_COMBINE"); return e && e[0] == '1'; }();
+    const int rows_per_wg = 16 * ((variant == 3) ? 8 : (variant == 2 ? 6 : 4));       // TM = 1 variants only (hs > 1 implies variant 1..3)
+    const int n_rb = (M + rows_per_wg - 1) / rows_per_wg;
+    const bool in_kernel = hs > 1 && fuse_combine && tickets && n_rb <= n_tickets && (size_t)hs * M * Cp * sizeof(float) < 0xffffffffull && !out &&
+                           (Cp == 192 || Cp == 384) && (variant == 1 || variant == 3);
+    if (combined) *combined = in_kernel;
     MlpArgs a{x, gamma, beta, reinterpret_cast<const f32x4*>(w1f), b1, reinterpret_cast<const f32x4*>(w2f), b2,
-              reinterpret_cast<const f32x4*>(wcf), M, C, hiddenP / 16, 1e-5f, g_mlp_trace, hs, partial, out};
+              reinterpret_cast<const f32x4*>(wcf), M, C, hiddenP / 16, 1e-5f, g_mlp_trace, hs, partial, out, in_kernel ? tickets : nullptr};
     if (out && (hs > 1 || variant >= 100)) return -1;       // a separate output: plain epilogues only (no hidden split, no ablation builds)
     if (variant >= 100) {      // timing-only ablations: variant = 100 + ABL bits
         const int abl = variant - 100;

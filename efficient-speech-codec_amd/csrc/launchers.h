@@ -28,7 +28,8 @@ constexpr int attn_windows_per_wave(int Cp) { return Cp <= ESCX_ATTN_TMW2_MAX ? 
 // ---- fused register-resident Swin kernels (fused_swin.hip); return -1 when the width is not instantiated ----
 int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* w1f, const float* b1,
               const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, int* hs_io, float* partial, hipStream_t s,
-              float* out = nullptr);      // out != nullptr: x untouched, x + mlp(x) goes to out (not with a hidden split)
+              float* out = nullptr,       // out != nullptr: x untouched, x + mlp(x) goes to out (not with a hidden split)
+              int* tickets = nullptr, int n_tickets = 0, bool* combined = nullptr);    // hidden split: arrival counters (zeroed) -> *combined = the launch did the combine itself
 void rows_combine(float* dst, const float* src, const float* partial, const float* bias, long long M, int Cp, int n, hipStream_t s);
 
 // LN + linear for PatchMerge (segs = 2, map gives the two source rows) / PatchSplit (segs = 1, split = 1: pixel-shuffled store)
