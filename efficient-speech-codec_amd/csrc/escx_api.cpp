@@ -1031,6 +1031,23 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
     float* cur = L.scale ? h->work : y;
     const float* src = x_in;
     int rc;
+    // Combine of a hidden-split MLP (fused_mlp.h), alternative form: not a launch of its own - the NEXT kernel of the layer (the following block's
+    // fused attention, or the merge / split) forms x + (((P0 + P1) + P2) + bias) while it loads its rows (same arithmetic, same order: bit-identical).
+    // Motivation: in the two-stream execution the 20 short combine launches per step cost 2.6x their isolated time (they queue behind the other batch
+    // part's resident workgroups).  Consumers without a combine-on-load instantiation get the explicit rows_combine launch.
+    // OPT-IN (ESCX_COMBINE_ON_LOAD=1).  MEASURED (round 4, B = 36, profiles/r4_mlp_combine_ab.txt): bit-identical, and slower - the consumers' gather
+    // prologues are latency-bound and badly coalesced (64-byte pieces), four row reads there (twice in the attention: LayerNorm input and shortcut) cost
+    // more than the streaming combine launch at 6 TB/s: attention C = 192 / 384 +0.14 / +0.13, merge / split +0.18 ms per step against 0.30 removed.
+    static const bool comb_on_load = [] { const char* e = getenv("ESCX_COMBINE_ON_LOAD"); return e && e[0] == '1'; }();
+    CombineOnLoad pend{nullptr, nullptr, 0, 0};
+    std::string pend_tag;
+    auto flush_pending = [&]() {                        // explicit combine launch (fallback)
+        if (pend.n > 0) {
+            const double dMp = M;
+            PROF("mlp_combine" + pend_tag, 0, (pend.n + 2) * dMp * L.Cp * sizeof(float), rows_combine(cur, cur, pend.partial, pend.bias, M, L.Cp, pend.n, st));
+            pend.n = 0;
+        }
+    };
     for (size_t j = 0; j < L.blocks.size(); ++j) {
         const BlockW& bw = L.blocks[j];
         const int shift = (j % 2 == 0) ? 0 : 2;                               // attention.py:29
@@ -1045,6 +1062,17 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             if (H == 2 && W % 4 == 0 && h->attn_pack) nw = -(h->attn_nw ? h->attn_nw : (L.Cp > 192 ? 4 : pick_nw((Ms / 16 + 1) / 2, 1)));    // packed half-window pairs
             const double proj_rows = nw < 0 ? dM : dMs;         // packed pairs project only the real tokens
             int gs = h->attn_gs > 0 ? (L.hiddenP >= h->attn_gs * L.Cp ? h->attn_gs : 1) : attn_gs_for(tokens, L.n_groups, L.hiddenP, L.Cp);
+            bool launched = false;
+            if (pend.n > 0) {                           // block input still split over the previous MLP's slabs: combine on load if this kernel can
+                int gs0 = gs;
+                const size_t n_recs = h->prof_recs.size();
+                PROF("attn_fused" + tag, 2 * proj_rows * dC * 4 * dC + 4 * dMs * 16 * dC, (2 + pend.n) * dM * dC * f4,
+                     frc = attn_fused(src, cur, L.Cp, L.C, L.attn_mode, L.n_groups, bw.ln1_g, bw.ln1_b, bw.waf, bw.baf, bw.bias_tab_f, bw.bproj,
+                                      map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, &gs0, h->hid, M, st, &pend));
+                if (frc == 0) { pend.n = 0; gs = gs0; launched = true; }
+                else { if (h->prof_recs.size() > n_recs) h->prof_recs.pop_back(); flush_pending(); }      // nothing was launched: no record, explicit combine
+            }
+            if (!launched)
             PROF("attn_fused" + tag, 2 * proj_rows * dC * 4 * dC + 4 * dMs * 16 * dC, 2 * dM * dC * f4,
                  frc = attn_fused(src, cur, L.Cp, L.C, L.attn_mode, L.n_groups, bw.ln1_g, bw.ln1_b, bw.waf, bw.baf, bw.bias_tab_f, bw.bproj,
                                   map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, &gs, h->hid, M, st));
@@ -1053,6 +1081,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
                 PROF("attn_combine" + tag, 0, (gs + 2) * dM * L.Cp * f4, rows_combine(cur, src, h->hid, bw.bproj, M, L.Cp, gs, st));
         }
         if (!attn_done) {
+        flush_pending();
         PROF("ln1_gather" + tag, 0, (dM + dMs) * dC * f4,
              ln_rows(1, src, h->xn, bw.ln1_g, bw.ln1_b, map, slots, tokens, Ms, L.C, L.Cp, st));
         PROF("gemm_qkv" + tag, 2 * dMs * dC * 3 * dC, (dMs * 4 * dC + 3 * dC * dC) * f4,
@@ -1075,8 +1104,10 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             PROF("mlp_fused" + tag, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
                  frc = mlp_fused(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP, variant, &hs, h->hid, st, nullptr,
                                  h->tickets, WsFields::N_TICKETS, &combined));
-            if (frc == 0 && hs > 1 && !combined)
-                PROF("mlp_combine" + tag, 0, (hs + 2) * dM * L.Cp * f4, rows_combine(cur, cur, h->hid, bw.b2, M, L.Cp, hs, st));
+            if (frc == 0 && hs > 1 && !combined) {
+                pend = CombineOnLoad{h->hid, bw.b2, (long long)M * L.Cp, hs}; pend_tag = tag;
+                if (!comb_on_load) flush_pending();
+            }
             if (frc == 0) { src = cur; continue; }
         }
         PROF("ln2" + tag, 0, 2 * dM * dC * f4,
@@ -1092,7 +1123,14 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         const int* map;
         if ((rc = get_map(h, H, W, -1, &map))) return rc;
         int mrc = -1;
-        if (h->use_fused)
+        if (h->use_fused && pend.n > 0) {
+            const size_t n_recs = h->prof_recs.size();
+            PROF("merge_fused" + (h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string()), 2.0 * B * H2 * W * 2 * L.C * L.Cout, ((double)M * L.C * (1 + pend.n) + (double)B * H2 * W * L.Cout) * 4,
+                 mrc = rowgemm_fused(2, cur, y, L.sub_g, L.sub_b, L.sub_wf, map, B * H2 * W, H2 * W, tokens, L.C, L.Cp, L.CoutP, 0, 0, 0, 0, st, &pend));
+            if (mrc == 0) pend.n = 0; else if (h->prof_recs.size() > n_recs) h->prof_recs.pop_back();
+        }
+        flush_pending();
+        if (h->use_fused && mrc != 0)
             PROF("merge_fused" + (h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string()), 2.0 * B * H2 * W * 2 * L.C * L.Cout, ((double)M * L.C + (double)B * H2 * W * L.Cout) * 4,
                  mrc = rowgemm_fused(2, cur, y, L.sub_g, L.sub_b, L.sub_wf, map, B * H2 * W, H2 * W, tokens, L.C, L.Cp, L.CoutP, 0, 0, 0, 0, st));
         if (mrc != 0) {
@@ -1104,7 +1142,14 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         *Hout = H2;
     } else if (L.scale == 2) {
         int src2 = -1;
-        if (h->use_fused)
+        if (h->use_fused && pend.n > 0) {
+            const size_t n_recs = h->prof_recs.size();
+            PROF("split_fused" + (h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string()), 2.0 * M * L.C * 2 * L.Cout, (double)M * (L.C * (1 + pend.n) + 2 * L.Cout) * 4,
+                 src2 = rowgemm_fused(1, cur, y, L.sub_g, L.sub_b, L.sub_wf, nullptr, M, tokens, tokens, L.C, L.Cp, 2 * L.CoutP, 1, H, W, L.CoutP, st, &pend));
+            if (src2 == 0) pend.n = 0; else if (h->prof_recs.size() > n_recs) h->prof_recs.pop_back();
+        }
+        flush_pending();
+        if (h->use_fused && src2 != 0)
             PROF("split_fused" + (h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string()), 2.0 * M * L.C * 2 * L.Cout, (double)M * (L.C + 2 * L.Cout) * 4,
                  src2 = rowgemm_fused(1, cur, y, L.sub_g, L.sub_b, L.sub_wf, nullptr, M, tokens, tokens, L.C, L.Cp, 2 * L.CoutP, 1, H, W, L.CoutP, st));
         if (src2 != 0) {
@@ -1115,6 +1160,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         }
         *Hout = 2 * H;
     } else {
+        flush_pending();
         *Hout = H;
     }
     return launch_ok(L.prefix.c_str());

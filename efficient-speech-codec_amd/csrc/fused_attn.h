@@ -40,7 +40,24 @@ struct AttnArgs {
     // stores its projection partial sums to partial[gs][rows][CP]; rows_combine_kernel adds them in fixed order.
     int GS; float* partial; int rows;
     unsigned long long* trace;  // tuning builds only (-DESCX_ATTN_TRACE): per-wave cycle sums of the head-group phases
+    // Combine-on-load (COMB instantiations, round 4): the block input is still split over the comb_n fc2 partial-sum slabs of the PREVIOUS block's
+    // hidden-split MLP.  x = src + (((P0 + P1) + ...) + bias) - the arithmetic of rows_combine_kernel, bit for bit - is formed wherever a row is
+    // read (LayerNorm input and shortcut), which removes the combine launch and one write + one read of the map between the two blocks.
+    const float* comb_partial; const float* comb_bias; long long comb_stride; int comb_n;
 };
+
+// One 16-byte piece of a block-input row: plain, or combined on the fly from the hidden-split MLP's slabs (see AttnArgs).
+template <bool COMB, class Args>
+__device__ __forceinline__ f32x4 load_block_input(const Args& a, size_t elem, int col) {
+    f32x4 x = ld4(a.src + elem);
+    if constexpr (COMB) {
+        f32x4 v = ld4(a.comb_partial + elem);
+        for (int h = 1; h < a.comb_n; ++h) v += ld4(a.comb_partial + (size_t)h * a.comb_stride + elem);
+        v += ld4(a.comb_bias + col);
+        x = x + v;
+    }
+    return x;
+}
 
 // Shift mask of one window for this lane's (query l15, keys 4lg..4lg+3): -100 where query and key carry different region labels
 // (attention.py:56-75, 233-236).  It only depends on the window, so it is built once per window, not once per head.
@@ -81,7 +98,7 @@ __device__ __forceinline__ f32x4 window_softmax(f32x4 s, f32x4 bias_row, f32x4 s
 #endif
 template <int CP, int TMW> constexpr int attn_min_waves() { return (CP * TMW <= 96) ? 4 : ((CP * TMW <= ESCX_ATTN_OCC3) ? 3 : ((CP * TMW <= 192) ? 2 : 1)); }
 
-template <int CP, int MODE, int UT, int TMW, int NW>
+template <int CP, int MODE, int UT, int TMW, int NW, bool COMB = false>
 __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fused_kernel(AttnArgs a) {
 #ifdef ESCX_ATTN_PRIO
     __builtin_amdgcn_s_setprio(ESCX_ATTN_PRIO);     // tuning builds: static wave priority against co-running launches of the other batch part
@@ -137,11 +154,11 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
             const int tk = a.map[wloc * 16 + l15];
             if (tk >= 0) tok[t] = b * a.tokens + tk;
         }
-        const float* xr = a.src + (size_t)(tok[t] < 0 ? 0 : tok[t]) * CP + 4 * lg;
+        const size_t xoff = (size_t)(tok[t] < 0 ? 0 : tok[t]) * CP + 4 * lg;
         float s = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            xf[t][kk] = tok[t] >= 0 ? ld4(xr + 16 * kk) : zero4();
+            xf[t][kk] = tok[t] >= 0 ? load_block_input<COMB>(a, xoff + 16 * kk, 16 * kk + 4 * lg) : zero4();
 #pragma unroll
             for (int e = 0; e < 4; ++e) s += xf[t][kk][e];            // pad channels are exact zeros
         }
@@ -437,11 +454,11 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
 #pragma unroll
     for (int t = 0; t < TMW; ++t) {
         if (tok[t] < 0) continue;
-        const float* sr = a.src + (size_t)tok[t] * CP + 4 * lg;
+        const size_t soff = (size_t)tok[t] * CP + 4 * lg;
         float* dr = a.dst + (size_t)tok[t] * CP + 4 * lg;
         f32x4 res[KK];          // all loads, then all stores (dst may alias src: interleaved, every store fences the next load)
 #pragma unroll
-        for (int o = 0; o < KK; ++o) { res[o] = ld4(sr + 16 * o); acc[o][t] += ld4(a.bproj + 16 * o + 4 * lg); }
+        for (int o = 0; o < KK; ++o) { res[o] = load_block_input<COMB>(a, soff + 16 * o, 16 * o + 4 * lg); acc[o][t] += ld4(a.bproj + 16 * o + 4 * lg); }
 #pragma unroll
         for (int o = 0; o < KK; ++o) st4(dr + 16 * o, res[o] + acc[o][t]);
     }
@@ -455,7 +472,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
 // key / value operands are rebuilt in registers: real slots come from the packed tile (a half-row swap for K, a
 // lane-group swap for V^T), padded slots are the bias.  Requires H == 2, W % 4 == 0, one head per tile (MODE 0).
 // ------------------------------------------------------------------------------------------------
-template <int CP, int UT, int NW>
+template <int CP, int UT, int NW, bool COMB = false>
 __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packed_kernel(AttnArgs a) {
 #ifdef ESCX_ATTN_PRIO
     __builtin_amdgcn_s_setprio(ESCX_ATTN_PRIO);
@@ -505,11 +522,11 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
     }
     f32x4 xf[KK];
     {
-        const float* xr = a.src + (size_t)(tok < 0 ? 0 : tok) * CP + 4 * lg;
+        const size_t xoff = (size_t)(tok < 0 ? 0 : tok) * CP + 4 * lg;
         float s = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            xf[kk] = tok >= 0 ? ld4(xr + 16 * kk) : zero4();
+            xf[kk] = tok >= 0 ? load_block_input<COMB>(a, xoff + 16 * kk, 16 * kk + 4 * lg) : zero4();
 #pragma unroll
             for (int e = 0; e < 4; ++e) s += xf[kk][e];
         }
@@ -677,11 +694,11 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
         return;
     }
     if (tok >= 0) {
-        const float* sr = a.src + (size_t)tok * CP + 4 * lg;
+        const size_t soff = (size_t)tok * CP + 4 * lg;
         float* dr = a.dst + (size_t)tok * CP + 4 * lg;
         f32x4 res[KK];
 #pragma unroll
-        for (int o = 0; o < KK; ++o) { res[o] = ld4(sr + 16 * o); acc[o] += ld4(a.bproj + 16 * o + 4 * lg); }
+        for (int o = 0; o < KK; ++o) { res[o] = load_block_input<COMB>(a, soff + 16 * o, 16 * o + 4 * lg); acc[o] += ld4(a.bproj + 16 * o + 4 * lg); }
 #pragma unroll
         for (int o = 0; o < KK; ++o) st4(dr + 16 * o, res[o] + acc[o]);
     }

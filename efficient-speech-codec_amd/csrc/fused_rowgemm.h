@@ -27,9 +27,11 @@ struct RowGemmArgs {
     int split, H, W, C2p;       // split != 0: out[(b, 2h+s, w)][c] with n = s*C2p + c ; else out[m][n], row stride 16*NT
     float eps;
     int nt_chunk;               // output tiles per workgroup column: blockIdx.y owns tiles [y * nt_chunk, (y + 1) * nt_chunk)
+    // combine-on-load (COMB instantiations): x is still split over the comb_n fc2 slabs of the last block's hidden-split MLP (see AttnArgs in fused_attn.h)
+    const float* comb_partial; const float* comb_bias; long long comb_stride; int comb_n;
 };
 
-template <int KP, int SEGS, int TM, int NW, int UT>
+template <int KP, int SEGS, int TM, int NW, int UT, bool COMB = false>
 __global__ __launch_bounds__(64 * NW) void rowgemm_fused_kernel(RowGemmArgs a) {
     ESCX_SET_PRIO_SMALL();
     constexpr int KK = KP / 16;
@@ -69,7 +71,19 @@ __global__ __launch_bounds__(64 * NW) void rowgemm_fused_kernel(RowGemmArgs a) {
         for (int kk = 0; kk < KK; ++kk) {
             const int k = 16 * kk + 4 * lg;
             const int s = k / SEGK, c = k - s * SEGK;
-            xf[t][kk] = sp[s] ? ld4(sp[s] + c) : zero4();
+            if constexpr (COMB) {
+                f32x4 x = zero4();
+                if (sp[s]) {
+                    const size_t elem = (size_t)(sp[s] - a.x) + c;
+                    f32x4 v = ld4(a.comb_partial + elem);
+                    for (int h2 = 1; h2 < a.comb_n; ++h2) v += ld4(a.comb_partial + (size_t)h2 * a.comb_stride + elem);
+                    v += ld4(a.comb_bias + c);
+                    x = ld4(sp[s] + c) + v;
+                }
+                xf[t][kk] = x;
+            } else {
+                xf[t][kk] = sp[s] ? ld4(sp[s] + c) : zero4();
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) sum += xf[t][kk][e];          // pad channels are exact zeros
         }

@@ -210,9 +210,22 @@ static bool launch_rowgemm_xs_variant(const RowGemmArgs& a, hipStream_t s) {
 }
 
 template <int KP, int SEGS>
-static void launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
-    if (launch_rowgemm_xs_variant<KP, SEGS>(a, s)) return;
-    if (launch_rowgemm_ws_variant<KP, SEGS>(a, s)) return;
+static int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
+    constexpr bool HAS_COMB = (KP == 384) || (KP == 192 && SEGS == 1);      // the scale changes that follow a hidden-split MLP (C = 192 / 384)
+    if (a.comb_n > 0) {
+        if constexpr (HAS_COMB) {
+            constexpr int KK = KP / 16;
+            constexpr int UT = KK <= 6 ? 4 : (KK <= 12 ? 2 : 1);
+            constexpr int TM = KP <= 192 ? 2 : 1;
+            constexpr int NW = 4;
+            RowGemmArgs b = a; b.nt_chunk = a.NT;
+            hipLaunchKernelGGL((rowgemm_fused_kernel<KP, SEGS, TM, NW, UT, true>), dim3((a.M + 16 * TM * NW - 1) / (16 * TM * NW), 1), dim3(64 * NW), 0, s, b);
+            return 0;
+        }
+        return ESCX_COMB_UNSUPPORTED;
+    }
+    if (launch_rowgemm_xs_variant<KP, SEGS>(a, s)) return 0;
+    if (launch_rowgemm_ws_variant<KP, SEGS>(a, s)) return 0;
     constexpr int KK = KP / 16;
     constexpr int UT = KK <= 6 ? 4 : (KK <= 12 ? 2 : 1);
     constexpr int TM = KP <= 192 ? 2 : 1;
@@ -230,32 +243,34 @@ static void launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
     b.nt_chunk = (b.nt_chunk + UT - 1) / UT * UT;                 // whole stages
     chunks = (a.NT + b.nt_chunk - 1) / b.nt_chunk;
     hipLaunchKernelGGL((rowgemm_fused_kernel<KP, SEGS, TM, NW, UT>), dim3((a.M + rows - 1) / rows, chunks), dim3(64 * NW), 0, s, b);
+    return 0;
 }
 
 int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, const float* beta, const float* wf, const int* map, int M,
-                  int rows_per_clip, int src_rows_per_clip, int C, int Cp, int Np, int split, int H, int W, int C2p, hipStream_t s) {
+                  int rows_per_clip, int src_rows_per_clip, int C, int Cp, int Np, int split, int H, int W, int C2p, hipStream_t s,
+                  const CombineOnLoad* comb) {
     RowGemmArgs a{x, out, gamma, beta, reinterpret_cast<const f32x4*>(wf), map, M, rows_per_clip, src_rows_per_clip, C, Cp, Np / 16,
-                  split, H, W, C2p, 1e-5f, Np / 16};
+                  split, H, W, C2p, 1e-5f, Np / 16, comb ? comb->partial : nullptr, comb ? comb->bias : nullptr, comb ? comb->stride : 0, comb ? comb->n : 0};
     const int KP = segs * Cp;
     if (segs == 1) {
         switch (KP) {
-            case 16: launch_rowgemm<16, 1>(a, s); return 0;
-            case 48: launch_rowgemm<48, 1>(a, s); return 0;
-            case 80: launch_rowgemm<80, 1>(a, s); return 0;
-            case 96: launch_rowgemm<96, 1>(a, s); return 0;
-            case 144: launch_rowgemm<144, 1>(a, s); return 0;
-            case 192: launch_rowgemm<192, 1>(a, s); return 0;
-            case 384: launch_rowgemm<384, 1>(a, s); return 0;
+            case 16: return launch_rowgemm<16, 1>(a, s);
+            case 48: return launch_rowgemm<48, 1>(a, s);
+            case 80: return launch_rowgemm<80, 1>(a, s);
+            case 96: return launch_rowgemm<96, 1>(a, s);
+            case 144: return launch_rowgemm<144, 1>(a, s);
+            case 192: return launch_rowgemm<192, 1>(a, s);
+            case 384: return launch_rowgemm<384, 1>(a, s);
             default: return -1;
         }
     }
     switch (KP) {
-        case 32: launch_rowgemm<32, 2>(a, s); return 0;
-        case 96: launch_rowgemm<96, 2>(a, s); return 0;
-        case 160: launch_rowgemm<160, 2>(a, s); return 0;
-        case 192: launch_rowgemm<192, 2>(a, s); return 0;
-        case 288: launch_rowgemm<288, 2>(a, s); return 0;
-        case 384: launch_rowgemm<384, 2>(a, s); return 0;
+        case 32: return launch_rowgemm<32, 2>(a, s);
+        case 96: return launch_rowgemm<96, 2>(a, s);
+        case 160: return launch_rowgemm<160, 2>(a, s);
+        case 192: return launch_rowgemm<192, 2>(a, s);
+        case 288: return launch_rowgemm<288, 2>(a, s);
+        case 384: return launch_rowgemm<384, 2>(a, s);
         default: return -1;
     }
 }
@@ -276,53 +291,69 @@ int deembed7_fused(const float* tok, int B, int H, int W, int Cp, const float* w
 
 // ---- fused window attention --------------------------------------------------------------------
 template <int CP, int MODE, int NW>
-static void launch_attn(const AttnArgs& a, hipStream_t s) {
+static int launch_attn(const AttnArgs& a, hipStream_t s) {
     constexpr int UT = CP <= 96 ? 4 : (CP <= 192 ? 2 : 1);
     constexpr int TMW = attn_windows_per_wave(CP);
     const int per_block = TMW * NW;
     const int gs = a.GS > 1 ? a.GS : 1;
+    if (a.comb_n > 0) {
+        if constexpr (CP == 192 && MODE == 1) {        // the C = 192 blocks that follow a hidden-split MLP (ESC-Base / Large: 24 heads of 8)
+            if (gs == 1) { hipLaunchKernelGGL((attn_fused_kernel<CP, MODE, UT, TMW, NW, true>), dim3((a.n_windows + per_block - 1) / per_block), dim3(64 * NW), 0, s, a); return 0; }
+        }
+        return ESCX_COMB_UNSUPPORTED;
+    }
     hipLaunchKernelGGL((attn_fused_kernel<CP, MODE, UT, TMW, NW>), dim3(((a.n_windows + per_block - 1) / per_block) * gs), dim3(64 * NW), 0, s, a);
+    return 0;
 }
 
 template <int CP>
 static int launch_attn_cp(int mode, int nw, const AttnArgs& a, hipStream_t s) {
     if (nw == 8) {
         switch (mode) {
-            case 0: launch_attn<CP, 0, 8>(a, s); return 0;
-            case 1: launch_attn<CP, 1, 8>(a, s); return 0;
-            case 2: launch_attn<CP, 2, 8>(a, s); return 0;
+            case 0: return launch_attn<CP, 0, 8>(a, s);
+            case 1: return launch_attn<CP, 1, 8>(a, s);
+            case 2: return launch_attn<CP, 2, 8>(a, s);
         }
     } else {
         switch (mode) {
-            case 0: launch_attn<CP, 0, 4>(a, s); return 0;
-            case 1: launch_attn<CP, 1, 4>(a, s); return 0;
-            case 2: launch_attn<CP, 2, 4>(a, s); return 0;
+            case 0: return launch_attn<CP, 0, 4>(a, s);
+            case 1: return launch_attn<CP, 1, 4>(a, s);
+            case 2: return launch_attn<CP, 2, 4>(a, s);
         }
     }
     return -1;
 }
 
 template <int CP, int NW>
-static void launch_attn_packed(const AttnArgs& a, hipStream_t s) {
+static int launch_attn_packed(const AttnArgs& a, hipStream_t s) {
     constexpr int UT = CP <= 96 ? 4 : (CP <= 192 ? 2 : 1);
     const int pairs = (a.n_windows + 1) / 2;
     const int gs = a.GS > 1 ? a.GS : 1;
+    if (a.comb_n > 0) {
+        if constexpr (CP == 384 && NW == 4) {
+            if (gs == 1) { hipLaunchKernelGGL((attn_packed_kernel<CP, UT, NW, true>), dim3((pairs + NW - 1) / NW), dim3(64 * NW), 0, s, a); return 0; }
+        }
+        return ESCX_COMB_UNSUPPORTED;
+    }
     hipLaunchKernelGGL((attn_packed_kernel<CP, UT, NW>), dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), 0, s, a);
+    return 0;
 }
 
 int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_groups, const float* gamma, const float* beta,
                const float* wf, const float* bqkv, const float* bias_tab, const float* bproj, const int* map, int slots, int tokens,
-               int n_windows, int nWh, int nWw, int shifted, float scale, int nw, int* gs_io, float* partial, int rows, hipStream_t s) {
+               int n_windows, int nWh, int nWw, int shifted, float scale, int nw, int* gs_io, float* partial, int rows, hipStream_t s,
+               const CombineOnLoad* comb) {
     int gs = gs_io ? *gs_io : 1;        // head-group split: same in/out convention as mlp_fused
     if (gs > 1 && (!partial || n_groups % gs)) gs = 1;
     if (gs_io) *gs_io = gs;
     AttnArgs a{src, dst, gamma, beta, reinterpret_cast<const f32x4*>(wf), bqkv, bias_tab, bproj, map, slots, tokens, n_windows,
-               nWh, nWw, shifted, C, n_groups, scale, 1e-5f, gs, partial, rows, g_mlp_trace};
+               nWh, nWw, shifted, C, n_groups, scale, 1e-5f, gs, partial, rows, g_mlp_trace,
+               comb ? comb->partial : nullptr, comb ? comb->bias : nullptr, comb ? comb->stride : 0, comb ? comb->n : 0};
     // H == 2 scale with no padding along W: two half-real windows share one tile (nw < 0 encodes "packing allowed", |nw| waves)
     if (nw < 0) {
         nw = -nw;
         if (mode == 0) {
-#define ESCX_PACK(CPV) case CPV: if (nw == 8) launch_attn_packed<CPV, 8>(a, s); else launch_attn_packed<CPV, 4>(a, s); return 0;
+#define ESCX_PACK(CPV) case CPV: return nw == 8 ? launch_attn_packed<CPV, 8>(a, s) : launch_attn_packed<CPV, 4>(a, s);
             switch (Cp) { ESCX_PACK(64) ESCX_PACK(96) ESCX_PACK(128) ESCX_PACK(192) ESCX_PACK(256) ESCX_PACK(384) default: break; }
 #undef ESCX_PACK
         }

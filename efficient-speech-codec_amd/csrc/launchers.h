@@ -33,8 +33,13 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
 void rows_combine(float* dst, const float* src, const float* partial, const float* bias, long long M, int Cp, int n, hipStream_t s);
 
 // LN + linear for PatchMerge (segs = 2, map gives the two source rows) / PatchSplit (segs = 1, split = 1: pixel-shuffled store)
+// Pending combine of a hidden-split MLP (fused_mlp.h): the consumer forms x + (((P0 + P1) + ...) + bias) while it loads its rows.  Kernels without a
+// combine-on-load instantiation return ESCX_COMB_UNSUPPORTED without launching: the caller then runs rows_combine and calls again without it.
+struct CombineOnLoad { const float* partial; const float* bias; long long stride; int n; };
+constexpr int ESCX_COMB_UNSUPPORTED = -3;
 int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, const float* beta, const float* wf, const int* map, int M,
-                  int rows_per_clip, int src_rows_per_clip, int C, int Cp, int Np, int split, int H, int W, int C2p, hipStream_t s);
+                  int rows_per_clip, int src_rows_per_clip, int C, int Cp, int Np, int split, int H, int W, int C2p, hipStream_t s,
+                  const CombineOnLoad* comb = nullptr);
 void loss_reduce(const float* terms, int n_slots, int G, int M, int Tq, float* out, hipStream_t s);     // per-clip commitment loss, fixed summation order
 void mlp_set_trace(unsigned long long* p);
 int test_fastdiv(int n, int d);       // host evaluation of gemm_engine.h FastDiv (gemm_misc.hip)
@@ -44,7 +49,8 @@ int deembed7_fused(const float* tok, int B, int H, int W, int Cp, const float* w
 // mode: 0 one head (<=16 dims) per tile, 1 two heads (<=8 dims) per tile, 2 one head (<=32 dims) over two tiles
 int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_groups, const float* gamma, const float* beta,
                const float* wf, const float* bqkv, const float* bias_tab, const float* bproj, const int* map, int slots, int tokens,
-               int n_windows, int nWh, int nWw, int shifted, float scale, int nw, int* gs_io, float* partial, int rows, hipStream_t s);
+               int n_windows, int nWh, int nWw, int shifted, float scale, int nw, int* gs_io, float* partial, int rows, hipStream_t s,
+               const CombineOnLoad* comb = nullptr);
 
 // ---- everything else that is a contraction (gemm_misc.hip) ----
 void gemm_frames(const float* wave, int B, int L, int T, int hop, int off, const float* W, int Np, int Kp, float* out, hipStream_t s);
