@@ -1011,7 +1011,12 @@ static int mlp_hs_for(int tokens_per_clip, int HT, int Cp) { return (tokens_per_
 // MFMA-bound on its own: three workgroups per pair put a small grid on three times the CUs, a full grid gains nothing and pays the
 // combine).  The throughput configurations are the ones BASELINE quotes, so the split is OFF by default; all parity tests and the
 // 576-clip sweep are bit-exact with it on, a latency-bound deployment can switch it on.
-static int attn_gs_for(int tokens_per_clip, int n_groups, int hiddenP, int Cp) { static const int lim = [] { const char* e = getenv("ESCX_ATTN_GS_TOKENS"); return e && e[0] ? atoi(e) : 0; }(); return (tokens_per_clip <= lim && n_groups % 3 == 0 && hiddenP >= 3 * Cp) ? 3 : 1; }
+// Round 4: decided on parity evidence, not on the 36-clip throughput.  Oracle sweeps of BOTH settings on the same clips
+// (profiles/r4_parity_sweep_*_gs_{on,off}.log): ESC-Base 576 clips - split ON 576 / 576 bit-exact, split OFF 575 / 576 (one near-tie code); ESC-Large 288
+// clips - 286 / 288 either way (the same two near-tie clips).  The split is therefore ON for every batch size (geometry rule: maps of up to 600
+// tokens per clip = the C = 384 scale of a 3 s clip).  Cost / gain on the day's build (tools/ab.py): 36 clips 15.79 -> 15.87 ms (+0.5 %), 8 clips
+// 5.59 -> 5.18 ms, one clip 3.52 -> 3.12 ms.  ESCX_ATTN_GS_TOKENS=0 switches it off.
+static int attn_gs_for(int tokens_per_clip, int n_groups, int hiddenP, int Cp) { static const int lim = [] { const char* e = getenv("ESCX_ATTN_GS_TOKENS"); return e && e[0] ? atoi(e) : 600; }(); return (tokens_per_clip <= lim && n_groups % 3 == 0 && hiddenP >= 3 * Cp) ? 3 : 1; }
 static int mlp_variant_for(int M, int Cp) { return pick_nw((M + 15) / 16, 1, mlp_cap(Cp)) == 8 ? 3 : 1; }     // fused_swin.hip: 1 = (TM 1, NW 4), 3 = (TM 1, NW 8)
 // The hidden-split MLP at C >= 384: 8-wave workgroups when that fills one dispatch round anyway (36-clip batches: 255 workgroups, half the
 // weight DMA per wave), 4-wave ones for small grids - with 8 waves two waves share every SIMD's MFMA pipe and a 15-workgroup launch takes

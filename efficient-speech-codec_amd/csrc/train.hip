@@ -23,6 +23,13 @@
 using namespace escx;
 
 namespace {
+// The training forward runs the FOLDED de-embedding (composed on the device by refresh_from_flat) when the geometry has one; the tape is sized
+// without the fine map then.  ESCX_TRAIN_DEEMBED_COMPOSED=0: the reference's two convolutions (A/B baseline).
+bool train_deembed_composed(const escx_handle_s* h) {
+    static const bool want = [] { const char* e = getenv("ESCX_TRAIN_DEEMBED_COMPOSED"); return !(e && e[0] == '0'); }();
+    return want && h->cfg.in_dim * h->Q <= 16 && h->dcv_w && h->dcv_b && h->dcc_w && h->dcc_b && h->dch_w;
+}
+
 
 struct BlockTape { float *x0, *xn1, *qkv, *obuf, *x1, *xn2, *hpre, *hact, *x2; };
 struct LayerTape { std::vector<BlockTape> blk; float* sub_xn = nullptr; float* y = nullptr; int H = 0, Hout = 0; };
@@ -33,6 +40,7 @@ struct TrainTape {
     int B = 0, L = 0, S = 0, freeze = 0;
     Shapes shp;
     float *spec = nullptr, *pe_pre = nullptr, *tok0 = nullptr, *deemb = nullptr, *rspec = nullptr, *terms = nullptr;
+    bool composed = false;                   // the forward ran the folded de-embedding: no fine map (deemb) on the tape
     long long* codes = nullptr;              // (B, max_streams, G, Tq)
     std::vector<LayerTape> layers;           // 2n
     std::vector<float*> enc_hs;              // n
@@ -353,7 +361,7 @@ size_t tape_bytes(escx_handle_s* h, const Shapes& s) {
     add((size_t)c.max_streams * c.group_size * Mq);                  // loss terms
     add((size_t)B * c.max_streams * c.group_size * s.Tq * 2);        // codes (int64)
     const int T2 = c.patch_t * s.W, F2 = c.patch_f * s.H0;
-    add((size_t)B * T2 * F2 * h->C0p);                               // de-embedding fine map
+    if (!train_deembed_composed(h)) add((size_t)B * T2 * F2 * h->C0p);       // de-embedding fine map (two-convolution form only)
     add((size_t)B * T2 * c.in_dim * h->Fp);                          // rspec
     // backward scratch (upper bounds): activations-sized gradients, dW partials, LN / attention partials, frames
     const size_t fine = (size_t)B * T2 * F2 * h->C0p;
@@ -478,7 +486,16 @@ int refresh_from_flat(escx_handle_s* h, const float* flat, hipStream_t st) {
         const int rows = c.group_size * c.codebook_size;
         hipLaunchKernelGGL(codebook_normalize_kernel, dim3(blocks_for(rows)), dim3(256), 0, st, q.cbraw, q.cbn, q.c2, rows, q.d, q.dt, c.l2norm);
     }
-    h->composed_stale = true;           // the folded de-embedding of the inference path is a host-side fp64 product: not refreshed here
+    // the folded 7x7 de-embedding (inference path, and the training forward below) from the refreshed convolution weights: fp64 on the device, the
+    // host fold's summation order - bit-identical to escx_finalize_params, so the model decodes correctly after device-side optimiser steps
+    if (c.in_dim * h->Q <= 16 && h->dcv_w && h->dcc_w && h->dch_w) {
+        const long long n = (long long)16 * c.in_dim * h->Q * 49 * h->C0 + 16 * c.in_dim * h->Q;
+        hipLaunchKernelGGL(deembed_compose_kernel, dim3(blocks_for(n)), dim3(256), 0, st, h->dc1_w, h->dc1_b, h->dc2_w, h->dc2_b, h->dcv_w, h->dcv_b,
+                           h->dcc_w, h->dcc_b, h->dch_w, h->C0, h->C0p, c.patch_f, c.patch_t, c.in_dim);
+        h->composed_stale = false;
+    } else {
+        h->composed_stale = true;       // no folded form for this geometry: the inference path needs escx_load_flat_params(full = 1)
+    }
     return launch_ok("refresh_from_flat");
 }
 
@@ -586,13 +603,30 @@ int train_forward_impl(escx_handle_s* h, const float* wave, int B, int L, int S,
     if ((rc = layer_fwd(h, h->layers[2 * n - 1], T.layers[2 * n - 1], dec, B, H, s.W, st))) return rc;
     T.post = T.layers[2 * n - 1].y;
 
-    // de-embedding as the two convolutions of the reference (scale.py:73-81; the folded 7x7 form of the inference path has no separate weights)
+    // De-embedding (scale.py:73-81).  Round 4: the FOLDED 7x7 form of the inference path (composed on the device from the current weights in
+    // refresh_from_flat): 11x fewer FLOPs than the two convolutions, and the 270-channel fine map (0.75 GB at 36 clips) never exists - the backward
+    // gets conv3x3's weight gradient from the product it already forms for conv5x5's (deembed_x_from_r_kernel).  The two convolutions of the
+    // reference remain for geometries without a folded form and as the A/B baseline (ESCX_TRAIN_DEEMBED_COMPOSED=0).
     const int F2 = c.patch_f * s.H0;
-    T.deemb = tp.take((size_t)B * T2 * F2 * h->C0p);
+    T.composed = train_deembed_composed(h);
+    if (T.composed && h->composed_stale) ESCX_FAIL(ESCX_ERR_STATE, "folded de-embedding is stale in a training forward (refresh_from_flat did not run)");
+    T.deemb = T.composed ? nullptr : tp.take((size_t)B * T2 * F2 * h->C0p);
     T.rspec = tp.take((size_t)B * T2 * c.in_dim * h->Fp);
-    if (!T.rspec) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small");
+    if (!T.rspec || (!T.composed && !T.deemb)) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small");
     ESCX_HIP(hipMemsetAsync(T.rspec, 0, (size_t)B * T2 * c.in_dim * h->Fp * sizeof(float), st));       // Fp - F pad columns stay zero
-    {
+    if (T.composed) {
+        const double tk = (double)B * s.H0 * s.W;
+        int hrc = -1;
+        PROF("T.deembed_composed7x7", 2.0 * tk * 49 * h->C0 * c.in_dim * h->Q, (tk * h->C0 + tk * c.in_dim * h->Q) * 4,
+             hrc = deembed7_fused(T.post, B, s.H0, s.W, h->C0p, h->dch_w, h->dcc_b, T.rspec, c.patch_f, c.patch_t, c.in_dim, h->Fp, st));
+        if (hrc != 0)
+            PROF("T.deembed_composed7x7", 2.0 * tk * 49 * h->C0 * c.in_dim * h->Q, (tk * h->C0 + tk * c.in_dim * h->Q) * 4,
+                 gemm_deembed_composed(T.post, B, s.H0, s.W, h->C0p, h->dcc_w, T.rspec, h->dcc_b, c.patch_f, c.patch_t, c.in_dim, h->Fp, st));
+        int brc = 0;
+        PROF("T.deembed_border", 0, 0,
+             brc = deembed_border(T.post, h->dcv_w, h->dcv_b, T.rspec, B, s.H0, s.W, h->C0, h->C0p, c.patch_f, c.patch_t, c.in_dim, h->Fp, st));
+        if (brc) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "patch size unsupported by the de-embedding border kernel");
+    } else {
         const double toks = (double)B * s.H0 * s.W, pix = toks * h->Q;
         PROF("T.deembed_conv5x5", 2.0 * toks * 25 * h->C0 * h->C0 * h->Q, (toks * h->C0 + pix * h->C0) * 4,
              gemm_conv_deembed1(T.post, B, s.H0, s.W, h->C0p, h->dc1_w, h->Q * h->C0p, T.deemb, h->dc1_b, c.patch_f, c.patch_t, st));
@@ -897,12 +931,20 @@ int train_backward_impl(escx_handle_s* h, const float* d_wave, const float* d_re
         // needed - one 20 x C0p contraction per sub-pixel q instead of the full 128 x Q*C0p product; db2 = the centre-tap column sums of P
         float* X = sc.take((size_t)Q * DEP_J * h->C0p);
         if (!X) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
+        if (T.composed) {               // no saved fine map: X from R, the conv5x5 weights and the column sums of P (train_kernels.h)
+            ESCX_HIP(hipMemsetAsync(X, 0, (size_t)Q * DEP_J * h->C0p * sizeof(float), st));
+            const int nj = c.in_dim * 9;
+            PROF("B.dw_conv3", 2.0 * Q * nj * h->C0 * K1, 0,
+                 hipLaunchKernelGGL(deembed_x_from_r_kernel, dim3(blocks_for((long long)Q * nj * h->C0p * 64)), dim3(256), 0, st, R, Rb, h->dc1_w, h->dc1_b, X,
+                                    Q, h->C0, h->C0p, K1, nj));
+        } else {
         ShuffleA ysh{T.deemb, s.H0, s.W, h->C0p, c.patch_f, c.patch_t, Mt, FastDiv(s.H0 * s.W), FastDiv(s.W), FastDiv(h->C0p)};
         PROF("B.dw_conv3", 2.0 * Mt * Q * 9 * h->C0 * c.in_dim, 0, {
              for (int q = 0; q < Q && !rc; ++q)
                  rc = dw_launch(h, ColOffset<PlainA>{PlainA{P, DEP_LD, Mt}, q * DEP_J}, ColOffset<ShuffleA>{ysh, q * h->C0p}, Mt, DEP_J, h->C0p,
                                 X + (size_t)q * DEP_J * h->C0p, nullptr, part, st); });
         if (rc) return rc;
+        }
         hipLaunchKernelGGL(deembed_fold_dw2_kernel, dim3(blocks_for((long long)c.in_dim * 9 * h->C0p + c.in_dim)), dim3(256), 0, st, X, Rb, G(h, h->dc2_w),
                            G(h, h->dc2_b), Q, h->C0, h->C0p, c.in_dim);
         ConvA cp{P, s.H0, s.W, DEP_LD, 5, 5, Mt};

@@ -1182,6 +1182,77 @@ static __global__ void deembed_weff_kernel(const float* __restrict__ w1, const f
     weff[idx] = s;
 }
 
+// conv3x3 weight gradient WITHOUT the saved conv5x5 output (round 4): Y1[pix][(q, cc)] = b1[(q, cc)] + sum_k W1[(q, cc)][k] * patch5x5(x0)[pix][k], so
+//   X[q][j][cc] = sum_pix P[pix][q*20 + j] * Y1[pix][(q, cc)] = sum_k R[q*20 + j][k] * W1[(q, cc)][k] + Rb[q*20 + j] * b1[(q, cc)]
+// with R = P^T . patches (the product the conv5x5 weight gradient already needs) and Rb = the column sums of P: the fine map never has to exist.
+// One wave per (q, j) row: lanes stride k, 64-lane butterfly, every cc.  w1 = packed conv5x5 matrix [Q*Cp][K], b1 [Q*Cp].
+static __global__ __launch_bounds__(256) void deembed_x_from_r_kernel(const float* __restrict__ R, const float* __restrict__ Rb, const float* __restrict__ w1,
+                                                                       const float* __restrict__ b1, float* __restrict__ X, int Q, int C, int Cp, int K, int nj) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= Q * nj * Cp) return;
+    const int cc = wave % Cp; const int t = wave / Cp; const int j = t % nj, q = t / nj;
+    float s = 0.f;
+    if (cc < C) {
+        const float* r = R + (size_t)(q * DEP_J + j) * K;
+        const float* w = w1 + (size_t)(q * Cp + cc) * K;
+        for (int k = lane; k < K; k += 64) s = fmaf(r[k], w[k], s);
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) s += __shfl_xor(s, sft);
+        s += Rb[q * DEP_J + j] * b1[q * Cp + cc];
+    }
+    if (lane == 0) X[((size_t)q * DEP_J + j) * Cp + cc] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Composed de-embedding ON THE DEVICE (round 4): conv3x3 o pixel_shuffle o conv5x5 folded into the 7x7 / 12-output map of the inference path
+// (escx_api.cpp, "composed de-embedding"), from the CURRENT packed convolution weights, in fp64 and in the host fold's summation order - every
+// element is the same sum of the same double products (contraction off: the host compiler does not fuse them either), so the fp32 results are the
+// host's bit for bit.  With it the training forward runs the folded kernels (11x fewer FLOPs, no 270-channel map on the tape) and a model that
+// has taken optimiser steps on the device needs no host round trip before it decodes again.
+//   w1 [Q*Cp][25*Cp] (k = (kh*5 + kw)*Cp + ci), b1 [Q*Cp], w2 [16][9*Cp] (k = (kw*3 + kh)*Cp + ci), b2 [16]
+//   outputs: all 16 border variants wv [16][NO][49*C], bv [16][NO]; the interior variant again as GEMM rows wc [16][49*Cp], bc [16] and as MFMA
+//   fragments wh [tap][Cp/16][64][4] (lane (n = l & 15, g = l >> 4), channel 16kk + 4g + r)
+// ------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void deembed_compose_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                                      const float* __restrict__ b2, float* __restrict__ wv, float* __restrict__ bv,
+                                                                      float* __restrict__ wc, float* __restrict__ bc, float* __restrict__ wh,
+                                                                      int C, int Cp, int pf, int pt, int in_dim) {
+#pragma clang fp contract(off)
+    const int Q = pf * pt, NO = in_dim * Q, Kc = 49 * C, K1 = 25 * Cp, K2 = 9 * Cp;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n_w = (long long)16 * NO * Kc;
+    if (idx >= n_w + 16 * NO) return;
+    auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+    const bool is_bias = idx >= n_w;
+    int v, n, tap = 0, ci = 0;
+    if (is_bias) { const int r = (int)(idx - n_w); v = r / NO; n = r - v * NO; }
+    else { long long r = idx; ci = (int)(r % C); r /= C; tap = (int)(r % 49); r /= 49; n = (int)(r % NO); v = (int)(r / NO); }
+    const int eh = v >> 2, ew = v & 3;
+    const int co = n / Q, qq = n - co * Q, s1 = qq / pt, s2 = qq - s1 * pt;
+    const int dh = tap / 7 - 3, dw = tap % 7 - 3;
+    double acc = is_bias ? (double)b2[co] : 0.0;
+    for (int a = 0; a < 3; ++a) for (int bq = 0; bq < 3; ++bq) {
+        const int dh0 = fdiv(s1 + a - 1, pf), s1n = s1 + a - 1 - dh0 * pf;
+        const int dw0 = fdiv(s2 + bq - 1, pt), s2n = s2 + bq - 1 - dw0 * pt;
+        if ((dh0 < 0 && (eh & 1)) || (dh0 > 0 && (eh & 2)) || (dw0 < 0 && (ew & 1)) || (dw0 > 0 && (ew & 2))) continue;   // fine neighbour outside the map
+        const int qn = s1n * pt + s2n;
+        const int kh = dh - dh0 + 2, kw = dw - dw0 + 2;
+        if (!is_bias && (kh < 0 || kh >= 5 || kw < 0 || kw >= 5)) continue;
+        for (int cc = 0; cc < C; ++cc) {
+            const double w2v = (double)w2[(size_t)co * K2 + (size_t)(bq * 3 + a) * Cp + cc];
+            if (is_bias) acc += w2v * b1[qn * Cp + cc];
+            else acc += w2v * w1[(size_t)(qn * Cp + cc) * K1 + (size_t)(kh * 5 + kw) * Cp + ci];
+        }
+    }
+    const float r = (float)acc;
+    if (is_bias) { bv[v * NO + n] = r; if (v == 0) bc[n] = r; return; }
+    wv[idx] = r;
+    if (v == 0) {
+        wc[(size_t)n * 49 * Cp + (size_t)tap * Cp + ci] = r;
+        if (NO <= 16) wh[((size_t)(tap * (Cp / 16) + ci / 16) * 64 + (n + 16 * ((ci % 16) / 4))) * 4 + (ci % 4)] = r;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // ComplexSTFTLoss with power-law compression (generator_loss.py:12-35): per clip mean over (2, F, T) of (pl(raw) - pl(recon))^2,
 // pl(x) = sign(x) (|x| + 1e-10)^0.3.  Spectra are frame-major (B, T, in_dim, F).  part[b][block] partial sums; unit gradient optional.

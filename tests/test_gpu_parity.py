@@ -787,6 +787,33 @@ def test_parity_sweep_many_clips():
 
 
 @pytest.mark.gpu
+def test_opt_in_kernel_forms_against_the_default(tmp_path):
+    """Round 4 left four measured-and-rejected kernel forms in the library as opt-in switches (each reads its switch once per process, hence one
+    child process per arm, tools/ab.py): the in-launch combine of the hidden-split MLP and the combine-on-load consumers must reproduce the
+    default's codes AND audio bit for bit (same arithmetic, same order); the weight-stationary / shared-rows merge-split kernels pin their
+    LayerNorm contraction explicitly, so they may differ from the default in low-order bits: identical codes, audio within 1e-6 RMS."""
+    import subprocess, sys
+    from conftest import ROOT
+    ab = os.path.join(ROOT, "tools", "ab.py")
+    arms = {"default": {}, "mlp_fused_combine": {"ESCX_MLP_FUSED_COMBINE": "1"}, "combine_on_load": {"ESCX_COMBINE_ON_LOAD": "1"},
+            "rowgemm_ws": {"ESCX_ROWGEMM_WS": "4"}, "rowgemm_xs": {"ESCX_ROWGEMM_XS": "1"}}
+    got = {}
+    for name, env in arms.items():
+        out = str(tmp_path / f"{name}.npz")
+        e = dict(os.environ, AB_STEPS="1", AB_BATCH="8", AB_GROUPS="", AB_DUMP=out, **env)
+        r = subprocess.run([sys.executable, ab, "--child"], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "AB_RESULT" in r.stdout, f"{name}: {r.stderr[-800:]}"
+        got[name] = np.load(out)
+    ref = got["default"]
+    for name in ("mlp_fused_combine", "combine_on_load"):
+        assert np.array_equal(got[name]["codes"], ref["codes"]) and np.array_equal(got[name]["wave"], ref["wave"]), f"{name} is not bit-identical to the default"
+    for name in ("rowgemm_ws", "rowgemm_xs"):
+        assert np.array_equal(got[name]["codes"], ref["codes"]), f"{name}: codes differ from the default"
+        rms = float(np.sqrt(np.mean((got[name]["wave"].astype(np.float64) - ref["wave"]) ** 2)))
+        assert rms <= 1e-6, f"{name}: audio rms {rms}"
+
+
+@pytest.mark.gpu
 def test_batch_sizes_alternating_between_one_and_two_parts():
     """Batches under 6 clips run as one part, larger ones as two parts on two streams: the clips a part holds are not monotone in the batch
     (8 -> 2 x 4, 5 -> 1 x 5), the workspace has to grow per part; every clip keeps its codes and its audio in every batch it appears in."""

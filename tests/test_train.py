@@ -393,9 +393,10 @@ def test_flat_gradients_and_adam_moments_survive_a_handle_rebuild():
 
 @pytest.mark.gpu
 def test_native_state_guards_of_the_training_path():
-    """ADVICE r2, C-ABI level: (1) after a device-side weight refresh (a training forward) the inference entry points that run the fp64-folded
-    de-embedding refuse with ESCX_ERR_STATE until escx_load_flat_params(full=1) - they do not decode with stale weights; (2) the handle keeps ONE
-    tape: a backward that belongs to an earlier forward raises instead of consuming the later forward's activations."""
+    """ADVICE r2, C-ABI level: (1) after a device-side weight refresh (a training forward) the inference entry points must not decode with a stale
+    folded de-embedding.  Round 4: the refresh re-folds it ON THE DEVICE (fp64, the host fold's summation order), so the decode is valid at once
+    and equals - bit for bit - the decode after the host round trip escx_load_flat_params(full=1); (2) the handle keeps ONE tape: a backward that
+    belongs to an earlier forward raises instead of consuming the later forward's activations."""
     import ctypes
     from esc import _native
     from esc.models import make_model
@@ -407,12 +408,14 @@ def test_native_state_guards_of_the_training_path():
     out_a = model(x=x, x_feat=None, num_streams=3, freeze_codebook=False)
     lib, hd = model._handle(x.device, for_training=True)
     wave = torch.empty((x.shape[0], model.hop_length * (2 * shape[1] - 1)), device="cuda")
-    rc = lib.escx_decode(hd, codes.data_ptr(), codes.shape[0], 3, shape[0], shape[1], wave.data_ptr(), None, None)
-    assert rc == _native.ESCX_ERR_STATE and b"escx_load_flat_params" in lib.escx_last_error()
+    _native.check(lib.escx_decode(hd, codes.data_ptr(), codes.shape[0], 3, shape[0], shape[1], wave.data_ptr(), None, None))
+    torch.cuda.synchronize()
+    wave_device_fold = wave.clone()
     flat, _ = model.flat_buffers(x.device)
-    _native.check(lib.escx_load_flat_params(hd, ctypes.c_void_p(flat.data_ptr()), 1, None))
+    _native.check(lib.escx_load_flat_params(hd, ctypes.c_void_p(flat.data_ptr()), 1, None))          # host fold of the same weights
     assert lib.escx_decode(hd, codes.data_ptr(), codes.shape[0], 3, shape[0], shape[1], wave.data_ptr(), None, None) == 0
     torch.cuda.synchronize()
+    assert torch.equal(wave_device_fold, wave), "device-side fold of the de-embedding differs from the host fold"
     assert torch.equal(wave, model.eval().decode(codes, shape))
     # (2) two graphs alive at once
     model.train()

@@ -31,6 +31,9 @@ def child():
     wave = model.decode(codes, shape)
     torch.cuda.synchronize()
     h = hashlib.sha256(codes.cpu().numpy().tobytes() + wave.cpu().numpy().tobytes()).hexdigest()[:16]
+    if os.environ.get("AB_DUMP"):                       # tests/test_gpu_parity.py: the arrays themselves, for arms that are not meant to be bit-identical
+        import numpy as np
+        np.savez(os.environ["AB_DUMP"], codes=codes.cpu().numpy(), wave=wave.cpu().numpy())
     for _ in range(3):
         c, s = model.encode(x, bench.NUM_STREAMS); model.decode(c, s)
     torch.cuda.synchronize()
