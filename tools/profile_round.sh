@@ -45,5 +45,9 @@ timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_adv -o p -- pytho
 cp $(find $O/prof_adv -name "*kernel_stats.csv" | head -1) $O/train_adv_kernel_stats.csv 2>/dev/null
 rm -rf $O/prof_adv
 cd $R
+# round 4: small-batch latencies, datapath utilisation tables of the codec AND of the training step
+timeout 600 python tools/small_batch.py > $O/small_batch.txt 2>&1
+timeout 1200 bash tools/sq_util.sh > /dev/null 2>&1; cp gpurun_out/sq_util.txt $O/sq_util.txt 2>/dev/null
+SQ_BENCH_ARGS="--mode train --steps 2 --warmup 1 --profile-steps 2 --no-cpu-baseline" SQ_OUT=sq_util_train.txt SQ_TOP=45 ESCX_TRAIN_PARTS=1 timeout 1500 bash tools/sq_util.sh > /dev/null 2>&1; cp gpurun_out/sq_util_train.txt $O/sq_util_train.txt 2>/dev/null
 find $O -name "*.csv" ! -name "*kernel_stats.csv" -delete; rm -rf $O/prof $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/cal_fetch $O/cal_write
 ls -la $O
