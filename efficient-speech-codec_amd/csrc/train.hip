@@ -914,19 +914,28 @@ int train_backward_impl(escx_handle_s* h, const float* d_wave, const float* d_re
         // (train_kernels.h: deembed_p_kernel): dW and dX contract over 128 columns of P instead of the 288 channels of dY1
         const int Mt = B * s.H0 * s.W, Q = h->Q, K1 = 25 * h->C0p;
         if (Q * DEP_J > DEP_LD || c.in_dim * 9 > DEP_J) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "patch size / in_dim outside the de-embedding backward kernels");
-        float* P = sc.take((size_t)Mt * DEP_LD);
-        float* R = sc.take((size_t)DEP_LD * K1 + DEP_LD);
-        float* weff = sc.take((size_t)h->C0p * 25 * DEP_LD);
+        // Distinct-value columns (train_kernels.h, deembed_d_kernel): 48 instead of 128.  Needs the forward without the fine map (X from R) and the
+        // 40 values to fit; ESCX_TRAIN_DEEMBED_SLOTS=0 keeps the 128-column P (A/B baseline).
+        static const bool want_slots = [] { const char* e = getenv("ESCX_TRAIN_DEEMBED_SLOTS"); return !(e && e[0] == '0'); }();
+        const int pf = c.patch_f, pt = c.patch_t;
+        const bool slots = want_slots && T.composed && c.in_dim * (pf + 2) * (pt + 2) <= DEP_LD2;
+        const int LD = slots ? DEP_LD2 : DEP_LD;
+        float* P = sc.take((size_t)Mt * LD);
+        float* R = sc.take((size_t)LD * K1 + LD);
+        float* weff = sc.take((size_t)h->C0p * 25 * LD);
         if (!weff) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small (backward scratch)");
-        hipLaunchKernelGGL(deembed_p_kernel, dim3(blocks_for((long long)Mt * DEP_LD)), dim3(256), 0, st, drspec, P, B, s.H0, s.W, c.patch_f, c.patch_t, c.in_dim, h->Fp);
+        if (slots) hipLaunchKernelGGL(deembed_d_kernel, dim3(blocks_for((long long)Mt * LD)), dim3(256), 0, st, drspec, P, B, s.H0, s.W, pf, pt, c.in_dim, h->Fp);
+        else hipLaunchKernelGGL(deembed_p_kernel, dim3(blocks_for((long long)Mt * LD)), dim3(256), 0, st, drspec, P, B, s.H0, s.W, pf, pt, c.in_dim, h->Fp);
         ConvA ctok{T.post, s.H0, s.W, h->C0p, 5, 5, Mt};
-        float* Rb = R + (size_t)DEP_LD * K1;
-        PROF("B.dw_conv5", 2.0 * Mt * 25 * h->C0 * Q * c.in_dim * 9, 0,
-             rc = (dw_launch_wide<4, 4>(h, PlainA{P, DEP_LD, Mt}, ctok, Mt, DEP_LD, K1, R, Rb, part, st)));
+        float* Rb = R + (size_t)LD * K1;
+        PROF("B.dw_conv5", 2.0 * Mt * 25 * h->C0 * (slots ? c.in_dim * (pf + 2) * (pt + 2) : Q * c.in_dim * 9), 0,
+             rc = slots ? (dw_launch_wide<3, 4, 1, 4>(h, PlainA{P, LD, Mt}, ctok, Mt, LD, K1, R, Rb, part, st))          // 48 x 256 workgroup tiles
+                        : (dw_launch_wide<4, 4>(h, PlainA{P, LD, Mt}, ctok, Mt, LD, K1, R, Rb, part, st)));
         if (rc) return rc;
-        hipLaunchKernelGGL(deembed_fold_dw_kernel, dim3(blocks_for((long long)Q * h->C0p * K1)), dim3(256), 0, st, R, h->dc2_w, G(h, h->dc1_w), Q, h->C0, h->C0p, K1, c.in_dim);
-        hipLaunchKernelGGL(deembed_fold_dw_kernel, dim3(blocks_for((long long)Q * h->C0p)), dim3(256), 0, st, Rb, h->dc2_w, G(h, h->dc1_b), Q, h->C0, h->C0p, 1, c.in_dim);
-        hipLaunchKernelGGL(deembed_weff_kernel, dim3(blocks_for((long long)h->C0p * 25 * DEP_LD)), dim3(256), 0, st, h->dc1_w, h->dc2_w, weff, Q, h->C0, h->C0p, c.in_dim);
+        hipLaunchKernelGGL(deembed_fold_dw_kernel, dim3(blocks_for((long long)Q * h->C0p * K1)), dim3(256), 0, st, R, h->dc2_w, G(h, h->dc1_w), Q, h->C0, h->C0p, K1, c.in_dim, pf, pt, slots);
+        hipLaunchKernelGGL(deembed_fold_dw_kernel, dim3(blocks_for((long long)Q * h->C0p)), dim3(256), 0, st, Rb, h->dc2_w, G(h, h->dc1_b), Q, h->C0, h->C0p, 1, c.in_dim, pf, pt, slots);
+        if (slots) hipLaunchKernelGGL(deembed_weff_slots_kernel, dim3(blocks_for((long long)h->C0p * 25 * LD)), dim3(256), 0, st, h->dc1_w, h->dc2_w, weff, h->C0, h->C0p, pf, pt, c.in_dim);
+        else hipLaunchKernelGGL(deembed_weff_kernel, dim3(blocks_for((long long)h->C0p * 25 * LD)), dim3(256), 0, st, h->dc1_w, h->dc2_w, weff, Q, h->C0, h->C0p, c.in_dim);
         // conv3x3 weight gradient with the same P: only the Q diagonal blocks of P^T . Y1 (Y1 = the saved fine map viewed per coarse pixel) are
         // needed - one 20 x C0p contraction per sub-pixel q instead of the full 128 x Q*C0p product; db2 = the centre-tap column sums of P
         float* X = sc.take((size_t)Q * DEP_J * h->C0p);
@@ -936,20 +945,20 @@ int train_backward_impl(escx_handle_s* h, const float* d_wave, const float* d_re
             const int nj = c.in_dim * 9;
             PROF("B.dw_conv3", 2.0 * Q * nj * h->C0 * K1, 0,
                  hipLaunchKernelGGL(deembed_x_from_r_kernel, dim3(blocks_for((long long)Q * nj * h->C0p * 64)), dim3(256), 0, st, R, Rb, h->dc1_w, h->dc1_b, X,
-                                    Q, h->C0, h->C0p, K1, nj));
+                                    Q, h->C0, h->C0p, K1, nj, pf, pt, slots));
         } else {
         ShuffleA ysh{T.deemb, s.H0, s.W, h->C0p, c.patch_f, c.patch_t, Mt, FastDiv(s.H0 * s.W), FastDiv(s.W), FastDiv(h->C0p)};
         PROF("B.dw_conv3", 2.0 * Mt * Q * 9 * h->C0 * c.in_dim, 0, {
              for (int q = 0; q < Q && !rc; ++q)
-                 rc = dw_launch(h, ColOffset<PlainA>{PlainA{P, DEP_LD, Mt}, q * DEP_J}, ColOffset<ShuffleA>{ysh, q * h->C0p}, Mt, DEP_J, h->C0p,
+                 rc = dw_launch(h, ColOffset<PlainA>{PlainA{P, LD, Mt}, q * DEP_J}, ColOffset<ShuffleA>{ysh, q * h->C0p}, Mt, DEP_J, h->C0p,
                                 X + (size_t)q * DEP_J * h->C0p, nullptr, part, st); });
         if (rc) return rc;
         }
         hipLaunchKernelGGL(deembed_fold_dw2_kernel, dim3(blocks_for((long long)c.in_dim * 9 * h->C0p + c.in_dim)), dim3(256), 0, st, X, Rb, G(h, h->dc2_w),
-                           G(h, h->dc2_b), Q, h->C0, h->C0p, c.in_dim);
-        ConvA cp{P, s.H0, s.W, DEP_LD, 5, 5, Mt};
-        PROF("B.dx_conv5", 2.0 * Mt * 25 * h->C0 * Q * c.in_dim * 9, 0,
-             gemm_any(cp, weff, Mt, h->C0p, 25 * DEP_LD, EpiStore{gtok, h->C0p, nullptr}, st, pick_bk(DEP_LD)));
+                           G(h, h->dc2_b), Q, h->C0, h->C0p, c.in_dim, pf, pt, slots);
+        ConvA cp{P, s.H0, s.W, LD, 5, 5, Mt};
+        PROF("B.dx_conv5", 2.0 * Mt * 25 * h->C0 * (slots ? c.in_dim * (pf + 2) * (pt + 2) : Q * c.in_dim * 9), 0,
+             gemm_any(cp, weff, Mt, h->C0p, 25 * LD, EpiStore{gtok, h->C0p, nullptr}, st, pick_bk(LD)));
     }
     // ---- decoder (post_nn, blocks n-2 .. 0) interleaved with the quantisers ----
     float* gcur = nullptr;

@@ -1114,6 +1114,31 @@ static __global__ void conv3_dx_kernel(const float* __restrict__ g, const float*
 //   g      frame-major spectrum gradient [(b, t)][oc*Fp + f]
 // ------------------------------------------------------------------------------------------------
 constexpr int DEP_J = 20, DEP_LD = 128;
+// Round 4: the 6 x 18 columns of P are COPIES of only in_dim * (pf + 2) * (pt + 2) = 40 distinct spectrum-gradient values per coarse pixel (its pf x pt
+// fine block plus a one-pixel halo), so the two big contractions run on D[pix][slot] (40 -> 48 columns instead of 128: 2.7x fewer FLOPs again) and
+// the copy pattern moves to the weight side, exact including the zero-padded borders (a value outside the fine map is 0 in D as it was in every
+// P column that referenced it).  slot(q = (s1, s2), j = (oc, a, b)) = oc * NS + (s1 - a + 2) * (pt + 2) + (s2 - b + 2), NS = (pf + 2)(pt + 2).
+constexpr int DEP_LD2 = 48;
+__device__ __forceinline__ int dep_row(int q, int j, int pf, int pt, bool slots) {
+    if (!slots) return q * DEP_J + j;
+    const int oc = j / 9, ab = j - oc * 9, a = ab / 3, bq = ab - a * 3;
+    const int s1 = q / pt, s2 = q - s1 * pt;
+    return oc * (pf + 2) * (pt + 2) + (s1 - a + 2) * (pt + 2) + (s2 - bq + 2);
+}
+static __global__ void deembed_d_kernel(const float* __restrict__ g, float* __restrict__ D, int B, int H, int W, int pf, int pt, int in_dim, int Fp) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * H * W * DEP_LD2) return;
+    const int col = (int)(idx % DEP_LD2); long long pix = idx / DEP_LD2;
+    const int w = (int)(pix % W); pix /= W; const int h = (int)(pix % H), b = (int)(pix / H);
+    const int NS = (pf + 2) * (pt + 2);
+    float v = 0.f;
+    if (col < in_dim * NS) {
+        const int oc = col / NS, r = col - oc * NS, rf = r / (pt + 2), rt = r - rf * (pt + 2);
+        const int f = pf * h + rf - 1, t = pt * w + rt - 1;
+        if (f >= 0 && f < pf * H && t >= 0 && t < pt * W) v = g[((size_t)b * (pt * W) + t) * (in_dim * Fp) + oc * Fp + f];
+    }
+    D[idx] = v;
+}
 static __global__ void deembed_p_kernel(const float* __restrict__ g, float* __restrict__ P, int B, int H, int W, int pf, int pt, int in_dim, int Fp) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)B * H * W * DEP_LD) return;
@@ -1131,7 +1156,7 @@ static __global__ void deembed_p_kernel(const float* __restrict__ g, float* __re
 }
 // dW1[(q*Cp + cc)][k] = sum_j W2[oc][cc][a][b] * R[q*20 + j][k] ; w2 is the packed conv3x3 matrix [16][9*Cp], tap order (b*3 + a)
 static __global__ void deembed_fold_dw_kernel(const float* __restrict__ R, const float* __restrict__ w2, float* __restrict__ dW1, int Q, int C, int Cp, int K,
-                                       int in_dim) {
+                                       int in_dim, int pf = 0, int pt = 1, bool slots = false) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)Q * Cp * K) return;
     const int k = (int)(idx % K); const int r = (int)(idx / K); const int q = r / Cp, cc = r - q * Cp;
@@ -1139,14 +1164,14 @@ static __global__ void deembed_fold_dw_kernel(const float* __restrict__ R, const
     if (cc < C)
         for (int j = 0; j < in_dim * 9; ++j) {
             const int oc = j / 9, ab = j - oc * 9, a = ab / 3, bq = ab - a * 3;
-            s += w2[(size_t)oc * 9 * Cp + (size_t)(bq * 3 + a) * Cp + cc] * R[(size_t)(q * DEP_J + j) * K + k];
+            s += w2[(size_t)oc * 9 * Cp + (size_t)(bq * 3 + a) * Cp + cc] * R[(size_t)dep_row(q, j, pf, pt, slots) * K + k];
         }
     dW1[idx] = s;
 }
 // conv3x3 weight gradient from the Q diagonal blocks X[q][j][cc] = sum_pix P[pix][q*20 + j] * Y1[pix][q*Cp + cc]:
 //   dW2[oc][(b*3 + a)*Cp + cc] = sum_q X[q][j][cc],  j = oc*9 + a*3 + b ;   db2[oc] = sum_q Rb[q*20 + oc*9 + 4]  (centre tap: no border exclusion)
 static __global__ void deembed_fold_dw2_kernel(const float* __restrict__ X, const float* __restrict__ Rb, float* __restrict__ dW2, float* __restrict__ db2, int Q,
-                                        int C, int Cp, int in_dim) {
+                                        int C, int Cp, int in_dim, int pf = 0, int pt = 1, bool slots = false) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = in_dim * 9 * Cp;
     if (idx < n) {
@@ -1159,7 +1184,7 @@ static __global__ void deembed_fold_dw2_kernel(const float* __restrict__ X, cons
     } else if (idx < n + in_dim) {
         const int oc = idx - n;
         float s = 0.f;
-        for (int q = 0; q < Q; ++q) s += Rb[q * DEP_J + oc * 9 + 4];
+        for (int q = 0; q < Q; ++q) s += Rb[dep_row(q, oc * 9 + 4, pf, pt, slots)];
         db2[oc] = s;
     }
 }
@@ -1187,18 +1212,20 @@ static __global__ void deembed_weff_kernel(const float* __restrict__ w1, const f
 // with R = P^T . patches (the product the conv5x5 weight gradient already needs) and Rb = the column sums of P: the fine map never has to exist.
 // One wave per (q, j) row: lanes stride k, 64-lane butterfly, every cc.  w1 = packed conv5x5 matrix [Q*Cp][K], b1 [Q*Cp].
 static __global__ __launch_bounds__(256) void deembed_x_from_r_kernel(const float* __restrict__ R, const float* __restrict__ Rb, const float* __restrict__ w1,
-                                                                       const float* __restrict__ b1, float* __restrict__ X, int Q, int C, int Cp, int K, int nj) {
+                                                                       const float* __restrict__ b1, float* __restrict__ X, int Q, int C, int Cp, int K, int nj,
+                                                                       int pf = 0, int pt = 1, bool slots = false) {
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= Q * nj * Cp) return;
     const int cc = wave % Cp; const int t = wave / Cp; const int j = t % nj, q = t / nj;
     float s = 0.f;
     if (cc < C) {
-        const float* r = R + (size_t)(q * DEP_J + j) * K;
+        const int row = dep_row(q, j, pf, pt, slots);
+        const float* r = R + (size_t)row * K;
         const float* w = w1 + (size_t)(q * Cp + cc) * K;
         for (int k = lane; k < K; k += 64) s = fmaf(r[k], w[k], s);
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) s += __shfl_xor(s, sft);
-        s += Rb[q * DEP_J + j] * b1[q * Cp + cc];
+        s += Rb[row] * b1[q * Cp + cc];
     }
     if (lane == 0) X[((size_t)q * DEP_J + j) * Cp + cc] = s;
 }
@@ -1251,6 +1278,31 @@ static __global__ __launch_bounds__(256) void deembed_compose_kernel(const float
         wc[(size_t)n * 49 * Cp + (size_t)tap * Cp + ci] = r;
         if (NO <= 16) wh[((size_t)(tap * (Cp / 16) + ci / 16) * 64 + (n + 16 * ((ci % 16) / 4))) * 4 + (ci % 4)] = r;
     }
+}
+
+// effective dX weights over the distinct-value columns: Weff2[ci][(t0*5 + t1)*48 + slot] = sum over the (q, a, b) that reference the slot of
+// sum_cc W2[oc][cc][a][b] * W1[(q, cc)][ci][4 - t0][4 - t1]   (slot = (oc, rf, rt): s1 = rf + a - 2, s2 = rt + b - 2)
+static __global__ void deembed_weff_slots_kernel(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ weff, int C, int Cp, int pf, int pt,
+                                                 int in_dim) {
+    const int KE = 25 * DEP_LD2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)Cp * KE) return;
+    const int k = (int)(idx % KE), ci = (int)(idx / KE);
+    const int tap = k / DEP_LD2, col = k - tap * DEP_LD2;
+    const int NS = (pf + 2) * (pt + 2);
+    float s = 0.f;
+    if (ci < C && col < in_dim * NS) {
+        const int oc = col / NS, r = col - oc * NS, rf = r / (pt + 2), rt = r - rf * (pt + 2);
+        const int t0 = tap / 5, t1 = tap - t0 * 5, kh = 4 - t0, kw = 4 - t1;
+        for (int a = 0; a < 3; ++a) for (int bq = 0; bq < 3; ++bq) {
+            const int s1 = rf + a - 2, s2 = rt + bq - 2;
+            if (s1 < 0 || s1 >= pf || s2 < 0 || s2 >= pt) continue;
+            const int q = s1 * pt + s2;
+            for (int cc = 0; cc < C; ++cc)
+                s += w2[(size_t)oc * 9 * Cp + (size_t)(bq * 3 + a) * Cp + cc] * w1[(size_t)(q * Cp + cc) * 25 * Cp + (size_t)(kh * 5 + kw) * Cp + ci];
+        }
+    }
+    weff[idx] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
