@@ -1220,8 +1220,16 @@ static int run_pvq_decode(escx_handle_s* h, const Quant& q, const long long* cod
                           float* out, hipStream_t st) {
     const escx_config& c = h->cfg;
     const double vec = (double)c.overlap * q.Hq * q.C, Mv = (double)B * (W / c.overlap);
+    static const bool special = [] { const char* e = getenv("ESCX_PVQ_UP_KERNEL"); return !(e && e[0] == '0'); }();     // 0: the GEMM engine's generic form (A/B, fallback)
+    int urc = -1;
+    if (special)
+        PROF("pvq_up_gemm", 2.0 * Mv * vec * q.d, Mv * vec * (dec ? 2 : 1) * 4,
+             urc = pvq_up(codes, bstride, q.cbraw, c.group_size, c.codebook_size, q.dt, B, q.Hq, W, q.Cp, c.overlap, q.wup, q.Kq, q.Kup, dec, out, st));
+    if (urc != 0) {
+        if (special && h->prof && !h->prof_recs.empty()) h->prof_recs.pop_back();
     PROF("pvq_up_gemm", 2.0 * Mv * vec * q.d, Mv * vec * (dec ? 2 : 1) * 4,
          gemm_pvq_up(codes, bstride, q.cbraw, c.group_size, c.codebook_size, q.dt, B, q.Hq, W, q.Cp, c.overlap, q.wup, q.Kq, q.Kup, dec, out, st));
+    }
     return launch_ok("pvq_decode");
 }
 

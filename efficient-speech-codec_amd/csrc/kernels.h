@@ -292,6 +292,71 @@ __global__ __launch_bounds__(256) void pvq_search_kernel(SearchArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// PVQ de-quantisation + up-projection + un-frame + residual add (quantization.py:93-108, 124-136, 412-432; csrvq.py:19-21), round 4:
+//     out[(b, h, ov*t + o)][c] = dec[...] + sum_k W_up[n = (o, h, c)][k] * cb_g(k)[code[b, g(k), t]][k - g(k)*dt]
+// The GEMM engine ran this as a generic tile kernel (CodeGatherA loader + EpiPvqAdd epilogue): with K = 32..96 it issued 7-10 VALU instructions
+// per MFMA on index arithmetic (three multiply-high divisions per 16-byte store, a dependent code load per operand fetch) - 16-22 % MFMA-busy,
+// 30-43 us alone on the GPU for 20 us of HBM traffic, and 3.2x that next to the other batch part.  Here a wave gathers its 16 vectors' codebook
+// rows ONCE into the MFMA operand, then walks output tiles: per tile KC weight fragments straight from L2, 4*KC MFMAs, and a store whose
+// address is a wave-uniform tile offset plus a per-lane row base.  The contraction order is the engine's (16-wide k chunks ascending, within
+// a chunk MFMA r = 0..3 with k = chunk + 4*slot + r, one accumulator chain, then + dec): bit-identical results.
+// ------------------------------------------------------------------------------------------------
+struct PvqUpArgs {
+    const long long* codes; long long bstride; const float* cb; const float* W; const float* dec; float* out;
+    int G, Ksz, dt, Tq, M, Hq, Wd, Cp, ov, Kup, NT, nt_per_wg;
+};
+
+template <int KC>
+__global__ __launch_bounds__(256) void pvq_up_kernel(PvqUpArgs a) {
+    ESCX_SET_PRIO_SMALL();
+    constexpr int UNR = 4;                      // output tiles in flight per wave
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = blockIdx.x * 16 + l15;
+    const bool live = m < a.M;
+    const int b = live ? m / a.Tq : 0, t = live ? m - b * a.Tq : 0;
+    const size_t base = ((size_t)b * a.Hq * a.Wd + (size_t)a.ov * t) * a.Cp + 4 * lg;
+    f32x4 zf[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const int k = 16 * c + 4 * lg, g = k / a.dt;
+        zf[c] = zero4();
+        if (live && g < a.G) {
+            long long code = a.codes[(size_t)b * a.bstride + (size_t)g * a.Tq + t];
+            code = code < 0 ? 0 : (code >= a.Ksz ? a.Ksz - 1 : code);       // a corrupt index must not read outside the codebook (F.embedding would raise)
+            zf[c] = ld4(a.cb + ((size_t)g * a.Ksz + (size_t)code) * a.dt + (k - g * a.dt));
+        }
+    }
+    const int nt_lo = blockIdx.y * a.nt_per_wg, nt_hi = min(a.NT, nt_lo + a.nt_per_wg);
+    const float* wrow = a.W + (size_t)l15 * a.Kup + 4 * lg;
+    for (int nt0 = nt_lo + wave * UNR; nt0 < nt_hi; nt0 += 4 * UNR) {
+        f32x4 wf[UNR][KC], dv[UNR];
+        size_t idx[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int nt = min(nt0 + u, nt_hi - 1);                            // ragged tail: a duplicate tile, not stored
+#pragma unroll
+            for (int c = 0; c < KC; ++c) wf[u][c] = ld4(wrow + (size_t)(16 * nt) * a.Kup + 16 * c);
+            const int n0 = 16 * nt, oh = n0 / a.Cp, c0 = n0 - oh * a.Cp, o = oh / a.Hq, h = oh - o * a.Hq;      // wave-uniform
+            idx[u] = base + (size_t)(h * a.Wd + o) * a.Cp + c0;
+            dv[u] = (live && a.dec) ? ld4(a.dec + idx[u]) : zero4();
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            f32x4 acc = zero4();
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][c][r], zf[c][r], acc, 0, 0, 0);
+            if (live && nt0 + u < nt_hi) {
+                if (a.dec) acc += dv[u];
+                st4(a.out + idx[u], acc);
+            }
+        }
+    }
+}
+
 // cm_loss[b] = sum over (stream slot, group, frame) of the per-vector terms written by pvq_search_kernel, in a fixed order:
 // lane l of the clip's wave adds terms l, l+64, ... in increasing index order, then a fixed butterfly joins the 64 lanes.
 // terms: [n_slots][G][M] with M = B*Tq rows laid out (b, t).

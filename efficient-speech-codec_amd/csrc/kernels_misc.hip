@@ -57,6 +57,27 @@ void loss_reduce(const float* terms, int n_slots, int G, int M, int Tq, float* o
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(M / Tq), dim3(64), 0, s, terms, n_slots, G, M, Tq, out);
 }
 
+int pvq_up(const long long* codes, long long bstride, const float* cbraw, int G, int Ksz, int dt, int B, int Hq, int Wd, int Cp, int ov,
+           const float* W, int Np, int Kp, const float* dec, float* out, hipStream_t s) {
+    const int Tq = Wd / ov, M = B * Tq;
+    if (Np % 16 || Kp % 16 || Cp % 16 || dt % 4) return -1;
+    PvqUpArgs a{codes, bstride, cbraw, W, dec, out, G, Ksz, dt, Tq, M, Hq, Wd, Cp, ov, Kp, Np / 16, 0};
+    const int mt = (M + 15) / 16;
+    // enough workgroups for the chip (the launch is HBM-bound: dec read + out written), whole multiples of the 16 tiles a workgroup has in flight
+    int per = 16;
+    while (per < a.NT && (long long)mt * ((a.NT + per - 1) / per) > 2048) per += 16;
+    a.nt_per_wg = per;
+    const dim3 grid(mt, (a.NT + per - 1) / per);
+    switch (Kp / 16) {
+        case 1: hipLaunchKernelGGL(pvq_up_kernel<1>, grid, dim3(256), 0, s, a); return 0;
+        case 2: hipLaunchKernelGGL(pvq_up_kernel<2>, grid, dim3(256), 0, s, a); return 0;
+        case 3: hipLaunchKernelGGL(pvq_up_kernel<3>, grid, dim3(256), 0, s, a); return 0;
+        case 4: hipLaunchKernelGGL(pvq_up_kernel<4>, grid, dim3(256), 0, s, a); return 0;
+        case 6: hipLaunchKernelGGL(pvq_up_kernel<6>, grid, dim3(256), 0, s, a); return 0;
+        default: return -1;
+    }
+}
+
 void istft_ola(const float* frames, const float* win2, float* wave, int B, int T, int ldf, int win, int hop, int left, int half,
                int out_len, hipStream_t s) {
     const long long n = (long long)B * out_len;

@@ -77,6 +77,9 @@ void ln_rows(int mode, const float* src, float* dst, const float* gamma, const f
              int src_rows_per_clip, int total_rows, int C, int Cp, hipStream_t s);
 int window_attention(const float* qkv, const float* bias, float* out, int total_windows, int nH, int hdp, int ldq, int ldo, int nWh,
                      int nWw, int shifted, hipStream_t s);
+// specialised PVQ de-quantise + up-project + un-frame + add (kernels.h); -1: geometry not covered, the caller falls back to gemm_pvq_up
+int pvq_up(const long long* codes, long long bstride, const float* cbraw, int G, int Ksz, int dt, int B, int Hq, int Wd, int Cp, int ov,
+           const float* W, int Np, int Kp, const float* dec, float* out, hipStream_t s);
 int pvq_search(const float* zpart, int splits, int M, int ldz, const float* cbn, const float* c2, const float* cbraw, int G, int Ksz,
                int d, int dt, int Tq, long long* codes, long long bstride, float* loss, float loss_scale, int l2norm, hipStream_t s);
 void istft_ola(const float* frames, const float* win2, float* wave, int B, int T, int ldf, int win, int hop, int left, int half,
