@@ -44,6 +44,11 @@ struct AttnArgs {
     // hidden-split MLP.  x = src + (((P0 + P1) + ...) + bias) - the arithmetic of rows_combine_kernel, bit for bit - is formed wherever a row is
     // read (LayerNorm input and shortcut), which removes the combine launch and one write + one read of the map between the two blocks.
     const float* comb_partial; const float* comb_bias; long long comb_stride; int comb_n;
+    // TAPE instantiations (training forward, round 4): what the hand-written backward reads is written out as it is produced, in the unfused
+    // path's layouts - the normalised rows in window-slot order [slots][CP], q (scaled) | k | v per head in [slots][ldq] with hdp columns per
+    // head (q at h*hdp, k at nH*hdp + h*hdp, v at 2*nH*hdp + h*hdp), the attention output [slots][ldo] - so LayerNorm, QKV projection,
+    // window attention and output projection are ONE launch and nothing is read back (train.hip, layer_fwd).
+    float* tape_xn; float* tape_qkv; float* tape_o; int ldq, ldo, hdp, nH;
 };
 
 // One 16-byte piece of a block-input row: plain, or combined on the fly from the hidden-split MLP's slabs (see AttnArgs).
@@ -98,7 +103,7 @@ __device__ __forceinline__ f32x4 window_softmax(f32x4 s, f32x4 bias_row, f32x4 s
 #endif
 template <int CP, int TMW> constexpr int attn_min_waves() { return (CP * TMW <= 96) ? 4 : ((CP * TMW <= ESCX_ATTN_OCC3) ? 3 : ((CP * TMW <= 192) ? 2 : 1)); }
 
-template <int CP, int MODE, int UT, int TMW, int NW, bool COMB = false>
+template <int CP, int MODE, int UT, int TMW, int NW, bool COMB = false, bool TAPE = false>
 __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fused_kernel(AttnArgs a) {
 #ifdef ESCX_ATTN_PRIO
     __builtin_amdgcn_s_setprio(ESCX_ATTN_PRIO);     // tuning builds: static wave priority against co-running launches of the other batch part
@@ -180,11 +185,48 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
         }
     }
 
+    if constexpr (TAPE) {           // the normalised rows, window-slot order (zeros in padded slots), + zeros in the pad columns of the q|k|v and output rows
+#pragma unroll
+        for (int t = 0; t < TMW; ++t) {
+            if (win0 + t >= a.n_windows) continue;
+            const size_t row = (size_t)(win0 + t) * 16 + l15;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) st4(a.tape_xn + row * CP + 16 * kk + 4 * lg, xf[t][kk]);
+            const int q_end = 3 * a.nH * a.hdp, o_end = a.nH * a.hdp;
+            if (q_end + 4 * lg < a.ldq) st4(a.tape_qkv + row * a.ldq + q_end + 4 * lg, zero4());
+            if (o_end + 4 * lg < a.ldo) st4(a.tape_o + row * a.ldo + o_end + 4 * lg, zero4());
+        }
+    }
+
     f32x4 acc[KK][TMW];
 #pragma unroll
     for (int o = 0; o < KK; ++o)
 #pragma unroll
         for (int t = 0; t < TMW; ++t) acc[o][t] = zero4();
+
+    // Tape stores of one head-group tile (TAPE).  Tile row i of group g (half `half` in MODE 2) is (head, dim) = MODE 0: (g, i); MODE 1: (2g + i / 8, i % 8);
+    // MODE 2: (g, 16 half + i) - the weight packer's hd_of - and lives at column head * hdp + dim of its q / k / v / o block (hdp = head_dim rounded up to 4).
+    auto tape_col = [&](int g, int half, int i, bool* ok) -> int {
+        const int head = (MODE == 1) ? 2 * g + (i >> 3) : g;
+        const int dim = (MODE == 1) ? (i & 7) : ((MODE == 2) ? 16 * half + i : i);
+        *ok = head < a.nH && dim < a.hdp;
+        return head * a.hdp + dim;
+    };
+    auto tape_rows = [&](float* basep, int ld, int block_col, int g, int half, const f32x4* v) {       // lane (slot l15, tile rows 4lg .. 4lg + 3)
+        bool ok; const int c = tape_col(g, half, 4 * lg, &ok);
+#pragma unroll
+        for (int t = 0; t < TMW; ++t)
+            if (win0 + t < a.n_windows && ok) st4(basep + ((size_t)(win0 + t) * 16 + l15) * ld + block_col + c, v[t]);
+    };
+    auto tape_cols = [&](float* basep, int ld, int block_col, int g, int half, const f32x4* vt) {      // transposed tile: lane (tile row l15, slots 4lg .. 4lg + 3)
+        bool ok; const int c = tape_col(g, half, l15, &ok);
+#pragma unroll
+        for (int t = 0; t < TMW; ++t)
+            if (win0 + t < a.n_windows && ok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) basep[((size_t)(win0 + t) * 16 + 4 * lg + r) * ld + block_col + c] = vt[t][r];
+            }
+    };
 
     // LDS -> register fragment ring over the whole stage (UT tiles = NP consecutive 1 KiB fragments): the read of fragment
     // f + PD is in flight while fragment f feeds the MFMAs, across tile boundaries; only the first PD reads of a stage are
@@ -340,6 +382,10 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
             for (int t = 0; t < TMW; ++t) q[t] *= a.scale;
             begin_tile();
             gemm_w_rows(k, cur.b[1]);
+            if constexpr (TAPE) {
+                tape_rows(a.tape_qkv, a.ldq, 0, g, 0, q);
+                tape_rows(a.tape_qkv, a.ldq, a.nH * a.hdp, g, 0, k);
+            }
             ESCX_TS(t2)
             f32x4 p0[TMW], p1[TMW];
 #pragma unroll
@@ -380,6 +426,10 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
                 }
             }
             ESCX_SGB_MFMA((MODE == 0 ? 4 : 8) * TMW);
+            if constexpr (TAPE) {
+                tape_cols(a.tape_qkv, a.ldq, 2 * a.nH * a.hdp, g, 0, vt);
+                tape_rows(a.tape_o, a.ldo, 0, g, 0, o);
+            }
             ESCX_TS(t5)
             begin_tile();
             proj_accumulate(o);
@@ -399,6 +449,10 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
                 for (int t = 0; t < TMW; ++t) q[t] *= a.scale;
                 begin_tile();
                 gemm_w_rows(k, cur.b[2 * half + 1]);
+                if constexpr (TAPE) {
+                    tape_rows(a.tape_qkv, a.ldq, 0, g, half, q);
+                    tape_rows(a.tape_qkv, a.ldq, a.nH * a.hdp, g, half, k);
+                }
 #pragma unroll
                 for (int t = 0; t < TMW; ++t)
 #pragma unroll
@@ -419,6 +473,10 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
                     for (int r = 0; r < 4; ++r) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[t][r], p[t][r], o[t], 0, 0, 0);
                 }
                 ESCX_SGB_MFMA(4 * TMW);
+                if constexpr (TAPE) {
+                    tape_cols(a.tape_qkv, a.ldq, 2 * a.nH * a.hdp, g, half, vt);
+                    tape_rows(a.tape_o, a.ldo, 0, g, half, o);
+                }
                 begin_tile();
                 proj_accumulate(o);
             }

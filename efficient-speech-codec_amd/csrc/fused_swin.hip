@@ -296,6 +296,15 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
     constexpr int TMW = attn_windows_per_wave(CP);
     const int per_block = TMW * NW;
     const int gs = a.GS > 1 ? a.GS : 1;
+    if (a.tape_qkv) {               // training forward (TAPE instantiations for the memory-bound widths; the deep scales keep their GEMMs)
+        if constexpr (CP == 16 || CP == 48 || CP == 80 || CP == 96) {
+            if (gs == 1 && a.comb_n == 0) {
+                hipLaunchKernelGGL((attn_fused_kernel<CP, MODE, UT, TMW, NW, false, true>), dim3((a.n_windows + per_block - 1) / per_block), dim3(64 * NW), 0, s, a);
+                return 0;
+            }
+        }
+        return ESCX_COMB_UNSUPPORTED;
+    }
     if (a.comb_n > 0) {
         if constexpr (CP == 192 && MODE == 1) {        // the C = 192 blocks that follow a hidden-split MLP (ESC-Base / Large: 24 heads of 8)
             if (gs == 1) { hipLaunchKernelGGL((attn_fused_kernel<CP, MODE, UT, TMW, NW, true>), dim3((a.n_windows + per_block - 1) / per_block), dim3(64 * NW), 0, s, a); return 0; }
@@ -342,13 +351,16 @@ static int launch_attn_packed(const AttnArgs& a, hipStream_t s) {
 int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_groups, const float* gamma, const float* beta,
                const float* wf, const float* bqkv, const float* bias_tab, const float* bproj, const int* map, int slots, int tokens,
                int n_windows, int nWh, int nWw, int shifted, float scale, int nw, int* gs_io, float* partial, int rows, hipStream_t s,
-               const CombineOnLoad* comb) {
+               const CombineOnLoad* comb, const AttnTape* tape) {
     int gs = gs_io ? *gs_io : 1;        // head-group split: same in/out convention as mlp_fused
     if (gs > 1 && (!partial || n_groups % gs)) gs = 1;
     if (gs_io) *gs_io = gs;
     AttnArgs a{src, dst, gamma, beta, reinterpret_cast<const f32x4*>(wf), bqkv, bias_tab, bproj, map, slots, tokens, n_windows,
                nWh, nWw, shifted, C, n_groups, scale, 1e-5f, gs, partial, rows, g_mlp_trace,
-               comb ? comb->partial : nullptr, comb ? comb->bias : nullptr, comb ? comb->stride : 0, comb ? comb->n : 0};
+               comb ? comb->partial : nullptr, comb ? comb->bias : nullptr, comb ? comb->stride : 0, comb ? comb->n : 0,
+               tape ? tape->xn : nullptr, tape ? tape->qkv : nullptr, tape ? tape->o : nullptr, tape ? tape->ldq : 0, tape ? tape->ldo : 0,
+               tape ? tape->hdp : 0, tape ? tape->nH : 0};
+    if (tape && nw < 0) return ESCX_COMB_UNSUPPORTED;      // the packed H = 2 form has no tape stores
     // H == 2 scale with no padding along W: two half-real windows share one tile (nw < 0 encodes "packing allowed", |nw| waves)
     if (nw < 0) {
         nw = -nw;

@@ -50,7 +50,10 @@ int deembed7_fused(const float* tok, int B, int H, int W, int Cp, const float* w
 int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_groups, const float* gamma, const float* beta,
                const float* wf, const float* bqkv, const float* bias_tab, const float* bproj, const int* map, int slots, int tokens,
                int n_windows, int nWh, int nWw, int shifted, float scale, int nw, int* gs_io, float* partial, int rows, hipStream_t s,
-               const CombineOnLoad* comb = nullptr);
+               const CombineOnLoad* comb = nullptr, const struct AttnTape* tape = nullptr);
+// training forward: the fused attention also writes what the backward reads (fused_attn.h, TAPE); returns ESCX_COMB_UNSUPPORTED when the width has
+// no TAPE instantiation (the caller runs the unfused sequence)
+struct AttnTape { float* xn; float* qkv; float* o; int ldq, ldo, hdp, nH; };
 
 // ---- everything else that is a contraction (gemm_misc.hip) ----
 void gemm_frames(const float* wave, int B, int L, int T, int hop, int off, const float* W, int Np, int Kp, float* out, hipStream_t s);

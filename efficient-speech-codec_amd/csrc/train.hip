@@ -395,6 +395,24 @@ int layer_fwd(escx_handle_s* h, const Layer& L, LayerTape& LT, const float* x_in
         if (!fmlp) { bt.xn2 = tp.take((size_t)M * L.Cp); bt.hpre = tp.take((size_t)M * L.hiddenP); bt.hact = tp.take((size_t)M * L.hiddenP); }
         bt.x2 = tp.take((size_t)M * L.Cp);
         if (!bt.x2) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small");
+        // Round 4: at the memory-bound widths (C <= 96) LayerNorm + QKV projection + window attention + output projection are ONE launch of the
+        // inference path's fused kernel, which also writes the tape entries (xn1, q | k | v, attention output) in the layouts the backward reads
+        // (fused_attn.h, TAPE): 1.73 GB -> 0.93 GB of HBM traffic per C = 45 block at 36 clips.  ESCX_TRAIN_ATTN_FUSED=0: the four launches.
+        static const bool attn_fused_ok = [] { const char* e = getenv("ESCX_TRAIN_ATTN_FUSED"); return !(e && e[0] == '0'); }();
+        int afrc = -1;
+        if (attn_fused_ok && L.attn_mode >= 0 && L.Cp <= 96) {
+            const AttnTape tape{bt.xn1, bt.qkv, bt.obuf, L.Nqkv, L.Ko, L.hdp, L.nH};
+            const int tmw = attn_windows_per_wave(L.Cp);
+            const long long wg4 = (Ms / 16 / tmw + 3) / 4;
+            const int nw = wg4 >= 2048 ? 8 : 4;
+            int gs = 1;
+            const size_t n_recs = h->prof_recs.size();
+            PROF("T.attn_fused" + tg, 8 * dMs * dC * dC + 4 * dMs * 16 * dC, (dM * 2 + dMs * 6) * dC * f4,
+                 afrc = attn_fused(x, bt.x1, L.Cp, L.C, L.attn_mode, L.n_groups, bw.ln1_g, bw.ln1_b, bw.waf, bw.baf, bw.bias_tab_f, bw.bproj, map, slots, tokens,
+                                   Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, &gs, nullptr, M, st, nullptr, &tape));
+            if (afrc != 0 && h->prof_recs.size() > n_recs) h->prof_recs.pop_back();
+        }
+        if (afrc != 0) {
         PROF("T.ln1_gather" + tg, 0, (dM + dMs) * dC * f4, ln_rows(1, x, bt.xn1, bw.ln1_g, bw.ln1_b, map, slots, tokens, Ms, L.C, L.Cp, st));
         PROF("T.gemm_qkv" + tg, 2 * dMs * dC * 3 * dC, dMs * 4 * dC * f4,
              gemm_qkv(bt.xn1, L.Cp, Ms, bw.wqkv, L.Nqkv, L.Cp, bt.qkv, bw.bqkv, L.nH * L.hdp, 1.0f / std::sqrt((float)L.hd), st));
@@ -404,6 +422,7 @@ int layer_fwd(escx_handle_s* h, const Layer& L, LayerTape& LT, const float* x_in
         if (arc) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "head_dim %d unsupported by the attention kernel", L.hd);
         PROF("T.gemm_proj" + tg, 2 * dMs * dC * dC, (dMs * dC + 2 * dM * dC) * f4,
              gemm_proj_scatter(bt.obuf, L.Ko, Ms, bw.wproj, L.Cp, L.Ko, bt.x1, x, bw.bproj, map, slots, tokens, st));
+        }
         if (fmlp) {       // LN2 + fc1 + GELU + fc2 + residual in one kernel: x1 -> x2 (x1 itself is what the backward recomputes from)
             int hs = 1, frc = 0;
             PROF("T.mlp_fused" + tg, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
