@@ -297,7 +297,7 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
     const int per_block = TMW * NW;
     const int gs = a.GS > 1 ? a.GS : 1;
     if (a.tape_qkv) {               // training forward (TAPE instantiations for the memory-bound widths; the deep scales keep their GEMMs)
-        if constexpr (CP == 16 || CP == 48 || CP == 80 || CP == 96) {
+        if constexpr (CP == 16 || CP == 48 || CP == 80 || CP == 96) {      // C = 144 / 192 measured: no gain over their GEMM sequence (62.5 vs 62.3-62.6 ms per step)
             if (gs == 1 && a.comb_n == 0) {
                 hipLaunchKernelGGL((attn_fused_kernel<CP, MODE, UT, TMW, NW, false, true>), dim3((a.n_windows + per_block - 1) / per_block), dim3(64 * NW), 0, s, a);
                 return 0;

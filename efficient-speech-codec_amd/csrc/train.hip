@@ -400,7 +400,8 @@ int layer_fwd(escx_handle_s* h, const Layer& L, LayerTape& LT, const float* x_in
         // (fused_attn.h, TAPE): 1.73 GB -> 0.93 GB of HBM traffic per C = 45 block at 36 clips.  ESCX_TRAIN_ATTN_FUSED=0: the four launches.
         static const bool attn_fused_ok = [] { const char* e = getenv("ESCX_TRAIN_ATTN_FUSED"); return !(e && e[0] == '0'); }();
         int afrc = -1;
-        if (attn_fused_ok && L.attn_mode >= 0 && L.Cp <= 96) {
+        static const int attn_fused_max = [] { const char* e = getenv("ESCX_TRAIN_ATTN_FUSED_MAXCP"); return e && e[0] ? atoi(e) : 96; }();
+        if (attn_fused_ok && L.attn_mode >= 0 && L.Cp <= attn_fused_max) {
             const AttnTape tape{bt.xn1, bt.qkv, bt.obuf, L.Nqkv, L.Ko, L.hdp, L.nH};
             const int tmw = attn_windows_per_wave(L.Cp);
             const long long wg4 = (Ms / 16 / tmw + 3) / 4;
