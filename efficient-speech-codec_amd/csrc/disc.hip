@@ -192,6 +192,15 @@ int disc_fork(escx_disc_s* d, hipStream_t st, int n) {
     }
     return 0;
 }
+int disc_join(escx_disc_s* d, hipStream_t st, int n);
+// an error return between fork and join must not leave the aux streams running on scratch and caller tensors that the host is about to
+// release.  The guard joins them into the caller's stream (events, no host wait) unless the normal join already ran.
+struct DiscJoinGuard {
+    escx_disc_s* d; hipStream_t st; int n; bool armed;
+    DiscJoinGuard(escx_disc_s* d_, hipStream_t st_, int n_) : d(d_), st(st_), n(n_), armed(n_ > 1) {}
+    ~DiscJoinGuard() { if (armed) (void)disc_join(d, st, n); }
+    int join() { armed = false; return disc_join(d, st, n); }
+};
 int disc_join(escx_disc_s* d, hipStream_t st, int n) {
     for (int i = 0; i + 1 < n; ++i) {
         ESCX_HIP(hipEventRecord(d->ev_join[i], d->aux[i]));
@@ -466,6 +475,7 @@ extern "C" int escx_disc_forward(escx_disc d, const float* flat_params, int64_t 
     const int nq = disc_streams();
     if (nq > 1 && (rc = disc_fork(d, st, nq))) return rc;
     const hipStream_t st0 = st;
+    DiscJoinGuard guard(d, st0, nq);
     int fi = 0;
     for (size_t si = 0; si < d->subs.size(); ++si) {
         const DSub& S = d->subs[si];
@@ -497,7 +507,7 @@ extern "C" int escx_disc_forward(escx_disc d, const float* flat_params, int64_t 
         }
     }
     st = st0;
-    if (nq > 1 && (rc = disc_join(d, st, nq))) return rc;
+    if (nq > 1 && (rc = guard.join())) return rc;
     return launch_ok("disc_forward");
 }
 
@@ -588,6 +598,7 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
     if (d_wave) for (int q = 0; q < nq; ++q) ESCX_HIP(hipMemsetAsync(dy_q[q], 0, (size_t)B * L * sizeof(float), st));
     if (nq > 1 && (rc = disc_fork(d, st, nq))) return rc;
     const hipStream_t st0 = st;
+    DiscJoinGuard guard(d, st0, nq);
     float *gin = gin_q[0], *gspec = gspec_q[0], *gfr = gfr_q[0], *dWs = dWs_q[0], *part = part_q[0], *dy = dy_q[0];      // re-pointed per sub-discriminator
 
     // g: gradient of the layer's output map (g_pre: already the pre-activation gradient).  gx: gradient view of its input map; fin = 1 writes it
@@ -690,7 +701,7 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
     }
     st = st0; dy = dy_q[0];
     if (nq > 1) {
-        if ((rc = disc_join(d, st, nq))) return rc;
+        if ((rc = guard.join())) return rc;
         // the waveform gradients of the streams' sub-discriminators, added in a fixed order
         if (d_wave) for (int q = 1; q < nq; ++q) hipLaunchKernelGGL(add_into_kernel, dim3(blk((long long)B * L)), dim3(256), 0, st, dy, dy_q[q], (long long)B * L);
     }

@@ -549,9 +549,11 @@ extern "C" int escx_load_flat_params(escx_handle h, const float* flat_dev, int f
 
 extern "C" int64_t escx_train_tape_bytes(escx_handle h) {
     if (!h) return 0;
+    // everything the handle holds for activation tapes: the one-part arena AND the per-part arenas when both forms have been used
     const TrainRoot* r = static_cast<TrainRoot*>(h->train_state);
-    if (r && r->parts > 1) { int64_t t = 0; for (int p = 0; p < r->parts; ++p) t += (int64_t)r->arena[p].cap; return t; }
-    return (int64_t)h->tape.cap;
+    int64_t t = (int64_t)h->tape.cap;
+    if (r) for (int p = 0; p < TrainRoot::MAXP; ++p) t += (int64_t)r->arena[p].cap;
+    return t;
 }
 extern "C" int64_t escx_train_tape_generation(escx_handle h) { return (h && h->train_state) ? (int64_t)static_cast<TrainRoot*>(h->train_state)->generation : 0; }
 
@@ -696,6 +698,12 @@ extern "C" int escx_train_forward(escx_handle h, const float* flat_dev, const fl
     R.valid = false;
     ++R.generation;
     R.parts = train_parts_for(h, B);
+    {   // only the arenas of the form in use stay allocated (a run that alternates between one part and several - profiling, mixed batch
+        // sizes - used to hold both: ~35 GB + 2 x 17 GB at 36 clips)
+        auto drop = [&](Arena& a) -> int { if (a.base) { ESCX_HIP(hipDeviceSynchronize()); ESCX_HIP(hipFree(a.base)); a = Arena(); } return 0; };
+        if (R.parts == 1) { for (int p = 0; p < TrainRoot::MAXP; ++p) if ((rc = drop(R.arena[p]))) return rc; }
+        else if ((rc = drop(h->tape))) return rc;
+    }
     if (R.parts == 1) {
         R.cur = &R.single;
         rc = train_forward_impl(h, wave, B, L, S, freeze, codes_out, wave_out, raw_feat, recon_feat, cm_loss, cb_loss, st);
@@ -726,14 +734,14 @@ extern "C" int escx_train_forward(escx_handle h, const float* flat_dev, const fl
                                 cm_loss ? cm_loss + b0 : nullptr, cb_loss ? cb_loss + b0 : nullptr, p ? R.aux[p] : st);
         std::swap(h->tape, R.arena[p]);
         R.cur = &R.single;
-        if (rc) return rc;
+        if (rc) break;                  // join the aux streams below even on an error, they may still run on caller tensors
     }
     for (int p = 1; p < R.parts; ++p) {
         ESCX_HIP(hipEventRecord(R.ev_join[p], R.aux[p]));
         ESCX_HIP(hipStreamWaitEvent(st, R.ev_join[p], 0));
     }
-    R.valid = true;
-    return ESCX_OK;
+    R.valid = rc == 0;
+    return rc;
 }
 
 namespace {
@@ -1076,15 +1084,17 @@ extern "C" int escx_train_backward(escx_handle h, const float* d_wave, const flo
         std::swap(h->tape, R.arena[p]);
         if (p) std::swap(h->garena, R.garena[p]);
         R.cur = &R.single;
-        if (rc) return rc;
+        if (rc) break;                  // the aux streams are joined below on the error path too
     }
     // d loss / d parameter = ((part 0 + part 1) + part 2) + ... (fixed order)
     for (int p = 1; p < R.parts; ++p) {
         ESCX_HIP(hipEventRecord(R.ev_join[p], R.aux[p]));
         ESCX_HIP(hipStreamWaitEvent(st, R.ev_join[p], 0));
+        if (rc) continue;
         hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks_for((long long)h->flat_total / 4 + 1)), dim3(256), 0, st, grad_flat, R.gflat[p], (long long)(h->flat_total / 4));
         if (h->flat_total % 4) hipLaunchKernelGGL(add_tail_kernel, dim3(1), dim3(4), 0, st, grad_flat, R.gflat[p], (long long)(h->flat_total / 4 * 4), (long long)h->flat_total);
     }
+    if (rc) return rc;
     return launch_ok("train_backward");
 }
 
