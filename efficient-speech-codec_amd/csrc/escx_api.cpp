@@ -1206,8 +1206,16 @@ static int run_pvq_encode(escx_handle_s* h, const Quant& q, const float* enc, co
     const int splits = pvq_down_splits(M, q.Kq, q.Cp);
     if ((size_t)splits * M * q.Nz > h->zpart_cap) ESCX_FAIL(ESCX_ERR_STATE, "split-K scratch too small");
     const double vec = (double)c.overlap * q.Hq * q.C;
+    static const bool special = [] { const char* e = getenv("ESCX_PVQ_DOWN_KERNEL"); return e && e[0] == '1'; }();   // opt-in: bit-identical but slower than the engine form (profiles/r4_pvq_ab.txt)
+    int drc = -1;
+    if (special)
+        PROF("pvq_down_gemm", 2.0 * M * vec * q.d, (double)M * vec * (dec ? 2 : 1) * 4,
+             drc = pvq_down(enc, dec, B, q.Hq, W, q.Cp, c.overlap, q.wd, q.Nz, q.Kq, h->zpart, splits, pvq_down_bk(q.Cp), st));
+    if (drc != 0) {
+        if (special && h->prof && !h->prof_recs.empty()) h->prof_recs.pop_back();
     PROF("pvq_down_gemm", 2.0 * M * vec * q.d, (double)M * vec * (dec ? 2 : 1) * 4,
          gemm_pvq_down(enc, dec, B, q.Hq, W, q.Cp, c.overlap, q.wd, q.Nz, q.Kq, h->zpart, splits, st));
+    }
     int src_rc = 0;
     PROF("pvq_search", 2.0 * M * c.group_size * c.codebook_size * q.d, ((double)c.group_size * c.codebook_size * q.d + (double)M * c.group_size * q.d) * 4,
          src_rc = pvq_search(h->zpart, splits, M, q.Nz, q.cbn, q.c2, q.cbraw, c.group_size, c.codebook_size, q.d, q.dt, Tq, codes, bstride,

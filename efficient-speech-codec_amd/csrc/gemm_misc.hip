@@ -54,6 +54,8 @@ int pvq_down_splits(int /*M*/, int Kp, int Cp) {
     return (kIters + per - 1) / per;
 }
 
+int pvq_down_bk(int Cp) { return pick_bk(Cp); }
+
 void gemm_pvq_down(const float* enc, const float* dec, int B, int Hq, int Wd, int Cp, int ov, const float* W, int Np, int Kp,
                    float* zpart, int splits, hipStream_t s) {
     const int Tq = Wd / ov, M = B * Tq;

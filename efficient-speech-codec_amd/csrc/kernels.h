@@ -293,6 +293,57 @@ __global__ __launch_bounds__(256) void pvq_search_kernel(SearchArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// PVQ framing + residual + down-projection, split-K slices (quantization.py:74-91, 388-410; csrvq.py:16-18), round 4:
+//     zpart[z][(b, t)][n] = sum over k in slice z of W_down[n][k] * (enc - dec)[(b, h, ov*t + o)][c],   k = (o, h, c)
+// the specialised form of gemm_kernel<64, BN, BK, ResidualGatherA, EpiPartial>: a wave owns 16 framed vectors and one K slice; per 16-wide k chunk the
+// (o, h, c) decomposition is wave-uniform scalar arithmetic (the engine's loader did two multiply-high divisions per 16-byte operand fetch), the operand
+// and the NT weight fragments come straight from global memory one chunk ahead.  Same contraction order as the engine (chunks ascending, MFMA r = 0..3,
+// one chain per output tile), same slice boundaries (k_per_z from pvq_down_splits): bit-identical partial sums.
+// ------------------------------------------------------------------------------------------------
+struct PvqDownArgs { const float* enc; const float* dec; const float* W; float* zpart; int M, Tq, Hq, Wd, Cp, ov, Kp, Np, k_per_z; };
+
+template <int NT>
+__global__ __launch_bounds__(256) void pvq_down_kernel(PvqDownArgs a) {
+    ESCX_SET_PRIO_SMALL();
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = (blockIdx.x * 4 + wave) * 16 + l15;
+    const bool live = m < a.M;
+    const int b = live ? m / a.Tq : 0, t = live ? m - b * a.Tq : 0;
+    const size_t vecbase = ((size_t)b * a.Hq * a.Wd + (size_t)a.ov * t) * a.Cp + 4 * lg;
+    const int kbeg = blockIdx.y * a.k_per_z, kend = min(a.Kp, kbeg + a.k_per_z);
+    const float* wrow = a.W + (size_t)l15 * a.Kp + 4 * lg;
+    auto load = [&](int k0, f32x4& af, f32x4 (&wf)[NT]) {
+        const int oh = k0 / a.Cp, cc = k0 - oh * a.Cp, o = oh / a.Hq, h = oh - o * a.Hq;       // wave-uniform: a chunk never straddles a (o, h) row (Cp % 16 == 0)
+        const size_t idx = vecbase + (size_t)(h * a.Wd + o) * a.Cp + cc;
+        af = live ? ld4(a.enc + idx) : zero4();
+        if (a.dec && live) af -= ld4(a.dec + idx);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wf[n] = ld4(wrow + (size_t)(16 * n) * a.Kp + k0);
+    };
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = zero4();
+    f32x4 af, wf[NT], afn, wfn[NT];
+    if (kbeg < kend) load(kbeg, af, wf);
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        load(min(k0 + 16, kend - 16), afn, wfn);                // the last chunk re-reads itself (harmless)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][r], af[r], acc[n], 0, 0, 0);
+        af = afn;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wf[n] = wfn[n];
+    }
+    if (live) {
+        float* zr = a.zpart + ((size_t)blockIdx.y * a.M + m) * a.Np + 4 * lg;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) st4(zr + 16 * n, acc[n]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // PVQ de-quantisation + up-projection + un-frame + residual add (quantization.py:93-108, 124-136, 412-432; csrvq.py:19-21), round 4:
 //     out[(b, h, ov*t + o)][c] = dec[...] + sum_k W_up[n = (o, h, c)][k] * cb_g(k)[code[b, g(k), t]][k - g(k)*dt]
 // The GEMM engine ran this as a generic tile kernel (CodeGatherA loader + EpiPvqAdd epilogue): with K = 32..96 it issued 7-10 VALU instructions

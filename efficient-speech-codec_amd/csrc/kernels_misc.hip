@@ -57,6 +57,24 @@ void loss_reduce(const float* terms, int n_slots, int G, int M, int Tq, float* o
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(M / Tq), dim3(64), 0, s, terms, n_slots, G, M, Tq, out);
 }
 
+int pvq_down(const float* enc, const float* dec, int B, int Hq, int Wd, int Cp, int ov, const float* W, int Np, int Kp, float* zpart, int splits,
+             int bk, hipStream_t s) {
+    const int Tq = Wd / ov, M = B * Tq;
+    if (Np % 16 || Kp % 16 || Cp % 16 || bk % 16 || Kp % bk) return -1;
+    const int kIters = Kp / bk, per = (kIters + splits - 1) / splits;      // gemm_engine.h launch_tile: the SAME slice boundaries as the engine's split-K
+    if ((kIters + per - 1) / per != splits) return -1;
+    PvqDownArgs a{enc, dec, W, zpart, M, Tq, Hq, Wd, Cp, ov, Kp, Np, per * bk};
+    const dim3 grid((M + 63) / 64, splits);
+    switch (Np / 16) {
+        case 1: hipLaunchKernelGGL(pvq_down_kernel<1>, grid, dim3(256), 0, s, a); return 0;
+        case 2: hipLaunchKernelGGL(pvq_down_kernel<2>, grid, dim3(256), 0, s, a); return 0;
+        case 3: hipLaunchKernelGGL(pvq_down_kernel<3>, grid, dim3(256), 0, s, a); return 0;
+        case 4: hipLaunchKernelGGL(pvq_down_kernel<4>, grid, dim3(256), 0, s, a); return 0;
+        case 6: hipLaunchKernelGGL(pvq_down_kernel<6>, grid, dim3(256), 0, s, a); return 0;
+        default: return -1;
+    }
+}
+
 int pvq_up(const long long* codes, long long bstride, const float* cbraw, int G, int Ksz, int dt, int B, int Hq, int Wd, int Cp, int ov,
            const float* W, int Np, int Kp, const float* dec, float* out, hipStream_t s) {
     const int Tq = Wd / ov, M = B * Tq;

@@ -80,6 +80,10 @@ void ln_rows(int mode, const float* src, float* dst, const float* gamma, const f
              int src_rows_per_clip, int total_rows, int C, int Cp, hipStream_t s);
 int window_attention(const float* qkv, const float* bias, float* out, int total_windows, int nH, int hdp, int ldq, int ldo, int nWh,
                      int nWw, int shifted, hipStream_t s);
+// specialised PVQ framing + residual + down-projection (split-K partial sums, kernels.h); -1: geometry not covered, the caller falls back to gemm_pvq_down
+int pvq_down(const float* enc, const float* dec, int B, int Hq, int Wd, int Cp, int ov, const float* W, int Np, int Kp, float* zpart, int splits,
+             int bk, hipStream_t s);
+int pvq_down_bk(int Cp);        // the K step the engine would use for this map width (fixes the slice boundaries)
 // specialised PVQ de-quantise + up-project + un-frame + add (kernels.h); -1: geometry not covered, the caller falls back to gemm_pvq_up
 int pvq_up(const long long* codes, long long bstride, const float* cbraw, int G, int Ksz, int dt, int B, int Hq, int Wd, int Cp, int ov,
            const float* W, int Np, int Kp, const float* dec, float* out, hipStream_t s);
