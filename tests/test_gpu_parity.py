@@ -788,7 +788,7 @@ def test_parity_sweep_many_clips():
 
 @pytest.mark.gpu
 def test_opt_in_kernel_forms_against_the_default(tmp_path):
-    """Round 4 left four measured-and-rejected kernel forms in the library as opt-in switches (each reads its switch once per process, hence one
+    """Round 4 left measured-and-rejected kernel forms (and the engine forms the new PVQ up-projection replaced) in the library as switches (each reads its switch once per process, hence one
     child process per arm, tools/ab.py): the in-launch combine of the hidden-split MLP and the combine-on-load consumers must reproduce the
     default's codes AND audio bit for bit (same arithmetic, same order); the weight-stationary / shared-rows merge-split kernels pin their
     LayerNorm contraction explicitly, so they may differ from the default in low-order bits: identical codes, audio within 1e-6 RMS."""
@@ -796,7 +796,8 @@ def test_opt_in_kernel_forms_against_the_default(tmp_path):
     from conftest import ROOT
     ab = os.path.join(ROOT, "tools", "ab.py")
     arms = {"default": {}, "mlp_fused_combine": {"ESCX_MLP_FUSED_COMBINE": "1"}, "combine_on_load": {"ESCX_COMBINE_ON_LOAD": "1"},
-            "rowgemm_ws": {"ESCX_ROWGEMM_WS": "4"}, "rowgemm_xs": {"ESCX_ROWGEMM_XS": "1"}}
+            "rowgemm_ws": {"ESCX_ROWGEMM_WS": "4"}, "rowgemm_xs": {"ESCX_ROWGEMM_XS": "1"},
+            "pvq_down_kernel": {"ESCX_PVQ_DOWN_KERNEL": "1"}, "pvq_up_engine": {"ESCX_PVQ_UP_KERNEL": "0"}, "attn_gs_off": {"ESCX_ATTN_GS_TOKENS": "0"}}
     got = {}
     for name, env in arms.items():
         out = str(tmp_path / f"{name}.npz")
@@ -805,9 +806,9 @@ def test_opt_in_kernel_forms_against_the_default(tmp_path):
         assert r.returncode == 0 and "AB_RESULT" in r.stdout, f"{name}: {r.stderr[-800:]}"
         got[name] = np.load(out)
     ref = got["default"]
-    for name in ("mlp_fused_combine", "combine_on_load"):
+    for name in ("mlp_fused_combine", "combine_on_load", "pvq_down_kernel", "pvq_up_engine"):
         assert np.array_equal(got[name]["codes"], ref["codes"]) and np.array_equal(got[name]["wave"], ref["wave"]), f"{name} is not bit-identical to the default"
-    for name in ("rowgemm_ws", "rowgemm_xs"):
+    for name in ("rowgemm_ws", "rowgemm_xs", "attn_gs_off"):     # attn_gs_off: the C=384 attention without the head-group split (other projection order)
         assert np.array_equal(got[name]["codes"], ref["codes"]), f"{name}: codes differ from the default"
         rms = float(np.sqrt(np.mean((got[name]["wave"].astype(np.float64) - ref["wave"]) ** 2)))
         assert rms <= 1e-6, f"{name}: audio rms {rms}"
