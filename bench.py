@@ -379,6 +379,8 @@ def run_train_adv(args, rank, world, device, use_dist, emit=True):
     from scripts.train import AdvStepper
     model, cfg, sd = build_model(device, "large")
     disc = Discriminator(sample_rate=16000).to(device)
+    prec = getattr(args, "adv_precision", None) or os.environ.get("ESCX_BENCH_ADV_PRECISION", "fp32")
+    disc.set_conv_precision(prec)           # "bf16": the wide period convolutions on the bf16 MFMA (opt-in; BASELINE configs[4] names bf16, the reference trains fp32)
     bsz = int(os.environ.get("ESCX_BENCH_ADV_BATCH", CLIPS_PER_GPU))
     pcm = np.stack([(synth.voiced_clip_int16 if i % 2 else synth.noise_clip_int16)(f"bench-r{rank}-{i}", TRAIN_SAMPLES) for i in range(bsz)])
     x = torch.from_numpy(synth.pcm_to_float(pcm)).to(device)
@@ -439,10 +441,13 @@ def run_train_adv(args, rank, world, device, use_dist, emit=True):
     audio_s = bsz * world * args.steps * (TRAIN_SAMPLES / 16000.0)
     out = {"metric": "audio-seconds/sec trained, adversarial step (generator + discriminator updates), ESC-Large 9kbps 3s@16kHz",
            "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": (dist.get_world_size() if use_dist else 1), "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" if prec == "fp32" else "f32 + bf16 MFMA (fp32 accumulate) in the discriminator's wide convolutions",
            "data": "synthetic",
            "config": {"workload": f"BASELINE configs[4]: ESC-Large 9kbps + adversarial training step (scripts/trainer_adv.py:61-107), batch={bsz} clips of "
-                                  f"{TRAIN_SAMPLES} samples per GPU, num_streams=6, fp32 (the reference has no bf16 / AMP path)",
+                                  f"{TRAIN_SAMPLES} samples per GPU, num_streams=6, " + ("fp32 (the reference has no bf16 / AMP path)" if prec == "fp32" else
+                                  "generator fp32, discriminator period convolutions 128->512->1024->1024 with bf16 operands (opt-in precision)"),
+                      "discriminator_conv_precision": prec,
                       "global_batch": bsz * world, "clip_samples": TRAIN_SAMPLES, "num_streams": NUM_STREAMS, "parallelism": f"dp{world}",
                       "generator_params_M": round(n_gen / 1e6, 2), "discriminator_params_M": round(n_disc / 1e6, 2),
                       "losses": {k: round(float(v), 5) for k, v in log.items() if torch.is_tensor(v)}},
@@ -495,6 +500,8 @@ def main():
     ap.add_argument("--mode", choices=["codec", "train", "train_adv"], default="codec",
                     help="codec (default): encode+decode throughput, the BASELINE metric; train: the non-adversarial optimisation step (ESC-Base); "
                          "train_adv: BASELINE configs[4] - ESC-Large + the adversarial step (generator and discriminator updates), fp32")
+    ap.add_argument("--adv-precision", choices=["fp32", "bf16"], default=None,
+                    help="train_adv: arithmetic of the discriminator's wide convolutions (default fp32 = the reference's; bf16 = operands rounded to bf16, fp32 accumulation)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
                     help="timed steps (default: 200 for the codec = 3 s of GPU work, enough for a utilisation sampler to see it; 20 for train, 6 for train_adv)")

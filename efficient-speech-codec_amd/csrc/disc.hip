@@ -21,6 +21,7 @@
 #include "launchers.h"
 #include "train_kernels.h"
 #include "disc_kernels.h"
+#include "gemm_bf16.h"
 
 using namespace escx;
 
@@ -55,6 +56,7 @@ struct escx_disc_s {
     float* wbuf = nullptr; size_t wfloats = 0;
     float* scratch = nullptr; size_t scratch_bytes = 0;
     const float* packed_ptr = nullptr; long long packed_version = -1;      // which (buffer, version) the packed weights were derived from
+    int precision = 0;                   // escx_disc_set_precision: 1 = bf16 MFMA for the wide convolutions
     hipStream_t aux[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};    // extra streams: the sub-discriminators are independent of each other
 };
 
@@ -231,9 +233,14 @@ inline int conv_cp(const ConvTS& l) { return l.y.Cp; }
 inline int conv_cp(const ConvTSP& l) { return l.y.Cp; }
 inline int conv_cp(const PlainA&) { return 0; }
 
+thread_local int tls_conv_bf16 = 0;      // precision of the handle whose forward / backward is being enqueued by this thread
+
 template <class Ld, class Epi>
 void conv_gemm(const Ld& ld_in, const float* W, int M, int Np, int Kp, const Epi& ep, hipStream_t st) {
     Ld ld = ld_in;
+    if constexpr (!std::is_same<Ld, PlainA>::value) {            // opt-in bf16 MFMA for the wide layers (gemm_bf16.h): same gathers, same epilogues
+        if (tls_conv_bf16 && bf16_gemm_ok(M, Np, Kp) && conv_cp(ld) % 32 == 0) { ld.fast = 1; launch_gemm_bf16(ld, W, M, Np, Kp, ep, st); return; }
+    }
     const long long tiles128 = (long long)((M + 127) / 128) * ((Np + 95) / 96);
     // K steps of 16: 18 KB of LDS per workgroup instead of 75 KB at the engine's default step of 80 for K = 5 x 1024 - twice the resident
     // workgroups per CU; measured on the step's convolutions (tools/disc_trace.py): forward 73.5 -> 60.2 ms, dX 115.8 -> 99.0 ms
@@ -282,7 +289,10 @@ int disc_dw(const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, floa
         int mps = ((M + slices - 1) / slices + 31) / 32 * 32;
         slices = (M + mps - 1) / mps;
         float* bpart = part + (size_t)slices * Np * Kp;
-        if (big) hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, 4, 4, 2, 2, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+        static const bool dw_bf16_ok = [] { const char* e = getenv("ESCX_DISC_BF16_DW"); return !(e && e[0] == '0'); }();      // 0: bf16 precision keeps the fp32 dW kernels (A/B)
+        if (big && tls_conv_bf16 && dw_bf16_ok && Np % 128 == 0 && Kp % 128 == 0)
+            hipLaunchKernelGGL((gemm_dw_bf16_kernel<LdA, LdB>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+        else if (big) hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, 4, 4, 2, 2, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
         else hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, 2, 3, 1, 4, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
         launch_reduce_partials(part, slices, (long long)Np * Kp, dW, 0, st);
         launch_reduce_partials(bpart, slices, (long long)Np, db, 0, st);
@@ -391,6 +401,14 @@ extern "C" void escx_disc_destroy(escx_disc d) {
     delete d;
 }
 
+extern "C" int escx_disc_set_precision(escx_disc d, int mode) {
+    if (!d) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null handle");
+    if (mode != 0 && mode != 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "discriminator precision %d: 0 (fp32) or 1 (bf16 MFMA for the wide convolutions)", mode);
+    d->precision = mode;
+    return ESCX_OK;
+}
+extern "C" int escx_disc_get_precision(escx_disc d) { return d ? d->precision : -1; }
+
 extern "C" int escx_disc_param_count(escx_disc d) { return d ? (int)d->keys.size() : 0; }
 extern "C" const char* escx_disc_param_key(escx_disc d, int i) { return (d && i >= 0 && i < (int)d->keys.size()) ? d->keys[i].c_str() : nullptr; }
 extern "C" int64_t escx_disc_param_offset(escx_disc d, int i) { return (d && i >= 0 && i < (int)d->offs.size()) ? (int64_t)d->offs[i] : -1; }
@@ -464,6 +482,7 @@ extern "C" int escx_disc_forward(escx_disc d, const float* flat_params, int64_t 
     if (!d || !flat_params || !wave || !fmaps || B < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
     ESCX_HIP(hipSetDevice(d->device));
     hipStream_t st = (hipStream_t)stream;
+    tls_conv_bf16 = d->precision;
     int maxp = 1; for (const DSub& S : d->subs) if (S.kind == 0) maxp = std::max(maxp, S.arg);
     if (L <= maxp + 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "clip too short for the reflect padding of the period discriminators");
     std::vector<FmapShape> shp; fmap_shapes(d, L, &shp);
@@ -518,6 +537,7 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
     if (!d || !flat_params || !wave || !fmaps || !d_fmaps || B < 1 || (!grad_flat && !d_wave)) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "bad argument");
     ESCX_HIP(hipSetDevice(d->device));
     hipStream_t st = (hipStream_t)stream;
+    tls_conv_bf16 = d->precision;
     std::vector<FmapShape> shp; fmap_shapes(d, L, &shp);
     // scratch: front + gradient buffers of every feature-map BUFFER (concatenated buffers once) + input-map gradients + dW staging
     const size_t front = front_floats(d, B, L);

@@ -1,0 +1,203 @@
+// bf16-MFMA variant of the GEMM engine for the adversarial step's wide convolutions (BASELINE configs[4] names bf16; the reference itself trains in fp32,
+// so this is an OPT-IN precision of the discriminator: escx_disc_set_precision).  Out = epilogue( A_loader(m, k) . W[n][k] ), operands rounded to bf16
+// (round to nearest even) when they are staged into LDS, products and sums in fp32 on v_mfma_f32_16x16x32_bf16 - 16x the matrix rate of the fp32 MFMA.
+//
+//  * same loader / epilogue interfaces as gemm_engine.h (the implicit-GEMM gathers ConvSU / ConvTS / ConvTSP and the dX / activation epilogues are shared):
+//    the feature maps and the packed weights stay fp32 in HBM, every other kernel of the step is unchanged;
+//  * same operand roles: the WEIGHT tile is the MFMA "A" operand, the ACTIVATION tile the "B" operand: lane (l15, lg) ends up with 4 consecutive output
+//    features of one output row; a lane's 8 bf16 of an operand are 8 consecutive k of one tile row (one ds_read_b128 from the [row][k] LDS image) - the
+//    k slots of the two operands pair up whatever the instruction's internal k order is;
+//  * K step 32 (one MFMA deep), 256 x 128 or 128 x 128 workgroup tiles: at 16x the matrix rate the kernel is bound by what the L2 feeds (fp32 operands:
+//    44 / 32 FLOP per byte), so the tile is as large as the register file allows;
+//  * 1-D grid with the N tiles of one M tile adjacent (they gather the same activation rows at the same time), n tiles first in the block index.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gemm_engine.h"
+
+namespace escx {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
+    bf16x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (__bf16)v[e];           // v_cvt_pk_bf16_f32: round to nearest even
+    return r;
+}
+
+template <int BM, int BN, class Loader, class Epi>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* __restrict__ Wt, int M, int Np, int Kp, int nblk_n, Epi ep) {
+    static_assert(BM % 64 == 0 && BN % 16 == 0, "tile shape");
+    constexpr int BK = 32;
+    constexpr int LD = BK + 8;                 // bf16 per LDS row: 80 B, the 16 rows of a fragment read start 20 banks apart
+    constexpr int TM = BM / 64, TN = BN / 16;
+    constexpr int KV = BK / 4;                 // float4 per tile row and K step
+    constexpr int AJ = BM * KV / 256, BJ = BN * KV / 256;
+    static_assert((BM * KV) % 256 == 0 && (BN * KV) % 256 == 0, "tile rows x K step must fill the workgroup");
+
+    __shared__ __attribute__((aligned(16))) __bf16 As[BM * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[BN * LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int bm = blockIdx.x / nblk_n, bn = blockIdx.x - bm * nblk_n;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    typename Loader::Ctx ctx[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) ctx[j] = ld.make_ctx(m0 + (tid + j * 256) / KV);
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = zero4();
+
+    f32x4 ra[AJ], rb[BJ];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) ra[j] = ld.load4(ctx[j], k0, 4 * ((tid + j * 256) % KV));
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int i = tid + j * 256, row = i / KV, c4 = i % KV;
+            rb[j] = (n0 + row < Np) ? ld4(Wt + (size_t)(n0 + row) * Kp + k0 + 4 * c4) : zero4();
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < Kp; k0 += BK) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) { const int i = tid + j * 256; *reinterpret_cast<bf16x4*>(&As[(i / KV) * LD + 4 * (i % KV)]) = to_bf16x4(ra[j]); }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) { const int i = tid + j * 256; *reinterpret_cast<bf16x4*>(&Bs[(i / KV) * LD + 4 * (i % KV)]) = to_bf16x4(rb[j]); }
+        __syncthreads();
+        if (k0 + BK < Kp) fetch(k0 + BK);
+        bf16x8 af[TM];
+#pragma unroll
+        for (int b = 0; b < TM; ++b) af[b] = *reinterpret_cast<const bf16x8*>(&As[(wave * (BM / 4) + b * 16 + l15) * LD + 8 * lg]);
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(&Bs[(a * 16 + l15) * LD + 8 * lg]);
+#pragma unroll
+            for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const int m = m0 + wave * (BM / 4) + b * 16 + l15;
+        if (m >= M) continue;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int n = n0 + a * 16 + 4 * lg;
+            if (n < Np) ep.store(m, n, acc[a][b], 0);
+        }
+    }
+}
+
+// Shapes this variant takes: K a multiple of the 32-wide step, outputs a multiple of the 128-wide tile, enough rows to fill the chip with the chosen tile.
+inline bool bf16_gemm_ok(int M, int Np, int Kp) { return Np % 128 == 0 && Kp % 32 == 0 && Kp >= 256 && M >= 4096; }
+
+template <class Loader, class Epi>
+inline void launch_gemm_bf16(const Loader& ld, const float* Wt, int M, int Np, int Kp, const Epi& ep, hipStream_t s) {
+    static const int env_bm = [] { const char* e = getenv("ESCX_BF16_BM"); return e ? atoi(e) : 0; }();       // tuning aid: 128 / 256 rows per workgroup
+    const int nbn = Np / 128;
+    const bool big = env_bm ? env_bm == 256 : (long long)((M + 255) / 256) * nbn >= 1024;
+    if (big) hipLaunchKernelGGL((gemm_bf16_kernel<256, 128, Loader, Epi>), dim3(((M + 255) / 256) * nbn), dim3(256), 0, s, ld, Wt, M, Np, Kp, nbn, ep);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, Loader, Epi>), dim3(((M + 127) / 128) * nbn), dim3(256), 0, s, ld, Wt, M, Np, Kp, nbn, ep);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dW[n][k] = sum_m A[m][n] * B[m][k] on the bf16 MFMA (A = upstream-gradient rows, B = the gathered input rows), db[n] = sum_m A[m][n] in fp32.
+// The contraction runs over ROWS, so both operands have to reach the MFMA transposed (8 consecutive m per lane): a thread loads rows (m, m + 1) of its four
+// columns, rounds, packs the two rows into one 32-bit word and writes [column][m] into LDS - lanes walk m fastest, so the 64 words of a write hit 64 banks,
+// and the fragment reads are the same conflict-free 16-byte reads as in the forward kernel.  One workgroup = one 128 x 128 tile of dW and one slice of M,
+// 2 x 2 waves of 64 x 64; the X side is the MFMA "A" operand so that a lane holds four consecutive k of one n (16-byte stores into part[slice][n][k]).
+// Slices are added in increasing order by reduce_partials, as in the fp32 kernels.
+// ------------------------------------------------------------------------------------------------
+template <class LdA, class LdB>
+__global__ __launch_bounds__(256) void gemm_dw_bf16_kernel(LdA la, LdB lb, int M, int Np, int Kp, int nblk_k, int m_per_slice, float* __restrict__ part,
+                                                           float* __restrict__ bpart) {
+    constexpr int T = 128, MS = 32, LD = MS + 8;
+    __shared__ __attribute__((aligned(16))) __bf16 At[T * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bt[T * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int mp = lane & 15, cq = 4 * (4 * wave + (lane >> 4));          // staging role: row pair mp of the step, columns cq .. cq + 3 (and + 64)
+    const int bn = blockIdx.x / nblk_k, bk = blockIdx.x - bn * nblk_k;
+    const int n0 = bn * T, k0 = bk * T;
+    const int mbeg = blockIdx.y * m_per_slice, mend = min(M, mbeg + m_per_slice);
+    const int wi = wave & 1, wj = wave >> 1;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = zero4();
+    f32x4 bs[2] = {zero4(), zero4()};
+    f32x4 ra[2][2], rb[2][2];                   // [column group][row of the pair]
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int m = m0 + 2 * mp + r;
+            const typename LdA::Ctx ca = la.make_ctx(m < mend ? m : M);         // rows behind the slice (or the matrix) read as zero
+            const typename LdB::Ctx cb = lb.make_ctx(m < mend ? m : M);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { ra[j][r] = la.load4(ca, n0 + 64 * j + cq, 0); rb[j][r] = lb.load4(cb, k0 + 64 * j + cq, 0); }
+        }
+    };
+    auto pack2 = [](float lo, float hi) -> unsigned {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        bf16x2 p; p[0] = (__bf16)lo; p[1] = (__bf16)hi;
+        return __builtin_bit_cast(unsigned, p);
+    };
+    if (mbeg < mend) fetch(mbeg);
+    for (int m0 = mbeg; m0 < mend; m0 += MS) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bs[j] += ra[j][0] + ra[j][1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                *reinterpret_cast<unsigned*>(&At[(64 * j + cq + e) * LD + 2 * mp]) = pack2(ra[j][0][e], ra[j][1][e]);
+                *reinterpret_cast<unsigned*>(&Bt[(64 * j + cq + e) * LD + 2 * mp]) = pack2(rb[j][0][e], rb[j][1][e]);
+            }
+        }
+        __syncthreads();
+        if (m0 + MS < mend) fetch(m0 + MS);
+        bf16x8 af[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) af[b] = *reinterpret_cast<const bf16x8*>(&At[(64 * wj + 16 * b + l15) * LD + 8 * lg]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(&Bt[(64 * wi + 16 * a + l15) * LD + 8 * lg]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* pt = part + (size_t)blockIdx.y * Np * Kp;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int n = n0 + 64 * wj + 16 * b + l15;
+        if (n >= Np) continue;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int k = k0 + 64 * wi + 16 * a + 4 * lg;
+            if (k < Kp) st4(pt + (size_t)n * Kp + k, acc[a][b]);
+        }
+    }
+    if (bpart && bk == 0) {                     // column sums of the upstream rows this thread staged, over the 16 row pairs of a step: a fixed shuffle tree
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = bs[j][e];
+#pragma unroll
+                for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o, 16);
+                bs[j][e] = v;
+            }
+            const int n = n0 + 64 * j + cq;
+            if (mp == 0 && n < Np) st4(bpart + (size_t)blockIdx.y * Np + n, bs[j]);
+        }
+    }
+}
+
+}  // namespace escx

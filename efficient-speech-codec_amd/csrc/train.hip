@@ -226,16 +226,26 @@ constexpr size_t LN_PART_FLOATS = (size_t)513 * 2 * 2 * 384;
 
 // dx_fc1 GEMM with the LayerNorm backward as its row epilogue (EpiLnBwdRows; Cp <= 96): out = add + LNbwd(dh . W; x), dgamma / dbeta.
 // `part` needs ceil(M / 64) * 4 * 2 * Cp floats (+ 2 * Cp for the reduced row): the dW partial-sum scratch is used.
+// Round 4: also for the wide maps (Cp = 144 / 192 / 384) - one workgroup tile spans the row there too (BN = Cp), with the register-lean form of the epilogue.
+bool ln_rows_fusable(int Cp) {
+    static const bool wide = [] { const char* e = getenv("ESCX_LN_FUSED_WIDE"); return e && e[0] == '1'; }();          // opt-in: measured slower than the stand-alone LayerNorm backward above Cp = 96
+    return Cp <= 96 || (wide && (Cp == 144 || Cp == 192 || Cp == 384));
+}
 void gemm_ln_bwd_rows(const float* A, int lda, int M, const float* Wt, int Cp, int Kp, const float* x, const float* gamma, const float* add, float* dx,
                       float* dx_slots, const int* slot_of, int rows_per_clip, int slots_per_clip, int C, float* dg, float* dbt, float* part, hipStream_t st,
                       const int* row_map = nullptr) {
     EpiLnBwdRows ep{x, gamma, add, dx, dx_slots, slot_of, part, C, Cp, rows_per_clip, slots_per_clip, 1e-5f, row_map};
-    const bool big = (long long)((M + 127) / 128) >= 512;
+    static const int wide_bm = [] { const char* e = getenv("ESCX_LNBWD_WIDE_BM"); return e ? atoi(e) : 0; }();       // tuning aid: 64 / 128 rows per workgroup for the 144 / 192-wide tiles
+    const bool big = Cp > 96 ? (Cp != 384 && (wide_bm ? wide_bm == 128 : (long long)((M + 127) / 128) >= 512)) : (long long)((M + 127) / 128) >= 512;
     const int rows = (big ? (M + 127) / 128 : (M + 63) / 64) * 4;
     static const int env_bk = [] { const char* e = getenv("ESCX_LNBWD_BK"); return e ? atoi(e) : 16; }();
     const int bk = (env_bk > 0 && Kp % env_bk == 0) ? env_bk : 16;
-    if (big) launch_gemm<128>(PlainA{A, lda, M}, Wt, M, Cp, Kp, ep, st, 1, bk);
-    else launch_gemm<64>(PlainA{A, lda, M}, Wt, M, Cp, Kp, ep, st, 1, bk);
+    const PlainA la{A, lda, M};
+    if (Cp == 144) { if (big) launch_tile<128, 144, 16>(la, Wt, M, Cp, Kp, 1, ep, st); else launch_tile<64, 144, 16>(la, Wt, M, Cp, Kp, 1, ep, st); }
+    else if (Cp == 192) { if (big) launch_tile<128, 192, 16>(la, Wt, M, Cp, Kp, 1, ep, st); else launch_tile<64, 192, 16>(la, Wt, M, Cp, Kp, 1, ep, st); }
+    else if (Cp == 384) launch_tile<64, 384, 16>(la, Wt, M, Cp, Kp, 1, ep, st);
+    else if (big) launch_gemm<128>(la, Wt, M, Cp, Kp, ep, st, 1, bk);
+    else launch_gemm<64>(la, Wt, M, Cp, Kp, ep, st, 1, bk);
     float* red = part + (size_t)rows * 2 * Cp;
     launch_reduce_partials(part, rows, (long long)2 * Cp, red, 0, st, red + 2 * Cp);
     hipLaunchKernelGGL(copy2_kernel, dim3(blocks_for(2 * Cp)), dim3(256), 0, st, red, dg, dbt, Cp);
@@ -815,7 +825,7 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
              rc = dw_rows(h, dhpre, L.hiddenP, bt.xn2, L.Cp, M, L.hiddenP, L.Cp, G(h, bw.w1), G(h, bw.b1), part, st));
         if (rc) return rc;
         if (slots != tokens) ESCX_HIP(hipMemsetAsync(dx1s, 0, (size_t)Ms * L.Cp * sizeof(float), st));      // pad slots carry no gradient
-        if (ln_fused && L.Cp <= 96) {       // narrow maps: LN2's backward rides in the epilogue of the GEMM that produces its upstream gradient
+        if (ln_fused && ln_rows_fusable(L.Cp)) {       // LN2's backward rides in the epilogue of the GEMM that produces its upstream gradient
             PROF("B.dx_fc1+ln2" + tg, 2.0 * M * L.C * L.hidden, ((double)M * (L.hiddenP + 3 * L.Cp) + (double)Ms * L.Cp) * 4,
                  gemm_ln_bwd_rows(dhpre, L.hiddenP, M, bw.w1T, L.Cp, L.hiddenP, bt.x1, bw.ln2_g, dy, dx1, dx1s, inv, tokens, slots, L.C, G(h, bw.ln2_g),
                                   G(h, bw.ln2_b), part, st));
@@ -841,7 +851,7 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
         PROF("B.dw_qkv" + tg, 2.0 * Ms * L.C * 3 * L.C, (double)Ms * (L.Nqkv + L.Cp) * 4,
              rc = dw_rows(h, dqkv, L.Nqkv, bt.xn1, L.Cp, Ms, L.Nqkv, L.Cp, G(h, bw.wqkv), G(h, bw.bqkv), part, st));
         if (rc) return rc;
-        if (ln_fused && L.Cp <= 96) {       // LN1's backward in the epilogue of the QKV dX GEMM: its rows are window slots, map = slot -> token
+        if (ln_fused && ln_rows_fusable(L.Cp)) {       // LN1's backward in the epilogue of the QKV dX GEMM: its rows are window slots, map = slot -> token
             PROF("B.dx_qkv+ln1" + tg, 2.0 * Ms * L.C * 3 * L.C, ((double)Ms * L.Nqkv + 3.0 * M * L.Cp) * 4,
                  gemm_ln_bwd_rows(dqkv, L.Nqkv, Ms, bw.wqkvT, L.Cp, L.Nqkv, bt.x0, bw.ln1_g, dx1, dprev, nullptr, nullptr, tokens, slots, L.C, G(h, bw.ln1_g),
                                   G(h, bw.ln1_b), part, st, map));
@@ -881,8 +891,15 @@ int quant_bwd(escx_handle_s* h, TrainTape& T, int sid, const float* gref, float*
     const float scale = 1.0f / ((float)Tq * q.d * Gr);
     hipLaunchKernelGGL(pvq_train_bwd_kernel, dim3(blocks_for((long long)M * Gr)), dim3(256), 0, st, Q.ze, codes, bstride, q.cbraw, dzup, dcm, dcb, dze, gq,
                        M, Gr, c.codebook_size, q.d, q.dt, q.Nz, Tq, scale, T.freeze);
-    hipLaunchKernelGGL(codebook_grad_kernel, dim3(Gr * ((c.codebook_size + CBG_CODES - 1) / CBG_CODES)), dim3(256), 0, st, codes, bstride, gq, G(h, q.cbraw), M,
-                       Gr, c.codebook_size, q.dt, q.Nz, Tq);
+    {
+        const dim3 cg(Gr * ((c.codebook_size + CBG_CODES - 1) / CBG_CODES));
+        float* dcbw = G(h, q.cbraw);
+        if (q.dt <= 8) hipLaunchKernelGGL(codebook_grad_kernel<8>, cg, dim3(256), 0, st, codes, bstride, gq, dcbw, M, Gr, c.codebook_size, q.dt, q.Nz, Tq);
+        else if (q.dt <= 16) hipLaunchKernelGGL(codebook_grad_kernel<16>, cg, dim3(256), 0, st, codes, bstride, gq, dcbw, M, Gr, c.codebook_size, q.dt, q.Nz, Tq);
+        else if (q.dt <= 32) hipLaunchKernelGGL(codebook_grad_kernel<32>, cg, dim3(256), 0, st, codes, bstride, gq, dcbw, M, Gr, c.codebook_size, q.dt, q.Nz, Tq);
+        else if (q.dt <= 64) hipLaunchKernelGGL(codebook_grad_kernel<64>, cg, dim3(256), 0, st, codes, bstride, gq, dcbw, M, Gr, c.codebook_size, q.dt, q.Nz, Tq);
+        else ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "codebook gradient: code dimension above 64");
+    }
     // down-projection: ze = residual_frames . Wd^T   (Wd packed [Nz][Kq])
     ResidualGatherA rfr{Q.enc, Q.dec, q.Hq, W, q.Cp, Tq, c.overlap, M, FastDiv(Tq), FastDiv(q.Cp), FastDiv(q.Hq)};
     if ((rc = dw_launch(h, PlainA{dze, q.Nz, M}, rfr, M, q.Nz, q.Kq, G(h, q.wd), nullptr, part, st))) return rc;

@@ -192,8 +192,85 @@ struct EpiLnBwdRows {
     const int* row_map;         // optional: the GEMM's rows are window SLOTS (LN1: the upstream gradient comes out of the QKV GEMM in slot order);
                                 // row_map[slot] = token of the clip or -1 for a pad slot, x / add / dx are indexed by token
     __device__ __forceinline__ void store(int, int, f32x4, int) const {}
+    // Wide maps (Cp = 144 / 192 / 384, round 4): the narrow form below keeps x, gamma and both column-sum accumulators of a whole row tile in
+    // registers (4 x TN float4 next to the accumulators) - at TN = 12..24 that is beyond the register file.  Here phase 1 takes the row statistics and
+    // the two projection sums per row tile (x held for ONE row tile at a time), phase 2 walks the column tiles, re-reads x (an L2 hit) and finishes
+    // each column tile's rows and column sums before the next: the same per-element arithmetic in the same order, accumulators + ~60 registers.
+    template <int TN, int TM>
+    __device__ __forceinline__ void finish_wide(f32x4 (&acc)[TN][TM], int row0, int lane, int M) const {
+        const int l15 = lane & 15, lg = lane >> 4;
+        const float invC = 1.0f / (float)C;
+        int mrow[TM], dsrow[TM]; bool lv[TM]; float mean[TM], rstd[TM], c1[TM], c2[TM];
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            int m = row0 + 16 * b + l15;
+            bool live = m < M;
+            if (row_map && live) {
+                const int bi = m / slots_per_clip; const int tok = row_map[m - bi * slots_per_clip];
+                live = tok >= 0; m = bi * rows_per_clip + tok;
+            }
+            mrow[b] = live ? m : 0; lv[b] = live; dsrow[b] = -1;
+            if (live && dx_slots) { const int bi = m / rows_per_clip, rr = m - bi * rows_per_clip; dsrow[b] = bi * slots_per_clip + slot_of[rr]; }
+            f32x4 xv[TN];
+            float s = 0.f;
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int n = 16 * a + 4 * lg;
+                xv[a] = (live && n < Cp) ? ld4(x + (size_t)m * Cp + n) : zero4();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (n + e < C) s += xv[a][e];
+            }
+            mean[b] = sum_groups(s) * invC;
+            float var = 0.f;
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (16 * a + 4 * lg + e < C) { const float d = xv[a][e] - mean[b]; var += d * d; }
+            rstd[b] = 1.0f / sqrtf(sum_groups(var) * invC + eps);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int n = 16 * a + 4 * lg;
+                const f32x4 gm = n < Cp ? ld4(gamma + n) : zero4();
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < C) { const float xh = (xv[a][e] - mean[b]) * rstd[b], t = acc[a][b][e] * gm[e]; s1 += t; s2 += t * xh; }
+            }
+            c1[b] = sum_groups(s1) * invC; c2[b] = sum_groups(s2) * invC;
+        }
+        float* pr = part + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 * Cp;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int n = 16 * a + 4 * lg;
+            const f32x4 gm = n < Cp ? ld4(gamma + n) : zero4();
+            f32x4 ag = zero4(), ab = zero4();
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                if (!lv[b] || n >= Cp) continue;
+                const f32x4 xr = ld4(x + (size_t)mrow[b] * Cp + n);
+                f32x4 o = add ? ld4(add + (size_t)mrow[b] * Cp + n) : zero4();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (xr[e] - mean[b]) * rstd[b], g = acc[a][b][e];
+                    if (n + e < C) { ag[e] += g * xh; ab[e] += g; o[e] = o[e] + rstd[b] * (g * gm[e] - c1[b] - xh * c2[b]); }
+                    else o[e] = 0.f;
+                }
+                st4(dx + (size_t)mrow[b] * Cp + n, o);
+                if (dsrow[b] >= 0) st4(dx_slots + (size_t)dsrow[b] * Cp + n, o);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float u = ag[e], w = ab[e];
+#pragma unroll
+                for (int o = 8; o >= 1; o >>= 1) { u += __shfl_xor(u, o, 16); w += __shfl_xor(w, o, 16); }
+                ag[e] = u; ab[e] = w;
+            }
+            if (l15 == 0 && n < Cp) { st4(pr + n, ag); st4(pr + Cp + n, ab); }
+        }
+    }
     template <int TN, int TM>
     __device__ __forceinline__ void finish(f32x4 (&acc)[TN][TM], int row0, int lane, int M) const {
+        if constexpr (TN > 6) { finish_wide<TN, TM>(acc, row0, lane, M); return; }
         const int l15 = lane & 15, lg = lane >> 4;
         const float invC = 1.0f / (float)C;
         f32x4 gm[TN], ag[TN], ab[TN];
@@ -1007,19 +1084,38 @@ static __global__ void pvq_train_bwd_kernel(const float* __restrict__ ze, const 
 }
 
 // embedding gradient without atomics.  One workgroup per (group, 16 codes): the group's codes are staged once in LDS as int16 (the
-// per-element b / t division happens there, not once per code), then each of the 4 waves takes 4 codes in turn, scans the vectors 64 at a
-// time and adds the rows of those that chose the code in increasing vector order (lane j carries dimension j).  The wave-per-code form
-// re-read and re-divided all codes for every code: 425 us per stream, 2.6 % of the training step.
-constexpr int CBG_CODES = 16, CBG_MAXM = 24576;
+// per-element b / t division happens there, not once per code), then each of the 4 waves takes 4 codes in turn and scans the vectors 64 at a
+// time.  Round 4: the vectors that chose the code are first COLLECTED - ballot + prefix rank into a wave-private LDS list, in increasing vector
+// order - and the list is summed in batches of F = SL * 16 rows with all 16 row loads of a lane in flight together: the 64 lanes are SL = 64 / DTP
+// slots of DTP dimensions, slot s adds the hits whose position in the code's hit order is = s (mod SL), in increasing order, and the slots are
+// added in slot order at the end - a fixed order whatever the launch geometry.  Rounds 2-3 added the hit rows one dependent load (then four) at a
+// time: with a skewed code usage (a few codes chosen by hundreds of vectors - every untrained codebook) that chain was the kernel, 200 us per stream.
+constexpr int CBG_CODES = 16, CBG_MAXM = 24576, CBG_U = 16;
+template <int DTP>
 static __global__ __launch_bounds__(256) void codebook_grad_kernel(const long long* __restrict__ codes, long long bstride, const float* __restrict__ gq,
                                                             float* __restrict__ dcb, int M, int G, int Ksz, int dt, int ldz, int Tq) {
+    constexpr int SL = 64 / DTP, F = SL * CBG_U;            // rows per batch (a multiple of SL: a hit's slot does not depend on the batch it lands in)
     __shared__ short lc[CBG_MAXM];
+    __shared__ int hits[4][F + 64];                         // per wave: pending hit rows (vector indices), at most F - 1 left over + one window of 64
     const int blocks_per_group = (Ksz + CBG_CODES - 1) / CBG_CODES;
     const int g = blockIdx.x / blocks_per_group, k0 = (blockIdx.x - g * blocks_per_group) * CBG_CODES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = lane / DTP, j = lane - slot * DTP;
+    int* hl = hits[wave];
     float acc[CBG_CODES / 4];
 #pragma unroll
     for (int c = 0; c < CBG_CODES / 4; ++c) acc[c] = 0.f;
+    const float* gcol = gq + g * dt + j;
+    auto flush = [&](float& a, int n) {                      // adds the first n (<= F) list entries: lane (slot, j) takes entries slot, slot + SL, ...
+        float v[CBG_U];
+#pragma unroll
+        for (int u = 0; u < CBG_U; ++u) {
+            const int i = u * SL + slot;
+            v[u] = (i < n && j < dt) ? gcol[(size_t)hl[i] * ldz] : 0.0f;      // a missing entry adds 0.0f: the sum is bitwise unchanged
+        }
+#pragma unroll
+        for (int u = 0; u < CBG_U; ++u) a += v[u];
+    };
     for (int mbase = 0; mbase < M; mbase += CBG_MAXM) {                      // M beyond the LDS image: walk it in pieces, still in vector order
         const int mcnt = min(CBG_MAXM, M - mbase);
         __syncthreads();
@@ -1031,29 +1127,31 @@ static __global__ __launch_bounds__(256) void codebook_grad_kernel(const long lo
 #pragma unroll
         for (int c = 0; c < CBG_CODES / 4; ++c) {
             const int k = k0 + wave * (CBG_CODES / 4) + c;
+            int cnt = 0;                                                     // wave-uniform
             for (int m0 = 0; m0 < mcnt; m0 += 64) {
                 const bool hit = (m0 + lane < mcnt) && lc[m0 + lane] == (short)k;
-                unsigned long long mask = __ballot(hit);
-                // four hits per trip: their row loads are independent and in flight together, the adds stay in vector order (a missing hit adds
-                // 0.0f, which leaves the sum bitwise unchanged).  One load + dependent add per hit cost a memory round trip each: with a skewed
-                // code usage (a few codes chosen by hundreds of vectors - every untrained codebook) that chain WAS the kernel: 320 us per stream.
-                while (mask) {
-                    int l[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { l[u] = mask ? __ffsll((long long)mask) - 1 : -1; mask &= mask - 1; }
-                    float v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = (l[u] >= 0 && lane < dt) ? gq[(size_t)(mbase + m0 + l[u]) * ldz + g * dt + lane] : 0.0f;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[c] += v[u];
+                const unsigned long long mask = __ballot(hit);
+                if (!mask) continue;
+                if (hit) hl[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = mbase + m0 + lane;
+                cnt += __popcll(mask);
+                while (cnt >= F) {                                           // one batch; the (< 64) entries behind it move to the front
+                    flush(acc[c], F);
+                    const int rest = cnt - F;
+                    const int mv = lane < rest ? hl[F + lane] : 0;
+                    if (lane < rest) hl[lane] = mv;
+                    cnt = rest;
                 }
             }
+            if (cnt) flush(acc[c], cnt);
         }
     }
 #pragma unroll
     for (int c = 0; c < CBG_CODES / 4; ++c) {
+        float a = acc[c], tot = a;
+#pragma unroll
+        for (int sidx = 1; sidx < SL; ++sidx) tot += __shfl(a, sidx * DTP + j, 64);   // slot order 0, 1, ...: every lane computes the same chain
         const int k = k0 + wave * (CBG_CODES / 4) + c;
-        if (k < Ksz && lane < dt) dcb[((size_t)g * Ksz + k) * dt + lane] = acc[c];
+        if (k < Ksz && slot == 0 && j < dt) dcb[((size_t)g * Ksz + k) * dt + j] = tot;
     }
 }
 

@@ -90,6 +90,8 @@ SIGNATURES = {
     "escx_disc_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_void_p]),
     "escx_gan_term": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "escx_gan_term_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "escx_disc_set_precision": (c_int, [c_void_p, c_int]),
+    "escx_disc_get_precision": (c_int, [c_void_p]),
     "escx_disc_profile_enable": (c_int, [c_int]),
     "escx_disc_profile_report": (c_char_p, []),
     "escx_set_rccl_library": (c_int, [c_char_p]),

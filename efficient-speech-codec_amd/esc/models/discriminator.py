@@ -110,6 +110,20 @@ class Discriminator(nn.Module):
         if st is not None and "gflat" in st:
             st["gfresh"] = True
 
+    def set_conv_precision(self, precision: str = "fp32"):
+        """Arithmetic of the wide convolutions (include/escx.h escx_disc_set_precision): "fp32" (default, the reference's; parity-tested against it) or
+        "bf16" - operands of the 128 -> 512 -> 1024 -> 1024 period convolutions rounded to bf16 while staged, fp32 accumulation on the bf16 MFMA (BASELINE
+        configs[4] names bf16).  Feature maps, parameters and gradients stay fp32 tensors either way."""
+        mode = {"fp32": 0, "bf16": 1}.get(precision)
+        if mode is None:
+            raise ValueError(f"conv precision {precision!r}: 'fp32' or 'bf16'")
+        self._conv_precision = mode
+        if getattr(self, "_handles", None):
+            lib = _native.load()
+            for hd in self._handles.values():
+                _native.check(lib.escx_disc_set_precision(hd, mode))
+        return self
+
     def note_params_updated(self):
         self._native_updates += 1               # a native kernel wrote the flat buffer: autograd's version counters did not move
 
@@ -156,6 +170,8 @@ class Discriminator(nn.Module):
             hd = ctypes.c_void_p()
             _native.check(lib.escx_disc_create(ctypes.byref(cc), idx, ctypes.byref(hd)))
             self._handles[idx] = hd
+            if getattr(self, "_conv_precision", 0):
+                _native.check(lib.escx_disc_set_precision(hd, self._conv_precision))
             if self._flat_grad_mode and idx in self._carry:
                 self._flat_grad_mode = False             # (guards the re-entry through enable_flat_grads -> _handle)
                 self.enable_flat_grads(device)

@@ -233,6 +233,12 @@ int escx_disc_forward(escx_disc d, const float* flat_params_dev, int64_t params_
  * and / or d_wave_dev (optional, (B, L), overwritten). */
 int escx_disc_backward(escx_disc d, const float* flat_params_dev, int64_t params_version, const float* wave_dev, int batch, int n_samples,
                        float* const* fmaps_dev, const float* const* d_fmaps_dev, float* grad_flat_dev, float* d_wave_dev, void* stream);
+/* Arithmetic of the discriminator's wide convolutions (round 4; BASELINE configs[4] names bf16, the reference's trainer_adv.py runs fp32).
+ * 0 (default): fp32 MFMA everywhere, the parity-tested path.  1: the implicit GEMMs with at least 128 output and 256 contraction columns (the 128 -> 512 ->
+ * 1024 -> 1024 period convolutions: forward, dX, dW) round their operands to bf16 (nearest even) while staging them and accumulate in fp32 on the bf16 MFMA;
+ * feature maps, parameters, gradients and every other kernel stay fp32.  Returns ESCX_ERR_INVALID_ARG for another mode. */
+int escx_disc_set_precision(escx_disc d, int mode);
+int escx_disc_get_precision(escx_disc d);
 /* One GAN loss term over a feature-map buffer (gan_loss.py:30-51): loss_dev[b] (+)= mean over the C x D0 x D1 real elements of
  * (target - x)^2 (mode 0) or |x - ref| (mode 1); grad_dev (optional, layout of x) receives d term_b / d x. */
 int escx_gan_term(const float* x_dev, const float* ref_dev, float* grad_dev, int batch, int C, int Cp, int D0, int D1, int P1, int mode, float target,
