@@ -456,7 +456,9 @@ def run_train_adv(args, rank, world, device, use_dist, emit=True):
                         "kernel": "discriminator convolutions (all launches of the step)",
                         "note": "algorithmic discriminator-convolution FLOPs of the step (7 pass-equivalents of "
                                 f"{d_flops / 1e9:.1f} GFLOP per clip) over the WHOLE step time, generator included: a lower bound on the conv kernels' rate",
-                        "dominant_launch_group": kern_roof},
+                        "dominant_launch_group": kern_roof,
+                        **({} if prec == "fp32" else {"precision_note": "fractions are against the fp32 MFMA peak (157.3 TFLOP/s); the period convolutions 128->512->1024->1024 "
+                                                                        "run on the bf16 MFMA (dense peak 2500 TFLOP/s) and can exceed it, see dominant_launch_group.top"})},
            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else
                            train_adv_cpu_baseline(cfg, sd, {k: v.detach().cpu() for k, v in disc.state_dict().items()}, x.cpu(), st.w)}
     if not emit:
@@ -470,9 +472,10 @@ def other_workloads(args, device):
     driver-observed too.  Same code paths as --mode train / --mode train_adv, fewer steps, no CPU baseline."""
     import copy
     res = {}
-    for name, fn, steps, warm in (("train", run_train, 5, 2), ("train_adv", run_train_adv, 3, 1)):
+    for name, fn, steps, warm in (("train", run_train, 5, 2), ("train_adv", run_train_adv, 3, 1), ("train_adv_bf16", run_train_adv, 3, 1)):
         a = copy.copy(args)
         a.steps, a.warmup, a.no_cpu_baseline, a.profile_steps = steps, warm, True, 2
+        a.adv_precision = "bf16" if name.endswith("bf16") else "fp32"      # train_adv_bf16: the opt-in precision of the discriminator's wide convolutions
         t0 = time.perf_counter()
         try:
             full = fn(a, 0, 1, device, False, emit=False)

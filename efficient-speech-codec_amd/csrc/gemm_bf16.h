@@ -7,8 +7,8 @@
 //  * same operand roles: the WEIGHT tile is the MFMA "A" operand, the ACTIVATION tile the "B" operand: lane (l15, lg) ends up with 4 consecutive output
 //    features of one output row; a lane's 8 bf16 of an operand are 8 consecutive k of one tile row (one ds_read_b128 from the [row][k] LDS image) - the
 //    k slots of the two operands pair up whatever the instruction's internal k order is;
-//  * K step 32 (one MFMA deep), 256 x 128 or 128 x 128 workgroup tiles: at 16x the matrix rate the kernel is bound by what the L2 feeds (fp32 operands:
-//    44 / 32 FLOP per byte), so the tile is as large as the register file allows;
+//  * K step 32 (one MFMA deep), 128 x 128 workgroup tiles (256 x 128 as a tuning switch): at 16x the matrix rate the kernel is bound by what the L2 feeds
+//    (fp32 operands: 32 FLOP per byte) and by the bytes in flight per CU, not by the matrix pipe;
 //  * 1-D grid with the N tiles of one M tile adjacent (they gather the same activation rows at the same time), n tiles first in the block index.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -95,13 +95,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* 
 }
 
 // Shapes this variant takes: K a multiple of the 32-wide step, outputs a multiple of the 128-wide tile, enough rows to fill the chip with the chosen tile.
-inline bool bf16_gemm_ok(int M, int Np, int Kp) { return Np % 128 == 0 && Kp % 32 == 0 && Kp >= 256 && M >= 4096; }
+inline bool bf16_gemm_ok(int M, int Np, int Kp) { return Np % 128 == 0 && Kp % 32 == 0 && Kp >= 256 && M >= 1024; }
 
 template <class Loader, class Epi>
 inline void launch_gemm_bf16(const Loader& ld, const float* Wt, int M, int Np, int Kp, const Epi& ep, hipStream_t s) {
     static const int env_bm = [] { const char* e = getenv("ESCX_BF16_BM"); return e ? atoi(e) : 0; }();       // tuning aid: 128 / 256 rows per workgroup
     const int nbn = Np / 128;
-    const bool big = env_bm ? env_bm == 256 : (long long)((M + 255) / 256) * nbn >= 1024;
+    // 128 rows: 156 registers, three workgroups per CU; 256 rows: 272 registers, ONE wave per SIMD - measured on the 1024 -> 1024 period layer: 409 against
+    // 271 TFLOP/s forward, 384 against 252 dX (the K step is one memory round trip deep, so the bytes in flight per CU decide)
+    const bool big = env_bm == 256;
     if (big) hipLaunchKernelGGL((gemm_bf16_kernel<256, 128, Loader, Epi>), dim3(((M + 255) / 256) * nbn), dim3(256), 0, s, ld, Wt, M, Np, Kp, nbn, ep);
     else hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, Loader, Epi>), dim3(((M + 127) / 128) * nbn), dim3(256), 0, s, ld, Wt, M, Np, Kp, nbn, ep);
 }

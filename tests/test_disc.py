@@ -504,3 +504,57 @@ def test_second_discriminator_configuration_against_the_reference_fixture():
     assert [[list(t.shape) for t in f] for f in fm] == json.loads(str(g["fmap_shapes_json"]))
     _alt_check(g, ld.detach().cpu().numpy(), lg.detach().cpu().numpy(), lf.detach().cpu().numpy(), fk.grad.cpu().numpy(), gn,
                [[float(t.double().pow(2).mean().sqrt()) for t in f] for f in fm], 5e-3)
+
+
+@pytest.mark.gpu
+def test_bf16_convolution_precision_against_the_fp32_path():
+    """Discriminator.set_conv_precision("bf16") (escx_disc_set_precision, round 4; BASELINE configs[4] names bf16): the 128 -> 512 -> 1024 -> 1024 period
+    convolutions round their operands to bf16 and accumulate in fp32; everything else is the fp32 path.  Against the parity-tested fp32 path on the same
+    weights and clips: every feature map within 3e-2 relative RMS (the untouched ones - MRD, first period layers - bit-identical), the loss of the period
+    heads within 1e-2, the gradients that flow through the bf16 forward / dX / dW kernels within 5e-2 with a cosine above 0.999 - and NOT equal, i.e. the
+    bf16 kernels did run."""
+    disc, sd = _gpu_models()
+    B, L = 8, 48000
+    pcm = np.stack([(synth.voiced_clip_int16 if i % 2 else synth.noise_clip_int16)(f"disc-bf16-{i}", L) for i in range(B)])
+    x0 = torch.from_numpy(synth.pcm_to_float(pcm)).cuda().unsqueeze(1)
+    res = {}
+    for prec in ("fp32", "bf16"):
+        disc.set_conv_precision(prec)
+        lib, hd = disc._handle(torch.device("cuda:0"))
+        assert lib.escx_disc_get_precision(hd) == (1 if prec == "bf16" else 0)
+        for p in disc.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        outs = disc(x)
+        loss = sum((f[-1] ** 2).mean() for f in outs[:5])              # the period heads only: every gradient below passed through the wide layers
+        loss.backward()
+        res[prec] = dict(fm=[[t.detach().clone() for t in f] for f in outs], loss=float(loss.detach()), gx=x.grad.clone(),
+                         g={k: p.grad.clone() for k, p in disc.named_parameters() if p.grad is not None})
+    with pytest.raises(ValueError):
+        disc.set_conv_precision("fp8")
+    disc.set_conv_precision("fp32")
+    a, b = res["fp32"], res["bf16"]
+    worst = 0.0
+    for i, (fa, fb) in enumerate(zip(a["fm"], b["fm"])):
+        for j, (u, v) in enumerate(zip(fa, fb)):
+            if i >= 5 or j < 2:
+                assert torch.equal(u, v), f"sub-discriminator {i} map {j} is outside the bf16 layers and must not change"
+            else:
+                e = _rel(v.cpu().numpy(), u.cpu().numpy()); worst = max(worst, e)
+                assert 0.0 < e < 3e-2, f"sub-discriminator {i} map {j}: rel rms {e:.3e}"
+    assert abs(b["loss"] - a["loss"]) <= 1e-2 * abs(a["loss"])
+
+    def cos(u, v):
+        return float((u.double() * v.double()).sum() / (u.double().norm() * v.double().norm() + 1e-300))
+    e = _rel(b["gx"].cpu().numpy(), a["gx"].cpu().numpy())
+    assert 0.0 < e < 5e-2 and cos(a["gx"], b["gx"]) > 0.999, f"d loss / d waveform: rel rms {e:.3e}"
+    gw = (0.0, "")
+    for k in a["g"]:
+        if not k.startswith(tuple(f"discriminators.{i}." for i in range(5))):
+            continue
+        u, v = a["g"][k], b["g"][k]
+        if float(u.norm()) == 0.0:
+            continue
+        ek = _rel(v.cpu().numpy(), u.cpu().numpy()); gw = max(gw, (ek, k))
+        assert ek < 5e-2 and cos(u, v) > 0.999, f"gradient of {k}: rel rms {ek:.3e}, cosine {cos(u, v):.6f}"
+    print(f"[disc bf16] feature maps worst rel rms {worst:.2e}, d wave {e:.2e}, parameter gradients worst {gw[0]:.2e} ({gw[1]})")
