@@ -45,6 +45,13 @@ timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_adv -o p -- pytho
 cp $(find $O/prof_adv -name "*kernel_stats.csv" | head -1) $O/train_adv_kernel_stats.csv 2>/dev/null
 rm -rf $O/prof_adv
 cd $R
+# opt-in bf16 precision of the discriminator's wide convolutions: bench line + kernel stats of the same step
+timeout 900 python bench.py --mode train_adv --adv-precision bf16 --steps 4 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_train_adv_bf16.json; cut -c1-300 $O/bench_train_adv_bf16.json
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_adv16 -o p -- python $R/bench.py --mode train_adv --adv-precision bf16 --steps 4 --warmup 1 --no-cpu-baseline > $O/prof_adv16.log 2>&1
+cp $(find $O/prof_adv16 -name "*kernel_stats.csv" | head -1) $O/train_adv_bf16_kernel_stats.csv 2>/dev/null
+rm -rf $O/prof_adv16
+cd $R
 # round 4: small-batch latencies, datapath utilisation tables of the codec AND of the training step
 timeout 600 python tools/small_batch.py > $O/small_batch.txt 2>&1
 timeout 1200 bash tools/sq_util.sh > /dev/null 2>&1; cp gpurun_out/sq_util.txt $O/sq_util.txt 2>/dev/null
