@@ -472,7 +472,7 @@ def other_workloads(args, device):
     driver-observed too.  Same code paths as --mode train / --mode train_adv, fewer steps, no CPU baseline."""
     import copy
     res = {}
-    for name, fn, steps, warm in (("train", run_train, 5, 2), ("train_adv", run_train_adv, 3, 1), ("train_adv_bf16", run_train_adv, 3, 1)):
+    for name, fn, steps, warm in (("train", run_train, 5, 2), ("train_adv", run_train_adv, 4, 2), ("train_adv_bf16", run_train_adv, 4, 2)):
         a = copy.copy(args)
         a.steps, a.warmup, a.no_cpu_baseline, a.profile_steps = steps, warm, True, 2
         a.adv_precision = "bf16" if name.endswith("bf16") else "fp32"      # train_adv_bf16: the opt-in precision of the discriminator's wide convolutions

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include "disc_kernels.h"
+#include "gemm_bf16.h"
 
 namespace escx {
 
@@ -110,6 +111,79 @@ __global__ __launch_bounds__(256) void conv32_halo_kernel(Halo32 g, const float*
     }
 }
 
+// The same tile on the bf16 MFMA (the discriminator's opt-in bf16 precision, gemm_bf16.h): the input image and the weight slices are rounded to bf16 when they are
+// staged (80-byte LDS rows: one ds_read_b128 = the 8 channels of a lane's k slots), a tap is ONE 32-deep MFMA step per accumulator tile; fp32 accumulation in tap order.
+constexpr int H32_P16 = 40;
+template <class Epi>
+__global__ __launch_bounds__(256) void conv32_halo_bf16_kernel(Halo32 g, const float* __restrict__ W, int Kp, int tiles0, int tiles1, Epi ep) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 h16_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int NF = H32_TO0 + g.T0 - 1, HW = (H32_TO1 - 1) * g.s1 + g.T1;
+    __bf16* Hs = h16_lds;                                       // [NF][HW][P16]
+    __bf16* Ws = h16_lds + (size_t)NF * HW * H32_P16;           // [3][32][P16]
+    int bid = blockIdx.x;
+    const int t1i = bid % tiles1; bid /= tiles1;
+    const int t0i = bid % tiles0; const int bi = bid / tiles0;
+    const int o0b = t0i * H32_TO0, o1b = t1i * H32_TO1;
+    const int lo0 = g.d0 < 0 ? -(g.T0 - 1) : 0, lo1 = g.d1 < 0 ? -(g.T1 - 1) : 0;
+    const int in0b = o0b + g.off0 + lo0, in1b = o1b * g.s1 + g.off1 + lo1;
+    const int total = NF * HW * 8;
+    const float* xb = g.x.p + (size_t)bi * g.x.D0 * g.x.P1 * g.x.Cp;
+    for (int i = tid; i < total; i += 256) {
+        const int c4 = i & 7, pos = i >> 3;
+        const int h0 = pos / HW, h1 = pos - h0 * HW;
+        const int i0 = in0b + h0, i1 = in1b + h1;
+        const bool ok = (unsigned)i0 < (unsigned)g.x.D0 && (unsigned)i1 < (unsigned)g.x.D1;
+        const f32x4 v = ok ? ld4(xb + ((size_t)i0 * g.x.P1 + i1) * g.x.Cp + 4 * c4) : zero4();
+        *reinterpret_cast<bf16x4*>(Hs + (size_t)pos * H32_P16 + 4 * c4) = to_bf16x4(v);
+    }
+    const int wn = tid >> 3, wc = 4 * (tid & 7);
+    const int NT = g.T0 * g.T1;
+    const float* wsrc = W + (size_t)wn * Kp + wc;
+    __bf16* wdst = Ws + wn * H32_P16 + wc;
+    *reinterpret_cast<bf16x4*>(wdst) = to_bf16x4(ld4(wsrc));
+    if (NT > 1) *reinterpret_cast<bf16x4*>(wdst + 32 * H32_P16) = to_bf16x4(ld4(wsrc + 32));
+    f32x4 wreg = NT > 2 ? ld4(wsrc + 64) : zero4();
+    __syncthreads();
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = zero4();
+    int t0 = 0, t1 = 0, slot = 0;
+    for (int tap = 0; tap < NT; ++tap) {
+        f32x4 wnew = zero4();
+        if (tap + 3 < NT) wnew = ld4(wsrc + (tap + 3) * 32);
+        const __bf16* hrow = Hs + ((size_t)(wave + g.d0 * t0 - lo0) * HW + (g.d1 * t1 - lo1)) * H32_P16 + 8 * lg;
+        const __bf16* wrow = Ws + slot * 32 * H32_P16 + l15 * H32_P16 + 8 * lg;
+        bf16x8 af[2], wf[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) af[b] = *reinterpret_cast<const bf16x8*>(hrow + (size_t)((16 * b + l15) * g.s1) * H32_P16);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) wf[a] = *reinterpret_cast<const bf16x8*>(wrow + 16 * a * H32_P16);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], af[b], acc[a][b], 0, 0, 0);
+        const int wslot = slot == 0 ? 2 : slot - 1;
+        if (tap + 2 < NT) *reinterpret_cast<bf16x4*>(wdst + wslot * 32 * H32_P16) = to_bf16x4(wreg);
+        if (tap + 1 < NT) __syncthreads();
+        wreg = wnew;
+        slot = slot == 2 ? 0 : slot + 1;
+        if (++t1 == g.T1) { t1 = 0; ++t0; }
+    }
+    const int o0 = o0b + wave;
+    if (o0 >= g.O0) return;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int o1 = o1b + 16 * b + l15;
+        if (o1 >= g.O1) continue;
+        const int m = (bi * g.O0 + o0) * g.O1 + o1;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) ep.store(m, 16 * a + 4 * lg, acc[a][b], 0);
+    }
+}
+
 inline Halo32 make_halo32(const ConvSU& l, int M, int Np, int Kp) {
     Halo32 h{l.x, l.g.T0, l.g.T1, l.g.s1, 1, 1, -l.g.p0, -l.g.p1, l.g.O0, l.g.O1, 0, 0};
     h.B = M / std::max(1, l.g.O0 * l.g.O1);
@@ -140,6 +214,16 @@ inline bool launch_conv32_halo(const Halo32& h, const float* W, int Kp, const Ep
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv32_halo_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
     const int tiles0 = (h.O0 + H32_TO0 - 1) / H32_TO0, tiles1 = (h.O1 + H32_TO1 - 1) / H32_TO1;
     hipLaunchKernelGGL((conv32_halo_kernel<Epi>), dim3((unsigned)((size_t)h.B * tiles0 * tiles1)), dim3(256), lds, st, h, W, Kp, tiles0, tiles1, ep);
+    return true;
+}
+
+template <class Epi>
+inline bool launch_conv32_halo_bf16(const Halo32& h, const float* W, int Kp, const Epi& ep, hipStream_t st) {
+    if (!h.ok || h.T0 > 4 || h.T1 > 9) return false;
+    const int NF = H32_TO0 + h.T0 - 1, HW = (H32_TO1 - 1) * h.s1 + h.T1;
+    const size_t lds = ((size_t)NF * HW * H32_P16 + 3 * 32 * H32_P16) * sizeof(__bf16);       // <= 36 KB
+    const int tiles0 = (h.O0 + H32_TO0 - 1) / H32_TO0, tiles1 = (h.O1 + H32_TO1 - 1) / H32_TO1;
+    hipLaunchKernelGGL((conv32_halo_bf16_kernel<Epi>), dim3((unsigned)((size_t)h.B * tiles0 * tiles1)), dim3(256), lds, st, h, W, Kp, tiles0, tiles1, ep);
     return true;
 }
 

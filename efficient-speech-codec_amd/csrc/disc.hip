@@ -242,6 +242,8 @@ void conv_gemm(const Ld& ld_in, const float* W, int M, int Np, int Kp, const Epi
     if constexpr (!std::is_same<Ld, PlainA>::value) {            // the 32 -> 32-channel band convolutions: input tile held in LDS (conv32_halo.h), bit-identical to the engine
         static const bool halo = [] { const char* e = getenv("ESCX_CONV32_HALO"); return e && e[0] == '1'; }();       // opt-in: bit-identical, 4-10 % faster alone, the step 4 % SLOWER
         if (halo && Np == 32 && launch_conv32_halo(make_halo32(ld_in, M, Np, Kp), W, Kp, ep, st)) return;
+        static const bool halo16 = [] { const char* e = getenv("ESCX_CONV32_HALO_BF16"); return !(e && e[0] == '0'); }();      // bf16 precision: the band convolutions too (A/B: 0)
+        if (tls_conv_bf16 && halo16 && Np == 32 && launch_conv32_halo_bf16(make_halo32(ld_in, M, Np, Kp), W, Kp, ep, st)) return;
     }
     if constexpr (!std::is_same<Ld, PlainA>::value) {            // opt-in bf16 MFMA for the wide layers (gemm_bf16.h): same gathers, same epilogues
         if (tls_conv_bf16 && bf16_gemm_ok(M, Np, Kp) && conv_cp(ld) % 32 == 0) { ld.fast = 1; launch_gemm_bf16(ld, W, M, Np, Kp, ep, st); return; }
@@ -286,6 +288,19 @@ int disc_dw(const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, floa
     const size_t per = (size_t)Np * Kp + Np;
     static const bool wide_ok = [] { const char* e = getenv("ESCX_DW_WIDE"); return !(e && e[0] == '0'); }();
     const bool big = Np >= 256 && Kp >= 256, narrow = Np == 32 && Kp >= 192;
+    static const bool dw16n = [] { const char* e = getenv("ESCX_DISC_BF16_DW_NARROW"); return !(e && e[0] == '0'); }();       // bf16 precision: dW of the band stacks too (A/B: 0)
+    if (narrow && tls_conv_bf16 && dw16n && Kp % 16 == 0) {     // 32 x 128 tiles of dW on the bf16 MFMA (gemm_bf16.h)
+        const int nbk = (Kp + 127) / 128;
+        int slices = std::max(1, std::min((2560 + nbk / 2) / nbk, (M + 255) / 256));
+        slices = (int)std::max<size_t>(1, std::min<size_t>(slices, DISC_DW_PART / per));
+        int mps = ((M + slices - 1) / slices + 31) / 32 * 32;
+        slices = (M + mps - 1) / mps;
+        float* bpart = part + (size_t)slices * Np * Kp;
+        hipLaunchKernelGGL((gemm_dw_bf16_n32_kernel<LdA, LdB>), dim3(nbk, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+        launch_reduce_partials(part, slices, (long long)Np * Kp, dW, 0, st);
+        launch_reduce_partials(bpart, slices, (long long)Np, db, 0, st);
+        return 0;
+    }
     if (wide_ok && (big || narrow)) {                         // wide workgroup tiles (gemm_dw3_kernel), ~5 rounds of 2 workgroups per CU
         const int WA = big ? 128 : 32, WB = big ? 128 : 192;
         const int nbn = (Np + WA - 1) / WA, nbk = (Kp + WB - 1) / WB, blocks = nbn * nbk;

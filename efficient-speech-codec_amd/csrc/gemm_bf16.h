@@ -202,4 +202,86 @@ __global__ __launch_bounds__(256) void gemm_dw_bf16_kernel(LdA la, LdB lb, int M
     }
 }
 
+// The same contraction for 32 output rows (the 32-channel band stacks): one workgroup = 32 x 128 tile of dW and one slice of M, wave w owns the k columns
+// [32 w, 32 w + 32) x all 32 n; the upstream rows are staged by waves 0 and 1 (32 columns), the gathered input rows by everybody.
+template <class LdA, class LdB>
+__global__ __launch_bounds__(256) void gemm_dw_bf16_n32_kernel(LdA la, LdB lb, int M, int Np, int Kp, int nblk_k, int m_per_slice, float* __restrict__ part,
+                                                               float* __restrict__ bpart) {
+    constexpr int TB = 128, MS = 32, LD = MS + 8;
+    __shared__ __attribute__((aligned(16))) __bf16 At[32 * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bt[TB * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int mp = lane & 15, cq = 4 * (4 * wave + (lane >> 4));
+    const int k0 = blockIdx.x * TB;
+    const int mbeg = blockIdx.y * m_per_slice, mend = min(M, mbeg + m_per_slice);
+    const bool stage_a = wave < 2;              // columns cq .. cq + 3 < 32
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = zero4();
+    f32x4 bs = zero4();
+    f32x4 ra[2], rb[2][2];
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int m = m0 + 2 * mp + r;
+            const typename LdB::Ctx cb = lb.make_ctx(m < mend ? m : M);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rb[j][r] = lb.load4(cb, k0 + 64 * j + cq, 0);
+            if (stage_a) { const typename LdA::Ctx ca = la.make_ctx(m < mend ? m : M); ra[r] = la.load4(ca, cq, 0); }
+        }
+    };
+    auto pack2 = [](float lo, float hi) -> unsigned {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        bf16x2 p; p[0] = (__bf16)lo; p[1] = (__bf16)hi;
+        return __builtin_bit_cast(unsigned, p);
+    };
+    if (mbeg < mend) fetch(mbeg);
+    for (int m0 = mbeg; m0 < mend; m0 += MS) {
+        if (stage_a) {
+            bs += ra[0] + ra[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *reinterpret_cast<unsigned*>(&At[(cq + e) * LD + 2 * mp]) = pack2(ra[0][e], ra[1][e]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *reinterpret_cast<unsigned*>(&Bt[(64 * j + cq + e) * LD + 2 * mp]) = pack2(rb[j][0][e], rb[j][1][e]);
+        __syncthreads();
+        if (m0 + MS < mend) fetch(m0 + MS);
+        bf16x8 af[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) af[b] = *reinterpret_cast<const bf16x8*>(&At[(16 * b + l15) * LD + 8 * lg]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(&Bt[(32 * wave + 16 * a + l15) * LD + 8 * lg]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* pt = part + (size_t)blockIdx.y * Np * Kp;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = 16 * b + l15;
+        if (n >= Np) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int k = k0 + 32 * wave + 16 * a + 4 * lg;
+            if (k < Kp) st4(pt + (size_t)n * Kp + k, acc[a][b]);
+        }
+    }
+    if (bpart && blockIdx.x == 0 && stage_a) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = bs[e];
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o, 16);
+            bs[e] = v;
+        }
+        if (mp == 0 && cq < Np) st4(bpart + (size_t)blockIdx.y * Np + cq, bs);
+    }
+}
+
 }  // namespace escx

@@ -235,7 +235,8 @@ int escx_disc_backward(escx_disc d, const float* flat_params_dev, int64_t params
                        float* const* fmaps_dev, const float* const* d_fmaps_dev, float* grad_flat_dev, float* d_wave_dev, void* stream);
 /* Arithmetic of the discriminator's wide convolutions (round 4; BASELINE configs[4] names bf16, the reference's trainer_adv.py runs fp32).
  * 0 (default): fp32 MFMA everywhere, the parity-tested path.  1: the implicit GEMMs with at least 128 output and 256 contraction columns (the 128 -> 512 ->
- * 1024 -> 1024 period convolutions: forward, dX, dW) round their operands to bf16 (nearest even) while staging them and accumulate in fp32 on the bf16 MFMA;
+ * 1024 -> 1024 period convolutions: forward, dX, dW) and the 32 -> 32-channel band convolutions of the spectrogram discriminators (forward, dX, dW) round
+ * their operands to bf16 (nearest even) while staging them and accumulate in fp32 on the bf16 MFMA;
  * feature maps, parameters, gradients and every other kernel stay fp32.  Returns ESCX_ERR_INVALID_ARG for another mode. */
 int escx_disc_set_precision(escx_disc d, int mode);
 int escx_disc_get_precision(escx_disc d);

@@ -509,8 +509,8 @@ def test_second_discriminator_configuration_against_the_reference_fixture():
 @pytest.mark.gpu
 def test_bf16_convolution_precision_against_the_fp32_path():
     """Discriminator.set_conv_precision("bf16") (escx_disc_set_precision, round 4; BASELINE configs[4] names bf16): the 128 -> 512 -> 1024 -> 1024 period
-    convolutions round their operands to bf16 and accumulate in fp32; everything else is the fp32 path.  Against the parity-tested fp32 path on the same
-    weights and clips: every feature map within 3e-2 relative RMS (the untouched ones - MRD, first period layers - bit-identical), the loss of the period
+    convolutions and the 32 -> 32 band convolutions round their operands to bf16 and accumulate in fp32; everything else is the fp32 path.  Against the parity-tested fp32 path on the same
+    weights and clips: every feature map within 3e-2 relative RMS (the untouched ones - first layers - bit-identical), the loss of the
     heads within 1e-2, the gradients that flow through the bf16 forward / dX / dW kernels within 5e-2 with a cosine above 0.999 - and NOT equal, i.e. the
     bf16 kernels did run."""
     disc, sd = _gpu_models()
@@ -526,7 +526,7 @@ def test_bf16_convolution_precision_against_the_fp32_path():
             p.grad = None
         x = x0.clone().requires_grad_(True)
         outs = disc(x)
-        loss = sum((f[-1] ** 2).mean() for f in outs[:5])              # the period heads only: every gradient below passed through the wide layers
+        loss = sum((f[-1] ** 2).mean() for f in outs)                  # the heads only: every gradient below passed through the bf16 layers
         loss.backward()
         res[prec] = dict(fm=[[t.detach().clone() for t in f] for f in outs], loss=float(loss.detach()), gx=x.grad.clone(),
                          g={k: p.grad.clone() for k, p in disc.named_parameters() if p.grad is not None})
@@ -537,7 +537,7 @@ def test_bf16_convolution_precision_against_the_fp32_path():
     worst = 0.0
     for i, (fa, fb) in enumerate(zip(a["fm"], b["fm"])):
         for j, (u, v) in enumerate(zip(fa, fb)):
-            if i >= 5 or j < 2:
+            if (i < 5 and j < 2) or (i >= 5 and j < 25 and j % 5 == 0):      # period layers 1 -> 32 -> 128; the 2 -> 32 first layer of every band stack
                 assert torch.equal(u, v), f"sub-discriminator {i} map {j} is outside the bf16 layers and must not change"
             else:
                 e = _rel(v.cpu().numpy(), u.cpu().numpy()); worst = max(worst, e)
@@ -550,8 +550,6 @@ def test_bf16_convolution_precision_against_the_fp32_path():
     assert 0.0 < e < 5e-2 and cos(a["gx"], b["gx"]) > 0.999, f"d loss / d waveform: rel rms {e:.3e}"
     gw = (0.0, "")
     for k in a["g"]:
-        if not k.startswith(tuple(f"discriminators.{i}." for i in range(5))):
-            continue
         u, v = a["g"][k], b["g"][k]
         if float(u.norm()) == 0.0:
             continue
