@@ -556,3 +556,49 @@ def test_bf16_convolution_precision_against_the_fp32_path():
         ek = _rel(v.cpu().numpy(), u.cpu().numpy()); gw = max(gw, (ek, k))
         assert ek < 5e-2 and cos(u, v) > 0.999, f"gradient of {k}: rel rms {ek:.3e}, cosine {cos(u, v):.6f}"
     print(f"[disc bf16] feature maps worst rel rms {worst:.2e}, d wave {e:.2e}, parameter gradients worst {gw[0]:.2e} ({gw[1]})")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,B,L", [
+    (dict(periods=[7], fft_sizes=[1024, 256], bands=[(0.0, 0.1), (0.1, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0)]), 3, 6001),        # tiny maps: every tile of the band kernels is an edge tile
+    (dict(periods=[2, 3], fft_sizes=[512], bands=[(0.0, 0.25), (0.25, 1.0)]), 5, 40007),                                               # prime length, two wide bands, period layers above the bf16 row threshold
+])
+def test_bf16_precision_on_other_configurations(cfg, B, L):
+    """The bf16 kernels on geometries the default configuration does not produce (frame counts that are no multiple of the 4-frame tile, band widths below
+    one 32-wide tile, ragged M slices of the dW contractions, the engine fallback below the row threshold): the GAN losses of both updates and every
+    gradient against the fp32 path of the same module - within bf16 rounding, with the sign structure intact (cosine)."""
+    from esc.models import Discriminator
+    from esc.modules import GANLoss
+    torch.manual_seed(5)
+    disc = Discriminator(sample_rate=16000, **cfg).cuda()
+    real = torch.from_numpy(synth.pcm_to_float(np.stack([synth.voiced_clip_int16(f"d16-real-{i}", L) for i in range(B)]))).cuda()
+    fake = 0.7 * real + torch.from_numpy(synth.pcm_to_float(np.stack([synth.noise_clip_int16(f"d16-fake-{i}", L, amp=0.03) for i in range(B)]))).cuda()
+    gan = GANLoss(disc)
+    out = {}
+    for prec in ("fp32", "bf16"):
+        disc.set_conv_precision(prec)
+        disc.zero_grad()
+        ld = gan.discriminator_loss(fake, real)
+        ld.mean().backward()
+        gd = {k: p.grad.clone() for k, p in disc.named_parameters()}
+        disc.zero_grad()
+        fk = fake.clone().requires_grad_(True)
+        lg, lf = gan.generator_loss(fk, real)
+        (lg + 2.0 * lf).mean().backward()
+        out[prec] = dict(ld=ld.detach().cpu().numpy(), lg=lg.detach().cpu().numpy(), lf=lf.detach().cpu().numpy(), gd=gd, gx=fk.grad.clone())
+    disc.set_conv_precision("fp32")
+    a, b = out["fp32"], out["bf16"]
+    for k in ("ld", "lg", "lf"):
+        np.testing.assert_allclose(b[k], a[k], rtol=2e-2)
+        assert not np.array_equal(b[k], a[k]), f"{k}: the bf16 kernels did not run"
+
+    def cos(u, v):
+        return float((u.double() * v.double()).sum() / (u.double().norm() * v.double().norm() + 1e-300))
+    assert _rel(b["gx"].cpu().numpy(), a["gx"].cpu().numpy()) < 5e-2 and cos(a["gx"], b["gx"]) > 0.999
+    worst = (0.0, "")
+    for k, u in a["gd"].items():
+        if float(u.norm()) == 0.0:
+            continue
+        e = _rel(b["gd"][k].cpu().numpy(), u.cpu().numpy()); worst = max(worst, (e, k))
+        assert e < 8e-2 and cos(u, b["gd"][k]) > 0.997, f"gradient of {k}: rel rms {e:.3e}, cosine {cos(u, b['gd'][k]):.6f}"
+    print(f"[disc bf16 {cfg['periods']}/{cfg['fft_sizes']}] worst parameter-gradient rel rms {worst[0]:.2e} ({worst[1]})")
