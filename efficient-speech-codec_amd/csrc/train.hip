@@ -205,12 +205,14 @@ int dw_rows(escx_handle_s* h, const float* A, int lda, const float* Bm, int ldb,
     }
 }
 
+constexpr int LN_BWD_MAX_GRID = 2048;
 // LayerNorm backward launcher; dgamma -> dg[SEGS*Cp], dbeta -> dbt[SEGS*Cp]
 int ln_bwd(int mode, const float* x, const float* dy, const float* gamma, const int* map, const float* add, float* dx, float* dg, float* dbt,
            int rows_per_clip, int src_rows_per_clip, int dy_rows_per_clip, int total_rows, int C, int Cp, float* part, hipStream_t st,
            float* dx_slots = nullptr, const int* slot_of = nullptr, int slots_per_clip = 0) {
     const int segs = mode == 2 ? 2 : 1;
-    const int grid = (int)std::min<long long>(512, ((long long)total_rows + 15) / 16);
+    static const int grid_cap = [] { const char* e = getenv("ESCX_LN_BWD_GRID"); const int v = e ? atoi(e) : 512; return std::max(1, std::min(v, LN_BWD_MAX_GRID)); }();
+    const int grid = (int)std::min<long long>(grid_cap, ((long long)total_rows + 15) / 16);
     const size_t shm = (size_t)16 * 2 * segs * Cp * sizeof(float);
     const int RW = segs * Cp;
     if (mode == 0) hipLaunchKernelGGL((ln_bwd_kernel<1, 0>), dim3(grid), dim3(256), shm, st, x, dy, gamma, map, add, dx, part, rows_per_clip, src_rows_per_clip, dy_rows_per_clip, total_rows, C, Cp, 1e-5f, dx_slots, slot_of, slots_per_clip);
@@ -222,7 +224,7 @@ int ln_bwd(int mode, const float* x, const float* dy, const float* gamma, const 
     hipLaunchKernelGGL(copy2_kernel, dim3(blocks_for(2 * RW)), dim3(256), 0, st, red, dg, dbt, RW);          // one launch instead of two copy-engine packets (~7 us each)
     return 0;
 }
-constexpr size_t LN_PART_FLOATS = (size_t)513 * 2 * 2 * 384;
+constexpr size_t LN_PART_FLOATS = (size_t)(LN_BWD_MAX_GRID + 1) * 2 * 2 * 384;
 
 // dx_fc1 GEMM with the LayerNorm backward as its row epilogue (EpiLnBwdRows; Cp <= 96): out = add + LNbwd(dh . W; x), dgamma / dbeta.
 // `part` needs ceil(M / 64) * 4 * 2 * Cp floats (+ 2 * Cp for the reduced row): the dW partial-sum scratch is used.
