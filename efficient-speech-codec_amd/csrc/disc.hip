@@ -58,6 +58,7 @@ struct escx_disc_s {
     float* scratch = nullptr; size_t scratch_bytes = 0;
     const float* packed_ptr = nullptr; long long packed_version = -1;      // which (buffer, version) the packed weights were derived from
     int precision = 0;                   // escx_disc_set_precision: 1 = bf16 MFMA for the wide convolutions
+    __bf16* wbuf16 = nullptr; const float* w16_ptr = nullptr; long long w16_version = -2;       // bf16 image of wbuf (precision 1), and what it was derived from
     hipStream_t aux[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};    // extra streams: the sub-discriminators are independent of each other
 };
 
@@ -161,6 +162,9 @@ struct DTrace {
 
 // params_version: any number that changes whenever the flat buffer's CONTENTS change (negative = unknown: always re-pack).  The weight-normalised
 // operands are rebuilt only then - an adversarial step makes five calls on the same weights, 108 pack launches each otherwise.
+thread_local int tls_conv_bf16 = 0;      // precision of the handle whose forward / backward is being enqueued by this thread
+thread_local const float* tls_w32 = nullptr; thread_local const __bf16* tls_w16 = nullptr; thread_local size_t tls_wn = 0;      // its packed weights and their bf16 image
+
 int pack_weights(escx_disc_s* d, const float* flat, long long params_version, hipStream_t st) {
     if (params_version >= 0 && params_version == d->packed_version && flat == d->packed_ptr) return 0;
     d->packed_version = params_version; d->packed_ptr = flat;
@@ -169,6 +173,20 @@ int pack_weights(escx_disc_s* d, const float* flat, long long params_version, hi
             hipLaunchKernelGGL(wn_pack_kernel, dim3(c.Cout), dim3(256), 0, st, flat + c.off_v, flat + c.off_g, flat + c.off_b, c.Wf, c.Wt, c.bias, c.scale,
                                c.Cout, c.Cin, c.T0 * c.T1, c.CinP, c.CoutP, c.Kf, c.Kt, c.Wp, c.T0, c.T1, c.s0, c.s1, c.p0, c.p1, c.CinR);
     return launch_ok("disc_pack_weights");
+}
+
+// bf16 precision: the packed weights rounded once per parameter version (the convolution kernels would round the same values again for every tile they stage)
+int refresh_bf16_weights(escx_disc_s* d, hipStream_t st) {
+    tls_conv_bf16 = d->precision; tls_w32 = d->wbuf; tls_wn = d->wfloats; tls_w16 = nullptr;
+    static const bool w16_ok = [] { const char* e = getenv("ESCX_DISC_BF16_WEIGHTS"); return !(e && e[0] == '0'); }();      // 0: weights rounded while staged (A/B)
+    if (!d->precision || !w16_ok) return 0;
+    if (!d->wbuf16) ESCX_HIP(hipMalloc((void**)&d->wbuf16, d->wfloats * sizeof(__bf16)));
+    if (d->w16_ptr != d->packed_ptr || d->w16_version != d->packed_version || d->packed_version < 0) {
+        hipLaunchKernelGGL(cvt_bf16_kernel, dim3(2048), dim3(256), 0, st, d->wbuf, d->wbuf16, d->wfloats / 4);
+        d->w16_ptr = d->packed_ptr; d->w16_version = d->packed_version;
+    }
+    tls_w16 = d->wbuf16;
+    return launch_ok("disc_bf16_weights");
 }
 
 // Multi-stream schedule over the sub-discriminators (they share nothing but the input): the launches of one sub-discriminator fill the dispatch tails and the
@@ -234,7 +252,6 @@ inline int conv_cp(const ConvTS& l) { return l.y.Cp; }
 inline int conv_cp(const ConvTSP& l) { return l.y.Cp; }
 inline int conv_cp(const PlainA&) { return 0; }
 
-thread_local int tls_conv_bf16 = 0;      // precision of the handle whose forward / backward is being enqueued by this thread
 
 template <class Ld, class Epi>
 void conv_gemm(const Ld& ld_in, const float* W, int M, int Np, int Kp, const Epi& ep, hipStream_t st) {
@@ -246,7 +263,10 @@ void conv_gemm(const Ld& ld_in, const float* W, int M, int Np, int Kp, const Epi
         if (tls_conv_bf16 && halo16 && Np == 32 && launch_conv32_halo_bf16(make_halo32(ld_in, M, Np, Kp), W, Kp, ep, st)) return;
     }
     if constexpr (!std::is_same<Ld, PlainA>::value) {            // opt-in bf16 MFMA for the wide layers (gemm_bf16.h): same gathers, same epilogues
-        if (tls_conv_bf16 && bf16_gemm_ok(M, Np, Kp) && conv_cp(ld) % 32 == 0) { ld.fast = 1; launch_gemm_bf16(ld, W, M, Np, Kp, ep, st); return; }
+        if (tls_conv_bf16 && bf16_gemm_ok(M, Np, Kp) && conv_cp(ld) % 32 == 0) {
+            const __bf16* W16 = (tls_w16 && W >= tls_w32 && W < tls_w32 + tls_wn) ? tls_w16 + (W - tls_w32) : nullptr;
+            ld.fast = 1; launch_gemm_bf16(ld, W, W16, M, Np, Kp, ep, st); return;
+        }
     }
     const long long tiles128 = (long long)((M + 127) / 128) * ((Np + 95) / 96);
     // K steps of 16: 18 KB of LDS per workgroup instead of 75 KB at the engine's default step of 80 for K = 5 x 1024 - twice the resident
@@ -412,6 +432,7 @@ extern "C" void escx_disc_destroy(escx_disc d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
     if (d->wbuf) (void)hipFree(d->wbuf);
+    if (d->wbuf16) (void)hipFree(d->wbuf16);
     if (d->scratch) (void)hipFree(d->scratch);
     for (int i = 0; i < 3; ++i) {
         if (d->aux[i]) { (void)hipStreamSynchronize(d->aux[i]); (void)hipStreamDestroy(d->aux[i]); }
@@ -509,6 +530,7 @@ extern "C" int escx_disc_forward(escx_disc d, const float* flat_params, int64_t 
     int rc = check_map_sizes(shp, B); if (rc) return rc;
     if ((rc = ensure_scratch(d, front_floats(d, B, L) * sizeof(float)))) return rc;
     if ((rc = pack_weights(d, flat_params, (long long)params_version, st))) return rc;
+    if ((rc = refresh_bf16_weights(d, st))) return rc;
     std::vector<std::vector<float*>> ins; std::vector<float*> specs; float *y, *stats;
     build_front(d, wave, B, L, d->scratch, &ins, &specs, &y, &stats, st);
     const int nq = disc_streams();
@@ -582,6 +604,7 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
     int rc = check_map_sizes(shp, B); if (rc) return rc;
     if ((rc = ensure_scratch(d, total * sizeof(float)))) return rc;
     if ((rc = pack_weights(d, flat_params, (long long)params_version, st))) return rc;
+    if ((rc = refresh_bf16_weights(d, st))) return rc;
     std::vector<std::vector<float*>> ins; std::vector<float*> specs; float *y, *stats;
     build_front(d, wave, B, L, d->scratch, &ins, &specs, &y, &stats, st);
     float* cur = d->scratch + front;

@@ -26,8 +26,10 @@ __device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
     return r;
 }
 
-template <int BM, int BN, class Loader, class Epi>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* __restrict__ Wt, int M, int Np, int Kp, int nblk_n, Epi ep) {
+// WB16: the weight matrix is read from its bf16 image (the packed weights rounded once per parameter version, escx_disc.cpp: cvt_bf16_kernel) - half the
+// bytes of the weight operand and no conversion in the staging path; the rounding is the same nearest-even, so the results are bit-identical to WB16 = false.
+template <int BM, int BN, bool WB16, class Loader, class Epi>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* __restrict__ Wt, const __bf16* __restrict__ Wt16, int M, int Np, int Kp, int nblk_n, Epi ep) {
     static_assert(BM % 64 == 0 && BN % 16 == 0, "tile shape");
     constexpr int BK = 32;
     constexpr int LD = BK + 8;                 // bf16 per LDS row: 80 B, the 16 rows of a fragment read start 20 banks apart
@@ -53,22 +55,37 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* 
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = zero4();
 
-    f32x4 ra[AJ], rb[BJ];
+    constexpr int BJ16 = BN * 4 / 256;          // 16-byte pieces (8 bf16) of the weight tile per thread
+    f32x4 ra[AJ], rb[WB16 ? 1 : BJ];
+    uint4 rb16[WB16 ? BJ16 : 1];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) ra[j] = ld.load4(ctx[j], k0, 4 * ((tid + j * 256) % KV));
+        if constexpr (WB16) {
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const int i = tid + j * 256, row = i / KV, c4 = i % KV;
-            rb[j] = (n0 + row < Np) ? ld4(Wt + (size_t)(n0 + row) * Kp + k0 + 4 * c4) : zero4();
+            for (int j = 0; j < BJ16; ++j) {
+                const int i = tid + j * 256, row = i >> 2, c8 = i & 3;
+                rb16[j] = (n0 + row < Np) ? *reinterpret_cast<const uint4*>(Wt16 + (size_t)(n0 + row) * Kp + k0 + 8 * c8) : make_uint4(0, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const int i = tid + j * 256, row = i / KV, c4 = i % KV;
+                rb[j] = (n0 + row < Np) ? ld4(Wt + (size_t)(n0 + row) * Kp + k0 + 4 * c4) : zero4();
+            }
         }
     };
     fetch(0);
     for (int k0 = 0; k0 < Kp; k0 += BK) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) { const int i = tid + j * 256; *reinterpret_cast<bf16x4*>(&As[(i / KV) * LD + 4 * (i % KV)]) = to_bf16x4(ra[j]); }
+        if constexpr (WB16) {
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) { const int i = tid + j * 256; *reinterpret_cast<bf16x4*>(&Bs[(i / KV) * LD + 4 * (i % KV)]) = to_bf16x4(rb[j]); }
+            for (int j = 0; j < BJ16; ++j) { const int i = tid + j * 256; *reinterpret_cast<uint4*>(&Bs[(i >> 2) * LD + 8 * (i & 3)]) = rb16[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) { const int i = tid + j * 256; *reinterpret_cast<bf16x4*>(&Bs[(i / KV) * LD + 4 * (i % KV)]) = to_bf16x4(rb[j]); }
+        }
         __syncthreads();
         if (k0 + BK < Kp) fetch(k0 + BK);
         bf16x8 af[TM];
@@ -97,15 +114,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* 
 // Shapes this variant takes: K a multiple of the 32-wide step, outputs a multiple of the 128-wide tile, enough rows to fill the chip with the chosen tile.
 inline bool bf16_gemm_ok(int M, int Np, int Kp) { return Np % 128 == 0 && Kp % 32 == 0 && Kp >= 256 && M >= 1024; }
 
+static __global__ void cvt_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n4) {      // n4 float4s -> bf16x4s
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        reinterpret_cast<bf16x4*>(dst)[i] = to_bf16x4(reinterpret_cast<const f32x4*>(src)[i]);
+}
+
 template <class Loader, class Epi>
-inline void launch_gemm_bf16(const Loader& ld, const float* Wt, int M, int Np, int Kp, const Epi& ep, hipStream_t s) {
+inline void launch_gemm_bf16(const Loader& ld, const float* Wt, const __bf16* Wt16, int M, int Np, int Kp, const Epi& ep, hipStream_t s) {
     static const int env_bm = [] { const char* e = getenv("ESCX_BF16_BM"); return e ? atoi(e) : 0; }();       // tuning aid: 128 / 256 rows per workgroup
     const int nbn = Np / 128;
     // 128 rows: 156 registers, three workgroups per CU; 256 rows: 272 registers, ONE wave per SIMD - measured on the 1024 -> 1024 period layer: 409 against
     // 271 TFLOP/s forward, 384 against 252 dX (the K step is one memory round trip deep, so the bytes in flight per CU decide)
     const bool big = env_bm == 256;
-    if (big) hipLaunchKernelGGL((gemm_bf16_kernel<256, 128, Loader, Epi>), dim3(((M + 255) / 256) * nbn), dim3(256), 0, s, ld, Wt, M, Np, Kp, nbn, ep);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, Loader, Epi>), dim3(((M + 127) / 128) * nbn), dim3(256), 0, s, ld, Wt, M, Np, Kp, nbn, ep);
+    if (big) hipLaunchKernelGGL((gemm_bf16_kernel<256, 128, false, Loader, Epi>), dim3(((M + 255) / 256) * nbn), dim3(256), 0, s, ld, Wt, Wt16, M, Np, Kp, nbn, ep);
+    else if (Wt16) hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, true, Loader, Epi>), dim3(((M + 127) / 128) * nbn), dim3(256), 0, s, ld, Wt, Wt16, M, Np, Kp, nbn, ep);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, false, Loader, Epi>), dim3(((M + 127) / 128) * nbn), dim3(256), 0, s, ld, Wt, Wt16, M, Np, Kp, nbn, ep);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -532,6 +532,8 @@ def test_bf16_convolution_precision_against_the_fp32_path():
                          g={k: p.grad.clone() for k, p in disc.named_parameters() if p.grad is not None})
     with pytest.raises(ValueError):
         disc.set_conv_precision("fp8")
+    from esc import _native
+    assert lib.escx_disc_set_precision(hd, 7) == _native.ESCX_ERR_INVALID_ARG and lib.escx_disc_get_precision(hd) == 1      # the C ABI refuses other modes, the mode is unchanged
     disc.set_conv_precision("fp32")
     a, b = res["fp32"], res["bf16"]
     worst = 0.0
