@@ -198,8 +198,6 @@ def main():
     ap.add_argument("--scheduler_type", default="constant")
     ap.add_argument("--num_warmup_steps", type=int, default=0)
     ap.add_argument("--adv", action="store_true", help="adversarial training (trainer_adv.py): adds the DAC discriminator and its update")
-    ap.add_argument("--disc_precision", choices=["fp32", "bf16"], default="fp32",
-                    help="--adv: arithmetic of the discriminator's wide period convolutions (fp32 = the reference's; bf16 = bf16 operands, fp32 accumulation)")
     ap.add_argument("--save_path", default=None)
     ap.add_argument("--val_data", default=None, help="folder of 16 kHz wavs: every --eval_every steps the model is evaluated at max_streams (trainer_no_adv.py:132-145)")
     ap.add_argument("--eval_every", type=int, default=0)
@@ -229,7 +227,6 @@ def main():
         from esc.models import Discriminator
         dcfg = (cfg.get("discriminator") if args.config else None) or dict(sample_rate=16000)
         disc = Discriminator(**dcfg).to(device)
-        disc.set_conv_precision(args.disc_precision)
         st = AdvStepper(model, disc, args.lr, loss_w, args.dropout_rate, args.pretraining_steps, seed=args.seed, scheduler=args.scheduler_type,
                         total_steps=args.steps, warmup_steps=args.num_warmup_steps)
     else:
