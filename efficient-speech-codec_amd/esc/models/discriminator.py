@@ -295,13 +295,18 @@ class _DiscFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             _native.check(lib.escx_disc_forward(hd, ctypes.c_void_p(flat.data_ptr()), disc._version(), ctypes.c_void_p(wave.data_ptr()), B, L, ptrs,
                                                 ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-        ctx.disc, ctx.layout, ctx.where, ctx.wave, ctx.bufs, ctx.idx = disc, layout, where, wave, bufs, (dev.index if dev.index is not None else torch.cuda.current_device())
+        # The feature-map buffers are OUTPUTS of this node: kept as plain attributes of ctx they would form a cycle (ctx -> buffer -> grad_fn -> ctx) that runs through
+        # autograd's C++ node, invisible to Python's collector - every forward then leaked its 108 maps (13 GB at 72 signals) until the process ended (rounds 2-3).
+        # save_for_backward stores outputs without that edge.
+        ctx.save_for_backward(wave, *bufs)
+        ctx.disc, ctx.layout, ctx.where, ctx.idx = disc, layout, where, (dev.index if dev.index is not None else torch.cuda.current_device())
         ctx.want_wave, ctx.want_params = ctx.needs_input_grad[1], (any(ctx.needs_input_grad[3:]) and not detach_params)
         return tuple(bufs)
 
     @staticmethod
     def backward(ctx, *dbufs):
-        disc, layout, where, wave, bufs = ctx.disc, ctx.layout, ctx.where, ctx.wave, ctx.bufs
+        disc, layout, where = ctx.disc, ctx.layout, ctx.where
+        wave, bufs = ctx.saved_tensors[0], list(ctx.saved_tensors[1:])
         dev = wave.device
         lib, hd = disc._handle(dev)
         st = disc._flat[ctx.idx]
