@@ -16,6 +16,7 @@ def main():
     dev = torch.device("cuda:0")
     model, cfg, sd = bench.build_model(dev, "large")
     disc = Discriminator(sample_rate=16000).to(dev)
+    disc.set_conv_precision(os.environ.get("ADV_PRECISION", "fp32"))
     pcm = np.stack([(synth.voiced_clip_int16 if i % 2 else synth.noise_clip_int16)(f"bench-r0-{i}", bench.TRAIN_SAMPLES) for i in range(bsz)])
     x = torch.from_numpy(synth.pcm_to_float(pcm)).to(dev)
     st = AdvStepper(model, disc, lr=1e-4, dropout_rate=0.0)
