@@ -26,12 +26,12 @@ __device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
     return r;
 }
 
-// WB16: the weight matrix is read from its bf16 image (the packed weights rounded once per parameter version, escx_disc.cpp: cvt_bf16_kernel) - half the
+// WB16: the weight matrix is read from its bf16 image (the packed weights rounded once per parameter version: cvt_bf16_kernel below, disc.hip refresh_bf16_weights) - half the
 // bytes of the weight operand and no conversion in the staging path; the rounding is the same nearest-even, so the results are bit-identical to WB16 = false.
-template <int BM, int BN, bool WB16, class Loader, class Epi>
+template <int BM, int BN, bool WB16, class Loader, class Epi, int KS = 1>       // KS: 32-deep MFMA steps per staged tile (one barrier pair per KS steps)
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* __restrict__ Wt, const __bf16* __restrict__ Wt16, int M, int Np, int Kp, int nblk_n, Epi ep) {
     static_assert(BM % 64 == 0 && BN % 16 == 0, "tile shape");
-    constexpr int BK = 32;
+    constexpr int BK = 32 * KS;
     constexpr int LD = BK + 8;                 // bf16 per LDS row: 80 B, the 16 rows of a fragment read start 20 banks apart
     constexpr int TM = BM / 64, TN = BN / 16;
     constexpr int KV = BK / 4;                 // float4 per tile row and K step
@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* 
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = zero4();
 
-    constexpr int BJ16 = BN * 4 / 256;          // 16-byte pieces (8 bf16) of the weight tile per thread
+    constexpr int P16 = BK / 8;                 // 16-byte pieces (8 bf16) per weight-tile row
+    constexpr int BJ16 = BN * P16 / 256;        // ... per thread
     f32x4 ra[AJ], rb[WB16 ? 1 : BJ];
     uint4 rb16[WB16 ? BJ16 : 1];
     auto fetch = [&](int k0) {
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* 
         if constexpr (WB16) {
 #pragma unroll
             for (int j = 0; j < BJ16; ++j) {
-                const int i = tid + j * 256, row = i >> 2, c8 = i & 3;
+                const int i = tid + j * 256, row = i / P16, c8 = i % P16;
                 rb16[j] = (n0 + row < Np) ? *reinterpret_cast<const uint4*>(Wt16 + (size_t)(n0 + row) * Kp + k0 + 8 * c8) : make_uint4(0, 0, 0, 0);
             }
         } else {
@@ -81,21 +82,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* 
         for (int j = 0; j < AJ; ++j) { const int i = tid + j * 256; *reinterpret_cast<bf16x4*>(&As[(i / KV) * LD + 4 * (i % KV)]) = to_bf16x4(ra[j]); }
         if constexpr (WB16) {
 #pragma unroll
-            for (int j = 0; j < BJ16; ++j) { const int i = tid + j * 256; *reinterpret_cast<uint4*>(&Bs[(i >> 2) * LD + 8 * (i & 3)]) = rb16[j]; }
+            for (int j = 0; j < BJ16; ++j) { const int i = tid + j * 256; *reinterpret_cast<uint4*>(&Bs[(i / P16) * LD + 8 * (i % P16)]) = rb16[j]; }
         } else {
 #pragma unroll
             for (int j = 0; j < BJ; ++j) { const int i = tid + j * 256; *reinterpret_cast<bf16x4*>(&Bs[(i / KV) * LD + 4 * (i % KV)]) = to_bf16x4(rb[j]); }
         }
         __syncthreads();
         if (k0 + BK < Kp) fetch(k0 + BK);
-        bf16x8 af[TM];
 #pragma unroll
-        for (int b = 0; b < TM; ++b) af[b] = *reinterpret_cast<const bf16x8*>(&As[(wave * (BM / 4) + b * 16 + l15) * LD + 8 * lg]);
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 af[TM];
 #pragma unroll
-        for (int a = 0; a < TN; ++a) {
-            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(&Bs[(a * 16 + l15) * LD + 8 * lg]);
+            for (int b = 0; b < TM; ++b) af[b] = *reinterpret_cast<const bf16x8*>(&As[(wave * (BM / 4) + b * 16 + l15) * LD + 32 * ks + 8 * lg]);
 #pragma unroll
-            for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[b], acc[a][b], 0, 0, 0);
+            for (int a = 0; a < TN; ++a) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(&Bs[(a * 16 + l15) * LD + 32 * ks + 8 * lg]);
+#pragma unroll
+                for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[b], acc[a][b], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -122,11 +126,13 @@ static __global__ void cvt_bf16_kernel(const float* __restrict__ src, __bf16* __
 template <class Loader, class Epi>
 inline void launch_gemm_bf16(const Loader& ld, const float* Wt, const __bf16* Wt16, int M, int Np, int Kp, const Epi& ep, hipStream_t s) {
     static const int env_bm = [] { const char* e = getenv("ESCX_BF16_BM"); return e ? atoi(e) : 0; }();       // tuning aid: 128 / 256 rows per workgroup
+    static const int env_ks = [] { const char* e = getenv("ESCX_BF16_KS"); return e ? atoi(e) : 1; }();        // tuning aid: 2 = 64-deep staged tiles
     const int nbn = Np / 128;
     // 128 rows: 156 registers, three workgroups per CU; 256 rows: 272 registers, ONE wave per SIMD - measured on the 1024 -> 1024 period layer: 409 against
     // 271 TFLOP/s forward, 384 against 252 dX (the K step is one memory round trip deep, so the bytes in flight per CU decide)
     const bool big = env_bm == 256;
     if (big) hipLaunchKernelGGL((gemm_bf16_kernel<256, 128, false, Loader, Epi>), dim3(((M + 255) / 256) * nbn), dim3(256), 0, s, ld, Wt, Wt16, M, Np, Kp, nbn, ep);
+    else if (Wt16 && env_ks == 2 && Kp % 64 == 0) hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, true, Loader, Epi, 2>), dim3(((M + 127) / 128) * nbn), dim3(256), 0, s, ld, Wt, Wt16, M, Np, Kp, nbn, ep);
     else if (Wt16) hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, true, Loader, Epi>), dim3(((M + 127) / 128) * nbn), dim3(256), 0, s, ld, Wt, Wt16, M, Np, Kp, nbn, ep);
     else hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, false, Loader, Epi>), dim3(((M + 127) / 128) * nbn), dim3(256), 0, s, ld, Wt, Wt16, M, Np, Kp, nbn, ep);
 }
