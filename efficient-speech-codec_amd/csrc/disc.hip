@@ -307,8 +307,21 @@ template <class LdA, class LdB>
 int disc_dw(const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
     const size_t per = (size_t)Np * Kp + Np;
     static const bool wide_ok = [] { const char* e = getenv("ESCX_DW_WIDE"); return !(e && e[0] == '0'); }();
-    const bool big = Np >= 256 && Kp >= 256, narrow = Np == 32 && Kp >= 192;
+    const bool big = Np >= 256 && Kp >= 256, narrow = Np == 32 && Kp >= 96;        // narrow: the 32-channel band stacks, from round 4 their 2 -> 32 first layers too (K = 112)
     static const bool dw16n = [] { const char* e = getenv("ESCX_DISC_BF16_DW_NARROW"); return !(e && e[0] == '0'); }();       // bf16 precision: dW of the band stacks too (A/B: 0)
+    static const bool dw_bf16_ok = [] { const char* e = getenv("ESCX_DISC_BF16_DW"); return !(e && e[0] == '0'); }();      // 0: bf16 precision keeps the fp32 dW kernels (A/B)
+    if (tls_conv_bf16 && dw_bf16_ok && Np % 128 == 0 && Kp >= 128 && Kp % 16 == 0) {      // 128 x 128 tiles of dW on the bf16 MFMA (gemm_bf16.h); columns behind Kp read as zero taps
+        const int nbn = Np / 128, nbk = (Kp + 127) / 128, blocks = nbn * nbk;
+        int slices = std::max(1, std::min((2560 + blocks / 2) / blocks, (M + 255) / 256));
+        slices = (int)std::max<size_t>(1, std::min<size_t>(slices, DISC_DW_PART / per));
+        int mps = ((M + slices - 1) / slices + 31) / 32 * 32;
+        slices = (M + mps - 1) / mps;
+        float* bpart = part + (size_t)slices * Np * Kp;
+        hipLaunchKernelGGL((gemm_dw_bf16_kernel<LdA, LdB>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+        launch_reduce_partials(part, slices, (long long)Np * Kp, dW, 0, st);
+        launch_reduce_partials(bpart, slices, (long long)Np, db, 0, st);
+        return 0;
+    }
     if (narrow && tls_conv_bf16 && dw16n && Kp % 16 == 0) {     // 32 x 128 tiles of dW on the bf16 MFMA (gemm_bf16.h)
         const int nbk = (Kp + 127) / 128;
         int slices = std::max(1, std::min((2560 + nbk / 2) / nbk, (M + 255) / 256));
@@ -329,10 +342,7 @@ int disc_dw(const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, floa
         int mps = ((M + slices - 1) / slices + 31) / 32 * 32;
         slices = (M + mps - 1) / mps;
         float* bpart = part + (size_t)slices * Np * Kp;
-        static const bool dw_bf16_ok = [] { const char* e = getenv("ESCX_DISC_BF16_DW"); return !(e && e[0] == '0'); }();      // 0: bf16 precision keeps the fp32 dW kernels (A/B)
-        if (big && tls_conv_bf16 && dw_bf16_ok && Np % 128 == 0 && Kp % 128 == 0)
-            hipLaunchKernelGGL((gemm_dw_bf16_kernel<LdA, LdB>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
-        else if (big) hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, 4, 4, 2, 2, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+        if (big) hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, 4, 4, 2, 2, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
         else hipLaunchKernelGGL((gemm_dw3_kernel<LdA, LdB, 2, 3, 1, 4, true>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
         launch_reduce_partials(part, slices, (long long)Np * Kp, dW, 0, st);
         launch_reduce_partials(bpart, slices, (long long)Np, db, 0, st);
