@@ -28,6 +28,7 @@ namespace escx {
 struct Halo32 {
     TView x; int T0, T1, s1, d0, d1, off0, off1, O0, O1, B;
     int ok;                     // host: geometry is covered (32 channels in and out, unit stride along the frames)
+    int ok16;                   // ... with 16 (padded) output channels: dX of the 2 -> 32 first layers (bf16 form only)
 };
 
 constexpr int H32_TO0 = 4, H32_TO1 = 32, H32_P = 36;           // output tile; LDS floats per input position (32 channels + 4: fragment reads of consecutive positions spread over the banks)
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void conv32_halo_kernel(Halo32 g, const float*
 // The same tile on the bf16 MFMA (the discriminator's opt-in bf16 precision, gemm_bf16.h): the input image and the weight slices are rounded to bf16 when they are
 // staged (80-byte LDS rows: one ds_read_b128 = the 8 channels of a lane's k slots), a tap is ONE 32-deep MFMA step per accumulator tile; fp32 accumulation in tap order.
 constexpr int H32_P16 = 40;
-template <class Epi>
+template <int TN, class Epi>                // TN: 16-wide tiles of output channels (2: the 32 -> 32 layers; 1: dX of the 2 -> 32 first layers, 16 padded input channels)
 __global__ __launch_bounds__(256) void conv32_halo_bf16_kernel(Halo32 g, const float* __restrict__ W, int Kp, int tiles0, int tiles1, Epi ep) {
     extern __shared__ __attribute__((aligned(16))) __bf16 h16_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
@@ -139,30 +140,31 @@ __global__ __launch_bounds__(256) void conv32_halo_bf16_kernel(Halo32 g, const f
     }
     const int wn = tid >> 3, wc = 4 * (tid & 7);
     const int NT = g.T0 * g.T1;
-    const float* wsrc = W + (size_t)wn * Kp + wc;
+    const bool wrow_ok = wn < 16 * TN;          // the weight matrix has 16 TN rows
+    const float* wsrc = W + (size_t)(wrow_ok ? wn : 0) * Kp + wc;
     __bf16* wdst = Ws + wn * H32_P16 + wc;
-    *reinterpret_cast<bf16x4*>(wdst) = to_bf16x4(ld4(wsrc));
-    if (NT > 1) *reinterpret_cast<bf16x4*>(wdst + 32 * H32_P16) = to_bf16x4(ld4(wsrc + 32));
-    f32x4 wreg = NT > 2 ? ld4(wsrc + 64) : zero4();
+    *reinterpret_cast<bf16x4*>(wdst) = to_bf16x4(wrow_ok ? ld4(wsrc) : zero4());
+    if (NT > 1) *reinterpret_cast<bf16x4*>(wdst + 32 * H32_P16) = to_bf16x4(wrow_ok ? ld4(wsrc + 32) : zero4());
+    f32x4 wreg = (NT > 2 && wrow_ok) ? ld4(wsrc + 64) : zero4();
     __syncthreads();
-    f32x4 acc[2][2];
+    f32x4 acc[TN][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = zero4();
     int t0 = 0, t1 = 0, slot = 0;
     for (int tap = 0; tap < NT; ++tap) {
         f32x4 wnew = zero4();
-        if (tap + 3 < NT) wnew = ld4(wsrc + (tap + 3) * 32);
+        if (tap + 3 < NT && wrow_ok) wnew = ld4(wsrc + (tap + 3) * 32);
         const __bf16* hrow = Hs + ((size_t)(wave + g.d0 * t0 - lo0) * HW + (g.d1 * t1 - lo1)) * H32_P16 + 8 * lg;
         const __bf16* wrow = Ws + slot * 32 * H32_P16 + l15 * H32_P16 + 8 * lg;
-        bf16x8 af[2], wf[2];
+        bf16x8 af[2], wf[TN];
 #pragma unroll
         for (int b = 0; b < 2; ++b) af[b] = *reinterpret_cast<const bf16x8*>(hrow + (size_t)((16 * b + l15) * g.s1) * H32_P16);
 #pragma unroll
-        for (int a = 0; a < 2; ++a) wf[a] = *reinterpret_cast<const bf16x8*>(wrow + 16 * a * H32_P16);
+        for (int a = 0; a < TN; ++a) wf[a] = *reinterpret_cast<const bf16x8*>(wrow + 16 * a * H32_P16);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < TN; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], af[b], acc[a][b], 0, 0, 0);
         const int wslot = slot == 0 ? 2 : slot - 1;
@@ -180,24 +182,25 @@ __global__ __launch_bounds__(256) void conv32_halo_bf16_kernel(Halo32 g, const f
         if (o1 >= g.O1) continue;
         const int m = (bi * g.O0 + o0) * g.O1 + o1;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) ep.store(m, 16 * a + 4 * lg, acc[a][b], 0);
+        for (int a = 0; a < TN; ++a) ep.store(m, 16 * a + 4 * lg, acc[a][b], 0);
     }
 }
 
 inline Halo32 make_halo32(const ConvSU& l, int M, int Np, int Kp) {
-    Halo32 h{l.x, l.g.T0, l.g.T1, l.g.s1, 1, 1, -l.g.p0, -l.g.p1, l.g.O0, l.g.O1, 0, 0};
+    Halo32 h{l.x, l.g.T0, l.g.T1, l.g.s1, 1, 1, -l.g.p0, -l.g.p1, l.g.O0, l.g.O1, 0, 0, 0};
     h.B = M / std::max(1, l.g.O0 * l.g.O1);
     h.ok = Np == 32 && l.x.Cp == 32 && l.g.s0 == 1 && Kp == l.g.T0 * l.g.T1 * 32 && h.B * l.g.O0 * l.g.O1 == M;
     return h;
 }
 inline Halo32 make_halo32(const ConvTS& l, int M, int Np, int Kp) {             // dX of a stride-1 layer: rows walk the INPUT map of the layer
-    Halo32 h{l.y, l.g.T0, l.g.T1, 1, -1, -1, l.g.p0, l.g.p1, l.D0, l.D1, 0, 0};
+    Halo32 h{l.y, l.g.T0, l.g.T1, 1, -1, -1, l.g.p0, l.g.p1, l.D0, l.D1, 0, 0, 0};
     h.B = M / std::max(1, l.D0 * l.D1);
-    h.ok = Np == 32 && l.y.Cp == 32 && l.g.s0 == 1 && l.g.s1 == 1 && Kp == l.g.T0 * l.g.T1 * 32 && h.B * l.D0 * l.D1 == M;
+    const bool geom = l.y.Cp == 32 && l.g.s0 == 1 && l.g.s1 == 1 && Kp == l.g.T0 * l.g.T1 * 32 && h.B * l.D0 * l.D1 == M;
+    h.ok = Np == 32 && geom; h.ok16 = Np == 16 && geom;
     return h;
 }
 inline Halo32 make_halo32(const ConvTSP& l, int M, int Np, int Kp) {            // dX of one residue class of a strided layer
-    Halo32 h{l.y, l.g.n0, l.g.n1, 1, -1, -1, l.g.c0, l.g.c1, l.g.Q0, l.g.Q1, 0, 0};
+    Halo32 h{l.y, l.g.n0, l.g.n1, 1, -1, -1, l.g.c0, l.g.c1, l.g.Q0, l.g.Q1, 0, 0, 0};
     h.B = M / std::max(1, l.g.Q0 * l.g.Q1);
     h.ok = Np == 32 && l.y.Cp == 32 && l.g.n0 >= 1 && l.g.n1 >= 1 && Kp == l.g.n0 * l.g.n1 * 32 && h.B * l.g.Q0 * l.g.Q1 == M;
     return h;
@@ -219,11 +222,12 @@ inline bool launch_conv32_halo(const Halo32& h, const float* W, int Kp, const Ep
 
 template <class Epi>
 inline bool launch_conv32_halo_bf16(const Halo32& h, const float* W, int Kp, const Epi& ep, hipStream_t st) {
-    if (!h.ok || h.T0 > 4 || h.T1 > 9) return false;
+    if ((!h.ok && !h.ok16) || h.T0 > 4 || h.T1 > 9) return false;
     const int NF = H32_TO0 + h.T0 - 1, HW = (H32_TO1 - 1) * h.s1 + h.T1;
     const size_t lds = ((size_t)NF * HW * H32_P16 + 3 * 32 * H32_P16) * sizeof(__bf16);       // <= 36 KB
     const int tiles0 = (h.O0 + H32_TO0 - 1) / H32_TO0, tiles1 = (h.O1 + H32_TO1 - 1) / H32_TO1;
-    hipLaunchKernelGGL((conv32_halo_bf16_kernel<Epi>), dim3((unsigned)((size_t)h.B * tiles0 * tiles1)), dim3(256), lds, st, h, W, Kp, tiles0, tiles1, ep);
+    if (h.ok) hipLaunchKernelGGL((conv32_halo_bf16_kernel<2, Epi>), dim3((unsigned)((size_t)h.B * tiles0 * tiles1)), dim3(256), lds, st, h, W, Kp, tiles0, tiles1, ep);
+    else hipLaunchKernelGGL((conv32_halo_bf16_kernel<1, Epi>), dim3((unsigned)((size_t)h.B * tiles0 * tiles1)), dim3(256), lds, st, h, W, Kp, tiles0, tiles1, ep);
     return true;
 }
 

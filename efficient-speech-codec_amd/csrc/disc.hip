@@ -260,7 +260,7 @@ void conv_gemm(const Ld& ld_in, const float* W, int M, int Np, int Kp, const Epi
         static const bool halo = [] { const char* e = getenv("ESCX_CONV32_HALO"); return e && e[0] == '1'; }();       // opt-in: bit-identical, 4-10 % faster alone, the step 4 % SLOWER
         if (halo && Np == 32 && launch_conv32_halo(make_halo32(ld_in, M, Np, Kp), W, Kp, ep, st)) return;
         static const bool halo16 = [] { const char* e = getenv("ESCX_CONV32_HALO_BF16"); return !(e && e[0] == '0'); }();      // bf16 precision: the band convolutions too (A/B: 0)
-        if (tls_conv_bf16 && halo16 && Np == 32 && launch_conv32_halo_bf16(make_halo32(ld_in, M, Np, Kp), W, Kp, ep, st)) return;
+        if (tls_conv_bf16 && halo16 && (Np == 32 || Np == 16) && launch_conv32_halo_bf16(make_halo32(ld_in, M, Np, Kp), W, Kp, ep, st)) return;
     }
     if constexpr (!std::is_same<Ld, PlainA>::value) {            // opt-in bf16 MFMA for the wide layers (gemm_bf16.h): same gathers, same epilogues
         if (tls_conv_bf16 && bf16_gemm_ok(M, Np, Kp) && conv_cp(ld) % 32 == 0) {
