@@ -307,7 +307,7 @@ template <class LdA, class LdB>
 int disc_dw(const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
     const size_t per = (size_t)Np * Kp + Np;
     static const bool wide_ok = [] { const char* e = getenv("ESCX_DW_WIDE"); return !(e && e[0] == '0'); }();
-    const bool big = Np >= 256 && Kp >= 256, narrow = Np == 32 && Kp >= 96;        // narrow: the 32-channel band stacks, from round 4 their 2 -> 32 first layers too (K = 112)
+    const bool big = Np >= 128 && Kp >= 128, narrow = Np == 32 && Kp >= 96;        // narrow: the 32-channel band stacks, from round 4 their 2 -> 32 first layers too (K = 112)
     static const bool dw16n = [] { const char* e = getenv("ESCX_DISC_BF16_DW_NARROW"); return !(e && e[0] == '0'); }();       // bf16 precision: dW of the band stacks too (A/B: 0)
     static const bool dw_bf16_ok = [] { const char* e = getenv("ESCX_DISC_BF16_DW"); return !(e && e[0] == '0'); }();      // 0: bf16 precision keeps the fp32 dW kernels (A/B)
     if (tls_conv_bf16 && dw_bf16_ok && Np % 128 == 0 && Kp >= 128 && Kp % 16 == 0) {      // 128 x 128 tiles of dW on the bf16 MFMA (gemm_bf16.h); columns behind Kp read as zero taps
