@@ -684,11 +684,16 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
             ViewRowsA la{g, M, FastDiv(yv.D0 * yv.D1), FastDiv(yv.D1)};
             ConvS lb = make_convs(x, c, yv.D0, yv.D1, B);
             int r;
-            { DTrace tr(st, "dW", c.prefix.c_str(), M, c.CoutP, c.Kf); r = disc_dw(la, lb, M, c.CoutP, c.Kf, dWs, dWs + (size_t)c.CoutP * c.Kf, part, st); }
+            // the bias gradient is reduced straight into the flat gradient buffer where the channel count needs no padding (every layer but the 1-channel heads:
+            // 100 copy-engine packets per backward less)
+            static const bool db_direct_ok = [] { const char* e = getenv("ESCX_DISC_DB_DIRECT"); return !(e && e[0] == '0'); }();
+            const bool db_direct = db_direct_ok && c.Cout == c.CoutP;
+            float* db = db_direct ? grad_flat + c.off_b : dWs + (size_t)c.CoutP * c.Kf;
+            { DTrace tr(st, "dW", c.prefix.c_str(), M, c.CoutP, c.Kf); r = disc_dw(la, lb, M, c.CoutP, c.Kf, dWs, db, part, st); }
             if (r) return r;
             hipLaunchKernelGGL(wn_bwd_kernel, dim3(c.Cout), dim3(256), 0, st, dWs, flat_params + c.off_v, c.scale, grad_flat + c.off_v, grad_flat + c.off_g, c.Cin,
                                c.T0 * c.T1, c.CinP, c.Kf);
-            ESCX_HIP(hipMemcpyAsync(grad_flat + c.off_b, dWs + (size_t)c.CoutP * c.Kf, (size_t)c.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+            if (!db_direct) ESCX_HIP(hipMemcpyAsync(grad_flat + c.off_b, db, (size_t)c.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
         }
         if (gx || gx_plain) {
             TView gxv = gx ? *gx : TView{gx_plain, x.D0, x.D1, x.D1, x.Cp};
