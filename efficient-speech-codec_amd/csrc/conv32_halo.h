@@ -33,6 +33,7 @@ struct Halo32 {
 
 constexpr int H32_TO0 = 4, H32_TO1 = 32, H32_P = 36;           // output tile; LDS floats per input position (32 channels + 4: fragment reads of consecutive positions spread over the banks)
 
+#ifdef ESCX_EXPERIMENTAL       // the fp32 form of the tile kernel: tagged builds only (tune_env.h)
 template <class Epi>
 __global__ __launch_bounds__(256) void conv32_halo_kernel(Halo32 g, const float* __restrict__ W, int Kp, int tiles0, int tiles1, Epi ep) {
     extern __shared__ __attribute__((aligned(16))) float h32_lds[];
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(256) void conv32_halo_kernel(Halo32 g, const float*
         for (int a = 0; a < 2; ++a) ep.store(m, 16 * a + 4 * lg, acc[a][b], 0);
     }
 }
+#endif  // ESCX_EXPERIMENTAL
 
 // The same tile on the bf16 MFMA (the discriminator's opt-in bf16 precision, gemm_bf16.h): the input image and the weight slices are rounded to bf16 when they are
 // staged (80-byte LDS rows: one ds_read_b128 = the 8 channels of a lane's k slots), a tap is ONE 32-deep MFMA step per accumulator tile; fp32 accumulation in tap order.
@@ -207,6 +209,7 @@ inline Halo32 make_halo32(const ConvTSP& l, int M, int Np, int Kp) {            
 }
 inline Halo32 make_halo32(const PlainA&, int, int, int) { Halo32 h{}; h.ok = 0; return h; }
 
+#ifdef ESCX_EXPERIMENTAL
 template <class Epi>
 inline bool launch_conv32_halo(const Halo32& h, const float* W, int Kp, const Epi& ep, hipStream_t st) {
     if (!h.ok || h.T0 > 4 || h.T1 > 9) return false;
@@ -220,6 +223,7 @@ inline bool launch_conv32_halo(const Halo32& h, const float* W, int Kp, const Ep
     return true;
 }
 
+#endif
 template <class Epi>
 inline bool launch_conv32_halo_bf16(const Halo32& h, const float* W, int Kp, const Epi& ep, hipStream_t st) {
     if ((!h.ok && !h.ok16) || h.T0 > 4 || h.T1 > 9) return false;

@@ -178,7 +178,7 @@ int pack_weights(escx_disc_s* d, const float* flat, long long params_version, hi
 // bf16 precision: the packed weights rounded once per parameter version (the convolution kernels would round the same values again for every tile they stage)
 int refresh_bf16_weights(escx_disc_s* d, hipStream_t st) {
     tls_conv_bf16 = d->precision; tls_w32 = d->wbuf; tls_wn = d->wfloats; tls_w16 = nullptr;
-    static const bool w16_ok = [] { const char* e = getenv("ESCX_DISC_BF16_WEIGHTS"); return !(e && e[0] == '0'); }();      // 0: weights rounded while staged (A/B)
+    static const bool w16_ok = [] { const char* e = ESCX_TUNE_ENV("ESCX_DISC_BF16_WEIGHTS"); return !(e && e[0] == '0'); }();      // 0: weights rounded while staged (A/B)
     if (!d->precision || !w16_ok) return 0;
     if (!d->wbuf16) ESCX_HIP(hipMalloc((void**)&d->wbuf16, d->wfloats * sizeof(__bf16)));
     if (d->w16_ptr != d->packed_ptr || d->w16_version != d->packed_version || d->packed_version < 0) {
@@ -197,7 +197,7 @@ int disc_streams() {
     return DTrace::on() ? 1 : n;
 }
 int disc_stream_of(int si, int n) {
-    static const std::string map = [] { const char* e = getenv("ESCX_DISC_STREAM_MAP"); return std::string(e ? e : ""); }();
+    static const std::string map = [] { const char* e = ESCX_TUNE_ENV("ESCX_DISC_STREAM_MAP"); return std::string(e ? e : ""); }();
     const int q = si < (int)map.size() && map[si] >= '0' && map[si] <= '3' ? map[si] - '0' : si % n;
     return q < n ? q : si % n;
 }
@@ -257,9 +257,11 @@ template <class Ld, class Epi>
 void conv_gemm(const Ld& ld_in, const float* W, int M, int Np, int Kp, const Epi& ep, hipStream_t st) {
     Ld ld = ld_in;
     if constexpr (!std::is_same<Ld, PlainA>::value) {            // the 32 -> 32-channel band convolutions: input tile held in LDS (conv32_halo.h), bit-identical to the engine
-        static const bool halo = [] { const char* e = getenv("ESCX_CONV32_HALO"); return e && e[0] == '1'; }();       // opt-in: bit-identical, 4-10 % faster alone, the step 4 % SLOWER
+#ifdef ESCX_EXPERIMENTAL       // fp32 LDS-tile form: bit-identical, 4-10 % faster alone, the step 4 % SLOWER (profiles/r4_disc_ab.txt); tagged builds only
+        static const bool halo = [] { const char* e = ESCX_TUNE_ENV("ESCX_CONV32_HALO"); return e && e[0] == '1'; }();
         if (halo && Np == 32 && launch_conv32_halo(make_halo32(ld_in, M, Np, Kp), W, Kp, ep, st)) return;
-        static const bool halo16 = [] { const char* e = getenv("ESCX_CONV32_HALO_BF16"); return !(e && e[0] == '0'); }();      // bf16 precision: the band convolutions too (A/B: 0)
+#endif
+        static const bool halo16 = [] { const char* e = ESCX_TUNE_ENV("ESCX_CONV32_HALO_BF16"); return !(e && e[0] == '0'); }();      // bf16 precision: the band convolutions too (A/B: 0)
         if (tls_conv_bf16 && halo16 && (Np == 32 || Np == 16) && launch_conv32_halo_bf16(make_halo32(ld_in, M, Np, Kp), W, Kp, ep, st)) return;
     }
     if constexpr (!std::is_same<Ld, PlainA>::value) {            // opt-in bf16 MFMA for the wide layers (gemm_bf16.h): same gathers, same epilogues
@@ -271,8 +273,8 @@ void conv_gemm(const Ld& ld_in, const float* W, int M, int Np, int Kp, const Epi
     const long long tiles128 = (long long)((M + 127) / 128) * ((Np + 95) / 96);
     // K steps of 16: 18 KB of LDS per workgroup instead of 75 KB at the engine's default step of 80 for K = 5 x 1024 - twice the resident
     // workgroups per CU; measured on the step's convolutions (tools/disc_trace.py): forward 73.5 -> 60.2 ms, dX 115.8 -> 99.0 ms
-    static const int env_bk = [] { const char* e = getenv("ESCX_CONV_BK"); return e ? atoi(e) : 16; }();
-    static const int env_bkn = [] { const char* e = getenv("ESCX_CONV_BK_NARROW"); return e ? atoi(e) : 0; }();       // K step of the <= 48-channel outputs (0: the same)
+    static const int env_bk = [] { const char* e = ESCX_TUNE_ENV("ESCX_CONV_BK"); return e ? atoi(e) : 16; }();
+    static const int env_bkn = [] { const char* e = ESCX_TUNE_ENV("ESCX_CONV_BK_NARROW"); return e ? atoi(e) : 0; }();       // K step of the <= 48-channel outputs (0: the same)
     const int want_bk = (Np <= 48 && env_bkn > 0) ? env_bkn : env_bk;
     const int fbk = (want_bk > 0 && Kp % want_bk == 0) ? want_bk : 0;
     if constexpr (!std::is_same<Ld, PlainA>::value) {            // uniform-tap gathers only when no K step of the engine straddles a tap
@@ -283,7 +285,7 @@ void conv_gemm(const Ld& ld_in, const float* W, int M, int Np, int Kp, const Epi
     // fragment reads and per K step; 256 rows double the MFMAs per weight fragment and per barrier.  MEASURED SLOWER (round 3, adversarial step at 36
     // clips): MRD band convolutions forward 79 -> 67 TFLOP/s, dX 68 -> 63, step 399.6 -> 402.0 ms (half the workgroups, 4 gather contexts per
     // thread).  Kept as an A/B switch only: ESCX_CONV_BM256=1.
-    static const bool bm256 = [] { const char* e = getenv("ESCX_CONV_BM256"); return e && e[0] == '1'; }();
+    static const bool bm256 = [] { const char* e = ESCX_TUNE_ENV("ESCX_CONV_BM256"); return e && e[0] == '1'; }();
     if (bm256 && Np <= 48 && (long long)((M + 255) / 256) * ((Np + 47) / 48) >= 1024) { launch_gemm<256>(ld, W, M, Np, Kp, ep, st, 1, fbk); return; }
     if (tiles128 >= 512) launch_gemm<128>(ld, W, M, Np, Kp, ep, st, 1, fbk);
     else launch_gemm<64>(ld, W, M, Np, Kp, ep, st, 1, fbk);
@@ -306,10 +308,10 @@ constexpr size_t DISC_DW_PART = (size_t)48 << 20;          // floats: 192 MB of 
 template <class LdA, class LdB>
 int disc_dw(const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
     const size_t per = (size_t)Np * Kp + Np;
-    static const bool wide_ok = [] { const char* e = getenv("ESCX_DW_WIDE"); return !(e && e[0] == '0'); }();
+    static const bool wide_ok = [] { const char* e = ESCX_TUNE_ENV("ESCX_DW_WIDE"); return !(e && e[0] == '0'); }();
     const bool big = Np >= 128 && Kp >= 128, narrow = Np == 32 && Kp >= 96;        // narrow: the 32-channel band stacks, from round 4 their 2 -> 32 first layers too (K = 112)
-    static const bool dw16n = [] { const char* e = getenv("ESCX_DISC_BF16_DW_NARROW"); return !(e && e[0] == '0'); }();       // bf16 precision: dW of the band stacks too (A/B: 0)
-    static const bool dw_bf16_ok = [] { const char* e = getenv("ESCX_DISC_BF16_DW"); return !(e && e[0] == '0'); }();      // 0: bf16 precision keeps the fp32 dW kernels (A/B)
+    static const bool dw16n = [] { const char* e = ESCX_TUNE_ENV("ESCX_DISC_BF16_DW_NARROW"); return !(e && e[0] == '0'); }();       // bf16 precision: dW of the band stacks too (A/B: 0)
+    static const bool dw_bf16_ok = [] { const char* e = ESCX_TUNE_ENV("ESCX_DISC_BF16_DW"); return !(e && e[0] == '0'); }();      // 0: bf16 precision keeps the fp32 dW kernels (A/B)
     if (tls_conv_bf16 && dw_bf16_ok && Np % 128 == 0 && Kp >= 128 && Kp % 16 == 0) {      // 128 x 128 tiles of dW on the bf16 MFMA (gemm_bf16.h); columns behind Kp read as zero taps
         const int nbn = Np / 128, nbk = (Kp + 127) / 128, blocks = nbn * nbk;
         int slices = std::max(1, std::min((2560 + blocks / 2) / blocks, (M + 255) / 256));
@@ -686,7 +688,7 @@ extern "C" int escx_disc_backward(escx_disc d, const float* flat_params, int64_t
             int r;
             // the bias gradient is reduced straight into the flat gradient buffer where the channel count needs no padding (every layer but the 1-channel heads:
             // 100 copy-engine packets per backward less)
-            static const bool db_direct_ok = [] { const char* e = getenv("ESCX_DISC_DB_DIRECT"); return !(e && e[0] == '0'); }();
+            static const bool db_direct_ok = [] { const char* e = ESCX_TUNE_ENV("ESCX_DISC_DB_DIRECT"); return !(e && e[0] == '0'); }();
             const bool db_direct = db_direct_ok && c.Cout == c.CoutP;
             float* db = db_direct ? grad_flat + c.off_b : dWs + (size_t)c.CoutP * c.Kf;
             { DTrace tr(st, "dW", c.prefix.c_str(), M, c.CoutP, c.Kf); r = disc_dw(la, lb, M, c.CoutP, c.Kf, dWs, db, part, st); }

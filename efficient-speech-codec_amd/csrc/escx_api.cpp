@@ -126,14 +126,14 @@ extern "C" int escx_create(const escx_config* cfg, int device, escx_handle* out)
     escx_handle_s* h = new escx_handle_s();
     h->cfg = *cfg; h->device = device;
     { const char* e = getenv("ESCX_NO_FUSED"); h->use_fused = !(e && e[0] == '1'); }
-    { const char* e = getenv("ESCX_MLP_VARIANT"); if (e && e[0]) h->mlp_variant = atoi(e); }
-    { const char* e = getenv("ESCX_MLP_HS"); if (e && e[0]) h->mlp_hs = atoi(e); }
-    { const char* e = getenv("ESCX_ATTN_GS"); if (e && e[0]) h->attn_gs = atoi(e); }
+    { const char* e = ESCX_TUNE_ENV("ESCX_MLP_VARIANT"); if (e && e[0]) h->mlp_variant = atoi(e); }
+    { const char* e = ESCX_TUNE_ENV("ESCX_MLP_HS"); if (e && e[0]) h->mlp_hs = atoi(e); }
+    { const char* e = ESCX_TUNE_ENV("ESCX_ATTN_GS"); if (e && e[0]) h->attn_gs = atoi(e); }
     { const char* e = getenv("ESCX_STREAMS"); if (e && e[0]) { h->parts = std::min(std::max(atoi(e), 1), (int)escx_handle_s::MAX_PARTS); h->parts_forced = true; } }
     { const char* e = getenv("ESCX_DEEMBED_TWO_STAGE"); h->deembed_two_stage = (e && e[0] == '1'); }
     { const char* e = getenv("ESCX_DEEMBED_GEMM"); h->deembed_halo = !(e && e[0] == '1'); }
-    { const char* e = getenv("ESCX_ATTN_NW"); if (e && e[0]) h->attn_nw = atoi(e); }
-    { const char* e = getenv("ESCX_NO_ATTN_PACK"); h->attn_pack = !(e && e[0] == '1'); }
+    { const char* e = ESCX_TUNE_ENV("ESCX_ATTN_NW"); if (e && e[0]) h->attn_nw = atoi(e); }
+    { const char* e = ESCX_TUNE_ENV("ESCX_NO_ATTN_PACK"); h->attn_pack = !(e && e[0] == '1'); }
     { const char* e = getenv("ESCX_NO_FUSED_ATTN"); h->use_fused_attn = !(e && e[0] == '1'); }
     int rc = build_geometry(h);
     if (rc) { delete h; return rc; }
@@ -153,6 +153,8 @@ extern "C" void escx_destroy(escx_handle h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (auto& kv : h->maps) (void)hipFree(kv.second);
     if (h->coll_buf) (void)hipFree(h->coll_buf);
+    for (Quant& q : h->quants) if (q.tab) (void)hipFree(q.tab);
+    if (h->iota_codes) (void)hipFree(h->iota_codes);
     if (h->gmap) (void)hipFree(h->gmap);
     if (h->garena) (void)hipFree(h->garena);
     if (h->grad_seg) (void)hipFree(h->grad_seg);
@@ -519,6 +521,8 @@ static int pack_image(escx_handle_s* h, std::vector<float>& image, std::vector<s
         size_t owd = gslot(&q.wd, (size_t)q.Nz * q.Kq), owu = gslot(&q.wup, (size_t)q.Kq * q.Kup);
         size_t owdT = slot(&q.wdT, (size_t)q.Kq * q.Nz), owuT = slot(&q.wupT, (size_t)q.Kup * q.Kq);
         size_t ocn = cslot(&q.cbn, (size_t)G * Ksz * q.dt), oc2 = cslot(&q.c2, (size_t)G * Ksz), ocr = gslot(&q.cbraw, (size_t)G * Ksz * q.dt);
+        size_t owf = slot(&q.wdf, (size_t)q.Nz * q.Kq), ogq = cslot(&q.gq, (size_t)q.Kq / 4);
+        std::vector<int> grp_of((size_t)q.Kq, -1);                             // group of every element of the framed vector in memory order
         int start = 0;
         for (int g = 0; g < G; ++g) {
             const std::string gs = std::to_string(g);
@@ -529,6 +533,7 @@ static int pack_image(escx_handle_s* h, std::vector<float>& image, std::vector<s
                 const int flat = start + e;                                     // (o, c, h) order: quantization.py:400-409
                 const int o = flat / fix, r = flat - o * fix, cc = r / q.Hq, hh = r - cc * q.Hq;
                 const size_t col = (size_t)(o * q.Hq + hh) * q.Cp + cc;         // internal (o, h, c) order
+                grp_of[col] = g;
                 for (int j = 0; j < q.d; ++j) {
                     pk.host[owd + (size_t)(g * q.dt + j) * q.Kq + col] = dw->data[(size_t)j * dims[g] + e];
                     pk.host[owu + col * q.Kup + g * q.dt + j] = uw->data[(size_t)e * q.d + j];
@@ -552,7 +557,26 @@ static int pack_image(escx_handle_s* h, std::vector<float>& image, std::vector<s
             }
             start += dims[g];
         }
+        // fragment order of the down-projection for the fused kernel: (k chunk, n tile, lane = 16 * slot + i, j) = W[16 tile + i][16 chunk + 4 slot + j]
+        {
+            const int NT = q.Nz / 16, KC = q.Kq / 16;
+            for (int ck = 0; ck < KC; ++ck) for (int tn = 0; tn < NT; ++tn) for (int sl = 0; sl < 4; ++sl) for (int i = 0; i < 16; ++i) for (int j = 0; j < 4; ++j)
+                pk.host[owf + ((((size_t)ck * NT + tn) * 64) + 16 * sl + i) * 4 + j] = pk.host[owd + (size_t)(16 * tn + i) * q.Kq + 16 * ck + 4 * sl + j];
+        }
+        // group of every float4 (padding channels belong to no group); a float4 that straddles two groups rules the table form out
+        q.tab_ok = true;
+        for (int f4 = 0; f4 < q.Kq / 4; ++f4) {
+            int g4 = -1;
+            for (int e = 0; e < 4; ++e) {
+                const int ge = grp_of[(size_t)4 * f4 + e];
+                if (ge < 0) continue;
+                if (g4 >= 0 && ge != g4) q.tab_ok = false;
+                g4 = ge;
+            }
+            pk.host[ogq + f4] = (float)g4;
+        }
     }
+    h->pvq_tab_stale = true;
 
     image.swap(pk.host);
     return 0;
@@ -893,15 +917,33 @@ static int run_halves(escx_handle_s* h, int B, hipStream_t st, F part) {
     static const bool prof_serial = [] { const char* e = getenv("ESCX_PROF_SERIAL"); return e && e[0] == '1'; }();
     const bool concurrent = !(h->prof && (prof_serial || h->prof_isolated));
     if (concurrent) ESCX_HIP(hipEventRecord(h->ev_fork, st));
+    // Join guard: once a part has been enqueued on a side stream, NO error path may return before the caller's stream waits
+    // for it - the caller is free to release or reuse the buffers the moment this function returns an error.  Failures between fork and join are
+    // therefore collected, every started side stream is joined (event, or a blocking stream synchronise when the event cannot be recorded), and
+    // only then is the first failure reported.
     int rc = 0;
+    bool started[8] = {false, false, false, false, false, false, false, false};
+    auto hip_fail = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == 0) { set_error("run_halves: %s: %s", what, hipGetErrorString(e)); rc = ESCX_ERR_HIP; }
+        return e != hipSuccess;
+    };
     for (int i = 0; i < k && !rc; ++i) {
         const int b0 = i * per, nb = std::min(per, B - b0);
         if (nb <= 0) break;
-        hipStream_t si = (concurrent && i > 0) ? h->sx[i] : st;
-        if (concurrent && i > 0) ESCX_HIP(hipStreamWaitEvent(si, h->ev_fork, 0));
+        const bool side = concurrent && i > 0;
+        hipStream_t si = side ? h->sx[i] : st;
+        if (side && hip_fail(hipStreamWaitEvent(si, h->ev_fork, 0), "fork wait")) break;
         use_set(h, i);
-        rc = part(b0, nb, si);
-        if (concurrent && i > 0) { ESCX_HIP(hipEventRecord(h->ev_join[i], si)); ESCX_HIP(hipStreamWaitEvent(st, h->ev_join[i], 0)); }
+        if (side && i < 8) started[i] = true;
+        const int prc = part(b0, nb, si);
+        if (prc && !rc) rc = prc;
+    }
+    for (int i = 1; i < k && i < 8; ++i) {
+        if (!started[i]) continue;
+        if (hipEventRecord(h->ev_join[i], h->sx[i]) != hipSuccess || hipStreamWaitEvent(st, h->ev_join[i], 0) != hipSuccess) {
+            const hipError_t e = hipStreamSynchronize(h->sx[i]);          // cannot order the streams with an event: wait on the host instead
+            hip_fail(e == hipSuccess ? hipErrorUnknown : e, "join");
+        }
     }
     use_set(h, 0);
     return rc;
@@ -991,7 +1033,7 @@ extern "C" const char* escx_profile_report(escx_handle h) {
 // `cap` = waves per SIMD the kernel's register budget allows (mlp_min_waves / attn_min_waves): at 3, an 8-wave workgroup leaves
 // the third slot of every SIMD empty (one workgroup = 2 waves per SIMD, a second one does not fit), so 4-wave workgroups it is.
 static int pick_nw(long long tiles, int units, int cap = 4) {
-    static const bool cap_rule = [] { const char* e = getenv("ESCX_NW_CAP_RULE"); return !(e && e[0] == '0'); }();
+    static const bool cap_rule = [] { const char* e = ESCX_TUNE_ENV("ESCX_NW_CAP_RULE"); return !(e && e[0] == '0'); }();
     if (cap == 3 && cap_rule) return 4;
     auto cost = [&](int nw) { const long long wg = (tiles / units + nw - 1) / nw; return ((wg + 255) / 256) * ((nw + 3) / 4) * units; };
     return cost(8) <= cost(4) ? 8 : 4;
@@ -1043,7 +1085,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
     // OPT-IN (ESCX_COMBINE_ON_LOAD=1).  MEASURED (round 4, B = 36, profiles/r4_mlp_combine_ab.txt): bit-identical, and slower - the consumers' gather
     // prologues are latency-bound and badly coalesced (64-byte pieces), four row reads there (twice in the attention: LayerNorm input and shortcut) cost
     // more than the streaming combine launch at 6 TB/s: attention C = 192 / 384 +0.14 / +0.13, merge / split +0.18 ms per step against 0.30 removed.
-    static const bool comb_on_load = [] { const char* e = getenv("ESCX_COMBINE_ON_LOAD"); return e && e[0] == '1'; }();
+    static const bool comb_on_load = [] { const char* e = ESCX_TUNE_ENV("ESCX_COMBINE_ON_LOAD"); return e && e[0] == '1'; }();
     CombineOnLoad pend{nullptr, nullptr, 0, 0};
     std::string pend_tag;
     auto flush_pending = [&]() {                        // explicit combine launch (fallback)
@@ -1100,9 +1142,9 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         }
         if (h->use_fused) {
             int frc = 0;
-            static const int hs_nw8_cp = [] { const char* e = getenv("ESCX_MLP_HS_NW8_CP"); return e && e[0] ? atoi(e) : 384; }();
-            static const int tm2_max = [] { const char* e = getenv("ESCX_MLP_TM2_MAXCP"); return e && e[0] ? atoi(e) : 0; }();
-            static const int tm2_nw8 = [] { const char* e = getenv("ESCX_MLP_TM2_NW8"); return e && e[0] == '1'; }();
+            static const int hs_nw8_cp = [] { const char* e = ESCX_TUNE_ENV("ESCX_MLP_HS_NW8_CP"); return e && e[0] ? atoi(e) : 384; }();
+            static const int tm2_max = [] { const char* e = ESCX_TUNE_ENV("ESCX_MLP_TM2_MAXCP"); return e && e[0] ? atoi(e) : 0; }();
+            static const int tm2_nw8 = [] { const char* e = ESCX_TUNE_ENV("ESCX_MLP_TM2_NW8"); return e && e[0] == '1'; }();
             bool combined = false;
             int hs = (h->mlp_hs > 0 && L.hiddenP >= h->mlp_hs * L.Cp) ? h->mlp_hs : mlp_hs_for(tokens, L.hiddenP / 16, L.Cp);
             const int variant = h->mlp_variant >= 0 ? h->mlp_variant : (hs > 1 ? ((L.Cp >= hs_nw8_cp && mlp_split_nw(M, hs) == 8) ? 3 : 1) : (L.Cp <= tm2_max ? (tm2_nw8 ? 5 : 4) : mlp_variant_for(M, L.Cp)));
@@ -1199,6 +1241,33 @@ static int run_encoder(escx_handle_s* h, const Shapes& s, hipStream_t st) {     
     return 0;
 }
 
+// De-quantisation tables of the product quantisers (Quant::tab, escx_internal.h): out = dec + up_proj_g(codebook_g[code]) becomes a table-row add.
+// Built by pvq_up_kernel ITSELF on Ksz pseudo-vectors (vector k carries code k in every group; one "clip" of ov * Ksz frames), so a table entry is
+// bit for bit what the up-projection MFMA chain produces for that code (inference only - like the folded de-embedding the tables are derived
+// state: finalisation and every device-side parameter refresh mark them stale, the next inference entry rebuilds them on the caller's stream
+// before the batch parts fork).  ESCX_PVQ_TABLE=0: no tables (up-projection on the MFMA, the round-4 form).
+static int ensure_pvq_tables(escx_handle_s* h, hipStream_t st) {
+    if (!h->pvq_tab_stale) return 0;
+    static const bool on = [] { const char* e = getenv("ESCX_PVQ_TABLE"); return !(e && e[0] == '0'); }();
+    const escx_config& c = h->cfg;
+    const int G = c.group_size, Ksz = c.codebook_size;
+    if (on && !h->iota_codes) {
+        std::vector<long long> iota((size_t)G * Ksz);
+        for (int g = 0; g < G; ++g) for (int k = 0; k < Ksz; ++k) iota[(size_t)g * Ksz + k] = k;
+        ESCX_HIP(hipMalloc((void**)&h->iota_codes, iota.size() * sizeof(long long)));
+        ESCX_HIP(hipMemcpy(h->iota_codes, iota.data(), iota.size() * sizeof(long long), hipMemcpyHostToDevice));
+    }
+    for (Quant& q : h->quants) {
+        if (!on || !q.tab_ok) { if (q.tab) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(q.tab); q.tab = nullptr; } continue; }
+        if (!q.tab) ESCX_HIP(hipMalloc((void**)&q.tab, (size_t)Ksz * q.Kq * sizeof(float)));
+        if (pvq_up(h->iota_codes, (long long)G * Ksz, q.cbraw, G, Ksz, q.dt, 1, q.Hq, c.overlap * Ksz, q.Cp, c.overlap, q.wup, q.Kq, q.Kup, nullptr, q.tab, st) != 0) {
+            ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(q.tab); q.tab = nullptr;      // no up-projection kernel for this width: the engine form stays
+        }
+    }
+    h->pvq_tab_stale = false;
+    return launch_ok("pvq_tables");
+}
+
 static int run_pvq_encode(escx_handle_s* h, const Quant& q, const float* enc, const float* dec, int B, int W, long long* codes,
                           long long bstride, float* loss, hipStream_t st) {
     const escx_config& c = h->cfg;
@@ -1206,7 +1275,7 @@ static int run_pvq_encode(escx_handle_s* h, const Quant& q, const float* enc, co
     const int splits = pvq_down_splits(M, q.Kq, q.Cp);
     if ((size_t)splits * M * q.Nz > h->zpart_cap) ESCX_FAIL(ESCX_ERR_STATE, "split-K scratch too small");
     const double vec = (double)c.overlap * q.Hq * q.C;
-    static const bool special = [] { const char* e = getenv("ESCX_PVQ_DOWN_KERNEL"); return e && e[0] == '1'; }();   // opt-in: bit-identical but slower than the engine form (profiles/r4_pvq_ab.txt)
+    static const bool special = [] { const char* e = ESCX_TUNE_ENV("ESCX_PVQ_DOWN_KERNEL"); return e && e[0] == '1'; }();   // opt-in: bit-identical but slower than the engine form (profiles/r4_pvq_ab.txt)
     int drc = -1;
     if (special)
         PROF("pvq_down_gemm", 2.0 * M * vec * q.d, (double)M * vec * (dec ? 2 : 1) * 4,
@@ -1229,6 +1298,11 @@ static int run_pvq_decode(escx_handle_s* h, const Quant& q, const long long* cod
     const escx_config& c = h->cfg;
     const double vec = (double)c.overlap * q.Hq * q.C, Mv = (double)B * (W / c.overlap);
     static const bool special = [] { const char* e = getenv("ESCX_PVQ_UP_KERNEL"); return !(e && e[0] == '0'); }();     // 0: the GEMM engine's generic form (A/B, fallback)
+    if (q.tab && special) {          // table-row add (Quant::tab): no contraction at run time, bit-identical to the kernels below
+        PROF("pvq_tab_add", 0, Mv * vec * (dec ? 3 : 2) * 4,
+             pvq_tab_add(codes, bstride, q.tab, q.gq, c.group_size, c.codebook_size, B, q.Hq, W, q.Cp, c.overlap, dec, out, st));
+        return launch_ok("pvq_decode");
+    }
     int urc = -1;
     if (special)
         PROF("pvq_up_gemm", 2.0 * Mv * vec * q.d, Mv * vec * (dec ? 2 : 1) * 4,
@@ -1239,6 +1313,30 @@ static int run_pvq_decode(escx_handle_s* h, const Quant& q, const long long* cod
          gemm_pvq_up(codes, bstride, q.cbraw, c.group_size, c.codebook_size, q.dt, B, q.Hq, W, q.Cp, c.overlap, q.wup, q.Kq, q.Kup, dec, out, st));
     }
     return launch_ok("pvq_decode");
+}
+
+// One stream of the cross-scale quantiser: codes = search(down(enc - dec)); when `out` is given also out = dec + up(codebook[codes]) (csrvq.py:15-21).
+// Default: ONE launch (fused_pvq.h).  ESCX_PVQ_FUSED=0, or a geometry the fused kernel is not instantiated for: the three-launch form
+// (split-K down-projection GEMM -> pvq_search -> pvq_up), whose arithmetic the fused kernel reproduces bit for bit (profiles/r5_pvq_ab.txt).
+static int run_pvq_quantize(escx_handle_s* h, const Quant& q, const float* enc, const float* dec, int B, int W, long long* codes, long long bstride,
+                            float* loss, float* out, hipStream_t st) {
+    const escx_config& c = h->cfg;
+    static const bool fused = [] { const char* e = getenv("ESCX_PVQ_FUSED"); return !(e && e[0] == '0'); }();
+    if (fused) {
+        const int Tq = W / c.overlap, M = B * Tq;
+        const double vec = (double)c.overlap * q.Hq * q.C;
+        int frc = -1;
+        PROF(out ? "pvq_fused" : "pvq_fused_codes", 2.0 * M * vec * q.d * (out ? 2 : 1) + 2.0 * M * c.group_size * c.codebook_size * q.d,
+             (double)M * vec * ((dec ? 2 : 1) + (out ? (dec ? 2 : 1) : 0)) * 4,
+             frc = pvq_fused(enc, dec, B, q.Hq, W, q.Cp, c.overlap, q.wdf, q.Nz, q.Kq, pvq_down_splits(M, q.Kq, q.Cp), pvq_down_bk(q.Cp), q.cbn, q.c2, q.cbraw,
+                             c.group_size, c.codebook_size, q.d, q.dt, q.wup, q.tab, q.gq, out, codes, bstride, loss, 1.0f / ((float)Tq * q.d * c.group_size), c.l2norm, st));
+        if (frc == 0) return launch_ok("pvq_quantize");
+        if (h->prof && !h->prof_recs.empty()) h->prof_recs.pop_back();
+    }
+    int rc;
+    if ((rc = run_pvq_encode(h, q, enc, dec, B, W, codes, bstride, loss, st))) return rc;
+    if (out && (rc = run_pvq_decode(h, q, codes, bstride, dec, B, W, out, st))) return rc;
+    return 0;
 }
 
 static int run_deembed(escx_handle_s* h, const float* tok, int B, int W, float* rspec, hipStream_t st) {   // scale.py:73-81
@@ -1292,15 +1390,14 @@ static int run_csvq_encode(escx_handle_s* h, const Shapes& s, int S, long long* 
     const int n = h->n, G = c.group_size;
     const long long bstride = (long long)S * G * s.Tq, sstride = (long long)G * s.Tq;
     int rc, H = s.encH[n - 1], Hn;
-    if ((rc = run_pvq_encode(h, h->quants[0], h->enc_hs[n - 1], nullptr, s.B, s.W, codes, bstride, nullptr, st))) return rc;
-    if (S == 1) return 0;
     float* dec = h->decA; float* other = h->decB;
-    if ((rc = run_pvq_decode(h, h->quants[0], codes, bstride, nullptr, s.B, s.W, dec, st))) return rc;
+    if ((rc = run_pvq_quantize(h, h->quants[0], h->enc_hs[n - 1], nullptr, s.B, s.W, codes, bstride, nullptr, S == 1 ? nullptr : dec, st))) return rc;
+    if (S == 1) return 0;
     for (int i = 0; i < S - 1; ++i) {
         const Quant& q = h->quants[i + 1];
-        if ((rc = run_pvq_encode(h, q, h->enc_hs[n - 1 - i], dec, s.B, s.W, codes + (i + 1) * sstride, bstride, nullptr, st))) return rc;
-        if (i + 2 == S) break;                                               // csrvq.py:151
-        if ((rc = run_pvq_decode(h, q, codes + (i + 1) * sstride, bstride, dec, s.B, s.W, dec, st))) return rc;
+        const bool last = (i + 2 == S);                                      // csrvq.py:151: the last requested stream only emits codes
+        if ((rc = run_pvq_quantize(h, q, h->enc_hs[n - 1 - i], dec, s.B, s.W, codes + (i + 1) * sstride, bstride, nullptr, last ? nullptr : dec, st))) return rc;
+        if (last) break;
         if ((rc = run_layer(h, h->layers[n + i], dec, other, s.B, H, s.W, &Hn, st))) return rc;
         std::swap(dec, other); H = Hn;
     }
@@ -1314,6 +1411,7 @@ extern "C" int escx_encode(escx_handle h, const float* wave, int B, int L, int S
     if (L <= h->n_fft / 2) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_samples=%d too short for reflect padding of %d", L, h->n_fft / 2);
     Shapes s; if ((rc = ensure_ws(h, B, frames_of(h, L), &s))) return rc;
     const long long cstride = (long long)S * h->cfg.group_size * s.Tq;
+    if ((rc = ensure_pvq_tables(h, (hipStream_t)stream))) return rc;
     rc = run_halves(h, B, (hipStream_t)stream, [&](int b0, int nb, hipStream_t st) -> int {
         Shapes sp = s; sp.B = nb; int r;
         if ((r = run_stft(h, wave + (size_t)b0 * L, nb, L, sp.T, h->spec, st))) return r;
@@ -1354,6 +1452,7 @@ extern "C" int escx_decode(escx_handle h, const int64_t* codes, int B, int S, in
     if (s.W != fw || s.encH[h->n - 1] != fh) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "feat_shape (%d,%d) does not match the model (%d,%d)", fh, fw, s.encH[h->n - 1], s.W);
     const int T2 = c.patch_t * fw, out_len = c.hop_length * (T2 - 1);
     const long long cstride = (long long)S * c.group_size * (fw / c.overlap);
+    if ((rc = ensure_pvq_tables(h, (hipStream_t)stream))) return rc;
     rc = run_halves(h, B, (hipStream_t)stream, [&](int b0, int nb, hipStream_t st) -> int {
         int r;
         if ((r = run_csvq_decode(h, (const long long*)codes + b0 * cstride, nb, S, fh, fw, h->rspec, st))) return r;
@@ -1380,6 +1479,7 @@ static int forward_impl(escx_handle h, const float* wave, const float* feat, int
     const int n = h->n, G = c.group_size;
     const long long bstride = (long long)S * G * s.Tq, sstride = (long long)G * s.Tq;
     const int T2 = c.patch_t * s.W, out_len = c.hop_length * (T2 - 1);
+    if ((rc = ensure_pvq_tables(h, (hipStream_t)stream))) return rc;
     return run_halves(h, B, (hipStream_t)stream, [&](int b0, int nb, hipStream_t st) -> int {
         Shapes sp = s; sp.B = nb; int r;
         long long* cd = (long long*)codes + b0 * bstride;
@@ -1394,14 +1494,12 @@ static int forward_impl(escx_handle h, const float* wave, const float* feat, int
         // csrvq.py:97-129 in eval mode: stream 0, then (stream i+1, block i) pairs; untransmitted streams pass through
         int H = sp.encH[n - 1], Hn;
         float* dec = h->decA; float* other = h->decB;
-        if ((r = run_pvq_encode(h, h->quants[0], h->enc_hs[n - 1], nullptr, nb, sp.W, cd, bstride, loss, st))) return r;
-        if ((r = run_pvq_decode(h, h->quants[0], cd, bstride, nullptr, nb, sp.W, dec, st))) return r;
+        if ((r = run_pvq_quantize(h, h->quants[0], h->enc_hs[n - 1], nullptr, nb, sp.W, cd, bstride, loss, dec, st))) return r;
         for (int i = 0; i + 1 < n; ++i) {
             if (i < S - 1) {
                 const Quant& q = h->quants[i + 1];
-                if ((r = run_pvq_encode(h, q, h->enc_hs[n - 1 - i], dec, nb, sp.W, cd + (i + 1) * sstride, bstride, loss ? loss + (size_t)(i + 1) * lslot : nullptr, st))) return r;
+                if ((r = run_pvq_quantize(h, q, h->enc_hs[n - 1 - i], dec, nb, sp.W, cd + (i + 1) * sstride, bstride, loss ? loss + (size_t)(i + 1) * lslot : nullptr, dec, st))) return r;
                 n_slots = i + 2;
-                if ((r = run_pvq_decode(h, q, cd + (i + 1) * sstride, bstride, dec, nb, sp.W, dec, st))) return r;
             }
             if ((r = run_layer(h, h->layers[n + i], dec, other, nb, H, sp.W, &Hn, st))) return r;
             std::swap(dec, other); H = Hn;
@@ -1504,9 +1602,10 @@ extern "C" int escx_pvq_encode(escx_handle h, int sid, const float* enc, const f
     Shapes s; if ((rc = stage_ws_for_w(h, B, W, &s))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)B * q.Hq * W;
+    if ((rc = ensure_pvq_tables(h, st))) return rc;
     pad_rows(enc, h->stageA, rows, q.C, q.Cp, st);
     if (dec) pad_rows(dec, h->stageB, rows, q.C, q.Cp, st);
-    return run_pvq_encode(h, q, h->stageA, dec ? h->stageB : nullptr, B, W, (long long*)codes, bstride, nullptr, st);
+    return run_pvq_quantize(h, q, h->stageA, dec ? h->stageB : nullptr, B, W, (long long*)codes, bstride, nullptr, nullptr, st);
 }
 
 extern "C" int escx_pvq_decode(escx_handle h, int sid, const int64_t* codes, int64_t bstride, const float* dec, int B, int W, float* out,
@@ -1518,6 +1617,7 @@ extern "C" int escx_pvq_decode(escx_handle h, int sid, const int64_t* codes, int
     Shapes s; if ((rc = stage_ws_for_w(h, B, W, &s))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)B * q.Hq * W;
+    if ((rc = ensure_pvq_tables(h, st))) return rc;
     if (dec) pad_rows(dec, h->stageB, rows, q.C, q.Cp, st);
     if ((rc = run_pvq_decode(h, q, (const long long*)codes, bstride, dec ? h->stageB : nullptr, B, W, h->stageA, st))) return rc;
     unpad_rows(h->stageA, out, rows, q.C, q.Cp, st);

@@ -58,6 +58,13 @@ struct Quant {                       // one ProductVectorQuantize (quantization.
     int C, Cp, Hq, d, dt, Nz, Kq, Kup;
     float *wd, *cbn, *c2, *cbraw, *wup;
     float *wdT = nullptr, *wupT = nullptr;       // transposed for dX (training)
+    // fused product-VQ kernel (fused_pvq.h): down-projection in MFMA fragment order ([k chunk][n tile][lane][4]: one coalesced 1 KiB fetch per
+    // fragment), the group of every float4 of the framed vector in memory order (as floats; -1 = padding), and the de-quantisation TABLE
+    //   tab[(h, ov * code + o)][c] = up_proj_g(codebook_g[code]) for the group g that owns element (o, h, c)
+    // built on the device by pvq_up_kernel itself on 1024 pseudo-vectors (bit-identical to the up-projection it replaces; inference only,
+    // rebuilt after a parameter refresh like the folded de-embedding)
+    float *wdf = nullptr, *gq = nullptr, *tab = nullptr;
+    bool tab_ok = false;
 };
 
 struct Shapes {                      // geometry for one (batch, n_samples)
@@ -131,6 +138,8 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     long long* grad_seg = nullptr; int grad_nseg = 0; long long grad_seg_total = 0;     // device table [nseg][2] = (first element, arena offset) for the one-launch scatter
     escx::Arena tape;                            // activations kept between escx_train_forward and escx_train_backward
     void* train_state = nullptr;                 // TrainTape* (train.hip)
+    bool pvq_tab_stale = true;                   // de-quantisation tables (Quant::tab) are out of date: rebuilt on the caller's stream by the next inference entry
+    long long* iota_codes = nullptr;             // [G][Ksz] int64, codes[g][k] = k: the pseudo-vectors the tables are built from
     bool composed_stale = false;                 // weights were refreshed on the device: the fp64-folded de-embedding of the inference path is out of date
     bool deembed_halo = true;        // ESCX_DEEMBED_GEMM=1: implicit-GEMM form of the composed convolution instead (A/B, fallback)
     bool deembed_two_stage = false;  // ESCX_DEEMBED_TWO_STAGE=1: run conv5x5 and conv3x3 separately (A/B, fallback)

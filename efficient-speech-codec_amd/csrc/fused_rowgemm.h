@@ -154,6 +154,7 @@ __global__ __launch_bounds__(64 * NW) void rowgemm_fused_kernel(RowGemmArgs a) {
     }
 }
 
+#ifdef ESCX_EXPERIMENTAL       // tagged builds only (tune_env.h): both forms are faster alone and slower in the two-stream step, profiles/r4_rowgemm_ab.txt
 // ------------------------------------------------------------------------------------------------
 // Round 4 forms.  The streaming kernel above re-streams the whole weight matrix through LDS for every 16*TM*NW rows, issues each stage's
 // DMA as one burst behind the barrier (~190 cycles per 1 KiB piece when a wave issues them back to back, tools/ubench_dma_cost.hip)
@@ -408,5 +409,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void rowgemm_xs_kernel(RowGemmArgs a)
         }
     }
 }
+
+#endif  // ESCX_EXPERIMENTAL
 
 }  // namespace escx

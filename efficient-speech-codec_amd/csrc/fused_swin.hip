@@ -17,9 +17,11 @@ template <int CP, int TM, int NW>
 static void launch_mlp_lds(const MlpArgs& a, hipStream_t s) {
     const int rows = 16 * TM * NW;
     const int hs = a.HS > 1 ? a.HS : 1;
+#ifdef ESCX_EXPERIMENTAL       // in-launch combine of the hidden split: measured slower (profiles/r4_mlp_combine_ab.txt), tagged builds only
     if constexpr (TM == 1 && (CP == 192 || CP == 384) && (NW == 4 || NW == 8)) {      // the widths that take the hidden split
         if (a.tickets) { hipLaunchKernelGGL((mlp_fused_lds_kernel<CP, TM, NW, 0, true>), dim3(((a.M + rows - 1) / rows) * hs), dim3(64 * NW), 0, s, a); return; }
     }
+#endif
     MlpArgs b = a; b.tickets = nullptr;
     hipLaunchKernelGGL((mlp_fused_lds_kernel<CP, TM, NW>), dim3(((a.M + rows - 1) / rows) * hs), dim3(64 * NW), 0, s, b);
 }
@@ -29,22 +31,27 @@ template <int CP>
 static int launch_mlp_lds_variant(int variant, const MlpArgs& a, hipStream_t s) {
     switch (variant) {
         case 1: launch_mlp_lds<CP, 1, 4>(a, s); return 0;
-        case 2: launch_mlp_lds<CP, 1, 6>(a, s); return 0;
         case 3: launch_mlp_lds<CP, 1, 8>(a, s); return 0;
+#ifdef ESCX_EXPERIMENTAL       // 6-wave workgroups and two row tiles per wave: measured no better, tagged builds only
+        case 2: launch_mlp_lds<CP, 1, 6>(a, s); return 0;
         case 4: if constexpr (CP <= 192) { launch_mlp_lds<CP, 2, 4>(a, s); return 0; } return -1;
         case 5: if constexpr (CP <= 192) { launch_mlp_lds<CP, 2, 8>(a, s); return 0; } return -1;
+#endif
         default: return -1;
     }
 }
 
+#ifdef ESCX_EXPERIMENTAL
 template <int CP, int TM, int NW, int ABL>
 static void launch_mlp_abl(const MlpArgs& a, hipStream_t s) {
     const int rows = 16 * TM * NW;
     hipLaunchKernelGGL((mlp_fused_lds_kernel<CP, TM, NW, ABL>), dim3((a.M + rows - 1) / rows), dim3(64 * NW), 0, s, a);
 }
+#endif
 
 static unsigned long long* g_mlp_trace = nullptr;      // debug only (ESCX_MLP_VARIANT=164): 8 x u64 per wave, see fused_mlp.h
 void mlp_set_trace(unsigned long long* p) { g_mlp_trace = p; }
+unsigned long long* debug_trace_buffer() { return g_mlp_trace; }
 
 void rows_combine(float* dst, const float* src, const float* partial, const float* bias, long long M, int Cp, int n, hipStream_t s) {
     const long long n4 = M * Cp / 4;
@@ -63,7 +70,7 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
     // OPT-IN (ESCX_MLP_FUSED_COMBINE=1).  MEASURED (round 4, B = 36, profiles/r4_mlp_combine_ab.txt): bit-identical to the two-launch form, but the
     // last arriver's serial tail (drain of the write-through stores, ticket, acquire, two slab reads from memory) costs more than the combine launches
     // it removes - mlp C = 192 / 384 +0.44 / +0.36 ms per step against 0.30 ms of combine launches, whole step 16.06 -> 16.45 ms.
-    static const bool fuse_combine = [] { const char* e = getenv("ESCX_MLP_FUSED_COMBINE"); return e && e[0] == '1'; }();
+    static const bool fuse_combine = [] { const char* e = ESCX_TUNE_ENV("ESCX_MLP_FUSED_COMBINE"); return e && e[0] == '1'; }();
     const int rows_per_wg = 16 * ((variant == 3) ? 8 : (variant == 2 ? 6 : 4));       // TM = 1 variants only (hs > 1 implies variant 1..3)
     const int n_rb = (M + rows_per_wg - 1) / rows_per_wg;
     const bool in_kernel = hs > 1 && fuse_combine && tickets && n_rb <= n_tickets && (size_t)hs * M * Cp * sizeof(float) < 0xffffffffull && !out &&
@@ -72,6 +79,7 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
     MlpArgs a{x, gamma, beta, reinterpret_cast<const f32x4*>(w1f), b1, reinterpret_cast<const f32x4*>(w2f), b2,
               reinterpret_cast<const f32x4*>(wcf), M, C, hiddenP / 16, 1e-5f, g_mlp_trace, hs, partial, out, in_kernel ? tickets : nullptr};
     if (out && (hs > 1 || variant >= 100)) return -1;       // a separate output: plain epilogues only (no hidden split, no ablation builds)
+#ifdef ESCX_EXPERIMENTAL
     if (variant >= 100) {      // timing-only ablations: variant = 100 + ABL bits
         const int abl = variant - 100;
         if (Cp == 192) {
@@ -96,6 +104,9 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
         if (Cp == 48 && abl == 64) { launch_mlp_abl<48, 1, 8, 64>(a, s); return 0; }
         variant = 1;
     }
+#else
+    if (variant >= 100) variant = 1;      // timing-only ablation kernels exist in tagged builds only
+#endif
     if (variant > 0) {
         switch (Cp) {
             case 48: return launch_mlp_lds_variant<48>(variant, a, s);
@@ -127,6 +138,7 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
 }
 
 // ---- fused LN + linear for PatchMerge / PatchSplit ----
+#ifdef ESCX_EXPERIMENTAL       // weight-stationary / shared-rows forms: faster alone, slower in the two-stream step (profiles/r4_rowgemm_ab.txt)
 // Weight-stationary persistent form (fused_rowgemm.h).  Chunking over output tiles never changes an output element's arithmetic, so it
 // may depend on the batch: the LDS budget bounds a chunk from above, and small grids (few row groups) take more, smaller chunks so that
 // every SIMD gets a wave.
@@ -140,7 +152,7 @@ static void launch_rowgemm_ws(const RowGemmArgs& a, hipStream_t s) {
     constexpr int WPS0 = rowgemm_ws_wps(REGS);
     constexpr int WPS = (WPS0 * 4 < NW) ? (NW / 4) : WPS0;        // one workgroup must fit a CU
     auto kern = rowgemm_ws_kernel<KP, SEGS, TM, NW, WPS, PF>;
-    static const int lds_cap = [] { const char* e = getenv("ESCX_RG_LDS_KB"); return (e && e[0] ? atoi(e) : 144) * 1024; }();
+    static const int lds_cap = [] { const char* e = ESCX_TUNE_ENV("ESCX_RG_LDS_KB"); return (e && e[0] ? atoi(e) : 144) * 1024; }();
     const int tile_bytes = KK * 1024;
     const int max_tiles = std::max(1, lds_cap / tile_bytes);
     const int n_groups = (a.M + 16 * TM - 1) / (16 * TM);
@@ -168,7 +180,7 @@ static bool launch_rowgemm_ws_variant(const RowGemmArgs& a, hipStream_t s) {
     // 0 (default): streaming kernel; 2..5: weight-stationary form with (NW, PF) = (4, no), (4, yes), (8, no), (8, yes).  MEASURED (round 4, B = 36,
     // profiles/r4_rowgemm_ab.txt): alone on the GPU the new forms are 5-25 % faster per launch, but in the product's two-stream execution the step gets
     // 0.1-0.2 ms SLOWER (the co-running MLP / attention launches stretch by more than these kernels shrink), so they stay opt-in.
-    static const int mode = [] { const char* e = getenv("ESCX_ROWGEMM_WS"); return e && e[0] ? atoi(e) : 0; }();
+    static const int mode = [] { const char* e = ESCX_TUNE_ENV("ESCX_ROWGEMM_WS"); return e && e[0] ? atoi(e) : 0; }();
     if (mode == 0) return false;
     constexpr int KK = KP / 16;
     switch (mode) {
@@ -196,7 +208,7 @@ static void launch_rowgemm_xs(const RowGemmArgs& a, hipStream_t s) {
 template <int KP, int SEGS>
 static bool launch_rowgemm_xs_variant(const RowGemmArgs& a, hipStream_t s) {
     if constexpr (KP >= 144) {
-        static const bool on = [] { const char* e = getenv("ESCX_ROWGEMM_XS"); return e && e[0] == '1'; }();      // opt-in, see launch_rowgemm_ws_variant
+        static const bool on = [] { const char* e = ESCX_TUNE_ENV("ESCX_ROWGEMM_XS"); return e && e[0] == '1'; }();      // opt-in, see launch_rowgemm_ws_variant
         if (!on || a.NT * (KP / 16) < 96) return false;         // matrices under ~96 KB stay with the weight-stationary form
         switch ((a.NT + 2) / 3) {
             case 3: launch_rowgemm_xs<KP, SEGS, 3>(a, s); return true;
@@ -209,10 +221,13 @@ static bool launch_rowgemm_xs_variant(const RowGemmArgs& a, hipStream_t s) {
     return false;
 }
 
+#endif
+
 template <int KP, int SEGS>
 static int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
-    constexpr bool HAS_COMB = (KP == 384) || (KP == 192 && SEGS == 1);      // the scale changes that follow a hidden-split MLP (C = 192 / 384)
     if (a.comb_n > 0) {
+#ifdef ESCX_EXPERIMENTAL       // combine on load: measured slower (profiles/r4_mlp_combine_ab.txt)
+        constexpr bool HAS_COMB = (KP == 384) || (KP == 192 && SEGS == 1);      // the scale changes that follow a hidden-split MLP (C = 192 / 384)
         if constexpr (HAS_COMB) {
             constexpr int KK = KP / 16;
             constexpr int UT = KK <= 6 ? 4 : (KK <= 12 ? 2 : 1);
@@ -222,10 +237,13 @@ static int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((rowgemm_fused_kernel<KP, SEGS, TM, NW, UT, true>), dim3((a.M + 16 * TM * NW - 1) / (16 * TM * NW), 1), dim3(64 * NW), 0, s, b);
             return 0;
         }
+#endif
         return ESCX_COMB_UNSUPPORTED;
     }
+#ifdef ESCX_EXPERIMENTAL
     if (launch_rowgemm_xs_variant<KP, SEGS>(a, s)) return 0;
     if (launch_rowgemm_ws_variant<KP, SEGS>(a, s)) return 0;
+#endif
     constexpr int KK = KP / 16;
     constexpr int UT = KK <= 6 ? 4 : (KK <= 12 ? 2 : 1);
     constexpr int TM = KP <= 192 ? 2 : 1;
@@ -234,7 +252,7 @@ static int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
     // Output-column chunks (fused_rowgemm.h), bit-identical for every chunking.  MEASURED (round 3, B = 36): targets of 3072 / 6144 waves make the
     // merge + split kernels 3 % / 8 % SLOWER alone (1.333 -> 1.379 / 1.452 ms per step) and the step 2 - 2.6 % slower: these kernels are not short of
     // waves, the re-done gather + LayerNorm costs more than the extra occupancy returns.  Off by default (ESCX_ROWGEMM_WAVES = target to try it).
-    static const int target = [] { const char* e = getenv("ESCX_ROWGEMM_WAVES"); return e ? atoi(e) : 0; }();
+    static const int target = [] { const char* e = ESCX_TUNE_ENV("ESCX_ROWGEMM_WAVES"); return e ? atoi(e) : 0; }();
     RowGemmArgs b = a;
     const int waves = (a.M + 16 * TM - 1) / (16 * TM);
     int chunks = target > 0 ? (target + waves - 1) / waves : 1;
@@ -306,9 +324,11 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
         return ESCX_COMB_UNSUPPORTED;
     }
     if (a.comb_n > 0) {
+#ifdef ESCX_EXPERIMENTAL
         if constexpr (CP == 192 && MODE == 1) {        // the C = 192 blocks that follow a hidden-split MLP (ESC-Base / Large: 24 heads of 8)
             if (gs == 1) { hipLaunchKernelGGL((attn_fused_kernel<CP, MODE, UT, TMW, NW, true>), dim3((a.n_windows + per_block - 1) / per_block), dim3(64 * NW), 0, s, a); return 0; }
         }
+#endif
         return ESCX_COMB_UNSUPPORTED;
     }
     hipLaunchKernelGGL((attn_fused_kernel<CP, MODE, UT, TMW, NW>), dim3(((a.n_windows + per_block - 1) / per_block) * gs), dim3(64 * NW), 0, s, a);
@@ -339,9 +359,11 @@ static int launch_attn_packed(const AttnArgs& a, hipStream_t s) {
     const int pairs = (a.n_windows + 1) / 2;
     const int gs = a.GS > 1 ? a.GS : 1;
     if (a.comb_n > 0) {
+#ifdef ESCX_EXPERIMENTAL
         if constexpr (CP == 384 && NW == 4) {
             if (gs == 1) { hipLaunchKernelGGL((attn_packed_kernel<CP, UT, NW, true>), dim3((pairs + NW - 1) / NW), dim3(64 * NW), 0, s, a); return 0; }
         }
+#endif
         return ESCX_COMB_UNSUPPORTED;
     }
     hipLaunchKernelGGL((attn_packed_kernel<CP, UT, NW>), dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), 0, s, a);

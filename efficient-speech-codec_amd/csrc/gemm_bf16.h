@@ -125,8 +125,8 @@ static __global__ void cvt_bf16_kernel(const float* __restrict__ src, __bf16* __
 
 template <class Loader, class Epi>
 inline void launch_gemm_bf16(const Loader& ld, const float* Wt, const __bf16* Wt16, int M, int Np, int Kp, const Epi& ep, hipStream_t s) {
-    static const int env_bm = [] { const char* e = getenv("ESCX_BF16_BM"); return e ? atoi(e) : 0; }();       // tuning aid: 128 / 256 rows per workgroup
-    static const int env_ks = [] { const char* e = getenv("ESCX_BF16_KS"); return e ? atoi(e) : 1; }();        // tuning aid: 2 = 64-deep staged tiles
+    static const int env_bm = [] { const char* e = ESCX_TUNE_ENV("ESCX_BF16_BM"); return e ? atoi(e) : 0; }();       // tuning aid: 128 / 256 rows per workgroup
+    static const int env_ks = [] { const char* e = ESCX_TUNE_ENV("ESCX_BF16_KS"); return e ? atoi(e) : 1; }();        // tuning aid: 2 = 64-deep staged tiles
     const int nbn = Np / 128;
     // 128 rows: 156 registers, three workgroups per CU; 256 rows: 272 registers, ONE wave per SIMD - measured on the 1024 -> 1024 period layer: 409 against
     // 271 TFLOP/s forward, 384 against 252 dX (the K step is one memory round trip deep, so the bytes in flight per CU decide)

@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "tune_env.h"
+
 // tuning builds (-DESCX_SMALL_PRIO=n): static wave priority of the short, latency-bound launches (GEMM engine, merge / split, PVQ search, combine,
 // de-embedding) against the MFMA-dense fused MLP / attention launches of the other batch part they share the GPU with
 #ifdef ESCX_SMALL_PRIO
@@ -480,7 +482,7 @@ struct EpiPartial {             // split-K partial sums, reduced in a fixed orde
 // Host-side tile selection and launch.
 // ------------------------------------------------------------------------------------------------
 inline int pick_bk(int Kp) {
-    static const int env_bk = [] { const char* e = getenv("ESCX_BK"); return e ? atoi(e) : 0; }();          // tuning aid (results are identical for every step size)
+    static const int env_bk = [] { const char* e = ESCX_TUNE_ENV("ESCX_BK"); return e ? atoi(e) : 0; }();          // tuning aid (results are identical for every step size)
     if (env_bk > 0 && Kp % env_bk == 0) return env_bk;
     return Kp % 48 == 0 ? 48 : (Kp % 80 == 0 ? 80 : (Kp % 32 == 0 ? 32 : 16));
 }     // 80: the C = 72 maps (a 16-wide step there means 5x the K steps)

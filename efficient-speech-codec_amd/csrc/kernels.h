@@ -300,6 +300,7 @@ __global__ __launch_bounds__(256) void pvq_search_kernel(SearchArgs a) {
 // and the NT weight fragments come straight from global memory one chunk ahead.  Same contraction order as the engine (chunks ascending, MFMA r = 0..3,
 // one chain per output tile), same slice boundaries (k_per_z from pvq_down_splits): bit-identical partial sums.
 // ------------------------------------------------------------------------------------------------
+#ifdef ESCX_EXPERIMENTAL
 struct PvqDownArgs { const float* enc; const float* dec; const float* W; float* zpart; int M, Tq, Hq, Wd, Cp, ov, Kp, Np, k_per_z; };
 
 template <int NT>
@@ -342,6 +343,8 @@ __global__ __launch_bounds__(256) void pvq_down_kernel(PvqDownArgs a) {
         for (int n = 0; n < NT; ++n) st4(zr + 16 * n, acc[n]);
     }
 }
+
+#endif  // ESCX_EXPERIMENTAL
 
 // ------------------------------------------------------------------------------------------------
 // PVQ de-quantisation + up-projection + un-frame + residual add (quantization.py:93-108, 124-136, 412-432; csrvq.py:19-21), round 4:

@@ -1,5 +1,7 @@
 // Launchers for the non-GEMM kernels.
 #include "kernels.h"
+#include "fused_pvq.h"
+#include <atomic>
 #include "launchers.h"
 
 namespace escx {
@@ -59,6 +61,7 @@ void loss_reduce(const float* terms, int n_slots, int G, int M, int Tq, float* o
 
 int pvq_down(const float* enc, const float* dec, int B, int Hq, int Wd, int Cp, int ov, const float* W, int Np, int Kp, float* zpart, int splits,
              int bk, hipStream_t s) {
+#ifdef ESCX_EXPERIMENTAL       // bit-identical to the engine form but 30 % slower alone (profiles/r4_pvq_ab.txt): tagged builds only
     const int Tq = Wd / ov, M = B * Tq;
     if (Np % 16 || Kp % 16 || Cp % 16 || bk % 16 || Kp % bk) return -1;
     const int kIters = Kp / bk, per = (kIters + splits - 1) / splits;      // gemm_engine.h launch_tile: the SAME slice boundaries as the engine's split-K
@@ -73,6 +76,61 @@ int pvq_down(const float* enc, const float* dec, int B, int Hq, int Wd, int Cp, 
         case 6: hipLaunchKernelGGL(pvq_down_kernel<6>, grid, dim3(256), 0, s, a); return 0;
         default: return -1;
     }
+#else
+    return -1;
+#endif
+}
+
+// One product-VQ stream in one launch (fused_pvq.h).  -1: geometry not covered, the caller runs the three-launch form.
+template <int NT, int STEPS, bool DEC>
+static void launch_pvq_fused_d(const PvqFusedArgs& a, hipStream_t s) {
+    auto kern = pvq_fused_kernel<NT, STEPS, DEC>;
+    constexpr int lds = pvqf_lds_floats<NT>() * (int)sizeof(float);
+    if constexpr (lds > 48 * 1024) {            // function attributes are per device: one flag per device, set before the first launch there
+        static std::atomic<unsigned> done{0};
+        int dev = 0; (void)hipGetDevice(&dev);
+        const unsigned bit = 1u << (dev & 31);
+        if (!(done.load(std::memory_order_relaxed) & bit)) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            done.fetch_or(bit, std::memory_order_relaxed);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((a.M + 15) / 16), dim3(64 * PVQF_WAVES), lds, s, a);
+}
+template <int NT, int STEPS>
+static void launch_pvq_fused(const PvqFusedArgs& a, hipStream_t s) {
+    if (a.dec) launch_pvq_fused_d<NT, STEPS, true>(a, s); else launch_pvq_fused_d<NT, STEPS, false>(a, s);
+}
+
+void pvq_tab_add(const long long* codes, long long bstride, const float* tab, const float* gq, int G, int Ksz, int B, int Hq, int Wd, int Cp, int ov,
+                 const float* dec, float* out, hipStream_t s) {
+    PvqTabAddArgs a{codes, bstride, tab, gq, dec, out, G, Ksz, Wd / ov, Hq, Wd, Cp, ov, (long long)B * Hq * Wd * (Cp / 4)};
+    hipLaunchKernelGGL(pvq_tab_add_kernel, dim3((unsigned)((a.n4 + 255) / 256)), dim3(256), 0, s, a);
+}
+
+int pvq_fused(const float* enc, const float* dec, int B, int Hq, int Wd, int Cp, int ov, const float* wd, int Np, int Kq, int splits, int bk,
+              const float* cbn, const float* c2, const float* cbraw, int G, int Ksz, int d, int dt, const float* wup, const float* tab, const float* gq,
+              float* out, long long* codes, long long bstride, float* loss, float loss_scale, int l2norm, hipStream_t s) {
+    const int Tq = Wd / ov, M = B * Tq;
+    if (Np % 16 || Kq % 16 || Cp % 16 || bk % 16 || Kq % bk || dt % 4 || G < 1 || G > PVQF_GMAX || G * dt > Np || splits < 1 || splits > PVQF_WAVES || Ksz < 1) return -1;
+    const int kIters = Kq / bk, per = (kIters + splits - 1) / splits;      // gemm_engine.h launch_tile: the slice boundaries of the engine's split-K
+    if ((kIters + per - 1) / per != splits) return -1;
+    PvqFusedArgs a{enc, dec, wd, cbn, c2, cbraw, wup, tab, gq, out, codes, bstride, loss, loss_scale, M, Tq, Hq, Wd, Cp, ov, Kq, per * bk, splits, G, Ksz, d, l2norm, nullptr};
+#ifdef ESCX_PVQ_TRACE
+    {   // slot n of the buffer for the n-th fused launch since the buffer was (re)set: 4096 workgroups x 8 stamps per slot
+        static unsigned long long* last = nullptr; static int n = 0;
+        unsigned long long* p = debug_trace_buffer();
+        if (p != last) { last = p; n = 0; }
+        a.trace = p ? p + (size_t)(n++ % 16) * 4096 * 8 : nullptr;
+    }
+#endif
+    const int NT = Np / 16, STEPS = dt / 4;
+    if (NT == 6 && STEPS == 8) { launch_pvq_fused<6, 8>(a, s); return 0; }
+    if (NT == 3 && STEPS == 4) { launch_pvq_fused<3, 4>(a, s); return 0; }
+    if (NT == 3 && STEPS == 3) { launch_pvq_fused<3, 3>(a, s); return 0; }
+    if (NT == 2 && STEPS == 2) { launch_pvq_fused<2, 2>(a, s); return 0; }
+    if (NT == 1 && STEPS == 1) { launch_pvq_fused<1, 1>(a, s); return 0; }
+    return -1;
 }
 
 int pvq_up(const long long* codes, long long bstride, const float* cbraw, int G, int Ksz, int dt, int B, int Hq, int Wd, int Cp, int ov,

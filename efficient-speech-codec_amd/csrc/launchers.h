@@ -1,6 +1,7 @@
 // Host-callable launchers (one per kernel group); implemented in gemm_swin.hip / gemm_misc.hip / kernels_misc.hip.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "tune_env.h"
 
 namespace escx {
 
@@ -30,6 +31,7 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
               const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, int* hs_io, float* partial, hipStream_t s,
               float* out = nullptr,       // out != nullptr: x untouched, x + mlp(x) goes to out (not with a hidden split)
               int* tickets = nullptr, int n_tickets = 0, bool* combined = nullptr);    // hidden split: arrival counters (zeroed) -> *combined = the launch did the combine itself
+unsigned long long* debug_trace_buffer();      // device buffer set by escx_debug_mlp_trace (tuning builds: in-kernel phase stamps), or nullptr
 void rows_combine(float* dst, const float* src, const float* partial, const float* bias, long long M, int Cp, int n, hipStream_t s);
 
 // LN + linear for PatchMerge (segs = 2, map gives the two source rows) / PatchSplit (segs = 1, split = 1: pixel-shuffled store)
@@ -80,6 +82,15 @@ void ln_rows(int mode, const float* src, float* dst, const float* gamma, const f
              int src_rows_per_clip, int total_rows, int C, int Cp, hipStream_t s);
 int window_attention(const float* qkv, const float* bias, float* out, int total_windows, int nH, int hdp, int ldq, int ldo, int nWh,
                      int nWw, int shifted, hipStream_t s);
+// One product-VQ stream in ONE launch (fused_pvq.h): frame + residual + down-projection (split-K slices = waves, added in slice order in LDS) + normalise +
+// codebook search + de-quantise + up-projection + un-frame + add.  out == nullptr: codes only; out may alias dec.  -1: geometry not covered.
+// wdf: down-projection in fragment order; tab / gq: de-quantisation table and float4 -> group map (escx_internal.h Quant), tab == nullptr: up-projection on the MFMA
+int pvq_fused(const float* enc, const float* dec, int B, int Hq, int Wd, int Cp, int ov, const float* wdf, int Np, int Kq, int splits, int bk,
+              const float* cbn, const float* c2, const float* cbraw, int G, int Ksz, int d, int dt, const float* wup, const float* tab, const float* gq,
+              float* out, long long* codes, long long bstride, float* loss, float loss_scale, int l2norm, hipStream_t s);
+// out = dec + tab[(h, ov * code_g + o)][c] (g = group of element (o, h, c)): the de-quantise + up-projection + un-frame + add of one stream as a table-row add
+void pvq_tab_add(const long long* codes, long long bstride, const float* tab, const float* gq, int G, int Ksz, int B, int Hq, int Wd, int Cp, int ov,
+                 const float* dec, float* out, hipStream_t s);
 // specialised PVQ framing + residual + down-projection (split-K partial sums, kernels.h); -1: geometry not covered, the caller falls back to gemm_pvq_down
 int pvq_down(const float* enc, const float* dec, int B, int Hq, int Wd, int Cp, int ov, const float* W, int Np, int Kp, float* zpart, int splits,
              int bk, hipStream_t s);

@@ -101,7 +101,7 @@ void gemm_any(const Ld& ld, const float* W, int M, int Np, int Kp, const Epi& ep
     // 128-row tiles halve the weight traffic per output row; 64 when the grid would not fill the chip (same rule as gemm_swin.hip)
     const long long tiles128 = (long long)((M + 127) / 128) * ((Np + 95) / 96);
     // K steps of 16 keep the workgroup's LDS image small (more resident workgroups): 98.0 -> 96.1 ms/step over the engine's default steps
-    static const int env_bk = [] { const char* e = getenv("ESCX_TRAIN_BK"); return e ? atoi(e) : 16; }();
+    static const int env_bk = [] { const char* e = ESCX_TUNE_ENV("ESCX_TRAIN_BK"); return e ? atoi(e) : 16; }();
     if (!force_bk && env_bk > 0 && Kp % env_bk == 0) force_bk = env_bk;
     if (tiles128 >= 512) launch_gemm<128>(ld, W, M, Np, Kp, ep, st, 1, force_bk);
     else launch_gemm<64>(ld, W, M, Np, Kp, ep, st, 1, force_bk);
@@ -128,7 +128,7 @@ int dw_launch(escx_handle_s* h, const LdA& la, const LdB& lb, int M, int Np, int
     // back) is paid per slice, so the narrow matrices - few output tiles, i.e. many slices each - want FEWER, longer slices even if that leaves slots empty
     // (measured, B = 36, ESCX_DW_TARGET sweep in profiles/r3_dw_target_sweep.txt: dw_proj[C=45] (1 tile) 0.631 / 0.535 / 0.444 ms at 2048 / 1024 / 512,
     // dw_qkv[C=45] (3 tiles) 1.218 / 1.137 / 1.026; from 10 tiles up 2048 wins: dw_fc1[C=72] 1.275 / 1.270 / 1.793).  ESCX_DW_TARGET overrides (tuning aid).
-    static const int env_target = [] { const char* e = getenv("ESCX_DW_TARGET"); return e ? atoi(e) : 0; }();
+    static const int env_target = [] { const char* e = ESCX_TUNE_ENV("ESCX_DW_TARGET"); return e ? atoi(e) : 0; }();
     const int target = env_target > 0 ? env_target : (blocks <= 3 ? 512 : (blocks <= 4 ? 1024 : 2048));
     int slices = std::max(1, std::min((target + blocks - 1) / blocks, (M + 127) / 128));
     const size_t per = (size_t)Np * Kp + Np;
@@ -149,7 +149,7 @@ template <int TA, int TB, int WN = 2, int WK = 2, class LdA, class LdB>
 int dw_launch_wide(escx_handle_s* h, const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
     constexpr int WA = 16 * TA * WN, WB = 16 * TB * WK;
     const int nbn = (Np + WA - 1) / WA, nbk = (Kp + WB - 1) / WB, blocks = nbn * nbk;
-    static const int env_target = [] { const char* e = getenv("ESCX_DW_WIDE_TARGET"); return e ? atoi(e) : 0; }();
+    static const int env_target = [] { const char* e = ESCX_TUNE_ENV("ESCX_DW_WIDE_TARGET"); return e ? atoi(e) : 0; }();
     // ONE round of resident workgroups (2 per CU at 65-74 KB of LDS each): a partly filled extra round costs a whole slice time, and every further slice
     // another partial tile (up to 64 KB) written and read back (ESCX_DW_WIDE_TARGET sweep, 36 clips: 512 -> 79.6 ms/step, 768 -> 80.9, 2560 -> 80.4)
     constexpr int LDS_BYTES = 2 * 32 * ((WA % 32 == 0 ? WA + 16 : WA) + (WB % 32 == 0 ? WB + 16 : WB)) * 4;
@@ -170,12 +170,12 @@ int dw_launch_wide(escx_handle_s* h, const LdA& la, const LdB& lb, int M, int Np
 // plain row-major operands (the linear layers): the workgroup tile (128 / 96 / 64 per side) with the least padding, wide tiles preferred;
 // the 48 x 48 kernel where none fits within 15 % (C = 45, 72, 144: multiples of 48) or the matrix is small
 int dw_rows(escx_handle_s* h, const float* A, int lda, const float* Bm, int ldb, int M, int Np, int Kp, float* dW, float* db, float* part, hipStream_t st) {
-    static const bool wide_ok = [] { const char* e = getenv("ESCX_DW_WIDE"); return !(e && e[0] == '0'); }();
-    static const double pad_limit = [] { const char* e = getenv("ESCX_DW_WIDE_PAD"); return e ? atof(e) : 1.15; }();      // tile padding a wide tile may add
+    static const bool wide_ok = [] { const char* e = ESCX_TUNE_ENV("ESCX_DW_WIDE"); return !(e && e[0] == '0'); }();
+    static const double pad_limit = [] { const char* e = ESCX_TUNE_ENV("ESCX_DW_WIDE_PAD"); return e ? atof(e) : 1.15; }();      // tile padding a wide tile may add
     const PlainA la{A, lda, M}, lb{Bm, ldb, M};
     // the 144- and 80-wide maps (C = 144, 72) fit none of the 32-multiple tiles: one side of the workgroup tile IS the map width (9 or 5 accumulator tiles per
     // wave, all four waves along the other side).  ESCX_DW_ODD=0: the 48 x 48 kernel as before.
-    static const bool odd_ok = [] { const char* e = getenv("ESCX_DW_ODD"); return !(e && e[0] == '0'); }();
+    static const bool odd_ok = [] { const char* e = ESCX_TUNE_ENV("ESCX_DW_ODD"); return !(e && e[0] == '0'); }();
     if (wide_ok && odd_ok) {
         if (Kp == 144 && Np >= 256) return dw_launch_wide<2, 9, 4, 1>(h, la, lb, M, Np, Kp, dW, db, part, st);         // 128 x 144
         if (Np == 144 && Kp >= 256) return dw_launch_wide<9, 2, 1, 4>(h, la, lb, M, Np, Kp, dW, db, part, st);         // 144 x 128
@@ -211,7 +211,7 @@ int ln_bwd(int mode, const float* x, const float* dy, const float* gamma, const 
            int rows_per_clip, int src_rows_per_clip, int dy_rows_per_clip, int total_rows, int C, int Cp, float* part, hipStream_t st,
            float* dx_slots = nullptr, const int* slot_of = nullptr, int slots_per_clip = 0) {
     const int segs = mode == 2 ? 2 : 1;
-    static const int grid_cap = [] { const char* e = getenv("ESCX_LN_BWD_GRID"); const int v = e ? atoi(e) : 512; return std::max(1, std::min(v, LN_BWD_MAX_GRID)); }();
+    static const int grid_cap = [] { const char* e = ESCX_TUNE_ENV("ESCX_LN_BWD_GRID"); const int v = e ? atoi(e) : 512; return std::max(1, std::min(v, LN_BWD_MAX_GRID)); }();
     const int grid = (int)std::min<long long>(grid_cap, ((long long)total_rows + 15) / 16);
     const size_t shm = (size_t)16 * 2 * segs * Cp * sizeof(float);
     const int RW = segs * Cp;
@@ -230,17 +230,17 @@ constexpr size_t LN_PART_FLOATS = (size_t)(LN_BWD_MAX_GRID + 1) * 2 * 2 * 384;
 // `part` needs ceil(M / 64) * 4 * 2 * Cp floats (+ 2 * Cp for the reduced row): the dW partial-sum scratch is used.
 // Round 4: also for the wide maps (Cp = 144 / 192 / 384) - one workgroup tile spans the row there too (BN = Cp), with the register-lean form of the epilogue.
 bool ln_rows_fusable(int Cp) {
-    static const bool wide = [] { const char* e = getenv("ESCX_LN_FUSED_WIDE"); return e && e[0] == '1'; }();          // opt-in: measured slower than the stand-alone LayerNorm backward above Cp = 96
+    static const bool wide = [] { const char* e = ESCX_TUNE_ENV("ESCX_LN_FUSED_WIDE"); return e && e[0] == '1'; }();          // opt-in: measured slower than the stand-alone LayerNorm backward above Cp = 96
     return Cp <= 96 || (wide && (Cp == 144 || Cp == 192 || Cp == 384));
 }
 void gemm_ln_bwd_rows(const float* A, int lda, int M, const float* Wt, int Cp, int Kp, const float* x, const float* gamma, const float* add, float* dx,
                       float* dx_slots, const int* slot_of, int rows_per_clip, int slots_per_clip, int C, float* dg, float* dbt, float* part, hipStream_t st,
                       const int* row_map = nullptr) {
     EpiLnBwdRows ep{x, gamma, add, dx, dx_slots, slot_of, part, C, Cp, rows_per_clip, slots_per_clip, 1e-5f, row_map};
-    static const int wide_bm = [] { const char* e = getenv("ESCX_LNBWD_WIDE_BM"); return e ? atoi(e) : 0; }();       // tuning aid: 64 / 128 rows per workgroup for the 144 / 192-wide tiles
+    static const int wide_bm = [] { const char* e = ESCX_TUNE_ENV("ESCX_LNBWD_WIDE_BM"); return e ? atoi(e) : 0; }();       // tuning aid: 64 / 128 rows per workgroup for the 144 / 192-wide tiles
     const bool big = Cp > 96 ? (Cp != 384 && (wide_bm ? wide_bm == 128 : (long long)((M + 127) / 128) >= 512)) : (long long)((M + 127) / 128) >= 512;
     const int rows = (big ? (M + 127) / 128 : (M + 63) / 64) * 4;
-    static const int env_bk = [] { const char* e = getenv("ESCX_LNBWD_BK"); return e ? atoi(e) : 16; }();
+    static const int env_bk = [] { const char* e = ESCX_TUNE_ENV("ESCX_LNBWD_BK"); return e ? atoi(e) : 16; }();
     const int bk = (env_bk > 0 && Kp % env_bk == 0) ? env_bk : 16;
     const PlainA la{A, lda, M};
     if (Cp == 144) { if (big) launch_tile<128, 144, 16>(la, Wt, M, Cp, Kp, 1, ep, st); else launch_tile<64, 144, 16>(la, Wt, M, Cp, Kp, 1, ep, st); }
@@ -259,8 +259,8 @@ int attn_bwd(const float* qkv, const float* bias, const float* dout, float* dqkv
     // fetched once).  Grid: ONE workgroup per CU in total - measured at 36 clips (profiles/r3_attn_bwd_grid_sweep.txt): the kernel moves 1.06 GB per launch
     // at C = 45 and runs at 5.0 TB/s with 256 workgroups, 4.1 TB/s with 384 and 3.0 TB/s with the chip full (1 536, one head per wave): more concurrent row
     // streams only cost DRAM efficiency, there is no latency left to hide.  ESCX_ATTN_BWD_GX = n: n window chunks; ESCX_ATTN_BWD_HPW=1: one head per wave.
-    static const int gx_env = [] { const char* e = getenv("ESCX_ATTN_BWD_GX"); return e ? atoi(e) : 0; }();
-    static const int hpw_env = [] { const char* e = getenv("ESCX_ATTN_BWD_HPW"); return e ? atoi(e) : 3; }();
+    static const int gx_env = [] { const char* e = ESCX_TUNE_ENV("ESCX_ATTN_BWD_GX"); return e ? atoi(e) : 0; }();
+    static const int hpw_env = [] { const char* e = ESCX_TUNE_ENV("ESCX_ATTN_BWD_HPW"); return e ? atoi(e) : 3; }();
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -315,7 +315,7 @@ int mlp_bwd_fused(escx_handle_s* h, const Layer& L, const BlockW& bw, const floa
     const size_t per = 2 * (size_t)n1 + L.hiddenP + L.Cp;
     if ((size_t)grid * per + n1 > DW_PART_FLOATS) ESCX_FAIL(ESCX_ERR_STATE, "dW scratch too small for the fused MLP backward");
     MlpBwdArgs a{x1, dy, dx1, dx1s, slot_of, bw.ln2_g, bw.ln2_b, bw.w1, bw.b1, bw.w2T, bw.w1T, part, slabs, M, L.C, L.hiddenP, tokens, slots, 1e-5f, 0};
-    { static const int dbg = [] { const char* e = getenv("ESCX_MLPBWD_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
+    { static const int dbg = [] { const char* e = ESCX_TUNE_ENV("ESCX_MLPBWD_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     if (split) hipLaunchKernelGGL((mlp_bwd_fused_kernel<80, 9, 2>), dim3(grid, 2), dim3(64 * 12), 0, st, a);
     else hipLaunchKernelGGL((mlp_bwd_fused_kernel<48, 12, 1>), dim3(grid), dim3(64 * 15), 0, st, a);
     float* Etot = part + (size_t)grid * per;
@@ -412,7 +412,7 @@ int layer_fwd(escx_handle_s* h, const Layer& L, LayerTape& LT, const float* x_in
         // (fused_attn.h, TAPE): 1.73 GB -> 0.93 GB of HBM traffic per C = 45 block at 36 clips.  ESCX_TRAIN_ATTN_FUSED=0: the four launches.
         static const bool attn_fused_ok = [] { const char* e = getenv("ESCX_TRAIN_ATTN_FUSED"); return !(e && e[0] == '0'); }();
         int afrc = -1;
-        static const int attn_fused_max = [] { const char* e = getenv("ESCX_TRAIN_ATTN_FUSED_MAXCP"); return e && e[0] ? atoi(e) : 96; }();
+        static const int attn_fused_max = [] { const char* e = ESCX_TUNE_ENV("ESCX_TRAIN_ATTN_FUSED_MAXCP"); return e && e[0] ? atoi(e) : 96; }();
         if (attn_fused_ok && L.attn_mode >= 0 && L.Cp <= attn_fused_max) {
             const AttnTape tape{bt.xn1, bt.qkv, bt.obuf, L.Nqkv, L.Ko, L.hdp, L.nH};
             const int tmw = attn_windows_per_wave(L.Cp);
