@@ -1148,6 +1148,18 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             bool combined = false;
             int hs = (h->mlp_hs > 0 && L.hiddenP >= h->mlp_hs * L.Cp) ? h->mlp_hs : mlp_hs_for(tokens, L.hiddenP / 16, L.Cp);
             const int variant = h->mlp_variant >= 0 ? h->mlp_variant : (hs > 1 ? ((L.Cp >= hs_nw8_cp && mlp_split_nw(M, hs) == 8) ? 3 : 1) : (L.Cp <= tm2_max ? (tm2_nw8 ? 5 : 4) : mlp_variant_for(M, L.Cp)));
+            // PatchSplit in the epilogue of the layer's last MLP (fused_mlp.h SPLIT): one launch and one HBM round trip of the
+            // pre-split map less.  ESCX_MLP_SPLIT_FOLD=0: the separate LN + linear launch (rowgemm_fused_kernel), as before.
+            static const bool split_fold = [] { const char* e = getenv("ESCX_MLP_SPLIT_FOLD"); return !(e && e[0] == '0'); }();
+            if (split_fold && L.scale == 2 && j + 1 == L.blocks.size() && hs == 1 && pend.n == 0) {
+                const MlpSplit sp{L.sub_wf, L.sub_g, L.sub_b, y, 2 * L.CoutP / 16, H, W, L.CoutP};
+                int sfrc = -1;
+                PROF("mlp_split_fused" + tag, 4 * dM * dC * L.hidden + 2.0 * dM * dC * 2 * L.Cout, (dM * dC + dM * 2 * L.Cout) * f4,
+                     sfrc = mlp_fused(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP, variant, &hs, h->hid, st, nullptr,
+                                     nullptr, 0, nullptr, &sp));
+                if (sfrc == 0) { *Hout = 2 * H; return launch_ok(L.prefix.c_str()); }
+                if (h->prof && !h->prof_recs.empty()) h->prof_recs.pop_back();      // no SPLIT instantiation for this width: nothing was launched
+            }
             PROF("mlp_fused" + tag, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
                  frc = mlp_fused(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP, variant, &hs, h->hid, st, nullptr,
                                  h->tickets, WsFields::N_TICKETS, &combined));

@@ -39,6 +39,13 @@ struct MlpArgs {
     // publishes its slab write-through and takes a ticket; the LAST arriver adds the slabs in slab-index order - ((P0 + P1) + P2) + bias, then
     // + x, the arithmetic of rows_combine_kernel - and writes x.  nullptr: slabs only, the caller runs rows_combine_kernel.
     int* tickets;
+    // PatchSplit in the epilogue (SPLIT instantiations, round 5; scale.py:131-145): the wave still owns its 16 rows x + mlp(x) in registers after the
+    // residual add, and nothing else reads the pre-split map (csrvq.py:173-181), so LayerNorm(C) -> Linear(C -> 2 C', no bias) -> two-row scatter
+    // runs right there: the split weights (fragment order, Layer::sub_wf) stream through the same LDS ring as further stages, two output tiles per
+    // stage.  The arithmetic is rowgemm_fused_kernel's (statistics in lane order then over the 4 k-slot groups, one k-ordered chain per output).
+    // x is NOT written.  sp_wf == nullptr: plain epilogue.
+    const f32x4* sp_wf; const float* sp_gamma; const float* sp_beta; float* sp_out;
+    int sp_NT, sp_H, sp_W, sp_C2p;
 };
 
 // buffer descriptor over [p, p + bytes): raw (stride 0) addressing; for write-through (sc1) stores of hand-off data
@@ -167,8 +174,9 @@ template <int CP, int TM> constexpr int mlp_min_waves() { return (CP * TM <= ESC
 // FC: compile the in-launch combine of the hidden split (a.tickets).  A SEPARATE instantiation on purpose: with that code in the body, hipcc
 // allocates registers differently for the whole kernel and the plain (slabs + rows_combine_kernel) path of every hidden-split width gets
 // 10-12 % slower (measured, profiles/r4_mlp_combine_ab.txt).
-template <int CP, int TM, int NW, int ABL = 0, bool FC = false>      // ABL: timing-only ablation bits (never used by the product path)
+template <int CP, int TM, int NW, int ABL = 0, bool FC = false, bool SPLIT = false>      // ABL: timing-only ablation bits (never used by the product path)
 __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_lds_kernel(MlpArgs a) {
+    static_assert(!SPLIT || (TM == 1 && ABL == 0 && !FC), "the PatchSplit epilogue exists for the plain one-tile form only");
 #ifdef ESCX_MLP_PRIO
     __builtin_amdgcn_s_setprio(ESCX_MLP_PRIO);      // tuning builds: static wave priority against co-running launches of the other batch part
 #endif
@@ -255,7 +263,8 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
         constexpr bool SPREAD = (ABL & 256) == 0;
         if (!SPREAD && ht + 1 < ht1 && !(ABL & 32)) issue(ht + 1, (ht + 1) & 1);
         // SPREAD: the last stage re-loads its own tile into the idle buffer (harmless) so that the loop body stays branch-free
-        const f32x4* dsrc = a.wcf + (size_t)min(ht + 1, ht1 - 1) * CH * 64 + lane;
+        const f32x4* dsrc = (SPLIT && ht + 1 == ht1) ? a.sp_wf + lane                         // SPLIT: the stage after the last hidden tile is the first pair of split tiles
+                                                     : a.wcf + (size_t)min(ht + 1, ht1 - 1) * CH * 64 + lane;
         f32x4* ddst = &wbuf[(ht + 1) & 1][0];
         ESCX_TS(t2)
         // The no-op pin makes the compiler wait for this tile's bias HERE, behind the vmcnt(0) above (free), instead of at its first
@@ -407,6 +416,70 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
             float* orow = a.x + (size_t)row * CP + 4 * lg;
 #pragma unroll
             for (int o = 0; o < KK; ++o) { v[o] += ld4(a.b2 + 16 * o + 4 * lg); st4(orow + 16 * o, res[o] + v[o]); }
+        }
+        return;
+    }
+    if constexpr (SPLIT) {
+        // ---- y = x + (mlp + b2) in registers (the plain epilogue's arithmetic), then PatchSplit: LayerNorm + linear + pixel-shuffled store ----
+        const int row = m0 + l15;
+        const bool live = row < a.M;
+        const float* xr = a.x + (size_t)(live ? row : 0) * CP + 4 * lg;
+        f32x4 y[KK];
+#pragma unroll
+        for (int o = 0; o < KK; ++o) { const f32x4 res = ld4(xr + 16 * o); acc[o][0] += ld4(a.b2 + 16 * o + 4 * lg); y[o] = live ? res + acc[o][0] : zero4(); }
+        float sum = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += y[kk][e];                    // pad channels are exact zeros
+        sum = sum_groups(sum);
+        const float smean = sum / (float)a.C;
+        float v = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = y[kk][e] - smean; v += d * d; }
+        v = sum_groups(v) - (float)(CP - a.C) * smean * smean;              // the zero pads each added mean^2
+        const float srstd = 1.0f / sqrtf(v / (float)a.C + a.eps);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const f32x4 g = ld4(a.sp_gamma + 16 * kk + 4 * lg), bb = ld4(a.sp_beta + 16 * kk + 4 * lg);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[kk][e] = (y[kk][e] - smean) * srstd * g[e] + bb[e];       // gamma = beta = 0 in the pads
+        }
+        size_t ob0 = 0, ob1 = 0;
+        if (live) {
+            const int b = row / (a.sp_H * a.sp_W); const int r0 = row - b * a.sp_H * a.sp_W; const int h = r0 / a.sp_W, w = r0 - h * a.sp_W;
+            ob0 = ((size_t)(b * 2 * a.sp_H + 2 * h) * a.sp_W + w) * a.sp_C2p;
+            ob1 = ((size_t)(b * 2 * a.sp_H + 2 * h + 1) * a.sp_W + w) * a.sp_C2p;
+        }
+        const int n_st = a.sp_NT / 2;                                        // stages of two output tiles (CH = 2 KK fragments, the ring's stage size)
+        for (int st = 0; st < n_st; ++st) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                                // split stage st is in LDS for every wave; nobody still reads the other buffer
+            const int sbuf = (ht1 + st) & 1;
+            if (st + 1 < n_st) {
+                const f32x4* src = a.sp_wf + (size_t)(st + 1) * CH * 64 + lane;
+                for (int c = wave; c < CH; c += NW)
+                    __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(&wbuf[sbuf ^ 1][c * 64]), 16, 0, 0);
+            }
+            const f32x4* wb = &wbuf[sbuf][lane];
+            f32x4 o0 = zero4(), o1 = zero4();
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const f32x4 w0 = wb[kk * 64], w1 = wb[(KK + kk) * 64];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                               // one k-ordered chain per output tile (rowgemm_fused_kernel, K <= 192); the two tiles alternate
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[r], y[kk][r], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[r], y[kk][r], o1, 0, 0, 0);
+                }
+            }
+            if (live) {
+                const int n0 = 16 * (2 * st) + 4 * lg, n1 = n0 + 16;
+                const int s0 = n0 / a.sp_C2p, s1 = n1 / a.sp_C2p;
+                st4(a.sp_out + (s0 ? ob1 : ob0) + (n0 - s0 * a.sp_C2p), o0);
+                st4(a.sp_out + (s1 ? ob1 : ob0) + (n1 - s1 * a.sp_C2p), o1);
+            }
         }
         return;
     }

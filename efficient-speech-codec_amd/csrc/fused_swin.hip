@@ -59,9 +59,30 @@ void rows_combine(float* dst, const float* src, const float* partial, const floa
 }
 
 // *hs: requested hidden split in, split actually used out (> 1: x is untouched, partial[hs][M][Cp] is filled, the caller runs rows_combine)
+template <int CP, int NW>
+static void launch_mlp_split(const MlpArgs& a, hipStream_t s) {
+    const int rows = 16 * NW;
+    hipLaunchKernelGGL((mlp_fused_lds_kernel<CP, 1, NW, 0, false, true>), dim3((a.M + rows - 1) / rows), dim3(64 * NW), 0, s, a);
+}
+
 int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* w1f, const float* b1,
               const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, int* hs_io, float* partial, hipStream_t s, float* out,
-              int* tickets, int n_tickets, bool* combined) {
+              int* tickets, int n_tickets, bool* combined, const MlpSplit* split) {
+    if (split) {        // PatchSplit in the epilogue: the widths whose MLP is not hidden-split (ESC: C = 144, 96, 72), plain 4- / 8-wave variants
+        const int hs0 = hs_io ? *hs_io : 1;
+        if (hs0 > 1 || out || (variant != 1 && variant != 3) || (split->NT & 1) || !(Cp == 80 || Cp == 96 || Cp == 144)) return ESCX_COMB_UNSUPPORTED;
+        if (combined) *combined = false;
+        MlpArgs a{x, gamma, beta, reinterpret_cast<const f32x4*>(w1f), b1, reinterpret_cast<const f32x4*>(w2f), b2,
+                  reinterpret_cast<const f32x4*>(wcf), M, C, hiddenP / 16, 1e-5f, nullptr, 1, nullptr, nullptr, nullptr,
+                  reinterpret_cast<const f32x4*>(split->wf), split->gamma, split->beta, split->out, split->NT, split->H, split->W, split->C2p};
+        const bool nw8 = variant == 3;
+        switch (Cp) {
+            case 80: if (nw8) launch_mlp_split<80, 8>(a, s); else launch_mlp_split<80, 4>(a, s); return 0;
+            case 96: if (nw8) launch_mlp_split<96, 8>(a, s); else launch_mlp_split<96, 4>(a, s); return 0;
+            case 144: if (nw8) launch_mlp_split<144, 8>(a, s); else launch_mlp_split<144, 4>(a, s); return 0;
+        }
+        return ESCX_COMB_UNSUPPORTED;
+    }
     int hs = hs_io ? *hs_io : 1;
     const bool lds_width = Cp == 48 || Cp == 80 || Cp == 96 || Cp == 144 || Cp == 192 || Cp == 384;
     if (hs > 1 && (variant <= 0 || variant >= 100 || variant > 3 || !lds_width || !partial || (hiddenP / 16) % hs)) hs = 1;
@@ -77,7 +98,8 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
                            (Cp == 192 || Cp == 384) && (variant == 1 || variant == 3);
     if (combined) *combined = in_kernel;
     MlpArgs a{x, gamma, beta, reinterpret_cast<const f32x4*>(w1f), b1, reinterpret_cast<const f32x4*>(w2f), b2,
-              reinterpret_cast<const f32x4*>(wcf), M, C, hiddenP / 16, 1e-5f, g_mlp_trace, hs, partial, out, in_kernel ? tickets : nullptr};
+              reinterpret_cast<const f32x4*>(wcf), M, C, hiddenP / 16, 1e-5f, g_mlp_trace, hs, partial, out, in_kernel ? tickets : nullptr,
+              nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
     if (out && (hs > 1 || variant >= 100)) return -1;       // a separate output: plain epilogues only (no hidden split, no ablation builds)
 #ifdef ESCX_EXPERIMENTAL
     if (variant >= 100) {      // timing-only ablations: variant = 100 + ABL bits

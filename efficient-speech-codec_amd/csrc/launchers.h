@@ -27,10 +27,15 @@ void gemm_split(const float* A, int lda, int M, const float* W, int Np, int Kp, 
 constexpr int attn_windows_per_wave(int Cp) { return Cp <= ESCX_ATTN_TMW2_MAX ? 2 : 1; }
 
 // ---- fused register-resident Swin kernels (fused_swin.hip); return -1 when the width is not instantiated ----
+constexpr int ESCX_COMB_UNSUPPORTED = -3;     // "this kernel has no instantiation for the requested fused form": nothing was launched
+// PatchSplit folded into the epilogue of a layer's LAST fused MLP (fused_mlp.h, SPLIT instantiations): LayerNorm(C) + Linear(C -> 2 C') + two-row scatter of
+// x + mlp(x) from registers; x itself is not written.  wf: Layer::sub_wf (fragment order), NT = 2 * C'p / 16 output tiles (even), out = the (2H, W, C'p) map.
+struct MlpSplit { const float* wf; const float* gamma; const float* beta; float* out; int NT, H, W, C2p; };
 int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* w1f, const float* b1,
               const float* w2f, const float* b2, const float* wcf, int hiddenP, int variant, int* hs_io, float* partial, hipStream_t s,
               float* out = nullptr,       // out != nullptr: x untouched, x + mlp(x) goes to out (not with a hidden split)
-              int* tickets = nullptr, int n_tickets = 0, bool* combined = nullptr);    // hidden split: arrival counters (zeroed) -> *combined = the launch did the combine itself
+              int* tickets = nullptr, int n_tickets = 0, bool* combined = nullptr,     // hidden split: arrival counters (zeroed) -> *combined = the launch did the combine itself
+              const MlpSplit* split = nullptr);   // ESCX_COMB_UNSUPPORTED (nothing launched) when this width / variant has no SPLIT instantiation
 unsigned long long* debug_trace_buffer();      // device buffer set by escx_debug_mlp_trace (tuning builds: in-kernel phase stamps), or nullptr
 void rows_combine(float* dst, const float* src, const float* partial, const float* bias, long long M, int Cp, int n, hipStream_t s);
 
@@ -38,7 +43,6 @@ void rows_combine(float* dst, const float* src, const float* partial, const floa
 // Pending combine of a hidden-split MLP (fused_mlp.h): the consumer forms x + (((P0 + P1) + ...) + bias) while it loads its rows.  Kernels without a
 // combine-on-load instantiation return ESCX_COMB_UNSUPPORTED without launching: the caller then runs rows_combine and calls again without it.
 struct CombineOnLoad { const float* partial; const float* bias; long long stride; int n; };
-constexpr int ESCX_COMB_UNSUPPORTED = -3;
 int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, const float* beta, const float* wf, const int* map, int M,
                   int rows_per_clip, int src_rows_per_clip, int C, int Cp, int Np, int split, int H, int W, int C2p, hipStream_t s,
                   const CombineOnLoad* comb = nullptr);

@@ -92,6 +92,30 @@ def synth_state_dict(manifest: dict) -> dict:
     return {k: synth_tensor(k, shp) for k, shp in manifest.items()}
 
 
+def cluster_codebook(key: str, emb: np.ndarray) -> np.ndarray:
+    """Stress form of one codebook (SURVEY hard part 1: trained codebooks may have tighter margins than random ones):
+    the second half of the rows become NEAR-DUPLICATES of the first half - row K/2 + k = row k + rel_k * |row k| * v_k with v_k a hashed unit
+    vector and rel_k cycling log-uniformly through 1e-4 ... 1e-6 (eight steps) - so that for most input vectors the best and the second-best
+    code sit at relative distance 1e-4 ... 1e-6 of each other, i.e. hundreds of argmin margins per clip fall below 1e-5.  Pure function of the key."""
+    K, d = emb.shape
+    half = K // 2
+    out = emb.astype(np.float64).copy()
+    v = hashed_uniform(key + ":near-duplicate", half * d).reshape(half, d)
+    v /= np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-30)
+    rel = 10.0 ** (-4.0 - 2.0 * ((np.arange(half) % 8) / 7.0))
+    out[half:2 * half] = out[:half] + rel[:, None] * np.linalg.norm(out[:half], axis=1, keepdims=True) * v
+    return out.astype(np.float32)
+
+
+def clustered_state_dict(manifest: dict) -> dict:
+    """synth_state_dict with every codebook replaced by its clustered form (tests/golden/clustered.npz, oracle/gen_clustered_golden.py)."""
+    sd = synth_state_dict(manifest)
+    for k in sd:
+        if k.endswith("embedding.weight"):
+            sd[k] = cluster_codebook(k, sd[k])
+    return sd
+
+
 def noise_clip_int16(tag: str, n_samples: int, amp: float = 0.1) -> np.ndarray:
     """Approximately Gaussian noise (sum of 4 hashed uniforms), quantised to int16 PCM."""
     s = sum(hashed_uniform(tag, n_samples, salt=i) for i in range(4)) * (np.sqrt(3.0) / 2.0)

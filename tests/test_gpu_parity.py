@@ -501,6 +501,45 @@ def test_unfiltered_reference_clips(name):
     assert rms(wave[:, ::16], u[f"{name}_audio_sub"]) <= AUDIO_TOL
 
 
+def test_clustered_codebooks_against_the_reference():
+    """VERDICT r4 item 4b / SURVEY hard part 1: parity on trained-like margin statistics.  tests/golden/clustered.npz holds what the REAL reference
+    emits for ESC-Base when every codebook row has a near-duplicate at relative distance 1e-4 ... 1e-6 (esc/synth.py cluster_codebook;
+    oracle/gen_clustered_golden.py): ~13 000 of its 16 200 argmin margins are below 1e-5, ~5 600 below 1e-6.  Requirement: ZERO unattributable
+    differences - a code the HIP path resolves the other way must sit on a reference margin < 2e-6 in the earliest differing stream of its clip, and
+    the later streams of that clip must equal the oracle continued from the device's choice; the flip count per margin decade is printed."""
+    import json
+    from esc.models import make_model
+    from oracle.esc_oracle import EscOracle
+    from conftest import load_manifest
+    g = load_golden("base")
+    cfg = json.loads(str(g["config_json"]))
+    sd = {}
+    for k, v in synth.clustered_state_dict(load_manifest("base")).items():
+        sd[k] = torch.hann_window(v.shape[0]) if k.endswith(".window") else torch.from_numpy(np.ascontiguousarray(v))
+    model = make_model(cfg); model.load_state_dict(sd, strict=True); model = model.to("cuda:0").eval()
+    orc = EscOracle(cfg, sd)
+    u = load_golden("clustered")
+    tags = json.loads(str(u["tags"]))
+    pcm = np.stack([(synth.noise_clip_int16 if k == "noise" else synth.voiced_clip_int16)(t, 48000) for k, t in tags])
+    x = torch.from_numpy(synth.pcm_to_float(pcm))
+    codes, shape = model.encode(x.cuda(), cfg["max_streams"])
+    got, ref, m = codes.cpu().numpy(), u["codes"].astype(np.int64), u["margins"]
+    # flips against the reference in the FIRST stream (every clip sees the reference's own residual there): by decade of the reference margin
+    first = got[:, 0] != ref[:, 0]
+    by_decade = {f"<1e-{e}": (int((first & (m[:, 0] < 10.0 ** -e) & (m[:, 0] >= 10.0 ** -(e + 1))).sum()), int(((m[:, 0] < 10.0 ** -e) & (m[:, 0] >= 10.0 ** -(e + 1))).sum()))
+                 for e in (4, 5, 6, 7, 8)}
+    by_decade["exact ties (0)"] = (int((first & (m[:, 0] == 0)).sum()), int((m[:, 0] == 0).sum()))
+    bad, forced, cont = attribute_with_continuation(orc, x, got, ref, m, cfg["max_streams"])
+    print(f"[clustered] {int((got != ref).sum())} of {ref.size} codes differ from the reference fixture ({forced} attributed near-ties forced, {len(cont)} clips continued); "
+          f"stream-0 flips / codes per reference-margin decade: {by_decade}; reference margins under 1e-5: {int((m < 1e-5).sum())}")
+    assert not bad, "\n".join(bad[:10])
+    # the near-duplicates decode to (almost) the same vectors: the device's own round trip stays within the audio tolerance of the reference's
+    wave = model.decode(codes, shape).cpu().numpy()
+    ref_rms = float(np.sqrt(np.mean(u["audio_sub"].astype(np.float64) ** 2)))
+    assert rms(wave[:, ::16], u["audio_sub"]) <= 1e-3 * ref_rms + AUDIO_TOL        # flipped near-duplicates (relative distance <= 1e-4) move the audio by ~1e-5 relative
+    assert rms(model.decode(torch.from_numpy(ref).cuda(), shape).cpu().numpy()[:, ::16], u["audio_sub"]) <= AUDIO_TOL
+
+
 def test_decode_partial_streams_and_errors(base):
     model, orc, g, cfg = base
     x = torch.from_numpy(synth.pcm_to_float(g["pcm"])).cuda()
@@ -754,16 +793,12 @@ def test_allgather_codes_through_the_c_abi_one_rank_rccl(base):
         rccl.ncclCommDestroy(comm)
 
 
-@pytest.mark.gpu
-@pytest.mark.skipif(not os.environ.get("ESCX_PARITY_SWEEP"), reason="opt-in: ESCX_PARITY_SWEEP=<clips per family> (minutes of host time for the oracle)")
-def test_parity_sweep_many_clips():
-    """Opt-in sweep (its log is committed under profiles/): N noise + N voiced clips in batches of 36 against the oracle, every code; a
-    difference must sit on a reference near-tie (margin < 2e-6) in the earliest differing stream of its clip.  ESCX_PARITY_SWEEP_MODEL=large
-    sweeps ESC-Large instead of ESC-Base."""
-    model, orc, g, cfg = build_models(os.environ.get("ESCX_PARITY_SWEEP_MODEL", "base"))
+def _parity_sweep(model_name, n):
+    """n noise + n voiced clips in batches of 36 against the oracle, every code; a difference must sit on a reference near-tie (margin < 2e-6) in the
+    earliest differing stream of its clip, and the later streams of such a clip are verified against the oracle CONTINUED from the device's choice."""
+    model, orc, g, cfg = build_models(model_name)
     Trace = __import__("oracle.esc_oracle", fromlist=["Trace"]).Trace
-    n = int(os.environ["ESCX_PARITY_SWEEP"])
-    tot = dict(clips=0, exact=0, codes=0, diff=0, under_1e5=0, under_2e6=0)
+    tot = dict(model=model_name, clips=0, exact=0, codes=0, diff=0, under_1e5=0, under_2e6=0)
     min_margin = 1.0
     for fam, fn in (("noise", synth.noise_clip_int16), ("voiced", synth.voiced_clip_int16)):
         for lo in range(0, n, 36):
@@ -782,33 +817,79 @@ def test_parity_sweep_many_clips():
             tot["forced"] = tot.get("forced", 0) + forced; tot["continued"] = tot.get("continued", 0) + len(cont)
             tot["clips"] += k; tot["exact"] += int((got == ref).reshape(k, -1).all(1).sum()); tot["codes"] += got.size; tot["diff"] += int((got != ref).sum())
             tot["under_1e5"] += int((m < 1e-5).sum()); tot["under_2e6"] += int((m < 2e-6).sum()); min_margin = min(min_margin, float(m.min()))
-            print(f"[sweep {fam} {lo}..{lo + k}] exact {tot['exact']}/{tot['clips']} clips, smallest reference margin so far {min_margin:.2e}", flush=True)
+            print(f"[sweep {model_name} {fam} {lo}..{lo + k}] exact {tot['exact']}/{tot['clips']} clips, smallest reference margin so far {min_margin:.2e}", flush=True)
     print(f"[sweep] {tot}; smallest reference margin {min_margin:.2e}")
+    return tot
 
 
 @pytest.mark.gpu
-def test_opt_in_kernel_forms_against_the_default(tmp_path):
-    """Round 4 left measured-and-rejected kernel forms (and the engine forms the new PVQ up-projection replaced) in the library as switches (each reads its switch once per process, hence one
-    child process per arm, tools/ab.py): the in-launch combine of the hidden-split MLP and the combine-on-load consumers must reproduce the
-    default's codes AND audio bit for bit (same arithmetic, same order); the weight-stationary / shared-rows merge-split kernels pin their
-    LayerNorm contraction explicitly, so they may differ from the default in low-order bits: identical codes, audio within 1e-6 RMS."""
+def test_parity_sweep_base_always_on():
+    """the sweep is part of every GPU run - 72 noise + 72 voiced 3 s clips of ESC-Base against the oracle, every code
+    (ESCX_PARITY_SWEEP=<clips per family> widens it: 288 is the sweep whose log is committed under profiles/).  ESC-Base has been bit-exact on
+    every clip of every sweep so far; the rule tolerates an attributed near-tie, the count is printed."""
+    tot = _parity_sweep("base", int(os.environ.get("ESCX_PARITY_SWEEP", "72")))
+    assert tot["exact"] >= tot["clips"] - 1, tot           # at most one attributed near-tie clip per 144 (observed: none)
+
+
+@pytest.mark.gpu
+def test_parity_sweep_large_always_on():
+    """The same for ESC-Large (depth 4, where the two attributed near-tie clips of the 288-clip sweep live): 18 + 18 clips in every GPU run
+    (ESCX_PARITY_SWEEP_LARGE=<clips per family> widens it; 144 = the committed sweep)."""
+    tot = _parity_sweep("large", int(os.environ.get("ESCX_PARITY_SWEEP_LARGE", "18")))
+    assert tot["exact"] >= tot["clips"] - 1, tot
+
+
+def _ab_arms(arms, tmp_path, extra_env=None):
     import subprocess, sys
     from conftest import ROOT
     ab = os.path.join(ROOT, "tools", "ab.py")
-    arms = {"default": {}, "mlp_fused_combine": {"ESCX_MLP_FUSED_COMBINE": "1"}, "combine_on_load": {"ESCX_COMBINE_ON_LOAD": "1"},
-            "rowgemm_ws": {"ESCX_ROWGEMM_WS": "4"}, "rowgemm_xs": {"ESCX_ROWGEMM_XS": "1"},
-            "pvq_down_kernel": {"ESCX_PVQ_DOWN_KERNEL": "1"}, "pvq_up_engine": {"ESCX_PVQ_UP_KERNEL": "0"}, "attn_gs_off": {"ESCX_ATTN_GS_TOKENS": "0"}}
     got = {}
     for name, env in arms.items():
         out = str(tmp_path / f"{name}.npz")
-        e = dict(os.environ, AB_STEPS="1", AB_BATCH="8", AB_GROUPS="", AB_DUMP=out, **env)
+        e = dict(os.environ, AB_STEPS="1", AB_BATCH="8", AB_GROUPS="", AB_DUMP=out, **(extra_env or {}), **env)
         r = subprocess.run([sys.executable, ab, "--child"], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "AB_RESULT" in r.stdout, f"{name}: {r.stderr[-800:]}"
         got[name] = np.load(out)
+    return got
+
+
+@pytest.mark.gpu
+def test_fallback_kernel_forms_against_the_default(tmp_path):
+    """The PRODUCT library keeps a handful of fallback forms behind switches (each is read once per process, hence one child process per arm,
+    tools/ab.py).  Round 5: the fused product-VQ kernel (fused_pvq.h) and the de-quantisation tables must reproduce the three-launch form
+    (split-K GEMM -> search -> up-projection on the MFMA) bit for bit, codes AND audio, and so must the GEMM-engine up-projection;
+    attn_gs_off (the C = 384 attention without the head-group split: another projection order) keeps the codes, audio within 1e-6 RMS."""
+    arms = {"default": {}, "pvq_three_launch": {"ESCX_PVQ_FUSED": "0", "ESCX_PVQ_TABLE": "0"}, "pvq_fused_mfma_up": {"ESCX_PVQ_TABLE": "0"},
+            "pvq_tables_only": {"ESCX_PVQ_FUSED": "0"}, "pvq_up_engine": {"ESCX_PVQ_FUSED": "0", "ESCX_PVQ_TABLE": "0", "ESCX_PVQ_UP_KERNEL": "0"},
+            "attn_gs_off": {"ESCX_ATTN_GS_TOKENS": "0"}}
+    got = _ab_arms(arms, tmp_path)
     ref = got["default"]
-    for name in ("mlp_fused_combine", "combine_on_load", "pvq_down_kernel", "pvq_up_engine"):
+    for name in ("pvq_three_launch", "pvq_fused_mfma_up", "pvq_tables_only", "pvq_up_engine"):
         assert np.array_equal(got[name]["codes"], ref["codes"]) and np.array_equal(got[name]["wave"], ref["wave"]), f"{name} is not bit-identical to the default"
-    for name in ("rowgemm_ws", "rowgemm_xs", "attn_gs_off"):     # attn_gs_off: the C=384 attention without the head-group split (other projection order)
+    for name in ("attn_gs_off",):
+        assert np.array_equal(got[name]["codes"], ref["codes"]), f"{name}: codes differ from the default"
+        rms = float(np.sqrt(np.mean((got[name]["wave"].astype(np.float64) - ref["wave"]) ** 2)))
+        assert rms <= 1e-6, f"{name}: audio rms {rms}"
+
+
+@pytest.mark.gpu
+def test_experimental_kernel_forms_against_the_default(tmp_path):
+    """The measured-and-rejected kernel forms of rounds 3-4 are compiled into TAGGED builds only (tune_env.h: ESCX_BUILD_TAG=exp
+    ESCX_EXTRA_CXXFLAGS=-DESCX_EXPERIMENTAL python efficient-speech-codec_amd/build.py -> libescx_exp.so).  When that library is present they are
+    checked against the default library: the in-launch combine of the hidden-split MLP, the combine-on-load consumers and the specialised
+    down-projection kernel bit for bit; the weight-stationary / shared-rows merge-split kernels pin their LayerNorm contraction explicitly, so
+    they may differ in low-order bits: identical codes, audio within 1e-6 RMS."""
+    from conftest import ROOT
+    if not os.path.exists(os.path.join(ROOT, "efficient-speech-codec_amd", "esc", "lib", "libescx_exp.so")):
+        pytest.skip("no tagged experimental build (libescx_exp.so): the product library does not contain the rejected forms")
+    ref = _ab_arms({"default": {}}, tmp_path)["default"]
+    arms = {"mlp_fused_combine": {"ESCX_MLP_FUSED_COMBINE": "1"}, "combine_on_load": {"ESCX_COMBINE_ON_LOAD": "1"},
+            "rowgemm_ws": {"ESCX_ROWGEMM_WS": "4"}, "rowgemm_xs": {"ESCX_ROWGEMM_XS": "1"},
+            "pvq_down_kernel": {"ESCX_PVQ_FUSED": "0", "ESCX_PVQ_DOWN_KERNEL": "1"}}
+    got = _ab_arms(arms, tmp_path, {"ESCX_LIB_TAG": "exp"})
+    for name in ("mlp_fused_combine", "combine_on_load", "pvq_down_kernel"):
+        assert np.array_equal(got[name]["codes"], ref["codes"]) and np.array_equal(got[name]["wave"], ref["wave"]), f"{name} is not bit-identical to the default"
+    for name in ("rowgemm_ws", "rowgemm_xs"):
         assert np.array_equal(got[name]["codes"], ref["codes"]), f"{name}: codes differ from the default"
         rms = float(np.sqrt(np.mean((got[name]["wave"].astype(np.float64) - ref["wave"]) ** 2)))
         assert rms <= 1e-6, f"{name}: audio rms {rms}"

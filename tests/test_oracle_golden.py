@@ -136,6 +136,39 @@ def test_unfiltered_reference_clips(name):
     assert _rms(a[:, ::16], u[f"{name}_audio_sub"][: len(sel)]) <= 1e-6
 
 
+def _clustered_case():
+    """ESC-Base with clustered codebooks (esc/synth.py cluster_codebook) + the clips and reference outputs of tests/golden/clustered.npz."""
+    from oracle.esc_oracle import EscOracle
+    g = load_golden("base")
+    cfg = json.loads(str(g["config_json"]))
+    from conftest import load_manifest
+    sd = {}
+    for k, v in synth.clustered_state_dict(load_manifest("base")).items():
+        sd[k] = torch.hann_window(v.shape[0]) if k.endswith(".window") else torch.from_numpy(np.ascontiguousarray(v))
+    u = load_golden("clustered")
+    tags = json.loads(str(u["tags"]))
+    pcm = np.stack([(synth.noise_clip_int16 if k == "noise" else synth.voiced_clip_int16)(t, 48000) for k, t in tags])
+    return cfg, sd, EscOracle(cfg, sd), torch.from_numpy(synth.pcm_to_float(pcm)), u
+
+
+def test_clustered_codebooks_oracle_against_the_reference():
+    """tests/golden/clustered.npz (oracle/gen_clustered_golden.py, the REAL reference): every codebook row has a near-duplicate at relative
+    distance 1e-4 ... 1e-6, 80 % of the reference's own argmin margins are below 1e-5 and a third below 1e-6.  The oracle must reproduce the
+    reference up to near-ties (margin < 2e-6, later streams by continuation) - on the machine the fixture was generated on it reproduces every code."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from gpu_util import attribute_with_continuation
+    cfg, sd, orc, x, u = _clustered_case()
+    codes, shape = orc.encode(x, cfg["max_streams"])
+    ref, m = u["codes"].astype(np.int64), u["margins"]
+    bad, forced, cont = attribute_with_continuation(orc, x, codes.numpy(), ref, m, cfg["max_streams"])
+    print(f"[clustered oracle] {int((codes.numpy() != ref).sum())} of {ref.size} codes differ from the reference fixture, {forced} attributed near-ties; "
+          f"reference margins: {int((m < 1e-5).sum())} under 1e-5, {int((m < 1e-6).sum())} under 1e-6, min {m.min():.1e}")
+    assert not bad, "\n".join(bad[:10])
+    a = orc.decode(torch.from_numpy(ref), shape).numpy()
+    assert _rms(a[:, ::16], u["audio_sub"]) <= 1e-6
+
+
 def test_oracle_continuation_from_a_forced_code():
     """Test infrastructure of the GPU parity sweeps (tests/gpu_util.attribute_with_continuation): a "device" that resolves one stream-0 decision the
     other way and then continues consistently is accepted with exactly that one code forced (when the decision counts as a near-tie), is reported when
