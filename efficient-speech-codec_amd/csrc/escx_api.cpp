@@ -1045,7 +1045,7 @@ static int attn_cap(int Cp, int tmw) { const int v = Cp * tmw; return v <= 96 ? 
 // and a combine pass adds their fc2 partial sums in fixed order.  The rule depends on the layer geometry only - never on the
 // batch - so that a clip's arithmetic (and therefore its codes) is identical in any batch or shard it is processed in.
 // The partial sums live in the (otherwise unused) hidden-activation buffer of the unfused path: needs hiddenP >= 3 * Cp.
-static int mlp_hs_for(int tokens_per_clip, int HT, int Cp) { return (tokens_per_clip <= 1200 && HT % 3 == 0 && HT * 16 >= 3 * Cp) ? 3 : 1; }
+static int mlp_hs_for(int tokens_per_clip, int HT, int Cp) { static const int lim = [] { const char* e = ESCX_TUNE_ENV("ESCX_MLP_HS_TOKENS"); return e && e[0] ? atoi(e) : 1200; }(); return (tokens_per_clip <= lim && HT % 3 == 0 && HT * 16 >= 3 * Cp) ? 3 : 1; }
 // The same split over the head groups of the fused attention (partials share the buffer; an MLP always follows on the same
 // stream).  Like the hidden split it would have to depend on the clip's geometry only, never on the batch (it re-associates the projection
 // sum).  Measured with ESCX_ATTN_GS_TOKENS=600 (the C = 384 scale of a 3 s clip; tools/small_batch.py): one clip 3.52 -> 3.12 ms, 4 clips

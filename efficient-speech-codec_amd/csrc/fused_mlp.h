@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
         for (int f = 0; f < KK; ++f) {
             const f32x4 w = ring[f % PD];
             if (f + PD < CH) ring[f % PD] = wb[(f + PD) * 64];
-            if constexpr (SPREAD) {             // one 1 KiB DMA every DSTEP fragments, all issued within the fc1 phase
+            if constexpr (SPREAD && !(ABL & 32)) {             // one 1 KiB DMA every DSTEP fragments, all issued within the fc1 phase
                 constexpr int NDMA = (CH + NW - 1) / NW, DSTEP = KK / NDMA > 0 ? KK / NDMA : 1;
                 if (f % DSTEP == 0 && f / DSTEP < NDMA) {
                     int c = wave + (f / DSTEP) * NW;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64 * NW, (mlp_min_waves<CP, TM>())) void mlp_fused_
 #pragma unroll
             for (int f = 0; f < CH; ++f) {
                 if (f + PD < CH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if constexpr (SPREAD) {     // the DMA pieces stay where they are issued (unpinned, the scheduler sinks them to the end of the stage)
+                if constexpr (SPREAD && !(ABL & 32)) {     // the DMA pieces stay where they are issued (unpinned, the scheduler sinks them to the end of the stage)
                     constexpr int NDMA = (CH + NW - 1) / NW, DSTEP = KK / NDMA > 0 ? KK / NDMA : 1;
                     if (f < KK && f % DSTEP == 0 && f / DSTEP < NDMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }

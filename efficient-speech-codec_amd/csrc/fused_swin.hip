@@ -124,6 +124,10 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
             if (Cp == 192) { launch_mlp_abl<192, 1, 4, 256>(a, s); return 0; }
         }
         if (Cp == 48 && abl == 64) { launch_mlp_abl<48, 1, 8, 64>(a, s); return 0; }
+        if (Cp == 48 && abl == 34) { launch_mlp_abl<48, 1, 8, 34>(a, s); return 0; }      // round 5 timing experiment: no stage barrier, no weight DMA (what LDS-resident weights would save)
+        if (Cp == 48 && abl == 2) { launch_mlp_abl<48, 1, 8, 2>(a, s); return 0; }
+        if (Cp == 48 && abl == 32) { launch_mlp_abl<48, 1, 8, 32>(a, s); return 0; }
+        if (Cp == 48 && abl == 0) { launch_mlp_abl<48, 1, 8, 0>(a, s); return 0; }
         variant = 1;
     }
 #else

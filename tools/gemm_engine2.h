@@ -280,3 +280,88 @@ inline void launch_gemm3(const Loader& ld, const float* Wt, int M, int Np, int K
 }
 
 }  // namespace escx
+
+namespace escx {
+
+// Round 5: the engine's loop on v_mfma_f32_32x32x2_f32 instead of v_mfma_f32_16x16x4_f32.  Same loaders, epilogues, LDS image
+// ([row][k], stride BK + 4) and staging as gemm_kernel; a wave owns 32 rows (one column tile of the B operand) x BN / 32 weight tiles, its 16
+// accumulator values per tile are D[n = 8 q + 4 (lane / 32) + r][m = lane % 32]: still 4 consecutive output features per f32x4 store.
+// Within a 16-wide k chunk, MFMA step s takes k = 8 * (lane / 32) + s (each lane reads 8 consecutive floats = two ds_read_b128), so the
+// SUMMATION ORDER differs from the engine's - tolerance-level agreement only (loss terms, not codes).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int BM, int BN, int BK, class Loader, class Epi>
+__global__ __launch_bounds__(256) void gemm_kernel_m32(Loader ld, const float* __restrict__ Wt, int M, int Np, int Kp, int k_per_z, Epi ep) {
+    static_assert(BM == 128 && BN % 32 == 0 && BK % 16 == 0, "tile shape");
+    constexpr int LDS_LD = BK + 4;
+    constexpr int TN = BN / 32;
+    constexpr int KV = BK / 4;
+    constexpr int A4 = BM * KV, B4 = BN * KV;
+    constexpr int AJ = (A4 + 255) / 256, BJ = (B4 + 255) / 256;
+    __shared__ float As[BM * LDS_LD];
+    __shared__ float Bs[BN * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kbeg = blockIdx.z * k_per_z, kend = min(Kp, kbeg + k_per_z);
+    typename Loader::Ctx ctx[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) { const int i = tid + j * 256; ctx[j] = ld.make_ctx(m0 + (i < A4 ? i / KV : 0)); }
+    f32x16 acc[TN];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[a][v] = 0.f;
+    f32x4 ra[AJ], rb[BJ];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) { const int i = tid + j * 256; ra[j] = (A4 % 256 == 0 || i < A4) ? ld.load4(ctx[j], k0, 4 * (i % KV)) : zero4(); }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int i = tid + j * 256; const int row = i / KV, c4 = i % KV;
+            rb[j] = ((B4 % 256 == 0 || i < B4) && n0 + row < Np) ? ld4(Wt + (size_t)(n0 + row) * Kp + k0 + 4 * c4) : zero4();
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) { const int i = tid + j * 256; if (A4 % 256 == 0 || i < A4) st4(&As[(i / KV) * LDS_LD + 4 * (i % KV)], ra[j]); }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) { const int i = tid + j * 256; if (B4 % 256 == 0 || i < B4) st4(&Bs[(i / KV) * LDS_LD + 4 * (i % KV)], rb[j]); }
+        __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            f32x4 af[2], wf[TN][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) af[q] = ld4(&As[(wave * 32 + l31) * LDS_LD + kk + 8 * hf + 4 * q]);
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) wf[a][q] = ld4(&Bs[(a * 32 + l31) * LDS_LD + kk + 8 * hf + 4 * q]);
+#pragma unroll
+            for (int st = 0; st < 8; ++st)
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[a][st >> 2][st & 3], af[st >> 2][st & 3], acc[a], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int m = m0 + wave * 32 + l31;
+    if (m >= M) return;
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + a * 32 + 8 * q + 4 * hf;
+            if (n < Np) ep.store(m, n, f32x4{acc[a][4 * q], acc[a][4 * q + 1], acc[a][4 * q + 2], acc[a][4 * q + 3]}, blockIdx.z);
+        }
+}
+
+template <int BN, int BK, class Loader, class Epi>
+inline void launch_gemm_m32(const Loader& ld, const float* Wt, int M, int Np, int Kp, const Epi& ep, hipStream_t s) {
+    dim3 grid((M + 127) / 128, (Np + BN - 1) / BN, 1);
+    hipLaunchKernelGGL((gemm_kernel_m32<128, BN, BK, Loader, Epi>), grid, dim3(256), 0, s, ld, Wt, M, Np, Kp, Kp, ep);
+}
+
+}  // namespace escx

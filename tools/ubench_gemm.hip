@@ -3,6 +3,7 @@
 // Prints TFLOP/s per (kernel variant, shape).  Tuning aid only: not part of libescx.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cmath>
 #include <vector>
 #include "gemm_engine.h"
 #include "gemm_engine2.h"
@@ -53,6 +54,21 @@ int main(int argc, char** argv) {
         if (sh.K % 32 == 0) run("engine<128> bk32", [&] { launch_gemm<128>(ld, W, sh.M, sh.N, sh.K, ep, 0, 1, 32); });
         if (sh.K % 48 == 0) run("engine<128> bk48", [&] { launch_gemm<128>(ld, W, sh.M, sh.N, sh.K, ep, 0, 1, 48); });
         run("engine<64> bk16", [&] { launch_gemm<64>(ld, W, sh.M, sh.N, sh.K, ep, 0, 1, 16); });
+        // round 5: the same loop on v_mfma_f32_32x32x2_f32 (gemm_engine2.h gemm_kernel_m32); results agree to rounding, not bitwise (other k order)
+        run("m32<128,96,16>  (32x32x2 MFMA)", [&] { launch_gemm_m32<96, 16>(ld, W, sh.M, sh.N, sh.K, ep, 0); });
+        run("m32<128,128,16> (32x32x2 MFMA)", [&] { launch_gemm_m32<128, 16>(ld, W, sh.M, sh.N, sh.K, ep, 0); });
+        if (sh.K % 32 == 0) run("m32<128,128,32> (32x32x2 MFMA)", [&] { launch_gemm_m32<128, 32>(ld, W, sh.M, sh.N, sh.K, ep, 0); });
+        run("m32<128,64,16>  (32x32x2 MFMA)", [&] { launch_gemm_m32<64, 16>(ld, W, sh.M, sh.N, sh.K, ep, 0); });
+        {   // agreement with the engine (relative error of 4096 probed outputs)
+            launch_gemm<128>(ld, W, sh.M, sh.N, sh.K, ep, 0, 1, 16); hipDeviceSynchronize();
+            std::vector<float> r0(4096), r1(4096);
+            hipMemcpy(r0.data(), O + (size_t)(sh.M - 70) * sh.N, 4096 * 4, hipMemcpyDeviceToHost);
+            hipMemset(O, 0, (size_t)sh.M * sh.N * 4);
+            launch_gemm_m32<128, 16>(ld, W, sh.M, sh.N, sh.K, ep, 0); hipDeviceSynchronize();
+            hipMemcpy(r1.data(), O + (size_t)(sh.M - 70) * sh.N, 4096 * 4, hipMemcpyDeviceToHost);
+            double num = 0, den = 0; for (int i = 0; i < 4096; ++i) { num += (double)(r0[i] - r1[i]) * (r0[i] - r1[i]); den += (double)r0[i] * r0[i]; }
+            printf("   m32 vs engine: relative rms difference %.2e over 4096 probed outputs\n", std::sqrt(num / (den > 0 ? den : 1)));
+        }
 #ifdef HAVE_V2
         run("v3<128,96>", [&] { launch_gemm3<128, 96>(ld, W, sh.M, sh.N, sh.K, ep, 0); });
         run("v3<128,128>", [&] { launch_gemm3<128, 128>(ld, W, sh.M, sh.N, sh.K, ep, 0); });
