@@ -13,7 +13,8 @@ def main():
              "event_breakdown_1stream.txt": "event_breakdown_1stream.txt", "kernel_stats.csv": "kernel_stats.csv", "prof_bench_line.txt": "bench_under_rocprof.json",
              "other_configs.json": "other_configs.json", "pmc_hbm.json": "pmc_hbm.json", "pmc_calibration.json": "pmc_calibration.json",
              "sq_counters.txt": "sq_counters.txt", "sq_counters.json": "sq_counters.json", "train_breakdown.txt": "train_breakdown.txt",
-             "train_kernel_stats.csv": "train_kernel_stats.csv", "small_batch.txt": "small_batch.txt", "sq_util.txt": "sq_util.txt", "sq_util_train.txt": "sq_util_train.txt", "train_adv_kernel_stats.csv": "train_adv_kernel_stats.csv", "pytest_gpu.txt": "pytest_gpu.txt"}
+             "train_kernel_stats.csv": "train_kernel_stats.csv", "small_batch.txt": "small_batch.txt", "sq_util.txt": "sq_util.txt", "sq_util_train.txt": "sq_util_train.txt", "train_adv_kernel_stats.csv": "train_adv_kernel_stats.csv", "pytest_gpu.txt": "pytest_gpu.txt", "ubench_gemm.txt": "ubench_gemm.txt",
+             "parity_sweep_base576.log": "parity_sweep_base576.log", "parity_sweep_large288.log": "parity_sweep_large288.log"}
     for a, b in names.items():
         p = os.path.join(src, a)
         if os.path.exists(p) and os.path.getsize(p) > 0:
