@@ -216,8 +216,7 @@ inline bool launch_conv32_halo(const Halo32& h, const float* W, int Kp, const Ep
     const int NF = H32_TO0 + h.T0 - 1, HW = (H32_TO1 - 1) * h.s1 + h.T1;
     const size_t lds = ((size_t)NF * HW * H32_P + 3 * 32 * H32_P) * sizeof(float);
     if (lds > 150 * 1024) return false;
-    static bool attr_set = false;               // per Epi instantiation
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv32_halo_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv32_halo_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);   // per launch: per-device attribute, no shared flag
     const int tiles0 = (h.O0 + H32_TO0 - 1) / H32_TO0, tiles1 = (h.O1 + H32_TO1 - 1) / H32_TO1;
     hipLaunchKernelGGL((conv32_halo_kernel<Epi>), dim3((unsigned)((size_t)h.B * tiles0 * tiles1)), dim3(256), lds, st, h, W, Kp, tiles0, tiles1, ep);
     return true;

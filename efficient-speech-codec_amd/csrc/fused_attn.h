@@ -193,8 +193,8 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) st4(a.tape_xn + row * CP + 16 * kk + 4 * lg, xf[t][kk]);
             const int q_end = 3 * a.nH * a.hdp, o_end = a.nH * a.hdp;
-            if (q_end + 4 * lg < a.ldq) st4(a.tape_qkv + row * a.ldq + q_end + 4 * lg, zero4());
-            if (o_end + 4 * lg < a.ldo) st4(a.tape_o + row * a.ldo + o_end + 4 * lg, zero4());
+            for (int c = q_end + 4 * lg; c < a.ldq; c += 16) st4(a.tape_qkv + row * a.ldq + c, zero4());       // the WHOLE pad width (it used to stop after 16 columns)
+            for (int c = o_end + 4 * lg; c < a.ldo; c += 16) st4(a.tape_o + row * a.ldo + c, zero4());
         }
     }
 

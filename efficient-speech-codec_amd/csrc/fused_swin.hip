@@ -196,8 +196,7 @@ static void launch_rowgemm_ws(const RowGemmArgs& a, hipStream_t s) {
         const int it = (n_groups + gx * NW - 1) / (gx * NW);
         gx = std::max(1, (n_groups + it * NW - 1) / (it * NW));
     }
-    static thread_local int lds_set = 0;
-    if (lds > lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); lds_set = 160 * 1024; }
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      // per launch: function attributes are per device
     hipLaunchKernelGGL(kern, dim3(gx, chunks), dim3(64 * NW), lds, s, b);
 }
 
@@ -226,8 +225,7 @@ static void launch_rowgemm_xs(const RowGemmArgs& a, hipStream_t s) {
     constexpr int WPS = (WPS0 * 4 < NW) ? (NW / 4) : WPS0;
     auto kern = rowgemm_xs_kernel<KP, SEGS, R, NW, NTW, WPS>;
     const int lds = R * KK * 1024;
-    static thread_local bool lds_set = false;
-    if (lds > 64 * 1024 && !lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); lds_set = true; }
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);             // per launch: function attributes are per device
     hipLaunchKernelGGL(kern, dim3((a.M + 16 * R - 1) / (16 * R)), dim3(64 * NW), lds, s, a);
 }
 

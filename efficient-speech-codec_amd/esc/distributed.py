@@ -104,8 +104,25 @@ def all_gather_codes(codes_local: torch.Tensor, group: Optional[dist.ProcessGrou
 
 
 def _mapped_path(cdll) -> Optional[str]:
-    """Real path of a loaded shared object (from /proc/self/maps), None when it cannot be told."""
+    """Real path of a loaded shared object, None when it cannot be told.  First choice: dladdr() on a symbol resolved THROUGH THE HANDLE,
+    which names the object that handle really is even when two RCCL instances are mapped (torch's bundled one and /opt/rocm's); the
+    /proc/self/maps scan by basename is the fallback."""
     import os
+    try:
+        class _DlInfo(ctypes.Structure):
+            _fields_ = [("dli_fname", ctypes.c_char_p), ("dli_fbase", ctypes.c_void_p), ("dli_sname", ctypes.c_char_p), ("dli_saddr", ctypes.c_void_p)]
+        libdl = ctypes.CDLL(None)
+        libdl.dladdr.argtypes = [ctypes.c_void_p, ctypes.POINTER(_DlInfo)]
+        libdl.dladdr.restype = ctypes.c_int
+        for sym in ("ncclCommInitRank", "ncclGetUniqueId"):
+            fn = getattr(cdll, sym, None)
+            if fn is None:
+                continue
+            info = _DlInfo()
+            if libdl.dladdr(ctypes.cast(fn, ctypes.c_void_p), ctypes.byref(info)) and info.dli_fname:
+                return os.path.realpath(info.dli_fname.decode())
+    except Exception:
+        pass
     name = os.path.basename(getattr(cdll, "_name", "") or "")
     try:
         with open("/proc/self/maps") as f:
@@ -183,7 +200,8 @@ class AbiCodesGather:
         return out
 
     def start(self, codes_local: torch.Tensor) -> "PendingCodes":
-        """The same exchange on a side stream: ordered behind what the caller's stream has produced so far, joined in `wait()`."""
+        """The same exchange on a side stream: ordered behind what the caller's stream has produced so far, joined in `wait()`.
+        `__call__` and `start()` share the handle's single staging buffer: do not interleave them on different streams without `wait()` in between."""
         cur = torch.cuda.current_stream(self.device)
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
@@ -195,7 +213,9 @@ class AbiCodesGather:
         done.record(self._side)
 
         def finish(out=out, done=done):
-            torch.cuda.current_stream(self.device).wait_event(done)
+            consumer = torch.cuda.current_stream(self.device)
+            consumer.wait_event(done)
+            out.record_stream(consumer)        # `out` was allocated under the side stream; tell the caching allocator who reads it now
             return out
         return PendingCodes(finish)
 

@@ -57,8 +57,13 @@ class FlatAdamW:
         st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         with torch.cuda.device(self.device):
             clip = None
+            if self._inactive:        # torch does not count a None gradient in clip_grad_norm_: whatever the backward wrote for an inactive parameter is dropped first
+                slices = self._param_slices()
+                for i in self._inactive:
+                    if slices[i] is not None:
+                        gflat[slices[i][0]:slices[i][0] + slices[i][1]].zero_()
             if self.max_grad_norm is not None:
-                # inactive parameters hold zero gradients in the flat buffer: they add nothing to the norm, as a None gradient adds nothing in torch
+                # inactive parameters hold zero gradients in the flat buffer (zeroed above): they add nothing to the norm, as a None gradient adds nothing in torch
                 _native.check(lib.escx_grad_norm_clip(p(gflat), gflat.numel(), float(self.max_grad_norm), p(aux), st))
                 clip = p(aux)
                 self.last_grad_norm = aux[0]
@@ -156,6 +161,16 @@ class FlatAdamW:
             off, n, shp = slices[pos]
             m[off:off + n].copy_(st["exp_avg"].reshape(-1)); v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
             steps[pos] = int(float(st["step"]))
+        # a checkpoint in which SOME parameters have a state entry and others do not comes from a loop where the entry-less ones never
+        # received a gradient (torch skips `p.grad is None` parameters entirely: no weight decay, no step).  The native backward writes a (zero)
+        # gradient for every parameter, so loading them as active would start decaying them: they are marked inactive (set_inactive() semantics)
+        # and the caller is told.  A checkpoint with no state at all (saved before the first step) leaves everything active.
+        missing = [pos for pos, pid in enumerate(ids) if slices[pos] is not None and sd["state"].get(pid) is None]
+        if missing and len(missing) < sum(sl is not None for sl in slices):
+            import warnings
+            self._inactive = set(missing)
+            warnings.warn(f"FlatAdamW.load_state_dict: {len(missing)} parameter(s) have no optimiser state in the checkpoint (they never received a gradient "
+                          "there); they are loaded INACTIVE (no decay, no step) - call set_inactive(()) if they take part in this loop", RuntimeWarning)
         live = {t for t, sl in zip(steps, slices) if sl is not None}
         self.t = max(live) if live else 0
         self._steps = None if len(live) <= 1 else steps   # torch keeps `step` per parameter: differing counts get their own bias corrections
