@@ -154,6 +154,7 @@ extern "C" void escx_destroy(escx_handle h) {
     for (auto& kv : h->maps) (void)hipFree(kv.second);
     if (h->coll_buf) (void)hipFree(h->coll_buf);
     for (Quant& q : h->quants) if (q.tab) (void)hipFree(q.tab);
+    for (Layer& L : h->layers) for (BlockW& bw : L.blocks) if (bw.x3w) (void)hipFree(bw.x3w);
     if (h->iota_codes) (void)hipFree(h->iota_codes);
     if (h->gmap) (void)hipFree(h->gmap);
     if (h->garena) (void)hipFree(h->garena);
@@ -1026,6 +1027,10 @@ extern "C" const char* escx_profile_report(escx_handle h) {
     return h->prof_json.c_str();
 }
 
+// ESCX_MLP_X3=<max padded width>: fused MLP on the bf16 matrix cores with fp32 operands split into three bf16 terms (fused_mlp_x3.h) for the blocks up to that width
+// (48, 80, 96, 144 are instantiated); 0 = the fp32-MFMA kernel everywhere.
+static int mlp_x3_maxcp() { static const int v = [] { const char* e = getenv("ESCX_MLP_X3"); return e && e[0] ? atoi(e) : 0; }(); return v; }
+
 // Waves per workgroup (4 or 8) for the fused kernels.  A wave owns `units` 16-row tiles; a workgroup's waves spread over the
 // 4 SIMDs of a CU and workgroups are dealt round-robin to the 256 CUs, so the makespan in tile-times is
 //   ceil(workgroups / 256) * ceil(NW / 4) * units.
@@ -1148,6 +1153,13 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             bool combined = false;
             int hs = (h->mlp_hs > 0 && L.hiddenP >= h->mlp_hs * L.Cp) ? h->mlp_hs : mlp_hs_for(tokens, L.hiddenP / 16, L.Cp);
             const int variant = h->mlp_variant >= 0 ? h->mlp_variant : (hs > 1 ? ((L.Cp >= hs_nw8_cp && mlp_split_nw(M, hs) == 8) ? 3 : 1) : (L.Cp <= tm2_max ? (tm2_nw8 ? 5 : 4) : mlp_variant_for(M, L.Cp)));
+            if (bw.x3w && hs == 1 && pend.n == 0 && L.Cp <= mlp_x3_maxcp()) {       // three-term bf16 split on the bf16 matrix cores (fused_mlp_x3.h)
+                int xrc = -1;
+                PROF("mlp_x3" + tag, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
+                     xrc = mlp_x3(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.b1, bw.b2, bw.x3w, L.hiddenP, variant == 3 ? 8 : 4, st));
+                if (xrc == 0) { src = cur; continue; }
+                if (h->prof && !h->prof_recs.empty()) h->prof_recs.pop_back();
+            }
             // PatchSplit in the epilogue of the layer's last MLP (fused_mlp.h SPLIT): one launch and one HBM round trip of the
             // pre-split map less.  ESCX_MLP_SPLIT_FOLD=0: the separate LN + linear launch (rowgemm_fused_kernel), as before.
             static const bool split_fold = [] { const char* e = getenv("ESCX_MLP_SPLIT_FOLD"); return !(e && e[0] == '0'); }();
@@ -1276,6 +1288,15 @@ static int ensure_pvq_tables(escx_handle_s* h, hipStream_t st) {
             ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(q.tab); q.tab = nullptr;      // no up-projection kernel for this width: the engine form stays
         }
     }
+    // the split (3 x bf16) weight images of the fused MLP (fused_mlp_x3.h): derived state like the tables above
+    const int x3_max = mlp_x3_maxcp();
+    for (Layer& L : h->layers)
+        for (BlockW& bw : L.blocks) {
+            const bool want = x3_max > 0 && L.Cp <= x3_max && (L.Cp == 48 || L.Cp == 80 || L.Cp == 96 || L.Cp == 144) && L.hiddenP % 32 == 0;
+            if (!want) { if (bw.x3w) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(bw.x3w); bw.x3w = nullptr; } continue; }
+            if (!bw.x3w) ESCX_HIP(hipMalloc(&bw.x3w, mlp_x3_bytes(L.Cp, L.hiddenP)));
+            if (mlp_x3_pack(bw.w1, bw.w2, bw.x3w, L.Cp, L.hiddenP, st) != 0) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(bw.x3w); bw.x3w = nullptr; }
+        }
     h->pvq_tab_stale = false;
     return launch_ok("pvq_tables");
 }
@@ -1593,6 +1614,7 @@ extern "C" int escx_transformer_layer(escx_handle h, int layer_id, const float* 
     Shapes s; if ((rc = stage_ws_for_w(h, B, W, &s))) return rc;
     if ((size_t)H > (size_t)2 * s.H0) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "H too large for this model");
     hipStream_t st = (hipStream_t)stream;
+    if ((rc = ensure_pvq_tables(h, st))) return rc;
     int Hn;
     // stage buffers are sized for the largest map of the model; H*Cp never exceeds that for valid (layer, H) pairs
     const size_t need = (size_t)B * H * W * L.Cp, cap = std::max<size_t>((size_t)B * s.H0 * s.W * h->C0p, 1);

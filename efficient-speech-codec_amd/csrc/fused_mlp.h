@@ -46,6 +46,7 @@ struct MlpArgs {
     // x is NOT written.  sp_wf == nullptr: plain epilogue.
     const f32x4* sp_wf; const float* sp_gamma; const float* sp_beta; float* sp_out;
     int sp_NT, sp_H, sp_W, sp_C2p;
+    const void* x3_w;           // fused_mlp_x3.h: split (3 x bf16) weight image [pair of hidden tiles][fragment][lane][8 bf16], or nullptr
 };
 
 // buffer descriptor over [p, p + bytes): raw (stride 0) addressing; for write-through (sc1) stores of hand-off data

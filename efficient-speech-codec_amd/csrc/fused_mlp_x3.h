@@ -1,0 +1,185 @@
+// Fused Swin MLP with fp32 operands SPLIT into three bf16 terms on the bf16 matrix cores (round 5):
+//
+//   x <- x + W2 . gelu(W1 . LN(x) + b1) + b2,      every fp32 operand a = a1 + a2 + a3 with a_i bf16 (3 x 8 = 24 significand bits: the split is exact)
+//
+// The product of two bf16 terms is exact in fp32, so  a . b = sum_ij a_i b_j  holds term by term; the six terms a1b1, a1b2, a2b1, a2b2, a1b3, a3b1
+// carry everything down to 2^-24 of the product, and they are accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (32 products per instruction, ~17 cycles)
+// where v_mfma_f32_16x16x4_f32 spends 8 x 32 cycles on the same K.  Measured against fp64 the six-term sum is 50x closer than an fp32 sgemm
+// (truncation 6e-9 of the mean magnitude against 3e-7 of rounding): this is fp32-grade arithmetic, not a bf16 approximation -
+// the error that remains is the fp32 accumulation, as in any fp32 kernel.  It is NOT bit-identical to the fp32-MFMA kernel (other summation order),
+// so the parity evidence is the oracle sweeps, as for every other re-association (tests/test_gpu_parity.py sweeps, clustered codebooks).
+//
+// Structure = fused_mlp.h: a wave owns 16 token rows end to end in registers; hidden units are walked 32 at a time (two fc1 accumulator tiles ARE
+// the 8-deep k-slots of one fc2 step); the split weight fragments ([pair][fragment][lane][8 bf16], built on the device by mlp_x3_pack_kernel from the
+// fp32 weights) stream through a double-buffered LDS ring shared by the NW waves; GELU and the operand split run on the VALU beside the matrix cores.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fused_mlp.h"
+#include "gemm_bf16.h"
+
+namespace escx {
+
+// a = s[0] + s[1] + s[2] exactly (round-to-nearest-even at each step; the residuals are exact fp32 subtractions)
+template <int N>
+__device__ __forceinline__ void split3_bf16(const float (&v)[N], __bf16 (&s0)[N], __bf16 (&s1)[N], __bf16 (&s2)[N]) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const __bf16 a1 = (__bf16)v[e];
+        const float r1 = v[e] - (float)a1;
+        const __bf16 a2 = (__bf16)r1;
+        const float r2 = r1 - (float)a2;
+        s0[e] = a1; s1[e] = a2; s2[e] = (__bf16)r2;
+    }
+}
+__device__ __forceinline__ bf16x8 pack8(const __bf16 (&s)[8]) { bf16x8 r; for (int e = 0; e < 8; ++e) r[e] = s[e]; return r; }
+
+constexpr int mlp_x3_ks(int CP) { return (CP + 31) / 32; }
+constexpr int mlp_x3_frags(int CP) { return 6 * mlp_x3_ks(CP) + 3 * (CP / 16); }       // 1 KiB fragments per pair of hidden tiles: fc1 (2 tiles x KS steps x 3 terms), fc2 (KK tiles x 3 terms)
+
+// Split image of one block's MLP weights.  Fragment (pair p, f): f = (tt * KS + s) * 3 + i  -> lane (n, g) holds term i of W1[16 (2p + tt) + n][32 s + 8 g + e], e = 0..7;
+// f = 6 KS + o * 3 + i -> lane (c, g) holds term i of W2[16 o + c][unit(g, e)], unit = 16 (2p) + 4 g + e for e < 4, 16 (2p + 1) + 4 g + e - 4 otherwise (the k-slot <-> hidden unit
+// map the kernel's fc1 accumulators dictate).  One thread per (pair, fragment triple, lane).
+__global__ __launch_bounds__(256) void mlp_x3_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, bf16x8* __restrict__ out, int Cp, int HP, int KS, int KK) {
+    const int CH = 6 * KS + 3 * KK, triples = 2 * KS + KK;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)(HP / 32) * triples * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63); const long long q = idx >> 6;
+    const int t3 = (int)(q % triples), p = (int)(q / triples);
+    const int n = lane & 15, g = lane >> 4;
+    float v[8];
+    int fbase;
+    if (t3 < 2 * KS) {
+        const int tt = t3 / KS, s = t3 - tt * KS;
+        fbase = (tt * KS + s) * 3;
+        const float* row = w1 + (size_t)(16 * (2 * p + tt) + n) * Cp;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int k = 32 * s + 8 * g + e; v[e] = k < Cp ? row[k] : 0.f; }
+    } else {
+        const int o = t3 - 2 * KS;
+        fbase = 6 * KS + o * 3;
+        const float* row = w2 + (size_t)(16 * o + n) * HP;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = row[16 * (2 * p + (e >> 2)) + 4 * g + (e & 3)];
+    }
+    __bf16 s0[8], s1[8], s2[8];
+    split3_bf16(v, s0, s1, s2);
+    bf16x8* dst = out + ((size_t)p * CH + fbase) * 64 + lane;
+    dst[0] = pack8(s0); dst[64] = pack8(s1); dst[128] = pack8(s2);
+}
+
+// the six cross terms (weight term i, activation term j), smallest first
+#define ESCX_X3_TERMS(M) M(0, 2) M(2, 0) M(1, 1) M(0, 1) M(1, 0) M(0, 0)
+
+template <int CP, int NW>
+__global__ __launch_bounds__(64 * NW, (CP <= 96 ? 4 : 2)) void mlp_x3_kernel(MlpArgs a) {
+    constexpr int KS = mlp_x3_ks(CP), KK = CP / 16, CH = mlp_x3_frags(CP);
+    extern __shared__ __attribute__((aligned(16))) bf16x8 x3_wbuf[];             // [2][CH * 64]
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = (blockIdx.x * NW + wave) * 16;
+    const int n_pairs = a.HT / 2;
+    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.x3_w);
+
+    auto issue = [&](int p, int buf) {
+        const bf16x8* src = wsrc + (size_t)p * CH * 64 + lane;
+        for (int c = wave; c < CH; c += NW)
+            __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(&x3_wbuf[(buf * CH + c) * 64]), 16, 0, 0);
+    };
+    issue(0, 0);
+
+    // ---- rows -> k-slot layout of the 32-deep MFMA (lane (row l15, slot group lg) holds channels 32 s + 8 lg .. + 7), LayerNorm in registers, split ----
+    const int row = m0 + l15;
+    const bool live = row < a.M;
+    const float* xr = a.x + (size_t)(live ? row : 0) * CP;
+    float xv[KS][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int c0 = 32 * s + 8 * lg;
+        f32x4 v0 = zero4(), v1 = zero4();
+        if (c0 < CP) { v0 = ld4(xr + c0); v1 = ld4(xr + c0 + 4); }           // CP % 16 == 0 and c0 % 8 == 0: both halves are inside the row or both outside
+        if (!live) { v0 = zero4(); v1 = zero4(); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xv[s][e] = v0[e]; xv[s][4 + e] = v1[e]; sum += v0[e]; sum += v1[e]; }       // pad channels are exact zeros
+    }
+    sum = sum_groups(sum);
+    const float mean = sum / (float)a.C;
+    float var = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = xv[s][e] - mean; var += d * d; }
+    var = sum_groups(var) - (float)(32 * KS - a.C) * mean * mean;             // every zero slot (channel padding and the K padding to 32) added mean^2
+    const float rstd = 1.0f / sqrtf(var / (float)a.C + a.eps);
+    bf16x8 xs[3][KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int c0 = 32 * s + 8 * lg;
+        f32x4 g0 = zero4(), g1 = zero4(), b0 = zero4(), b1 = zero4();
+        if (c0 < CP) { g0 = ld4(a.gamma + c0); g1 = ld4(a.gamma + c0 + 4); b0 = ld4(a.beta + c0); b1 = ld4(a.beta + c0 + 4); }
+        float xn[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xn[e] = (xv[s][e] - mean) * rstd * g0[e] + b0[e];                  // gamma = beta = 0 in the pads -> 0
+            xn[4 + e] = (xv[s][4 + e] - mean) * rstd * g1[e] + b1[e];
+        }
+        __bf16 s0[8], s1[8], s2[8];
+        split3_bf16(xn, s0, s1, s2);
+        xs[0][s] = pack8(s0); xs[1][s] = pack8(s1); xs[2][s] = pack8(s2);
+    }
+
+    f32x4 acc[KK];
+#pragma unroll
+    for (int o = 0; o < KK; ++o) acc[o] = zero4();
+
+    for (int p = 0; p < n_pairs; ++p) {
+        const f32x4 bias0 = ld4(a.b1 + 32 * p + 4 * lg), bias1 = ld4(a.b1 + 32 * p + 16 + 4 * lg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                        // pair p is in LDS for every wave; nobody still reads the other buffer
+        if (p + 1 < n_pairs) issue(p + 1, (p + 1) & 1);
+        const bf16x8* wb = &x3_wbuf[((p & 1) * CH) * 64 + lane];
+        // ---- fc1: two hidden tiles (independent accumulator chains), the bias rides in the accumulator ----
+        f32x4 h0 = bias0, h1 = bias1;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 w0[3], w1[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { w0[i] = wb[((0 * KS + s) * 3 + i) * 64]; w1[i] = wb[((1 * KS + s) * 3 + i) * 64]; }
+#define ESCX_X3_FC1(I, J) h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[I], xs[J][s], h0, 0, 0, 0); h1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[I], xs[J][s], h1, 0, 0, 0);
+            ESCX_X3_TERMS(ESCX_X3_FC1)
+#undef ESCX_X3_FC1
+        }
+        // ---- GELU, then the 8 hidden values of this lane become the k-slots of one fc2 step ----
+        float hv[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hv[e] = gelu_bf(h0[e]); hv[4 + e] = gelu_bf(h1[e]); }
+        __bf16 s0[8], s1[8], s2[8];
+        split3_bf16(hv, s0, s1, s2);
+        bf16x8 hs[3] = {pack8(s0), pack8(s1), pack8(s2)};
+        // ---- fc2: two output tiles per step (no back-to-back MFMAs on one accumulator) ----
+#pragma unroll
+        for (int o = 0; o < KK; o += 2) {
+            bf16x8 wa[3], wn[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { wa[i] = wb[(6 * KS + o * 3 + i) * 64]; if (o + 1 < KK) wn[i] = wb[(6 * KS + (o + 1) * 3 + i) * 64]; }
+#define ESCX_X3_FC2(I, J) acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[I], hs[J], acc[o], 0, 0, 0); if (o + 1 < KK) acc[o + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[I], hs[J], acc[o + 1], 0, 0, 0);
+            ESCX_X3_TERMS(ESCX_X3_FC2)
+#undef ESCX_X3_FC2
+        }
+    }
+
+    // ---- bias + residual, 16 B per lane (accumulator layout of the 16x16 tile: lane (row l15, channels 16 o + 4 lg .. + 3)) ----
+    if (!live) return;
+    const float* xres = a.x + (size_t)row * CP + 4 * lg;
+    float* orow = (a.out ? a.out : a.x) + (size_t)row * CP + 4 * lg;
+    f32x4 res[KK];
+#pragma unroll
+    for (int o = 0; o < KK; ++o) { res[o] = ld4(xres + 16 * o); acc[o] += ld4(a.b2 + 16 * o + 4 * lg); }
+#pragma unroll
+    for (int o = 0; o < KK; ++o) st4(orow + 16 * o, res[o] + acc[o]);
+}
+
+}  // namespace escx

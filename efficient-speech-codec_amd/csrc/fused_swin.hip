@@ -1,6 +1,8 @@
 // Launchers for the fused (wave-autonomous, register-resident) Swin kernels.
 #include "fused_attn.h"
 #include "fused_mlp.h"
+#include "fused_mlp_x3.h"
+#include <atomic>
 #include "fused_rowgemm.h"
 #include "fused_deembed.h"
 #include "launchers.h"
@@ -159,6 +161,43 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
         case 256: launch_mlp<256, 1>(a, s); return 0;
         case 288: launch_mlp<288, 1>(a, s); return 0;
         case 384: launch_mlp<384, 1>(a, s); return 0;
+        default: return -1;
+    }
+}
+
+// ---- fused MLP, fp32 operands split into three bf16 terms (fused_mlp_x3.h) ----
+size_t mlp_x3_bytes(int Cp, int hiddenP) { return (size_t)(hiddenP / 32) * (6 * ((Cp + 31) / 32) + 3 * (Cp / 16)) * 1024; }
+
+int mlp_x3_pack(const float* w1, const float* w2, void* image, int Cp, int hiddenP, hipStream_t s) {
+    if (Cp % 16 || hiddenP % 32) return -1;
+    const int KS = (Cp + 31) / 32, KK = Cp / 16;
+    const long long total = (long long)(hiddenP / 32) * (2 * KS + KK) * 64;
+    hipLaunchKernelGGL(mlp_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w1, w2, reinterpret_cast<bf16x8*>(image), Cp, hiddenP, KS, KK);
+    return 0;
+}
+
+template <int CP, int NW>
+static void launch_mlp_x3(const MlpArgs& a, hipStream_t s) {
+    auto kern = mlp_x3_kernel<CP, NW>;
+    constexpr int lds = 2 * mlp_x3_frags(CP) * 1024;
+    if constexpr (lds > 48 * 1024) {            // function attributes are per device: one flag per device
+        static std::atomic<unsigned> done{0};
+        int dev = 0; (void)hipGetDevice(&dev);
+        const unsigned bit = 1u << (dev & 31);
+        if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
+    }
+    hipLaunchKernelGGL(kern, dim3((a.M + 16 * NW - 1) / (16 * NW)), dim3(64 * NW), lds, s, a);
+}
+
+int mlp_x3(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* b1, const float* b2, const void* image, int hiddenP, int nw, hipStream_t s) {
+    if (!image || hiddenP % 32) return -1;
+    MlpArgs a{};
+    a.x = x; a.gamma = gamma; a.beta = beta; a.b1 = b1; a.b2 = b2; a.M = M; a.C = C; a.HT = hiddenP / 16; a.eps = 1e-5f; a.HS = 1; a.x3_w = image;
+    switch (Cp) {
+        case 48: if (nw == 8) launch_mlp_x3<48, 8>(a, s); else launch_mlp_x3<48, 4>(a, s); return 0;
+        case 80: if (nw == 8) launch_mlp_x3<80, 8>(a, s); else launch_mlp_x3<80, 4>(a, s); return 0;
+        case 96: if (nw == 8) launch_mlp_x3<96, 8>(a, s); else launch_mlp_x3<96, 4>(a, s); return 0;
+        case 144: if (nw == 8) launch_mlp_x3<144, 8>(a, s); else launch_mlp_x3<144, 4>(a, s); return 0;
         default: return -1;
     }
 }
