@@ -42,6 +42,10 @@ NUM_STREAMS = 6
 FLOP_PER_CLIP = 56.75e9            # BASELINE.md section 3 (2xMAC over linear/bmm/conv, S=6)
 PEAK_F32_MFMA = 157.3e12           # MI355X_MICROARCH.md chip table
 PEAK_HBM = 8.0e12
+CODEC_DTYPE = ("f32" if os.environ.get("ESCX_MLP_X3") == "0" else
+               "f32 (fp32 storage and accumulation everywhere; in the fused MLPs every fp32 operand is split EXACTLY into three bf16 terms and the six leading "
+               "cross products run on the bf16 MFMA: fp32-grade error, tests/test_gpu_parity.py::test_layer_accuracy_against_fp64; ESCX_MLP_X3=0 = fp32 MFMA only, see fp32_mfma_only)")
+PEAK_BF16_MFMA = 2500e12          # dense bf16 (MI355X_MICROARCH.md): the fused MLPs issue six bf16 cross-term MFMAs per fp32 product (fused_mlp_x3.h)
 
 
 def base_config():
@@ -156,6 +160,13 @@ def workload_name(strong, total, world, counts):
             f"(BASELINE configs[{1 if world == 1 else 3}])")
 
 
+def group_frac(r):
+    """Fraction of the matrix-core peak of one launch group (record of escx_profile_report): the split-operand MLPs (mlp_x3*) issue six bf16 MFMA
+    cross terms per fp32 product and are priced against the dense bf16 peak, everything else against the fp32 MFMA peak."""
+    rate = r["flops"] / max(r["ms"], 1e-9) * 1e3                  # algorithmic FLOP/s
+    return 6.0 * rate / PEAK_BF16_MFMA if r["name"].startswith("mlp_x3") else rate / PEAK_F32_MFMA
+
+
 def kernel_symbol(group):
     """Launch-group name of the library's profiler -> the kernel template it launches (how the same kernel appears in rocprofv3's
     kernel_stats.csv); the trailing template arguments (waves per workgroup, ...) depend on the grid and are left open."""
@@ -164,7 +175,7 @@ def kernel_symbol(group):
     if not m:
         return group
     cp = (int(m.group(2)) + 15) // 16 * 16
-    fam = {"mlp_fused": "mlp_fused_lds_kernel", "attn_fused": "attn_packed_kernel" if cp == 384 else "attn_fused_kernel",
+    fam = {"mlp_fused": "mlp_fused_lds_kernel", "mlp_x3": "mlp_x3_kernel", "attn_fused": "attn_packed_kernel" if cp == 384 else "attn_fused_kernel",
            "mlp_combine": "rows_combine_kernel", "attn_combine": "rows_combine_kernel"}.get(m.group(1), m.group(1))
     return f"escx::{fam}<{cp}, ...>"
 
@@ -466,6 +477,23 @@ def run_train_adv(args, rank, world, device, use_dist, emit=True):
     print(json.dumps(out))
 
 
+def fp32_mfma_only_rider(args):
+    """The same workload with every contraction on the fp32 MFMA (ESCX_MLP_X3=0, the round-4 arithmetic): a child process (the library reads the switch once),
+    same steps, no riders.  Reported next to the headline so that both arithmetic choices are driver-observed."""
+    import subprocess
+    env = dict(os.environ, ESCX_MLP_X3="0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline", "--skip-isolated",
+           "--skip-single-clip", "--skip-other-workloads", "--profile-steps", "2"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
+                "note": "ESCX_MLP_X3=0: fused MLPs on v_mfma_f32_16x16x4_f32 (bit-identical to round 4's results)"}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def other_workloads(args, device):
     """the driver runs ONE command (codec mode).  After its timed region, the training step (ESC-Base, non-adversarial) and
     BASELINE configs[4] (ESC-Large + adversarial step) run for a few steps each and ride along in the JSON line, so that their numbers are
@@ -679,7 +707,16 @@ def main():
                     traffic_note = "profiles/pmc_dominant.json was measured on different kernel sources: not reported"
             except Exception as e:
                 traffic_note = f"unreadable PMC file: {e}"
-        if mfma_bound:
+        if mfma_bound and dom["name"].startswith("mlp_x3"):
+            # the split-operand MLP runs on the BF16 matrix cores: six bf16 cross-term MFMAs per fp32 product, so the instruction stream executes 6 x the
+            # algorithmic FLOPs (K padding to 32 not counted) and is priced against the dense bf16 peak; the fp32-equivalent rate rides along
+            ach = 6.0 * flops_per_launch / avg_s
+            roofline = {"bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_BF16_MFMA, 4), "traffic": traffic,
+                        "peak_of": "dense bf16 MFMA (v_mfma_f32_16x16x32_bf16); achieved = 6 cross-term products x algorithmic FLOPs / launch time",
+                        "algorithmic_fp32_tflops": round(flops_per_launch / avg_s / 1e12, 3),
+                        "algorithmic_frac_of_fp32_mfma_peak": round(flops_per_launch / avg_s / PEAK_F32_MFMA, 4)}
+        elif mfma_bound:
             ach = flops_per_launch / avg_s
             roofline = {"bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": traffic}
@@ -697,7 +734,7 @@ def main():
                          "kernel_symbol": kernel_symbol(dom["name"]),
                          "top3": [{"kernel": r["name"], "kernel_symbol": kernel_symbol(r["name"]), "share_of_gpu_time": round(r["ms"] / tot, 4),
                                    "avg_us": round(r["ms"] / r["calls"] * 1e3, 2),
-                                   "frac": round(r["flops"] / max(r["ms"], 1e-9) / 1e9 / (PEAK_F32_MFMA / 1e12), 4)} for r in top3],
+                                   "frac": round(group_frac(r), 4)} for r in top3],
                          "executed_gflop_per_clip": round(sum(r["flops"] for r in recs) / args.profile_steps / n_local / 1e9, 2)})
         if not args.skip_isolated:
             # the same kernel timed alone on the GPU (batch parts back to back instead of overlapped)
@@ -712,12 +749,14 @@ def main():
                 if t["kernel"] in iso:
                     ri = iso[t["kernel"]]
                     t["isolated_avg_us"] = round(ri["ms"] / ri["calls"] * 1e3, 2)
-                    t["isolated_frac"] = round(ri["flops"] / max(ri["ms"], 1e-9) / 1e9 / (PEAK_F32_MFMA / 1e12), 4)
+                    t["isolated_frac"] = round(group_frac(ri), 4)
             if dom["name"] in iso:
                 r = iso[dom["name"]]
                 iso_s = r["ms"] / r["calls"] * 1e-3
                 roofline["isolated_avg_us"] = round(iso_s * 1e6, 2)
-                roofline["isolated_frac"] = round((flops_per_launch / iso_s / PEAK_F32_MFMA) if mfma_bound else (bytes_per_launch / iso_s / PEAK_HBM), 4)
+                x3 = dom["name"].startswith("mlp_x3")
+                roofline["isolated_frac"] = round(((6.0 * flops_per_launch / iso_s / PEAK_BF16_MFMA) if x3 else (flops_per_launch / iso_s / PEAK_F32_MFMA)) if mfma_bound
+                                                  else (bytes_per_launch / iso_s / PEAK_HBM), 4)
             if os.environ.get("ESCX_BENCH_BREAKDOWN"):
                 recs = sorted(iso.values(), key=lambda r: -r["ms"])      # the isolated timings are the readable ones
                 for r in recs:
@@ -745,7 +784,7 @@ def main():
             "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": n_ranks, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_median": step_stats["median_ms"],
             "per_step": step_stats, "higher_is_better": True,
-            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": CODEC_DTYPE, "data": "synthetic",
             "config": {"workload": workload_name(strong, total_clips, world, counts),
                        "global_batch": total_clips, "clip_samples": N_SAMPLES, "num_streams": NUM_STREAMS,
                        "parallelism": f"dp{world}" + ((" + all_gather(codes int16" + (", escx_allgather_codes C ABI" if abi_gather is not None else ", torch.distributed")
@@ -766,6 +805,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, sd, x_cpu)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not use_dist and not args.skip_other_workloads and os.environ.get("ESCX_MLP_X3") != "0":
+            out["fp32_mfma_only"] = fp32_mfma_only_rider(args)
         if world == 1 and not use_dist and not args.skip_other_workloads:
             del model, x, allc, wave
             import gc

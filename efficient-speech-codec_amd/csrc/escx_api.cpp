@@ -1027,9 +1027,10 @@ extern "C" const char* escx_profile_report(escx_handle h) {
     return h->prof_json.c_str();
 }
 
-// ESCX_MLP_X3=<max padded width>: fused MLP on the bf16 matrix cores with fp32 operands split into three bf16 terms (fused_mlp_x3.h) for the blocks up to that width
-// (48, 80, 96, 144 are instantiated); 0 = the fp32-MFMA kernel everywhere.
-static int mlp_x3_maxcp() { static const int v = [] { const char* e = getenv("ESCX_MLP_X3"); return e && e[0] ? atoi(e) : 0; }(); return v; }
+// Fused MLP on the bf16 matrix cores with every fp32 operand split exactly into three bf16 terms (fused_mlp_x3.h): DEFAULT for every instantiated width
+// (48, 80, 96, 144, 192, 384).  ESCX_MLP_X3=<max padded width> restricts it, ESCX_MLP_X3=0 = the fp32-MFMA kernel (fused_mlp.h) everywhere - the
+// round-4 arithmetic, which bench.py also reports (`fp32_mfma_only`) and tests/test_gpu_parity.py keeps as an arm.
+static int mlp_x3_maxcp() { static const int v = [] { const char* e = getenv("ESCX_MLP_X3"); return e && e[0] ? atoi(e) : 384; }(); return v; }
 
 // Waves per workgroup (4 or 8) for the fused kernels.  A wave owns `units` 16-row tiles; a workgroup's waves spread over the
 // 4 SIMDs of a CU and workgroups are dealt round-robin to the 256 CUs, so the makespan in tile-times is
@@ -1153,11 +1154,14 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             bool combined = false;
             int hs = (h->mlp_hs > 0 && L.hiddenP >= h->mlp_hs * L.Cp) ? h->mlp_hs : mlp_hs_for(tokens, L.hiddenP / 16, L.Cp);
             const int variant = h->mlp_variant >= 0 ? h->mlp_variant : (hs > 1 ? ((L.Cp >= hs_nw8_cp && mlp_split_nw(M, hs) == 8) ? 3 : 1) : (L.Cp <= tm2_max ? (tm2_nw8 ? 5 : 4) : mlp_variant_for(M, L.Cp)));
-            if (bw.x3w && hs == 1 && pend.n == 0 && L.Cp <= mlp_x3_maxcp()) {       // three-term bf16 split on the bf16 matrix cores (fused_mlp_x3.h)
-                int xrc = -1;
+            if (bw.x3w && pend.n == 0 && L.Cp <= mlp_x3_maxcp()) {       // three-term bf16 split on the bf16 matrix cores (fused_mlp_x3.h); same hidden-split rule and combine
+                int xrc = -1, xhs = hs;
                 PROF("mlp_x3" + tag, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
-                     xrc = mlp_x3(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.b1, bw.b2, bw.x3w, L.hiddenP, variant == 3 ? 8 : 4, st));
-                if (xrc == 0) { src = cur; continue; }
+                     xrc = mlp_x3(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.b1, bw.b2, bw.x3w, L.hiddenP, (variant == 3 && L.Cp < 384) ? 8 : 4, &xhs, h->hid, st));      // C = 384: 4 waves (352 registers, one wave per SIMD; 8 waves would cap it at 256 and spill)
+                if (xrc == 0) {
+                    if (xhs > 1) { pend = CombineOnLoad{h->hid, bw.b2, (long long)M * L.Cp, xhs}; pend_tag = tag; flush_pending(); }
+                    src = cur; continue;
+                }
                 if (h->prof && !h->prof_recs.empty()) h->prof_recs.pop_back();
             }
             // PatchSplit in the epilogue of the layer's last MLP (fused_mlp.h SPLIT): one launch and one HBM round trip of the
@@ -1292,7 +1296,7 @@ static int ensure_pvq_tables(escx_handle_s* h, hipStream_t st) {
     const int x3_max = mlp_x3_maxcp();
     for (Layer& L : h->layers)
         for (BlockW& bw : L.blocks) {
-            const bool want = x3_max > 0 && L.Cp <= x3_max && (L.Cp == 48 || L.Cp == 80 || L.Cp == 96 || L.Cp == 144) && L.hiddenP % 32 == 0;
+            const bool want = x3_max > 0 && L.Cp <= x3_max && (L.Cp == 48 || L.Cp == 80 || L.Cp == 96 || L.Cp == 144 || L.Cp == 192 || L.Cp == 384) && L.hiddenP % 32 == 0;
             if (!want) { if (bw.x3w) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(bw.x3w); bw.x3w = nullptr; } continue; }
             if (!bw.x3w) ESCX_HIP(hipMalloc(&bw.x3w, mlp_x3_bytes(L.Cp, L.hiddenP)));
             if (mlp_x3_pack(bw.w1, bw.w2, bw.x3w, L.Cp, L.hiddenP, st) != 0) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(bw.x3w); bw.x3w = nullptr; }

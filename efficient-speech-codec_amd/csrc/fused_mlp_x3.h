@@ -35,11 +35,21 @@ __device__ __forceinline__ void split3_bf16(const float (&v)[N], __bf16 (&s0)[N]
 __device__ __forceinline__ bf16x8 pack8(const __bf16 (&s)[8]) { bf16x8 r; for (int e = 0; e < 8; ++e) r[e] = s[e]; return r; }
 
 constexpr int mlp_x3_ks(int CP) { return (CP + 31) / 32; }
-constexpr int mlp_x3_frags(int CP) { return 6 * mlp_x3_ks(CP) + 3 * (CP / 16); }       // 1 KiB fragments per pair of hidden tiles: fc1 (2 tiles x KS steps x 3 terms), fc2 (KK tiles x 3 terms)
+constexpr int mlp_x3_frags(int CP) { return 6 * mlp_x3_ks(CP) + 3 * (CP / 16); }       // 1 KiB fragments per pair of hidden tiles: fc1 (KS steps x 2 tiles x 3 terms), fc2 (KK tiles x 3 terms)
+// LDS staging.  Narrow layers (<= 36 fragments per pair): ONE stage per pair.  Wide layers: fc1 in stages of up to 6 K-steps (36 KiB), fc2 in stages of up to 6 pairs of
+// output tiles (36 KiB); two ring slots of the largest stage.
+constexpr int MLP_X3_STAGE = 36;
+constexpr bool mlp_x3_single(int CP) { return mlp_x3_frags(CP) <= MLP_X3_STAGE; }
+constexpr int mlp_x3_g1(int CP) { return mlp_x3_single(CP) ? mlp_x3_ks(CP) : (mlp_x3_ks(CP) <= 6 ? mlp_x3_ks(CP) : 6); }                    // K-steps per fc1 stage
+constexpr int mlp_x3_g2(int CP) { return mlp_x3_single(CP) ? (CP / 16 + 1) / 2 : ((CP / 16 + 1) / 2 <= 6 ? (CP / 16 + 1) / 2 : 6); }           // output-tile pairs per fc2 stage
+constexpr int mlp_x3_stage_frags(int CP) {
+    return mlp_x3_single(CP) ? mlp_x3_frags(CP) : (6 * mlp_x3_g1(CP) > 6 * mlp_x3_g2(CP) ? 6 * mlp_x3_g1(CP) : 6 * mlp_x3_g2(CP));
+}
 
-// Split image of one block's MLP weights.  Fragment (pair p, f): f = (tt * KS + s) * 3 + i  -> lane (n, g) holds term i of W1[16 (2p + tt) + n][32 s + 8 g + e], e = 0..7;
-// f = 6 KS + o * 3 + i -> lane (c, g) holds term i of W2[16 o + c][unit(g, e)], unit = 16 (2p) + 4 g + e for e < 4, 16 (2p + 1) + 4 g + e - 4 otherwise (the k-slot <-> hidden unit
-// map the kernel's fc1 accumulators dictate).  One thread per (pair, fragment triple, lane).
+// Split image of one block's MLP weights, fragments in CONSUMPTION order.  Pair p of hidden tiles (2p, 2p + 1):
+//   fc1 fragment f = (s * 2 + tt) * 3 + i          -> lane (n, g) holds term i of W1[16 (2p + tt) + n][32 s + 8 g + e], e = 0..7 (zero beyond Cp)
+//   fc2 fragment f = 6 KS + o * 3 + i              -> lane (c, g) holds term i of W2[16 o + c][unit(g, e)], unit = 16 (2p) + 4 g + e for e < 4, 16 (2p + 1) + 4 g + e - 4 otherwise
+// (the k-slot <-> hidden unit map the kernel's two fc1 accumulator tiles dictate).  One thread per (pair, fragment triple, lane).
 __global__ __launch_bounds__(256) void mlp_x3_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, bf16x8* __restrict__ out, int Cp, int HP, int KS, int KK) {
     const int CH = 6 * KS + 3 * KK, triples = 2 * KS + KK;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -51,8 +61,8 @@ __global__ __launch_bounds__(256) void mlp_x3_pack_kernel(const float* __restric
     float v[8];
     int fbase;
     if (t3 < 2 * KS) {
-        const int tt = t3 / KS, s = t3 - tt * KS;
-        fbase = (tt * KS + s) * 3;
+        const int s = t3 >> 1, tt = t3 & 1;
+        fbase = t3 * 3;
         const float* row = w1 + (size_t)(16 * (2 * p + tt) + n) * Cp;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const int k = 32 * s + 8 * g + e; v[e] = k < Cp ? row[k] : 0.f; }
@@ -72,82 +82,122 @@ __global__ __launch_bounds__(256) void mlp_x3_pack_kernel(const float* __restric
 // the six cross terms (weight term i, activation term j), smallest first
 #define ESCX_X3_TERMS(M) M(0, 2) M(2, 0) M(1, 1) M(0, 1) M(1, 0) M(0, 0)
 
+template <int CP> constexpr int mlp_x3_min_waves() { return CP <= 96 ? 4 : (CP <= 192 ? 2 : 1); }
+
 template <int CP, int NW>
-__global__ __launch_bounds__(64 * NW, (CP <= 96 ? 4 : 2)) void mlp_x3_kernel(MlpArgs a) {
-    constexpr int KS = mlp_x3_ks(CP), KK = CP / 16, CH = mlp_x3_frags(CP);
-    extern __shared__ __attribute__((aligned(16))) bf16x8 x3_wbuf[];             // [2][CH * 64]
+__global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kernel(MlpArgs a) {
+    constexpr int KS = mlp_x3_ks(CP), KK = CP / 16, CH = mlp_x3_frags(CP), NOP = (KK + 1) / 2;
+    constexpr bool SINGLE = mlp_x3_single(CP);
+    constexpr int G1 = mlp_x3_g1(CP), G2 = mlp_x3_g2(CP), NS1 = (KS + G1 - 1) / G1, NS2 = (NOP + G2 - 1) / G2;
+    constexpr int NSP = SINGLE ? 1 : NS1 + NS2;                                   // stages per pair
+    constexpr int SF = mlp_x3_stage_frags(CP);                                   // ring slot size in fragments
+    extern __shared__ __attribute__((aligned(16))) bf16x8 x3_wbuf[];             // [2][SF * 64]
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int m0 = (blockIdx.x * NW + wave) * 16;
-    const int n_pairs = a.HT / 2;
+    // hidden split (fused_mlp.h): workgroup (rb, hs) walks a third of the hidden pairs and writes raw fc2 partial sums; same XCD-aware block order
+    const int HS = a.HS > 1 ? a.HS : 1;
+    int rb = blockIdx.x, hs = 0;
+    if (HS > 1) {
+        const int nrb = (a.M + 16 * NW - 1) / (16 * NW), full = nrb & ~7, i = blockIdx.x;
+        if (i < full * HS) { const int grp = i / (8 * HS), r = i - grp * (8 * HS); rb = grp * 8 + (r & 7); hs = r >> 3; }
+        else { const int j = i - full * HS; rb = full + j / HS; hs = j - (j / HS) * HS; }
+    }
+    const int n_pairs_all = a.HT / 2;
+    const int p0 = hs * (n_pairs_all / HS), p1 = p0 + n_pairs_all / HS;
+    const int m0 = (rb * NW + wave) * 16;
     const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.x3_w);
 
-    auto issue = [&](int p, int buf) {
-        const bf16x8* src = wsrc + (size_t)p * CH * 64 + lane;
-        for (int c = wave; c < CH; c += NW)
-            __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(&x3_wbuf[(buf * CH + c) * 64]), 16, 0, 0);
+    // stage g (global counter over the pairs this workgroup walks): its fragments and where they start inside the pair's image
+    auto stage_off = [&](int k) -> int {        // k = stage index inside a pair
+        if (SINGLE) return 0;
+        return k < NS1 ? 6 * G1 * k : 6 * KS + 6 * G2 * (k - NS1);
     };
-    issue(0, 0);
+    auto stage_cnt = [&](int k) -> int {
+        if (SINGLE) return CH;
+        if (k < NS1) return 6 * (k + 1 < NS1 ? G1 : KS - G1 * (NS1 - 1));
+        const int pairs_before = G2 * (k - NS1), tiles = min(KK - 2 * pairs_before, 2 * G2);
+        return 3 * tiles;
+    };
+    auto issue = [&](int g) {                   // g counts stages from the first pair of this workgroup
+        const int p = p0 + g / NSP, k = g - (g / NSP) * NSP;
+        if (p >= p1) return;
+        const bf16x8* src = wsrc + ((size_t)p * CH + stage_off(k)) * 64 + lane;
+        bf16x8* dst = &x3_wbuf[((g & 1) * SF) * 64];
+        const int cnt = stage_cnt(k);
+        for (int c = wave; c < cnt; c += NW)
+            __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(dst + c * 64), 16, 0, 0);
+    };
+    issue(0);
 
     // ---- rows -> k-slot layout of the 32-deep MFMA (lane (row l15, slot group lg) holds channels 32 s + 8 lg .. + 7), LayerNorm in registers, split ----
     const int row = m0 + l15;
     const bool live = row < a.M;
     const float* xr = a.x + (size_t)(live ? row : 0) * CP;
-    float xv[KS][8];
-    float sum = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int c0 = 32 * s + 8 * lg;
-        f32x4 v0 = zero4(), v1 = zero4();
-        if (c0 < CP) { v0 = ld4(xr + c0); v1 = ld4(xr + c0 + 4); }           // CP % 16 == 0 and c0 % 8 == 0: both halves are inside the row or both outside
-        if (!live) { v0 = zero4(); v1 = zero4(); }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { xv[s][e] = v0[e]; xv[s][4 + e] = v1[e]; sum += v0[e]; sum += v1[e]; }       // pad channels are exact zeros
-    }
-    sum = sum_groups(sum);
-    const float mean = sum / (float)a.C;
-    float var = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = xv[s][e] - mean; var += d * d; }
-    var = sum_groups(var) - (float)(32 * KS - a.C) * mean * mean;             // every zero slot (channel padding and the K padding to 32) added mean^2
-    const float rstd = 1.0f / sqrtf(var / (float)a.C + a.eps);
     bf16x8 xs[3][KS];
+    {
+        float xv[KS][8];
+        float sum = 0.f;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int c0 = 32 * s + 8 * lg;
-        f32x4 g0 = zero4(), g1 = zero4(), b0 = zero4(), b1 = zero4();
-        if (c0 < CP) { g0 = ld4(a.gamma + c0); g1 = ld4(a.gamma + c0 + 4); b0 = ld4(a.beta + c0); b1 = ld4(a.beta + c0 + 4); }
-        float xn[8];
+        for (int s = 0; s < KS; ++s) {
+            const int c0 = 32 * s + 8 * lg;
+            f32x4 v0 = zero4(), v1 = zero4();
+            if (c0 < CP) { v0 = ld4(xr + c0); v1 = ld4(xr + c0 + 4); }           // CP % 16 == 0 and c0 % 8 == 0: both halves are inside the row or both outside
+            if (!live) { v0 = zero4(); v1 = zero4(); }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            xn[e] = (xv[s][e] - mean) * rstd * g0[e] + b0[e];                  // gamma = beta = 0 in the pads -> 0
-            xn[4 + e] = (xv[s][4 + e] - mean) * rstd * g1[e] + b1[e];
+            for (int e = 0; e < 4; ++e) { xv[s][e] = v0[e]; xv[s][4 + e] = v1[e]; sum += v0[e]; sum += v1[e]; }       // pad channels are exact zeros
         }
-        __bf16 s0[8], s1[8], s2[8];
-        split3_bf16(xn, s0, s1, s2);
-        xs[0][s] = pack8(s0); xs[1][s] = pack8(s1); xs[2][s] = pack8(s2);
+        sum = sum_groups(sum);
+        const float mean = sum / (float)a.C;
+        float var = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = xv[s][e] - mean; var += d * d; }
+        var = sum_groups(var) - (float)(32 * KS - a.C) * mean * mean;             // every zero slot (channel padding and the K padding to 32) added mean^2
+        const float rstd = 1.0f / sqrtf(var / (float)a.C + a.eps);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c0 = 32 * s + 8 * lg;
+            f32x4 g0 = zero4(), g1 = zero4(), b0 = zero4(), b1 = zero4();
+            if (c0 < CP) { g0 = ld4(a.gamma + c0); g1 = ld4(a.gamma + c0 + 4); b0 = ld4(a.beta + c0); b1 = ld4(a.beta + c0 + 4); }
+            float xn[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xn[e] = (xv[s][e] - mean) * rstd * g0[e] + b0[e];                  // gamma = beta = 0 in the pads -> 0
+                xn[4 + e] = (xv[s][4 + e] - mean) * rstd * g1[e] + b1[e];
+            }
+            __bf16 s0[8], s1[8], s2[8];
+            split3_bf16(xn, s0, s1, s2);
+            xs[0][s] = pack8(s0); xs[1][s] = pack8(s1); xs[2][s] = pack8(s2);
+        }
     }
 
     f32x4 acc[KK];
 #pragma unroll
     for (int o = 0; o < KK; ++o) acc[o] = zero4();
 
-    for (int p = 0; p < n_pairs; ++p) {
-        const f32x4 bias0 = ld4(a.b1 + 32 * p + 4 * lg), bias1 = ld4(a.b1 + 32 * p + 16 + 4 * lg);
+    int g = 0;                                  // stage counter
+    auto next_stage = [&]() -> const bf16x8* {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                        // pair p is in LDS for every wave; nobody still reads the other buffer
-        if (p + 1 < n_pairs) issue(p + 1, (p + 1) & 1);
-        const bf16x8* wb = &x3_wbuf[((p & 1) * CH) * 64 + lane];
+        __syncthreads();                        // stage g is in LDS for every wave; nobody still reads the other slot
+        issue(g + 1);
+        const bf16x8* wb = &x3_wbuf[((g & 1) * SF) * 64 + lane];
+        ++g;
+        return wb;
+    };
+    for (int p = p0; p < p1; ++p) {
+        const f32x4 bias0 = ld4(a.b1 + 32 * p + 4 * lg), bias1 = ld4(a.b1 + 32 * p + 16 + 4 * lg);
+        const bf16x8* wb = nullptr;
         // ---- fc1: two hidden tiles (independent accumulator chains), the bias rides in the accumulator ----
         f32x4 h0 = bias0, h1 = bias1;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
+            if (s % G1 == 0) wb = next_stage();
+            const bf16x8* wf = wb + (size_t)((s % G1) * 6) * 64;
             bf16x8 w0[3], w1[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { w0[i] = wb[((0 * KS + s) * 3 + i) * 64]; w1[i] = wb[((1 * KS + s) * 3 + i) * 64]; }
+            for (int i = 0; i < 3; ++i) { w0[i] = wf[i * 64]; w1[i] = wf[(3 + i) * 64]; }
 #define ESCX_X3_FC1(I, J) h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[I], xs[J][s], h0, 0, 0, 0); h1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[I], xs[J][s], h1, 0, 0, 0);
             ESCX_X3_TERMS(ESCX_X3_FC1)
 #undef ESCX_X3_FC1
@@ -158,21 +208,31 @@ __global__ __launch_bounds__(64 * NW, (CP <= 96 ? 4 : 2)) void mlp_x3_kernel(Mlp
         for (int e = 0; e < 4; ++e) { hv[e] = gelu_bf(h0[e]); hv[4 + e] = gelu_bf(h1[e]); }
         __bf16 s0[8], s1[8], s2[8];
         split3_bf16(hv, s0, s1, s2);
-        bf16x8 hs[3] = {pack8(s0), pack8(s1), pack8(s2)};
+        const bf16x8 hs3[3] = {pack8(s0), pack8(s1), pack8(s2)};
         // ---- fc2: two output tiles per step (no back-to-back MFMAs on one accumulator) ----
+        const bf16x8* w2b = SINGLE ? wb + (size_t)(6 * KS) * 64 : nullptr;
 #pragma unroll
-        for (int o = 0; o < KK; o += 2) {
+        for (int op = 0; op < NOP; ++op) {
+            if (!SINGLE && op % G2 == 0) w2b = next_stage();
+            const int o = 2 * op;
+            const bf16x8* wf = w2b + (size_t)((SINGLE ? op : op % G2) * 6) * 64;
             bf16x8 wa[3], wn[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { wa[i] = wb[(6 * KS + o * 3 + i) * 64]; if (o + 1 < KK) wn[i] = wb[(6 * KS + (o + 1) * 3 + i) * 64]; }
-#define ESCX_X3_FC2(I, J) acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[I], hs[J], acc[o], 0, 0, 0); if (o + 1 < KK) acc[o + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[I], hs[J], acc[o + 1], 0, 0, 0);
+            for (int i = 0; i < 3; ++i) { wa[i] = wf[i * 64]; if (o + 1 < KK) wn[i] = wf[(3 + i) * 64]; }
+#define ESCX_X3_FC2(I, J) acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[I], hs3[J], acc[o], 0, 0, 0); if (o + 1 < KK) acc[o + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[I], hs3[J], acc[o + 1], 0, 0, 0);
             ESCX_X3_TERMS(ESCX_X3_FC2)
 #undef ESCX_X3_FC2
         }
     }
 
-    // ---- bias + residual, 16 B per lane (accumulator layout of the 16x16 tile: lane (row l15, channels 16 o + 4 lg .. + 3)) ----
     if (!live) return;
+    if (HS > 1) {               // raw fc2 partial sums; bias + residual are applied by rows_combine_kernel
+        float* pr = a.partial + ((size_t)hs * a.M + row) * CP + 4 * lg;
+#pragma unroll
+        for (int o = 0; o < KK; ++o) st4(pr + 16 * o, acc[o]);
+        return;
+    }
+    // ---- bias + residual, 16 B per lane (accumulator layout of the 16x16 tile: lane (row l15, channels 16 o + 4 lg .. + 3)) ----
     const float* xres = a.x + (size_t)row * CP + 4 * lg;
     float* orow = (a.out ? a.out : a.x) + (size_t)row * CP + 4 * lg;
     f32x4 res[KK];

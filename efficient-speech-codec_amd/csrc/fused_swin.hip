@@ -179,27 +179,32 @@ int mlp_x3_pack(const float* w1, const float* w2, void* image, int Cp, int hidde
 template <int CP, int NW>
 static void launch_mlp_x3(const MlpArgs& a, hipStream_t s) {
     auto kern = mlp_x3_kernel<CP, NW>;
-    constexpr int lds = 2 * mlp_x3_frags(CP) * 1024;
+    constexpr int lds = 2 * mlp_x3_stage_frags(CP) * 1024;
     if constexpr (lds > 48 * 1024) {            // function attributes are per device: one flag per device
         static std::atomic<unsigned> done{0};
         int dev = 0; (void)hipGetDevice(&dev);
         const unsigned bit = 1u << (dev & 31);
         if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
     }
-    hipLaunchKernelGGL(kern, dim3((a.M + 16 * NW - 1) / (16 * NW)), dim3(64 * NW), lds, s, a);
+    const int hs = a.HS > 1 ? a.HS : 1;
+    hipLaunchKernelGGL(kern, dim3(((a.M + 16 * NW - 1) / (16 * NW)) * hs), dim3(64 * NW), lds, s, a);
 }
 
-int mlp_x3(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* b1, const float* b2, const void* image, int hiddenP, int nw, hipStream_t s) {
+// *hs_io: requested hidden split in, split used out (> 1: x untouched, partial[hs][M][Cp] filled, the caller runs rows_combine) - as mlp_fused
+int mlp_x3(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* b1, const float* b2, const void* image, int hiddenP, int nw, int* hs_io, float* partial,
+           hipStream_t s) {
     if (!image || hiddenP % 32) return -1;
+    int hs = hs_io ? *hs_io : 1;
+    if (hs > 1 && (!partial || (hiddenP / 32) % hs)) hs = 1;
+    if (hs_io) *hs_io = hs;
     MlpArgs a{};
-    a.x = x; a.gamma = gamma; a.beta = beta; a.b1 = b1; a.b2 = b2; a.M = M; a.C = C; a.HT = hiddenP / 16; a.eps = 1e-5f; a.HS = 1; a.x3_w = image;
+    a.x = x; a.gamma = gamma; a.beta = beta; a.b1 = b1; a.b2 = b2; a.M = M; a.C = C; a.HT = hiddenP / 16; a.eps = 1e-5f; a.HS = hs; a.partial = partial; a.x3_w = image;
+#define ESCX_X3_CASE(CPV) case CPV: if (nw == 8) launch_mlp_x3<CPV, 8>(a, s); else launch_mlp_x3<CPV, 4>(a, s); return 0;
     switch (Cp) {
-        case 48: if (nw == 8) launch_mlp_x3<48, 8>(a, s); else launch_mlp_x3<48, 4>(a, s); return 0;
-        case 80: if (nw == 8) launch_mlp_x3<80, 8>(a, s); else launch_mlp_x3<80, 4>(a, s); return 0;
-        case 96: if (nw == 8) launch_mlp_x3<96, 8>(a, s); else launch_mlp_x3<96, 4>(a, s); return 0;
-        case 144: if (nw == 8) launch_mlp_x3<144, 8>(a, s); else launch_mlp_x3<144, 4>(a, s); return 0;
+        ESCX_X3_CASE(48) ESCX_X3_CASE(80) ESCX_X3_CASE(96) ESCX_X3_CASE(144) ESCX_X3_CASE(192) ESCX_X3_CASE(384)
         default: return -1;
     }
+#undef ESCX_X3_CASE
 }
 
 // ---- fused LN + linear for PatchMerge / PatchSplit ----

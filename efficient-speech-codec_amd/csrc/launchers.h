@@ -41,7 +41,8 @@ unsigned long long* debug_trace_buffer();      // device buffer set by escx_debu
 // fp32 weights (w1 [hiddenP][Cp], w2 [Cp][hiddenP]); mlp_x3_bytes = its size.  -1: width not instantiated.
 size_t mlp_x3_bytes(int Cp, int hiddenP);
 int mlp_x3_pack(const float* w1, const float* w2, void* image, int Cp, int hiddenP, hipStream_t s);
-int mlp_x3(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* b1, const float* b2, const void* image, int hiddenP, int nw, hipStream_t s);
+int mlp_x3(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* b1, const float* b2, const void* image, int hiddenP, int nw, int* hs_io, float* partial,
+           hipStream_t s);
 void rows_combine(float* dst, const float* src, const float* partial, const float* bias, long long M, int Cp, int n, hipStream_t s);
 
 // LN + linear for PatchMerge (segs = 2, map gives the two source rows) / PatchSplit (segs = 1, split = 1: pixel-shuffled store)

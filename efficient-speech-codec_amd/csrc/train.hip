@@ -528,6 +528,7 @@ int refresh_from_flat(escx_handle_s* h, const float* flat, hipStream_t st) {
     } else {
         h->composed_stale = true;       // no folded form for this geometry: the inference path needs escx_load_flat_params(full = 1)
     }
+    h->pvq_tab_stale = true;            // derived inference state (de-quantisation tables, split MLP weight images): rebuilt by the next inference entry
     return launch_ok("refresh_from_flat");
 }
 

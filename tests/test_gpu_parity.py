@@ -131,6 +131,33 @@ def test_every_transformer_layer(which, W, request):
         assert err < ACT_TOL, f"{which} layer {lid} ({pfx}) H={H} W={W}: rel rms {err:.3e}"
 
 
+def test_layer_accuracy_against_fp64(base):
+    """Precision of the device arithmetic, measured: every TransformerLayer of ESC-Base against the oracle evaluated in FLOAT64, next to the error of
+    the oracle's own float32 evaluation (the reference's arithmetic: ATen sgemm) against the same float64 result.  Round 5: the fused MLPs run their
+    contractions on the bf16 matrix cores with every fp32 operand split exactly into three bf16 terms (fused_mlp_x3.h; six exact cross products,
+    fp32 accumulation) - fp32-grade arithmetic, not a bf16 approximation, and this is the test that says so: the device error must not exceed twice the
+    reference's own float32 error (+ 1e-7).  Printed per layer; ESCX_MLP_X3=0 (fp32 MFMA everywhere) passes the same bound."""
+    from oracle import esc_oracle as O
+    model, orc, g, cfg = base
+    lib, hd = _h(model)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in orc.sd.items()}
+    torch.manual_seed(23)
+    W = 20
+    worst = 0.0
+    for lid, pfx, C, nH, scale, H in _layer_cases(cfg):
+        x = torch.randn(2, H * W, C)
+        ref64, Hr, _ = O.transformer_layer(x.double(), H, W, sd64, pfx, nH, cfg["swin_depth"], cfg["window_size"], scale)
+        ref32, _, _ = O.transformer_layer(x, H, W, orc.sd, pfx, nH, cfg["swin_depth"], cfg["window_size"], scale)
+        y = torch.empty(ref32.shape, device="cuda"); Hn = ctypes.c_int()
+        xg = x.cuda()
+        _native.check(lib.escx_transformer_layer(hd, lid, _ptr(xg), 2, H, W, _ptr(y), ctypes.byref(Hn), None))
+        e_dev, e_cpu = rel_rms(y.cpu().double(), ref64), rel_rms(ref32.double(), ref64)
+        print(f"[fp64] layer {lid:2d} {pfx:22s} C={C:3d}: device {e_dev:.2e}   reference float32 {e_cpu:.2e}   ratio {e_dev / max(e_cpu, 1e-30):.2f}")
+        worst = max(worst, e_dev / (2 * e_cpu + 1e-7))
+        assert e_dev <= 2 * e_cpu + 1e-7, f"layer {lid} ({pfx}): device error {e_dev:.3e} vs float32 reference error {e_cpu:.3e}"
+    print(f"[fp64] worst device error / bound: {worst:.2f}")
+
+
 def test_merge_with_odd_height(base):
     from oracle import esc_oracle as O
     model, orc, g, cfg = base
@@ -861,12 +888,12 @@ def test_fallback_kernel_forms_against_the_default(tmp_path):
     attn_gs_off (the C = 384 attention without the head-group split: another projection order) keeps the codes, audio within 1e-6 RMS."""
     arms = {"default": {}, "pvq_three_launch": {"ESCX_PVQ_FUSED": "0", "ESCX_PVQ_TABLE": "0"}, "pvq_fused_mfma_up": {"ESCX_PVQ_TABLE": "0"},
             "pvq_tables_only": {"ESCX_PVQ_FUSED": "0"}, "pvq_up_engine": {"ESCX_PVQ_FUSED": "0", "ESCX_PVQ_TABLE": "0", "ESCX_PVQ_UP_KERNEL": "0"},
-            "attn_gs_off": {"ESCX_ATTN_GS_TOKENS": "0"}}
+            "attn_gs_off": {"ESCX_ATTN_GS_TOKENS": "0"}, "mlp_fp32_mfma": {"ESCX_MLP_X3": "0"}}
     got = _ab_arms(arms, tmp_path)
     ref = got["default"]
     for name in ("pvq_three_launch", "pvq_fused_mfma_up", "pvq_tables_only", "pvq_up_engine"):
         assert np.array_equal(got[name]["codes"], ref["codes"]) and np.array_equal(got[name]["wave"], ref["wave"]), f"{name} is not bit-identical to the default"
-    for name in ("attn_gs_off",):
+    for name in ("attn_gs_off", "mlp_fp32_mfma"):      # mlp_fp32_mfma: the fused MLPs on the fp32 MFMA instead of the three-term bf16 split (fused_mlp_x3.h): other summation order
         assert np.array_equal(got[name]["codes"], ref["codes"]), f"{name}: codes differ from the default"
         rms = float(np.sqrt(np.mean((got[name]["wave"].astype(np.float64) - ref["wave"]) ** 2)))
         assert rms <= 1e-6, f"{name}: audio rms {rms}"
@@ -882,11 +909,13 @@ def test_experimental_kernel_forms_against_the_default(tmp_path):
     from conftest import ROOT
     if not os.path.exists(os.path.join(ROOT, "efficient-speech-codec_amd", "esc", "lib", "libescx_exp.so")):
         pytest.skip("no tagged experimental build (libescx_exp.so): the product library does not contain the rejected forms")
-    ref = _ab_arms({"default": {}}, tmp_path)["default"]
+    # the rejected forms are variants of the fp32-MFMA kernels: both sides run with the split-operand kernels off (ESCX_MLP_X3=0, ESCX_ATTN_X3=0)
+    f32 = {"ESCX_MLP_X3": "0", "ESCX_ATTN_X3": "0"}
+    ref = _ab_arms({"default": {}}, tmp_path, f32)["default"]
     arms = {"mlp_fused_combine": {"ESCX_MLP_FUSED_COMBINE": "1"}, "combine_on_load": {"ESCX_COMBINE_ON_LOAD": "1"},
             "rowgemm_ws": {"ESCX_ROWGEMM_WS": "4"}, "rowgemm_xs": {"ESCX_ROWGEMM_XS": "1"},
             "pvq_down_kernel": {"ESCX_PVQ_FUSED": "0", "ESCX_PVQ_DOWN_KERNEL": "1"}}
-    got = _ab_arms(arms, tmp_path, {"ESCX_LIB_TAG": "exp"})
+    got = _ab_arms(arms, tmp_path, dict(f32, ESCX_LIB_TAG="exp"))
     for name in ("mlp_fused_combine", "combine_on_load", "pvq_down_kernel"):
         assert np.array_equal(got[name]["codes"], ref["codes"]) and np.array_equal(got[name]["wave"], ref["wave"]), f"{name} is not bit-identical to the default"
     for name in ("rowgemm_ws", "rowgemm_xs"):
