@@ -154,7 +154,7 @@ extern "C" void escx_destroy(escx_handle h) {
     for (auto& kv : h->maps) (void)hipFree(kv.second);
     if (h->coll_buf) (void)hipFree(h->coll_buf);
     for (Quant& q : h->quants) if (q.tab) (void)hipFree(q.tab);
-    for (Layer& L : h->layers) for (BlockW& bw : L.blocks) if (bw.x3w) (void)hipFree(bw.x3w);
+    for (Layer& L : h->layers) for (BlockW& bw : L.blocks) { if (bw.x3w) (void)hipFree(bw.x3w); if (bw.x3a) (void)hipFree(bw.x3a); }
     if (h->iota_codes) (void)hipFree(h->iota_codes);
     if (h->gmap) (void)hipFree(h->gmap);
     if (h->garena) (void)hipFree(h->garena);
@@ -1128,7 +1128,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             if (!launched)
             PROF("attn_fused" + tag, 2 * proj_rows * dC * 4 * dC + 4 * dMs * 16 * dC, 2 * dM * dC * f4,
                  frc = attn_fused(src, cur, L.Cp, L.C, L.attn_mode, L.n_groups, bw.ln1_g, bw.ln1_b, bw.waf, bw.baf, bw.bias_tab_f, bw.bproj,
-                                  map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, &gs, h->hid, M, st));
+                                  map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, &gs, h->hid, M, st, nullptr, nullptr, nw > 0 ? bw.x3a : nullptr));
             attn_done = (frc == 0);
             if (attn_done && gs > 1)
                 PROF("attn_combine" + tag, 0, (gs + 2) * dM * L.Cp * f4, rows_combine(cur, src, h->hid, bw.bproj, M, L.Cp, gs, st));
@@ -1300,6 +1300,16 @@ static int ensure_pvq_tables(escx_handle_s* h, hipStream_t st) {
             if (!want) { if (bw.x3w) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(bw.x3w); bw.x3w = nullptr; } continue; }
             if (!bw.x3w) ESCX_HIP(hipMalloc(&bw.x3w, mlp_x3_bytes(L.Cp, L.hiddenP)));
             if (mlp_x3_pack(bw.w1, bw.w2, bw.x3w, L.Cp, L.hiddenP, st) != 0) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(bw.x3w); bw.x3w = nullptr; }
+        }
+    // the split Q / K / V weight streams of the fused attention (fused_attn.h X3; ESCX_ATTN_X3=0: fp32 MFMA)
+    static const int ax3_max = [] { const char* e = getenv("ESCX_ATTN_X3"); return e && e[0] ? atoi(e) : 192; }();
+    for (Layer& L : h->layers)
+        for (BlockW& bw : L.blocks) {
+            const bool want = ax3_max > 0 && L.Cp <= ax3_max && L.attn_mode >= 0 && h->use_fused_attn &&
+                              ((L.Cp == 48 && L.attn_mode == 0) || (L.Cp == 80 && L.attn_mode != 1) || (L.Cp == 96 && L.attn_mode != 2) || (L.Cp == 144 && L.attn_mode != 2) || (L.Cp == 192 && L.attn_mode == 1));
+            if (!want) { if (bw.x3a) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(bw.x3a); bw.x3a = nullptr; } continue; }
+            if (!bw.x3a) ESCX_HIP(hipMalloc(&bw.x3a, attn_x3_bytes(L.Cp, L.attn_mode, L.n_groups)));
+            attn_x3_pack(bw.waf, bw.x3a, L.Cp, L.attn_mode, L.n_groups, st);
         }
     h->pvq_tab_stale = false;
     return launch_ok("pvq_tables");

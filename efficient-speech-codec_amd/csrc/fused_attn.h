@@ -22,8 +22,53 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gemm_engine.h"
+#include "gemm_bf16.h"
 
 namespace escx {
+
+// ---- split-operand (3 x bf16) form of the Q / K / V projections (round 5, see fused_mlp_x3.h for the arithmetic) ----
+// The K = C contractions of a head group's Q, K and V tiles run on v_mfma_f32_16x16x32_bf16 with every fp32 operand split exactly into three bf16
+// terms (six cross products, fp32 accumulation); their outputs land in the same accumulator layout as the fp32 MFMA's, so the 16 x 16 attention
+// itself (scores, softmax, P.V) and the output projection (K = 16 per head group) stay on the fp32 MFMA unchanged.
+// Weight stream of the X3 instantiations: [group][tile][TF][64 lanes][16 B], TF = max(3 KS, KK) fragments per tile; a Q / K / V tile holds its
+// 3 KS split fragments (K-step s, term i) -> lane (row, g): term i of W[row][32 s + 8 g + e]; a projection tile holds its KK fp32 fragments as before.
+constexpr int attn_x3_ks(int CP) { return (CP + 31) / 32; }
+constexpr int attn_x3_tf(int CP) { return 3 * attn_x3_ks(CP) > CP / 16 ? 3 * attn_x3_ks(CP) : CP / 16; }
+__device__ __forceinline__ void attn_split3(const float (&v)[8], bf16x8& t0, bf16x8& t1, bf16x8& t2) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 a1 = (__bf16)v[e];
+        const float r1 = v[e] - (float)a1;
+        const __bf16 a2 = (__bf16)r1;
+        const float r2 = r1 - (float)a2;
+        t0[e] = a1; t1[e] = a2; t2[e] = (__bf16)r2;
+    }
+}
+// builds the X3 stream from the fp32 fragment stream (BlockW::waf): one thread per (group, tile, K-step or projection fragment, lane)
+__global__ __launch_bounds__(256) void attn_x3_pack_kernel(const f32x4* __restrict__ waf, bf16x8* __restrict__ out, int n_tiles, int TPG, int KK, int KS, int TF, unsigned proj_mask) {
+    const int per_tile = (KS > KK ? KS : KK) * 64;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)n_tiles * per_tile) return;
+    const int tile = (int)(idx / per_tile), r = (int)(idx - (long long)tile * per_tile), f = r >> 6, lane = r & 63;
+    const f32x4* src = waf + (size_t)tile * KK * 64;
+    bf16x8* dst = out + (size_t)tile * TF * 64;
+    if ((proj_mask >> (tile % TPG)) & 1) {              // projection tile: fp32 fragments, copied
+        if (f < KK) reinterpret_cast<f32x4*>(dst)[f * 64 + lane] = src[f * 64 + lane];
+        return;
+    }
+    if (f >= KS) return;
+    const int l15 = lane & 15, g = lane >> 4;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int kk = 2 * f + (g >> 1), lgs = 2 * (g & 1) + (e >> 2);
+        v[e] = kk < KK ? src[kk * 64 + 16 * lgs + l15][e & 3] : 0.f;
+    }
+    bf16x8 t0, t1, t2;
+    attn_split3(v, t0, t1, t2);
+    dst[(f * 3 + 0) * 64 + lane] = t0; dst[(f * 3 + 1) * 64 + lane] = t1; dst[(f * 3 + 2) * 64 + lane] = t2;
+}
 
 struct AttnArgs {
     const float* src;           // [B*tokens][CP] block input (also the shortcut)
@@ -49,6 +94,7 @@ struct AttnArgs {
     // head (q at h*hdp, k at nH*hdp + h*hdp, v at 2*nH*hdp + h*hdp), the attention output [slots][ldo] - so LayerNorm, QKV projection,
     // window attention and output projection are ONE launch and nothing is read back (train.hip, layer_fwd).
     float* tape_xn; float* tape_qkv; float* tape_o; int ldq, ldo, hdp, nH;
+    const void* x3_wf;          // X3 instantiations: the split weight stream (attn_x3_pack_kernel), else unused
 };
 
 // One 16-byte piece of a block-input row: plain, or combined on the fly from the hidden-split MLP's slabs (see AttnArgs).
@@ -103,8 +149,12 @@ __device__ __forceinline__ f32x4 window_softmax(f32x4 s, f32x4 bias_row, f32x4 s
 #endif
 template <int CP, int TMW> constexpr int attn_min_waves() { return (CP * TMW <= 96) ? 4 : ((CP * TMW <= ESCX_ATTN_OCC3) ? 3 : ((CP * TMW <= 192) ? 2 : 1)); }
 
-template <int CP, int MODE, int UT, int TMW, int NW, bool COMB = false, bool TAPE = false>
-__global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fused_kernel(AttnArgs a) {
+// X3 instantiations hold the LayerNorm output as three bf16 terms (1.5x the registers of the fp32 operand): one occupancy step down
+template <int CP, int TMW, bool X3> constexpr int attn_min_waves_x() { return !X3 ? attn_min_waves<CP, TMW>() : ((CP * TMW <= 96) ? 3 : ((CP * TMW <= 160) ? 2 : 1)); }
+
+template <int CP, int MODE, int UT, int TMW, int NW, bool COMB = false, bool TAPE = false, bool X3 = false>
+__global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void attn_fused_kernel(AttnArgs a) {
+    static_assert(!X3 || (!COMB && !TAPE), "the split-operand form exists for the plain inference instantiations");
 #ifdef ESCX_ATTN_PRIO
     __builtin_amdgcn_s_setprio(ESCX_ATTN_PRIO);     // tuning builds: static wave priority against co-running launches of the other batch part
 #endif
@@ -112,7 +162,11 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
     constexpr int TPG = (MODE == 2) ? 8 : 4;    // weight tiles per head group
     constexpr int NB = (MODE == 2) ? 6 : 3;     // bias rows per group
     static_assert(TPG % UT == 0, "stage size must divide the tiles of a head group");
-    __shared__ f32x4 wbuf[2][UT * KK * 64];
+    constexpr int KS = attn_x3_ks(CP);
+    constexpr int TF = X3 ? attn_x3_tf(CP) : KK;            // fragments (1 KiB) per weight tile in the stream
+    __shared__ f32x4 wbuf_static[X3 ? 1 : 2 * UT * KK * 64];
+    extern __shared__ __attribute__((aligned(16))) f32x4 wbuf_dyn[];      // X3: 2 * UT * TF KiB (above the 64 KiB of static LDS at the wide layers)
+    f32x4* const wbuf0 = X3 ? wbuf_dyn : wbuf_static;
 
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -122,15 +176,15 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
     const int g0 = gs * (a.n_groups / GS), g1 = g0 + a.n_groups / GS;
     const int win0 = (wgb * NW + wave) * TMW;
     const int n_stages = (g1 - g0) * (TPG / UT);
-    const f32x4* wfb = a.wf + (size_t)g0 * TPG * KK * 64;
+    const f32x4* wfb = (X3 ? reinterpret_cast<const f32x4*>(a.x3_wf) : a.wf) + (size_t)g0 * TPG * TF * 64;
 
     // Weight stream: stage s+1 is DMA'd into the idle LDS buffer while stage s feeds the MFMAs.  The NPW pieces (1 KiB each) a
     // wave owes per stage are not issued in one burst but one per dma_slot() call, which the tile GEMMs make every other
     // k-step.  `slot` is a compile-time constant after unrolling, so the schedule is static and branch-free: the compiler
     // can count the VMEM operations in flight (precise vmcnt for the bias loads) and schedule across the whole stage.
-    constexpr int NP = UT * KK, NPW = (NP + NW - 1) / NW;
+    constexpr int NP = UT * TF, NPW = (NP + NW - 1) / NW;
     const f32x4* dma_src = wfb + lane;
-    f32x4* dma_dst = &wbuf[0][0];
+    f32x4* dma_dst = wbuf0;
     int slot = 0;
     auto dma_slot = [&]() {
         if (slot < NPW) {
@@ -145,7 +199,8 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
 
     // ---- 1. gather + LayerNorm in registers ------------------------------------------------------
     const int nW = a.nWh * a.nWw;
-    f32x4 xf[TMW][KK];
+    f32x4 xf[X3 ? 1 : TMW][X3 ? 1 : KK];
+    bf16x8 xs[X3 ? TMW : 1][3][X3 ? KS : 1];                 // X3: LayerNorm output split into three bf16 terms, lane (slot l15, group lg) holds channels 32 s + 8 lg .. + 7
     int tok[TMW];                               // this lane's token row (element offset / CP), or -1
     bool lastH[TMW], lastW[TMW];
 #pragma unroll
@@ -159,6 +214,43 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
             const int tk = a.map[wloc * 16 + l15];
             if (tk >= 0) tok[t] = b * a.tokens + tk;
         }
+        if constexpr (X3) {
+            const float* xrow = a.src + (size_t)(tok[t] < 0 ? 0 : tok[t]) * CP;
+            float xv[KS][8];
+            float s = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int c0 = 32 * ks + 8 * lg;
+                f32x4 v0 = zero4(), v1 = zero4();
+                if (c0 < CP) { v0 = ld4(xrow + c0); v1 = ld4(xrow + c0 + 4); }
+                if (tok[t] < 0) { v0 = zero4(); v1 = zero4(); }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xv[ks][e] = v0[e]; xv[ks][4 + e] = v1[e]; s += v0[e]; s += v1[e]; }
+            }
+            s = sum_groups(s);
+            const float mean = s / (float)a.C;
+            float v = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = xv[ks][e] - mean; v += d * d; }
+            v = sum_groups(v) - (float)(32 * KS - a.C) * mean * mean;      // every zero slot (channel padding, K padding to 32) added mean^2
+            const float rstd = 1.0f / sqrtf(v / (float)a.C + a.eps);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int c0 = 32 * ks + 8 * lg;
+                f32x4 g0v = zero4(), g1v = zero4(), b0v = zero4(), b1v = zero4();
+                if (c0 < CP) { g0v = ld4(a.gamma + c0); g1v = ld4(a.gamma + c0 + 4); b0v = ld4(a.beta + c0); b1v = ld4(a.beta + c0 + 4); }
+                float xn[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xn[e] = tok[t] >= 0 ? (xv[ks][e] - mean) * rstd * g0v[e] + b0v[e] : 0.f;            // padded slots become zero rows AFTER the norm
+                    xn[4 + e] = tok[t] >= 0 ? (xv[ks][4 + e] - mean) * rstd * g1v[e] + b1v[e] : 0.f;
+                }
+                attn_split3(xn, xs[t][0][ks], xs[t][1][ks], xs[t][2][ks]);
+            }
+        }
+        if constexpr (!X3) {
         const size_t xoff = (size_t)(tok[t] < 0 ? 0 : tok[t]) * CP + 4 * lg;
         float s = 0.f;
 #pragma unroll
@@ -182,6 +274,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 xf[t][kk][e] = tok[t] >= 0 ? (xf[t][kk][e] - mean) * rstd * g[e] + bb[e] : 0.f;   // gamma = beta = 0 in the pad channels
+        }
         }
     }
 
@@ -233,10 +326,11 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
     // exposed.  `frag` and `slot` are compile-time constants after unrolling.  The sched_group_barrier sequence pins the order
     // (hipcc otherwise sinks each ds_read to its first use and waits, and sinks every DMA piece to the end of the stage where
     // the vmcnt(0) before the next barrier would wait out the whole L2 round trip).
-    constexpr int PD = NP < 3 ? NP : 3;
-#define ESCX_SGB_DS() __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)
-#define ESCX_SGB_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
-#define ESCX_SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+    constexpr int PD = X3 ? 1 : (NP < 3 ? NP : 3);         // X3 reads its fragments straight from LDS (no register ring)
+    // (the pinned schedule below was tuned for the fp32 instruction stream; the X3 instantiations leave the order to the compiler)
+#define ESCX_SGB_DS() do { if constexpr (!X3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } while (0)
+#define ESCX_SGB_VMEM(n) do { if constexpr (!X3) __builtin_amdgcn_sched_group_barrier(0x020, n, 0); } while (0)
+#define ESCX_SGB_MFMA(n) do { if constexpr (!X3) __builtin_amdgcn_sched_group_barrier(0x008, n, 0); } while (0)
     int stage = 0, frag = 0;
     const f32x4* wb = nullptr;
     f32x4 ring[PD];
@@ -248,14 +342,16 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
         __syncthreads();
 #endif
         // arm the DMA of the following stage; after the last one its own tiles are re-loaded into the idle buffer (harmless)
-        dma_src = wfb + (size_t)min(stage + 1, n_stages - 1) * (UT * KK * 64) + lane;
-        dma_dst = &wbuf[(stage + 1) & 1][0];
+        dma_src = wfb + (size_t)min(stage + 1, n_stages - 1) * (UT * TF * 64) + lane;
+        dma_dst = wbuf0 + ((stage + 1) & 1) * (NP * 64);
         slot = 0;
-        wb = &wbuf[stage & 1][lane];
+        wb = wbuf0 + (stage & 1) * (NP * 64) + lane;
         ++stage;
         frag = 0;
+        if constexpr (!X3) {
 #pragma unroll
         for (int i = 0; i < PD; ++i) { ring[i] = wb[i * 64]; ESCX_SGB_DS(); }
+        }
     };
     auto next_frag = [&]() -> f32x4 {
         const f32x4 w = ring[frag % PD];
@@ -266,12 +362,38 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
     auto dma_pinned = [&]() {
         const bool issues = slot < NPW;
         dma_slot();
-        if (issues) ESCX_SGB_VMEM(1);
+        if (issues && !X3) ESCX_SGB_VMEM(1);
     };
     int tile = 0;
     auto begin_tile = [&]() { if (tile % UT == 0) next_stage(); ++tile; };
+    // X3: the Q / K / V tile GEMMs on the bf16 MFMA, six cross terms (weight term I, activation term J) smallest first, two accumulator chains
+#define ESCX_ATTN_X3_TERMS(M) M(0, 2) M(2, 0) M(1, 1) M(0, 1) M(1, 0) M(0, 0)
+    auto gemm_x3 = [&](f32x4* out, f32x4 init, bool x_rows) {
+        const bf16x8* tb = reinterpret_cast<const bf16x8*>(wb) + (size_t)(((tile - 1) % UT) * TF) * 64;
+        f32x4 o2[TMW];
+#pragma unroll
+        for (int t = 0; t < TMW; ++t) { out[t] = init; o2[t] = zero4(); }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 w[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) w[i] = tb[(ks * 3 + i) * 64];
+            dma_pinned();
+            int n = 0;
+#define ESCX_ATTN_X3_STEP(I, J) \
+            _Pragma("unroll") for (int t = 0; t < TMW; ++t) { \
+                f32x4& d = (n & 1) ? o2[t] : out[t]; \
+                d = x_rows ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(xs[t][J][ks], w[I], d, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[I], xs[t][J][ks], d, 0, 0, 0); \
+            } ++n;
+            ESCX_ATTN_X3_TERMS(ESCX_ATTN_X3_STEP)
+#undef ESCX_ATTN_X3_STEP
+        }
+#pragma unroll
+        for (int t = 0; t < TMW; ++t) out[t] += o2[t];
+    };
     // tile GEMM with the weight tile as the row operand: out[t] = W_tile . x^T  -> lane (token l15, rows 4lg + r)
     auto gemm_w_rows = [&](f32x4* out, f32x4 init) {       // init: the tile's bias rides in the accumulator
+        if constexpr (X3) { gemm_x3(out, init, false); return; }
         f32x4 o2[TMW];
 #pragma unroll
         for (int t = 0; t < TMW; ++t) { out[t] = init; o2[t] = zero4(); }
@@ -292,6 +414,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
     };
     // swapped: out[t] = x . W_tile^T -> lane (row l15 of the weight tile, tokens 4lg + r)
     auto gemm_x_rows = [&](f32x4* out, f32x4 init) {
+        if constexpr (X3) { gemm_x3(out, init, true); return; }
         f32x4 o2[TMW];
 #pragma unroll
         for (int t = 0; t < TMW; ++t) { out[t] = init; o2[t] = zero4(); }
@@ -311,11 +434,12 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
         if (TMW == 1) out[0] += o2[0];
     };
     auto proj_accumulate = [&](const f32x4* o) {
+        const f32x4* tb = wb + (size_t)(((tile - 1) % UT) * TF) * 64;       // X3: the projection tile's fp32 fragments, read straight from LDS
 #pragma unroll
         for (int to = 0; to < KK; to += 2) {    // two output tiles per step: no back-to-back MFMAs on one accumulator
-            const f32x4 w = next_frag();
-            f32x4 wn = zero4();
-            if (to + 1 < KK) wn = next_frag();
+            f32x4 w, wn = zero4();
+            if constexpr (X3) { w = tb[to * 64]; if (to + 1 < KK) wn = tb[(to + 1) * 64]; }
+            else { w = next_frag(); if (to + 1 < KK) wn = next_frag(); }
             dma_pinned();
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -324,7 +448,7 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, TMW>())) void attn_fus
                     acc[to][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], o[t][r], acc[to][t], 0, 0, 0);
                     if (to + 1 < KK) acc[to + 1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[r], o[t][r], acc[to + 1][t], 0, 0, 0);
                 }
-            if (to + 1 < KK) ESCX_SGB_MFMA(8 * TMW); else ESCX_SGB_MFMA(4 * TMW);
+            if constexpr (!X3) { if (to + 1 < KK) ESCX_SGB_MFMA(8 * TMW); else ESCX_SGB_MFMA(4 * TMW); }
         }
     };
 

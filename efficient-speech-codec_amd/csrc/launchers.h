@@ -62,7 +62,10 @@ int deembed7_fused(const float* tok, int B, int H, int W, int Cp, const float* w
 int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_groups, const float* gamma, const float* beta,
                const float* wf, const float* bqkv, const float* bias_tab, const float* bproj, const int* map, int slots, int tokens,
                int n_windows, int nWh, int nWw, int shifted, float scale, int nw, int* gs_io, float* partial, int rows, hipStream_t s,
-               const CombineOnLoad* comb = nullptr, const struct AttnTape* tape = nullptr);
+               const CombineOnLoad* comb = nullptr, const struct AttnTape* tape = nullptr,
+               const void* x3_wf = nullptr);     // split (3 x bf16) Q / K / V weight stream of this block (attn_x3_pack), or nullptr = fp32 MFMA everywhere
+size_t attn_x3_bytes(int Cp, int mode, int n_groups);
+int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, hipStream_t s);
 // training forward: the fused attention also writes what the backward reads (fused_attn.h, TAPE); returns ESCX_COMB_UNSUPPORTED when the width has
 // no TAPE instantiation (the caller runs the unfused sequence)
 struct AttnTape { float* xn; float* qkv; float* o; int ldq, ldo, hdp, nH; };
