@@ -1128,7 +1128,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             if (!launched)
             PROF("attn_fused" + tag, 2 * proj_rows * dC * 4 * dC + 4 * dMs * 16 * dC, 2 * dM * dC * f4,
                  frc = attn_fused(src, cur, L.Cp, L.C, L.attn_mode, L.n_groups, bw.ln1_g, bw.ln1_b, bw.waf, bw.baf, bw.bias_tab_f, bw.bproj,
-                                  map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, &gs, h->hid, M, st, nullptr, nullptr, nw > 0 ? bw.x3a : nullptr));
+                                  map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, &gs, h->hid, M, st, nullptr, nullptr, (nw > 0 || L.Cp == 384) ? bw.x3a : nullptr));      // C = 384: the split stream exists for the packed (nw < 0) kernel only
             attn_done = (frc == 0);
             if (attn_done && gs > 1)
                 PROF("attn_combine" + tag, 0, (gs + 2) * dM * L.Cp * f4, rows_combine(cur, src, h->hid, bw.bproj, M, L.Cp, gs, st));
@@ -1302,11 +1302,11 @@ static int ensure_pvq_tables(escx_handle_s* h, hipStream_t st) {
             if (mlp_x3_pack(bw.w1, bw.w2, bw.x3w, L.Cp, L.hiddenP, st) != 0) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(bw.x3w); bw.x3w = nullptr; }
         }
     // the split Q / K / V weight streams of the fused attention (fused_attn.h X3; ESCX_ATTN_X3=0: fp32 MFMA)
-    static const int ax3_max = [] { const char* e = getenv("ESCX_ATTN_X3"); return e && e[0] ? atoi(e) : 192; }();
+    static const int ax3_max = [] { const char* e = getenv("ESCX_ATTN_X3"); return e && e[0] ? atoi(e) : 384; }();
     for (Layer& L : h->layers)
         for (BlockW& bw : L.blocks) {
             const bool want = ax3_max > 0 && L.Cp <= ax3_max && L.attn_mode >= 0 && h->use_fused_attn &&
-                              ((L.Cp == 48 && L.attn_mode == 0) || (L.Cp == 80 && L.attn_mode != 1) || (L.Cp == 96 && L.attn_mode != 2) || (L.Cp == 144 && L.attn_mode != 2) || (L.Cp == 192 && L.attn_mode == 1));
+                              ((L.Cp == 48 && L.attn_mode == 0) || (L.Cp == 80 && L.attn_mode != 1) || (L.Cp == 96 && L.attn_mode != 2) || (L.Cp == 144 && L.attn_mode != 2) || (L.Cp == 192 && L.attn_mode == 1) || (L.Cp == 384 && L.attn_mode == 0));      // 384: the packed H = 2 kernel only (the launcher falls back to fp32 elsewhere)
             if (!want) { if (bw.x3a) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(bw.x3a); bw.x3a = nullptr; } continue; }
             if (!bw.x3a) ESCX_HIP(hipMalloc(&bw.x3a, attn_x3_bytes(L.Cp, L.attn_mode, L.n_groups)));
             attn_x3_pack(bw.waf, bw.x3a, L.Cp, L.attn_mode, L.n_groups, st);

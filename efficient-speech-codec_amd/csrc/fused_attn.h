@@ -654,15 +654,20 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void at
 // key / value operands are rebuilt in registers: real slots come from the packed tile (a half-row swap for K, a
 // lane-group swap for V^T), padded slots are the bias.  Requires H == 2, W % 4 == 0, one head per tile (MODE 0).
 // ------------------------------------------------------------------------------------------------
-template <int CP, int UT, int NW, bool COMB = false>
-__global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packed_kernel(AttnArgs a) {
+template <int CP, int UT, int NW, bool COMB = false, bool X3 = false>
+__global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, 1, X3>())) void attn_packed_kernel(AttnArgs a) {
+    static_assert(!X3 || !COMB, "the split-operand form exists for the plain instantiation");
 #ifdef ESCX_ATTN_PRIO
     __builtin_amdgcn_s_setprio(ESCX_ATTN_PRIO);
 #endif
     constexpr int KK = CP / 16;
     constexpr int TPG = 4;
     static_assert(TPG % UT == 0, "stage size must divide the tiles of a head group");
-    __shared__ f32x4 wbuf[2][UT * KK * 64];
+    constexpr int KS = attn_x3_ks(CP);
+    constexpr int TF = X3 ? attn_x3_tf(CP) : KK;            // fragments per weight tile in the stream (attn_fused_kernel)
+    __shared__ f32x4 wbuf_static[X3 ? 1 : 2 * UT * KK * 64];
+    extern __shared__ __attribute__((aligned(16))) f32x4 wbuf_dyn[];
+    f32x4* const wbuf0 = X3 ? wbuf_dyn : wbuf_static;
 
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -672,11 +677,11 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
     const int g0 = gs * (a.n_groups / GS), g1 = g0 + a.n_groups / GS;
     const int pair = wgb * NW + wave;
     const int n_stages = (g1 - g0) * (TPG / UT);
-    const f32x4* wfb = a.wf + (size_t)g0 * TPG * KK * 64;
+    const f32x4* wfb = (X3 ? reinterpret_cast<const f32x4*>(a.x3_wf) : a.wf) + (size_t)g0 * TPG * TF * 64;
 
-    constexpr int NP = UT * KK, NPW = (NP + NW - 1) / NW;      // static, branch-free DMA schedule as in attn_fused_kernel
+    constexpr int NP = UT * TF, NPW = (NP + NW - 1) / NW;      // static, branch-free DMA schedule as in attn_fused_kernel
     const f32x4* dma_src = wfb + lane;
-    f32x4* dma_dst = &wbuf[0][0];
+    f32x4* dma_dst = wbuf0;
     int slot = 0;
     auto dma_slot = [&]() {
         if (slot < NPW) {
@@ -702,8 +707,44 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
         const int tk = a.map[wloc * 16 + qslot];
         if (tk >= 0) tok = b * a.tokens + tk;
     }
-    f32x4 xf[KK];
-    {
+    f32x4 xf[X3 ? 1 : KK];
+    bf16x8 xs[3][X3 ? KS : 1];
+    if constexpr (X3) {
+        const float* xrow = a.src + (size_t)(tok < 0 ? 0 : tok) * CP;
+        float xv[KS][8];
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c0 = 32 * ks + 8 * lg;
+            f32x4 v0 = zero4(), v1 = zero4();
+            if (c0 < CP) { v0 = ld4(xrow + c0); v1 = ld4(xrow + c0 + 4); }
+            if (tok < 0) { v0 = zero4(); v1 = zero4(); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xv[ks][e] = v0[e]; xv[ks][4 + e] = v1[e]; s += v0[e]; s += v1[e]; }
+        }
+        s = sum_groups(s);
+        const float mean = s / (float)a.C;
+        float v = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = xv[ks][e] - mean; v += d * d; }
+        v = sum_groups(v) - (float)(32 * KS - a.C) * mean * mean;
+        const float rstd = 1.0f / sqrtf(v / (float)a.C + a.eps);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c0 = 32 * ks + 8 * lg;
+            f32x4 g0v = zero4(), g1v = zero4(), b0v = zero4(), b1v = zero4();
+            if (c0 < CP) { g0v = ld4(a.gamma + c0); g1v = ld4(a.gamma + c0 + 4); b0v = ld4(a.beta + c0); b1v = ld4(a.beta + c0 + 4); }
+            float xn[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xn[e] = tok >= 0 ? (xv[ks][e] - mean) * rstd * g0v[e] + b0v[e] : 0.f;
+                xn[4 + e] = tok >= 0 ? (xv[ks][4 + e] - mean) * rstd * g1v[e] + b1v[e] : 0.f;
+            }
+            attn_split3(xn, xs[0][ks], xs[1][ks], xs[2][ks]);
+        }
+    } else {
         const size_t xoff = (size_t)(tok < 0 ? 0 : tok) * CP + 4 * lg;
         float s = 0.f;
 #pragma unroll
@@ -738,10 +779,10 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
 #pragma unroll
     for (int o = 0; o < KK; ++o) acc[o] = zero4();
 
-    constexpr int PD = NP < 3 ? NP : 3;         // stage-long fragment ring + pinned schedule, as in attn_fused_kernel
-#define ESCX_SGB_DS() __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)
-#define ESCX_SGB_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
-#define ESCX_SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+    constexpr int PD = X3 ? 1 : (NP < 3 ? NP : 3);         // stage-long fragment ring + pinned schedule, as in attn_fused_kernel (X3: fragments straight from LDS)
+#define ESCX_SGB_DS() do { if constexpr (!X3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } while (0)
+#define ESCX_SGB_VMEM(n) do { if constexpr (!X3) __builtin_amdgcn_sched_group_barrier(0x020, n, 0); } while (0)
+#define ESCX_SGB_MFMA(n) do { if constexpr (!X3) __builtin_amdgcn_sched_group_barrier(0x008, n, 0); } while (0)
     int stage = 0, frag = 0;
     const f32x4* wb = nullptr;
     f32x4 ring[PD];
@@ -750,14 +791,16 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
         for (int i = 0; i < NPW; ++i) dma_slot();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        dma_src = wfb + (size_t)min(stage + 1, n_stages - 1) * (UT * KK * 64) + lane;
-        dma_dst = &wbuf[(stage + 1) & 1][0];
+        dma_src = wfb + (size_t)min(stage + 1, n_stages - 1) * (UT * TF * 64) + lane;
+        dma_dst = wbuf0 + ((stage + 1) & 1) * (NP * 64);
         slot = 0;
-        wb = &wbuf[stage & 1][lane];
+        wb = wbuf0 + (stage & 1) * (NP * 64) + lane;
         ++stage;
         frag = 0;
+        if constexpr (!X3) {
 #pragma unroll
         for (int i = 0; i < PD; ++i) { ring[i] = wb[i * 64]; ESCX_SGB_DS(); }
+        }
     };
     auto next_frag = [&]() -> f32x4 {
         const f32x4 w = ring[frag % PD];
@@ -774,6 +817,20 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
     auto begin_tile = [&]() { if (tile % UT == 0) next_stage(); ++tile; };
     auto tile_gemm = [&](bool x_rows, f32x4 init) -> f32x4 {       // init: the tile's bias rides in the accumulator
         f32x4 o1 = init, o2 = zero4();
+        if constexpr (X3) {          // Q / K / V on the bf16 MFMA: six cross terms of the three-term split, smallest first, two accumulator chains
+            const bf16x8* tb = reinterpret_cast<const bf16x8*>(wb) + (size_t)(((tile - 1) % UT) * TF) * 64;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 w[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) w[i] = tb[(ks * 3 + i) * 64];
+                dma_pinned();
+#define ESCX_PK_X3(I, J, D) D = x_rows ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(xs[J][ks], w[I], D, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[I], xs[J][ks], D, 0, 0, 0);
+                ESCX_PK_X3(0, 2, o1) ESCX_PK_X3(2, 0, o2) ESCX_PK_X3(1, 1, o1) ESCX_PK_X3(0, 1, o2) ESCX_PK_X3(1, 0, o1) ESCX_PK_X3(0, 0, o2)
+#undef ESCX_PK_X3
+            }
+            return o1 + o2;
+        }
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const f32x4 w = next_frag();
@@ -848,11 +905,12 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves<CP, 1>())) void attn_packe
         ESCX_SGB_MFMA(8);
         const f32x4 o = isB ? oB : oA;
         begin_tile();
+        const f32x4* ptb = wb + (size_t)(((tile - 1) % UT) * TF) * 64;      // X3: the projection tile's fp32 fragments, read straight from LDS
 #pragma unroll
         for (int to = 0; to < KK; to += 2) {
-            const f32x4 w = next_frag();
-            f32x4 wn = zero4();
-            if (to + 1 < KK) wn = next_frag();
+            f32x4 w, wn = zero4();
+            if constexpr (X3) { w = ptb[to * 64]; if (to + 1 < KK) wn = ptb[(to + 1) * 64]; }
+            else { w = next_frag(); if (to + 1 < KK) wn = next_frag(); }
             dma_pinned();
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -449,6 +449,18 @@ static int launch_attn_packed(const AttnArgs& a, hipStream_t s) {
 #endif
         return ESCX_COMB_UNSUPPORTED;
     }
+    if constexpr (CP == 384 && NW == 4) {        // split-operand Q / K / V projections (ESC's bottom scale)
+        if (a.x3_wf) {
+            auto kern = attn_packed_kernel<CP, UT, NW, false, true>;
+            constexpr int lds = 2 * UT * attn_x3_tf(CP) * 1024;
+            static std::atomic<unsigned> done{0};
+            int dev = 0; (void)hipGetDevice(&dev);
+            const unsigned bit = 1u << (dev & 31);
+            if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
+            hipLaunchKernelGGL(kern, dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), lds, s, a);
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((attn_packed_kernel<CP, UT, NW>), dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), 0, s, a);
     return 0;
 }
