@@ -154,6 +154,7 @@ extern "C" void escx_destroy(escx_handle h) {
     for (auto& kv : h->maps) (void)hipFree(kv.second);
     if (h->coll_buf) (void)hipFree(h->coll_buf);
     for (Quant& q : h->quants) if (q.tab) (void)hipFree(q.tab);
+    for (Layer& L : h->layers) if (L.sub_x3) (void)hipFree(L.sub_x3);
     for (Layer& L : h->layers) for (BlockW& bw : L.blocks) { if (bw.x3w) (void)hipFree(bw.x3w); if (bw.x3a) (void)hipFree(bw.x3a); }
     if (h->iota_codes) (void)hipFree(h->iota_codes);
     if (h->gmap) (void)hipFree(h->gmap);
@@ -1207,7 +1208,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         flush_pending();
         if (h->use_fused && mrc != 0)
             PROF("merge_fused" + (h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string()), 2.0 * B * H2 * W * 2 * L.C * L.Cout, ((double)M * L.C + (double)B * H2 * W * L.Cout) * 4,
-                 mrc = rowgemm_fused(2, cur, y, L.sub_g, L.sub_b, L.sub_wf, map, B * H2 * W, H2 * W, tokens, L.C, L.Cp, L.CoutP, 0, 0, 0, 0, st));
+                 mrc = rowgemm_fused(2, cur, y, L.sub_g, L.sub_b, L.sub_wf, map, B * H2 * W, H2 * W, tokens, L.C, L.Cp, L.CoutP, 0, 0, 0, 0, st, nullptr, L.sub_x3));
         if (mrc != 0) {
         PROF("merge_ln", 0, 2.0 * M * L.C * 4,
              ln_rows(2, cur, h->xn, L.sub_g, L.sub_b, map, H2 * W, tokens, B * H2 * W, L.C, L.Cp, st));
@@ -1226,7 +1227,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         flush_pending();
         if (h->use_fused && src2 != 0)
             PROF("split_fused" + (h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string()), 2.0 * M * L.C * 2 * L.Cout, (double)M * (L.C + 2 * L.Cout) * 4,
-                 src2 = rowgemm_fused(1, cur, y, L.sub_g, L.sub_b, L.sub_wf, nullptr, M, tokens, tokens, L.C, L.Cp, 2 * L.CoutP, 1, H, W, L.CoutP, st));
+                 src2 = rowgemm_fused(1, cur, y, L.sub_g, L.sub_b, L.sub_wf, nullptr, M, tokens, tokens, L.C, L.Cp, 2 * L.CoutP, 1, H, W, L.CoutP, st, nullptr, L.sub_x3));
         if (src2 != 0) {
         PROF("split_ln", 0, 2.0 * M * L.C * 4,
              ln_rows(0, cur, h->xn, L.sub_g, L.sub_b, nullptr, tokens, tokens, M, L.C, L.Cp, st));
@@ -1311,6 +1312,15 @@ static int ensure_pvq_tables(escx_handle_s* h, hipStream_t st) {
             if (!bw.x3a) ESCX_HIP(hipMalloc(&bw.x3a, attn_x3_bytes(L.Cp, L.attn_mode, L.n_groups)));
             attn_x3_pack(bw.waf, bw.x3a, L.Cp, L.attn_mode, L.n_groups, st);
         }
+    // the split weight streams of PatchMerge / PatchSplit (fused_rowgemm.h rowgemm_x3_kernel; ESCX_ROWGEMM_X3=0: fp32 MFMA)
+    static const bool rg_x3 = [] { const char* e = getenv("ESCX_ROWGEMM_X3"); return !(e && e[0] == '0'); }();
+    for (Layer& L : h->layers) {
+        const int KP = L.scale == 1 ? 2 * L.Cp : L.Cp, Np = L.scale == 1 ? L.CoutP : 2 * L.CoutP;
+        const bool want = rg_x3 && L.scale != 0 && L.sub_wf && (KP == 80 || KP == 96 || KP == 144 || KP == 160 || KP == 192 || KP == 288 || KP == 384);
+        if (!want) { if (L.sub_x3) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(L.sub_x3); L.sub_x3 = nullptr; } continue; }
+        if (!L.sub_x3) ESCX_HIP(hipMalloc(&L.sub_x3, rowgemm_x3_bytes(KP, Np)));
+        rowgemm_x3_pack(L.sub_wf, L.sub_x3, KP, Np, st);
+    }
     h->pvq_tab_stale = false;
     return launch_ok("pvq_tables");
 }

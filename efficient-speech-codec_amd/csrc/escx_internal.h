@@ -52,6 +52,7 @@ struct Layer {                       // one TransformerLayer (attention.py:9-91)
     std::vector<BlockW> blocks;
     float *sub_g = nullptr, *sub_b = nullptr, *sub_w = nullptr;
     float *sub_wf = nullptr;         // scale-change weights in fragment order (fused LN + linear)
+    void* sub_x3 = nullptr;          // the same, split into three bf16 terms (rowgemm_x3_kernel; derived state like BlockW::x3w)
     float *sub_wT = nullptr;         // transposed for dX (training)
 };
 

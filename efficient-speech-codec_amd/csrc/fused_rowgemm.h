@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gemm_engine.h"
+#include "fused_attn.h"       // attn_split3, attn_x3_pack_kernel, bf16x8
 
 namespace escx {
 
@@ -29,6 +30,7 @@ struct RowGemmArgs {
     int nt_chunk;               // output tiles per workgroup column: blockIdx.y owns tiles [y * nt_chunk, (y + 1) * nt_chunk)
     // combine-on-load (COMB instantiations): x is still split over the comb_n fc2 slabs of the last block's hidden-split MLP (see AttnArgs in fused_attn.h)
     const float* comb_partial; const float* comb_bias; long long comb_stride; int comb_n;
+    const void* x3_wf;          // rowgemm_x3_kernel: split weight stream [output tile][3 KS fragments] (attn_x3_pack_kernel), else unused
 };
 
 template <int KP, int SEGS, int TM, int NW, int UT, bool COMB = false>
@@ -148,6 +150,125 @@ __global__ __launch_bounds__(64 * NW) void rowgemm_fused_kernel(RowGemmArgs a) {
                 if (m0 + t * 16 + l15 >= a.M) continue;
                 const f32x4 v = TM == 1 ? acc[t] + acc2[t] : acc[t];
                 if (a.split) { const int s = n / a.C2p; st4(a.out + obase[t][s] + (n - s * a.C2p), v); }
+                else st4(a.out + obase[t][0] + n, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split-operand form (round 5; arithmetic: fused_mlp_x3.h): the K = SEGS * Cp contraction of PatchMerge / PatchSplit on v_mfma_f32_16x16x32_bf16 with
+// the normalised rows and the weights each split exactly into three bf16 terms (six cross products, fp32 accumulation).  Same gather, same
+// LayerNorm, same stores as rowgemm_fused_kernel; the weight stream is [output tile][3 KS fragments] (attn_x3_pack_kernel with no projection tiles,
+// built from Layer::sub_wf), UT tiles per LDS stage.
+// ------------------------------------------------------------------------------------------------
+template <int KP, int SEGS, int TM, int NW, int UT>
+__global__ __launch_bounds__(64 * NW) void rowgemm_x3_kernel(RowGemmArgs a) {
+    ESCX_SET_PRIO_SMALL();
+    constexpr int KS = (KP + 31) / 32, TF = 3 * KS, SEGK = KP / SEGS;
+    extern __shared__ __attribute__((aligned(16))) bf16x8 rg_wbuf[];            // [2][UT * TF * 64]
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = (blockIdx.x * NW + wave) * (16 * TM);
+    const int n_stages = (a.NT + UT - 1) / UT;
+    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.x3_wf);
+
+    auto issue = [&](int st, int buf) {
+        const int cnt = min(UT, a.NT - st * UT) * TF;
+        const bf16x8* src = wsrc + (size_t)(st * UT) * TF * 64 + lane;
+        for (int c = wave; c < cnt; c += NW)
+            __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(&rg_wbuf[(buf * UT * TF + c) * 64]), 16, 0, 0);
+    };
+    issue(0, 0);
+
+    bf16x8 xs[TM][3][KS];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int row = m0 + t * 16 + l15;
+        const float* sp[SEGS];
+#pragma unroll
+        for (int s = 0; s < SEGS; ++s) {
+            sp[s] = nullptr;
+            if (row < a.M) {
+                const int b = row / a.rows_per_clip, rr = row - b * a.rows_per_clip;
+                const int srow = (SEGS == 1) ? rr : a.map[rr * SEGS + s];
+                if (srow >= 0) sp[s] = a.x + ((size_t)b * a.src_rows_per_clip + srow) * a.Cp;
+            }
+        }
+        float xv[KS][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = 32 * ks + 8 * lg;                     // 8 consecutive k of one segment (SEGK % 16 == 0)
+            const int sg = k / SEGK, c = k - sg * SEGK;
+            f32x4 v0 = zero4(), v1 = zero4();
+            if (k < KP && sp[sg < SEGS ? sg : 0] && sg < SEGS) { v0 = ld4(sp[sg] + c); v1 = ld4(sp[sg] + c + 4); }     // rows past M, missing merge sources and the K padding read as zeros
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xv[ks][e] = v0[e]; xv[ks][4 + e] = v1[e]; sum += v0[e]; sum += v1[e]; }
+        }
+        sum = sum_groups(sum);
+        const float mean = sum / (float)(SEGS * a.C);
+        float v = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = xv[ks][e] - mean; v += d * d; }
+        v = sum_groups(v) - (float)(32 * KS - SEGS * a.C) * mean * mean;       // every zero slot added mean^2 (also the all-zero row of a missing merge source: as in the fp32 kernel)
+        const float rstd = 1.0f / sqrtf(v / (float)(SEGS * a.C) + a.eps);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = 32 * ks + 8 * lg;
+            f32x4 g0 = zero4(), g1 = zero4(), b0 = zero4(), b1 = zero4();
+            if (k < KP) { g0 = ld4(a.gamma + k); g1 = ld4(a.gamma + k + 4); b0 = ld4(a.beta + k); b1 = ld4(a.beta + k + 4); }
+            float xn[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xn[e] = (xv[ks][e] - mean) * rstd * g0[e] + b0[e];             // gamma = beta = 0 in the pads
+                xn[4 + e] = (xv[ks][4 + e] - mean) * rstd * g1[e] + b1[e];
+            }
+            attn_split3(xn, xs[t][0][ks], xs[t][1][ks], xs[t][2][ks]);
+        }
+    }
+
+    size_t obase[TM][2];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int row = m0 + t * 16 + l15;
+        if (a.split) {
+            const int b = row / (a.H * a.W); const int r0 = row - b * a.H * a.W; const int h = r0 / a.W, w = r0 - h * a.W;
+            obase[t][0] = ((size_t)(b * 2 * a.H + 2 * h) * a.W + w) * a.C2p;
+            obase[t][1] = ((size_t)(b * 2 * a.H + 2 * h + 1) * a.W + w) * a.C2p;
+        } else {
+            obase[t][0] = obase[t][1] = (size_t)row * (16 * a.NT);
+        }
+    }
+
+    for (int st = 0; st < n_stages; ++st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + 1 < n_stages) issue(st + 1, (st + 1) & 1);
+        const bf16x8* wb = &rg_wbuf[((st & 1) * UT * TF) * 64 + lane];
+        const int nt_end = min(a.NT, (st + 1) * UT);
+        for (int nt = st * UT; nt < nt_end; ++nt, wb += TF * 64) {
+            f32x4 acc[TM], acc2[TM];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) { acc[t] = zero4(); acc2[t] = zero4(); }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 w[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) w[i] = wb[(ks * 3 + i) * 64];
+#define ESCX_RG_X3(I, J, D) _Pragma("unroll") for (int t = 0; t < TM; ++t) D[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[I], xs[t][J][ks], D[t], 0, 0, 0);
+                ESCX_RG_X3(0, 2, acc) ESCX_RG_X3(2, 0, acc2) ESCX_RG_X3(1, 1, acc) ESCX_RG_X3(0, 1, acc2) ESCX_RG_X3(1, 0, acc) ESCX_RG_X3(0, 0, acc2)
+#undef ESCX_RG_X3
+            }
+            const int n = 16 * nt + 4 * lg;
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                if (m0 + t * 16 + l15 >= a.M) continue;
+                const f32x4 v = acc[t] + acc2[t];
+                if (a.split) { const int s2 = n / a.C2p; st4(a.out + obase[t][s2] + (n - s2 * a.C2p), v); }
                 else st4(a.out + obase[t][0] + n, v);
             }
         }

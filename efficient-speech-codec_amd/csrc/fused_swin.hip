@@ -293,6 +293,22 @@ static bool launch_rowgemm_xs_variant(const RowGemmArgs& a, hipStream_t s) {
 
 template <int KP, int SEGS>
 static int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
+    if (a.x3_wf && a.comb_n == 0) {           // split-operand form (fused_rowgemm.h rowgemm_x3_kernel): the widths of the ESC scale changes
+        if constexpr (KP == 96 || KP == 160 || KP == 192 || KP == 288 || KP == 384 || KP == 144 || KP == 80) {
+            constexpr int KSx = (KP + 31) / 32, TFx = 3 * KSx, UTx = 36 / TFx >= 4 ? 4 : (36 / TFx >= 2 ? 2 : 1);
+            constexpr int TMx = KP <= 96 ? 2 : 1, NWx = 4;           // one row tile per wave above K = 96: the three-term operand costs 1.5x the registers of the fp32 one
+            auto kern = rowgemm_x3_kernel<KP, SEGS, TMx, NWx, UTx>;
+            constexpr int lds = 2 * UTx * TFx * 1024;
+            if constexpr (lds > 48 * 1024) {
+                static std::atomic<unsigned> done{0};
+                int dev = 0; (void)hipGetDevice(&dev);
+                const unsigned bit = 1u << (dev & 31);
+                if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
+            }
+            hipLaunchKernelGGL(kern, dim3((a.M + 16 * TMx * NWx - 1) / (16 * TMx * NWx), 1), dim3(64 * NWx), lds, s, a);
+            return 0;
+        }
+    }
     if (a.comb_n > 0) {
 #ifdef ESCX_EXPERIMENTAL       // combine on load: measured slower (profiles/r4_mlp_combine_ab.txt)
         constexpr bool HAS_COMB = (KP == 384) || (KP == 192 && SEGS == 1);      // the scale changes that follow a hidden-split MLP (C = 192 / 384)
@@ -332,11 +348,21 @@ static int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
     return 0;
 }
 
+size_t rowgemm_x3_bytes(int KP, int Np) { return (size_t)(Np / 16) * 3 * ((KP + 31) / 32) * 1024; }
+int rowgemm_x3_pack(const float* wf, void* image, int KP, int Np, hipStream_t s) {
+    const int KK = KP / 16, KS = (KP + 31) / 32, NT = Np / 16;
+    const long long total = (long long)NT * (KS > KK ? KS : KK) * 64;
+    hipLaunchKernelGGL(attn_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(wf), reinterpret_cast<bf16x8*>(image),
+                       NT, 1, KK, KS, 3 * KS, 0u);
+    return 0;
+}
+
 int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, const float* beta, const float* wf, const int* map, int M,
                   int rows_per_clip, int src_rows_per_clip, int C, int Cp, int Np, int split, int H, int W, int C2p, hipStream_t s,
-                  const CombineOnLoad* comb) {
+                  const CombineOnLoad* comb, const void* x3_wf) {
     RowGemmArgs a{x, out, gamma, beta, reinterpret_cast<const f32x4*>(wf), map, M, rows_per_clip, src_rows_per_clip, C, Cp, Np / 16,
-                  split, H, W, C2p, 1e-5f, Np / 16, comb ? comb->partial : nullptr, comb ? comb->bias : nullptr, comb ? comb->stride : 0, comb ? comb->n : 0};
+                  split, H, W, C2p, 1e-5f, Np / 16, comb ? comb->partial : nullptr, comb ? comb->bias : nullptr, comb ? comb->stride : 0, comb ? comb->n : 0,
+                  comb ? nullptr : x3_wf};
     const int KP = segs * Cp;
     if (segs == 1) {
         switch (KP) {
