@@ -154,7 +154,7 @@ extern "C" void escx_destroy(escx_handle h) {
     for (auto& kv : h->maps) (void)hipFree(kv.second);
     if (h->coll_buf) (void)hipFree(h->coll_buf);
     for (Quant& q : h->quants) if (q.tab) (void)hipFree(q.tab);
-    for (Layer& L : h->layers) if (L.sub_x3) (void)hipFree(L.sub_x3);
+    for (Layer& L : h->layers) { if (L.sub_x3) (void)hipFree(L.sub_x3); if (L.sub_x3s) (void)hipFree(L.sub_x3s); }
     for (Layer& L : h->layers) for (BlockW& bw : L.blocks) { if (bw.x3w) (void)hipFree(bw.x3w); if (bw.x3a) (void)hipFree(bw.x3a); }
     if (h->iota_codes) (void)hipFree(h->iota_codes);
     if (h->gmap) (void)hipFree(h->gmap);
@@ -1039,6 +1039,16 @@ static int mlp_x3_maxcp() { static const int v = [] { const char* e = getenv("ES
 // 8 waves share each weight fragment between twice as many rows (half the L2->LDS traffic) and win ties.
 // `cap` = waves per SIMD the kernel's register budget allows (mlp_min_waves / attn_min_waves): at 3, an 8-wave workgroup leaves
 // the third slot of every SIMD empty (one workgroup = 2 waves per SIMD, a second one does not fit), so 4-wave workgroups it is.
+// Waves per workgroup of the split-operand MLP (fused_mlp_x3.h), measured at 36 clips (tools/ab.py, ESCX_MLP_X3_NW in tagged builds; ms per step alone, 4 -> 8 waves):
+// C = 45 1.25 -> 1.17, C = 72 0.96 -> 0.84, C = 96 1.13 -> 0.97, C = 144 1.34 -> 1.55, C = 192 0.97 -> 1.00, C = 384 1.59 -> 1.11 (8 waves cap the kernel at 256
+// registers with a small spill, but put two waves on every SIMD).  Small grids keep the fp32 kernel's rule (`variant`): a wave per SIMD first.
+static int mlp_x3_nw(int M, int Cp, int variant) {
+    const long long tiles = (M + 15) / 16;
+    if (Cp == 144 || Cp == 192) return 4;
+    if (Cp == 384) return variant == 3 ? 8 : 4;
+    return tiles >= 8 * 512 ? 8 : (variant == 3 ? 8 : 4);
+}
+
 static int pick_nw(long long tiles, int units, int cap = 4) {
     static const bool cap_rule = [] { const char* e = ESCX_TUNE_ENV("ESCX_NW_CAP_RULE"); return !(e && e[0] == '0'); }();
     if (cap == 3 && cap_rule) return 4;
@@ -1112,7 +1122,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         bool attn_done = false;
         if (h->use_fused && h->use_fused_attn && L.attn_mode >= 0) {
             int frc = 0;
-            int nw = h->attn_nw ? h->attn_nw : (L.Cp > 192 ? 4 : pick_nw(Ms / 16, attn_windows_per_wave(L.Cp), attn_cap(L.Cp, attn_windows_per_wave(L.Cp))));    // 8 waves cap the kernel at 256 VGPRs: spills above C = 192
+            int nw = h->attn_nw ? h->attn_nw : ((L.Cp > 192 || (L.Cp == 192 && bw.x3a)) ? 4 : pick_nw(Ms / 16, attn_windows_per_wave(L.Cp), attn_cap(L.Cp, attn_windows_per_wave(L.Cp))));    // 8 waves cap the kernel at 256 VGPRs: spills above C = 192
             if (H == 2 && W % 4 == 0 && h->attn_pack) nw = -(h->attn_nw ? h->attn_nw : (L.Cp > 192 ? 4 : pick_nw((Ms / 16 + 1) / 2, 1)));    // packed half-window pairs
             const double proj_rows = nw < 0 ? dM : dMs;         // packed pairs project only the real tokens
             int gs = h->attn_gs > 0 ? (L.hiddenP >= h->attn_gs * L.Cp ? h->attn_gs : 1) : attn_gs_for(tokens, L.n_groups, L.hiddenP, L.Cp);
@@ -1155,10 +1165,20 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             bool combined = false;
             int hs = (h->mlp_hs > 0 && L.hiddenP >= h->mlp_hs * L.Cp) ? h->mlp_hs : mlp_hs_for(tokens, L.hiddenP / 16, L.Cp);
             const int variant = h->mlp_variant >= 0 ? h->mlp_variant : (hs > 1 ? ((L.Cp >= hs_nw8_cp && mlp_split_nw(M, hs) == 8) ? 3 : 1) : (L.Cp <= tm2_max ? (tm2_nw8 ? 5 : 4) : mlp_variant_for(M, L.Cp)));
+            static const int x3_nw_force = [] { const char* e = ESCX_TUNE_ENV("ESCX_MLP_X3_NW"); return e && e[0] ? atoi(e) : 0; }();
             if (bw.x3w && pend.n == 0 && L.Cp <= mlp_x3_maxcp()) {       // three-term bf16 split on the bf16 matrix cores (fused_mlp_x3.h); same hidden-split rule and combine
+                static const bool split_fold_x3 = [] { const char* e = getenv("ESCX_MLP_SPLIT_FOLD"); return !(e && e[0] == '0'); }();
+                if (split_fold_x3 && L.scale == 2 && j + 1 == L.blocks.size() && hs == 1 && L.sub_x3s) {      // PatchSplit in the epilogue of the layer's last MLP
+                    const MlpSplit sp{reinterpret_cast<const float*>(L.sub_x3s), L.sub_g, L.sub_b, y, 2 * L.CoutP / 16, H, W, L.CoutP};
+                    int src3 = -1, one = 1;
+                    PROF("mlp_x3_split" + tag, 4 * dM * dC * L.hidden + 2.0 * dM * dC * 2 * L.Cout, (dM * dC + dM * 2 * L.Cout) * f4,
+                         src3 = mlp_x3(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.b1, bw.b2, bw.x3w, L.hiddenP, x3_nw_force ? x3_nw_force : mlp_x3_nw(M, L.Cp, variant), &one, nullptr, st, &sp));
+                    if (src3 == 0) { *Hout = 2 * H; return launch_ok(L.prefix.c_str()); }
+                    if (h->prof && !h->prof_recs.empty()) h->prof_recs.pop_back();
+                }
                 int xrc = -1, xhs = hs;
                 PROF("mlp_x3" + tag, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
-                     xrc = mlp_x3(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.b1, bw.b2, bw.x3w, L.hiddenP, (variant == 3 && L.Cp < 384) ? 8 : 4, &xhs, h->hid, st));      // C = 384: 4 waves (352 registers, one wave per SIMD; 8 waves would cap it at 256 and spill)
+                     xrc = mlp_x3(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.b1, bw.b2, bw.x3w, L.hiddenP, x3_nw_force ? x3_nw_force : mlp_x3_nw(M, L.Cp, variant), &xhs, h->hid, st));
                 if (xrc == 0) {
                     if (xhs > 1) { pend = CombineOnLoad{h->hid, bw.b2, (long long)M * L.Cp, xhs}; pend_tag = tag; flush_pending(); }
                     src = cur; continue;
@@ -1320,6 +1340,10 @@ static int ensure_pvq_tables(escx_handle_s* h, hipStream_t st) {
         if (!want) { if (L.sub_x3) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(L.sub_x3); L.sub_x3 = nullptr; } continue; }
         if (!L.sub_x3) ESCX_HIP(hipMalloc(&L.sub_x3, rowgemm_x3_bytes(KP, Np)));
         rowgemm_x3_pack(L.sub_wf, L.sub_x3, KP, Np, st);
+        if (L.scale == 2 && (L.Cp == 80 || L.Cp == 96 || L.Cp == 144) && L.Cp <= x3_max) {       // PatchSplit folded into the split-operand MLP's epilogue
+            if (!L.sub_x3s) ESCX_HIP(hipMalloc(&L.sub_x3s, mlp_x3_split_bytes(L.Cp, Np)));
+            mlp_x3_split_pack(L.sub_wf, L.sub_x3s, L.Cp, Np, st);
+        }
     }
     h->pvq_tab_stale = false;
     return launch_ok("pvq_tables");

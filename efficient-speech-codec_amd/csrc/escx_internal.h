@@ -53,6 +53,7 @@ struct Layer {                       // one TransformerLayer (attention.py:9-91)
     float *sub_g = nullptr, *sub_b = nullptr, *sub_w = nullptr;
     float *sub_wf = nullptr;         // scale-change weights in fragment order (fused LN + linear)
     void* sub_x3 = nullptr;          // the same, split into three bf16 terms (rowgemm_x3_kernel; derived state like BlockW::x3w)
+    void* sub_x3s = nullptr;         // PatchSplit weights in the k-slot order of mlp_x3_kernel's SPLIT epilogue
     float *sub_wT = nullptr;         // transposed for dX (training)
 };
 

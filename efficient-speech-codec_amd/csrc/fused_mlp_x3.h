@@ -79,12 +79,30 @@ __global__ __launch_bounds__(256) void mlp_x3_pack_kernel(const float* __restric
     dst[0] = pack8(s0); dst[64] = pack8(s1); dst[128] = pack8(s2);
 }
 
+// PatchSplit weights for the SPLIT epilogue of mlp_x3_kernel, from the fp32 fragment stream (Layer::sub_wf, [NT][KK][64] float4): fragment (nt, s, i) -> lane (n, g) holds
+// term i of W[16 nt + n][16 (2 s + (e >> 2)) + 4 g + (e & 3)], e = 0..7 - the k-slot <-> channel map of the epilogue (two accumulator tiles = one K step).
+__global__ __launch_bounds__(256) void mlp_x3_split_pack_kernel(const f32x4* __restrict__ wf, bf16x8* __restrict__ out, int NT, int KK) {
+    const int KSY = (KK + 1) / 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)NT * KSY * 64) return;
+    const int lane = (int)(idx & 63), q = (int)(idx >> 6), s = q % KSY, nt = q / KSY;
+    const int l15 = lane & 15, g = lane >> 4;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int kk = 2 * s + (e >> 2); v[e] = kk < KK ? wf[((size_t)nt * KK + kk) * 64 + 16 * g + l15][e & 3] : 0.f; }
+    __bf16 s0[8], s1[8], s2[8];
+    split3_bf16(v, s0, s1, s2);
+    bf16x8* dst = out + ((size_t)(nt * KSY + s) * 3) * 64 + lane;
+    dst[0] = pack8(s0); dst[64] = pack8(s1); dst[128] = pack8(s2);
+}
+
 // the six cross terms (weight term i, activation term j), smallest first
 #define ESCX_X3_TERMS(M) M(0, 2) M(2, 0) M(1, 1) M(0, 1) M(1, 0) M(0, 0)
 
 template <int CP> constexpr int mlp_x3_min_waves() { return CP <= 96 ? 4 : (CP <= 192 ? 2 : 1); }
 
-template <int CP, int NW>
+// SPLIT: PatchSplit in the epilogue (as fused_mlp.h SPLIT): LayerNorm(C) of x + mlp(x) in registers, Linear(C -> 2 C') with split operands, two-row scatter; x is not written.
+template <int CP, int NW, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kernel(MlpArgs a) {
     constexpr int KS = mlp_x3_ks(CP), KK = CP / 16, CH = mlp_x3_frags(CP), NOP = (KK + 1) / 2;
     constexpr bool SINGLE = mlp_x3_single(CP);
@@ -225,6 +243,91 @@ __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kern
         }
     }
 
+    if constexpr (SPLIT) {
+        constexpr int KSY = (KK + 1) / 2, TFY = 3 * KSY, UTY = SF / TFY;           // fragments per output tile of the split weights, output tiles per LDS stage
+        static_assert(UTY >= 1, "one output tile of the split weights must fit a ring slot");
+        const bf16x8* ssrc = reinterpret_cast<const bf16x8*>(a.sp_wf);
+        const int n_st = (a.sp_NT + UTY - 1) / UTY;
+        auto issue_split = [&](int st, int buf) {
+            const int cnt = min(UTY, a.sp_NT - st * UTY) * TFY;
+            const bf16x8* src = ssrc + (size_t)(st * UTY) * TFY * 64 + lane;
+            for (int c = wave; c < cnt; c += NW)
+                __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(&x3_wbuf[(buf * SF + c) * 64]), 16, 0, 0);
+        };
+        __syncthreads();                        // every wave has finished reading the last hidden stage
+        issue_split(0, g & 1);
+        // y = x + (mlp + b2), LayerNorm (rowgemm_fused_kernel's expressions), split: lane (row l15, channels 16 o + 4 lg + r) - two accumulator tiles = the 8 k-slots of one step
+        const float* xres = a.x + (size_t)(live ? row : 0) * CP + 4 * lg;
+        float sum = 0.f;
+#pragma unroll
+        for (int o = 0; o < KK; ++o) {
+            const f32x4 res = ld4(xres + 16 * o);
+            acc[o] += ld4(a.b2 + 16 * o + 4 * lg);
+            acc[o] = live ? res + acc[o] : zero4();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += acc[o][e];
+        }
+        sum = sum_groups(sum);
+        const float smean = sum / (float)a.C;
+        float v = 0.f;
+#pragma unroll
+        for (int o = 0; o < KK; ++o)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = acc[o][e] - smean; v += d * d; }
+        v = sum_groups(v) - (float)(CP - a.C) * smean * smean;
+        const float srstd = 1.0f / sqrtf(v / (float)a.C + a.eps);
+        bf16x8 ys[3][KSY];
+#pragma unroll
+        for (int sy = 0; sy < KSY; ++sy) {
+            float yn[8];
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const int o = 2 * sy + hlf;
+                if (o < KK) {
+                    const f32x4 gm = ld4(a.sp_gamma + 16 * o + 4 * lg), bb = ld4(a.sp_beta + 16 * o + 4 * lg);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) yn[4 * hlf + e] = (acc[o][e] - smean) * srstd * gm[e] + bb[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) yn[4 * hlf + e] = 0.f;
+                }
+            }
+            __bf16 t0[8], t1[8], t2[8];
+            split3_bf16(yn, t0, t1, t2);
+            ys[0][sy] = pack8(t0); ys[1][sy] = pack8(t1); ys[2][sy] = pack8(t2);
+        }
+        size_t ob0 = 0, ob1 = 0;
+        if (live) {
+            const int bb = row / (a.sp_H * a.sp_W); const int r0 = row - bb * a.sp_H * a.sp_W; const int hh = r0 / a.sp_W, ww = r0 - hh * a.sp_W;
+            ob0 = ((size_t)(bb * 2 * a.sp_H + 2 * hh) * a.sp_W + ww) * a.sp_C2p;
+            ob1 = ((size_t)(bb * 2 * a.sp_H + 2 * hh + 1) * a.sp_W + ww) * a.sp_C2p;
+        }
+        for (int st = 0; st < n_st; ++st) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int buf = (g + st) & 1;
+            if (st + 1 < n_st) issue_split(st + 1, buf ^ 1);
+            const bf16x8* wbs = &x3_wbuf[(buf * SF) * 64 + lane];
+            const int nt_end = min(a.sp_NT, (st + 1) * UTY);
+            for (int nt = st * UTY; nt < nt_end; ++nt, wbs += TFY * 64) {
+                f32x4 o0 = zero4(), o1 = zero4();
+#pragma unroll
+                for (int sy = 0; sy < KSY; ++sy) {
+                    bf16x8 w[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) w[i] = wbs[(sy * 3 + i) * 64];
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], ys[2][sy], o0, 0, 0, 0); o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], ys[0][sy], o1, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], ys[1][sy], o0, 0, 0, 0); o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], ys[1][sy], o1, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], ys[0][sy], o0, 0, 0, 0); o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], ys[0][sy], o1, 0, 0, 0);
+                }
+                if (live) {
+                    const int n = 16 * nt + 4 * lg, s2 = n / a.sp_C2p;
+                    st4(a.sp_out + (s2 ? ob1 : ob0) + (n - s2 * a.sp_C2p), o0 + o1);
+                }
+            }
+        }
+        return;
+    }
     if (!live) return;
     if (HS > 1) {               // raw fc2 partial sums; bias + residual are applied by rows_combine_kernel
         float* pr = a.partial + ((size_t)hs * a.M + row) * CP + 4 * lg;

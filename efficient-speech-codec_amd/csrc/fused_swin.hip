@@ -190,10 +190,45 @@ static void launch_mlp_x3(const MlpArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(((a.M + 16 * NW - 1) / (16 * NW)) * hs), dim3(64 * NW), lds, s, a);
 }
 
+size_t mlp_x3_split_bytes(int Cp, int Np) { return (size_t)(Np / 16) * 3 * ((Cp / 16 + 1) / 2) * 1024; }
+int mlp_x3_split_pack(const float* wf, void* image, int Cp, int Np, hipStream_t s) {
+    const int KK = Cp / 16, NT = Np / 16;
+    const long long total = (long long)NT * ((KK + 1) / 2) * 64;
+    hipLaunchKernelGGL(mlp_x3_split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(wf), reinterpret_cast<bf16x8*>(image), NT, KK);
+    return 0;
+}
+
+template <int CP, int NW>
+static void launch_mlp_x3_split(const MlpArgs& a, hipStream_t s) {
+    auto kern = mlp_x3_kernel<CP, NW, true>;
+    constexpr int lds = 2 * mlp_x3_stage_frags(CP) * 1024;
+    if constexpr (lds > 48 * 1024) {
+        static std::atomic<unsigned> done{0};
+        int dev = 0; (void)hipGetDevice(&dev);
+        const unsigned bit = 1u << (dev & 31);
+        if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
+    }
+    hipLaunchKernelGGL(kern, dim3((a.M + 16 * NW - 1) / (16 * NW)), dim3(64 * NW), lds, s, a);
+}
+
 // *hs_io: requested hidden split in, split used out (> 1: x untouched, partial[hs][M][Cp] filled, the caller runs rows_combine) - as mlp_fused
+// split: PatchSplit in the epilogue (split->wf = the image of mlp_x3_split_pack); ESCX_COMB_UNSUPPORTED when the width has no such instantiation
 int mlp_x3(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* b1, const float* b2, const void* image, int hiddenP, int nw, int* hs_io, float* partial,
-           hipStream_t s) {
+           hipStream_t s, const MlpSplit* split) {
     if (!image || hiddenP % 32) return -1;
+    if (split) {
+        if ((hs_io && *hs_io > 1) || !split->wf || !(Cp == 80 || Cp == 96 || Cp == 144)) return ESCX_COMB_UNSUPPORTED;
+        MlpArgs a{};
+        a.x = x; a.gamma = gamma; a.beta = beta; a.b1 = b1; a.b2 = b2; a.M = M; a.C = C; a.HT = hiddenP / 16; a.eps = 1e-5f; a.HS = 1; a.x3_w = image;
+        a.sp_wf = reinterpret_cast<const f32x4*>(split->wf); a.sp_gamma = split->gamma; a.sp_beta = split->beta; a.sp_out = split->out;
+        a.sp_NT = split->NT; a.sp_H = split->H; a.sp_W = split->W; a.sp_C2p = split->C2p;
+        switch (Cp) {
+            case 80: if (nw == 8) launch_mlp_x3_split<80, 8>(a, s); else launch_mlp_x3_split<80, 4>(a, s); return 0;
+            case 96: if (nw == 8) launch_mlp_x3_split<96, 8>(a, s); else launch_mlp_x3_split<96, 4>(a, s); return 0;
+            case 144: if (nw == 8) launch_mlp_x3_split<144, 8>(a, s); else launch_mlp_x3_split<144, 4>(a, s); return 0;
+        }
+        return ESCX_COMB_UNSUPPORTED;
+    }
     int hs = hs_io ? *hs_io : 1;
     if (hs > 1 && (!partial || (hiddenP / 32) % hs)) hs = 1;
     if (hs_io) *hs_io = hs;

@@ -41,8 +41,11 @@ unsigned long long* debug_trace_buffer();      // device buffer set by escx_debu
 // fp32 weights (w1 [hiddenP][Cp], w2 [Cp][hiddenP]); mlp_x3_bytes = its size.  -1: width not instantiated.
 size_t mlp_x3_bytes(int Cp, int hiddenP);
 int mlp_x3_pack(const float* w1, const float* w2, void* image, int Cp, int hiddenP, hipStream_t s);
+struct MlpSplit;
 int mlp_x3(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* b1, const float* b2, const void* image, int hiddenP, int nw, int* hs_io, float* partial,
-           hipStream_t s);
+           hipStream_t s, const MlpSplit* split = nullptr);      // split: PatchSplit in the epilogue, split->wf = image of mlp_x3_split_pack
+size_t mlp_x3_split_bytes(int Cp, int Np);
+int mlp_x3_split_pack(const float* wf, void* image, int Cp, int Np, hipStream_t s);
 void rows_combine(float* dst, const float* src, const float* partial, const float* bias, long long M, int Cp, int n, hipStream_t s);
 
 // LN + linear for PatchMerge (segs = 2, map gives the two source rows) / PatchSplit (segs = 1, split = 1: pixel-shuffled store)
