@@ -42,9 +42,11 @@ NUM_STREAMS = 6
 FLOP_PER_CLIP = 56.75e9            # BASELINE.md section 3 (2xMAC over linear/bmm/conv, S=6)
 PEAK_F32_MFMA = 157.3e12           # MI355X_MICROARCH.md chip table
 PEAK_HBM = 8.0e12
-CODEC_DTYPE = ("f32" if os.environ.get("ESCX_MLP_X3") == "0" else
-               "f32 (fp32 storage and accumulation everywhere; in the fused MLPs every fp32 operand is split EXACTLY into three bf16 terms and the six leading "
-               "cross products run on the bf16 MFMA: fp32-grade error, tests/test_gpu_parity.py::test_layer_accuracy_against_fp64; ESCX_MLP_X3=0 = fp32 MFMA only, see fp32_mfma_only)")
+FP32_MFMA_ONLY = all(os.environ.get(k) == "0" for k in ("ESCX_MLP_X3", "ESCX_ATTN_X3", "ESCX_ROWGEMM_X3"))
+CODEC_DTYPE = ("f32" if FP32_MFMA_ONLY else
+               "f32 (fp32 storage and accumulation everywhere; the K = C contractions of the MLPs, of the attention's Q / K / V and output projections and of PatchMerge / PatchSplit "
+               "run on the bf16 MFMA with every fp32 operand split EXACTLY into three bf16 terms, six exact cross products each: fp32-grade error, measured at or below the "
+               "reference's own float32 error against float64 per layer (tests/test_gpu_parity.py::test_layer_accuracy_against_fp64); all-fp32-MFMA path: see fp32_mfma_only)")
 PEAK_BF16_MFMA = 2500e12          # dense bf16 (MI355X_MICROARCH.md): the fused MLPs issue six bf16 cross-term MFMAs per fp32 product (fused_mlp_x3.h)
 
 
@@ -481,7 +483,7 @@ def fp32_mfma_only_rider(args):
     """The same workload with every contraction on the fp32 MFMA (ESCX_MLP_X3=0, the round-4 arithmetic): a child process (the library reads the switch once),
     same steps, no riders.  Reported next to the headline so that both arithmetic choices are driver-observed."""
     import subprocess
-    env = dict(os.environ, ESCX_MLP_X3="0")
+    env = dict(os.environ, ESCX_MLP_X3="0", ESCX_ATTN_X3="0", ESCX_ROWGEMM_X3="0")
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline", "--skip-isolated",
            "--skip-single-clip", "--skip-other-workloads", "--profile-steps", "2"]
     try:
@@ -489,7 +491,7 @@ def fp32_mfma_only_rider(args):
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
         return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
-                "note": "ESCX_MLP_X3=0: fused MLPs on v_mfma_f32_16x16x4_f32 (bit-identical to round 4's results)"}
+                "note": "ESCX_MLP_X3=0 ESCX_ATTN_X3=0 ESCX_ROWGEMM_X3=0: every contraction on v_mfma_f32_16x16x4_f32 (bit-identical to round 4's results)"}
     except Exception as e:
         return {"error": f"{type(e).__name__}: {e}"}
 
@@ -805,7 +807,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, sd, x_cpu)
         else:
             out["cpu_baseline"] = None
-        if world == 1 and not use_dist and not args.skip_other_workloads and os.environ.get("ESCX_MLP_X3") != "0":
+        if world == 1 and not use_dist and not args.skip_other_workloads and not FP32_MFMA_ONLY:
             out["fp32_mfma_only"] = fp32_mfma_only_rider(args)
         if world == 1 and not use_dist and not args.skip_other_workloads:
             del model, x, allc, wave

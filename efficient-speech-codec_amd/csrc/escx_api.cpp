@@ -1139,7 +1139,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             if (!launched)
             PROF("attn_fused" + tag, 2 * proj_rows * dC * 4 * dC + 4 * dMs * 16 * dC, 2 * dM * dC * f4,
                  frc = attn_fused(src, cur, L.Cp, L.C, L.attn_mode, L.n_groups, bw.ln1_g, bw.ln1_b, bw.waf, bw.baf, bw.bias_tab_f, bw.bproj,
-                                  map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, &gs, h->hid, M, st, nullptr, nullptr, (nw > 0 || L.Cp == 384) ? bw.x3a : nullptr));      // C = 384: the split stream exists for the packed (nw < 0) kernel only
+                                  map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, &gs, h->hid, M, st, nullptr, nullptr, (nw > 0 || L.Cp == 384) ? bw.x3a : nullptr, bw.x3a_pairs ? 1 : 0));      // C = 384: the split stream exists for the packed (nw < 0) kernel only
             attn_done = (frc == 0);
             if (attn_done && gs > 1)
                 PROF("attn_combine" + tag, 0, (gs + 2) * dM * L.Cp * f4, rows_combine(cur, src, h->hid, bw.bproj, M, L.Cp, gs, st));
@@ -1330,7 +1330,12 @@ static int ensure_pvq_tables(escx_handle_s* h, hipStream_t st) {
                               ((L.Cp == 48 && L.attn_mode == 0) || (L.Cp == 80 && L.attn_mode != 1) || (L.Cp == 96 && L.attn_mode != 2) || (L.Cp == 144 && L.attn_mode != 2) || (L.Cp == 192 && L.attn_mode == 1) || (L.Cp == 384 && L.attn_mode == 0));      // 384: the packed H = 2 kernel only (the launcher falls back to fp32 elsewhere)
             if (!want) { if (bw.x3a) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(bw.x3a); bw.x3a = nullptr; } continue; }
             if (!bw.x3a) ESCX_HIP(hipMalloc(&bw.x3a, attn_x3_bytes(L.Cp, L.attn_mode, L.n_groups)));
-            attn_x3_pack(bw.waf, bw.x3a, L.Cp, L.attn_mode, L.n_groups, st);
+            // pair order (the output projection in split form too) where two head groups always travel together: mode 0 / 1, group counts that stay even under the 3-way head-group split
+            // OPT-IN, tagged builds (ESCX_ATTN_X3_PAIRS=1): measured no faster - the operand split of the O^T tiles and the two extra stage barriers per pair eat the
+            // matrix time saved, and at C = 192 the kernel drops to one wave per SIMD (profiles/r5_attn_ab.txt)
+            static const bool pairs_on = [] { const char* e = ESCX_TUNE_ENV("ESCX_ATTN_X3_PAIRS"); return e && e[0] == '1'; }();
+            bw.x3a_pairs = pairs_on && L.attn_mode != 2 && L.Cp != 48 && L.n_groups % 2 == 0 && (L.n_groups % 3 != 0 || (L.n_groups / 3) % 2 == 0);
+            attn_x3_pack(bw.waf, bw.x3a, L.Cp, L.attn_mode, L.n_groups, st, bw.x3a_pairs ? 1 : 0);
         }
     // the split weight streams of PatchMerge / PatchSplit (fused_rowgemm.h rowgemm_x3_kernel; ESCX_ROWGEMM_X3=0: fp32 MFMA)
     static const bool rg_x3 = [] { const char* e = getenv("ESCX_ROWGEMM_X3"); return !(e && e[0] == '0'); }();

@@ -39,6 +39,7 @@ struct BlockW {                      // one SwinBlock, packed
     float *waf, *baf, *bias_tab_f;   // fused attention: weight stream [group][tile][KK][64][4], tile biases, padded bias table
     float *wqkvT = nullptr, *wprojT = nullptr, *w1T = nullptr, *w2T = nullptr;     // transposed copies for the dX GEMMs of the training step
     long long tab_off = -1;          // flat offset of attn.relative_position_bias_table (its gradient is written there directly)
+    bool x3a_pairs = false;          // x3a is in pair order (output projection split as well: fused_attn.h X3P)
     void* x3a = nullptr;             // fused_attn.h X3: Q / K / V tiles split into three bf16 terms (derived state like x3w)
     void* x3w = nullptr;             // fused_mlp_x3.h: fc1 / fc2 split into three bf16 terms (device allocation of its own; derived state, rebuilt with the PVQ tables)
 };

@@ -21,6 +21,7 @@
 // LDS ring filled by global_load_lds_dwordx4, UT tiles per stage.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "gemm_engine.h"
 #include "gemm_bf16.h"
 
@@ -44,6 +45,41 @@ __device__ __forceinline__ void attn_split3(const float (&v)[8], bf16x8& t0, bf1
         const float r2 = r1 - (float)a2;
         t0[e] = a1; t1[e] = a2; t2[e] = (__bf16)r2;
     }
+}
+// Pair-order stream of the X3P instantiations, from the fp32 fragment stream ([group][Q K V P][KK][64] float4): per pair of groups eight tiles of TF fragments,
+// [Q0 K0 V0 Q1 K1 V1 P_lo P_hi]; the projection halves hold, per output tile `to`, three fragments (term i) -> lane (channel n, g): term i of
+// (e < 4 ? Wp_group0[16 to + n][4 g + e] : Wp_group1[16 to + n][4 g + e - 4]).  One thread per (pair, tile, fragment triple, lane).
+__global__ __launch_bounds__(256) void attn_x3p_pack_kernel(const f32x4* __restrict__ waf, bf16x8* __restrict__ out, int n_pairs, int KK, int KS, int TF) {
+    const int H = (KK + 1) / 2, per_tile = (KS > H ? KS : H) * 64;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)n_pairs * 8 * per_tile) return;
+    const int tile8 = (int)(idx / per_tile), r = (int)(idx - (long long)tile8 * per_tile), f = r >> 6, lane = r & 63;
+    const int pair = tile8 >> 3, ti = tile8 & 7;
+    const int l15 = lane & 15, g = lane >> 4;
+    bf16x8* dst = out + ((size_t)pair * 8 + ti) * TF * 64;
+    float v[8];
+    int fslot;
+    if (ti < 6) {
+        if (f >= KS) return;
+        const f32x4* src = waf + ((size_t)(2 * pair + ti / 3) * 4 + ti % 3) * KK * 64;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kk = 2 * f + (g >> 1), lgs = 2 * (g & 1) + (e >> 2);
+            v[e] = kk < KK ? src[kk * 64 + 16 * lgs + l15][e & 3] : 0.f;
+        }
+        fslot = f;
+    } else {
+        const int to = (ti == 6 ? 0 : H) + f;
+        if (f >= (ti == 6 ? H : KK - H)) return;
+        const f32x4* p0 = waf + ((size_t)(2 * pair) * 4 + 3) * KK * 64, *p1 = waf + ((size_t)(2 * pair + 1) * 4 + 3) * KK * 64;
+        const f32x4 a0 = p0[to * 64 + lane], a1 = p1[to * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a0[e]; v[4 + e] = a1[e]; }
+        fslot = f;
+    }
+    bf16x8 t0, t1, t2;
+    attn_split3(v, t0, t1, t2);
+    dst[(fslot * 3 + 0) * 64 + lane] = t0; dst[(fslot * 3 + 1) * 64 + lane] = t1; dst[(fslot * 3 + 2) * 64 + lane] = t2;
 }
 // builds the X3 stream from the fp32 fragment stream (BlockW::waf): one thread per (group, tile, K-step or projection fragment, lane)
 __global__ __launch_bounds__(256) void attn_x3_pack_kernel(const f32x4* __restrict__ waf, bf16x8* __restrict__ out, int n_tiles, int TPG, int KK, int KS, int TF, unsigned proj_mask) {
@@ -95,6 +131,7 @@ struct AttnArgs {
     // window attention and output projection are ONE launch and nothing is read back (train.hip, layer_fwd).
     float* tape_xn; float* tape_qkv; float* tape_o; int ldq, ldo, hdp, nH;
     const void* x3_wf;          // X3 instantiations: the split weight stream (attn_x3_pack_kernel), else unused
+    int x3_pairs;               // the stream is in pair order [Q0 K0 V0 Q1 K1 V1 P_lo P_hi] (attn_x3p_pack_kernel): X3P instantiations
 };
 
 // One 16-byte piece of a block-input row: plain, or combined on the fly from the hidden-split MLP's slabs (see AttnArgs).
@@ -152,9 +189,14 @@ template <int CP, int TMW> constexpr int attn_min_waves() { return (CP * TMW <= 
 // X3 instantiations hold the LayerNorm output as three bf16 terms (1.5x the registers of the fp32 operand): one occupancy step down
 template <int CP, int TMW, bool X3> constexpr int attn_min_waves_x() { return !X3 ? attn_min_waves<CP, TMW>() : ((CP * TMW <= 96) ? 3 : ((CP * TMW <= 160) ? 2 : 1)); }
 
-template <int CP, int MODE, int UT, int TMW, int NW, bool COMB = false, bool TAPE = false, bool X3 = false>
+// X3P (with X3, MODE 0 / 1, an even number of head groups per workgroup): the OUTPUT PROJECTION in split form too.  Its contraction is only 16 deep per head group, so two
+// consecutive groups form one 32-deep step: the two O^T accumulator tiles of a lane are the 8 k-slots (as the two fc1 tiles are in fused_mlp_x3.h).  Stream per PAIR of groups:
+// [Q0 K0 V0 Q1 K1 V1 P_lo P_hi] - the same eight tiles as two groups of [Q K V P]; P_lo / P_hi hold, per output tile of the first / second half, the three split fragments
+// -> lane (channel, g): term i of Wp[channel][dims of group 0: 4 g + e | group 1: 4 g + e - 4].
+template <int CP, int MODE, int UT, int TMW, int NW, bool COMB = false, bool TAPE = false, bool X3 = false, bool X3P = false>
 __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void attn_fused_kernel(AttnArgs a) {
     static_assert(!X3 || (!COMB && !TAPE), "the split-operand form exists for the plain inference instantiations");
+    static_assert(!X3P || (X3 && MODE != 2), "pair projection: split-operand instantiations with one tile per head group");
 #ifdef ESCX_ATTN_PRIO
     __builtin_amdgcn_s_setprio(ESCX_ATTN_PRIO);     // tuning builds: static wave priority against co-running launches of the other batch part
 #endif
@@ -451,6 +493,24 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void at
             if constexpr (!X3) { if (to + 1 < KK) ESCX_SGB_MFMA(8 * TMW); else ESCX_SGB_MFMA(4 * TMW); }
         }
     };
+    // X3P: half of the output tiles of the pair projection (tiles [lo, hi)), six cross terms per K = 32 step, two output tiles at a time
+    auto proj_pair = [&](auto lo_c, auto hi_c, const bf16x8 (*hs)[3]) {
+        constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;         // compile-time: acc[] must stay in registers
+        const bf16x8* tb = reinterpret_cast<const bf16x8*>(wb) + (size_t)(((tile - 1) % UT) * TF) * 64;
+#pragma unroll
+        for (int j = 0; j < hi - lo; j += 2) {
+            constexpr int dummy = 0; (void)dummy;
+            const int to = lo + j;
+            bf16x8 w[3], wn[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { w[i] = tb[(j * 3 + i) * 64]; wn[i] = tb[((j + 1 < hi - lo ? j + 1 : j) * 3 + i) * 64]; }
+            dma_pinned();
+#define ESCX_PP(I, J) _Pragma("unroll") for (int t = 0; t < TMW; ++t) { acc[to][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[I], hs[t][J], acc[to][t], 0, 0, 0); \
+                                                     if (to + 1 < hi) acc[to + 1 < hi ? to + 1 : to][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[I], hs[t][J], acc[to + 1 < hi ? to + 1 : to][t], 0, 0, 0); }
+            ESCX_PP(0, 2) ESCX_PP(2, 0) ESCX_PP(1, 1) ESCX_PP(0, 1) ESCX_PP(1, 0) ESCX_PP(0, 0)
+#undef ESCX_PP
+        }
+    };
 
     // Per-group constants (q/k/v biases, relative-position bias rows) are fetched one head group ahead, right behind a stage
     // barrier: they land under a whole group of MFMA work, and the no-op pin behind the next group's first barrier (whose
@@ -492,8 +552,9 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void at
 #pragma unroll
     for (int t = 0; t < TMW; ++t) shmask[t] = window_shift_mask(l15, lg, lastH[t], lastW[t]);
     GroupConst cur = load_consts(g0);
+    f32x4 o_prev[X3P ? TMW : 1];                // X3P: the first group's O^T tile waits for its partner
     for (int g = g0; g < g1; ++g) {
-        tile = 0;
+        if (!X3P || ((g - g0) & 1) == 0) tile = 0;
         ESCX_TS(t0)
         begin_tile();                           // stage barrier
         pin_consts(cur);
@@ -555,8 +616,28 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void at
                 tape_rows(a.tape_o, a.ldo, 0, g, 0, o);
             }
             ESCX_TS(t5)
+            if constexpr (X3P) {
+                if (((g - g0) & 1) == 0) {
+#pragma unroll
+                    for (int t = 0; t < TMW; ++t) o_prev[t] = o[t];
+                } else {
+                    bf16x8 hs[TMW][3];
+#pragma unroll
+                    for (int t = 0; t < TMW; ++t) {
+                        float v8[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v8[e] = o_prev[t][e]; v8[4 + e] = o[t][e]; }
+                        attn_split3(v8, hs[t][0], hs[t][1], hs[t][2]);
+                    }
+                    begin_tile();
+                    proj_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, (KK + 1) / 2>{}, hs);
+                    begin_tile();
+                    proj_pair(std::integral_constant<int, (KK + 1) / 2>{}, std::integral_constant<int, KK>{}, hs);
+                }
+            } else {
             begin_tile();
             proj_accumulate(o);
+            }
             ESCX_TS(t6)
 #ifdef ESCX_ATTN_TRACE
             tr[0] += t1 - t0; tr[1] += t2 - t1; tr[2] += t3 - t2; tr[3] += t4 - t3; tr[4] += t5 - t4; tr[5] += t6 - t5;
@@ -654,9 +735,10 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void at
 // key / value operands are rebuilt in registers: real slots come from the packed tile (a half-row swap for K, a
 // lane-group swap for V^T), padded slots are the bias.  Requires H == 2, W % 4 == 0, one head per tile (MODE 0).
 // ------------------------------------------------------------------------------------------------
-template <int CP, int UT, int NW, bool COMB = false, bool X3 = false>
+template <int CP, int UT, int NW, bool COMB = false, bool X3 = false, bool X3P = false>
 __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, 1, X3>())) void attn_packed_kernel(AttnArgs a) {
     static_assert(!X3 || !COMB, "the split-operand form exists for the plain instantiation");
+    static_assert(!X3P || X3, "pair projection: split-operand instantiation");
 #ifdef ESCX_ATTN_PRIO
     __builtin_amdgcn_s_setprio(ESCX_ATTN_PRIO);
 #endif
@@ -861,8 +943,9 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, 1, X3>())) void attn
 
     const f32x4 shmask = window_shift_mask(qslot, lg, true, lastW);
     GroupConst cur = load_consts(g0);
+    f32x4 o_prev = zero4();                     // X3P: the first group's O^T tile waits for its partner (attn_fused_kernel)
     for (int g = g0; g < g1; ++g) {
-        tile = 0;
+        if (!X3P || ((g - g0) & 1) == 0) tile = 0;
         begin_tile();
         asm volatile("" : "+v"(cur.bq), "+v"(cur.bk), "+v"(cur.bt), "+v"(cur.bv));     // see attn_fused_kernel
         const GroupConst nxt = load_consts(min(g + 1, g1 - 1));
@@ -904,6 +987,37 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, 1, X3>())) void attn
         }
         ESCX_SGB_MFMA(8);
         const f32x4 o = isB ? oB : oA;
+        if constexpr (X3P) {
+            if (((g - g0) & 1) == 0) { o_prev = o; cur = nxt; continue; }
+            float v8[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v8[e] = o_prev[e]; v8[4 + e] = o[e]; }
+            bf16x8 hs[3];
+            attn_split3(v8, hs[0], hs[1], hs[2]);
+            constexpr int H = (KK + 1) / 2;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                begin_tile();
+                const bf16x8* tb = reinterpret_cast<const bf16x8*>(wb) + (size_t)(((tile - 1) % UT) * TF) * 64;
+                const int lo = half ? H : 0, n = half ? KK - H : H;
+#pragma unroll
+                for (int j = 0; j < H; j += 2) {
+                    if (j < n) {
+                        const int to = lo + j;
+                        bf16x8 w[3], wn[3];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) { w[i] = tb[(j * 3 + i) * 64]; wn[i] = tb[((j + 1 < n ? j + 1 : j) * 3 + i) * 64]; }
+                        dma_pinned();
+#define ESCX_PKP(I, J) acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[I], hs[J], acc[to], 0, 0, 0); \
+                       if (j + 1 < n) acc[j + 1 < n ? to + 1 : to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[I], hs[J], acc[j + 1 < n ? to + 1 : to], 0, 0, 0);
+                        ESCX_PKP(0, 2) ESCX_PKP(2, 0) ESCX_PKP(1, 1) ESCX_PKP(0, 1) ESCX_PKP(1, 0) ESCX_PKP(0, 0)
+#undef ESCX_PKP
+                    }
+                }
+            }
+            cur = nxt;
+            continue;
+        }
         begin_tile();
         const f32x4* ptb = wb + (size_t)(((tile - 1) % UT) * TF) * 64;      // X3: the projection tile's fp32 fragments, read straight from LDS
 #pragma unroll

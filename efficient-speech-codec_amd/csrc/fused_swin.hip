@@ -462,7 +462,23 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
     }
     // split-operand (3 x bf16) Q / K / V projections: the (width, head mapping) pairs of the ESC configurations
     if constexpr ((CP == 48 && MODE == 0) || (CP == 80 && (MODE == 0 || MODE == 2)) || (CP == 96 && MODE != 2) || (CP == 144 && MODE != 2) || (CP == 192 && MODE == 1)) {
-        if (a.x3_wf) {
+#ifdef ESCX_EXPERIMENTAL       // pair-wise split output projection: measured no faster (profiles/r5_attn_ab.txt), tagged builds only
+        if constexpr (MODE != 2 && CP != 48) {
+        if (a.x3_wf && a.x3_pairs) {        // pair-order stream: the output projection in split form too
+            auto kern = attn_fused_kernel<CP, MODE, UT, TMW, NW, false, false, true, true>;
+            constexpr int lds = 2 * UT * attn_x3_tf(CP) * 1024;
+            if constexpr (lds > 48 * 1024) {
+                static std::atomic<unsigned> done{0};
+                int dev = 0; (void)hipGetDevice(&dev);
+                const unsigned bit = 1u << (dev & 31);
+                if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
+            }
+            hipLaunchKernelGGL(kern, dim3(((a.n_windows + per_block - 1) / per_block) * gs), dim3(64 * NW), lds, s, a);
+            return 0;
+        }
+        }
+#endif
+        if (a.x3_wf && !a.x3_pairs) {
             auto kern = attn_fused_kernel<CP, MODE, UT, TMW, NW, false, false, true>;
             constexpr int lds = 2 * UT * attn_x3_tf(CP) * 1024;
             if constexpr (lds > 48 * 1024) {
@@ -511,7 +527,19 @@ static int launch_attn_packed(const AttnArgs& a, hipStream_t s) {
         return ESCX_COMB_UNSUPPORTED;
     }
     if constexpr (CP == 384 && NW == 4) {        // split-operand Q / K / V projections (ESC's bottom scale)
-        if (a.x3_wf) {
+#ifdef ESCX_EXPERIMENTAL
+        if (a.x3_wf && a.x3_pairs) {
+            auto kern = attn_packed_kernel<CP, UT, NW, false, true, true>;
+            constexpr int lds = 2 * UT * attn_x3_tf(CP) * 1024;
+            static std::atomic<unsigned> done{0};
+            int dev = 0; (void)hipGetDevice(&dev);
+            const unsigned bit = 1u << (dev & 31);
+            if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
+            hipLaunchKernelGGL(kern, dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), lds, s, a);
+            return 0;
+        }
+#endif
+        if (a.x3_wf && !a.x3_pairs) {
             auto kern = attn_packed_kernel<CP, UT, NW, false, true>;
             constexpr int lds = 2 * UT * attn_x3_tf(CP) * 1024;
             static std::atomic<unsigned> done{0};
@@ -528,8 +556,18 @@ static int launch_attn_packed(const AttnArgs& a, hipStream_t s) {
 
 size_t attn_x3_bytes(int Cp, int mode, int n_groups) { return (size_t)n_groups * (mode == 2 ? 8 : 4) * attn_x3_tf(Cp) * 1024; }
 
-int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, hipStream_t s) {
+// pairs != 0: pair-order stream (mode 0 / 1, even group count): [Q0 K0 V0 Q1 K1 V1 P_lo P_hi] per two head groups, projection split as well
+int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, hipStream_t s, int pairs) {
     const int KK = Cp / 16, KS = attn_x3_ks(Cp), TF = attn_x3_tf(Cp), TPG = mode == 2 ? 8 : 4;
+    if (pairs) {
+        if (mode == 2 || (n_groups & 1)) return -1;
+        (void)hipMemsetAsync(image, 0, attn_x3_bytes(Cp, mode, n_groups), s);
+        const int H = (KK + 1) / 2;
+        const long long tot = (long long)(n_groups / 2) * 8 * (KS > H ? KS : H) * 64;
+        hipLaunchKernelGGL(attn_x3p_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(waf), reinterpret_cast<bf16x8*>(image),
+                           n_groups / 2, KK, KS, TF);
+        return 0;
+    }
     const unsigned proj_mask = mode == 2 ? ((1u << 5) | (1u << 7)) : (1u << 3);        // stream order [Q, K, V, P] / [Q_lo, K_lo, Q_hi, K_hi, V_lo, P_lo, V_hi, P_hi]
     const int n_tiles = n_groups * TPG;
     (void)hipMemsetAsync(image, 0, attn_x3_bytes(Cp, mode, n_groups), s);
@@ -542,7 +580,7 @@ int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, 
 int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_groups, const float* gamma, const float* beta,
                const float* wf, const float* bqkv, const float* bias_tab, const float* bproj, const int* map, int slots, int tokens,
                int n_windows, int nWh, int nWw, int shifted, float scale, int nw, int* gs_io, float* partial, int rows, hipStream_t s,
-               const CombineOnLoad* comb, const AttnTape* tape, const void* x3_wf) {
+               const CombineOnLoad* comb, const AttnTape* tape, const void* x3_wf, int x3_pairs) {
     int gs = gs_io ? *gs_io : 1;        // head-group split: same in/out convention as mlp_fused
     if (gs > 1 && (!partial || n_groups % gs)) gs = 1;
     if (gs_io) *gs_io = gs;
@@ -550,7 +588,7 @@ int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_grou
                nWh, nWw, shifted, C, n_groups, scale, 1e-5f, gs, partial, rows, g_mlp_trace,
                comb ? comb->partial : nullptr, comb ? comb->bias : nullptr, comb ? comb->stride : 0, comb ? comb->n : 0,
                tape ? tape->xn : nullptr, tape ? tape->qkv : nullptr, tape ? tape->o : nullptr, tape ? tape->ldq : 0, tape ? tape->ldo : 0,
-               tape ? tape->hdp : 0, tape ? tape->nH : 0, (comb || tape) ? nullptr : x3_wf};
+               tape ? tape->hdp : 0, tape ? tape->nH : 0, (comb || tape) ? nullptr : x3_wf, x3_pairs};
     if (tape && nw < 0) return ESCX_COMB_UNSUPPORTED;      // the packed H = 2 form has no tape stores
     // H == 2 scale with no padding along W: two half-real windows share one tile (nw < 0 encodes "packing allowed", |nw| waves)
     if (nw < 0) {

@@ -69,9 +69,9 @@ int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_grou
                const float* wf, const float* bqkv, const float* bias_tab, const float* bproj, const int* map, int slots, int tokens,
                int n_windows, int nWh, int nWw, int shifted, float scale, int nw, int* gs_io, float* partial, int rows, hipStream_t s,
                const CombineOnLoad* comb = nullptr, const struct AttnTape* tape = nullptr,
-               const void* x3_wf = nullptr);     // split (3 x bf16) Q / K / V weight stream of this block (attn_x3_pack), or nullptr = fp32 MFMA everywhere
+               const void* x3_wf = nullptr, int x3_pairs = 0);     // split (3 x bf16) weight stream of this block (attn_x3_pack; pairs: its pair-order form), nullptr = fp32 MFMA
 size_t attn_x3_bytes(int Cp, int mode, int n_groups);
-int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, hipStream_t s);
+int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, hipStream_t s, int pairs = 0);
 // training forward: the fused attention also writes what the backward reads (fused_attn.h, TAPE); returns ESCX_COMB_UNSUPPORTED when the width has
 // no TAPE instantiation (the caller runs the unfused sequence)
 struct AttnTape { float* xn; float* qkv; float* o; int ldq, ldo, hdp, nH; };

@@ -299,7 +299,7 @@ inline float* G(escx_handle_s* h, const float* w) { return h->garena + (w - rein
 // path's kernel (only x1 stays on the tape), backward = train_mlp_fused.h (hidden tile recomputed on the fly).  ESCX_TRAIN_MLP_FUSED=0: unfused.
 inline bool mlp_train_fused(const Layer& L) {
     static const bool on = [] { const char* e = getenv("ESCX_TRAIN_MLP_FUSED"); return !(e && e[0] == '0'); }();
-    static const bool on72 = [] { const char* e = getenv("ESCX_TRAIN_MLP_FUSED_C72"); return !(e && e[0] == '0'); }();
+    static const bool on72 = [] { const char* e = ESCX_TUNE_ENV("ESCX_TRAIN_MLP_FUSED_C72"); return !(e && e[0] == '0'); }();
     return on && ((L.Cp == 48 && L.hiddenP == 192) || (on72 && L.Cp == 80 && L.hiddenP == 288));
 }
 
@@ -812,7 +812,7 @@ int layer_bwd(escx_handle_s* h, const Layer& L, const LayerTape& LT, const float
         if ((rc = get_map(h, H, W, 10 + shift, &inv))) return rc;
         // ---- MLP: x2 = x1 + W2 gelu(W1 LN2(x1) + b1) + b2 ----
         const bool fmlp = mlp_train_fused(L);
-        static const bool ln_fused = [] { const char* e = getenv("ESCX_LN_FUSED"); return !(e && e[0] == '0'); }();
+        static const bool ln_fused = [] { const char* e = ESCX_TUNE_ENV("ESCX_LN_FUSED"); return !(e && e[0] == '0'); }();
         if (fmlp) {
             if (slots != tokens) ESCX_HIP(hipMemsetAsync(dx1s, 0, (size_t)Ms * L.Cp * sizeof(float), st));      // pad slots carry no gradient
             PROF("B.mlp_fused" + tg, 10.0 * M * L.C * L.hidden, (3.0 * M + Ms) * L.Cp * 4,

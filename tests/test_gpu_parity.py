@@ -888,12 +888,12 @@ def test_fallback_kernel_forms_against_the_default(tmp_path):
     attn_gs_off (the C = 384 attention without the head-group split: another projection order) keeps the codes, audio within 1e-6 RMS."""
     arms = {"default": {}, "pvq_three_launch": {"ESCX_PVQ_FUSED": "0", "ESCX_PVQ_TABLE": "0"}, "pvq_fused_mfma_up": {"ESCX_PVQ_TABLE": "0"},
             "pvq_tables_only": {"ESCX_PVQ_FUSED": "0"}, "pvq_up_engine": {"ESCX_PVQ_FUSED": "0", "ESCX_PVQ_TABLE": "0", "ESCX_PVQ_UP_KERNEL": "0"},
-            "attn_gs_off": {"ESCX_ATTN_GS_TOKENS": "0"}, "mlp_fp32_mfma": {"ESCX_MLP_X3": "0"}}
+            "attn_gs_off": {"ESCX_ATTN_GS_TOKENS": "0"}, "all_fp32_mfma": {"ESCX_MLP_X3": "0", "ESCX_ATTN_X3": "0", "ESCX_ROWGEMM_X3": "0"}}
     got = _ab_arms(arms, tmp_path)
     ref = got["default"]
     for name in ("pvq_three_launch", "pvq_fused_mfma_up", "pvq_tables_only", "pvq_up_engine"):
         assert np.array_equal(got[name]["codes"], ref["codes"]) and np.array_equal(got[name]["wave"], ref["wave"]), f"{name} is not bit-identical to the default"
-    for name in ("attn_gs_off", "mlp_fp32_mfma"):      # mlp_fp32_mfma: the fused MLPs on the fp32 MFMA instead of the three-term bf16 split (fused_mlp_x3.h): other summation order
+    for name in ("attn_gs_off", "all_fp32_mfma"):      # all_fp32_mfma: every contraction on the fp32 MFMA instead of the three-term bf16 split (DESIGN.md section 10): other summation order
         assert np.array_equal(got[name]["codes"], ref["codes"]), f"{name}: codes differ from the default"
         rms = float(np.sqrt(np.mean((got[name]["wave"].astype(np.float64) - ref["wave"]) ** 2)))
         assert rms <= 1e-6, f"{name}: audio rms {rms}"
@@ -910,7 +910,7 @@ def test_experimental_kernel_forms_against_the_default(tmp_path):
     if not os.path.exists(os.path.join(ROOT, "efficient-speech-codec_amd", "esc", "lib", "libescx_exp.so")):
         pytest.skip("no tagged experimental build (libescx_exp.so): the product library does not contain the rejected forms")
     # the rejected forms are variants of the fp32-MFMA kernels: both sides run with the split-operand kernels off (ESCX_MLP_X3=0, ESCX_ATTN_X3=0)
-    f32 = {"ESCX_MLP_X3": "0", "ESCX_ATTN_X3": "0"}
+    f32 = {"ESCX_MLP_X3": "0", "ESCX_ATTN_X3": "0", "ESCX_ROWGEMM_X3": "0"}
     ref = _ab_arms({"default": {}}, tmp_path, f32)["default"]
     arms = {"mlp_fused_combine": {"ESCX_MLP_FUSED_COMBINE": "1"}, "combine_on_load": {"ESCX_COMBINE_ON_LOAD": "1"},
             "rowgemm_ws": {"ESCX_ROWGEMM_WS": "4"}, "rowgemm_xs": {"ESCX_ROWGEMM_XS": "1"},

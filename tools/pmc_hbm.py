@@ -24,7 +24,7 @@ def load(d, counter):
 
 
 CODEC_KERNEL_SOURCES = ("fused_attn.h", "fused_deembed.h", "fused_mlp.h", "fused_rowgemm.h", "fused_swin.hip", "gemm_engine.h", "gemm_misc.hip",
-                        "gemm_swin.hip", "kernels.h", "kernels_misc.hip", "launchers.h", "fused_pvq.h", "tune_env.h")
+                        "gemm_swin.hip", "kernels.h", "kernels_misc.hip", "launchers.h", "fused_pvq.h", "tune_env.h", "fused_mlp_x3.h")
 
 
 def csrc_hash():
@@ -47,9 +47,12 @@ def main():
         n = max(fe[k][0], wr[k][0], 1)
         f = fe[k][1] / max(fe[k][0], 1); w = wr[k][1] / max(wr[k][0], 1)
         allk[k] = {"launches": n, "fetch_KiB_per_launch": round(f, 1), "write_KiB_per_launch": round(w, 1)}
-        m = re.match(r"(mlp_fused_lds_kernel|attn_fused_kernel|attn_packed_kernel)<(\d+),", k)
+        m = re.match(r"(mlp_fused_lds_kernel|mlp_x3_kernel|attn_fused_kernel|attn_packed_kernel)<(\d+),", k)
         if m:
-            ev = ("mlp_fused" if m.group(1).startswith("mlp") else "attn_fused") + f"[C={CP_TO_C.get(int(m.group(2)), int(m.group(2)))}]"
+            fam = "mlp_fused" if m.group(1) == "mlp_fused_lds_kernel" else ("mlp_x3" if m.group(1) == "mlp_x3_kernel" else "attn_fused")
+            if fam == "mlp_x3" and re.search(r", true>", k):
+                fam = "mlp_x3_split"                     # the PatchSplit-epilogue instantiations are their own launch group in bench.py
+            ev = fam + f"[C={CP_TO_C.get(int(m.group(2)), int(m.group(2)))}]"
             tot = dom.setdefault(ev, [0, 0.0])
             tot[0] += n; tot[1] += n * (f * ff + w * wf) * 1024
     dom = {k: int(v[1] / v[0]) for k, v in dom.items()}
