@@ -392,8 +392,10 @@ def run_train_adv(args, rank, world, device, use_dist, emit=True):
     from scripts.train import AdvStepper
     model, cfg, sd = build_model(device, "large")
     disc = Discriminator(sample_rate=16000).to(device)
-    prec = getattr(args, "adv_precision", None) or os.environ.get("ESCX_BENCH_ADV_PRECISION", "fp32")
-    disc.set_conv_precision(prec)           # "bf16": the wide period convolutions on the bf16 MFMA (opt-in; BASELINE configs[4] names bf16, the reference trains fp32)
+    prec = getattr(args, "adv_precision", None) or os.environ.get("ESCX_BENCH_ADV_PRECISION", "split")
+    # "split" (the default of Discriminator): the wide period convolutions with three-term bf16 operands, fp32-grade; "fp32": the fp32 MFMA everywhere;
+    # "bf16": operands rounded to bf16 (opt-in; BASELINE configs[4] names bf16, the reference trains fp32)
+    disc.set_conv_precision(prec)
     bsz = int(os.environ.get("ESCX_BENCH_ADV_BATCH", CLIPS_PER_GPU))
     pcm = np.stack([(synth.voiced_clip_int16 if i % 2 else synth.noise_clip_int16)(f"bench-r{rank}-{i}", TRAIN_SAMPLES) for i in range(bsz)])
     x = torch.from_numpy(synth.pcm_to_float(pcm)).to(device)
@@ -439,6 +441,9 @@ def run_train_adv(args, rank, world, device, use_dist, emit=True):
                  "share_of_profiled_gemm_time": round(dom["ms"] / ptot, 4), "profiled_gemm_ms_per_step": round(ptot / psteps, 2),
                  "profiled_gemm_tflops": round(sum(r["flops"] for r in recs) / ptot / 1e9, 2),
                  "top": [{"name": r["name"], "ms_per_step": round(r["ms"] / psteps, 3), "tflops": round(r["flops"] / r["ms"] / 1e9, 1)} for r in recs[:10]]}
+    if prec != "fp32":      # the dominant launches may run on the bf16 MFMA (one product, or six per fp32 product): a fraction of the fp32 peak says nothing about them
+        kern_roof["frac"] = None
+        kern_roof["frac_note"] = "achieved = algorithmic fp32 FLOPs / time; not priced against the fp32 MFMA peak in this precision (see --adv-precision fp32)"
     if os.environ.get("ESCX_BENCH_BREAKDOWN"):
         for r in recs:
             print(f"# {r['name']:60s} calls {r['calls']:4d}  {r['ms'] / psteps:9.3f} ms/step  {r['flops'] / r['ms'] / 1e9:9.1f} TFLOP/s", file=sys.stderr)
@@ -455,11 +460,13 @@ def run_train_adv(args, rank, world, device, use_dist, emit=True):
     out = {"metric": "audio-seconds/sec trained, adversarial step (generator + discriminator updates), ESC-Large 9kbps 3s@16kHz",
            "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": (dist.get_world_size() if use_dist else 1), "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32" if prec == "fp32" else "f32 + bf16 MFMA (fp32 accumulate) in the discriminator's wide convolutions",
+           "dtype": {"fp32": "f32", "split": "f32 (wide discriminator convolutions: fp32 operands as three exact bf16 terms, six cross products, fp32 accumulate)",
+                     "bf16": "f32 + bf16 MFMA (fp32 accumulate) in the discriminator's wide convolutions"}[prec],
            "data": "synthetic",
            "config": {"workload": f"BASELINE configs[4]: ESC-Large 9kbps + adversarial training step (scripts/trainer_adv.py:61-107), batch={bsz} clips of "
-                                  f"{TRAIN_SAMPLES} samples per GPU, num_streams=6, " + ("fp32 (the reference has no bf16 / AMP path)" if prec == "fp32" else
-                                  "generator fp32, discriminator period convolutions 128->512->1024->1024 with bf16 operands (opt-in precision)"),
+                                  f"{TRAIN_SAMPLES} samples per GPU, num_streams=6, " + {"fp32": "fp32 MFMA (the reference has no bf16 / AMP path)",
+                                  "split": "fp32-grade: discriminator period convolutions 128->512->1024->1024 with split (3 x bf16) operands, everything else fp32 MFMA",
+                                  "bf16": "generator fp32, discriminator period convolutions 128->512->1024->1024 with bf16 operands (opt-in precision)"}[prec],
                       "discriminator_conv_precision": prec,
                       "global_batch": bsz * world, "clip_samples": TRAIN_SAMPLES, "num_streams": NUM_STREAMS, "parallelism": f"dp{world}",
                       "generator_params_M": round(n_gen / 1e6, 2), "discriminator_params_M": round(n_disc / 1e6, 2),
@@ -470,7 +477,7 @@ def run_train_adv(args, rank, world, device, use_dist, emit=True):
                         "note": "algorithmic discriminator-convolution FLOPs of the step (7 pass-equivalents of "
                                 f"{d_flops / 1e9:.1f} GFLOP per clip) over the WHOLE step time, generator included: a lower bound on the conv kernels' rate",
                         "dominant_launch_group": kern_roof,
-                        **({} if prec == "fp32" else {"precision_note": "fractions are against the fp32 MFMA peak (157.3 TFLOP/s); the period convolutions 128->512->1024->1024 "
+                        **({} if prec != "bf16" else {"precision_note": "fractions are against the fp32 MFMA peak (157.3 TFLOP/s); the period convolutions 128->512->1024->1024 "
                                                                         "run on the bf16 MFMA (dense peak 2500 TFLOP/s) and can exceed it, see dominant_launch_group.top"})},
            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else
                            train_adv_cpu_baseline(cfg, sd, {k: v.detach().cpu() for k, v in disc.state_dict().items()}, x.cpu(), st.w)}
@@ -502,10 +509,12 @@ def other_workloads(args, device):
     driver-observed too.  Same code paths as --mode train / --mode train_adv, fewer steps, no CPU baseline."""
     import copy
     res = {}
-    for name, fn, steps, warm in (("train", run_train, 5, 2), ("train_adv", run_train_adv, 4, 2), ("train_adv_bf16", run_train_adv, 4, 2)):
+    for name, fn, steps, warm in (("train", run_train, 5, 2), ("train_adv", run_train_adv, 4, 2), ("train_adv_fp32mfma", run_train_adv, 4, 2), ("train_adv_bf16", run_train_adv, 4, 2)):
         a = copy.copy(args)
         a.steps, a.warmup, a.no_cpu_baseline, a.profile_steps = steps, warm, True, 2
-        a.adv_precision = "bf16" if name.endswith("bf16") else "fp32"      # train_adv_bf16: the opt-in precision of the discriminator's wide convolutions
+        # train_adv: the default (split operands, fp32-grade); _fp32mfma: the fp32 MFMA everywhere (rounds 2-4); _bf16: the opt-in reduced precision
+        a.adv_precision = "bf16" if name.endswith("bf16") else ("fp32" if name.endswith("fp32mfma") else "split")
+        mixed = name in ("train_adv", "train_adv_bf16")        # hot kernels on the bf16 MFMA: no meaningful fraction of the fp32 peak
         t0 = time.perf_counter()
         try:
             full = fn(a, 0, 1, device, False, emit=False)
@@ -513,11 +522,12 @@ def other_workloads(args, device):
             res[name] = {"ms_per_step": full["ms_per_step"], "value": full["value"], "unit": full["unit"], "steps": steps, "warmup": warm,
                          "config": full["config"]["workload"], "dtype": full["dtype"],
                          # a step whose hot kernels run on the bf16 MFMA has no meaningful fraction of the fp32 peak - not reported
-                         "frac": None if name.endswith("bf16") else roof.get("whole_step_frac_executed_flops", roof.get("frac")),
+                         "frac": None if mixed else roof.get("whole_step_frac_executed_flops", roof.get("frac")),
                          "frac_of": ("not reported: mixed fp32 / bf16 MFMA step (informational rider, narrower arithmetic than the reference's fp32)" if name.endswith("bf16") else
+                                     "not reported: the wide convolutions run six bf16 MFMA products per fp32 product (fp32-grade); see train_adv_fp32mfma for the all-fp32-MFMA step" if mixed else
                                      "executed FLOPs of the whole step over the step time / fp32 MFMA peak" if "whole_step_frac_executed_flops" in roof
                                      else "algorithmic discriminator-convolution FLOPs of the step over the WHOLE step time / fp32 MFMA peak (lower bound)"),
-                         "dominant_kernel": {k: (roof.get("dominant_launch_group") or roof).get(k) for k in (("kernel", "avg_us", "achieved") if name.endswith("bf16") else ("kernel", "avg_us", "achieved", "frac"))},
+                         "dominant_kernel": {k: (roof.get("dominant_launch_group") or roof).get(k) for k in (("kernel", "avg_us", "achieved") if mixed else ("kernel", "avg_us", "achieved", "frac"))},
                          "wall_s": None}
             if name == "train":
                 res[name]["tape_gb"] = full["config"].get("tape_gb")
@@ -535,8 +545,9 @@ def main():
     ap.add_argument("--mode", choices=["codec", "train", "train_adv"], default="codec",
                     help="codec (default): encode+decode throughput, the BASELINE metric; train: the non-adversarial optimisation step (ESC-Base); "
                          "train_adv: BASELINE configs[4] - ESC-Large + the adversarial step (generator and discriminator updates), fp32")
-    ap.add_argument("--adv-precision", choices=["fp32", "bf16"], default=None,
-                    help="train_adv: arithmetic of the discriminator's wide convolutions (default fp32 = the reference's; bf16 = operands rounded to bf16, fp32 accumulation)")
+    ap.add_argument("--adv-precision", choices=["split", "fp32", "bf16"], default=None,
+                    help="train_adv: arithmetic of the discriminator's wide convolutions (default split = fp32 operands as three bf16 terms, fp32-grade; fp32 = fp32 MFMA; "
+                         "bf16 = operands rounded to bf16, fp32 accumulation)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
                     help="timed steps (default: 200 for the codec = 3 s of GPU work, enough for a utilisation sampler to see it; 20 for train, 6 for train_adv)")

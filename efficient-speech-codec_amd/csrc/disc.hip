@@ -57,8 +57,8 @@ struct escx_disc_s {
     float* wbuf = nullptr; size_t wfloats = 0;
     float* scratch = nullptr; size_t scratch_bytes = 0;
     const float* packed_ptr = nullptr; long long packed_version = -1;      // which (buffer, version) the packed weights were derived from
-    int precision = 0;                   // escx_disc_set_precision: 1 = bf16 MFMA for the wide convolutions
-    __bf16* wbuf16 = nullptr; const float* w16_ptr = nullptr; long long w16_version = -2;       // bf16 image of wbuf (precision 1), and what it was derived from
+    int precision = 0;                   // escx_disc_set_precision: 1 = bf16 MFMA for the convolutions, 2 = three-term split operands (fp32-grade) for the wide ones
+    __bf16* wbuf16 = nullptr; const float* w16_ptr = nullptr; long long w16_version = -2; int w16_mode = 0;       // bf16 image of wbuf (precision 1), and what it was derived from
     hipStream_t aux[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};    // extra streams: the sub-discriminators are independent of each other
 };
 
@@ -180,10 +180,11 @@ int refresh_bf16_weights(escx_disc_s* d, hipStream_t st) {
     tls_conv_bf16 = d->precision; tls_w32 = d->wbuf; tls_wn = d->wfloats; tls_w16 = nullptr;
     static const bool w16_ok = [] { const char* e = ESCX_TUNE_ENV("ESCX_DISC_BF16_WEIGHTS"); return !(e && e[0] == '0'); }();      // 0: weights rounded while staged (A/B)
     if (!d->precision || !w16_ok) return 0;
-    if (!d->wbuf16) ESCX_HIP(hipMalloc((void**)&d->wbuf16, d->wfloats * sizeof(__bf16)));
-    if (d->w16_ptr != d->packed_ptr || d->w16_version != d->packed_version || d->packed_version < 0) {
-        hipLaunchKernelGGL(cvt_bf16_kernel, dim3(2048), dim3(256), 0, st, d->wbuf, d->wbuf16, d->wfloats / 4);
-        d->w16_ptr = d->packed_ptr; d->w16_version = d->packed_version;
+    if (!d->wbuf16) ESCX_HIP(hipMalloc((void**)&d->wbuf16, 3 * d->wfloats * sizeof(__bf16)));      // precision 2: three planes (the exact three-term split of every weight)
+    if (d->w16_ptr != d->packed_ptr || d->w16_version != d->packed_version || d->packed_version < 0 || d->w16_mode != d->precision) {
+        if (d->precision == 2) hipLaunchKernelGGL(split3_bf16_kernel, dim3(2048), dim3(256), 0, st, d->wbuf, d->wbuf16, d->wfloats / 4, d->wfloats);
+        else hipLaunchKernelGGL(cvt_bf16_kernel, dim3(2048), dim3(256), 0, st, d->wbuf, d->wbuf16, d->wfloats / 4);
+        d->w16_ptr = d->packed_ptr; d->w16_version = d->packed_version; d->w16_mode = d->precision;
     }
     tls_w16 = d->wbuf16;
     return launch_ok("disc_bf16_weights");
@@ -262,12 +263,12 @@ void conv_gemm(const Ld& ld_in, const float* W, int M, int Np, int Kp, const Epi
         if (halo && Np == 32 && launch_conv32_halo(make_halo32(ld_in, M, Np, Kp), W, Kp, ep, st)) return;
 #endif
         static const bool halo16 = [] { const char* e = ESCX_TUNE_ENV("ESCX_CONV32_HALO_BF16"); return !(e && e[0] == '0'); }();      // bf16 precision: the band convolutions too (A/B: 0)
-        if (tls_conv_bf16 && halo16 && (Np == 32 || Np == 16) && launch_conv32_halo_bf16(make_halo32(ld_in, M, Np, Kp), W, Kp, ep, st)) return;
+        if (tls_conv_bf16 == 1 && halo16 && (Np == 32 || Np == 16) && launch_conv32_halo_bf16(make_halo32(ld_in, M, Np, Kp), W, Kp, ep, st)) return;
     }
     if constexpr (!std::is_same<Ld, PlainA>::value) {            // opt-in bf16 MFMA for the wide layers (gemm_bf16.h): same gathers, same epilogues
         if (tls_conv_bf16 && bf16_gemm_ok(M, Np, Kp) && conv_cp(ld) % 32 == 0) {
             const __bf16* W16 = (tls_w16 && W >= tls_w32 && W < tls_w32 + tls_wn) ? tls_w16 + (W - tls_w32) : nullptr;
-            ld.fast = 1; launch_gemm_bf16(ld, W, W16, M, Np, Kp, ep, st); return;
+            ld.fast = 1; launch_gemm_bf16(ld, W, W16, M, Np, Kp, ep, st, tls_conv_bf16 == 2 ? 3 : 1, tls_wn); return;
         }
     }
     const long long tiles128 = (long long)((M + 127) / 128) * ((Np + 95) / 96);
@@ -319,12 +320,13 @@ int disc_dw(const LdA& la, const LdB& lb, int M, int Np, int Kp, float* dW, floa
         int mps = ((M + slices - 1) / slices + 31) / 32 * 32;
         slices = (M + mps - 1) / mps;
         float* bpart = part + (size_t)slices * Np * Kp;
-        hipLaunchKernelGGL((gemm_dw_bf16_kernel<LdA, LdB>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+        if (tls_conv_bf16 == 2) hipLaunchKernelGGL((gemm_dw_bf16_kernel<LdA, LdB, 3>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
+        else hipLaunchKernelGGL((gemm_dw_bf16_kernel<LdA, LdB>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, bpart);
         launch_reduce_partials(part, slices, (long long)Np * Kp, dW, 0, st);
         launch_reduce_partials(bpart, slices, (long long)Np, db, 0, st);
         return 0;
     }
-    if (narrow && tls_conv_bf16 && dw16n && Kp % 16 == 0) {     // 32 x 128 tiles of dW on the bf16 MFMA (gemm_bf16.h)
+    if (narrow && tls_conv_bf16 == 1 && dw16n && Kp % 16 == 0) {     // 32 x 128 tiles of dW on the bf16 MFMA (gemm_bf16.h)
         const int nbk = (Kp + 127) / 128;
         int slices = std::max(1, std::min((2560 + nbk / 2) / nbk, (M + 255) / 256));
         slices = (int)std::max<size_t>(1, std::min<size_t>(slices, DISC_DW_PART / per));
@@ -456,7 +458,8 @@ extern "C" void escx_disc_destroy(escx_disc d) {
 
 extern "C" int escx_disc_set_precision(escx_disc d, int mode) {
     if (!d) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null handle");
-    if (mode != 0 && mode != 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "discriminator precision %d: 0 (fp32) or 1 (bf16 MFMA for the wide convolutions)", mode);
+    if (mode < 0 || mode > 2)
+        ESCX_FAIL(ESCX_ERR_INVALID_ARG, "discriminator precision %d: 0 (fp32 MFMA), 1 (bf16 MFMA for the convolutions) or 2 (split operands: fp32-grade on the bf16 MFMA, wide convolutions)", mode);
     d->precision = mode;
     return ESCX_OK;
 }

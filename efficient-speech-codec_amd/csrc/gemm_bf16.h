@@ -26,10 +26,27 @@ __device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
     return r;
 }
 
+// Three-term split of four fp32 values (NTERM = 3 instantiations, round 5): v = t0 + t1 + t2 exactly, each term bf16 (see fused_mlp_x3.h for the arithmetic:
+// six exact cross products per operand pair, fp32 accumulation - fp32-grade results on the bf16 matrix cores).
+__device__ __forceinline__ void split3_bf16x4(f32x4 v, bf16x4& t0, bf16x4& t1, bf16x4& t2) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 a1 = (__bf16)v[e];
+        const float r1 = v[e] - (float)a1;
+        const __bf16 a2 = (__bf16)r1;
+        const float r2 = r1 - (float)a2;
+        t0[e] = a1; t1[e] = a2; t2[e] = (__bf16)r2;
+    }
+}
+
 // WB16: the weight matrix is read from its bf16 image (the packed weights rounded once per parameter version: cvt_bf16_kernel below, disc.hip refresh_bf16_weights) - half the
 // bytes of the weight operand and no conversion in the staging path; the rounding is the same nearest-even, so the results are bit-identical to WB16 = false.
-template <int BM, int BN, bool WB16, class Loader, class Epi, int KS = 1>       // KS: 32-deep MFMA steps per staged tile (one barrier pair per KS steps)
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* __restrict__ Wt, const __bf16* __restrict__ Wt16, int M, int Np, int Kp, int nblk_n, Epi ep) {
+// NTERM = 3: both operands are split into three bf16 terms while they are staged (three LDS planes per operand) and every tile product is the six leading cross terms,
+// smallest first: the discriminator's "split" precision - fp32-grade arithmetic (escx_disc_set_precision(d, 2)), not the bf16 approximation of NTERM = 1.
+template <int BM, int BN, bool WB16, class Loader, class Epi, int KS = 1, int NTERM = 1>       // KS: 32-deep MFMA steps per staged tile (one barrier pair per KS steps)
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* __restrict__ Wt, const __bf16* __restrict__ Wt16, int M, int Np, int Kp, int nblk_n, Epi ep,
+                                                        size_t w16_plane = 0) {     // NTERM = 3 with WB16: term p of the weights at Wt16 + p * w16_plane (split3_bf16_kernel)
     static_assert(BM % 64 == 0 && BN % 16 == 0, "tile shape");
     constexpr int BK = 32 * KS;
     constexpr int LD = BK + 8;                 // bf16 per LDS row: 80 B, the 16 rows of a fragment read start 20 banks apart
@@ -38,8 +55,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* 
     constexpr int AJ = BM * KV / 256, BJ = BN * KV / 256;
     static_assert((BM * KV) % 256 == 0 && (BN * KV) % 256 == 0, "tile rows x K step must fill the workgroup");
 
-    __shared__ __attribute__((aligned(16))) __bf16 As[BM * LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[BN * LD];
+    static_assert(NTERM == 1 || NTERM == 3, "one rounded term or three split terms");
+    __shared__ __attribute__((aligned(16))) __bf16 As[NTERM * BM * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[NTERM * BN * LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
     const int bm = blockIdx.x / nblk_n, bn = blockIdx.x - bm * nblk_n;
@@ -58,7 +76,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* 
     constexpr int P16 = BK / 8;                 // 16-byte pieces (8 bf16) per weight-tile row
     constexpr int BJ16 = BN * P16 / 256;        // ... per thread
     f32x4 ra[AJ], rb[WB16 ? 1 : BJ];
-    uint4 rb16[WB16 ? BJ16 : 1];
+    uint4 rb16[WB16 ? NTERM * BJ16 : 1];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) ra[j] = ld.load4(ctx[j], k0, 4 * ((tid + j * 256) % KV));
@@ -66,7 +84,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* 
 #pragma unroll
             for (int j = 0; j < BJ16; ++j) {
                 const int i = tid + j * 256, row = i / P16, c8 = i % P16;
-                rb16[j] = (n0 + row < Np) ? *reinterpret_cast<const uint4*>(Wt16 + (size_t)(n0 + row) * Kp + k0 + 8 * c8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < NTERM; ++p)
+                    rb16[p * BJ16 + j] = (n0 + row < Np) ? *reinterpret_cast<const uint4*>(Wt16 + p * w16_plane + (size_t)(n0 + row) * Kp + k0 + 8 * c8) : make_uint4(0, 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -79,16 +99,59 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* 
     fetch(0);
     for (int k0 = 0; k0 < Kp; k0 += BK) {
 #pragma unroll
-        for (int j = 0; j < AJ; ++j) { const int i = tid + j * 256; *reinterpret_cast<bf16x4*>(&As[(i / KV) * LD + 4 * (i % KV)]) = to_bf16x4(ra[j]); }
+        for (int j = 0; j < AJ; ++j) {
+            const int i = tid + j * 256;
+            if constexpr (NTERM == 3) {
+                bf16x4 t0, t1, t2; split3_bf16x4(ra[j], t0, t1, t2);
+                *reinterpret_cast<bf16x4*>(&As[(i / KV) * LD + 4 * (i % KV)]) = t0;
+                *reinterpret_cast<bf16x4*>(&As[BM * LD + (i / KV) * LD + 4 * (i % KV)]) = t1;
+                *reinterpret_cast<bf16x4*>(&As[2 * BM * LD + (i / KV) * LD + 4 * (i % KV)]) = t2;
+            } else {
+                *reinterpret_cast<bf16x4*>(&As[(i / KV) * LD + 4 * (i % KV)]) = to_bf16x4(ra[j]);
+            }
+        }
         if constexpr (WB16) {
 #pragma unroll
-            for (int j = 0; j < BJ16; ++j) { const int i = tid + j * 256; *reinterpret_cast<uint4*>(&Bs[(i / P16) * LD + 8 * (i % P16)]) = rb16[j]; }
+            for (int j = 0; j < BJ16; ++j) {
+                const int i = tid + j * 256;
+#pragma unroll
+                for (int p = 0; p < NTERM; ++p) *reinterpret_cast<uint4*>(&Bs[p * BN * LD + (i / P16) * LD + 8 * (i % P16)]) = rb16[p * BJ16 + j];
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) { const int i = tid + j * 256; *reinterpret_cast<bf16x4*>(&Bs[(i / KV) * LD + 4 * (i % KV)]) = to_bf16x4(rb[j]); }
+            for (int j = 0; j < BJ; ++j) {
+                const int i = tid + j * 256;
+                if constexpr (NTERM == 3) {
+                    bf16x4 t0, t1, t2; split3_bf16x4(rb[j], t0, t1, t2);
+                    *reinterpret_cast<bf16x4*>(&Bs[(i / KV) * LD + 4 * (i % KV)]) = t0;
+                    *reinterpret_cast<bf16x4*>(&Bs[BN * LD + (i / KV) * LD + 4 * (i % KV)]) = t1;
+                    *reinterpret_cast<bf16x4*>(&Bs[2 * BN * LD + (i / KV) * LD + 4 * (i % KV)]) = t2;
+                } else {
+                    *reinterpret_cast<bf16x4*>(&Bs[(i / KV) * LD + 4 * (i % KV)]) = to_bf16x4(rb[j]);
+                }
+            }
         }
         __syncthreads();
         if (k0 + BK < Kp) fetch(k0 + BK);
+        if constexpr (NTERM == 3) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 af3[3][TM];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) af3[p][b] = *reinterpret_cast<const bf16x8*>(&As[p * BM * LD + (wave * (BM / 4) + b * 16 + l15) * LD + 32 * ks + 8 * lg]);
+#pragma unroll
+                for (int a = 0; a < TN; ++a) {
+                    bf16x8 wf3[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) wf3[p] = *reinterpret_cast<const bf16x8*>(&Bs[p * BN * LD + (a * 16 + l15) * LD + 32 * ks + 8 * lg]);
+#define ESCX_G3(I, J) _Pragma("unroll") for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf3[I], af3[J][b], acc[a][b], 0, 0, 0);
+                    ESCX_G3(0, 2) ESCX_G3(2, 0) ESCX_G3(1, 1) ESCX_G3(0, 1) ESCX_G3(1, 0) ESCX_G3(0, 0)
+#undef ESCX_G3
+                }
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             bf16x8 af[TM];
@@ -118,13 +181,26 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* 
 // Shapes this variant takes: K a multiple of the 32-wide step, outputs a multiple of the 128-wide tile, enough rows to fill the chip with the chosen tile.
 inline bool bf16_gemm_ok(int M, int Np, int Kp) { return Np % 128 == 0 && Kp % 32 == 0 && Kp >= 256 && M >= 1024; }
 
+static __global__ void split3_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n4, size_t plane) {      // n4 float4s -> three planes of bf16x4s
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        bf16x4 t0, t1, t2; split3_bf16x4(reinterpret_cast<const f32x4*>(src)[i], t0, t1, t2);
+        reinterpret_cast<bf16x4*>(dst)[i] = t0; reinterpret_cast<bf16x4*>(dst + plane)[i] = t1; reinterpret_cast<bf16x4*>(dst + 2 * plane)[i] = t2;
+    }
+}
+
 static __global__ void cvt_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n4) {      // n4 float4s -> bf16x4s
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
         reinterpret_cast<bf16x4*>(dst)[i] = to_bf16x4(reinterpret_cast<const f32x4*>(src)[i]);
 }
 
 template <class Loader, class Epi>
-inline void launch_gemm_bf16(const Loader& ld, const float* Wt, const __bf16* Wt16, int M, int Np, int Kp, const Epi& ep, hipStream_t s) {
+inline void launch_gemm_bf16(const Loader& ld, const float* Wt, const __bf16* Wt16, int M, int Np, int Kp, const Epi& ep, hipStream_t s, int nterm = 1, size_t w16_plane = 0) {
+    if (nterm == 3) {           // split precision: three terms per operand; the weights from their pre-split image when there is one, else split while staged (same terms)
+        const dim3 grid(((M + 127) / 128) * (Np / 128));
+        if (Wt16) hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, true, Loader, Epi, 1, 3>), grid, dim3(256), 0, s, ld, Wt, Wt16, M, Np, Kp, Np / 128, ep, w16_plane);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, false, Loader, Epi, 1, 3>), grid, dim3(256), 0, s, ld, Wt, Wt16, M, Np, Kp, Np / 128, ep, (size_t)0);
+        return;
+    }
     static const int env_bm = [] { const char* e = ESCX_TUNE_ENV("ESCX_BF16_BM"); return e ? atoi(e) : 0; }();       // tuning aid: 128 / 256 rows per workgroup
     static const int env_ks = [] { const char* e = ESCX_TUNE_ENV("ESCX_BF16_KS"); return e ? atoi(e) : 1; }();        // tuning aid: 2 = 64-deep staged tiles
     const int nbn = Np / 128;
@@ -145,12 +221,12 @@ inline void launch_gemm_bf16(const Loader& ld, const float* Wt, const __bf16* Wt
 // 2 x 2 waves of 64 x 64; the X side is the MFMA "A" operand so that a lane holds four consecutive k of one n (16-byte stores into part[slice][n][k]).
 // Slices are added in increasing order by reduce_partials, as in the fp32 kernels.
 // ------------------------------------------------------------------------------------------------
-template <class LdA, class LdB>
+template <class LdA, class LdB, int NTERM = 1>       // NTERM = 3: three-term split of both operands, six cross terms per tile product (the "split" precision)
 __global__ __launch_bounds__(256) void gemm_dw_bf16_kernel(LdA la, LdB lb, int M, int Np, int Kp, int nblk_k, int m_per_slice, float* __restrict__ part,
                                                            float* __restrict__ bpart) {
     constexpr int T = 128, MS = 32, LD = MS + 8;
-    __shared__ __attribute__((aligned(16))) __bf16 At[T * LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Bt[T * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 At[NTERM * T * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bt[NTERM * T * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
     const int mp = lane & 15, cq = 4 * (4 * wave + (lane >> 4));          // staging role: row pair mp of the step, columns cq .. cq + 3 (and + 64)
     const int bn = blockIdx.x / nblk_k, bk = blockIdx.x - bn * nblk_k;
@@ -185,14 +261,48 @@ __global__ __launch_bounds__(256) void gemm_dw_bf16_kernel(LdA la, LdB lb, int M
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             bs[j] += ra[j][0] + ra[j][1];
+            if constexpr (NTERM == 3) {
+                bf16x4 a0[3], a1[3], b0[3], b1[3];              // [term] of rows m and m + 1
+                split3_bf16x4(ra[j][0], a0[0], a0[1], a0[2]); split3_bf16x4(ra[j][1], a1[0], a1[1], a1[2]);
+                split3_bf16x4(rb[j][0], b0[0], b0[1], b0[2]); split3_bf16x4(rb[j][1], b1[0], b1[1], b1[2]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                        bf16x2 pa; pa[0] = a0[p][e]; pa[1] = a1[p][e];
+                        bf16x2 pb; pb[0] = b0[p][e]; pb[1] = b1[p][e];
+                        *reinterpret_cast<unsigned*>(&At[p * T * LD + (64 * j + cq + e) * LD + 2 * mp]) = __builtin_bit_cast(unsigned, pa);
+                        *reinterpret_cast<unsigned*>(&Bt[p * T * LD + (64 * j + cq + e) * LD + 2 * mp]) = __builtin_bit_cast(unsigned, pb);
+                    }
+            } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 *reinterpret_cast<unsigned*>(&At[(64 * j + cq + e) * LD + 2 * mp]) = pack2(ra[j][0][e], ra[j][1][e]);
                 *reinterpret_cast<unsigned*>(&Bt[(64 * j + cq + e) * LD + 2 * mp]) = pack2(rb[j][0][e], rb[j][1][e]);
             }
+            }
         }
         __syncthreads();
         if (m0 + MS < mend) fetch(m0 + MS);
+        if constexpr (NTERM == 3) {
+            bf16x8 af3[3][4];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) af3[p][b] = *reinterpret_cast<const bf16x8*>(&At[p * T * LD + (64 * wj + 16 * b + l15) * LD + 8 * lg]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                bf16x8 wf3[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wf3[p] = *reinterpret_cast<const bf16x8*>(&Bt[p * T * LD + (64 * wi + 16 * a + l15) * LD + 8 * lg]);
+#define ESCX_D3(I, J) _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf3[I], af3[J][b], acc[a][b], 0, 0, 0);
+                ESCX_D3(0, 2) ESCX_D3(2, 0) ESCX_D3(1, 1) ESCX_D3(0, 1) ESCX_D3(1, 0) ESCX_D3(0, 0)
+#undef ESCX_D3
+            }
+            __syncthreads();
+            continue;
+        }
         bf16x8 af[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) af[b] = *reinterpret_cast<const bf16x8*>(&At[(64 * wj + 16 * b + l15) * LD + 8 * lg]);

@@ -19,6 +19,8 @@ from .. import _native
 from .codecs import _Node, _attach
 
 BANDS = [(0.0, 0.1), (0.1, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0)]
+_PRECISIONS = {"fp32": 0, "bf16": 1, "split": 2}
+_DEFAULT_CONV_PRECISION = _PRECISIONS[__import__("os").environ.get("ESCX_DISC_PRECISION", "split")]      # see Discriminator.set_conv_precision
 
 
 def _conv_specs(periods, fft_sizes, n_bands):
@@ -110,13 +112,17 @@ class Discriminator(nn.Module):
         if st is not None and "gflat" in st:
             st["gfresh"] = True
 
-    def set_conv_precision(self, precision: str = "fp32"):
-        """Arithmetic of the wide convolutions (include/escx.h escx_disc_set_precision): "fp32" (default, the reference's; parity-tested against it) or
-        "bf16" - operands of the 128 -> 512 -> 1024 -> 1024 period convolutions rounded to bf16 while staged, fp32 accumulation on the bf16 MFMA (BASELINE
-        configs[4] names bf16).  Feature maps, parameters and gradients stay fp32 tensors either way."""
-        mode = {"fp32": 0, "bf16": 1}.get(precision)
+    def set_conv_precision(self, precision: str = "split"):
+        """Arithmetic of the wide convolutions (include/escx.h escx_disc_set_precision).
+        "split" (default since round 5; ESCX_DISC_PRECISION overrides the default): the 128 -> 512 -> 1024 -> 1024 period convolutions (forward, dX, dW) on the
+        bf16 MFMA with every fp32 operand split exactly into three bf16 terms and the six leading cross products accumulated in fp32 - fp32-grade results
+        (feature maps within 2e-6 of the fp32-MFMA path, every parity test against the reference unchanged) at 1.4-1.7x its rate;
+        "fp32": the fp32 MFMA everywhere (the path of rounds 2-4);
+        "bf16": operands of those convolutions and of the 32 -> 32 band convolutions rounded to bf16 while staged, fp32 accumulation (BASELINE configs[4]
+        names bf16; narrower than the reference's arithmetic).  Feature maps, parameters and gradients stay fp32 tensors in every mode."""
+        mode = _PRECISIONS.get(precision)
         if mode is None:
-            raise ValueError(f"conv precision {precision!r}: 'fp32' or 'bf16'")
+            raise ValueError(f"conv precision {precision!r}: 'fp32', 'bf16' or 'split'")
         self._conv_precision = mode
         if getattr(self, "_handles", None):
             lib = _native.load()
@@ -170,8 +176,9 @@ class Discriminator(nn.Module):
             hd = ctypes.c_void_p()
             _native.check(lib.escx_disc_create(ctypes.byref(cc), idx, ctypes.byref(hd)))
             self._handles[idx] = hd
-            if getattr(self, "_conv_precision", 0):
-                _native.check(lib.escx_disc_set_precision(hd, self._conv_precision))
+            mode = getattr(self, "_conv_precision", _DEFAULT_CONV_PRECISION)
+            if mode:
+                _native.check(lib.escx_disc_set_precision(hd, mode))
             if self._flat_grad_mode and idx in self._carry:
                 self._flat_grad_mode = False             # (guards the re-entry through enable_flat_grads -> _handle)
                 self.enable_flat_grads(device)

@@ -237,7 +237,11 @@ int escx_disc_backward(escx_disc d, const float* flat_params_dev, int64_t params
  * 0 (default): fp32 MFMA everywhere, the parity-tested path.  1: the implicit GEMMs with at least 128 output and 256 contraction columns (the 128 -> 512 ->
  * 1024 -> 1024 period convolutions: forward, dX, dW) and the 32 -> 32-channel band convolutions of the spectrogram discriminators (forward, dX, dW) round
  * their operands to bf16 (nearest even) while staging them and accumulate in fp32 on the bf16 MFMA;
- * feature maps, parameters, gradients and every other kernel stay fp32.  Returns ESCX_ERR_INVALID_ARG for another mode. */
+ * feature maps, parameters, gradients and every other kernel stay fp32.
+ * 2 (round 5; the default of the Python host's Discriminator): the same wide implicit GEMMs (forward, dX, dW of the period convolutions) on the bf16 MFMA with BOTH
+ * operands split exactly into three bf16 terms (a = a1 + a2 + a3) and the six leading cross products accumulated in fp32, smallest first - fp32-grade results
+ * (within fp32 summation-order noise of mode 0; the truncated terms are below 2^-26 relative); the band convolutions stay on the fp32 MFMA.
+ * Returns ESCX_ERR_INVALID_ARG for another mode. */
 int escx_disc_set_precision(escx_disc d, int mode);
 int escx_disc_get_precision(escx_disc d);
 /* One GAN loss term over a feature-map buffer (gan_loss.py:30-51): loss_dev[b] (+)= mean over the C x D0 x D1 real elements of

@@ -561,6 +561,54 @@ def test_bf16_convolution_precision_against_the_fp32_path():
 
 
 @pytest.mark.gpu
+def test_split_convolution_precision_is_fp32_grade():
+    """Discriminator.set_conv_precision("split") (escx_disc_set_precision mode 2, round 5): the wide period convolutions (forward, dX, dW) on the bf16
+    MFMA with every fp32 operand split exactly into three bf16 terms (gemm_bf16.h NTERM = 3).  Against the fp32-MFMA path on the same weights and
+    clips the results differ by fp32 summation-order noise only: feature maps within 2e-6 relative RMS, the loss within 1e-6, the waveform gradient within 1e-4 (measured 2e-5), parameter gradients within 1e-5 in the median and 5e-4 each
+    - four orders of magnitude inside the bf16 mode's bounds above - and not all equal, i.e. the split kernels did run."""
+    disc, sd = _gpu_models()
+    B, L = 8, 48000
+    pcm = np.stack([(synth.voiced_clip_int16 if i % 2 else synth.noise_clip_int16)(f"disc-bf16-{i}", L) for i in range(B)])
+    x0 = torch.from_numpy(synth.pcm_to_float(pcm)).cuda().unsqueeze(1)
+    res = {}
+    for prec in ("fp32", "split"):
+        disc.set_conv_precision(prec)
+        lib, hd = disc._handle(torch.device("cuda:0"))
+        assert lib.escx_disc_get_precision(hd) == (2 if prec == "split" else 0)
+        for p in disc.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        outs = disc(x)
+        loss = sum((f[-1] ** 2).mean() for f in outs)
+        loss.backward()
+        res[prec] = dict(fm=[[t.detach().clone() for t in f] for f in outs], loss=float(loss.detach()), gx=x.grad.clone(),
+                         g={k: p.grad.clone() for k, p in disc.named_parameters() if p.grad is not None})
+    disc.set_conv_precision("fp32")
+    a, b = res["fp32"], res["split"]
+    worst, moved = 0.0, 0
+    for i, (fa, fb) in enumerate(zip(a["fm"], b["fm"])):
+        for j, (u, v) in enumerate(zip(fa, fb)):
+            if i >= 5 or j < 2:                 # the band stacks and the period layers 1 -> 32 -> 128 stay on the fp32 kernels
+                assert torch.equal(u, v), f"sub-discriminator {i} map {j} is outside the split layers and must not change"
+            else:
+                e = _rel(v.cpu().numpy(), u.cpu().numpy()); worst = max(worst, e); moved += int(e > 0.0)
+                assert e < 2e-6, f"sub-discriminator {i} map {j}: rel rms {e:.3e}"
+    assert moved > 0, "the split kernels did not run"
+    assert abs(b["loss"] - a["loss"]) <= 1e-6 * abs(a["loss"])
+    e = _rel(b["gx"].cpu().numpy(), a["gx"].cpu().numpy())
+    assert e < 1e-4, f"d loss / d waveform: rel rms {e:.3e}"        # through every layer and LeakyReLU mask; the fp32 path's bound against the reference is 2e-4
+    gw, errs = (0.0, ""), []
+    for k in a["g"]:
+        u, v = a["g"][k], b["g"][k]
+        if float(u.norm()) == 0.0:
+            continue
+        ek = _rel(v.cpu().numpy(), u.cpu().numpy()); gw = max(gw, (ek, k)); errs.append(ek)
+        assert ek < 5e-4, f"gradient of {k}: rel rms {ek:.3e}"        # the bound of the fp32 path against the fp64 oracle (test_gan_losses_and_gradients): first-layer weights sum with heavy cancellation
+    assert np.median(errs) < 1e-5, np.median(errs)
+    print(f"[disc split] feature maps worst rel rms {worst:.2e}, d wave {e:.2e}, parameter gradients median {np.median(errs):.2e}, worst {gw[0]:.2e} ({gw[1]})")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg,B,L", [
     (dict(periods=[7], fft_sizes=[1024, 256], bands=[(0.0, 0.1), (0.1, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0)]), 3, 6001),        # tiny maps: every tile of the band kernels is an edge tile
     (dict(periods=[2, 3], fft_sizes=[512], bands=[(0.0, 0.25), (0.25, 1.0)]), 5, 40007),                                               # prime length, two wide bands, period layers above the bf16 row threshold
