@@ -86,13 +86,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Loader ld, const float* 
                 const int i = tid + j * 256, row = i / P16, c8 = i % P16;
 #pragma unroll
                 for (int p = 0; p < NTERM; ++p)
-                    rb16[p * BJ16 + j] = (n0 + row < Np) ? *reinterpret_cast<const uint4*>(Wt16 + p * w16_plane + (size_t)(n0 + row) * Kp + k0 + 8 * c8) : make_uint4(0, 0, 0, 0);
+                    rb16[p * BJ16 + j] = (n0 + row < Np && k0 + 8 * c8 < Kp) ? *reinterpret_cast<const uint4*>(Wt16 + p * w16_plane + (size_t)(n0 + row) * Kp + k0 + 8 * c8) : make_uint4(0, 0, 0, 0);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < BJ; ++j) {
                 const int i = tid + j * 256, row = i / KV, c4 = i % KV;
-                rb[j] = (n0 + row < Np) ? ld4(Wt + (size_t)(n0 + row) * Kp + k0 + 4 * c4) : zero4();
+                rb[j] = (n0 + row < Np && k0 + 4 * c4 < Kp) ? ld4(Wt + (size_t)(n0 + row) * Kp + k0 + 4 * c4) : zero4();       // K tail of a ragged last step: zero
             }
         }
     };
@@ -211,6 +211,31 @@ inline void launch_gemm_bf16(const Loader& ld, const float* Wt, const __bf16* Wt
     else if (Wt16 && env_ks == 2 && Kp % 64 == 0) hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, true, Loader, Epi, 2>), dim3(((M + 127) / 128) * nbn), dim3(256), 0, s, ld, Wt, Wt16, M, Np, Kp, nbn, ep);
     else if (Wt16) hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, true, Loader, Epi>), dim3(((M + 127) / 128) * nbn), dim3(256), 0, s, ld, Wt, Wt16, M, Np, Kp, nbn, ep);
     else hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, false, Loader, Epi>), dim3(((M + 127) / 128) * nbn), dim3(256), 0, s, ld, Wt, Wt16, M, Np, Kp, nbn, ep);
+}
+
+// Row-major operand with a column bound (the linear layers of the training step through the split-operand kernels: widths that are no multiple of the 32-deep
+// K step or of the 128-wide dW tile read zeros behind the last column).
+struct PlainG {
+    const float* A; int lda; int M; int N;
+    typedef const float* Ctx;
+    __device__ __forceinline__ Ctx make_ctx(int m) const { return m < M ? A + (size_t)m * lda : nullptr; }
+    __device__ __forceinline__ f32x4 load4(Ctx c, int k0, int kin) const { return (c && k0 + kin < N) ? ld4(c + k0 + kin) : zero4(); }
+};
+
+// out = A . Wt^T with split (3 x bf16) operands for any epilogue of the fp32 engine: tile = 128 or 64 rows x 128 or 96 columns, least column padding first.
+template <class Loader, class Epi>
+inline void launch_gemm_x3(const Loader& ld, const float* Wt, int M, int Np, int Kp, const Epi& ep, hipStream_t s) {
+    const int pad128 = (Np + 127) / 128 * 128, pad96 = (Np + 95) / 96 * 96;
+    const bool n128 = pad128 <= pad96;
+    const int nbn = n128 ? pad128 / 128 : pad96 / 96;
+    const bool big = (long long)((M + 127) / 128) * nbn >= 512;          // two resident workgroups per CU, twice over: else 64-row tiles
+    const dim3 grid(((M + (big ? 127 : 63)) / (big ? 128 : 64)) * nbn);
+#define ESCX_X3_LAUNCH(BM, BN) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false, Loader, Epi, 1, 3>), grid, dim3(256), 0, s, ld, Wt, (const __bf16*)nullptr, M, Np, Kp, nbn, ep, (size_t)0)
+    if (big && n128) ESCX_X3_LAUNCH(128, 128);
+    else if (big) ESCX_X3_LAUNCH(128, 96);
+    else if (n128) ESCX_X3_LAUNCH(64, 128);
+    else ESCX_X3_LAUNCH(64, 96);
+#undef ESCX_X3_LAUNCH
 }
 
 // ------------------------------------------------------------------------------------------------

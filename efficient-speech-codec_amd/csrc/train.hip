@@ -19,6 +19,7 @@
 #include "launchers.h"
 #include "train_kernels.h"
 #include "train_mlp_fused.h"
+#include "gemm_bf16.h"
 
 using namespace escx;
 
@@ -96,8 +97,21 @@ void reduce_partials(const float* part, int slices, long long n, float* out, int
 }
 
 // ---- GEMM helpers --------------------------------------------------------------------------------
+// Split-operand route of the linear layers (round 5): every fp32 operand as three exact bf16 terms, six cross products per tile on the bf16 MFMA, fp32
+// accumulation (gemm_bf16.h NTERM = 3) - fp32-grade results at 1.4-1.7x the fp32 MFMA's rate where the tiles fill the chip.  ESCX_TRAIN_X3=0: the fp32 engine.
+bool train_x3() {
+    static const bool on = [] { const char* e = getenv("ESCX_TRAIN_X3"); return !(e && e[0] == '0'); }();
+    return on;
+}
+inline bool train_x3_shape(int Np, int Kp) {          // by the layer's geometry only: the arithmetic of a clip must not depend on the batch it is in (two-part passes, DDP shards)
+    return Kp % 16 == 0 && Kp >= 96 && Np >= 96;
+}
+
 template <class Ld, class Epi>
 void gemm_any(const Ld& ld, const float* W, int M, int Np, int Kp, const Epi& ep, hipStream_t st, int force_bk = 0) {
+    if constexpr (std::is_same<Ld, PlainA>::value && !epi_is_rowwise<Epi>::value) {
+        if (train_x3() && train_x3_shape(Np, Kp)) { launch_gemm_x3(PlainG{ld.A, ld.lda, ld.M, Kp}, W, M, Np, Kp, ep, st); return; }
+    }
     // 128-row tiles halve the weight traffic per output row; 64 when the grid would not fill the chip (same rule as gemm_swin.hip)
     const long long tiles128 = (long long)((M + 127) / 128) * ((Np + 95) / 96);
     // K steps of 16 keep the workgroup's LDS image small (more resident workgroups): 98.0 -> 96.1 ms/step over the engine's default steps
@@ -428,13 +442,13 @@ int layer_fwd(escx_handle_s* h, const Layer& L, LayerTape& LT, const float* x_in
         if (afrc != 0) {
         PROF("T.ln1_gather" + tg, 0, (dM + dMs) * dC * f4, ln_rows(1, x, bt.xn1, bw.ln1_g, bw.ln1_b, map, slots, tokens, Ms, L.C, L.Cp, st));
         PROF("T.gemm_qkv" + tg, 2 * dMs * dC * 3 * dC, dMs * 4 * dC * f4,
-             gemm_qkv(bt.xn1, L.Cp, Ms, bw.wqkv, L.Nqkv, L.Cp, bt.qkv, bw.bqkv, L.nH * L.hdp, 1.0f / std::sqrt((float)L.hd), st));
+             gemm_rows(bt.xn1, L.Cp, Ms, bw.wqkv, L.Nqkv, L.Cp, EpiQkv{bt.qkv, L.Nqkv, bw.bqkv, L.nH * L.hdp, 1.0f / std::sqrt((float)L.hd)}, st));
         int arc = 0;
         PROF("T.window_attn" + tg, 4 * dMs * 16 * dC, dMs * 4 * dC * f4,
              arc = window_attention(bt.qkv, bw.bias_tab, bt.obuf, Ms / 16, L.nH, L.hdp, L.Nqkv, L.Ko, Hp / 4, Wp / 4, shift > 0, st));
         if (arc) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "head_dim %d unsupported by the attention kernel", L.hd);
         PROF("T.gemm_proj" + tg, 2 * dMs * dC * dC, (dMs * dC + 2 * dM * dC) * f4,
-             gemm_proj_scatter(bt.obuf, L.Ko, Ms, bw.wproj, L.Cp, L.Ko, bt.x1, x, bw.bproj, map, slots, tokens, st));
+             gemm_rows(bt.obuf, L.Ko, Ms, bw.wproj, L.Cp, L.Ko, EpiProjScatter{bt.x1, x, bw.bproj, map, slots, tokens, L.Cp}, st));
         }
         if (fmlp) {       // LN2 + fc1 + GELU + fc2 + residual in one kernel: x1 -> x2 (x1 itself is what the backward recomputes from)
             int hs = 1, frc = 0;
@@ -448,7 +462,7 @@ int layer_fwd(escx_handle_s* h, const Layer& L, LayerTape& LT, const float* x_in
         PROF("T.gemm_fc1_gelu" + tg, 2 * dM * dC * L.hidden, dM * (dC + 2 * L.hidden) * f4,
              gemm_rows(bt.xn2, L.Cp, M, bw.w1, L.hiddenP, L.Cp, EpiGeluDual{bt.hpre, bt.hact, L.hiddenP, bw.b1}, st));
         PROF("T.gemm_fc2_res" + tg, 2 * dM * dC * L.hidden, dM * (2 * dC + L.hidden) * f4,
-             gemm_residual(bt.hact, L.hiddenP, M, bw.w2, L.Cp, L.hiddenP, bt.x2, bw.b2, bt.x1, st));
+             gemm_rows(bt.hact, L.hiddenP, M, bw.w2, L.Cp, L.hiddenP, EpiResidual{bt.x2, L.Cp, bw.b2, bt.x1}, st));
         x = bt.x2;
     }
     if (L.scale == 1) {
