@@ -104,7 +104,8 @@ bool train_x3() {
     return on;
 }
 inline bool train_x3_shape(int Np, int Kp) {          // by the layer's geometry only: the arithmetic of a clip must not depend on the batch it is in (two-part passes, DDP shards)
-    return Kp % 16 == 0 && Kp >= 96 && Np >= 96;
+    static const int min_k = [] { const char* e = ESCX_TUNE_ENV("ESCX_TRAIN_X3_MIN_K"); return e ? atoi(e) : 96; }();       // tuning aid (tagged builds)
+    return Kp % 16 == 0 && Kp >= min_k && Np >= min_k;
 }
 
 template <class Ld, class Epi>
@@ -187,6 +188,22 @@ int dw_rows(escx_handle_s* h, const float* A, int lda, const float* Bm, int ldb,
     static const bool wide_ok = [] { const char* e = ESCX_TUNE_ENV("ESCX_DW_WIDE"); return !(e && e[0] == '0'); }();
     static const double pad_limit = [] { const char* e = ESCX_TUNE_ENV("ESCX_DW_WIDE_PAD"); return e ? atof(e) : 1.15; }();      // tile padding a wide tile may add
     const PlainA la{A, lda, M}, lb{Bm, ldb, M};
+    // split-operand dW (gemm_bf16.h gemm_dw_bf16_kernel<.., 3>: 128 x 128 tiles of dW, both operands as three bf16 terms, slices of M added in a fixed order) where the
+    // tiles carry no padding - the C = 384 blocks; the narrower matrices keep the fp32 kernels with their fitted tile shapes below
+    static const bool dw_x3 = [] { const char* e = ESCX_TUNE_ENV("ESCX_TRAIN_X3_DW"); return !(e && e[0] == '0'); }();
+    if (train_x3() && dw_x3 && Np % 128 == 0 && Kp % 128 == 0) {
+        const int nbn = Np / 128, nbk = Kp / 128, blocks = nbn * nbk;
+        const size_t per = (size_t)Np * Kp + Np;
+        int slices = std::max(1, std::min((1024 + blocks / 2) / blocks, (M + 255) / 256));
+        slices = (int)std::max<size_t>(1, std::min<size_t>(slices, DW_PART_FLOATS / per));
+        int mps = ((M + slices - 1) / slices + 31) / 32 * 32;
+        slices = (M + mps - 1) / mps;
+        float* bpart = part + (size_t)slices * Np * Kp;
+        hipLaunchKernelGGL((gemm_dw_bf16_kernel<PlainA, PlainA, 3>), dim3(blocks, slices), dim3(256), 0, st, la, lb, M, Np, Kp, nbk, mps, part, db ? bpart : nullptr);
+        reduce_partials(part, slices, (long long)Np * Kp, dW, 0, st);
+        if (db) reduce_partials(bpart, slices, (long long)Np, db, 0, st);
+        return 0;
+    }
     // the 144- and 80-wide maps (C = 144, 72) fit none of the 32-multiple tiles: one side of the workgroup tile IS the map width (9 or 5 accumulator tiles per
     // wave, all four waves along the other side).  ESCX_DW_ODD=0: the 48 x 48 kernel as before.
     static const bool odd_ok = [] { const char* e = ESCX_TUNE_ENV("ESCX_DW_ODD"); return !(e && e[0] == '0'); }();
