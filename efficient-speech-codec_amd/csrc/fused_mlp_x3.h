@@ -96,8 +96,17 @@ __global__ __launch_bounds__(256) void mlp_x3_split_pack_kernel(const f32x4* __r
     dst[0] = pack8(s0); dst[64] = pack8(s1); dst[128] = pack8(s2);
 }
 
+// Timing-only ablations for tagged builds (-DESCX_X3_ABL=bits; results are wrong by construction, profiles/r5_mlp_x3_ablation.txt): 1 = one cross term instead of six,
+// 2 = no GELU and no operand split of the hidden tile (one conversion), 4 = no wait / barrier at the weight stages.
+#ifndef ESCX_X3_ABL
+#define ESCX_X3_ABL 0
+#endif
 // the six cross terms (weight term i, activation term j), smallest first
+#if ESCX_X3_ABL & 1
+#define ESCX_X3_TERMS(M) M(0, 0)
+#else
 #define ESCX_X3_TERMS(M) M(0, 2) M(2, 0) M(1, 1) M(0, 1) M(1, 0) M(0, 0)
+#endif
 
 template <int CP> constexpr int mlp_x3_min_waves() { return CP <= 96 ? 4 : (CP <= 192 ? 2 : 1); }
 
@@ -197,8 +206,10 @@ __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kern
 
     int g = 0;                                  // stage counter
     auto next_stage = [&]() -> const bf16x8* {
+#if !(ESCX_X3_ABL & 4)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                        // stage g is in LDS for every wave; nobody still reads the other slot
+#endif
         issue(g + 1);
         const bf16x8* wb = &x3_wbuf[((g & 1) * SF) * 64 + lane];
         ++g;
@@ -223,10 +234,18 @@ __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kern
         // ---- GELU, then the 8 hidden values of this lane become the k-slots of one fc2 step ----
         float hv[8];
 #pragma unroll
+#if ESCX_X3_ABL & 2
+        for (int e = 0; e < 4; ++e) { hv[e] = h0[e]; hv[4 + e] = h1[e]; }
+        __bf16 s0[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s0[e] = (__bf16)hv[e];
+        const bf16x8 hs3[3] = {pack8(s0), pack8(s0), pack8(s0)};
+#else
         for (int e = 0; e < 4; ++e) { hv[e] = gelu_bf(h0[e]); hv[4 + e] = gelu_bf(h1[e]); }
         __bf16 s0[8], s1[8], s2[8];
         split3_bf16(hv, s0, s1, s2);
         const bf16x8 hs3[3] = {pack8(s0), pack8(s1), pack8(s2)};
+#endif
         // ---- fc2: two output tiles per step (no back-to-back MFMAs on one accumulator) ----
         const bf16x8* w2b = SINGLE ? wb + (size_t)(6 * KS) * 64 : nullptr;
 #pragma unroll
@@ -344,5 +363,158 @@ __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kern
 #pragma unroll
     for (int o = 0; o < KK; ++o) st4(orow + 16 * o, res[o] + acc[o]);
 }
+
+#ifdef ESCX_EXPERIMENTAL
+// Two (TM) 16-row tiles per wave (round 5 experiment, tagged builds only; profiles/r5_mlp_x3_ablation.txt): the wave holds the split rows of TM tiles in registers and
+// each weight fragment read from LDS feeds TM MFMAs - the same per-row arithmetic in the same order (bit-identical to mlp_x3_kernel: hash 05247df3f135c41c), half the LDS
+// reads, weight DMA pieces and stage barriers per row, at half the resident waves (159 / 228 / 192 registers at C = 45 / 72 / 96).  MEASURED SLOWER: isolated C = 45
+// 1.208 -> 1.468 ms per step, C = 72 0.649 -> 0.715, C = 96 0.657 -> 0.870 - the kernel's floor is latency hidden by resident waves, not the fragment stream.
+template <int CP, int NW, int TM>
+__global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>() >= 2 * TM ? mlp_x3_min_waves<CP>() / TM : 1)) void mlp_x3_rows_kernel(MlpArgs a) {
+    constexpr int KS = mlp_x3_ks(CP), KK = CP / 16, CH = mlp_x3_frags(CP), NOP = (KK + 1) / 2;
+    constexpr bool SINGLE = mlp_x3_single(CP);
+    constexpr int G1 = mlp_x3_g1(CP), G2 = mlp_x3_g2(CP), NS1 = (KS + G1 - 1) / G1, NS2 = (NOP + G2 - 1) / G2;
+    constexpr int NSP = SINGLE ? 1 : NS1 + NS2;
+    constexpr int SF = mlp_x3_stage_frags(CP);
+    extern __shared__ __attribute__((aligned(16))) bf16x8 x3_wbuf[];             // [2][SF * 64]
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p1 = a.HT / 2;
+    const int m0 = (blockIdx.x * NW + wave) * 16 * TM;
+    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.x3_w);
+    auto stage_off = [&](int k) -> int { if (SINGLE) return 0; return k < NS1 ? 6 * G1 * k : 6 * KS + 6 * G2 * (k - NS1); };
+    auto stage_cnt = [&](int k) -> int {
+        if (SINGLE) return CH;
+        if (k < NS1) return 6 * (k + 1 < NS1 ? G1 : KS - G1 * (NS1 - 1));
+        const int pairs_before = G2 * (k - NS1), tiles = min(KK - 2 * pairs_before, 2 * G2);
+        return 3 * tiles;
+    };
+    auto issue = [&](int g) {
+        const int p = g / NSP, k = g - (g / NSP) * NSP;
+        if (p >= p1) return;
+        const bf16x8* src = wsrc + ((size_t)p * CH + stage_off(k)) * 64 + lane;
+        bf16x8* dst = &x3_wbuf[((g & 1) * SF) * 64];
+        const int cnt = stage_cnt(k);
+        for (int c = wave; c < cnt; c += NW)
+            __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(dst + c * 64), 16, 0, 0);
+    };
+    issue(0);
+
+    bf16x8 xs[TM][3][KS];
+    bool live[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {              // the expressions of mlp_x3_kernel, per row tile
+        const int row = m0 + 16 * t + l15;
+        live[t] = row < a.M;
+        const float* xr = a.x + (size_t)(live[t] ? row : 0) * CP;
+        float xv[KS][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c0 = 32 * s + 8 * lg;
+            f32x4 v0 = zero4(), v1 = zero4();
+            if (c0 < CP) { v0 = ld4(xr + c0); v1 = ld4(xr + c0 + 4); }
+            if (!live[t]) { v0 = zero4(); v1 = zero4(); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xv[s][e] = v0[e]; xv[s][4 + e] = v1[e]; sum += v0[e]; sum += v1[e]; }
+        }
+        sum = sum_groups(sum);
+        const float mean = sum / (float)a.C;
+        float var = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = xv[s][e] - mean; var += d * d; }
+        var = sum_groups(var) - (float)(32 * KS - a.C) * mean * mean;
+        const float rstd = 1.0f / sqrtf(var / (float)a.C + a.eps);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c0 = 32 * s + 8 * lg;
+            f32x4 g0 = zero4(), g1 = zero4(), b0 = zero4(), b1 = zero4();
+            if (c0 < CP) { g0 = ld4(a.gamma + c0); g1 = ld4(a.gamma + c0 + 4); b0 = ld4(a.beta + c0); b1 = ld4(a.beta + c0 + 4); }
+            float xn[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xn[e] = (xv[s][e] - mean) * rstd * g0[e] + b0[e];
+                xn[4 + e] = (xv[s][4 + e] - mean) * rstd * g1[e] + b1[e];
+            }
+            __bf16 s0[8], s1[8], s2[8];
+            split3_bf16(xn, s0, s1, s2);
+            xs[t][0][s] = pack8(s0); xs[t][1][s] = pack8(s1); xs[t][2][s] = pack8(s2);
+        }
+    }
+
+    f32x4 acc[TM][KK];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int o = 0; o < KK; ++o) acc[t][o] = zero4();
+
+    int g = 0;
+    auto next_stage = [&]() -> const bf16x8* {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        issue(g + 1);
+        const bf16x8* wb = &x3_wbuf[((g & 1) * SF) * 64 + lane];
+        ++g;
+        return wb;
+    };
+    for (int p = 0; p < p1; ++p) {
+        const f32x4 bias0 = ld4(a.b1 + 32 * p + 4 * lg), bias1 = ld4(a.b1 + 32 * p + 16 + 4 * lg);
+        const bf16x8* wb = nullptr;
+        f32x4 h0[TM], h1[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) { h0[t] = bias0; h1[t] = bias1; }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s % G1 == 0) wb = next_stage();
+            const bf16x8* wf = wb + (size_t)((s % G1) * 6) * 64;
+            bf16x8 w0[3], w1[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { w0[i] = wf[i * 64]; w1[i] = wf[(3 + i) * 64]; }
+#define ESCX_X3_FC1(I, J) _Pragma("unroll") for (int t = 0; t < TM; ++t) { h0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[I], xs[t][J][s], h0[t], 0, 0, 0); h1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[I], xs[t][J][s], h1[t], 0, 0, 0); }
+            ESCX_X3_TERMS(ESCX_X3_FC1)
+#undef ESCX_X3_FC1
+        }
+        bf16x8 hs3[TM][3];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            float hv[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { hv[e] = gelu_bf(h0[t][e]); hv[4 + e] = gelu_bf(h1[t][e]); }
+            __bf16 s0[8], s1[8], s2[8];
+            split3_bf16(hv, s0, s1, s2);
+            hs3[t][0] = pack8(s0); hs3[t][1] = pack8(s1); hs3[t][2] = pack8(s2);
+        }
+        const bf16x8* w2b = SINGLE ? wb + (size_t)(6 * KS) * 64 : nullptr;
+#pragma unroll
+        for (int op = 0; op < NOP; ++op) {
+            if (!SINGLE && op % G2 == 0) w2b = next_stage();
+            const int o = 2 * op;
+            const bf16x8* wf = w2b + (size_t)((SINGLE ? op : op % G2) * 6) * 64;
+            bf16x8 wa[3], wn[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { wa[i] = wf[i * 64]; if (o + 1 < KK) wn[i] = wf[(3 + i) * 64]; }
+#define ESCX_X3_FC2(I, J) _Pragma("unroll") for (int t = 0; t < TM; ++t) { acc[t][o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[I], hs3[t][J], acc[t][o], 0, 0, 0); if (o + 1 < KK) acc[t][o + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[I], hs3[t][J], acc[t][o + 1], 0, 0, 0); }
+            ESCX_X3_TERMS(ESCX_X3_FC2)
+#undef ESCX_X3_FC2
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        if (!live[t]) continue;
+        const int row = m0 + 16 * t + l15;
+        const float* xres = a.x + (size_t)row * CP + 4 * lg;
+        float* orow = (a.out ? a.out : a.x) + (size_t)row * CP + 4 * lg;
+        f32x4 res[KK];
+#pragma unroll
+        for (int o = 0; o < KK; ++o) { res[o] = ld4(xres + 16 * o); acc[t][o] += ld4(a.b2 + 16 * o + 4 * lg); }
+#pragma unroll
+        for (int o = 0; o < KK; ++o) st4(orow + 16 * o, res[o] + acc[t][o]);
+    }
+}
+
+#endif  // ESCX_EXPERIMENTAL
 
 }  // namespace escx

@@ -190,6 +190,21 @@ static void launch_mlp_x3(const MlpArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(((a.M + 16 * NW - 1) / (16 * NW)) * hs), dim3(64 * NW), lds, s, a);
 }
 
+#ifdef ESCX_EXPERIMENTAL       // two row tiles per wave: measured slower (fused_mlp_x3.h)
+template <int CP, int NW, int TM>
+static void launch_mlp_x3_rows(const MlpArgs& a, hipStream_t s) {
+    auto kern = mlp_x3_rows_kernel<CP, NW, TM>;
+    constexpr int lds = 2 * mlp_x3_stage_frags(CP) * 1024;
+    if constexpr (lds > 48 * 1024) {
+        static std::atomic<unsigned> done{0};
+        int dev = 0; (void)hipGetDevice(&dev);
+        const unsigned bit = 1u << (dev & 31);
+        if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
+    }
+    hipLaunchKernelGGL(kern, dim3((a.M + 16 * NW * TM - 1) / (16 * NW * TM)), dim3(64 * NW), lds, s, a);
+}
+#endif
+
 size_t mlp_x3_split_bytes(int Cp, int Np) { return (size_t)(Np / 16) * 3 * ((Cp / 16 + 1) / 2) * 1024; }
 int mlp_x3_split_pack(const float* wf, void* image, int Cp, int Np, hipStream_t s) {
     const int KK = Cp / 16, NT = Np / 16;
@@ -234,6 +249,17 @@ int mlp_x3(float* x, int M, int C, int Cp, const float* gamma, const float* beta
     if (hs_io) *hs_io = hs;
     MlpArgs a{};
     a.x = x; a.gamma = gamma; a.beta = beta; a.b1 = b1; a.b2 = b2; a.M = M; a.C = C; a.HT = hiddenP / 16; a.eps = 1e-5f; a.HS = hs; a.partial = partial; a.x3_w = image;
+#ifdef ESCX_EXPERIMENTAL
+    // two row tiles per wave (mlp_x3_rows_kernel, bit-identical, measured slower) for the narrow maps without a hidden split: ESCX_MLP_X3_TM=2
+    static const int tm_env = [] { const char* e = ESCX_TUNE_ENV("ESCX_MLP_X3_TM"); return e ? atoi(e) : 1; }();
+    if (hs == 1 && tm_env == 2 && Cp <= 96) {
+        switch (Cp) {
+            case 48: if (nw == 8) launch_mlp_x3_rows<48, 8, 2>(a, s); else launch_mlp_x3_rows<48, 4, 2>(a, s); return 0;
+            case 80: if (nw == 8) launch_mlp_x3_rows<80, 8, 2>(a, s); else launch_mlp_x3_rows<80, 4, 2>(a, s); return 0;
+            case 96: if (nw == 8) launch_mlp_x3_rows<96, 8, 2>(a, s); else launch_mlp_x3_rows<96, 4, 2>(a, s); return 0;
+        }
+    }
+#endif
 #define ESCX_X3_CASE(CPV) case CPV: if (nw == 8) launch_mlp_x3<CPV, 8>(a, s); else launch_mlp_x3<CPV, 4>(a, s); return 0;
     switch (Cp) {
         ESCX_X3_CASE(48) ESCX_X3_CASE(80) ESCX_X3_CASE(96) ESCX_X3_CASE(144) ESCX_X3_CASE(192) ESCX_X3_CASE(384)
