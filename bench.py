@@ -363,12 +363,14 @@ def run_train(args, rank, world, device, use_dist, emit=True):
                 "launches_per_step": dom["calls"] // psteps, "share_of_profiled_time": round(dom["ms"] / tot, 4),
                 "profiled_ms_per_step": round(tot / psteps, 3),
                 "executed_gflop_per_clip": round(sum(r["flops"] for r in recs) / psteps / CLIPS_PER_GPU / 1e9, 2),
-                "note": "kernel = the GEMM-class launch group with the largest share of the step; traffic not collected in train mode"}
+                "note": "kernel = the GEMM-class launch group with the largest share of the step; traffic not collected in train mode; FLOPs are algorithmic fp32 FLOPs "
+                        "(a split-operand launch executes six bf16 MFMA products per counted product), fractions are against the fp32 MFMA peak"}
     audio_s = CLIPS_PER_GPU * world * args.steps * (TRAIN_SAMPLES / 16000.0)
     roofline["whole_step_frac_executed_flops"] = round(roofline["executed_gflop_per_clip"] * 1e9 * CLIPS_PER_GPU * args.steps / elapsed / PEAK_F32_MFMA, 4)
     out = {"metric": "audio-seconds/sec trained (forward + mel/STFT/VQ losses + backward + clip + AdamW), ESC-Base 9kbps 3s@16kHz",
            "value": round(audio_s / elapsed, 2), "unit": "audio-seconds/sec", "n_gpus": (dist.get_world_size() if use_dist else 1), "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" if os.environ.get("ESCX_TRAIN_X3") == "0" else "f32 (linear layers from 96 columns up: fp32 operands as three exact bf16 terms, six cross products, fp32 accumulate)",
            "data": "synthetic",
            "config": {"workload": f"ESC-Base training step (scripts/trainer_no_adv.py:95-118, non-adversarial), batch={CLIPS_PER_GPU} clips of {TRAIN_SAMPLES} samples per GPU, "
                                   "num_streams=6, fp32 (the reference has no AMP); first slice of BASELINE configs[4]",

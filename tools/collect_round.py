@@ -9,7 +9,7 @@ def main():
     pre = sys.argv[1]
     src, dst = os.path.join(ROOT, "gpurun_out", "round"), os.path.join(ROOT, "profiles")
     names = {"bench.json": "bench.json", "bench_rccl_1rank.json": "bench_rccl_1rank.json", "bench_strong_n1.json": "bench_strong_n1.json",
-             "bench_train.json": "bench_train.json", "bench_train_adv.json": "bench_train_adv.json", "bench_train_adv_bf16.json": "bench_train_adv_bf16.json", "train_adv_bf16_kernel_stats.csv": "train_adv_bf16_kernel_stats.csv", "event_breakdown_isolated.txt": "event_breakdown.txt",
+             "bench_train.json": "bench_train.json", "bench_train_adv.json": "bench_train_adv.json", "bench_train_adv_bf16.json": "bench_train_adv_bf16.json", "bench_train_adv_fp32mfma.json": "bench_train_adv_fp32mfma.json", "train_adv_bf16_kernel_stats.csv": "train_adv_bf16_kernel_stats.csv", "event_breakdown_isolated.txt": "event_breakdown.txt",
              "event_breakdown_1stream.txt": "event_breakdown_1stream.txt", "kernel_stats.csv": "kernel_stats.csv", "prof_bench_line.txt": "bench_under_rocprof.json",
              "other_configs.json": "other_configs.json", "pmc_hbm.json": "pmc_hbm.json", "pmc_calibration.json": "pmc_calibration.json",
              "sq_counters.txt": "sq_counters.txt", "sq_counters.json": "sq_counters.json", "train_breakdown.txt": "train_breakdown.txt",

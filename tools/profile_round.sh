@@ -45,6 +45,8 @@ timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_adv -o p -- pytho
 cp $(find $O/prof_adv -name "*kernel_stats.csv" | head -1) $O/train_adv_kernel_stats.csv 2>/dev/null
 rm -rf $O/prof_adv
 cd $R
+# the all-fp32-MFMA adversarial step (rounds 2-4; the default is the split-operand precision since round 5)
+timeout 900 python bench.py --mode train_adv --adv-precision fp32 --steps 4 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_train_adv_fp32mfma.json; cut -c1-300 $O/bench_train_adv_fp32mfma.json
 # opt-in bf16 precision of the discriminator's wide convolutions: bench line + kernel stats of the same step
 timeout 900 python bench.py --mode train_adv --adv-precision bf16 --steps 4 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_train_adv_bf16.json; cut -c1-300 $O/bench_train_adv_bf16.json
 cd /tmp
