@@ -1031,6 +1031,8 @@ extern "C" const char* escx_profile_report(escx_handle h) {
 // Fused MLP on the bf16 matrix cores with every fp32 operand split exactly into three bf16 terms (fused_mlp_x3.h): DEFAULT for every instantiated width
 // (48, 80, 96, 144, 192, 384).  ESCX_MLP_X3=<max padded width> restricts it, ESCX_MLP_X3=0 = the fp32-MFMA kernel (fused_mlp.h) everywhere - the
 // round-4 arithmetic, which bench.py also reports (`fp32_mfma_only`) and tests/test_gpu_parity.py keeps as an arm.
+// terms per operand of the split-operand MLP: 3 = bf16 (exact split), 2 = fp16 with power-of-two weight scales (fused_mlp_x3.h); ESCX_MLP_X3_TERMS=2|3
+static int mlp_x3_terms() { static const int v = [] { const char* e = getenv("ESCX_MLP_X3_TERMS"); const int t = e && e[0] ? atoi(e) : 2; return t == 3 ? 3 : 2; }(); return v; }
 static int mlp_x3_maxcp() { static const int v = [] { const char* e = getenv("ESCX_MLP_X3"); return e && e[0] ? atoi(e) : 384; }(); return v; }
 
 // Waves per workgroup (4 or 8) for the fused kernels.  A wave owns `units` 16-row tiles; a workgroup's waves spread over the
@@ -1172,13 +1174,13 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
                     const MlpSplit sp{reinterpret_cast<const float*>(L.sub_x3s), L.sub_g, L.sub_b, y, 2 * L.CoutP / 16, H, W, L.CoutP};
                     int src3 = -1, one = 1;
                     PROF("mlp_x3_split" + tag, 4 * dM * dC * L.hidden + 2.0 * dM * dC * 2 * L.Cout, (dM * dC + dM * 2 * L.Cout) * f4,
-                         src3 = mlp_x3(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.b1, bw.b2, bw.x3w, L.hiddenP, x3_nw_force ? x3_nw_force : mlp_x3_nw(M, L.Cp, variant), &one, nullptr, st, &sp));
+                         src3 = mlp_x3(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.b1, bw.b2, bw.x3w, L.hiddenP, x3_nw_force ? x3_nw_force : mlp_x3_nw(M, L.Cp, variant), &one, nullptr, st, &sp, mlp_x3_terms()));
                     if (src3 == 0) { *Hout = 2 * H; return launch_ok(L.prefix.c_str()); }
                     if (h->prof && !h->prof_recs.empty()) h->prof_recs.pop_back();
                 }
                 int xrc = -1, xhs = hs;
                 PROF("mlp_x3" + tag, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
-                     xrc = mlp_x3(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.b1, bw.b2, bw.x3w, L.hiddenP, x3_nw_force ? x3_nw_force : mlp_x3_nw(M, L.Cp, variant), &xhs, h->hid, st));
+                     xrc = mlp_x3(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.b1, bw.b2, bw.x3w, L.hiddenP, x3_nw_force ? x3_nw_force : mlp_x3_nw(M, L.Cp, variant), &xhs, h->hid, st, nullptr, mlp_x3_terms()));
                 if (xrc == 0) {
                     if (xhs > 1) { pend = CombineOnLoad{h->hid, bw.b2, (long long)M * L.Cp, xhs}; pend_tag = tag; flush_pending(); }
                     src = cur; continue;
@@ -1319,8 +1321,8 @@ static int ensure_pvq_tables(escx_handle_s* h, hipStream_t st) {
         for (BlockW& bw : L.blocks) {
             const bool want = x3_max > 0 && L.Cp <= x3_max && (L.Cp == 48 || L.Cp == 80 || L.Cp == 96 || L.Cp == 144 || L.Cp == 192 || L.Cp == 384) && L.hiddenP % 32 == 0;
             if (!want) { if (bw.x3w) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(bw.x3w); bw.x3w = nullptr; } continue; }
-            if (!bw.x3w) ESCX_HIP(hipMalloc(&bw.x3w, mlp_x3_bytes(L.Cp, L.hiddenP)));
-            if (mlp_x3_pack(bw.w1, bw.w2, bw.x3w, L.Cp, L.hiddenP, st) != 0) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(bw.x3w); bw.x3w = nullptr; }
+            if (!bw.x3w) ESCX_HIP(hipMalloc(&bw.x3w, mlp_x3_bytes(L.Cp, L.hiddenP, 3)));      // sized for the larger (three-term) image
+            if (mlp_x3_pack(bw.w1, bw.w2, bw.x3w, L.Cp, L.hiddenP, st, mlp_x3_terms()) != 0) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(bw.x3w); bw.x3w = nullptr; }
         }
     // the split Q / K / V weight streams of the fused attention (fused_attn.h X3; ESCX_ATTN_X3=0: fp32 MFMA)
     static const int ax3_max = [] { const char* e = getenv("ESCX_ATTN_X3"); return e && e[0] ? atoi(e) : 384; }();

@@ -34,24 +34,75 @@ __device__ __forceinline__ void split3_bf16(const float (&v)[N], __bf16 (&s0)[N]
 }
 __device__ __forceinline__ bf16x8 pack8(const __bf16 (&s)[8]) { bf16x8 r; for (int e = 0; e < 8; ++e) r[e] = s[e]; return r; }
 
+// NT = 2 (round 5, second form): TWO fp16 terms per operand, a ~ a1 + a2 with a1 = fp16(a), a2 = fp16(a - a1) (11-bit significands, round to nearest: |a - a1 - a2| <= 2^-22 |a|,
+// typically 2^-24), and THREE cross products a1b1 + a1b2 + a2b1 on v_mfma_f32_16x16x32_f16 - half the matrix instructions and two thirds of the fragment stream of the
+// three-term bf16 form.  Not exact: the truncation measures 9.5e-8 of the mean result magnitude (numpy, exact accumulation) against 1.6e-7 ... 4.5e-7 of fp32 accumulation
+// rounding for K = 48 ... 1536, i.e. the fp32 error budget grows by 5-16 %.  fp16 has a 5-bit exponent: the weights are scaled by a power of two per matrix at pack time
+// (max |w| 2^k in [2^13, 2^14): the low term of every weight stays a normal number) and the accumulators are scaled back exactly (powers of two commute with fp32 rounding).
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+template <int N>
+__device__ __forceinline__ void split2_f16(const float (&v)[N], float scale, _Float16 (&s0)[N], _Float16 (&s1)[N]) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const float a = v[e] * scale;
+        const _Float16 a1 = (_Float16)a;
+        s0[e] = a1; s1[e] = (_Float16)(a - (float)a1);
+    }
+}
+__device__ __forceinline__ bf16x8 pack8h(const _Float16 (&s)[8]) { half8 r; for (int e = 0; e < 8; ++e) r[e] = s[e]; return __builtin_bit_cast(bf16x8, r); }
+// one 16 x 16 x 32 step on fragments held as 16 raw bytes per lane
+template <int NT>
+__device__ __forceinline__ f32x4 mma_x(bf16x8 w, bf16x8 x, f32x4 c) {
+    if constexpr (NT == 3) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, w), __builtin_bit_cast(half8, x), c, 0, 0, 0);
+}
+// rows of activations -> NT term fragments
+template <int NT>
+__device__ __forceinline__ void split_rows(const float (&v)[8], bf16x8 (&out)[NT]) {
+    if constexpr (NT == 3) {
+        __bf16 s0[8], s1[8], s2[8];
+        split3_bf16(v, s0, s1, s2);
+        out[0] = pack8(s0); out[1] = pack8(s1); out[2] = pack8(s2);
+    } else {
+        _Float16 s0[8], s1[8];
+        split2_f16(v, 1.0f, s0, s1);
+        out[0] = pack8h(s0); out[1] = pack8h(s1);
+    }
+}
+// power of two that brings max |w| into [2^13, 2^14) (1 for an all-zero matrix): bits of max |w| -> scale
+__device__ __forceinline__ float x2_scale(unsigned absmax_bits) {
+    const int ex = (int)((absmax_bits >> 23) & 0xff);       // biased exponent of max |w|
+    if (ex == 0 || ex == 0xff) return 1.0f;
+    return __uint_as_float((unsigned)(127 + 13 - (ex - 127)) << 23);
+}
+
 constexpr int mlp_x3_ks(int CP) { return (CP + 31) / 32; }
-constexpr int mlp_x3_frags(int CP) { return 6 * mlp_x3_ks(CP) + 3 * (CP / 16); }       // 1 KiB fragments per pair of hidden tiles: fc1 (KS steps x 2 tiles x 3 terms), fc2 (KK tiles x 3 terms)
+constexpr int mlp_x3_frags(int CP, int NT = 3) { return 2 * NT * mlp_x3_ks(CP) + NT * (CP / 16); }       // 1 KiB fragments per pair of hidden tiles: fc1 (KS steps x 2 tiles x NT terms), fc2 (KK tiles x NT terms)
 // LDS staging.  Narrow layers (<= 36 fragments per pair): ONE stage per pair.  Wide layers: fc1 in stages of up to 6 K-steps (36 KiB), fc2 in stages of up to 6 pairs of
 // output tiles (36 KiB); two ring slots of the largest stage.
 constexpr int MLP_X3_STAGE = 36;
-constexpr bool mlp_x3_single(int CP) { return mlp_x3_frags(CP) <= MLP_X3_STAGE; }
-constexpr int mlp_x3_g1(int CP) { return mlp_x3_single(CP) ? mlp_x3_ks(CP) : (mlp_x3_ks(CP) <= 6 ? mlp_x3_ks(CP) : 6); }                    // K-steps per fc1 stage
-constexpr int mlp_x3_g2(int CP) { return mlp_x3_single(CP) ? (CP / 16 + 1) / 2 : ((CP / 16 + 1) / 2 <= 6 ? (CP / 16 + 1) / 2 : 6); }           // output-tile pairs per fc2 stage
-constexpr int mlp_x3_stage_frags(int CP) {
-    return mlp_x3_single(CP) ? mlp_x3_frags(CP) : (6 * mlp_x3_g1(CP) > 6 * mlp_x3_g2(CP) ? 6 * mlp_x3_g1(CP) : 6 * mlp_x3_g2(CP));
+constexpr bool mlp_x3_single(int CP, int NT = 3) { return mlp_x3_frags(CP, NT) <= MLP_X3_STAGE; }
+constexpr int mlp_x3_gmax(int NT) { return MLP_X3_STAGE / (2 * NT); }               // K-steps (fc1) or output-tile pairs (fc2) per 36 KiB stage: 6 / 9
+constexpr int mlp_x3_g1(int CP, int NT = 3) { return mlp_x3_single(CP, NT) ? mlp_x3_ks(CP) : (mlp_x3_ks(CP) <= mlp_x3_gmax(NT) ? mlp_x3_ks(CP) : mlp_x3_gmax(NT)); }                    // K-steps per fc1 stage
+constexpr int mlp_x3_g2(int CP, int NT = 3) { return mlp_x3_single(CP, NT) ? (CP / 16 + 1) / 2 : ((CP / 16 + 1) / 2 <= mlp_x3_gmax(NT) ? (CP / 16 + 1) / 2 : mlp_x3_gmax(NT)); }           // output-tile pairs per fc2 stage
+constexpr int mlp_x3_stage_frags(int CP, int NT = 3) {
+    return mlp_x3_single(CP, NT) ? mlp_x3_frags(CP, NT) : 2 * NT * (mlp_x3_g1(CP, NT) > mlp_x3_g2(CP, NT) ? mlp_x3_g1(CP, NT) : mlp_x3_g2(CP, NT));
 }
 
 // Split image of one block's MLP weights, fragments in CONSUMPTION order.  Pair p of hidden tiles (2p, 2p + 1):
 //   fc1 fragment f = (s * 2 + tt) * 3 + i          -> lane (n, g) holds term i of W1[16 (2p + tt) + n][32 s + 8 g + e], e = 0..7 (zero beyond Cp)
 //   fc2 fragment f = 6 KS + o * 3 + i              -> lane (c, g) holds term i of W2[16 o + c][unit(g, e)], unit = 16 (2p) + 4 g + e for e < 4, 16 (2p + 1) + 4 g + e - 4 otherwise
 // (the k-slot <-> hidden unit map the kernel's two fc1 accumulator tiles dictate).  One thread per (pair, fragment triple, lane).
-__global__ __launch_bounds__(256) void mlp_x3_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, bf16x8* __restrict__ out, int Cp, int HP, int KS, int KK) {
-    const int CH = 6 * KS + 3 * KK, triples = 2 * KS + KK;
+// NT = 2: the image ends with two 16-byte slots - [0] bits of max |w1|, max |w2| (absmax_bits_kernel, before this kernel), [1] {2^-k1, 2^-k2, 2^k1, 2^k2} written here.
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ w, long long n, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = max(m, __float_as_uint(fabsf(w[i])));
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);       // non-negative floats order like their bit patterns; the maximum does not depend on the order of the updates
+}
+__global__ __launch_bounds__(256) void mlp_x3_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, bf16x8* __restrict__ out, int Cp, int HP, int KS, int KK, int NT) {
+    const int CH = 2 * NT * KS + NT * KK, triples = 2 * KS + KK;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)(HP / 32) * triples * 64;
     if (idx >= total) return;
@@ -62,21 +113,31 @@ __global__ __launch_bounds__(256) void mlp_x3_pack_kernel(const float* __restric
     int fbase;
     if (t3 < 2 * KS) {
         const int s = t3 >> 1, tt = t3 & 1;
-        fbase = t3 * 3;
+        fbase = t3 * NT;
         const float* row = w1 + (size_t)(16 * (2 * p + tt) + n) * Cp;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const int k = 32 * s + 8 * g + e; v[e] = k < Cp ? row[k] : 0.f; }
     } else {
         const int o = t3 - 2 * KS;
-        fbase = 6 * KS + o * 3;
+        fbase = 2 * NT * KS + o * NT;
         const float* row = w2 + (size_t)(16 * o + n) * HP;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = row[16 * (2 * p + (e >> 2)) + 4 * g + (e & 3)];
     }
-    __bf16 s0[8], s1[8], s2[8];
-    split3_bf16(v, s0, s1, s2);
     bf16x8* dst = out + ((size_t)p * CH + fbase) * 64 + lane;
-    dst[0] = pack8(s0); dst[64] = pack8(s1); dst[128] = pack8(s2);
+    if (NT == 3) {
+        __bf16 s0[8], s1[8], s2[8];
+        split3_bf16(v, s0, s1, s2);
+        dst[0] = pack8(s0); dst[64] = pack8(s1); dst[128] = pack8(s2);
+    } else {
+        bf16x8* tail = out + (size_t)(HP / 32) * CH * 64;
+        const unsigned* mx = reinterpret_cast<const unsigned*>(tail);
+        const float sc1 = x2_scale(mx[0]), sc2 = x2_scale(mx[1]);
+        _Float16 h0[8], h1[8];
+        split2_f16(v, t3 < 2 * KS ? sc1 : sc2, h0, h1);
+        dst[0] = pack8h(h0); dst[64] = pack8h(h1);
+        if (idx == 0) { float* f = reinterpret_cast<float*>(tail + 1); f[0] = 1.0f / sc1; f[1] = 1.0f / sc2; f[2] = sc1; f[3] = sc2; }
+    }
 }
 
 // PatchSplit weights for the SPLIT epilogue of mlp_x3_kernel, from the fp32 fragment stream (Layer::sub_wf, [NT][KK][64] float4): fragment (nt, s, i) -> lane (n, g) holds
@@ -107,17 +168,20 @@ __global__ __launch_bounds__(256) void mlp_x3_split_pack_kernel(const f32x4* __r
 #else
 #define ESCX_X3_TERMS(M) M(0, 2) M(2, 0) M(1, 1) M(0, 1) M(1, 0) M(0, 0)
 #endif
+// the three cross terms of the two-term fp16 form, smallest first
+#define ESCX_X2_TERMS(M) M(0, 1) M(1, 0) M(0, 0)
 
 template <int CP> constexpr int mlp_x3_min_waves() { return CP <= 96 ? 4 : (CP <= 192 ? 2 : 1); }
 
 // SPLIT: PatchSplit in the epilogue (as fused_mlp.h SPLIT): LayerNorm(C) of x + mlp(x) in registers, Linear(C -> 2 C') with split operands, two-row scatter; x is not written.
-template <int CP, int NW, bool SPLIT = false>
+template <int CP, int NW, bool SPLIT = false, int NT = 3>
 __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kernel(MlpArgs a) {
-    constexpr int KS = mlp_x3_ks(CP), KK = CP / 16, CH = mlp_x3_frags(CP), NOP = (KK + 1) / 2;
-    constexpr bool SINGLE = mlp_x3_single(CP);
-    constexpr int G1 = mlp_x3_g1(CP), G2 = mlp_x3_g2(CP), NS1 = (KS + G1 - 1) / G1, NS2 = (NOP + G2 - 1) / G2;
+    constexpr int KS = mlp_x3_ks(CP), KK = CP / 16, CH = mlp_x3_frags(CP, NT), NOP = (KK + 1) / 2;
+    constexpr bool SINGLE = mlp_x3_single(CP, NT);
+    constexpr int G1 = mlp_x3_g1(CP, NT), G2 = mlp_x3_g2(CP, NT), NS1 = (KS + G1 - 1) / G1, NS2 = (NOP + G2 - 1) / G2;
     constexpr int NSP = SINGLE ? 1 : NS1 + NS2;                                   // stages per pair
-    constexpr int SF = mlp_x3_stage_frags(CP);                                   // ring slot size in fragments
+    constexpr int SF = mlp_x3_stage_frags(CP, NT);                               // ring slot size in fragments
+    constexpr int N2 = 2 * NT;
     extern __shared__ __attribute__((aligned(16))) bf16x8 x3_wbuf[];             // [2][SF * 64]
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -138,13 +202,13 @@ __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kern
     // stage g (global counter over the pairs this workgroup walks): its fragments and where they start inside the pair's image
     auto stage_off = [&](int k) -> int {        // k = stage index inside a pair
         if (SINGLE) return 0;
-        return k < NS1 ? 6 * G1 * k : 6 * KS + 6 * G2 * (k - NS1);
+        return k < NS1 ? N2 * G1 * k : N2 * KS + N2 * G2 * (k - NS1);
     };
     auto stage_cnt = [&](int k) -> int {
         if (SINGLE) return CH;
-        if (k < NS1) return 6 * (k + 1 < NS1 ? G1 : KS - G1 * (NS1 - 1));
+        if (k < NS1) return N2 * (k + 1 < NS1 ? G1 : KS - G1 * (NS1 - 1));
         const int pairs_before = G2 * (k - NS1), tiles = min(KK - 2 * pairs_before, 2 * G2);
-        return 3 * tiles;
+        return NT * tiles;
     };
     auto issue = [&](int g) {                   // g counts stages from the first pair of this workgroup
         const int p = p0 + g / NSP, k = g - (g / NSP) * NSP;
@@ -156,12 +220,14 @@ __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kern
             __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(dst + c * 64), 16, 0, 0);
     };
     issue(0);
+    f32x4 x2sc = {1.f, 1.f, 1.f, 1.f};          // NT = 2: {2^-k1, 2^-k2, 2^k1, 2^k2} of this block's weight image
+    if constexpr (NT == 2) x2sc = *reinterpret_cast<const f32x4*>(wsrc + (size_t)n_pairs_all * CH * 64 + 1);
 
     // ---- rows -> k-slot layout of the 32-deep MFMA (lane (row l15, slot group lg) holds channels 32 s + 8 lg .. + 7), LayerNorm in registers, split ----
     const int row = m0 + l15;
     const bool live = row < a.M;
     const float* xr = a.x + (size_t)(live ? row : 0) * CP;
-    bf16x8 xs[3][KS];
+    bf16x8 xs[NT][KS];
     {
         float xv[KS][8];
         float sum = 0.f;
@@ -194,9 +260,10 @@ __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kern
                 xn[e] = (xv[s][e] - mean) * rstd * g0[e] + b0[e];                  // gamma = beta = 0 in the pads -> 0
                 xn[4 + e] = (xv[s][4 + e] - mean) * rstd * g1[e] + b1[e];
             }
-            __bf16 s0[8], s1[8], s2[8];
-            split3_bf16(xn, s0, s1, s2);
-            xs[0][s] = pack8(s0); xs[1][s] = pack8(s1); xs[2][s] = pack8(s2);
+            bf16x8 t[NT];
+            split_rows<NT>(xn, t);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) xs[i][s] = t[i];
         }
     }
 
@@ -220,46 +287,54 @@ __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kern
         const bf16x8* wb = nullptr;
         // ---- fc1: two hidden tiles (independent accumulator chains), the bias rides in the accumulator ----
         f32x4 h0 = bias0, h1 = bias1;
+        if constexpr (NT == 2) { h0 *= x2sc[2]; h1 *= x2sc[2]; }               // the sums of the scaled weights carry 2^k1: so does the bias (exact)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             if (s % G1 == 0) wb = next_stage();
-            const bf16x8* wf = wb + (size_t)((s % G1) * 6) * 64;
-            bf16x8 w0[3], w1[3];
+            const bf16x8* wf = wb + (size_t)((s % G1) * N2) * 64;
+            bf16x8 w0[NT], w1[NT];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { w0[i] = wf[i * 64]; w1[i] = wf[(3 + i) * 64]; }
-#define ESCX_X3_FC1(I, J) h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[I], xs[J][s], h0, 0, 0, 0); h1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[I], xs[J][s], h1, 0, 0, 0);
-            ESCX_X3_TERMS(ESCX_X3_FC1)
+            for (int i = 0; i < NT; ++i) { w0[i] = wf[i * 64]; w1[i] = wf[(NT + i) * 64]; }
+#define ESCX_X3_FC1(I, J) h0 = mma_x<NT>(w0[I], xs[J][s], h0); h1 = mma_x<NT>(w1[I], xs[J][s], h1);
+            if constexpr (NT == 3) { ESCX_X3_TERMS(ESCX_X3_FC1) } else { ESCX_X2_TERMS(ESCX_X3_FC1) }
 #undef ESCX_X3_FC1
         }
         // ---- GELU, then the 8 hidden values of this lane become the k-slots of one fc2 step ----
         float hv[8];
-#pragma unroll
 #if ESCX_X3_ABL & 2
+#pragma unroll
         for (int e = 0; e < 4; ++e) { hv[e] = h0[e]; hv[4 + e] = h1[e]; }
         __bf16 s0[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) s0[e] = (__bf16)hv[e];
-        const bf16x8 hs3[3] = {pack8(s0), pack8(s0), pack8(s0)};
+        bf16x8 hs3[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) hs3[i] = pack8(s0);
 #else
+        if constexpr (NT == 2) { h0 *= x2sc[0]; h1 *= x2sc[0]; }
+#pragma unroll
         for (int e = 0; e < 4; ++e) { hv[e] = gelu_bf(h0[e]); hv[4 + e] = gelu_bf(h1[e]); }
-        __bf16 s0[8], s1[8], s2[8];
-        split3_bf16(hv, s0, s1, s2);
-        const bf16x8 hs3[3] = {pack8(s0), pack8(s1), pack8(s2)};
+        bf16x8 hs3[NT];
+        split_rows<NT>(hv, hs3);
 #endif
         // ---- fc2: two output tiles per step (no back-to-back MFMAs on one accumulator) ----
-        const bf16x8* w2b = SINGLE ? wb + (size_t)(6 * KS) * 64 : nullptr;
+        const bf16x8* w2b = SINGLE ? wb + (size_t)(N2 * KS) * 64 : nullptr;
 #pragma unroll
         for (int op = 0; op < NOP; ++op) {
             if (!SINGLE && op % G2 == 0) w2b = next_stage();
             const int o = 2 * op;
-            const bf16x8* wf = w2b + (size_t)((SINGLE ? op : op % G2) * 6) * 64;
-            bf16x8 wa[3], wn[3];
+            const bf16x8* wf = w2b + (size_t)((SINGLE ? op : op % G2) * N2) * 64;
+            bf16x8 wa[NT], wn[NT];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { wa[i] = wf[i * 64]; if (o + 1 < KK) wn[i] = wf[(3 + i) * 64]; }
-#define ESCX_X3_FC2(I, J) acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[I], hs3[J], acc[o], 0, 0, 0); if (o + 1 < KK) acc[o + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wn[I], hs3[J], acc[o + 1], 0, 0, 0);
-            ESCX_X3_TERMS(ESCX_X3_FC2)
+            for (int i = 0; i < NT; ++i) { wa[i] = wf[i * 64]; if (o + 1 < KK) wn[i] = wf[(NT + i) * 64]; }
+#define ESCX_X3_FC2(I, J) acc[o] = mma_x<NT>(wa[I], hs3[J], acc[o]); if (o + 1 < KK) acc[o + 1] = mma_x<NT>(wn[I], hs3[J], acc[o + 1]);
+            if constexpr (NT == 3) { ESCX_X3_TERMS(ESCX_X3_FC2) } else { ESCX_X2_TERMS(ESCX_X3_FC2) }
 #undef ESCX_X3_FC2
         }
+    }
+    if constexpr (NT == 2) {
+#pragma unroll
+        for (int o = 0; o < KK; ++o) acc[o] *= x2sc[1];       // back from the 2^k2 of the scaled fc2 weights (exact)
     }
 
     if constexpr (SPLIT) {

@@ -166,20 +166,28 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
 }
 
 // ---- fused MLP, fp32 operands split into three bf16 terms (fused_mlp_x3.h) ----
-size_t mlp_x3_bytes(int Cp, int hiddenP) { return (size_t)(hiddenP / 32) * (6 * ((Cp + 31) / 32) + 3 * (Cp / 16)) * 1024; }
+// nt = 3: three bf16 terms per operand (exact split); nt = 2: two fp16 terms + per-matrix power-of-two scales in a 32-byte trailer (fused_mlp_x3.h)
+size_t mlp_x3_bytes(int Cp, int hiddenP, int nt) { return (size_t)(hiddenP / 32) * mlp_x3_frags(Cp, nt) * 1024 + 32; }
 
-int mlp_x3_pack(const float* w1, const float* w2, void* image, int Cp, int hiddenP, hipStream_t s) {
-    if (Cp % 16 || hiddenP % 32) return -1;
+int mlp_x3_pack(const float* w1, const float* w2, void* image, int Cp, int hiddenP, hipStream_t s, int nt) {
+    if (Cp % 16 || hiddenP % 32 || (nt != 2 && nt != 3)) return -1;
     const int KS = (Cp + 31) / 32, KK = Cp / 16;
     const long long total = (long long)(hiddenP / 32) * (2 * KS + KK) * 64;
-    hipLaunchKernelGGL(mlp_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w1, w2, reinterpret_cast<bf16x8*>(image), Cp, hiddenP, KS, KK);
+    if (nt == 2) {
+        unsigned* mx = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(image) + mlp_x3_bytes(Cp, hiddenP, nt) - 32);
+        if (hipMemsetAsync(mx, 0, 16, s) != hipSuccess) return -1;
+        const long long n = (long long)hiddenP * Cp;
+        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, w1, n, mx);
+        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, w2, n, mx + 1);
+    }
+    hipLaunchKernelGGL(mlp_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w1, w2, reinterpret_cast<bf16x8*>(image), Cp, hiddenP, KS, KK, nt);
     return 0;
 }
 
-template <int CP, int NW>
+template <int CP, int NW, int NT = 3>
 static void launch_mlp_x3(const MlpArgs& a, hipStream_t s) {
-    auto kern = mlp_x3_kernel<CP, NW>;
-    constexpr int lds = 2 * mlp_x3_stage_frags(CP) * 1024;
+    auto kern = mlp_x3_kernel<CP, NW, false, NT>;
+    constexpr int lds = 2 * mlp_x3_stage_frags(CP, NT) * 1024;
     if constexpr (lds > 48 * 1024) {            // function attributes are per device: one flag per device
         static std::atomic<unsigned> done{0};
         int dev = 0; (void)hipGetDevice(&dev);
@@ -213,10 +221,10 @@ int mlp_x3_split_pack(const float* wf, void* image, int Cp, int Np, hipStream_t 
     return 0;
 }
 
-template <int CP, int NW>
+template <int CP, int NW, int NT = 3>
 static void launch_mlp_x3_split(const MlpArgs& a, hipStream_t s) {
-    auto kern = mlp_x3_kernel<CP, NW, true>;
-    constexpr int lds = 2 * mlp_x3_stage_frags(CP) * 1024;
+    auto kern = mlp_x3_kernel<CP, NW, true, NT>;
+    constexpr int lds = 2 * mlp_x3_stage_frags(CP, NT) * 1024;
     if constexpr (lds > 48 * 1024) {
         static std::atomic<unsigned> done{0};
         int dev = 0; (void)hipGetDevice(&dev);
@@ -229,8 +237,8 @@ static void launch_mlp_x3_split(const MlpArgs& a, hipStream_t s) {
 // *hs_io: requested hidden split in, split used out (> 1: x untouched, partial[hs][M][Cp] filled, the caller runs rows_combine) - as mlp_fused
 // split: PatchSplit in the epilogue (split->wf = the image of mlp_x3_split_pack); ESCX_COMB_UNSUPPORTED when the width has no such instantiation
 int mlp_x3(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* b1, const float* b2, const void* image, int hiddenP, int nw, int* hs_io, float* partial,
-           hipStream_t s, const MlpSplit* split) {
-    if (!image || hiddenP % 32) return -1;
+           hipStream_t s, const MlpSplit* split, int nt) {
+    if (!image || hiddenP % 32 || (nt != 2 && nt != 3)) return -1;
     if (split) {
         if ((hs_io && *hs_io > 1) || !split->wf || !(Cp == 80 || Cp == 96 || Cp == 144)) return ESCX_COMB_UNSUPPORTED;
         MlpArgs a{};
@@ -238,9 +246,10 @@ int mlp_x3(float* x, int M, int C, int Cp, const float* gamma, const float* beta
         a.sp_wf = reinterpret_cast<const f32x4*>(split->wf); a.sp_gamma = split->gamma; a.sp_beta = split->beta; a.sp_out = split->out;
         a.sp_NT = split->NT; a.sp_H = split->H; a.sp_W = split->W; a.sp_C2p = split->C2p;
         switch (Cp) {
-            case 80: if (nw == 8) launch_mlp_x3_split<80, 8>(a, s); else launch_mlp_x3_split<80, 4>(a, s); return 0;
-            case 96: if (nw == 8) launch_mlp_x3_split<96, 8>(a, s); else launch_mlp_x3_split<96, 4>(a, s); return 0;
-            case 144: if (nw == 8) launch_mlp_x3_split<144, 8>(a, s); else launch_mlp_x3_split<144, 4>(a, s); return 0;
+#define ESCX_X3S_CASE(CPV) case CPV: if (nt == 2) { if (nw == 8) launch_mlp_x3_split<CPV, 8, 2>(a, s); else launch_mlp_x3_split<CPV, 4, 2>(a, s); } \
+                           else { if (nw == 8) launch_mlp_x3_split<CPV, 8>(a, s); else launch_mlp_x3_split<CPV, 4>(a, s); } return 0;
+            ESCX_X3S_CASE(80) ESCX_X3S_CASE(96) ESCX_X3S_CASE(144)
+#undef ESCX_X3S_CASE
         }
         return ESCX_COMB_UNSUPPORTED;
     }
@@ -260,7 +269,8 @@ int mlp_x3(float* x, int M, int C, int Cp, const float* gamma, const float* beta
         }
     }
 #endif
-#define ESCX_X3_CASE(CPV) case CPV: if (nw == 8) launch_mlp_x3<CPV, 8>(a, s); else launch_mlp_x3<CPV, 4>(a, s); return 0;
+#define ESCX_X3_CASE(CPV) case CPV: if (nt == 2) { if (nw == 8) launch_mlp_x3<CPV, 8, 2>(a, s); else launch_mlp_x3<CPV, 4, 2>(a, s); } \
+                          else { if (nw == 8) launch_mlp_x3<CPV, 8>(a, s); else launch_mlp_x3<CPV, 4>(a, s); } return 0;
     switch (Cp) {
         ESCX_X3_CASE(48) ESCX_X3_CASE(80) ESCX_X3_CASE(96) ESCX_X3_CASE(144) ESCX_X3_CASE(192) ESCX_X3_CASE(384)
         default: return -1;

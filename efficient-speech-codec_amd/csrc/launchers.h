@@ -39,11 +39,12 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
 unsigned long long* debug_trace_buffer();      // device buffer set by escx_debug_mlp_trace (tuning builds: in-kernel phase stamps), or nullptr
 // Fused MLP on the bf16 matrix cores with fp32 operands split into three bf16 terms (fused_mlp_x3.h).  mlp_x3_pack builds the split weight image from the row-major
 // fp32 weights (w1 [hiddenP][Cp], w2 [Cp][hiddenP]); mlp_x3_bytes = its size.  -1: width not instantiated.
-size_t mlp_x3_bytes(int Cp, int hiddenP);
-int mlp_x3_pack(const float* w1, const float* w2, void* image, int Cp, int hiddenP, hipStream_t s);
+// nt: terms per operand - 3 = bf16 (exact split, six cross products), 2 = fp16 with per-matrix power-of-two scales (three cross products); image and kernel must agree
+size_t mlp_x3_bytes(int Cp, int hiddenP, int nt = 3);
+int mlp_x3_pack(const float* w1, const float* w2, void* image, int Cp, int hiddenP, hipStream_t s, int nt = 3);
 struct MlpSplit;
 int mlp_x3(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* b1, const float* b2, const void* image, int hiddenP, int nw, int* hs_io, float* partial,
-           hipStream_t s, const MlpSplit* split = nullptr);      // split: PatchSplit in the epilogue, split->wf = image of mlp_x3_split_pack
+           hipStream_t s, const MlpSplit* split = nullptr, int nt = 3);      // split: PatchSplit in the epilogue, split->wf = image of mlp_x3_split_pack
 size_t mlp_x3_split_bytes(int Cp, int Np);
 int mlp_x3_split_pack(const float* wf, void* image, int Cp, int Np, hipStream_t s);
 void rows_combine(float* dst, const float* src, const float* partial, const float* bias, long long M, int Cp, int n, hipStream_t s);
