@@ -43,11 +43,17 @@ FLOP_PER_CLIP = 56.75e9            # BASELINE.md section 3 (2xMAC over linear/bm
 PEAK_F32_MFMA = 157.3e12           # MI355X_MICROARCH.md chip table
 PEAK_HBM = 8.0e12
 FP32_MFMA_ONLY = all(os.environ.get(k) == "0" for k in ("ESCX_MLP_X3", "ESCX_ATTN_X3", "ESCX_ROWGEMM_X3"))
+def _terms(name):
+    return 3 if os.environ.get(name) == "3" else 2      # library default since round 5: two fp16 terms (csrc/split_terms.h); 3 = three bf16 terms, exact split
+MLP_TERMS, ATTN_TERMS, ROWGEMM_TERMS = _terms("ESCX_MLP_X3_TERMS"), _terms("ESCX_ATTN_X3_TERMS"), _terms("ESCX_ROWGEMM_X3_TERMS")
+MLP_XPROD = 3 if MLP_TERMS == 2 else 6            # matrix products issued per fp32 product in the split-operand MLP
 CODEC_DTYPE = ("f32" if FP32_MFMA_ONLY else
-               "f32 (fp32 storage and accumulation everywhere; the K = C contractions of the MLPs, of the attention's Q / K / V and output projections and of PatchMerge / PatchSplit "
-               "run on the bf16 MFMA with every fp32 operand split EXACTLY into three bf16 terms, six exact cross products each: fp32-grade error, measured at or below the "
-               "reference's own float32 error against float64 per layer (tests/test_gpu_parity.py::test_layer_accuracy_against_fp64); all-fp32-MFMA path: see fp32_mfma_only)")
-PEAK_BF16_MFMA = 2500e12          # dense bf16 (MI355X_MICROARCH.md): the fused MLPs issue six bf16 cross-term MFMAs per fp32 product (fused_mlp_x3.h)
+               "f32 (fp32 storage and accumulation everywhere; the K = C contractions of the MLPs, of the attention's Q / K / V projections and of PatchMerge / PatchSplit run on the "
+               "16-bit matrix cores with every fp32 operand split into terms - MLP " + str(MLP_TERMS) + ", attention " + str(ATTN_TERMS) + ", merge/split " + str(ROWGEMM_TERMS) +
+               " terms; 2 = two fp16 terms + power-of-two weight scales, three cross products (truncation 1e-7 of the result, below fp32 accumulation rounding); 3 = three bf16 terms, "
+               "exact split, six cross products - fp32-grade either way: per-layer error at or below the reference's own float32 error against float64 "
+               "(tests/test_gpu_parity.py::test_layer_accuracy_against_fp64); all-fp32-MFMA path: see fp32_mfma_only)")
+PEAK_BF16_MFMA = 2500e12          # dense bf16 = dense fp16 rate (MI355X_MICROARCH.md): the fused MLPs issue MLP_XPROD 16-bit MFMA products per fp32 product (fused_mlp_x3.h)
 
 
 def base_config():
@@ -166,7 +172,7 @@ def group_frac(r):
     """Fraction of the matrix-core peak of one launch group (record of escx_profile_report): the split-operand MLPs (mlp_x3*) issue six bf16 MFMA
     cross terms per fp32 product and are priced against the dense bf16 peak, everything else against the fp32 MFMA peak."""
     rate = r["flops"] / max(r["ms"], 1e-9) * 1e3                  # algorithmic FLOP/s
-    return 6.0 * rate / PEAK_BF16_MFMA if r["name"].startswith("mlp_x3") else rate / PEAK_F32_MFMA
+    return MLP_XPROD * rate / PEAK_BF16_MFMA if r["name"].startswith("mlp_x3") else rate / PEAK_F32_MFMA
 
 
 def kernel_symbol(group):
@@ -725,10 +731,10 @@ def main():
         if mfma_bound and dom["name"].startswith("mlp_x3"):
             # the split-operand MLP runs on the BF16 matrix cores: six bf16 cross-term MFMAs per fp32 product, so the instruction stream executes 6 x the
             # algorithmic FLOPs (K padding to 32 not counted) and is priced against the dense bf16 peak; the fp32-equivalent rate rides along
-            ach = 6.0 * flops_per_launch / avg_s
+            ach = MLP_XPROD * flops_per_launch / avg_s
             roofline = {"bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_BF16_MFMA, 4), "traffic": traffic,
-                        "peak_of": "dense bf16 MFMA (v_mfma_f32_16x16x32_bf16); achieved = 6 cross-term products x algorithmic FLOPs / launch time",
+                        "peak_of": f"dense 16-bit MFMA (v_mfma_f32_16x16x32_{'f16' if MLP_TERMS == 2 else 'bf16'}); achieved = {MLP_XPROD} cross-term products x algorithmic FLOPs / launch time",
                         "algorithmic_fp32_tflops": round(flops_per_launch / avg_s / 1e12, 3),
                         "algorithmic_frac_of_fp32_mfma_peak": round(flops_per_launch / avg_s / PEAK_F32_MFMA, 4)}
         elif mfma_bound:
@@ -770,7 +776,7 @@ def main():
                 iso_s = r["ms"] / r["calls"] * 1e-3
                 roofline["isolated_avg_us"] = round(iso_s * 1e6, 2)
                 x3 = dom["name"].startswith("mlp_x3")
-                roofline["isolated_frac"] = round(((6.0 * flops_per_launch / iso_s / PEAK_BF16_MFMA) if x3 else (flops_per_launch / iso_s / PEAK_F32_MFMA)) if mfma_bound
+                roofline["isolated_frac"] = round(((MLP_XPROD * flops_per_launch / iso_s / PEAK_BF16_MFMA) if x3 else (flops_per_launch / iso_s / PEAK_F32_MFMA)) if mfma_bound
                                                   else (bytes_per_launch / iso_s / PEAK_HBM), 4)
             if os.environ.get("ESCX_BENCH_BREAKDOWN"):
                 recs = sorted(iso.values(), key=lambda r: -r["ms"])      # the isolated timings are the readable ones

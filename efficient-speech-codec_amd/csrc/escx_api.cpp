@@ -1032,6 +1032,9 @@ extern "C" const char* escx_profile_report(escx_handle h) {
 // (48, 80, 96, 144, 192, 384).  ESCX_MLP_X3=<max padded width> restricts it, ESCX_MLP_X3=0 = the fp32-MFMA kernel (fused_mlp.h) everywhere - the
 // round-4 arithmetic, which bench.py also reports (`fp32_mfma_only`) and tests/test_gpu_parity.py keeps as an arm.
 // terms per operand of the split-operand MLP: 3 = bf16 (exact split), 2 = fp16 with power-of-two weight scales (fused_mlp_x3.h); ESCX_MLP_X3_TERMS=2|3
+// ... of the split-operand Q / K / V projections and PatchMerge / PatchSplit (ESCX_ATTN_X3_TERMS, ESCX_ROWGEMM_X3_TERMS = 2|3)
+static int attn_x3_terms() { static const int v = [] { const char* e = getenv("ESCX_ATTN_X3_TERMS"); const int t = e && e[0] ? atoi(e) : 2; return t == 3 ? 3 : 2; }(); return v; }
+static int rowgemm_x3_terms() { static const int v = [] { const char* e = getenv("ESCX_ROWGEMM_X3_TERMS"); const int t = e && e[0] ? atoi(e) : 2; return t == 3 ? 3 : 2; }(); return v; }
 static int mlp_x3_terms() { static const int v = [] { const char* e = getenv("ESCX_MLP_X3_TERMS"); const int t = e && e[0] ? atoi(e) : 2; return t == 3 ? 3 : 2; }(); return v; }
 static int mlp_x3_maxcp() { static const int v = [] { const char* e = getenv("ESCX_MLP_X3"); return e && e[0] ? atoi(e) : 384; }(); return v; }
 
@@ -1141,7 +1144,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             if (!launched)
             PROF("attn_fused" + tag, 2 * proj_rows * dC * 4 * dC + 4 * dMs * 16 * dC, 2 * dM * dC * f4,
                  frc = attn_fused(src, cur, L.Cp, L.C, L.attn_mode, L.n_groups, bw.ln1_g, bw.ln1_b, bw.waf, bw.baf, bw.bias_tab_f, bw.bproj,
-                                  map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, &gs, h->hid, M, st, nullptr, nullptr, (nw > 0 || L.Cp == 384) ? bw.x3a : nullptr, bw.x3a_pairs ? 1 : 0));      // C = 384: the split stream exists for the packed (nw < 0) kernel only
+                                  map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, &gs, h->hid, M, st, nullptr, nullptr, (nw > 0 || L.Cp == 384) ? bw.x3a : nullptr, bw.x3a_pairs ? 1 : (attn_x3_terms() == 2 ? 2 : 0)));      // C = 384: the split stream exists for the packed (nw < 0) kernel only
             attn_done = (frc == 0);
             if (attn_done && gs > 1)
                 PROF("attn_combine" + tag, 0, (gs + 2) * dM * L.Cp * f4, rows_combine(cur, src, h->hid, bw.bproj, M, L.Cp, gs, st));
@@ -1230,7 +1233,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         flush_pending();
         if (h->use_fused && mrc != 0)
             PROF("merge_fused" + (h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string()), 2.0 * B * H2 * W * 2 * L.C * L.Cout, ((double)M * L.C + (double)B * H2 * W * L.Cout) * 4,
-                 mrc = rowgemm_fused(2, cur, y, L.sub_g, L.sub_b, L.sub_wf, map, B * H2 * W, H2 * W, tokens, L.C, L.Cp, L.CoutP, 0, 0, 0, 0, st, nullptr, L.sub_x3));
+                 mrc = rowgemm_fused(2, cur, y, L.sub_g, L.sub_b, L.sub_wf, map, B * H2 * W, H2 * W, tokens, L.C, L.Cp, L.CoutP, 0, 0, 0, 0, st, nullptr, L.sub_x3, rowgemm_x3_terms()));
         if (mrc != 0) {
         PROF("merge_ln", 0, 2.0 * M * L.C * 4,
              ln_rows(2, cur, h->xn, L.sub_g, L.sub_b, map, H2 * W, tokens, B * H2 * W, L.C, L.Cp, st));
@@ -1249,7 +1252,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         flush_pending();
         if (h->use_fused && src2 != 0)
             PROF("split_fused" + (h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string()), 2.0 * M * L.C * 2 * L.Cout, (double)M * (L.C + 2 * L.Cout) * 4,
-                 src2 = rowgemm_fused(1, cur, y, L.sub_g, L.sub_b, L.sub_wf, nullptr, M, tokens, tokens, L.C, L.Cp, 2 * L.CoutP, 1, H, W, L.CoutP, st, nullptr, L.sub_x3));
+                 src2 = rowgemm_fused(1, cur, y, L.sub_g, L.sub_b, L.sub_wf, nullptr, M, tokens, tokens, L.C, L.Cp, 2 * L.CoutP, 1, H, W, L.CoutP, st, nullptr, L.sub_x3, rowgemm_x3_terms()));
         if (src2 != 0) {
         PROF("split_ln", 0, 2.0 * M * L.C * 4,
              ln_rows(0, cur, h->xn, L.sub_g, L.sub_b, nullptr, tokens, tokens, M, L.C, L.Cp, st));
@@ -1337,7 +1340,7 @@ static int ensure_pvq_tables(escx_handle_s* h, hipStream_t st) {
             // matrix time saved, and at C = 192 the kernel drops to one wave per SIMD (profiles/r5_attn_ab.txt)
             static const bool pairs_on = [] { const char* e = ESCX_TUNE_ENV("ESCX_ATTN_X3_PAIRS"); return e && e[0] == '1'; }();
             bw.x3a_pairs = pairs_on && L.attn_mode != 2 && L.Cp != 48 && L.n_groups % 2 == 0 && (L.n_groups % 3 != 0 || (L.n_groups / 3) % 2 == 0);
-            attn_x3_pack(bw.waf, bw.x3a, L.Cp, L.attn_mode, L.n_groups, st, bw.x3a_pairs ? 1 : 0);
+            attn_x3_pack(bw.waf, bw.x3a, L.Cp, L.attn_mode, L.n_groups, st, bw.x3a_pairs ? 1 : (attn_x3_terms() == 2 ? 2 : 0));
         }
     // the split weight streams of PatchMerge / PatchSplit (fused_rowgemm.h rowgemm_x3_kernel; ESCX_ROWGEMM_X3=0: fp32 MFMA)
     static const bool rg_x3 = [] { const char* e = getenv("ESCX_ROWGEMM_X3"); return !(e && e[0] == '0'); }();
@@ -1346,7 +1349,7 @@ static int ensure_pvq_tables(escx_handle_s* h, hipStream_t st) {
         const bool want = rg_x3 && L.scale != 0 && L.sub_wf && (KP == 80 || KP == 96 || KP == 144 || KP == 160 || KP == 192 || KP == 288 || KP == 384);
         if (!want) { if (L.sub_x3) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(L.sub_x3); L.sub_x3 = nullptr; } continue; }
         if (!L.sub_x3) ESCX_HIP(hipMalloc(&L.sub_x3, rowgemm_x3_bytes(KP, Np)));
-        rowgemm_x3_pack(L.sub_wf, L.sub_x3, KP, Np, st);
+        rowgemm_x3_pack(L.sub_wf, L.sub_x3, KP, Np, st, rowgemm_x3_terms());
         if (L.scale == 2 && (L.Cp == 80 || L.Cp == 96 || L.Cp == 144) && L.Cp <= x3_max) {       // PatchSplit folded into the split-operand MLP's epilogue
             if (!L.sub_x3s) ESCX_HIP(hipMalloc(&L.sub_x3s, mlp_x3_split_bytes(L.Cp, Np)));
             mlp_x3_split_pack(L.sub_wf, L.sub_x3s, L.Cp, Np, st);

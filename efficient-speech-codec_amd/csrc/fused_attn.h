@@ -24,6 +24,7 @@
 #include <type_traits>
 #include "gemm_engine.h"
 #include "gemm_bf16.h"
+#include "split_terms.h"
 
 namespace escx {
 
@@ -82,7 +83,9 @@ __global__ __launch_bounds__(256) void attn_x3p_pack_kernel(const f32x4* __restr
     dst[(fslot * 3 + 0) * 64 + lane] = t0; dst[(fslot * 3 + 1) * 64 + lane] = t1; dst[(fslot * 3 + 2) * 64 + lane] = t2;
 }
 // builds the X3 stream from the fp32 fragment stream (BlockW::waf): one thread per (group, tile, K-step or projection fragment, lane)
-__global__ __launch_bounds__(256) void attn_x3_pack_kernel(const f32x4* __restrict__ waf, bf16x8* __restrict__ out, int n_tiles, int TPG, int KK, int KS, int TF, unsigned proj_mask) {
+// NT = 2 (split_terms.h): two fp16 terms per weight, scaled by the power of two of the block's max |w| - the stream then ends with two 16-byte slots,
+// [0] bits of max |w| (absmax_bits_kernel over the fp32 fragment stream, before this kernel), [1] {2^-k, 2^k, 0, 0} written here.
+__global__ __launch_bounds__(256) void attn_x3_pack_kernel(const f32x4* __restrict__ waf, bf16x8* __restrict__ out, int n_tiles, int TPG, int KK, int KS, int TF, unsigned proj_mask, int NT = 3) {
     const int per_tile = (KS > KK ? KS : KK) * 64;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)n_tiles * per_tile) return;
@@ -101,9 +104,18 @@ __global__ __launch_bounds__(256) void attn_x3_pack_kernel(const f32x4* __restri
         const int kk = 2 * f + (g >> 1), lgs = 2 * (g & 1) + (e >> 2);
         v[e] = kk < KK ? src[kk * 64 + 16 * lgs + l15][e & 3] : 0.f;
     }
-    bf16x8 t0, t1, t2;
-    attn_split3(v, t0, t1, t2);
-    dst[(f * 3 + 0) * 64 + lane] = t0; dst[(f * 3 + 1) * 64 + lane] = t1; dst[(f * 3 + 2) * 64 + lane] = t2;
+    if (NT == 3) {
+        bf16x8 t0, t1, t2;
+        attn_split3(v, t0, t1, t2);
+        dst[(f * 3 + 0) * 64 + lane] = t0; dst[(f * 3 + 1) * 64 + lane] = t1; dst[(f * 3 + 2) * 64 + lane] = t2;
+    } else {
+        bf16x8* tail = out + (size_t)n_tiles * TF * 64;
+        const float sc = x2_scale(*reinterpret_cast<const unsigned*>(tail));
+        bf16x8 t[2];
+        split_terms<2>(v, t, sc);
+        dst[(f * 2 + 0) * 64 + lane] = t[0]; dst[(f * 2 + 1) * 64 + lane] = t[1];
+        if (idx == 0) { float* o = reinterpret_cast<float*>(tail + 1); o[0] = 1.0f / sc; o[1] = sc; o[2] = 0.f; o[3] = 0.f; }
+    }
 }
 
 struct AttnArgs {
@@ -132,6 +144,7 @@ struct AttnArgs {
     float* tape_xn; float* tape_qkv; float* tape_o; int ldq, ldo, hdp, nH;
     const void* x3_wf;          // X3 instantiations: the split weight stream (attn_x3_pack_kernel), else unused
     int x3_pairs;               // the stream is in pair order [Q0 K0 V0 Q1 K1 V1 P_lo P_hi] (attn_x3p_pack_kernel): X3P instantiations
+    const float* x3_scale;      // NT = 2 instantiations: {2^-k, 2^k} of the block's weight stream (its last 16 bytes)
 };
 
 // One 16-byte piece of a block-input row: plain, or combined on the fly from the hidden-split MLP's slabs (see AttnArgs).
@@ -193,9 +206,10 @@ template <int CP, int TMW, bool X3> constexpr int attn_min_waves_x() { return !X
 // consecutive groups form one 32-deep step: the two O^T accumulator tiles of a lane are the 8 k-slots (as the two fc1 tiles are in fused_mlp_x3.h).  Stream per PAIR of groups:
 // [Q0 K0 V0 Q1 K1 V1 P_lo P_hi] - the same eight tiles as two groups of [Q K V P]; P_lo / P_hi hold, per output tile of the first / second half, the three split fragments
 // -> lane (channel, g): term i of Wp[channel][dims of group 0: 4 g + e | group 1: 4 g + e - 4].
-template <int CP, int MODE, int UT, int TMW, int NW, bool COMB = false, bool TAPE = false, bool X3 = false, bool X3P = false>
+template <int CP, int MODE, int UT, int TMW, int NW, bool COMB = false, bool TAPE = false, bool X3 = false, bool X3P = false, int NT = 3>
 __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void attn_fused_kernel(AttnArgs a) {
     static_assert(!X3 || (!COMB && !TAPE), "the split-operand form exists for the plain inference instantiations");
+    static_assert(NT == 3 || (NT == 2 && X3 && !X3P), "two fp16 terms: the split-operand instantiations without the pair projection");
     static_assert(!X3P || (X3 && MODE != 2), "pair projection: split-operand instantiations with one tile per head group");
 #ifdef ESCX_ATTN_PRIO
     __builtin_amdgcn_s_setprio(ESCX_ATTN_PRIO);     // tuning builds: static wave priority against co-running launches of the other batch part
@@ -242,7 +256,9 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void at
     // ---- 1. gather + LayerNorm in registers ------------------------------------------------------
     const int nW = a.nWh * a.nWw;
     f32x4 xf[X3 ? 1 : TMW][X3 ? 1 : KK];
-    bf16x8 xs[X3 ? TMW : 1][3][X3 ? KS : 1];                 // X3: LayerNorm output split into three bf16 terms, lane (slot l15, group lg) holds channels 32 s + 8 lg .. + 7
+    bf16x8 xs[X3 ? TMW : 1][NT][X3 ? KS : 1];                // X3: LayerNorm output split into NT terms, lane (slot l15, group lg) holds channels 32 s + 8 lg .. + 7
+    float x2_dn = 1.f, x2_up = 1.f;            // NT = 2: 2^-k, 2^k of the block's scaled weights
+    if constexpr (NT == 2) { x2_dn = a.x3_scale[0]; x2_up = a.x3_scale[1]; }
     int tok[TMW];                               // this lane's token row (element offset / CP), or -1
     bool lastH[TMW], lastW[TMW];
 #pragma unroll
@@ -289,7 +305,10 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void at
                     xn[e] = tok[t] >= 0 ? (xv[ks][e] - mean) * rstd * g0v[e] + b0v[e] : 0.f;            // padded slots become zero rows AFTER the norm
                     xn[4 + e] = tok[t] >= 0 ? (xv[ks][4 + e] - mean) * rstd * g1v[e] + b1v[e] : 0.f;
                 }
-                attn_split3(xn, xs[t][0][ks], xs[t][1][ks], xs[t][2][ks]);
+                bf16x8 tt[NT];
+                split_terms<NT>(xn, tt);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) xs[t][i][ks] = tt[i];
             }
         }
         if constexpr (!X3) {
@@ -414,24 +433,24 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void at
         const bf16x8* tb = reinterpret_cast<const bf16x8*>(wb) + (size_t)(((tile - 1) % UT) * TF) * 64;
         f32x4 o2[TMW];
 #pragma unroll
-        for (int t = 0; t < TMW; ++t) { out[t] = init; o2[t] = zero4(); }
+        for (int t = 0; t < TMW; ++t) { out[t] = NT == 2 ? init * x2_up : init; o2[t] = zero4(); }       // NT = 2: the sums carry 2^k, so does the bias (exact)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 w[3];
+            bf16x8 w[NT];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) w[i] = tb[(ks * 3 + i) * 64];
+            for (int i = 0; i < NT; ++i) w[i] = tb[(ks * NT + i) * 64];
             dma_pinned();
             int n = 0;
 #define ESCX_ATTN_X3_STEP(I, J) \
             _Pragma("unroll") for (int t = 0; t < TMW; ++t) { \
                 f32x4& d = (n & 1) ? o2[t] : out[t]; \
-                d = x_rows ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(xs[t][J][ks], w[I], d, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[I], xs[t][J][ks], d, 0, 0, 0); \
+                d = x_rows ? mma_x<NT>(xs[t][J][ks], w[I], d) : mma_x<NT>(w[I], xs[t][J][ks], d); \
             } ++n;
-            ESCX_ATTN_X3_TERMS(ESCX_ATTN_X3_STEP)
+            if constexpr (NT == 3) { ESCX_ATTN_X3_TERMS(ESCX_ATTN_X3_STEP) } else { ESCX_X2_TERMS(ESCX_ATTN_X3_STEP) }
 #undef ESCX_ATTN_X3_STEP
         }
 #pragma unroll
-        for (int t = 0; t < TMW; ++t) out[t] += o2[t];
+        for (int t = 0; t < TMW; ++t) { out[t] += o2[t]; if constexpr (NT == 2) out[t] *= x2_dn; }
     };
     // tile GEMM with the weight tile as the row operand: out[t] = W_tile . x^T  -> lane (token l15, rows 4lg + r)
     auto gemm_w_rows = [&](f32x4* out, f32x4 init) {       // init: the tile's bias rides in the accumulator
@@ -735,9 +754,10 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void at
 // key / value operands are rebuilt in registers: real slots come from the packed tile (a half-row swap for K, a
 // lane-group swap for V^T), padded slots are the bias.  Requires H == 2, W % 4 == 0, one head per tile (MODE 0).
 // ------------------------------------------------------------------------------------------------
-template <int CP, int UT, int NW, bool COMB = false, bool X3 = false, bool X3P = false>
+template <int CP, int UT, int NW, bool COMB = false, bool X3 = false, bool X3P = false, int NT = 3>
 __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, 1, X3>())) void attn_packed_kernel(AttnArgs a) {
     static_assert(!X3 || !COMB, "the split-operand form exists for the plain instantiation");
+    static_assert(NT == 3 || (NT == 2 && X3 && !X3P), "two fp16 terms: the split-operand instantiation without the pair projection");
     static_assert(!X3P || X3, "pair projection: split-operand instantiation");
 #ifdef ESCX_ATTN_PRIO
     __builtin_amdgcn_s_setprio(ESCX_ATTN_PRIO);
@@ -790,7 +810,9 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, 1, X3>())) void attn
         if (tk >= 0) tok = b * a.tokens + tk;
     }
     f32x4 xf[X3 ? 1 : KK];
-    bf16x8 xs[3][X3 ? KS : 1];
+    bf16x8 xs[NT][X3 ? KS : 1];
+    float x2_dn = 1.f, x2_up = 1.f;
+    if constexpr (NT == 2) { x2_dn = a.x3_scale[0]; x2_up = a.x3_scale[1]; }
     if constexpr (X3) {
         const float* xrow = a.src + (size_t)(tok < 0 ? 0 : tok) * CP;
         float xv[KS][8];
@@ -824,7 +846,10 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, 1, X3>())) void attn
                 xn[e] = tok >= 0 ? (xv[ks][e] - mean) * rstd * g0v[e] + b0v[e] : 0.f;
                 xn[4 + e] = tok >= 0 ? (xv[ks][4 + e] - mean) * rstd * g1v[e] + b1v[e] : 0.f;
             }
-            attn_split3(xn, xs[0][ks], xs[1][ks], xs[2][ks]);
+            bf16x8 tt[NT];
+            split_terms<NT>(xn, tt);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) xs[i][ks] = tt[i];
         }
     } else {
         const size_t xoff = (size_t)(tok < 0 ? 0 : tok) * CP + 4 * lg;
@@ -899,18 +924,21 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, 1, X3>())) void attn
     auto begin_tile = [&]() { if (tile % UT == 0) next_stage(); ++tile; };
     auto tile_gemm = [&](bool x_rows, f32x4 init) -> f32x4 {       // init: the tile's bias rides in the accumulator
         f32x4 o1 = init, o2 = zero4();
-        if constexpr (X3) {          // Q / K / V on the bf16 MFMA: six cross terms of the three-term split, smallest first, two accumulator chains
+        if constexpr (X3) {          // Q / K / V on the bf16 / fp16 MFMA: the cross terms of the split (split_terms.h), smallest first, two accumulator chains
             const bf16x8* tb = reinterpret_cast<const bf16x8*>(wb) + (size_t)(((tile - 1) % UT) * TF) * 64;
+            if constexpr (NT == 2) o1 *= x2_up;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                bf16x8 w[3];
+                bf16x8 w[NT];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) w[i] = tb[(ks * 3 + i) * 64];
+                for (int i = 0; i < NT; ++i) w[i] = tb[(ks * NT + i) * 64];
                 dma_pinned();
-#define ESCX_PK_X3(I, J, D) D = x_rows ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(xs[J][ks], w[I], D, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[I], xs[J][ks], D, 0, 0, 0);
-                ESCX_PK_X3(0, 2, o1) ESCX_PK_X3(2, 0, o2) ESCX_PK_X3(1, 1, o1) ESCX_PK_X3(0, 1, o2) ESCX_PK_X3(1, 0, o1) ESCX_PK_X3(0, 0, o2)
+#define ESCX_PK_X3(I, J, D) D = x_rows ? mma_x<NT>(xs[J][ks], w[I], D) : mma_x<NT>(w[I], xs[J][ks], D);
+                if constexpr (NT == 3) { ESCX_PK_X3(0, 2, o1) ESCX_PK_X3(2, 0, o2) ESCX_PK_X3(1, 1, o1) ESCX_PK_X3(0, 1, o2) ESCX_PK_X3(1, 0, o1) ESCX_PK_X3(0, 0, o2) }
+                else { ESCX_PK_X3(0, 1, o1) ESCX_PK_X3(1, 0, o2) ESCX_PK_X3(0, 0, o1) }
 #undef ESCX_PK_X3
             }
+            if constexpr (NT == 2) return (o1 + o2) * x2_dn;
             return o1 + o2;
         }
 #pragma unroll

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include "fused_mlp.h"
 #include "gemm_bf16.h"
+#include "split_terms.h"
 
 namespace escx {
 
@@ -34,12 +35,7 @@ __device__ __forceinline__ void split3_bf16(const float (&v)[N], __bf16 (&s0)[N]
 }
 __device__ __forceinline__ bf16x8 pack8(const __bf16 (&s)[8]) { bf16x8 r; for (int e = 0; e < 8; ++e) r[e] = s[e]; return r; }
 
-// NT = 2 (round 5, second form): TWO fp16 terms per operand, a ~ a1 + a2 with a1 = fp16(a), a2 = fp16(a - a1) (11-bit significands, round to nearest: |a - a1 - a2| <= 2^-22 |a|,
-// typically 2^-24), and THREE cross products a1b1 + a1b2 + a2b1 on v_mfma_f32_16x16x32_f16 - half the matrix instructions and two thirds of the fragment stream of the
-// three-term bf16 form.  Not exact: the truncation measures 9.5e-8 of the mean result magnitude (numpy, exact accumulation) against 1.6e-7 ... 4.5e-7 of fp32 accumulation
-// rounding for K = 48 ... 1536, i.e. the fp32 error budget grows by 5-16 %.  fp16 has a 5-bit exponent: the weights are scaled by a power of two per matrix at pack time
-// (max |w| 2^k in [2^13, 2^14): the low term of every weight stays a normal number) and the accumulators are scaled back exactly (powers of two commute with fp32 rounding).
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+// NT = 2: two fp16 terms per operand and three cross products (split_terms.h).
 template <int N>
 __device__ __forceinline__ void split2_f16(const float (&v)[N], float scale, _Float16 (&s0)[N], _Float16 (&s1)[N]) {
 #pragma clang fp contract(off)
@@ -51,31 +47,9 @@ __device__ __forceinline__ void split2_f16(const float (&v)[N], float scale, _Fl
     }
 }
 __device__ __forceinline__ bf16x8 pack8h(const _Float16 (&s)[8]) { half8 r; for (int e = 0; e < 8; ++e) r[e] = s[e]; return __builtin_bit_cast(bf16x8, r); }
-// one 16 x 16 x 32 step on fragments held as 16 raw bytes per lane
-template <int NT>
-__device__ __forceinline__ f32x4 mma_x(bf16x8 w, bf16x8 x, f32x4 c) {
-    if constexpr (NT == 3) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, w), __builtin_bit_cast(half8, x), c, 0, 0, 0);
-}
 // rows of activations -> NT term fragments
 template <int NT>
-__device__ __forceinline__ void split_rows(const float (&v)[8], bf16x8 (&out)[NT]) {
-    if constexpr (NT == 3) {
-        __bf16 s0[8], s1[8], s2[8];
-        split3_bf16(v, s0, s1, s2);
-        out[0] = pack8(s0); out[1] = pack8(s1); out[2] = pack8(s2);
-    } else {
-        _Float16 s0[8], s1[8];
-        split2_f16(v, 1.0f, s0, s1);
-        out[0] = pack8h(s0); out[1] = pack8h(s1);
-    }
-}
-// power of two that brings max |w| into [2^13, 2^14) (1 for an all-zero matrix): bits of max |w| -> scale
-__device__ __forceinline__ float x2_scale(unsigned absmax_bits) {
-    const int ex = (int)((absmax_bits >> 23) & 0xff);       // biased exponent of max |w|
-    if (ex == 0 || ex == 0xff) return 1.0f;
-    return __uint_as_float((unsigned)(127 + 13 - (ex - 127)) << 23);
-}
+__device__ __forceinline__ void split_rows(const float (&v)[8], bf16x8 (&out)[NT]) { split_terms<NT>(v, out); }
 
 constexpr int mlp_x3_ks(int CP) { return (CP + 31) / 32; }
 constexpr int mlp_x3_frags(int CP, int NT = 3) { return 2 * NT * mlp_x3_ks(CP) + NT * (CP / 16); }       // 1 KiB fragments per pair of hidden tiles: fc1 (KS steps x 2 tiles x NT terms), fc2 (KK tiles x NT terms)
@@ -95,12 +69,6 @@ constexpr int mlp_x3_stage_frags(int CP, int NT = 3) {
 //   fc2 fragment f = 6 KS + o * 3 + i              -> lane (c, g) holds term i of W2[16 o + c][unit(g, e)], unit = 16 (2p) + 4 g + e for e < 4, 16 (2p + 1) + 4 g + e - 4 otherwise
 // (the k-slot <-> hidden unit map the kernel's two fc1 accumulator tiles dictate).  One thread per (pair, fragment triple, lane).
 // NT = 2: the image ends with two 16-byte slots - [0] bits of max |w1|, max |w2| (absmax_bits_kernel, before this kernel), [1] {2^-k1, 2^-k2, 2^k1, 2^k2} written here.
-__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ w, long long n, unsigned* __restrict__ out) {
-    unsigned m = 0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = max(m, __float_as_uint(fabsf(w[i])));
-    for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, m);       // non-negative floats order like their bit patterns; the maximum does not depend on the order of the updates
-}
 __global__ __launch_bounds__(256) void mlp_x3_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, bf16x8* __restrict__ out, int Cp, int HP, int KS, int KK, int NT) {
     const int CH = 2 * NT * KS + NT * KK, triples = 2 * KS + KK;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -168,8 +136,7 @@ __global__ __launch_bounds__(256) void mlp_x3_split_pack_kernel(const f32x4* __r
 #else
 #define ESCX_X3_TERMS(M) M(0, 2) M(2, 0) M(1, 1) M(0, 1) M(1, 0) M(0, 0)
 #endif
-// the three cross terms of the two-term fp16 form, smallest first
-#define ESCX_X2_TERMS(M) M(0, 1) M(1, 0) M(0, 0)
+
 
 template <int CP> constexpr int mlp_x3_min_waves() { return CP <= 96 ? 4 : (CP <= 192 ? 2 : 1); }
 

@@ -31,6 +31,7 @@ struct RowGemmArgs {
     // combine-on-load (COMB instantiations): x is still split over the comb_n fc2 slabs of the last block's hidden-split MLP (see AttnArgs in fused_attn.h)
     const float* comb_partial; const float* comb_bias; long long comb_stride; int comb_n;
     const void* x3_wf;          // rowgemm_x3_kernel: split weight stream [output tile][3 KS fragments] (attn_x3_pack_kernel), else unused
+    const float* x3_scale;      // NT = 2: {2^-k, 2^k} of the scaled two-term stream (its last 16 bytes)
 };
 
 template <int KP, int SEGS, int TM, int NW, int UT, bool COMB = false>
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(64 * NW) void rowgemm_fused_kernel(RowGemmArgs a) {
 // LayerNorm, same stores as rowgemm_fused_kernel; the weight stream is [output tile][3 KS fragments] (attn_x3_pack_kernel with no projection tiles,
 // built from Layer::sub_wf), UT tiles per LDS stage.
 // ------------------------------------------------------------------------------------------------
-template <int KP, int SEGS, int TM, int NW, int UT>
+template <int KP, int SEGS, int TM, int NW, int UT, int NT = 3>      // NT = 2: two fp16 terms, three cross products (split_terms.h); the stream keeps its 3 KS fragment slots per tile
 __global__ __launch_bounds__(64 * NW) void rowgemm_x3_kernel(RowGemmArgs a) {
     ESCX_SET_PRIO_SMALL();
     constexpr int KS = (KP + 31) / 32, TF = 3 * KS, SEGK = KP / SEGS;
@@ -182,7 +183,9 @@ __global__ __launch_bounds__(64 * NW) void rowgemm_x3_kernel(RowGemmArgs a) {
     };
     issue(0, 0);
 
-    bf16x8 xs[TM][3][KS];
+    bf16x8 xs[TM][NT][KS];
+    float x2_dn = 1.f;
+    if constexpr (NT == 2) x2_dn = a.x3_scale[0];
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         const int row = m0 + t * 16 + l15;
@@ -227,7 +230,10 @@ __global__ __launch_bounds__(64 * NW) void rowgemm_x3_kernel(RowGemmArgs a) {
                 xn[e] = (xv[ks][e] - mean) * rstd * g0[e] + b0[e];             // gamma = beta = 0 in the pads
                 xn[4 + e] = (xv[ks][4 + e] - mean) * rstd * g1[e] + b1[e];
             }
-            attn_split3(xn, xs[t][0][ks], xs[t][1][ks], xs[t][2][ks]);
+            bf16x8 tt[NT];
+            split_terms<NT>(xn, tt);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) xs[t][i][ks] = tt[i];
         }
     }
 
@@ -256,18 +262,20 @@ __global__ __launch_bounds__(64 * NW) void rowgemm_x3_kernel(RowGemmArgs a) {
             for (int t = 0; t < TM; ++t) { acc[t] = zero4(); acc2[t] = zero4(); }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                bf16x8 w[3];
+                bf16x8 w[NT];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) w[i] = wb[(ks * 3 + i) * 64];
-#define ESCX_RG_X3(I, J, D) _Pragma("unroll") for (int t = 0; t < TM; ++t) D[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[I], xs[t][J][ks], D[t], 0, 0, 0);
-                ESCX_RG_X3(0, 2, acc) ESCX_RG_X3(2, 0, acc2) ESCX_RG_X3(1, 1, acc) ESCX_RG_X3(0, 1, acc2) ESCX_RG_X3(1, 0, acc) ESCX_RG_X3(0, 0, acc2)
+                for (int i = 0; i < NT; ++i) w[i] = wb[(ks * NT + i) * 64];
+#define ESCX_RG_X3(I, J, D) _Pragma("unroll") for (int t = 0; t < TM; ++t) D[t] = mma_x<NT>(w[I], xs[t][J][ks], D[t]);
+                if constexpr (NT == 3) { ESCX_RG_X3(0, 2, acc) ESCX_RG_X3(2, 0, acc2) ESCX_RG_X3(1, 1, acc) ESCX_RG_X3(0, 1, acc2) ESCX_RG_X3(1, 0, acc) ESCX_RG_X3(0, 0, acc2) }
+                else { ESCX_RG_X3(0, 1, acc) ESCX_RG_X3(1, 0, acc2) ESCX_RG_X3(0, 0, acc) }
 #undef ESCX_RG_X3
             }
             const int n = 16 * nt + 4 * lg;
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
                 if (m0 + t * 16 + l15 >= a.M) continue;
-                const f32x4 v = acc[t] + acc2[t];
+                f32x4 v = acc[t] + acc2[t];
+                if constexpr (NT == 2) v *= x2_dn;
                 if (a.split) { const int s2 = n / a.C2p; st4(a.out + obase[t][s2] + (n - s2 * a.C2p), v); }
                 else st4(a.out + obase[t][0] + n, v);
             }

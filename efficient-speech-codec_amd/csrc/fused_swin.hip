@@ -369,14 +369,20 @@ static int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
             constexpr int KSx = (KP + 31) / 32, TFx = 3 * KSx, UTx = 36 / TFx >= 4 ? 4 : (36 / TFx >= 2 ? 2 : 1);
             constexpr int TMx = KP <= 96 ? 2 : 1, NWx = 4;           // one row tile per wave above K = 96: the three-term operand costs 1.5x the registers of the fp32 one
             auto kern = rowgemm_x3_kernel<KP, SEGS, TMx, NWx, UTx>;
+            auto kern2 = rowgemm_x3_kernel<KP, SEGS, TMx, NWx, UTx, 2>;
             constexpr int lds = 2 * UTx * TFx * 1024;
             if constexpr (lds > 48 * 1024) {
                 static std::atomic<unsigned> done{0};
                 int dev = 0; (void)hipGetDevice(&dev);
                 const unsigned bit = 1u << (dev & 31);
-                if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
+                if (!(done.load(std::memory_order_relaxed) & bit)) {
+                    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    (void)hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    done.fetch_or(bit, std::memory_order_relaxed);
+                }
             }
-            hipLaunchKernelGGL(kern, dim3((a.M + 16 * TMx * NWx - 1) / (16 * TMx * NWx), 1), dim3(64 * NWx), lds, s, a);
+            if (a.x3_scale) hipLaunchKernelGGL(kern2, dim3((a.M + 16 * TMx * NWx - 1) / (16 * TMx * NWx), 1), dim3(64 * NWx), lds, s, a);
+            else hipLaunchKernelGGL(kern, dim3((a.M + 16 * TMx * NWx - 1) / (16 * TMx * NWx), 1), dim3(64 * NWx), lds, s, a);
             return 0;
         }
     }
@@ -419,22 +425,30 @@ static int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
     return 0;
 }
 
-size_t rowgemm_x3_bytes(int KP, int Np) { return (size_t)(Np / 16) * 3 * ((KP + 31) / 32) * 1024; }
-int rowgemm_x3_pack(const float* wf, void* image, int KP, int Np, hipStream_t s) {
+// 32-byte trailer: the two-term (nt = 2) form keeps max |w| and its power-of-two scales there (fused_attn.h attn_x3_pack_kernel)
+size_t rowgemm_x3_bytes(int KP, int Np) { return (size_t)(Np / 16) * 3 * ((KP + 31) / 32) * 1024 + 32; }
+int rowgemm_x3_pack(const float* wf, void* image, int KP, int Np, hipStream_t s, int nt) {
     const int KK = KP / 16, KS = (KP + 31) / 32, NT = Np / 16;
     const long long total = (long long)NT * (KS > KK ? KS : KK) * 64;
+    if (nt == 2) {
+        unsigned* mx = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(image) + rowgemm_x3_bytes(KP, Np) - 32);
+        (void)hipMemsetAsync(mx, 0, 16, s);
+        const long long n = (long long)NT * KK * 64 * 4;
+        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, wf, n, mx);
+    }
     hipLaunchKernelGGL(attn_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(wf), reinterpret_cast<bf16x8*>(image),
-                       NT, 1, KK, KS, 3 * KS, 0u);
+                       NT, 1, KK, KS, 3 * KS, 0u, nt == 2 ? 2 : 3);
     return 0;
 }
 
 int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, const float* beta, const float* wf, const int* map, int M,
                   int rows_per_clip, int src_rows_per_clip, int C, int Cp, int Np, int split, int H, int W, int C2p, hipStream_t s,
-                  const CombineOnLoad* comb, const void* x3_wf) {
+                  const CombineOnLoad* comb, const void* x3_wf, int x3_nt) {
+    const int KP = segs * Cp;
     RowGemmArgs a{x, out, gamma, beta, reinterpret_cast<const f32x4*>(wf), map, M, rows_per_clip, src_rows_per_clip, C, Cp, Np / 16,
                   split, H, W, C2p, 1e-5f, Np / 16, comb ? comb->partial : nullptr, comb ? comb->bias : nullptr, comb ? comb->stride : 0, comb ? comb->n : 0,
-                  comb ? nullptr : x3_wf};
-    const int KP = segs * Cp;
+                  comb ? nullptr : x3_wf,
+                  (!comb && x3_wf && x3_nt == 2) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(x3_wf) + rowgemm_x3_bytes(KP, Np) - 16) : nullptr};
     if (segs == 1) {
         switch (KP) {
             case 16: return launch_rowgemm<16, 1>(a, s);
@@ -516,14 +530,20 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
 #endif
         if (a.x3_wf && !a.x3_pairs) {
             auto kern = attn_fused_kernel<CP, MODE, UT, TMW, NW, false, false, true>;
+            auto kern2 = attn_fused_kernel<CP, MODE, UT, TMW, NW, false, false, true, false, 2>;        // two fp16 terms (split_terms.h)
             constexpr int lds = 2 * UT * attn_x3_tf(CP) * 1024;
             if constexpr (lds > 48 * 1024) {
                 static std::atomic<unsigned> done{0};
                 int dev = 0; (void)hipGetDevice(&dev);
                 const unsigned bit = 1u << (dev & 31);
-                if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
+                if (!(done.load(std::memory_order_relaxed) & bit)) {
+                    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    (void)hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    done.fetch_or(bit, std::memory_order_relaxed);
+                }
             }
-            hipLaunchKernelGGL(kern, dim3(((a.n_windows + per_block - 1) / per_block) * gs), dim3(64 * NW), lds, s, a);
+            if (a.x3_scale) hipLaunchKernelGGL(kern2, dim3(((a.n_windows + per_block - 1) / per_block) * gs), dim3(64 * NW), lds, s, a);
+            else hipLaunchKernelGGL(kern, dim3(((a.n_windows + per_block - 1) / per_block) * gs), dim3(64 * NW), lds, s, a);
             return 0;
         }
     }
@@ -577,12 +597,18 @@ static int launch_attn_packed(const AttnArgs& a, hipStream_t s) {
 #endif
         if (a.x3_wf && !a.x3_pairs) {
             auto kern = attn_packed_kernel<CP, UT, NW, false, true>;
+            auto kern2 = attn_packed_kernel<CP, UT, NW, false, true, false, 2>;
             constexpr int lds = 2 * UT * attn_x3_tf(CP) * 1024;
             static std::atomic<unsigned> done{0};
             int dev = 0; (void)hipGetDevice(&dev);
             const unsigned bit = 1u << (dev & 31);
-            if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
-            hipLaunchKernelGGL(kern, dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), lds, s, a);
+            if (!(done.load(std::memory_order_relaxed) & bit)) {
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                (void)hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                done.fetch_or(bit, std::memory_order_relaxed);
+            }
+            if (a.x3_scale) hipLaunchKernelGGL(kern2, dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), lds, s, a);
+            else hipLaunchKernelGGL(kern, dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), lds, s, a);
             return 0;
         }
     }
@@ -590,12 +616,13 @@ static int launch_attn_packed(const AttnArgs& a, hipStream_t s) {
     return 0;
 }
 
-size_t attn_x3_bytes(int Cp, int mode, int n_groups) { return (size_t)n_groups * (mode == 2 ? 8 : 4) * attn_x3_tf(Cp) * 1024; }
+size_t attn_x3_bytes(int Cp, int mode, int n_groups) { return (size_t)n_groups * (mode == 2 ? 8 : 4) * attn_x3_tf(Cp) * 1024 + 32; }      // + trailer of the two-term form (max |w|, scales)
 
-// pairs != 0: pair-order stream (mode 0 / 1, even group count): [Q0 K0 V0 Q1 K1 V1 P_lo P_hi] per two head groups, projection split as well
+// pairs == 1: pair-order stream (mode 0 / 1, even group count): [Q0 K0 V0 Q1 K1 V1 P_lo P_hi] per two head groups, projection split as well
+// pairs == 2: the two-term fp16 form of the plain stream (split_terms.h): weights scaled by the power of two of the block's max |w|, scales in the trailer
 int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, hipStream_t s, int pairs) {
     const int KK = Cp / 16, KS = attn_x3_ks(Cp), TF = attn_x3_tf(Cp), TPG = mode == 2 ? 8 : 4;
-    if (pairs) {
+    if (pairs == 1) {
         if (mode == 2 || (n_groups & 1)) return -1;
         (void)hipMemsetAsync(image, 0, attn_x3_bytes(Cp, mode, n_groups), s);
         const int H = (KK + 1) / 2;
@@ -608,8 +635,13 @@ int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, 
     const int n_tiles = n_groups * TPG;
     (void)hipMemsetAsync(image, 0, attn_x3_bytes(Cp, mode, n_groups), s);
     const long long total = (long long)n_tiles * (KS > KK ? KS : KK) * 64;
+    if (pairs == 2) {
+        unsigned* mx = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(image) + attn_x3_bytes(Cp, mode, n_groups) - 32);
+        const long long n = (long long)n_tiles * KK * 64 * 4;
+        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, waf, n, mx);
+    }
     hipLaunchKernelGGL(attn_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(waf), reinterpret_cast<bf16x8*>(image),
-                       n_tiles, TPG, KK, KS, TF, proj_mask);
+                       n_tiles, TPG, KK, KS, TF, proj_mask, pairs == 2 ? 2 : 3);
     return 0;
 }
 
@@ -624,7 +656,8 @@ int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_grou
                nWh, nWw, shifted, C, n_groups, scale, 1e-5f, gs, partial, rows, g_mlp_trace,
                comb ? comb->partial : nullptr, comb ? comb->bias : nullptr, comb ? comb->stride : 0, comb ? comb->n : 0,
                tape ? tape->xn : nullptr, tape ? tape->qkv : nullptr, tape ? tape->o : nullptr, tape ? tape->ldq : 0, tape ? tape->ldo : 0,
-               tape ? tape->hdp : 0, tape ? tape->nH : 0, (comb || tape) ? nullptr : x3_wf, x3_pairs};
+               tape ? tape->hdp : 0, tape ? tape->nH : 0, (comb || tape) ? nullptr : x3_wf, x3_pairs == 1 ? 1 : 0,
+               (!comb && !tape && x3_wf && x3_pairs == 2) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(x3_wf) + attn_x3_bytes(Cp, mode, n_groups) - 16) : nullptr};
     if (tape && nw < 0) return ESCX_COMB_UNSUPPORTED;      // the packed H = 2 form has no tape stores
     // H == 2 scale with no padding along W: two half-real windows share one tile (nw < 0 encodes "packing allowed", |nw| waves)
     if (nw < 0) {

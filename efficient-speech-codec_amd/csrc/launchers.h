@@ -56,9 +56,9 @@ struct CombineOnLoad { const float* partial; const float* bias; long long stride
 int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, const float* beta, const float* wf, const int* map, int M,
                   int rows_per_clip, int src_rows_per_clip, int C, int Cp, int Np, int split, int H, int W, int C2p, hipStream_t s,
                   const CombineOnLoad* comb = nullptr,
-                  const void* x3_wf = nullptr);      // split (3 x bf16) weight stream (rowgemm_x3_pack), or nullptr = fp32 MFMA
+                  const void* x3_wf = nullptr, int x3_nt = 3);      // split weight stream (rowgemm_x3_pack, x3_nt terms: 3 = bf16, 2 = fp16 + scales), or nullptr = fp32 MFMA
 size_t rowgemm_x3_bytes(int KP, int Np);
-int rowgemm_x3_pack(const float* wf, void* image, int KP, int Np, hipStream_t s);
+int rowgemm_x3_pack(const float* wf, void* image, int KP, int Np, hipStream_t s, int nt = 3);
 void loss_reduce(const float* terms, int n_slots, int G, int M, int Tq, float* out, hipStream_t s);     // per-clip commitment loss, fixed summation order
 void mlp_set_trace(unsigned long long* p);
 int test_fastdiv(int n, int d);       // host evaluation of gemm_engine.h FastDiv (gemm_misc.hip)

@@ -24,7 +24,7 @@ def load(d, counter):
 
 
 CODEC_KERNEL_SOURCES = ("fused_attn.h", "fused_deembed.h", "fused_mlp.h", "fused_rowgemm.h", "fused_swin.hip", "gemm_engine.h", "gemm_misc.hip",
-                        "gemm_swin.hip", "kernels.h", "kernels_misc.hip", "launchers.h", "fused_pvq.h", "tune_env.h", "fused_mlp_x3.h")
+                        "gemm_swin.hip", "kernels.h", "kernels_misc.hip", "launchers.h", "fused_pvq.h", "tune_env.h", "fused_mlp_x3.h", "split_terms.h")
 
 
 def csrc_hash():
