@@ -43,14 +43,13 @@ FLOP_PER_CLIP = 56.75e9            # BASELINE.md section 3 (2xMAC over linear/bm
 PEAK_F32_MFMA = 157.3e12           # MI355X_MICROARCH.md chip table
 PEAK_HBM = 8.0e12
 FP32_MFMA_ONLY = all(os.environ.get(k) == "0" for k in ("ESCX_MLP_X3", "ESCX_ATTN_X3", "ESCX_ROWGEMM_X3"))
-def _terms(name):
-    return 3 if os.environ.get(name) == "3" else 2      # library default since round 5: two fp16 terms (csrc/split_terms.h); 3 = three bf16 terms, exact split
-MLP_TERMS, ATTN_TERMS, ROWGEMM_TERMS = _terms("ESCX_MLP_X3_TERMS"), _terms("ESCX_ATTN_X3_TERMS"), _terms("ESCX_ROWGEMM_X3_TERMS")
+X3_TERMS = 3 if os.environ.get("ESCX_X3_TERMS") == "3" else 2      # library default since round 5: two fp16 terms (csrc/split_terms.h); 3 = three bf16 terms, exact split
+MLP_TERMS = ATTN_TERMS = ROWGEMM_TERMS = X3_TERMS
 MLP_XPROD = 3 if MLP_TERMS == 2 else 6            # matrix products issued per fp32 product in the split-operand MLP
 CODEC_DTYPE = ("f32" if FP32_MFMA_ONLY else
                "f32 (fp32 storage and accumulation everywhere; the K = C contractions of the MLPs, of the attention's Q / K / V projections and of PatchMerge / PatchSplit run on the "
-               "16-bit matrix cores with every fp32 operand split into terms - MLP " + str(MLP_TERMS) + ", attention " + str(ATTN_TERMS) + ", merge/split " + str(ROWGEMM_TERMS) +
-               " terms; 2 = two fp16 terms + power-of-two weight scales, three cross products (truncation 1e-7 of the result, below fp32 accumulation rounding); 3 = three bf16 terms, "
+               "16-bit matrix cores with every fp32 operand split into " + str(X3_TERMS) + " terms (ESCX_X3_TERMS); "
+               "2 = two fp16 terms + power-of-two weight scales, three cross products (truncation 1e-7 of the result, below fp32 accumulation rounding); 3 = three bf16 terms, "
                "exact split, six cross products - fp32-grade either way: per-layer error at or below the reference's own float32 error against float64 "
                "(tests/test_gpu_parity.py::test_layer_accuracy_against_fp64); all-fp32-MFMA path: see fp32_mfma_only)")
 PEAK_BF16_MFMA = 2500e12          # dense bf16 = dense fp16 rate (MI355X_MICROARCH.md): the fused MLPs issue MLP_XPROD 16-bit MFMA products per fp32 product (fused_mlp_x3.h)
@@ -741,6 +740,10 @@ def main():
             ach = flops_per_launch / avg_s
             roofline = {"bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": traffic}
+            if dom["name"].startswith("attn_fused") and not FP32_MFMA_ONLY:
+                roofline["peak_of"] = ("fp32 MFMA peak over the kernel's algorithmic FLOPs.  Mixed kernel: scores, softmax, P.V and the output projection run on the fp32 MFMA; the Q / K / V "
+                                       f"projections (3 C^2 of its ~4 C^2 + 64 C FLOPs per token) on the 16-bit matrix cores with {X3_TERMS}-term split operands "
+                                       f"({3 if X3_TERMS == 2 else 6} products per fp32 product) - the fraction is an fp32-equivalent rate, not a utilisation of either pipe")
         else:
             ach = bytes_per_launch / avg_s
             roofline = {"bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",

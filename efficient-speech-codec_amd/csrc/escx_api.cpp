@@ -1031,11 +1031,12 @@ extern "C" const char* escx_profile_report(escx_handle h) {
 // Fused MLP on the bf16 matrix cores with every fp32 operand split exactly into three bf16 terms (fused_mlp_x3.h): DEFAULT for every instantiated width
 // (48, 80, 96, 144, 192, 384).  ESCX_MLP_X3=<max padded width> restricts it, ESCX_MLP_X3=0 = the fp32-MFMA kernel (fused_mlp.h) everywhere - the
 // round-4 arithmetic, which bench.py also reports (`fp32_mfma_only`) and tests/test_gpu_parity.py keeps as an arm.
-// terms per operand of the split-operand MLP: 3 = bf16 (exact split), 2 = fp16 with power-of-two weight scales (fused_mlp_x3.h); ESCX_MLP_X3_TERMS=2|3
-// ... of the split-operand Q / K / V projections and PatchMerge / PatchSplit (ESCX_ATTN_X3_TERMS, ESCX_ROWGEMM_X3_TERMS = 2|3)
-static int attn_x3_terms() { static const int v = [] { const char* e = getenv("ESCX_ATTN_X3_TERMS"); const int t = e && e[0] ? atoi(e) : 2; return t == 3 ? 3 : 2; }(); return v; }
-static int rowgemm_x3_terms() { static const int v = [] { const char* e = getenv("ESCX_ROWGEMM_X3_TERMS"); const int t = e && e[0] ? atoi(e) : 2; return t == 3 ? 3 : 2; }(); return v; }
-static int mlp_x3_terms() { static const int v = [] { const char* e = getenv("ESCX_MLP_X3_TERMS"); const int t = e && e[0] ? atoi(e) : 2; return t == 3 ? 3 : 2; }(); return v; }
+// Terms per operand of the split-operand kernels (split_terms.h): 2 (default) = two fp16 terms + power-of-two weight scales, three cross products;
+// ESCX_X3_TERMS=3 = three bf16 terms, exact split, six cross products (the first round-5 form).  One switch for the MLPs, the Q / K / V projections and PatchMerge / PatchSplit.
+static int x3_terms() { static const int v = [] { const char* e = getenv("ESCX_X3_TERMS"); const int t = e && e[0] ? atoi(e) : 2; return t == 3 ? 3 : 2; }(); return v; }
+static int attn_x3_terms() { return x3_terms(); }
+static int rowgemm_x3_terms() { return x3_terms(); }
+static int mlp_x3_terms() { return x3_terms(); }
 static int mlp_x3_maxcp() { static const int v = [] { const char* e = getenv("ESCX_MLP_X3"); return e && e[0] ? atoi(e) : 384; }(); return v; }
 
 // Waves per workgroup (4 or 8) for the fused kernels.  A wave owns `units` 16-row tiles; a workgroup's waves spread over the

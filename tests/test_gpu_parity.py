@@ -899,7 +899,7 @@ def test_fallback_kernel_forms_against_the_default(tmp_path):
     arms = {"default": {}, "pvq_three_launch": {"ESCX_PVQ_FUSED": "0", "ESCX_PVQ_TABLE": "0"}, "pvq_fused_mfma_up": {"ESCX_PVQ_TABLE": "0"},
             "pvq_tables_only": {"ESCX_PVQ_FUSED": "0"}, "pvq_up_engine": {"ESCX_PVQ_FUSED": "0", "ESCX_PVQ_TABLE": "0", "ESCX_PVQ_UP_KERNEL": "0"},
             "attn_gs_off": {"ESCX_ATTN_GS_TOKENS": "0"}, "all_fp32_mfma": {"ESCX_MLP_X3": "0", "ESCX_ATTN_X3": "0", "ESCX_ROWGEMM_X3": "0"},
-            "bf16_three_terms": {"ESCX_MLP_X3_TERMS": "3", "ESCX_ATTN_X3_TERMS": "3", "ESCX_ROWGEMM_X3_TERMS": "3"}}
+            "bf16_three_terms": {"ESCX_X3_TERMS": "3"}}
     got = _ab_arms(arms, tmp_path)
     ref = got["default"]
     for name in ("pvq_three_launch", "pvq_fused_mfma_up", "pvq_tables_only", "pvq_up_engine"):
