@@ -444,7 +444,10 @@ int layer_fwd(escx_handle_s* h, const Layer& L, LayerTape& LT, const float* x_in
         static const bool attn_fused_ok = [] { const char* e = getenv("ESCX_TRAIN_ATTN_FUSED"); return !(e && e[0] == '0'); }();
         int afrc = -1;
         static const int attn_fused_max = [] { const char* e = ESCX_TUNE_ENV("ESCX_TRAIN_ATTN_FUSED_MAXCP"); return e && e[0] ? atoi(e) : 96; }();
-        if (attn_fused_ok && L.attn_mode >= 0 && L.Cp <= attn_fused_max) {
+        // the TAPE instantiation zeroes 16 pad columns of the q|k|v and attention-output rows; a wider pad (no ESC geometry has one) keeps the unfused launches, whose
+        // GEMM epilogues write whole rows - the backward contracts over the full Nqkv / Ko width
+        const bool tape_pad_ok = L.Nqkv - 3 * L.nH * L.hdp <= 16 && L.Ko - L.nH * L.hdp <= 16;
+        if (attn_fused_ok && tape_pad_ok && L.attn_mode >= 0 && L.Cp <= attn_fused_max) {
             const AttnTape tape{bt.xn1, bt.qkv, bt.obuf, L.Nqkv, L.Ko, L.hdp, L.nH};
             const int tmw = attn_windows_per_wave(L.Cp);
             const long long wg4 = (Ms / 16 / tmw + 3) / 4;
