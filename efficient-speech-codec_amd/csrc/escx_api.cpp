@@ -155,6 +155,7 @@ extern "C" void escx_destroy(escx_handle h) {
     if (h->coll_buf) (void)hipFree(h->coll_buf);
     for (Quant& q : h->quants) if (q.tab) (void)hipFree(q.tab);
     for (Layer& L : h->layers) { if (L.sub_x3) (void)hipFree(L.sub_x3); if (L.sub_x3s) (void)hipFree(L.sub_x3s); }
+    if (h->dch_x2) (void)hipFree(h->dch_x2);
     for (Layer& L : h->layers) for (BlockW& bw : L.blocks) { if (bw.x3w) (void)hipFree(bw.x3w); if (bw.x3a) (void)hipFree(bw.x3a); }
     if (h->iota_codes) (void)hipFree(h->iota_codes);
     if (h->gmap) (void)hipFree(h->gmap);
@@ -1321,6 +1322,16 @@ static int ensure_pvq_tables(escx_handle_s* h, hipStream_t st) {
     }
     // the split (3 x bf16) weight images of the fused MLP (fused_mlp_x3.h): derived state like the tables above
     const int x3_max = mlp_x3_maxcp();
+    // the two-term fp16 stream of the halo-tiled de-embedding (fused_deembed.h deembed7_x2_kernel): with the two-term default only - ESCX_X3_TERMS=3 and the
+    // all-fp32-MFMA path (ESCX_MLP_X3=0) keep the fp32 kernel (the latter stays bit-identical to round 4)
+    {
+        const bool want = x3_max > 0 && x3_terms() == 2 && h->deembed_halo && h->dch_w && deembed7_x2_image_bytes(h->C0p) > 0;
+        if (!want) { if (h->dch_x2) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(h->dch_x2); h->dch_x2 = nullptr; } }
+        else {
+            if (!h->dch_x2) ESCX_HIP(hipMalloc(&h->dch_x2, deembed7_x2_image_bytes(h->C0p)));
+            if (deembed7_x2_pack(h->dch_w, h->dch_x2, h->C0p, st) != 0) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(h->dch_x2); h->dch_x2 = nullptr; }
+        }
+    }
     for (Layer& L : h->layers)
         for (BlockW& bw : L.blocks) {
             const bool want = x3_max > 0 && L.Cp <= x3_max && (L.Cp == 48 || L.Cp == 80 || L.Cp == 96 || L.Cp == 144 || L.Cp == 192 || L.Cp == 384) && L.hiddenP % 32 == 0;
@@ -1439,7 +1450,7 @@ static int run_deembed(escx_handle_s* h, const float* tok, int B, int W, float* 
         int hrc = -1;
         if (h->deembed_halo)
             PROF("deembed_composed7x7", 2.0 * tk * 49 * h->C0 * c.in_dim * h->Q, (tk * h->C0 + tk * c.in_dim * h->Q) * 4,
-                 hrc = deembed7_fused(tok, B, H0, W, h->C0p, h->dch_w, h->dcc_b, rspec, c.patch_f, c.patch_t, c.in_dim, h->Fp, st));
+                 hrc = deembed7_fused(tok, B, H0, W, h->C0p, h->dch_w, h->dcc_b, rspec, c.patch_f, c.patch_t, c.in_dim, h->Fp, st, h->dch_x2));
         if (hrc != 0)
         PROF("deembed_composed7x7", 2.0 * tk * 49 * h->C0 * c.in_dim * h->Q, (tk * h->C0 + tk * c.in_dim * h->Q) * 4,
              gemm_deembed_composed(tok, B, H0, W, h->C0p, h->dcc_w, rspec, h->dcc_b, c.patch_f, c.patch_t, c.in_dim, h->Fp, st));

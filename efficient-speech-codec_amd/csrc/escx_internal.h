@@ -131,6 +131,7 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     float *dft_w = nullptr, *idft_w = nullptr, *win2 = nullptr;
     float *dcc_w = nullptr, *dcc_b = nullptr, *dcv_w = nullptr, *dcv_b = nullptr;   // composed de-embedding: interior GEMM weights, border variants
     float* dch_w = nullptr;          // the interior weights as MFMA fragments for the halo-tiled kernel
+    void* dch_x2 = nullptr;          // ... as the two-term fp16 stream of deembed7_x2_kernel (derived inference state, rebuilt with the tables)
     float *dc1_wT = nullptr, *idft_wT = nullptr;     // training: conv5x5 dX weights, transposed inverse-DFT matrix
 
     // ---- training step (train.hip) ----

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "gemm_engine.h"
+#include "split_terms.h"
 
 namespace escx {
 
@@ -129,6 +130,130 @@ __global__ __launch_bounds__(512) void deembed7_kernel(DeembedArgs a) {
             if (nn >= a.n_out) continue;
             const int co = nn / Q, q = nn - co * Q, s1 = q / a.pt, s2 = q - s1 * a.pt;
             a.out[((size_t)(b * (a.pt * a.W) + a.pt * w + s2) * a.in_dim + co) * a.Fp + a.pf * h + s1] = acc[t][r] + bv[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Two-term fp16 form (round 5, split_terms.h; the spectrum it writes feeds the ISTFT only - never a code).  The contraction is flattened over all 49 taps:
+// k = tap * CP + c, 32 per MFMA step (ceil(49 CP / 32) steps: no per-tap padding of the 48-channel map to 64).  A lane's eight k-slots 32 s + 8 g .. + 7 lie inside ONE tap
+// (CP % 8 == 0), so every lane group walks its own (dh, dw, c) through the halo tile.  The tile + halo sits in LDS ONCE as two fp16 planes (split when it is loaded,
+// 112 B per pixel: 16 consecutive pixels start in 16 distinct 16-byte granules of the 256-byte LDS row); the weights - two fp16 terms per step, scaled by the power of
+// two of max |w| (deembed7_x2_pack_kernel, from the fp32 fragment stream) - stream through a double-buffered LDS ring in chunks of 8 steps (16 KiB).
+// Per step and wave: 2 weight + 4 operand fragment reads, 6 MFMAs (terms (0,1), (1,0), (0,0) x two 16-pixel segments).  LDS: 116 + 32 KiB.
+// ------------------------------------------------------------------------------------------------
+constexpr int de2_steps(int CP) { return (49 * CP + 31) / 32; }
+inline size_t deembed7_x2_bytes(int CP) { return (size_t)de2_steps(CP) * 2 * 1024 + 32; }      // + trailer: bits of max |w|, {2^-k, 2^k}
+
+// one thread per (step, lane): lane (n, g) of step s holds the two terms of W[n][tap][c .. c + 7], k = 32 s + 8 g = tap CP + c (zero behind the last tap)
+__global__ __launch_bounds__(256) void deembed7_x2_pack_kernel(const f32x4* __restrict__ wf, bf16x8* __restrict__ out, int CP, int nsteps) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nsteps * 64) return;
+    const int step = idx >> 6, lane = idx & 63, n = lane & 15, g = lane >> 4, KK = CP / 16;
+    bf16x8* tail = out + (size_t)nsteps * 2 * 64;
+    const float sc = x2_scale(*reinterpret_cast<const unsigned*>(tail));
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 32 * step + 8 * g + e, tap = k / CP, c = k - tap * CP;
+        v[e] = tap < 49 ? wf[(size_t)(tap * KK + c / 16) * 64 + 16 * ((c % 16) / 4) + n][c % 4] : 0.f;
+    }
+    bf16x8 t[2];
+    split_terms<2>(v, t, sc);
+    out[(size_t)(step * 2 + 0) * 64 + lane] = t[0]; out[(size_t)(step * 2 + 1) * 64 + lane] = t[1];
+    if (idx == 0) { float* o = reinterpret_cast<float*>(tail + 1); o[0] = 1.0f / sc; o[1] = sc; o[2] = 0.f; o[3] = 0.f; }
+}
+
+template <int CP>
+__global__ __launch_bounds__(512) void deembed7_x2_kernel(DeembedArgs a, const bf16x8* __restrict__ wf2) {
+    static_assert(CP == 48, "one wrap of the channel index per 32-deep step");
+    ESCX_SET_PRIO_SMALL();
+    constexpr int TH = 8, TW = 32, HH = TH + 6, HW = TW + 6, PS = CP + 8;        // PS: halfs per pixel
+    constexpr int NSTEP = de2_steps(CP), CH = 8, NCH = (NSTEP + CH - 1) / CH, NW = 8, Q8 = CP / 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char de2_lds[];
+    _Float16* xh0 = reinterpret_cast<_Float16*>(de2_lds);                       // [HH][HW][PS] high terms
+    _Float16* xh1 = xh0 + HH * HW * PS;                                          // ... low terms
+    bf16x8* wr = reinterpret_cast<bf16x8*>(xh1 + HH * HW * PS);                  // [2][CH * 2 * 64]
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntw = (a.W + TW - 1) / TW, nth = (a.H + TH - 1) / TH;
+    int bid = blockIdx.x;
+    const int tw = bid % ntw; bid /= ntw;
+    const int th = bid % nth; const int b = bid / nth;
+    const int h0 = th * TH, w0 = tw * TW;
+
+    auto issue_chunk = [&](int ch, int buf) {
+        const int pieces = min(CH, NSTEP - ch * CH) * 2;
+        const bf16x8* src = wf2 + (size_t)ch * CH * 2 * 64 + lane;
+        for (int c = wave; c < pieces; c += NW)
+            __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(&wr[(buf * CH * 2 + c) * 64]), 16, 0, 0);
+    };
+    issue_chunk(0, 0);
+    const f32x4 scv = *reinterpret_cast<const f32x4*>(wf2 + (size_t)NSTEP * 2 * 64 + 1);       // {2^-k, 2^k, 0, 0}
+
+    // ---- tile + halo -> two fp16 planes (zero outside the map) ----
+    const float* xb = a.x + (size_t)b * a.H * a.W * CP;
+    for (int v = tid; v < HH * HW * Q8; v += 512) {
+        const int pix = v / Q8, q = v - pix * Q8;
+        const int ph = pix / HW, pw = pix - ph * HW;
+        const int gh = h0 - 3 + ph, gw = w0 - 3 + pw;
+        float xv[8];
+        if (gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) {
+            const float* p = xb + ((size_t)gh * a.W + gw) * CP + 8 * q;
+            const f32x4 u0 = ld4(p), u1 = ld4(p + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xv[e] = u0[e]; xv[4 + e] = u1[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[e] = 0.f;
+        }
+        bf16x8 t[2];
+        split_terms<2>(xv, t);
+        *reinterpret_cast<bf16x8*>(xh0 + pix * PS + 8 * q) = t[0];
+        *reinterpret_cast<bf16x8*>(xh1 + pix * PS + 8 * q) = t[1];
+    }
+
+    const bool seg1 = w0 + 16 < a.W;
+    f32x4 acc0 = zero4(), acc1 = zero4();
+    int c = 8 * lg, dw = 0, dh = 0;             // this lane group's position in the flattened contraction: k = (7 dh + dw) CP + c
+    for (int ch = 0; ch < NCH; ++ch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                        // chunk ch (and, the first time, the halo planes) are in LDS; nobody still reads the other ring slot
+        if (ch + 1 < NCH) issue_chunk(ch + 1, (ch + 1) & 1);
+        const bf16x8* wb = &wr[((ch & 1) * CH * 2) * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            if (ch * CH + s >= NSTEP) break;
+            const int dhc = dh > 6 ? 6 : dh;    // behind the last tap the weights are zero: any valid address
+            const int xoff = ((wave + dhc) * HW + dw + l15) * PS + c;
+            const bf16x8 wt0 = wb[(s * 2) * 64], wt1 = wb[(s * 2 + 1) * 64];
+            const bf16x8 x00 = *reinterpret_cast<const bf16x8*>(xh0 + xoff), x01 = *reinterpret_cast<const bf16x8*>(xh1 + xoff);
+            acc0 = mma_x<2>(wt0, x01, acc0); acc0 = mma_x<2>(wt1, x00, acc0); acc0 = mma_x<2>(wt0, x00, acc0);
+            if (seg1) {
+                const bf16x8 x10 = *reinterpret_cast<const bf16x8*>(xh0 + xoff + 16 * PS), x11 = *reinterpret_cast<const bf16x8*>(xh1 + xoff + 16 * PS);
+                acc1 = mma_x<2>(wt0, x11, acc1); acc1 = mma_x<2>(wt1, x10, acc1); acc1 = mma_x<2>(wt0, x10, acc1);
+            }
+            c += 32;
+            if (c >= CP) { c -= CP; if (++dw == 7) { dw = 0; ++dh; } }
+        }
+    }
+
+    // ---- scale back, bias, store: lane (pixel, outputs 4lg .. 4lg+3) - as deembed7_kernel ----
+    const int h = h0 + wave;
+    if (h >= a.H) return;
+    const int Q = a.pf * a.pt;
+    const f32x4 bv = ld4(a.bias + 4 * lg);
+    const f32x4 accs[2] = {acc0 * scv[0], acc1 * scv[0]};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int w = w0 + 16 * t + l15;
+        if (w >= a.W) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nn = 4 * lg + r;
+            if (nn >= a.n_out) continue;
+            const int co = nn / Q, q = nn - co * Q, s1 = q / a.pt, s2 = q - s1 * a.pt;
+            a.out[((size_t)(b * (a.pt * a.W) + a.pt * w + s2) * a.in_dim + co) * a.Fp + a.pf * h + s1] = accs[t][r] + bv[r];
         }
     }
 }

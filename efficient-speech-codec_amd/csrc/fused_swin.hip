@@ -473,11 +473,34 @@ int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, cons
 }
 
 // ---- halo-tiled composed de-embedding -----------------------------------------------------------
+// the two-term fp16 weight stream of deembed7_x2_kernel (fused_deembed.h), from the fp32 fragment stream; 0 bytes: no such instantiation for this width
+size_t deembed7_x2_image_bytes(int Cp) { return Cp == 48 ? deembed7_x2_bytes(Cp) : 0; }
+int deembed7_x2_pack(const float* wfrag, void* image, int Cp, hipStream_t s) {
+    if (Cp != 48) return -1;
+    const int nsteps = de2_steps(Cp);
+    unsigned* mx = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(image) + deembed7_x2_bytes(Cp) - 32);
+    if (hipMemsetAsync(mx, 0, 32, s) != hipSuccess) return -1;
+    const long long n = (long long)49 * (Cp / 16) * 64 * 4;
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, wfrag, n, mx);
+    hipLaunchKernelGGL(deembed7_x2_pack_kernel, dim3((nsteps * 64 + 255) / 256), dim3(256), 0, s, reinterpret_cast<const f32x4*>(wfrag), reinterpret_cast<bf16x8*>(image), Cp, nsteps);
+    return 0;
+}
+
 int deembed7_fused(const float* tok, int B, int H, int W, int Cp, const float* wfrag, const float* bias, float* out, int pf, int pt,
-                   int in_dim, int Fp, hipStream_t s) {
+                   int in_dim, int Fp, hipStream_t s, const void* x2_image) {
     DeembedArgs a{tok, reinterpret_cast<const f32x4*>(wfrag), bias, out, B, H, W, pf, pt, in_dim, Fp, in_dim * pf * pt};
     if (a.n_out > 16) return -1;
     const int grid = B * ((H + 7) / 8) * ((W + 31) / 32);
+    if (x2_image && Cp == 48) {                 // two fp16 terms, contraction flattened over the 49 taps (the spectrum feeds the ISTFT only)
+        auto kern = deembed7_x2_kernel<48>;
+        constexpr int lds = 2 * 14 * 38 * (48 + 8) * 2 + 2 * 8 * 2 * 1024;
+        static std::atomic<unsigned> done{0};
+        int dev = 0; (void)hipGetDevice(&dev);
+        const unsigned bit = 1u << (dev & 31);
+        if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const bf16x8*>(x2_image));
+        return 0;
+    }
     switch (Cp) {               // LDS: (8+6) x (32+6) pixels x (Cp+4) dwords + two 7-tap weight stages <= 160 KiB
         case 16: hipLaunchKernelGGL(deembed7_kernel<16>, dim3(grid), dim3(512), 0, s, a); return 0;
         case 32: hipLaunchKernelGGL(deembed7_kernel<32>, dim3(grid), dim3(512), 0, s, a); return 0;

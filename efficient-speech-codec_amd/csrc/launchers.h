@@ -64,7 +64,9 @@ void mlp_set_trace(unsigned long long* p);
 int test_fastdiv(int n, int d);       // host evaluation of gemm_engine.h FastDiv (gemm_misc.hip)
 // halo-tiled composed de-embedding (fused_deembed.h); -1 when the width / output count is not instantiated
 int deembed7_fused(const float* tok, int B, int H, int W, int Cp, const float* wfrag, const float* bias, float* out, int pf, int pt,
-                   int in_dim, int Fp, hipStream_t s);
+                   int in_dim, int Fp, hipStream_t s, const void* x2_image = nullptr);      // x2_image: two-term fp16 stream (deembed7_x2_pack), Cp = 48 only
+size_t deembed7_x2_image_bytes(int Cp);
+int deembed7_x2_pack(const float* wfrag, void* image, int Cp, hipStream_t s);
 // mode: 0 one head (<=16 dims) per tile, 1 two heads (<=8 dims) per tile, 2 one head (<=32 dims) over two tiles
 int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_groups, const float* gamma, const float* beta,
                const float* wf, const float* bqkv, const float* bias_tab, const float* bproj, const int* map, int slots, int tokens,
