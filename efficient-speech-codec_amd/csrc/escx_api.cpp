@@ -135,6 +135,18 @@ extern "C" int escx_create(const escx_config* cfg, int device, escx_handle* out)
     { const char* e = ESCX_TUNE_ENV("ESCX_ATTN_NW"); if (e && e[0]) h->attn_nw = atoi(e); }
     { const char* e = ESCX_TUNE_ENV("ESCX_NO_ATTN_PACK"); h->attn_pack = !(e && e[0] == '1'); }
     { const char* e = getenv("ESCX_NO_FUSED_ATTN"); h->use_fused_attn = !(e && e[0] == '1'); }
+    // precision DEFAULT of new handles (escx_set_precision changes it per handle): ESCX_PRECISION=fp32|bf16x3|f16x2 (or 0|3|2); ESCX_X3_TERMS=3 is the round-5 spelling of bf16x3
+    { const char* e = getenv("ESCX_X3_TERMS"); if (e && atoi(e) == 3) h->prec = 3; }
+    { const char* e = getenv("ESCX_PRECISION");
+      if (e && e[0]) {
+          const std::string v(e);
+          if (v == "fp32" || v == "0") h->prec = 0; else if (v == "bf16x3" || v == "3") h->prec = 3; else if (v == "f16x2" || v == "2") h->prec = 2;
+          else { delete h; ESCX_FAIL(ESCX_ERR_INVALID_ARG, "ESCX_PRECISION=%s (fp32 | bf16x3 | f16x2)", e); }
+      } }
+    { const char* e = getenv("ESCX_MLP_X3"); if (e && e[0]) h->mlp_x3_max = atoi(e); }
+    { const char* e = getenv("ESCX_ATTN_X3"); if (e && e[0]) h->attn_x3_max = atoi(e); }
+    { const char* e = getenv("ESCX_ROWGEMM_X3"); h->rowgemm_x3 = !(e && e[0] == '0'); }
+    { const char* e = getenv("ESCX_PVQ_TABLE"); h->pvq_table = !(e && e[0] == '0'); }
     int rc = build_geometry(h);
     if (rc) { delete h; return rc; }
     *out = h;
@@ -154,9 +166,9 @@ extern "C" void escx_destroy(escx_handle h) {
     for (auto& kv : h->maps) (void)hipFree(kv.second);
     if (h->coll_buf) (void)hipFree(h->coll_buf);
     for (Quant& q : h->quants) if (q.tab) (void)hipFree(q.tab);
-    for (Layer& L : h->layers) { if (L.sub_x3) (void)hipFree(L.sub_x3); if (L.sub_x3s) (void)hipFree(L.sub_x3s); }
-    if (h->dch_x2) (void)hipFree(h->dch_x2);
-    for (Layer& L : h->layers) for (BlockW& bw : L.blocks) { if (bw.x3w) (void)hipFree(bw.x3w); if (bw.x3a) (void)hipFree(bw.x3a); }
+    for (Layer& L : h->layers) { if (L.sub_x3_buf) (void)hipFree(L.sub_x3_buf); if (L.sub_x3s_buf) (void)hipFree(L.sub_x3s_buf); }
+    if (h->dch_x2_buf) (void)hipFree(h->dch_x2_buf);
+    for (Layer& L : h->layers) for (BlockW& bw : L.blocks) { if (bw.x3w_buf) (void)hipFree(bw.x3w_buf); if (bw.x3a_buf) (void)hipFree(bw.x3a_buf); }
     if (h->iota_codes) (void)hipFree(h->iota_codes);
     if (h->gmap) (void)hipFree(h->gmap);
     if (h->garena) (void)hipFree(h->garena);
@@ -925,7 +937,7 @@ static int run_halves(escx_handle_s* h, int B, hipStream_t st, F part) {
     // therefore collected, every started side stream is joined (event, or a blocking stream synchronise when the event cannot be recorded), and
     // only then is the first failure reported.
     int rc = 0;
-    bool started[8] = {false, false, false, false, false, false, false, false};
+    bool started[escx_handle_s::MAX_PARTS] = {};
     auto hip_fail = [&](hipError_t e, const char* what) {
         if (e != hipSuccess && rc == 0) { set_error("run_halves: %s: %s", what, hipGetErrorString(e)); rc = ESCX_ERR_HIP; }
         return e != hipSuccess;
@@ -937,11 +949,11 @@ static int run_halves(escx_handle_s* h, int B, hipStream_t st, F part) {
         hipStream_t si = side ? h->sx[i] : st;
         if (side && hip_fail(hipStreamWaitEvent(si, h->ev_fork, 0), "fork wait")) break;
         use_set(h, i);
-        if (side && i < 8) started[i] = true;
+        if (side) started[i] = true;
         const int prc = part(b0, nb, si);
         if (prc && !rc) rc = prc;
     }
-    for (int i = 1; i < k && i < 8; ++i) {
+    for (int i = 1; i < k; ++i) {
         if (!started[i]) continue;
         if (hipEventRecord(h->ev_join[i], h->sx[i]) != hipSuccess || hipStreamWaitEvent(st, h->ev_join[i], 0) != hipSuccess) {
             const hipError_t e = hipStreamSynchronize(h->sx[i]);          // cannot order the streams with an event: wait on the host instead
@@ -992,6 +1004,7 @@ int escx::launch_ok(const char* what) {
 }
 
 // ---- per-launch profiler (ProfScope / PROF live in escx_internal.h) ---------------------------
+thread_local escx::LaunchTimer* escx::g_launch_timer = nullptr;
 hipEvent_t escx::prof_event(escx_handle_s* h) {
     if (!h->prof_pool.empty()) { hipEvent_t e = h->prof_pool.back(); h->prof_pool.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
@@ -1034,11 +1047,8 @@ extern "C" const char* escx_profile_report(escx_handle h) {
 // round-4 arithmetic, which bench.py also reports (`fp32_mfma_only`) and tests/test_gpu_parity.py keeps as an arm.
 // Terms per operand of the split-operand kernels (split_terms.h): 2 (default) = two fp16 terms + power-of-two weight scales, three cross products;
 // ESCX_X3_TERMS=3 = three bf16 terms, exact split, six cross products (the first round-5 form).  One switch for the MLPs, the Q / K / V projections and PatchMerge / PatchSplit.
-static int x3_terms() { static const int v = [] { const char* e = getenv("ESCX_X3_TERMS"); const int t = e && e[0] ? atoi(e) : 2; return t == 3 ? 3 : 2; }(); return v; }
-static int attn_x3_terms() { return x3_terms(); }
-static int rowgemm_x3_terms() { return x3_terms(); }
-static int mlp_x3_terms() { return x3_terms(); }
-static int mlp_x3_maxcp() { static const int v = [] { const char* e = getenv("ESCX_MLP_X3"); return e && e[0] ? atoi(e) : 384; }(); return v; }
+// (round 6: the mode is a field of the handle, escx_set_precision; escx_handle_s::prec)
+static int x3_nt(const escx_handle_s* h) { return h->prec == 3 ? 3 : 2; }        // terms per operand of the split images / kernels (meaningful when prec != 0)
 
 // Waves per workgroup (4 or 8) for the fused kernels.  A wave owns `units` 16-row tiles; a workgroup's waves spread over the
 // 4 SIMDs of a CU and workgroups are dealt round-robin to the 256 CUs, so the makespan in tile-times is
@@ -1146,7 +1156,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             if (!launched)
             PROF("attn_fused" + tag, 2 * proj_rows * dC * 4 * dC + 4 * dMs * 16 * dC, 2 * dM * dC * f4,
                  frc = attn_fused(src, cur, L.Cp, L.C, L.attn_mode, L.n_groups, bw.ln1_g, bw.ln1_b, bw.waf, bw.baf, bw.bias_tab_f, bw.bproj,
-                                  map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, &gs, h->hid, M, st, nullptr, nullptr, (nw > 0 || L.Cp == 384) ? bw.x3a : nullptr, bw.x3a_pairs ? 1 : (attn_x3_terms() == 2 ? 2 : 0)));      // C = 384: the split stream exists for the packed (nw < 0) kernel only
+                                  map, slots, tokens, Ms / 16, Hp / 4, Wp / 4, shift > 0, 1.0f / std::sqrt((float)L.hd), nw, &gs, h->hid, M, st, nullptr, nullptr, (nw > 0 || L.Cp == 384) ? bw.x3a : nullptr, bw.x3a_pairs ? 1 : (x3_nt(h) == 2 ? 2 : 0)));      // C = 384: the split stream exists for the packed (nw < 0) kernel only
             attn_done = (frc == 0);
             if (attn_done && gs > 1)
                 PROF("attn_combine" + tag, 0, (gs + 2) * dM * L.Cp * f4, rows_combine(cur, src, h->hid, bw.bproj, M, L.Cp, gs, st));
@@ -1173,19 +1183,19 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             int hs = (h->mlp_hs > 0 && L.hiddenP >= h->mlp_hs * L.Cp) ? h->mlp_hs : mlp_hs_for(tokens, L.hiddenP / 16, L.Cp);
             const int variant = h->mlp_variant >= 0 ? h->mlp_variant : (hs > 1 ? ((L.Cp >= hs_nw8_cp && mlp_split_nw(M, hs) == 8) ? 3 : 1) : (L.Cp <= tm2_max ? (tm2_nw8 ? 5 : 4) : mlp_variant_for(M, L.Cp)));
             static const int x3_nw_force = [] { const char* e = ESCX_TUNE_ENV("ESCX_MLP_X3_NW"); return e && e[0] ? atoi(e) : 0; }();
-            if (bw.x3w && pend.n == 0 && L.Cp <= mlp_x3_maxcp()) {       // three-term bf16 split on the bf16 matrix cores (fused_mlp_x3.h); same hidden-split rule and combine
+            if (bw.x3w && pend.n == 0) {       // three-term bf16 split on the bf16 matrix cores (fused_mlp_x3.h); same hidden-split rule and combine
                 static const bool split_fold_x3 = [] { const char* e = getenv("ESCX_MLP_SPLIT_FOLD"); return !(e && e[0] == '0'); }();
                 if (split_fold_x3 && L.scale == 2 && j + 1 == L.blocks.size() && hs == 1 && L.sub_x3s) {      // PatchSplit in the epilogue of the layer's last MLP
                     const MlpSplit sp{reinterpret_cast<const float*>(L.sub_x3s), L.sub_g, L.sub_b, y, 2 * L.CoutP / 16, H, W, L.CoutP};
                     int src3 = -1, one = 1;
                     PROF("mlp_x3_split" + tag, 4 * dM * dC * L.hidden + 2.0 * dM * dC * 2 * L.Cout, (dM * dC + dM * 2 * L.Cout) * f4,
-                         src3 = mlp_x3(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.b1, bw.b2, bw.x3w, L.hiddenP, x3_nw_force ? x3_nw_force : mlp_x3_nw(M, L.Cp, variant), &one, nullptr, st, &sp, mlp_x3_terms()));
+                         src3 = mlp_x3(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.b1, bw.b2, bw.x3w, L.hiddenP, x3_nw_force ? x3_nw_force : mlp_x3_nw(M, L.Cp, variant), &one, nullptr, st, &sp, x3_nt(h)));
                     if (src3 == 0) { *Hout = 2 * H; return launch_ok(L.prefix.c_str()); }
                     if (h->prof && !h->prof_recs.empty()) h->prof_recs.pop_back();
                 }
                 int xrc = -1, xhs = hs;
                 PROF("mlp_x3" + tag, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
-                     xrc = mlp_x3(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.b1, bw.b2, bw.x3w, L.hiddenP, x3_nw_force ? x3_nw_force : mlp_x3_nw(M, L.Cp, variant), &xhs, h->hid, st, nullptr, mlp_x3_terms()));
+                     xrc = mlp_x3(cur, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.b1, bw.b2, bw.x3w, L.hiddenP, x3_nw_force ? x3_nw_force : mlp_x3_nw(M, L.Cp, variant), &xhs, h->hid, st, nullptr, x3_nt(h)));
                 if (xrc == 0) {
                     if (xhs > 1) { pend = CombineOnLoad{h->hid, bw.b2, (long long)M * L.Cp, xhs}; pend_tag = tag; flush_pending(); }
                     src = cur; continue;
@@ -1235,7 +1245,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         flush_pending();
         if (h->use_fused && mrc != 0)
             PROF("merge_fused" + (h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string()), 2.0 * B * H2 * W * 2 * L.C * L.Cout, ((double)M * L.C + (double)B * H2 * W * L.Cout) * 4,
-                 mrc = rowgemm_fused(2, cur, y, L.sub_g, L.sub_b, L.sub_wf, map, B * H2 * W, H2 * W, tokens, L.C, L.Cp, L.CoutP, 0, 0, 0, 0, st, nullptr, L.sub_x3, rowgemm_x3_terms()));
+                 mrc = rowgemm_fused(2, cur, y, L.sub_g, L.sub_b, L.sub_wf, map, B * H2 * W, H2 * W, tokens, L.C, L.Cp, L.CoutP, 0, 0, 0, 0, st, nullptr, L.sub_x3, x3_nt(h)));
         if (mrc != 0) {
         PROF("merge_ln", 0, 2.0 * M * L.C * 4,
              ln_rows(2, cur, h->xn, L.sub_g, L.sub_b, map, H2 * W, tokens, B * H2 * W, L.C, L.Cp, st));
@@ -1254,7 +1264,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         flush_pending();
         if (h->use_fused && src2 != 0)
             PROF("split_fused" + (h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string()), 2.0 * M * L.C * 2 * L.Cout, (double)M * (L.C + 2 * L.Cout) * 4,
-                 src2 = rowgemm_fused(1, cur, y, L.sub_g, L.sub_b, L.sub_wf, nullptr, M, tokens, tokens, L.C, L.Cp, 2 * L.CoutP, 1, H, W, L.CoutP, st, nullptr, L.sub_x3, rowgemm_x3_terms()));
+                 src2 = rowgemm_fused(1, cur, y, L.sub_g, L.sub_b, L.sub_wf, nullptr, M, tokens, tokens, L.C, L.Cp, 2 * L.CoutP, 1, H, W, L.CoutP, st, nullptr, L.sub_x3, x3_nt(h)));
         if (src2 != 0) {
         PROF("split_ln", 0, 2.0 * M * L.C * 4,
              ln_rows(0, cur, h->xn, L.sub_g, L.sub_b, nullptr, tokens, tokens, M, L.C, L.Cp, st));
@@ -1304,9 +1314,12 @@ static int run_encoder(escx_handle_s* h, const Shapes& s, hipStream_t st) {     
 // before the batch parts fork).  ESCX_PVQ_TABLE=0: no tables (up-projection on the MFMA, the round-4 form).
 static int ensure_pvq_tables(escx_handle_s* h, hipStream_t st) {
     if (!h->pvq_tab_stale) return 0;
-    static const bool on = [] { const char* e = getenv("ESCX_PVQ_TABLE"); return !(e && e[0] == '0'); }();
     const escx_config& c = h->cfg;
     const int G = c.group_size, Ksz = c.codebook_size;
+    const bool on = h->pvq_table;
+    // Derived buffers are allocated the first time they are wanted and KEPT (a precision switch or a parameter refresh only re-launches the pack kernels: no hipFree,
+    // no device synchronisation on the way - ADVICE r5); the ACTIVE pointer says whether the launch sequence uses them.
+    auto grab = [&](void** buf, size_t bytes) -> bool { return *buf || hipMalloc(buf, bytes) == hipSuccess; };
     if (on && !h->iota_codes) {
         std::vector<long long> iota((size_t)G * Ksz);
         for (int g = 0; g < G; ++g) for (int k = 0; k < Ksz; ++k) iota[(size_t)g * Ksz + k] = k;
@@ -1320,56 +1333,65 @@ static int ensure_pvq_tables(escx_handle_s* h, hipStream_t st) {
             ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(q.tab); q.tab = nullptr;      // no up-projection kernel for this width: the engine form stays
         }
     }
-    // the split (3 x bf16) weight images of the fused MLP (fused_mlp_x3.h): derived state like the tables above
-    const int x3_max = mlp_x3_maxcp();
-    // the two-term fp16 stream of the halo-tiled de-embedding (fused_deembed.h deembed7_x2_kernel): with the two-term default only - ESCX_X3_TERMS=3 and the
-    // all-fp32-MFMA path (ESCX_MLP_X3=0) keep the fp32 kernel (the latter stays bit-identical to round 4)
+    const int nt = x3_nt(h);
+    const bool split_on = h->prec != 0;
+    // tagged builds only: the two-term images WITHOUT the activation scales of the range rule (what tests/test_gpu_parity.py test_range_stress_checkpoints guards against)
+    static const bool no_act_scale = [] { const char* e = ESCX_TUNE_ENV("ESCX_X2_NO_ACT_SCALE"); return e && e[0] == '1'; }();
+    const int x3_max = split_on ? h->mlp_x3_max : 0;
+    // the two-term fp16 stream of the halo-tiled de-embedding (fused_deembed.h deembed7_x2_kernel): in the two-term mode only - the three-term mode and the fp32-MFMA
+    // mode keep the fp32 kernel (the latter stays bit-identical to round 4)
     {
-        const bool want = x3_max > 0 && x3_terms() == 2 && h->deembed_halo && h->dch_w && deembed7_x2_image_bytes(h->C0p) > 0;
-        if (!want) { if (h->dch_x2) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(h->dch_x2); h->dch_x2 = nullptr; } }
-        else {
-            if (!h->dch_x2) ESCX_HIP(hipMalloc(&h->dch_x2, deembed7_x2_image_bytes(h->C0p)));
-            if (deembed7_x2_pack(h->dch_w, h->dch_x2, h->C0p, st) != 0) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(h->dch_x2); h->dch_x2 = nullptr; }
-        }
+        const bool want = x3_max > 0 && h->prec == 2 && h->deembed_halo && h->dch_w && deembed7_x2_image_bytes(h->C0p) > 0;
+        h->dch_x2 = nullptr;
+        if (want && grab(&h->dch_x2_buf, deembed7_x2_image_bytes(h->C0p)) && deembed7_x2_pack(h->dch_w, h->dch_x2_buf, h->C0p, st) == 0) h->dch_x2 = h->dch_x2_buf;
     }
+    // the split weight images of the fused MLP (fused_mlp_x3.h)
     for (Layer& L : h->layers)
         for (BlockW& bw : L.blocks) {
             const bool want = x3_max > 0 && L.Cp <= x3_max && (L.Cp == 48 || L.Cp == 80 || L.Cp == 96 || L.Cp == 144 || L.Cp == 192 || L.Cp == 384) && L.hiddenP % 32 == 0;
-            if (!want) { if (bw.x3w) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(bw.x3w); bw.x3w = nullptr; } continue; }
-            if (!bw.x3w) ESCX_HIP(hipMalloc(&bw.x3w, mlp_x3_bytes(L.Cp, L.hiddenP, 3)));      // sized for the larger (three-term) image
-            if (mlp_x3_pack(bw.w1, bw.w2, bw.x3w, L.Cp, L.hiddenP, st, mlp_x3_terms()) != 0) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(bw.x3w); bw.x3w = nullptr; }
+            bw.x3w = nullptr;
+            if (want && grab(&bw.x3w_buf, mlp_x3_bytes(L.Cp, L.hiddenP, 3)) &&         // sized for the larger (three-term) image
+                mlp_x3_pack(bw.w1, bw.w2, bw.x3w_buf, L.Cp, L.hiddenP, st, nt, no_act_scale ? nullptr : bw.ln2_g, bw.ln2_b, bw.b1, L.C) == 0) bw.x3w = bw.x3w_buf;
         }
-    // the split Q / K / V weight streams of the fused attention (fused_attn.h X3; ESCX_ATTN_X3=0: fp32 MFMA)
-    static const int ax3_max = [] { const char* e = getenv("ESCX_ATTN_X3"); return e && e[0] ? atoi(e) : 384; }();
+    // the split Q / K / V weight streams of the fused attention (fused_attn.h X3)
+    const int ax3_max = split_on ? h->attn_x3_max : 0;
     for (Layer& L : h->layers)
         for (BlockW& bw : L.blocks) {
             const bool want = ax3_max > 0 && L.Cp <= ax3_max && L.attn_mode >= 0 && h->use_fused_attn &&
                               ((L.Cp == 48 && L.attn_mode == 0) || (L.Cp == 80 && L.attn_mode != 1) || (L.Cp == 96 && L.attn_mode != 2) || (L.Cp == 144 && L.attn_mode != 2) || (L.Cp == 192 && L.attn_mode == 1) || (L.Cp == 384 && L.attn_mode == 0));      // 384: the packed H = 2 kernel only (the launcher falls back to fp32 elsewhere)
-            if (!want) { if (bw.x3a) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(bw.x3a); bw.x3a = nullptr; } continue; }
-            if (!bw.x3a) ESCX_HIP(hipMalloc(&bw.x3a, attn_x3_bytes(L.Cp, L.attn_mode, L.n_groups)));
+            bw.x3a = nullptr;
+            if (!want || !grab(&bw.x3a_buf, attn_x3_bytes(L.Cp, L.attn_mode, L.n_groups))) continue;
             // pair order (the output projection in split form too) where two head groups always travel together: mode 0 / 1, group counts that stay even under the 3-way head-group split
             // OPT-IN, tagged builds (ESCX_ATTN_X3_PAIRS=1): measured no faster - the operand split of the O^T tiles and the two extra stage barriers per pair eat the
             // matrix time saved, and at C = 192 the kernel drops to one wave per SIMD (profiles/r5_attn_ab.txt)
             static const bool pairs_on = [] { const char* e = ESCX_TUNE_ENV("ESCX_ATTN_X3_PAIRS"); return e && e[0] == '1'; }();
-            bw.x3a_pairs = pairs_on && L.attn_mode != 2 && L.Cp != 48 && L.n_groups % 2 == 0 && (L.n_groups % 3 != 0 || (L.n_groups / 3) % 2 == 0);
-            attn_x3_pack(bw.waf, bw.x3a, L.Cp, L.attn_mode, L.n_groups, st, bw.x3a_pairs ? 1 : (attn_x3_terms() == 2 ? 2 : 0));
+            bw.x3a_pairs = pairs_on && nt == 3 && L.attn_mode != 2 && L.Cp != 48 && L.n_groups % 2 == 0 && (L.n_groups % 3 != 0 || (L.n_groups / 3) % 2 == 0);
+            if (attn_x3_pack(bw.waf, bw.x3a_buf, L.Cp, L.attn_mode, L.n_groups, st, bw.x3a_pairs ? 1 : (nt == 2 ? 2 : 0), no_act_scale ? nullptr : bw.ln1_g, bw.ln1_b, L.C) == 0) bw.x3a = bw.x3a_buf;
         }
-    // the split weight streams of PatchMerge / PatchSplit (fused_rowgemm.h rowgemm_x3_kernel; ESCX_ROWGEMM_X3=0: fp32 MFMA)
-    static const bool rg_x3 = [] { const char* e = getenv("ESCX_ROWGEMM_X3"); return !(e && e[0] == '0'); }();
+    // the split weight streams of PatchMerge / PatchSplit (fused_rowgemm.h rowgemm_x3_kernel)
     for (Layer& L : h->layers) {
         const int KP = L.scale == 1 ? 2 * L.Cp : L.Cp, Np = L.scale == 1 ? L.CoutP : 2 * L.CoutP;
-        const bool want = rg_x3 && L.scale != 0 && L.sub_wf && (KP == 80 || KP == 96 || KP == 144 || KP == 160 || KP == 192 || KP == 288 || KP == 384);
-        if (!want) { if (L.sub_x3) { ESCX_HIP(hipDeviceSynchronize()); (void)hipFree(L.sub_x3); L.sub_x3 = nullptr; } continue; }
-        if (!L.sub_x3) ESCX_HIP(hipMalloc(&L.sub_x3, rowgemm_x3_bytes(KP, Np)));
-        rowgemm_x3_pack(L.sub_wf, L.sub_x3, KP, Np, st, rowgemm_x3_terms());
-        if (L.scale == 2 && (L.Cp == 80 || L.Cp == 96 || L.Cp == 144) && L.Cp <= x3_max) {       // PatchSplit folded into the split-operand MLP's epilogue
-            if (!L.sub_x3s) ESCX_HIP(hipMalloc(&L.sub_x3s, mlp_x3_split_bytes(L.Cp, Np)));
-            mlp_x3_split_pack(L.sub_wf, L.sub_x3s, L.Cp, Np, st);
-        }
+        const bool want = split_on && h->rowgemm_x3 && L.scale != 0 && L.sub_wf && (KP == 80 || KP == 96 || KP == 144 || KP == 160 || KP == 192 || KP == 288 || KP == 384);
+        L.sub_x3 = nullptr; L.sub_x3s = nullptr;
+        if (!want || !grab(&L.sub_x3_buf, rowgemm_x3_bytes(KP, Np))) continue;
+        if (rowgemm_x3_pack(L.sub_wf, L.sub_x3_buf, KP, Np, st, nt, no_act_scale ? nullptr : L.sub_g, L.sub_b, (L.scale == 1 ? 2 : 1) * L.C) == 0) L.sub_x3 = L.sub_x3_buf;
+        if (L.scale == 2 && (L.Cp == 80 || L.Cp == 96 || L.Cp == 144) && L.Cp <= x3_max && grab(&L.sub_x3s_buf, mlp_x3_split_bytes(L.Cp, Np)) &&       // PatchSplit folded into the split-operand MLP's epilogue
+            mlp_x3_split_pack(L.sub_wf, L.sub_x3s_buf, L.Cp, Np, st) == 0) L.sub_x3s = L.sub_x3s_buf;
     }
     h->pvq_tab_stale = false;
-    return launch_ok("pvq_tables");
+    return launch_ok("derived images");
 }
+
+// escx_set_precision / escx_get_precision (include/escx.h): the arithmetic of the K = C contractions of this handle.  Takes effect with the next call: the
+// split images are derived state and are re-packed on that call's stream.
+extern "C" int escx_set_precision(escx_handle h, int mode) {
+    if (!h) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null handle");
+    if (mode != ESCX_PRECISION_FP32 && mode != ESCX_PRECISION_BF16X3 && mode != ESCX_PRECISION_F16X2)
+        ESCX_FAIL(ESCX_ERR_INVALID_ARG, "precision mode %d (0 = fp32 MFMA, 3 = three bf16 terms, 2 = two fp16 terms)", mode);
+    if (mode != h->prec) { h->prec = mode; h->pvq_tab_stale = true; }
+    return ESCX_OK;
+}
+extern "C" int escx_get_precision(escx_handle h) { return h ? h->prec : ESCX_ERR_INVALID_ARG; }
 
 static int run_pvq_encode(escx_handle_s* h, const Quant& q, const float* enc, const float* dec, int B, int W, long long* codes,
                           long long bstride, float* loss, hipStream_t st) {

@@ -40,8 +40,11 @@ struct BlockW {                      // one SwinBlock, packed
     float *wqkvT = nullptr, *wprojT = nullptr, *w1T = nullptr, *w2T = nullptr;     // transposed copies for the dX GEMMs of the training step
     long long tab_off = -1;          // flat offset of attn.relative_position_bias_table (its gradient is written there directly)
     bool x3a_pairs = false;          // x3a is in pair order (output projection split as well: fused_attn.h X3P)
-    void* x3a = nullptr;             // fused_attn.h X3: Q / K / V tiles split into three bf16 terms (derived state like x3w)
-    void* x3w = nullptr;             // fused_mlp_x3.h: fc1 / fc2 split into three bf16 terms (device allocation of its own; derived state, rebuilt with the PVQ tables)
+    // Split-operand weight images (derived state, rebuilt by ensure_derived() in escx_api.cpp whenever the parameters or the precision mode change).  `x3a` / `x3w` are the
+    // ACTIVE images (null = this block runs the fp32-MFMA kernel); the `_buf` pointers own the allocations, which are made once and kept across mode switches.
+    void* x3a = nullptr;             // fused_attn.h X3: Q / K / V tiles split into terms
+    void* x3w = nullptr;             // fused_mlp_x3.h: fc1 / fc2 split into terms
+    void *x3a_buf = nullptr, *x3w_buf = nullptr;
 };
 
 struct Layer {                       // one TransformerLayer (attention.py:9-91)
@@ -53,8 +56,9 @@ struct Layer {                       // one TransformerLayer (attention.py:9-91)
     std::vector<BlockW> blocks;
     float *sub_g = nullptr, *sub_b = nullptr, *sub_w = nullptr;
     float *sub_wf = nullptr;         // scale-change weights in fragment order (fused LN + linear)
-    void* sub_x3 = nullptr;          // the same, split into three bf16 terms (rowgemm_x3_kernel; derived state like BlockW::x3w)
+    void* sub_x3 = nullptr;          // the same, split into terms (rowgemm_x3_kernel; active image / owning buffer as BlockW::x3w)
     void* sub_x3s = nullptr;         // PatchSplit weights in the k-slot order of mlp_x3_kernel's SPLIT epilogue
+    void *sub_x3_buf = nullptr, *sub_x3s_buf = nullptr;
     float *sub_wT = nullptr;         // transposed for dX (training)
 };
 
@@ -121,6 +125,11 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     int mlp_hs = 0;                  // ESCX_MLP_HS: 0 = automatic hidden split, 1 = off, n = force n-way (tuning)
     int attn_nw = 0;                 // ESCX_ATTN_NW: waves per workgroup of the fused attention kernel (4 or 8)
     bool use_fused_attn = true;      // ESCX_NO_FUSED_ATTN=1
+    // Arithmetic of the dense contractions with K = C (MLPs, Q / K / V, PatchMerge / PatchSplit, de-embedding): escx_set_precision (include/escx.h).
+    //   0 = fp32 MFMA, 3 = three bf16 terms per fp32 operand (exact split), 2 = two fp16 terms (range rule of split_terms.h).  The environment only sets the DEFAULT.
+    int prec = 2;
+    int mlp_x3_max = 384, attn_x3_max = 384;     // ESCX_MLP_X3 / ESCX_ATTN_X3: largest padded width that runs split (A/B and fallback switches; 0 = that family on the fp32 MFMA)
+    bool rowgemm_x3 = true, pvq_table = true;    // ESCX_ROWGEMM_X3=0 / ESCX_PVQ_TABLE=0
     bool attn_pack = true;           // ESCX_NO_ATTN_PACK=1: do not pack half-real windows of the H == 2 scale
 
     escx::Arena wts;                 // packed weights
@@ -131,7 +140,8 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     float *dft_w = nullptr, *idft_w = nullptr, *win2 = nullptr;
     float *dcc_w = nullptr, *dcc_b = nullptr, *dcv_w = nullptr, *dcv_b = nullptr;   // composed de-embedding: interior GEMM weights, border variants
     float* dch_w = nullptr;          // the interior weights as MFMA fragments for the halo-tiled kernel
-    void* dch_x2 = nullptr;          // ... as the two-term fp16 stream of deembed7_x2_kernel (derived inference state, rebuilt with the tables)
+    void* dch_x2 = nullptr;          // ... as the two-term fp16 stream of deembed7_x2_kernel (derived inference state, rebuilt with the tables; active pointer / owning buffer)
+    void* dch_x2_buf = nullptr;
     float *dc1_wT = nullptr, *idft_wT = nullptr;     // training: conv5x5 dX weights, transposed inverse-DFT matrix
 
     // ---- training step (train.hip) ----
@@ -173,15 +183,27 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     std::string prof_json;
 };
 
+#include "launch_prof.h"
 namespace escx {
 hipEvent_t prof_event(escx_handle_s* h);
+// One profiled launch group.  The group's first kernel launch through ESCX_LAUNCH (launch_prof.h: every launcher of the inference path) is made with
+// hipExtLaunchKernel, so the pair (lt.start, lt.stop) brackets the DISPATCH ITSELF - begin and end of the kernel as rocprofv3's kernel trace sees them.  A group of
+// several launches ends with a marker event after the last one; a group whose launches do not go through ESCX_LAUNCH (train.hip's own kernels) is bracketed by
+// marker events as before; a group that launched nothing leaves a (near zero-length) record, which the callers that probe for an instantiation pop again.
 struct ProfScope {
-    escx_handle_s* h; hipStream_t st; hipEvent_t a;
-    ProfScope(escx_handle_s* h_, hipStream_t s) : h(h_), st(s), a(nullptr) { if (h->prof) { a = prof_event(h); (void)hipEventRecord(a, st); } }
+    escx_handle_s* h; hipStream_t st; LaunchTimer lt; LaunchTimer* prev = nullptr; hipEvent_t m_start = nullptr;
+    ProfScope(escx_handle_s* h_, hipStream_t s) : h(h_), st(s) {
+        if (h->prof) { m_start = prof_event(h); (void)hipEventRecord(m_start, st); lt.start = prof_event(h); lt.stop = prof_event(h); prev = g_launch_timer; g_launch_timer = &lt; }
+    }
+    ~ProfScope() { if (lt.start && g_launch_timer == &lt) g_launch_timer = prev; }
     void end(const std::string& name, double flops, double bytes) {
-        if (!a) return;
-        hipEvent_t b = prof_event(h); (void)hipEventRecord(b, st);
-        h->prof_recs.push_back({name, flops, bytes, a, b}); a = nullptr;
+        if (!lt.start) return;
+        g_launch_timer = prev;
+        if (lt.launches != 1) (void)hipEventRecord(lt.stop, st);
+        const bool dispatch_timed = lt.launches >= 1;
+        h->prof_recs.push_back({name, flops, bytes, dispatch_timed ? lt.start : m_start, lt.stop});
+        h->prof_pool.push_back(dispatch_timed ? m_start : lt.start);
+        lt.start = nullptr;
     }
 };
 }  // namespace escx

@@ -84,8 +84,10 @@ __global__ __launch_bounds__(256) void attn_x3p_pack_kernel(const f32x4* __restr
 }
 // builds the X3 stream from the fp32 fragment stream (BlockW::waf): one thread per (group, tile, K-step or projection fragment, lane)
 // NT = 2 (split_terms.h): two fp16 terms per weight, scaled by the power of two of the block's max |w| - the stream then ends with two 16-byte slots,
-// [0] bits of max |w| (absmax_bits_kernel over the fp32 fragment stream, before this kernel), [1] {2^-k, 2^k, 0, 0} written here.
-__global__ __launch_bounds__(256) void attn_x3_pack_kernel(const f32x4* __restrict__ waf, bf16x8* __restrict__ out, int n_tiles, int TPG, int KK, int KS, int TF, unsigned proj_mask, int NT = 3) {
+// [0] bits of max |w| (absmax_bits_kernel over the fp32 fragment stream, before this kernel), [1] {2^-k / sx, 2^k sx, sx, 0} written here: sx = the power-of-two scale of
+// the LayerNorm output that is split against these weights (range rule of split_terms.h; bound from the norm's gamma / beta over n_ln padded channels, C real ones).
+__global__ __launch_bounds__(256) void attn_x3_pack_kernel(const f32x4* __restrict__ waf, bf16x8* __restrict__ out, int n_tiles, int TPG, int KK, int KS, int TF, unsigned proj_mask, int NT = 3,
+                                                           const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr, int n_ln = 0, int C = 0) {
     const int per_tile = (KS > KK ? KS : KK) * 64;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)n_tiles * per_tile) return;
@@ -114,7 +116,10 @@ __global__ __launch_bounds__(256) void attn_x3_pack_kernel(const f32x4* __restri
         bf16x8 t[2];
         split_terms<2>(v, t, sc);
         dst[(f * 2 + 0) * 64 + lane] = t[0]; dst[(f * 2 + 1) * 64 + lane] = t[1];
-        if (idx == 0) { float* o = reinterpret_cast<float*>(tail + 1); o[0] = 1.0f / sc; o[1] = sc; o[2] = 0.f; o[3] = 0.f; }
+        if (idx == 0) {
+            const float sx = gamma ? act_pow2_scale(ln_out_bound(gamma, beta, n_ln, C)) : 1.0f;
+            float* o = reinterpret_cast<float*>(tail + 1); o[0] = (1.0f / sc) * (1.0f / sx); o[1] = sc * sx; o[2] = sx; o[3] = 0.f;
+        }
     }
 }
 
@@ -144,7 +149,7 @@ struct AttnArgs {
     float* tape_xn; float* tape_qkv; float* tape_o; int ldq, ldo, hdp, nH;
     const void* x3_wf;          // X3 instantiations: the split weight stream (attn_x3_pack_kernel), else unused
     int x3_pairs;               // the stream is in pair order [Q0 K0 V0 Q1 K1 V1 P_lo P_hi] (attn_x3p_pack_kernel): X3P instantiations
-    const float* x3_scale;      // NT = 2 instantiations: {2^-k, 2^k} of the block's weight stream (its last 16 bytes)
+    const float* x3_scale;      // NT = 2 instantiations: {2^-k / sx, 2^k sx, sx} of the block's weight stream (its last 16 bytes; sx = scale of the LayerNorm output, split_terms.h)
 };
 
 // One 16-byte piece of a block-input row: plain, or combined on the fly from the hidden-split MLP's slabs (see AttnArgs).
@@ -257,8 +262,8 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void at
     const int nW = a.nWh * a.nWw;
     f32x4 xf[X3 ? 1 : TMW][X3 ? 1 : KK];
     bf16x8 xs[X3 ? TMW : 1][NT][X3 ? KS : 1];                // X3: LayerNorm output split into NT terms, lane (slot l15, group lg) holds channels 32 s + 8 lg .. + 7
-    float x2_dn = 1.f, x2_up = 1.f;            // NT = 2: 2^-k, 2^k of the block's scaled weights
-    if constexpr (NT == 2) { x2_dn = a.x3_scale[0]; x2_up = a.x3_scale[1]; }
+    float x2_dn = 1.f, x2_up = 1.f, x2_sx = 1.f;   // NT = 2: 2^-k / sx, 2^k sx of the block's scaled weights, sx = the power-of-two scale of the LayerNorm output
+    if constexpr (NT == 2) { x2_dn = a.x3_scale[0]; x2_up = a.x3_scale[1]; x2_sx = a.x3_scale[2]; }
     int tok[TMW];                               // this lane's token row (element offset / CP), or -1
     bool lastH[TMW], lastW[TMW];
 #pragma unroll
@@ -304,6 +309,10 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void at
                 for (int e = 0; e < 4; ++e) {
                     xn[e] = tok[t] >= 0 ? (xv[ks][e] - mean) * rstd * g0v[e] + b0v[e] : 0.f;            // padded slots become zero rows AFTER the norm
                     xn[4 + e] = tok[t] >= 0 ? (xv[ks][4 + e] - mean) * rstd * g1v[e] + b1v[e] : 0.f;
+                }
+                if constexpr (NT == 2) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xn[e] *= x2_sx;
                 }
                 bf16x8 tt[NT];
                 split_terms<NT>(xn, tt);
@@ -811,8 +820,8 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, 1, X3>())) void attn
     }
     f32x4 xf[X3 ? 1 : KK];
     bf16x8 xs[NT][X3 ? KS : 1];
-    float x2_dn = 1.f, x2_up = 1.f;
-    if constexpr (NT == 2) { x2_dn = a.x3_scale[0]; x2_up = a.x3_scale[1]; }
+    float x2_dn = 1.f, x2_up = 1.f, x2_sx = 1.f;
+    if constexpr (NT == 2) { x2_dn = a.x3_scale[0]; x2_up = a.x3_scale[1]; x2_sx = a.x3_scale[2]; }
     if constexpr (X3) {
         const float* xrow = a.src + (size_t)(tok < 0 ? 0 : tok) * CP;
         float xv[KS][8];
@@ -845,6 +854,10 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, 1, X3>())) void attn
             for (int e = 0; e < 4; ++e) {
                 xn[e] = tok >= 0 ? (xv[ks][e] - mean) * rstd * g0v[e] + b0v[e] : 0.f;
                 xn[4 + e] = tok >= 0 ? (xv[ks][4 + e] - mean) * rstd * g1v[e] + b1v[e] : 0.f;
+            }
+            if constexpr (NT == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xn[e] *= x2_sx;
             }
             bf16x8 tt[NT];
             split_terms<NT>(xn, tt);

@@ -192,25 +192,46 @@ __global__ __launch_bounds__(512) void deembed7_x2_kernel(DeembedArgs a, const b
     const f32x4 scv = *reinterpret_cast<const f32x4*>(wf2 + (size_t)NSTEP * 2 * 64 + 1);       // {2^-k, 2^k, 0, 0}
 
     // ---- tile + halo -> two fp16 planes (zero outside the map) ----
+    // Range rule (split_terms.h): the decoder tokens reach this kernel un-normalised (scale.py:73-81 has no norm in front of de_proj1), so no bound is known when the image is
+    // packed: the workgroup scales ITS tile by the power of two that brings the tile's own max |x| into [2^13, 2^14) before the split and the accumulators back afterwards
+    // (exact; a pixel that lies in two tiles' halos may be split under two scales - either way to 2^-22 of the tile's largest value).
     const float* xb = a.x + (size_t)b * a.H * a.W * CP;
-    for (int v = tid; v < HH * HW * Q8; v += 512) {
+    constexpr int NV = (HH * HW * Q8 + 511) / 512;
+    float xr[NV][8];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + 512 * i;
         const int pix = v / Q8, q = v - pix * Q8;
         const int ph = pix / HW, pw = pix - ph * HW;
         const int gh = h0 - 3 + ph, gw = w0 - 3 + pw;
-        float xv[8];
-        if (gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) {
+        if (v < HH * HW * Q8 && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) {
             const float* p = xb + ((size_t)gh * a.W + gw) * CP + 8 * q;
             const f32x4 u0 = ld4(p), u1 = ld4(p + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { xv[e] = u0[e]; xv[4 + e] = u1[e]; }
+            for (int e = 0; e < 4; ++e) { xr[i][e] = u0[e]; xr[i][4 + e] = u1[e]; amax = fmaxf(amax, fmaxf(fabsf(u0[e]), fabsf(u1[e]))); }
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xv[e] = 0.f;
+            for (int e = 0; e < 8; ++e) xr[i][e] = 0.f;
         }
-        bf16x8 t[2];
-        split_terms<2>(xv, t);
-        *reinterpret_cast<bf16x8*>(xh0 + pix * PS + 8 * q) = t[0];
-        *reinterpret_cast<bf16x8*>(xh1 + pix * PS + 8 * q) = t[1];
+    }
+    __shared__ float de2_red[NW];
+    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (lane == 0) de2_red[wave] = amax;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NW; ++i) amax = fmaxf(amax, de2_red[i]);
+    const float act_sc = act_pow2_scale(amax), act_inv = 1.0f / act_sc;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + 512 * i;
+        if (v < HH * HW * Q8) {
+            const int pix = v / Q8, q = v - pix * Q8;
+            bf16x8 t[2];
+            split_terms<2>(xr[i], t, act_sc);
+            *reinterpret_cast<bf16x8*>(xh0 + pix * PS + 8 * q) = t[0];
+            *reinterpret_cast<bf16x8*>(xh1 + pix * PS + 8 * q) = t[1];
+        }
     }
 
     const bool seg1 = w0 + 16 < a.W;
@@ -243,7 +264,7 @@ __global__ __launch_bounds__(512) void deembed7_x2_kernel(DeembedArgs a, const b
     if (h >= a.H) return;
     const int Q = a.pf * a.pt;
     const f32x4 bv = ld4(a.bias + 4 * lg);
-    const f32x4 accs[2] = {acc0 * scv[0], acc1 * scv[0]};
+    const f32x4 accs[2] = {acc0 * (scv[0] * act_inv), acc1 * (scv[0] * act_inv)};
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int w = w0 + 16 * t + l15;

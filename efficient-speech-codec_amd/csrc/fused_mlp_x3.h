@@ -68,8 +68,11 @@ constexpr int mlp_x3_stage_frags(int CP, int NT = 3) {
 //   fc1 fragment f = (s * 2 + tt) * 3 + i          -> lane (n, g) holds term i of W1[16 (2p + tt) + n][32 s + 8 g + e], e = 0..7 (zero beyond Cp)
 //   fc2 fragment f = 6 KS + o * 3 + i              -> lane (c, g) holds term i of W2[16 o + c][unit(g, e)], unit = 16 (2p) + 4 g + e for e < 4, 16 (2p + 1) + 4 g + e - 4 otherwise
 // (the k-slot <-> hidden unit map the kernel's two fc1 accumulator tiles dictate).  One thread per (pair, fragment triple, lane).
-// NT = 2: the image ends with two 16-byte slots - [0] bits of max |w1|, max |w2| (absmax_bits_kernel, before this kernel), [1] {2^-k1, 2^-k2, 2^k1, 2^k2} written here.
-__global__ __launch_bounds__(256) void mlp_x3_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, bf16x8* __restrict__ out, int Cp, int HP, int KS, int KK, int NT) {
+// NT = 2: the image ends with three 16-byte slots - [0] bits of max |w1|, max |w2|, max_row ||w1_row||^2 (absmax_bits_kernel / rownorm2_max_bits_kernel, before this kernel),
+// [1] {2^-k1 / sx, 2^-k2 / sh, 2^k1 sx, 2^k2 sh} and [2] {sx, sh} written here: sx, sh = the power-of-two scales of the LayerNorm output and of the GELU output (split_terms.h
+// range rule; bounds from ln2's gamma / beta, the fc1 row norms and b1).
+__global__ __launch_bounds__(256) void mlp_x3_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, bf16x8* __restrict__ out, int Cp, int HP, int KS, int KK, int NT,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ b1, int C) {
     const int CH = 2 * NT * KS + NT * KK, triples = 2 * KS + KK;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)(HP / 32) * triples * 64;
@@ -104,7 +107,19 @@ __global__ __launch_bounds__(256) void mlp_x3_pack_kernel(const float* __restric
         _Float16 h0[8], h1[8];
         split2_f16(v, t3 < 2 * KS ? sc1 : sc2, h0, h1);
         dst[0] = pack8h(h0); dst[64] = pack8h(h1);
-        if (idx == 0) { float* f = reinterpret_cast<float*>(tail + 1); f[0] = 1.0f / sc1; f[1] = 1.0f / sc2; f[2] = sc1; f[3] = sc2; }
+        if (idx == 0) {
+            float sx = 1.f, sh = 1.f;             // gamma == nullptr: no activation scales (the round-5 form; tagged builds, ESCX_X2_NO_ACT_SCALE)
+            if (gamma) {
+                float gb = 0.f, mb1 = 0.f;
+                const float bx = ln_out_bound(gamma, beta, Cp, C, &gb);
+                for (int i = 0; i < HP; ++i) mb1 = fmaxf(mb1, fabsf(b1[i]));
+                const float bh = sqrtf(__uint_as_float(mx[2])) * sqrtf((float)C) * gb + mb1;       // |gelu(h)| <= |h| <= ||w1_row|| ||xn|| + |b1|
+                sx = act_pow2_scale(bx); sh = act_pow2_scale(bh);
+            }
+            float* f = reinterpret_cast<float*>(tail + 1);
+            f[0] = (1.0f / sc1) * (1.0f / sx); f[1] = (1.0f / sc2) * (1.0f / sh); f[2] = sc1 * sx; f[3] = sc2 * sh;
+            f[4] = sx; f[5] = sh; f[6] = 0.f; f[7] = 0.f;
+        }
     }
 }
 
@@ -141,7 +156,12 @@ __global__ __launch_bounds__(256) void mlp_x3_split_pack_kernel(const f32x4* __r
 template <int CP> constexpr int mlp_x3_min_waves() { return CP <= 96 ? 4 : (CP <= 192 ? 2 : 1); }
 
 // SPLIT: PatchSplit in the epilogue (as fused_mlp.h SPLIT): LayerNorm(C) of x + mlp(x) in registers, Linear(C -> 2 C') with split operands, two-row scatter; x is not written.
-template <int CP, int NW, bool SPLIT = false, int NT = 3>
+// PIPE (round 6; narrow layers whose pair of hidden tiles is ONE weight stage, CP <= 96): the main loop is software-pipelined over the pairs - iteration p issues the fc1
+// MFMAs of pair p + 1, the GELU + operand split of pair p (VALU) and the fc2 MFMAs of pair p - 1 as three INDEPENDENT instruction streams, so that one wave keeps the
+// matrix pipe, the VALU and the LDS busy at the same time instead of walking fc1 -> GELU -> fc2 in dependence order (round 5: both pipes ~50 % busy, in phase across the
+// barrier-synchronised waves of a workgroup).  Every accumulator sees the same products in the same order: bit-identical to the unpipelined loop.  The weight stage of a
+// pair is staged as two pieces (fc1 fragments, fc2 fragments) in two double-buffered rings of the same total size.
+template <int CP, int NW, bool SPLIT = false, int NT = 3, bool PIPE = false>
 __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kernel(MlpArgs a) {
     constexpr int KS = mlp_x3_ks(CP), KK = CP / 16, CH = mlp_x3_frags(CP, NT), NOP = (KK + 1) / 2;
     constexpr bool SINGLE = mlp_x3_single(CP, NT);
@@ -186,9 +206,31 @@ __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kern
         for (int c = wave; c < cnt; c += NW)
             __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(dst + c * 64), 16, 0, 0);
     };
-    issue(0);
+    // PIPE: ring 1 = [2][F1] fc1 fragments of pairs p + 1 / p + 2, ring 2 = [2][F2] fc2 fragments of pairs p - 1 / p
+    constexpr int F1 = N2 * KS, F2 = CH - F1;
+    static_assert(!PIPE || SINGLE, "the pipelined loop needs the one-stage-per-pair layout");
+    auto issue_f1 = [&](int p) {
+        if (p >= p1) return;
+        const bf16x8* src = wsrc + ((size_t)p * CH) * 64 + lane;
+        bf16x8* dst = &x3_wbuf[(((p - p0) & 1) * F1) * 64];
+        for (int c = wave; c < F1; c += NW)
+            __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(dst + c * 64), 16, 0, 0);
+    };
+    auto issue_f2 = [&](int p) {
+        if (p >= p1) return;
+        const bf16x8* src = wsrc + ((size_t)p * CH + F1) * 64 + lane;
+        bf16x8* dst = &x3_wbuf[(2 * F1 + ((p - p0) & 1) * F2) * 64];
+        for (int c = wave; c < F2; c += NW)
+            __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(dst + c * 64), 16, 0, 0);
+    };
+    if constexpr (PIPE) { issue_f1(p0); issue_f1(p0 + 1); } else issue(0);
     f32x4 x2sc = {1.f, 1.f, 1.f, 1.f};          // NT = 2: {2^-k1, 2^-k2, 2^k1, 2^k2} of this block's weight image
-    if constexpr (NT == 2) x2sc = *reinterpret_cast<const f32x4*>(wsrc + (size_t)n_pairs_all * CH * 64 + 1);
+    float x2sx = 1.f, x2sh = 1.f;               // NT = 2: power-of-two scales of the LayerNorm output / the GELU output (range rule, split_terms.h); folded into x2sc
+    if constexpr (NT == 2) {
+        x2sc = *reinterpret_cast<const f32x4*>(wsrc + (size_t)n_pairs_all * CH * 64 + 1);
+        const f32x4 act = *reinterpret_cast<const f32x4*>(wsrc + (size_t)n_pairs_all * CH * 64 + 2);
+        x2sx = act[0]; x2sh = act[1];
+    }
 
     // ---- rows -> k-slot layout of the 32-deep MFMA (lane (row l15, slot group lg) holds channels 32 s + 8 lg .. + 7), LayerNorm in registers, split ----
     const int row = m0 + l15;
@@ -227,6 +269,10 @@ __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kern
                 xn[e] = (xv[s][e] - mean) * rstd * g0[e] + b0[e];                  // gamma = beta = 0 in the pads -> 0
                 xn[4 + e] = (xv[s][4 + e] - mean) * rstd * g1[e] + b1[e];
             }
+            if constexpr (NT == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xn[e] *= x2sx;
+            }
             bf16x8 t[NT];
             split_rows<NT>(xn, t);
 #pragma unroll
@@ -249,6 +295,91 @@ __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kern
         ++g;
         return wb;
     };
+    if constexpr (PIPE) {
+        // the three streams of one pair, on explicit operands
+        // fc1 biases are loaded ONE ITERATION AHEAD, before the iteration's weight DMAs are issued: a load that follows the DMAs in program order can only be waited for
+        // with vmcnt(0), i.e. together with the next stage's fragments (loads return in order) - that would put the DMA latency back on the critical path
+        auto load_bias = [&](int p, f32x4& b0, f32x4& b1v) { const int q = p < p1 ? p : p1 - 1; b0 = ld4(a.b1 + 32 * q + 4 * lg); b1v = ld4(a.b1 + 32 * q + 16 + 4 * lg); };
+        auto fc1_pair = [&](f32x4 b0, f32x4 b1v, const bf16x8* wb, f32x4& h0, f32x4& h1) {          // wb: ring-1 slot of the pair (+ lane)
+            h0 = b0; h1 = b1v;
+            if constexpr (NT == 2) { h0 *= x2sc[2]; h1 *= x2sc[2]; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8* wf = wb + (size_t)(s * N2) * 64;
+                bf16x8 w0[NT], w1[NT];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) { w0[i] = wf[i * 64]; w1[i] = wf[(NT + i) * 64]; }
+#define ESCX_X3_FC1(I, J) h0 = mma_x<NT>(w0[I], xs[J][s], h0); h1 = mma_x<NT>(w1[I], xs[J][s], h1);
+                if constexpr (NT == 3) { ESCX_X3_TERMS(ESCX_X3_FC1) } else { ESCX_X2_TERMS(ESCX_X3_FC1) }
+#undef ESCX_X3_FC1
+            }
+        };
+        auto gelu_split = [&](f32x4 h0, f32x4 h1, bf16x8 (&hs3)[NT]) {
+            float hv[8];
+            if constexpr (NT == 2) { h0 *= x2sc[0]; h1 *= x2sc[0]; }
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {                      // packed-fp32 GELU (gelu_bf2: bit-identical to gelu_bf)
+                const f32x2 g0 = gelu_bf2(f32x2{h0[e], h0[e + 1]}), g1 = gelu_bf2(f32x2{h1[e], h1[e + 1]});
+                hv[e] = g0[0]; hv[e + 1] = g0[1]; hv[4 + e] = g1[0]; hv[4 + e + 1] = g1[1];
+            }
+            if constexpr (NT == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] *= x2sh;
+            }
+            split_rows<NT>(hv, hs3);
+        };
+        auto fc2_pair = [&](const bf16x8* w2b, const bf16x8 (&hs3)[NT]) {              // w2b: ring-2 slot of the pair (+ lane)
+#pragma unroll
+            for (int op = 0; op < NOP; ++op) {
+                const int o = 2 * op;
+                const bf16x8* wf = w2b + (size_t)(op * N2) * 64;
+                bf16x8 wa[NT], wn[NT];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) { wa[i] = wf[i * 64]; if (o + 1 < KK) wn[i] = wf[(NT + i) * 64]; }
+#define ESCX_X3_FC2(I, J) acc[o] = mma_x<NT>(wa[I], hs3[J], acc[o]); if (o + 1 < KK) acc[o + 1] = mma_x<NT>(wn[I], hs3[J], acc[o + 1]);
+                if constexpr (NT == 3) { ESCX_X3_TERMS(ESCX_X3_FC2) } else { ESCX_X2_TERMS(ESCX_X3_FC2) }
+#undef ESCX_X3_FC2
+            }
+        };
+        auto ring1 = [&](int p) -> const bf16x8* { return &x3_wbuf[(((p - p0) & 1) * F1) * 64 + lane]; };
+        auto ring2 = [&](int p) -> const bf16x8* { return &x3_wbuf[(2 * F1 + ((p - p0) & 1) * F2) * 64 + lane]; };
+        auto stage_sync = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); };
+        f32x4 hc0, hc1, hn0, hn1, bc0, bc1, bn0, bn1;
+        bf16x8 hs_prev[NT], hs_cur[NT];
+        load_bias(p0, bc0, bc1);
+        // fill: fc1 of the first pair (its fragments and the next pair's are already on their way)
+        stage_sync();
+        load_bias(p0 + 1, bn0, bn1);
+        fc1_pair(bc0, bc1, ring1(p0), hc0, hc1);
+        // first iteration: fc1(p0 + 1) || GELU(p0)
+        stage_sync();
+        bc0 = bn0; bc1 = bn1; load_bias(p0 + 2, bn0, bn1);
+        issue_f1(p0 + 2); issue_f2(p0);
+        fc1_pair(bc0, bc1, ring1(p0 + 1), hn0, hn1);
+        gelu_split(hc0, hc1, hs_prev);
+        hc0 = hn0; hc1 = hn1;
+        // steady state: fc1(p + 1) || GELU(p) || fc2(p - 1)
+        for (int p = p0 + 1; p + 1 < p1; ++p) {
+            stage_sync();
+            bc0 = bn0; bc1 = bn1; load_bias(p + 2, bn0, bn1);
+            issue_f1(p + 2); issue_f2(p);
+            fc1_pair(bc0, bc1, ring1(p + 1), hn0, hn1);
+            gelu_split(hc0, hc1, hs_cur);
+            fc2_pair(ring2(p - 1), hs_prev);
+            hc0 = hn0; hc1 = hn1;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) hs_prev[i] = hs_cur[i];
+        }
+        // last pair: GELU(p1 - 1) || fc2(p1 - 2)
+        stage_sync();
+        issue_f2(p1 - 1);
+        gelu_split(hc0, hc1, hs_cur);
+        fc2_pair(ring2(p1 - 2), hs_prev);
+        // drain: fc2(p1 - 1)
+        stage_sync();
+        fc2_pair(ring2(p1 - 1), hs_cur);
+        g = 0;
+    } else
     for (int p = p0; p < p1; ++p) {
         const f32x4 bias0 = ld4(a.b1 + 32 * p + 4 * lg), bias1 = ld4(a.b1 + 32 * p + 16 + 4 * lg);
         const bf16x8* wb = nullptr;
@@ -281,6 +412,10 @@ __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kern
         if constexpr (NT == 2) { h0 *= x2sc[0]; h1 *= x2sc[0]; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { hv[e] = gelu_bf(h0[e]); hv[4 + e] = gelu_bf(h1[e]); }
+        if constexpr (NT == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] *= x2sh;
+        }
         bf16x8 hs3[NT];
         split_rows<NT>(hv, hs3);
 #endif

@@ -31,7 +31,7 @@ struct RowGemmArgs {
     // combine-on-load (COMB instantiations): x is still split over the comb_n fc2 slabs of the last block's hidden-split MLP (see AttnArgs in fused_attn.h)
     const float* comb_partial; const float* comb_bias; long long comb_stride; int comb_n;
     const void* x3_wf;          // rowgemm_x3_kernel: split weight stream [output tile][3 KS fragments] (attn_x3_pack_kernel), else unused
-    const float* x3_scale;      // NT = 2: {2^-k, 2^k} of the scaled two-term stream (its last 16 bytes)
+    const float* x3_scale;      // NT = 2: {2^-k / sx, 2^k sx, sx} of the scaled two-term stream (its last 16 bytes)
 };
 
 template <int KP, int SEGS, int TM, int NW, int UT, bool COMB = false>
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(64 * NW) void rowgemm_x3_kernel(RowGemmArgs a) {
     issue(0, 0);
 
     bf16x8 xs[TM][NT][KS];
-    float x2_dn = 1.f;
-    if constexpr (NT == 2) x2_dn = a.x3_scale[0];
+    float x2_dn = 1.f, x2_sx = 1.f;             // NT = 2: 2^-k / sx of the scaled weights, sx = the power-of-two scale of the LayerNorm output (split_terms.h range rule)
+    if constexpr (NT == 2) { x2_dn = a.x3_scale[0]; x2_sx = a.x3_scale[2]; }
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         const int row = m0 + t * 16 + l15;
@@ -229,6 +229,10 @@ __global__ __launch_bounds__(64 * NW) void rowgemm_x3_kernel(RowGemmArgs a) {
             for (int e = 0; e < 4; ++e) {
                 xn[e] = (xv[ks][e] - mean) * rstd * g0[e] + b0[e];             // gamma = beta = 0 in the pads
                 xn[4 + e] = (xv[ks][4 + e] - mean) * rstd * g1[e] + b1[e];
+            }
+            if constexpr (NT == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xn[e] *= x2_sx;
             }
             bf16x8 tt[NT];
             split_terms<NT>(xn, tt);

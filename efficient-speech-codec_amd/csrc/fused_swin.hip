@@ -12,7 +12,7 @@ namespace escx {
 template <int CP, int TM>
 static void launch_mlp(const MlpArgs& a, hipStream_t s) {
     const int waves = (a.M + 16 * TM - 1) / (16 * TM);
-    hipLaunchKernelGGL((mlp_fused_kernel<CP, TM>), dim3((waves + 3) / 4), dim3(256), 0, s, a);
+    ESCX_LAUNCH((mlp_fused_kernel<CP, TM>), dim3((waves + 3) / 4), dim3(256), 0, s, a);
 }
 
 template <int CP, int TM, int NW>
@@ -21,11 +21,11 @@ static void launch_mlp_lds(const MlpArgs& a, hipStream_t s) {
     const int hs = a.HS > 1 ? a.HS : 1;
 #ifdef ESCX_EXPERIMENTAL       // in-launch combine of the hidden split: measured slower (profiles/r4_mlp_combine_ab.txt), tagged builds only
     if constexpr (TM == 1 && (CP == 192 || CP == 384) && (NW == 4 || NW == 8)) {      // the widths that take the hidden split
-        if (a.tickets) { hipLaunchKernelGGL((mlp_fused_lds_kernel<CP, TM, NW, 0, true>), dim3(((a.M + rows - 1) / rows) * hs), dim3(64 * NW), 0, s, a); return; }
+        if (a.tickets) { ESCX_LAUNCH((mlp_fused_lds_kernel<CP, TM, NW, 0, true>), dim3(((a.M + rows - 1) / rows) * hs), dim3(64 * NW), 0, s, a); return; }
     }
 #endif
     MlpArgs b = a; b.tickets = nullptr;
-    hipLaunchKernelGGL((mlp_fused_lds_kernel<CP, TM, NW>), dim3(((a.M + rows - 1) / rows) * hs), dim3(64 * NW), 0, s, b);
+    ESCX_LAUNCH((mlp_fused_lds_kernel<CP, TM, NW>), dim3(((a.M + rows - 1) / rows) * hs), dim3(64 * NW), 0, s, b);
 }
 
 // variant: 0 = wave-autonomous; otherwise LDS-staged with (TM, NW) = 1:(1,4) 2:(1,6) 3:(1,8) 4:(2,4) 5:(2,8)
@@ -47,7 +47,7 @@ static int launch_mlp_lds_variant(int variant, const MlpArgs& a, hipStream_t s) 
 template <int CP, int TM, int NW, int ABL>
 static void launch_mlp_abl(const MlpArgs& a, hipStream_t s) {
     const int rows = 16 * TM * NW;
-    hipLaunchKernelGGL((mlp_fused_lds_kernel<CP, TM, NW, ABL>), dim3((a.M + rows - 1) / rows), dim3(64 * NW), 0, s, a);
+    ESCX_LAUNCH((mlp_fused_lds_kernel<CP, TM, NW, ABL>), dim3((a.M + rows - 1) / rows), dim3(64 * NW), 0, s, a);
 }
 #endif
 
@@ -57,14 +57,14 @@ unsigned long long* debug_trace_buffer() { return g_mlp_trace; }
 
 void rows_combine(float* dst, const float* src, const float* partial, const float* bias, long long M, int Cp, int n, hipStream_t s) {
     const long long n4 = M * Cp / 4;
-    hipLaunchKernelGGL(rows_combine_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dst, src, partial, bias, M, Cp, n);
+    ESCX_LAUNCH(rows_combine_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dst, src, partial, bias, M, Cp, n);
 }
 
 // *hs: requested hidden split in, split actually used out (> 1: x is untouched, partial[hs][M][Cp] is filled, the caller runs rows_combine)
 template <int CP, int NW>
 static void launch_mlp_split(const MlpArgs& a, hipStream_t s) {
     const int rows = 16 * NW;
-    hipLaunchKernelGGL((mlp_fused_lds_kernel<CP, 1, NW, 0, false, true>), dim3((a.M + rows - 1) / rows), dim3(64 * NW), 0, s, a);
+    ESCX_LAUNCH((mlp_fused_lds_kernel<CP, 1, NW, 0, false, true>), dim3((a.M + rows - 1) / rows), dim3(64 * NW), 0, s, a);
 }
 
 int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* w1f, const float* b1,
@@ -167,26 +167,33 @@ int mlp_fused(float* x, int M, int C, int Cp, const float* gamma, const float* b
 
 // ---- fused MLP, fp32 operands split into three bf16 terms (fused_mlp_x3.h) ----
 // nt = 3: three bf16 terms per operand (exact split); nt = 2: two fp16 terms + per-matrix power-of-two scales in a 32-byte trailer (fused_mlp_x3.h)
-size_t mlp_x3_bytes(int Cp, int hiddenP, int nt) { return (size_t)(hiddenP / 32) * mlp_x3_frags(Cp, nt) * 1024 + 32; }
+size_t mlp_x3_bytes(int Cp, int hiddenP, int nt) { return (size_t)(hiddenP / 32) * mlp_x3_frags(Cp, nt) * 1024 + 48; }
 
-int mlp_x3_pack(const float* w1, const float* w2, void* image, int Cp, int hiddenP, hipStream_t s, int nt) {
+int mlp_x3_pack(const float* w1, const float* w2, void* image, int Cp, int hiddenP, hipStream_t s, int nt, const float* gamma, const float* beta, const float* b1, int C) {
     if (Cp % 16 || hiddenP % 32 || (nt != 2 && nt != 3)) return -1;
     const int KS = (Cp + 31) / 32, KK = Cp / 16;
     const long long total = (long long)(hiddenP / 32) * (2 * KS + KK) * 64;
     if (nt == 2) {
-        unsigned* mx = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(image) + mlp_x3_bytes(Cp, hiddenP, nt) - 32);
+        unsigned* mx = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(image) + mlp_x3_bytes(Cp, hiddenP, nt) - 48);
         if (hipMemsetAsync(mx, 0, 16, s) != hipSuccess) return -1;
         const long long n = (long long)hiddenP * Cp;
-        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, w1, n, mx);
-        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, w2, n, mx + 1);
+        ESCX_LAUNCH(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, w1, n, mx);
+        ESCX_LAUNCH(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, w2, n, mx + 1);
+        ESCX_LAUNCH(rownorm2_max_bits_kernel, dim3((unsigned)((hiddenP + 3) / 4)), dim3(256), 0, s, w1, hiddenP, Cp, Cp, mx + 2);      // range rule: bound of the fc1 outputs
     }
-    hipLaunchKernelGGL(mlp_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w1, w2, reinterpret_cast<bf16x8*>(image), Cp, hiddenP, KS, KK, nt);
+    ESCX_LAUNCH(mlp_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w1, w2, reinterpret_cast<bf16x8*>(image), Cp, hiddenP, KS, KK, nt, gamma, beta, b1, C);
     return 0;
 }
 
-template <int CP, int NW, int NT = 3>
+// Software-pipelined main loop (fused_mlp_x3.h PIPE) for the widths whose pair is one weight stage; ESCX_MLP_X3_PIPE=0: the round-5 loop (A/B, fallback; bit-identical results)
+static bool mlp_x3_pipe_on() { static const bool v = [] { const char* e = getenv("ESCX_MLP_X3_PIPE"); return !(e && e[0] == '0'); }(); return v; }
+
+template <int CP, int NW, int NT = 3, bool PIPE = false>
 static void launch_mlp_x3(const MlpArgs& a, hipStream_t s) {
-    auto kern = mlp_x3_kernel<CP, NW, false, NT>;
+    if constexpr (!PIPE && mlp_x3_single(CP, NT)) {
+        if (mlp_x3_pipe_on() && a.HS <= 1 && a.HT / 2 >= 2) { launch_mlp_x3<CP, NW, NT, true>(a, s); return; }
+    }
+    auto kern = mlp_x3_kernel<CP, NW, false, NT, PIPE>;
     constexpr int lds = 2 * mlp_x3_stage_frags(CP, NT) * 1024;
     if constexpr (lds > 48 * 1024) {            // function attributes are per device: one flag per device
         static std::atomic<unsigned> done{0};
@@ -195,7 +202,7 @@ static void launch_mlp_x3(const MlpArgs& a, hipStream_t s) {
         if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
     }
     const int hs = a.HS > 1 ? a.HS : 1;
-    hipLaunchKernelGGL(kern, dim3(((a.M + 16 * NW - 1) / (16 * NW)) * hs), dim3(64 * NW), lds, s, a);
+    ESCX_LAUNCH(kern, dim3(((a.M + 16 * NW - 1) / (16 * NW)) * hs), dim3(64 * NW), lds, s, a);
 }
 
 #ifdef ESCX_EXPERIMENTAL       // two row tiles per wave: measured slower (fused_mlp_x3.h)
@@ -209,7 +216,7 @@ static void launch_mlp_x3_rows(const MlpArgs& a, hipStream_t s) {
         const unsigned bit = 1u << (dev & 31);
         if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
     }
-    hipLaunchKernelGGL(kern, dim3((a.M + 16 * NW * TM - 1) / (16 * NW * TM)), dim3(64 * NW), lds, s, a);
+    ESCX_LAUNCH(kern, dim3((a.M + 16 * NW * TM - 1) / (16 * NW * TM)), dim3(64 * NW), lds, s, a);
 }
 #endif
 
@@ -217,13 +224,16 @@ size_t mlp_x3_split_bytes(int Cp, int Np) { return (size_t)(Np / 16) * 3 * ((Cp 
 int mlp_x3_split_pack(const float* wf, void* image, int Cp, int Np, hipStream_t s) {
     const int KK = Cp / 16, NT = Np / 16;
     const long long total = (long long)NT * ((KK + 1) / 2) * 64;
-    hipLaunchKernelGGL(mlp_x3_split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(wf), reinterpret_cast<bf16x8*>(image), NT, KK);
+    ESCX_LAUNCH(mlp_x3_split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(wf), reinterpret_cast<bf16x8*>(image), NT, KK);
     return 0;
 }
 
-template <int CP, int NW, int NT = 3>
+template <int CP, int NW, int NT = 3, bool PIPE = false>
 static void launch_mlp_x3_split(const MlpArgs& a, hipStream_t s) {
-    auto kern = mlp_x3_kernel<CP, NW, true, NT>;
+    if constexpr (!PIPE && mlp_x3_single(CP, NT)) {
+        if (mlp_x3_pipe_on() && a.HT / 2 >= 2) { launch_mlp_x3_split<CP, NW, NT, true>(a, s); return; }
+    }
+    auto kern = mlp_x3_kernel<CP, NW, true, NT, PIPE>;
     constexpr int lds = 2 * mlp_x3_stage_frags(CP, NT) * 1024;
     if constexpr (lds > 48 * 1024) {
         static std::atomic<unsigned> done{0};
@@ -231,7 +241,7 @@ static void launch_mlp_x3_split(const MlpArgs& a, hipStream_t s) {
         const unsigned bit = 1u << (dev & 31);
         if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
     }
-    hipLaunchKernelGGL(kern, dim3((a.M + 16 * NW - 1) / (16 * NW)), dim3(64 * NW), lds, s, a);
+    ESCX_LAUNCH(kern, dim3((a.M + 16 * NW - 1) / (16 * NW)), dim3(64 * NW), lds, s, a);
 }
 
 // *hs_io: requested hidden split in, split used out (> 1: x untouched, partial[hs][M][Cp] filled, the caller runs rows_combine) - as mlp_fused
@@ -312,7 +322,7 @@ static void launch_rowgemm_ws(const RowGemmArgs& a, hipStream_t s) {
         gx = std::max(1, (n_groups + it * NW - 1) / (it * NW));
     }
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      // per launch: function attributes are per device
-    hipLaunchKernelGGL(kern, dim3(gx, chunks), dim3(64 * NW), lds, s, b);
+    ESCX_LAUNCH(kern, dim3(gx, chunks), dim3(64 * NW), lds, s, b);
 }
 
 template <int KP, int SEGS>
@@ -341,7 +351,7 @@ static void launch_rowgemm_xs(const RowGemmArgs& a, hipStream_t s) {
     auto kern = rowgemm_xs_kernel<KP, SEGS, R, NW, NTW, WPS>;
     const int lds = R * KK * 1024;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);             // per launch: function attributes are per device
-    hipLaunchKernelGGL(kern, dim3((a.M + 16 * R - 1) / (16 * R)), dim3(64 * NW), lds, s, a);
+    ESCX_LAUNCH(kern, dim3((a.M + 16 * R - 1) / (16 * R)), dim3(64 * NW), lds, s, a);
 }
 
 template <int KP, int SEGS>
@@ -381,8 +391,8 @@ static int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
                     done.fetch_or(bit, std::memory_order_relaxed);
                 }
             }
-            if (a.x3_scale) hipLaunchKernelGGL(kern2, dim3((a.M + 16 * TMx * NWx - 1) / (16 * TMx * NWx), 1), dim3(64 * NWx), lds, s, a);
-            else hipLaunchKernelGGL(kern, dim3((a.M + 16 * TMx * NWx - 1) / (16 * TMx * NWx), 1), dim3(64 * NWx), lds, s, a);
+            if (a.x3_scale) ESCX_LAUNCH(kern2, dim3((a.M + 16 * TMx * NWx - 1) / (16 * TMx * NWx), 1), dim3(64 * NWx), lds, s, a);
+            else ESCX_LAUNCH(kern, dim3((a.M + 16 * TMx * NWx - 1) / (16 * TMx * NWx), 1), dim3(64 * NWx), lds, s, a);
             return 0;
         }
     }
@@ -395,7 +405,7 @@ static int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
             constexpr int TM = KP <= 192 ? 2 : 1;
             constexpr int NW = 4;
             RowGemmArgs b = a; b.nt_chunk = a.NT;
-            hipLaunchKernelGGL((rowgemm_fused_kernel<KP, SEGS, TM, NW, UT, true>), dim3((a.M + 16 * TM * NW - 1) / (16 * TM * NW), 1), dim3(64 * NW), 0, s, b);
+            ESCX_LAUNCH((rowgemm_fused_kernel<KP, SEGS, TM, NW, UT, true>), dim3((a.M + 16 * TM * NW - 1) / (16 * TM * NW), 1), dim3(64 * NW), 0, s, b);
             return 0;
         }
 #endif
@@ -421,23 +431,23 @@ static int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
     b.nt_chunk = (a.NT + chunks - 1) / chunks;
     b.nt_chunk = (b.nt_chunk + UT - 1) / UT * UT;                 // whole stages
     chunks = (a.NT + b.nt_chunk - 1) / b.nt_chunk;
-    hipLaunchKernelGGL((rowgemm_fused_kernel<KP, SEGS, TM, NW, UT>), dim3((a.M + rows - 1) / rows, chunks), dim3(64 * NW), 0, s, b);
+    ESCX_LAUNCH((rowgemm_fused_kernel<KP, SEGS, TM, NW, UT>), dim3((a.M + rows - 1) / rows, chunks), dim3(64 * NW), 0, s, b);
     return 0;
 }
 
 // 32-byte trailer: the two-term (nt = 2) form keeps max |w| and its power-of-two scales there (fused_attn.h attn_x3_pack_kernel)
 size_t rowgemm_x3_bytes(int KP, int Np) { return (size_t)(Np / 16) * 3 * ((KP + 31) / 32) * 1024 + 32; }
-int rowgemm_x3_pack(const float* wf, void* image, int KP, int Np, hipStream_t s, int nt) {
+int rowgemm_x3_pack(const float* wf, void* image, int KP, int Np, hipStream_t s, int nt, const float* gamma, const float* beta, int C) {
     const int KK = KP / 16, KS = (KP + 31) / 32, NT = Np / 16;
     const long long total = (long long)NT * (KS > KK ? KS : KK) * 64;
     if (nt == 2) {
         unsigned* mx = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(image) + rowgemm_x3_bytes(KP, Np) - 32);
         (void)hipMemsetAsync(mx, 0, 16, s);
         const long long n = (long long)NT * KK * 64 * 4;
-        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, wf, n, mx);
+        ESCX_LAUNCH(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, wf, n, mx);
     }
-    hipLaunchKernelGGL(attn_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(wf), reinterpret_cast<bf16x8*>(image),
-                       NT, 1, KK, KS, 3 * KS, 0u, nt == 2 ? 2 : 3);
+    ESCX_LAUNCH(attn_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(wf), reinterpret_cast<bf16x8*>(image),
+                       NT, 1, KK, KS, 3 * KS, 0u, nt == 2 ? 2 : 3, gamma, beta, KP, C);
     return 0;
 }
 
@@ -481,8 +491,8 @@ int deembed7_x2_pack(const float* wfrag, void* image, int Cp, hipStream_t s) {
     unsigned* mx = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(image) + deembed7_x2_bytes(Cp) - 32);
     if (hipMemsetAsync(mx, 0, 32, s) != hipSuccess) return -1;
     const long long n = (long long)49 * (Cp / 16) * 64 * 4;
-    hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, wfrag, n, mx);
-    hipLaunchKernelGGL(deembed7_x2_pack_kernel, dim3((nsteps * 64 + 255) / 256), dim3(256), 0, s, reinterpret_cast<const f32x4*>(wfrag), reinterpret_cast<bf16x8*>(image), Cp, nsteps);
+    ESCX_LAUNCH(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, wfrag, n, mx);
+    ESCX_LAUNCH(deembed7_x2_pack_kernel, dim3((nsteps * 64 + 255) / 256), dim3(256), 0, s, reinterpret_cast<const f32x4*>(wfrag), reinterpret_cast<bf16x8*>(image), Cp, nsteps);
     return 0;
 }
 
@@ -498,13 +508,13 @@ int deembed7_fused(const float* tok, int B, int H, int W, int Cp, const float* w
         int dev = 0; (void)hipGetDevice(&dev);
         const unsigned bit = 1u << (dev & 31);
         if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const bf16x8*>(x2_image));
+        ESCX_LAUNCH(kern, dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const bf16x8*>(x2_image));
         return 0;
     }
     switch (Cp) {               // LDS: (8+6) x (32+6) pixels x (Cp+4) dwords + two 7-tap weight stages <= 160 KiB
-        case 16: hipLaunchKernelGGL(deembed7_kernel<16>, dim3(grid), dim3(512), 0, s, a); return 0;
-        case 32: hipLaunchKernelGGL(deembed7_kernel<32>, dim3(grid), dim3(512), 0, s, a); return 0;
-        case 48: hipLaunchKernelGGL(deembed7_kernel<48>, dim3(grid), dim3(512), 0, s, a); return 0;
+        case 16: ESCX_LAUNCH(deembed7_kernel<16>, dim3(grid), dim3(512), 0, s, a); return 0;
+        case 32: ESCX_LAUNCH(deembed7_kernel<32>, dim3(grid), dim3(512), 0, s, a); return 0;
+        case 48: ESCX_LAUNCH(deembed7_kernel<48>, dim3(grid), dim3(512), 0, s, a); return 0;
         default: return -1;
     }
 }
@@ -519,7 +529,7 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
     if (a.tape_qkv) {               // training forward (TAPE instantiations for the memory-bound widths; the deep scales keep their GEMMs)
         if constexpr (CP == 16 || CP == 48 || CP == 80 || CP == 96) {      // C = 144 / 192 measured: no gain over their GEMM sequence (62.5 vs 62.3-62.6 ms per step)
             if (gs == 1 && a.comb_n == 0) {
-                hipLaunchKernelGGL((attn_fused_kernel<CP, MODE, UT, TMW, NW, false, true>), dim3((a.n_windows + per_block - 1) / per_block), dim3(64 * NW), 0, s, a);
+                ESCX_LAUNCH((attn_fused_kernel<CP, MODE, UT, TMW, NW, false, true>), dim3((a.n_windows + per_block - 1) / per_block), dim3(64 * NW), 0, s, a);
                 return 0;
             }
         }
@@ -528,7 +538,7 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
     if (a.comb_n > 0) {
 #ifdef ESCX_EXPERIMENTAL
         if constexpr (CP == 192 && MODE == 1) {        // the C = 192 blocks that follow a hidden-split MLP (ESC-Base / Large: 24 heads of 8)
-            if (gs == 1) { hipLaunchKernelGGL((attn_fused_kernel<CP, MODE, UT, TMW, NW, true>), dim3((a.n_windows + per_block - 1) / per_block), dim3(64 * NW), 0, s, a); return 0; }
+            if (gs == 1) { ESCX_LAUNCH((attn_fused_kernel<CP, MODE, UT, TMW, NW, true>), dim3((a.n_windows + per_block - 1) / per_block), dim3(64 * NW), 0, s, a); return 0; }
         }
 #endif
         return ESCX_COMB_UNSUPPORTED;
@@ -546,7 +556,7 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
                 const unsigned bit = 1u << (dev & 31);
                 if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
             }
-            hipLaunchKernelGGL(kern, dim3(((a.n_windows + per_block - 1) / per_block) * gs), dim3(64 * NW), lds, s, a);
+            ESCX_LAUNCH(kern, dim3(((a.n_windows + per_block - 1) / per_block) * gs), dim3(64 * NW), lds, s, a);
             return 0;
         }
         }
@@ -565,12 +575,12 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
                     done.fetch_or(bit, std::memory_order_relaxed);
                 }
             }
-            if (a.x3_scale) hipLaunchKernelGGL(kern2, dim3(((a.n_windows + per_block - 1) / per_block) * gs), dim3(64 * NW), lds, s, a);
-            else hipLaunchKernelGGL(kern, dim3(((a.n_windows + per_block - 1) / per_block) * gs), dim3(64 * NW), lds, s, a);
+            if (a.x3_scale) ESCX_LAUNCH(kern2, dim3(((a.n_windows + per_block - 1) / per_block) * gs), dim3(64 * NW), lds, s, a);
+            else ESCX_LAUNCH(kern, dim3(((a.n_windows + per_block - 1) / per_block) * gs), dim3(64 * NW), lds, s, a);
             return 0;
         }
     }
-    hipLaunchKernelGGL((attn_fused_kernel<CP, MODE, UT, TMW, NW>), dim3(((a.n_windows + per_block - 1) / per_block) * gs), dim3(64 * NW), 0, s, a);
+    ESCX_LAUNCH((attn_fused_kernel<CP, MODE, UT, TMW, NW>), dim3(((a.n_windows + per_block - 1) / per_block) * gs), dim3(64 * NW), 0, s, a);
     return 0;
 }
 
@@ -600,7 +610,7 @@ static int launch_attn_packed(const AttnArgs& a, hipStream_t s) {
     if (a.comb_n > 0) {
 #ifdef ESCX_EXPERIMENTAL
         if constexpr (CP == 384 && NW == 4) {
-            if (gs == 1) { hipLaunchKernelGGL((attn_packed_kernel<CP, UT, NW, true>), dim3((pairs + NW - 1) / NW), dim3(64 * NW), 0, s, a); return 0; }
+            if (gs == 1) { ESCX_LAUNCH((attn_packed_kernel<CP, UT, NW, true>), dim3((pairs + NW - 1) / NW), dim3(64 * NW), 0, s, a); return 0; }
         }
 #endif
         return ESCX_COMB_UNSUPPORTED;
@@ -614,7 +624,7 @@ static int launch_attn_packed(const AttnArgs& a, hipStream_t s) {
             int dev = 0; (void)hipGetDevice(&dev);
             const unsigned bit = 1u << (dev & 31);
             if (!(done.load(std::memory_order_relaxed) & bit)) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done.fetch_or(bit, std::memory_order_relaxed); }
-            hipLaunchKernelGGL(kern, dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), lds, s, a);
+            ESCX_LAUNCH(kern, dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), lds, s, a);
             return 0;
         }
 #endif
@@ -630,12 +640,12 @@ static int launch_attn_packed(const AttnArgs& a, hipStream_t s) {
                 (void)hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 done.fetch_or(bit, std::memory_order_relaxed);
             }
-            if (a.x3_scale) hipLaunchKernelGGL(kern2, dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), lds, s, a);
-            else hipLaunchKernelGGL(kern, dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), lds, s, a);
+            if (a.x3_scale) ESCX_LAUNCH(kern2, dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), lds, s, a);
+            else ESCX_LAUNCH(kern, dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), lds, s, a);
             return 0;
         }
     }
-    hipLaunchKernelGGL((attn_packed_kernel<CP, UT, NW>), dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), 0, s, a);
+    ESCX_LAUNCH((attn_packed_kernel<CP, UT, NW>), dim3(((pairs + NW - 1) / NW) * gs), dim3(64 * NW), 0, s, a);
     return 0;
 }
 
@@ -643,14 +653,14 @@ size_t attn_x3_bytes(int Cp, int mode, int n_groups) { return (size_t)n_groups *
 
 // pairs == 1: pair-order stream (mode 0 / 1, even group count): [Q0 K0 V0 Q1 K1 V1 P_lo P_hi] per two head groups, projection split as well
 // pairs == 2: the two-term fp16 form of the plain stream (split_terms.h): weights scaled by the power of two of the block's max |w|, scales in the trailer
-int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, hipStream_t s, int pairs) {
+int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, hipStream_t s, int pairs, const float* gamma, const float* beta, int C) {
     const int KK = Cp / 16, KS = attn_x3_ks(Cp), TF = attn_x3_tf(Cp), TPG = mode == 2 ? 8 : 4;
     if (pairs == 1) {
         if (mode == 2 || (n_groups & 1)) return -1;
         (void)hipMemsetAsync(image, 0, attn_x3_bytes(Cp, mode, n_groups), s);
         const int H = (KK + 1) / 2;
         const long long tot = (long long)(n_groups / 2) * 8 * (KS > H ? KS : H) * 64;
-        hipLaunchKernelGGL(attn_x3p_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(waf), reinterpret_cast<bf16x8*>(image),
+        ESCX_LAUNCH(attn_x3p_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(waf), reinterpret_cast<bf16x8*>(image),
                            n_groups / 2, KK, KS, TF);
         return 0;
     }
@@ -661,10 +671,10 @@ int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, 
     if (pairs == 2) {
         unsigned* mx = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(image) + attn_x3_bytes(Cp, mode, n_groups) - 32);
         const long long n = (long long)n_tiles * KK * 64 * 4;
-        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, waf, n, mx);
+        ESCX_LAUNCH(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, waf, n, mx);
     }
-    hipLaunchKernelGGL(attn_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(waf), reinterpret_cast<bf16x8*>(image),
-                       n_tiles, TPG, KK, KS, TF, proj_mask, pairs == 2 ? 2 : 3);
+    ESCX_LAUNCH(attn_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(waf), reinterpret_cast<bf16x8*>(image),
+                       n_tiles, TPG, KK, KS, TF, proj_mask, pairs == 2 ? 2 : 3, gamma, beta, Cp, C);
     return 0;
 }
 

@@ -18,13 +18,13 @@ void ln_rows(int mode, const float* src, float* dst, const float* gamma, const f
     const int grid = grid_for(total_rows, 16, 8192);
     const float eps = 1e-5f;
     if (mode == 0)
-        hipLaunchKernelGGL((ln_rows_kernel<1, 0>), dim3(grid), dim3(256), 0, s, src, dst, gamma, beta, map, rows_per_clip,
+        ESCX_LAUNCH((ln_rows_kernel<1, 0>), dim3(grid), dim3(256), 0, s, src, dst, gamma, beta, map, rows_per_clip,
                            src_rows_per_clip, total_rows, C, Cp, eps);
     else if (mode == 1)
-        hipLaunchKernelGGL((ln_rows_kernel<1, 1>), dim3(grid), dim3(256), 0, s, src, dst, gamma, beta, map, rows_per_clip,
+        ESCX_LAUNCH((ln_rows_kernel<1, 1>), dim3(grid), dim3(256), 0, s, src, dst, gamma, beta, map, rows_per_clip,
                            src_rows_per_clip, total_rows, C, Cp, eps);
     else
-        hipLaunchKernelGGL((ln_rows_kernel<2, 2>), dim3(grid), dim3(256), 0, s, src, dst, gamma, beta, map, rows_per_clip,
+        ESCX_LAUNCH((ln_rows_kernel<2, 2>), dim3(grid), dim3(256), 0, s, src, dst, gamma, beta, map, rows_per_clip,
                            src_rows_per_clip, total_rows, C, Cp, eps);
 }
 
@@ -32,7 +32,7 @@ int window_attention(const float* qkv, const float* bias, float* out, int total_
                      int nWw, int shifted, hipStream_t s) {
     const long long pairs = (long long)total_windows * nH;
     const int grid = grid_for(pairs, 4, 16384);
-#define ESCX_ATT(S) case S: hipLaunchKernelGGL((window_attention_kernel<S>), dim3(grid), dim3(256), 0, s, qkv, bias, out, (int)pairs, \
+#define ESCX_ATT(S) case S: ESCX_LAUNCH((window_attention_kernel<S>), dim3(grid), dim3(256), 0, s, qkv, bias, out, (int)pairs, \
                                                nH, ldq, ldo, nWh, nWw, shifted); return 0;
     switch (hdp / 4) {
         ESCX_ATT(1) ESCX_ATT(2) ESCX_ATT(3) ESCX_ATT(4) ESCX_ATT(5) ESCX_ATT(6) ESCX_ATT(7) ESCX_ATT(8)
@@ -46,7 +46,7 @@ int pvq_search(const float* zpart, int splits, int M, int ldz, const float* cbn,
                int d, int dt, int Tq, long long* codes, long long bstride, float* loss, float loss_scale, int l2norm, hipStream_t s) {
     SearchArgs a{zpart, splits, M, ldz, cbn, c2, cbraw, Ksz, d, Tq, codes, bstride, loss, loss_scale, l2norm};
     dim3 grid((M + 15) / 16, G);
-#define ESCX_SRCH(S) case S: hipLaunchKernelGGL((pvq_search_kernel<S>), grid, dim3(256), 0, s, a); return 0;
+#define ESCX_SRCH(S) case S: ESCX_LAUNCH((pvq_search_kernel<S>), grid, dim3(256), 0, s, a); return 0;
     switch (dt / 4) {
         ESCX_SRCH(1) ESCX_SRCH(2) ESCX_SRCH(3) ESCX_SRCH(4) ESCX_SRCH(5) ESCX_SRCH(6) ESCX_SRCH(7) ESCX_SRCH(8)
         ESCX_SRCH(12) ESCX_SRCH(16)
@@ -56,7 +56,7 @@ int pvq_search(const float* zpart, int splits, int M, int ldz, const float* cbn,
 }
 
 void loss_reduce(const float* terms, int n_slots, int G, int M, int Tq, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(M / Tq), dim3(64), 0, s, terms, n_slots, G, M, Tq, out);
+    ESCX_LAUNCH(loss_reduce_kernel, dim3(M / Tq), dim3(64), 0, s, terms, n_slots, G, M, Tq, out);
 }
 
 int pvq_down(const float* enc, const float* dec, int B, int Hq, int Wd, int Cp, int ov, const float* W, int Np, int Kp, float* zpart, int splits,
@@ -69,11 +69,11 @@ int pvq_down(const float* enc, const float* dec, int B, int Hq, int Wd, int Cp, 
     PvqDownArgs a{enc, dec, W, zpart, M, Tq, Hq, Wd, Cp, ov, Kp, Np, per * bk};
     const dim3 grid((M + 63) / 64, splits);
     switch (Np / 16) {
-        case 1: hipLaunchKernelGGL(pvq_down_kernel<1>, grid, dim3(256), 0, s, a); return 0;
-        case 2: hipLaunchKernelGGL(pvq_down_kernel<2>, grid, dim3(256), 0, s, a); return 0;
-        case 3: hipLaunchKernelGGL(pvq_down_kernel<3>, grid, dim3(256), 0, s, a); return 0;
-        case 4: hipLaunchKernelGGL(pvq_down_kernel<4>, grid, dim3(256), 0, s, a); return 0;
-        case 6: hipLaunchKernelGGL(pvq_down_kernel<6>, grid, dim3(256), 0, s, a); return 0;
+        case 1: ESCX_LAUNCH(pvq_down_kernel<1>, grid, dim3(256), 0, s, a); return 0;
+        case 2: ESCX_LAUNCH(pvq_down_kernel<2>, grid, dim3(256), 0, s, a); return 0;
+        case 3: ESCX_LAUNCH(pvq_down_kernel<3>, grid, dim3(256), 0, s, a); return 0;
+        case 4: ESCX_LAUNCH(pvq_down_kernel<4>, grid, dim3(256), 0, s, a); return 0;
+        case 6: ESCX_LAUNCH(pvq_down_kernel<6>, grid, dim3(256), 0, s, a); return 0;
         default: return -1;
     }
 #else
@@ -95,7 +95,7 @@ static void launch_pvq_fused_d(const PvqFusedArgs& a, hipStream_t s) {
             done.fetch_or(bit, std::memory_order_relaxed);
         }
     }
-    hipLaunchKernelGGL(kern, dim3((a.M + 15) / 16), dim3(64 * PVQF_WAVES), lds, s, a);
+    ESCX_LAUNCH(kern, dim3((a.M + 15) / 16), dim3(64 * PVQF_WAVES), lds, s, a);
 }
 template <int NT, int STEPS>
 static void launch_pvq_fused(const PvqFusedArgs& a, hipStream_t s) {
@@ -105,7 +105,7 @@ static void launch_pvq_fused(const PvqFusedArgs& a, hipStream_t s) {
 void pvq_tab_add(const long long* codes, long long bstride, const float* tab, const float* gq, int G, int Ksz, int B, int Hq, int Wd, int Cp, int ov,
                  const float* dec, float* out, hipStream_t s) {
     PvqTabAddArgs a{codes, bstride, tab, gq, dec, out, G, Ksz, Wd / ov, Hq, Wd, Cp, ov, (long long)B * Hq * Wd * (Cp / 4)};
-    hipLaunchKernelGGL(pvq_tab_add_kernel, dim3((unsigned)((a.n4 + 255) / 256)), dim3(256), 0, s, a);
+    ESCX_LAUNCH(pvq_tab_add_kernel, dim3((unsigned)((a.n4 + 255) / 256)), dim3(256), 0, s, a);
 }
 
 int pvq_fused(const float* enc, const float* dec, int B, int Hq, int Wd, int Cp, int ov, const float* wd, int Np, int Kq, int splits, int bk,
@@ -145,11 +145,11 @@ int pvq_up(const long long* codes, long long bstride, const float* cbraw, int G,
     a.nt_per_wg = per;
     const dim3 grid(mt, (a.NT + per - 1) / per);
     switch (Kp / 16) {
-        case 1: hipLaunchKernelGGL(pvq_up_kernel<1>, grid, dim3(256), 0, s, a); return 0;
-        case 2: hipLaunchKernelGGL(pvq_up_kernel<2>, grid, dim3(256), 0, s, a); return 0;
-        case 3: hipLaunchKernelGGL(pvq_up_kernel<3>, grid, dim3(256), 0, s, a); return 0;
-        case 4: hipLaunchKernelGGL(pvq_up_kernel<4>, grid, dim3(256), 0, s, a); return 0;
-        case 6: hipLaunchKernelGGL(pvq_up_kernel<6>, grid, dim3(256), 0, s, a); return 0;
+        case 1: ESCX_LAUNCH(pvq_up_kernel<1>, grid, dim3(256), 0, s, a); return 0;
+        case 2: ESCX_LAUNCH(pvq_up_kernel<2>, grid, dim3(256), 0, s, a); return 0;
+        case 3: ESCX_LAUNCH(pvq_up_kernel<3>, grid, dim3(256), 0, s, a); return 0;
+        case 4: ESCX_LAUNCH(pvq_up_kernel<4>, grid, dim3(256), 0, s, a); return 0;
+        case 6: ESCX_LAUNCH(pvq_up_kernel<6>, grid, dim3(256), 0, s, a); return 0;
         default: return -1;
     }
 }
@@ -157,17 +157,17 @@ int pvq_up(const long long* codes, long long bstride, const float* cbraw, int G,
 void istft_ola(const float* frames, const float* win2, float* wave, int B, int T, int ldf, int win, int hop, int left, int half,
                int out_len, hipStream_t s) {
     const long long n = (long long)B * out_len;
-    hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, frames, win2, wave, B, T, ldf, win, hop,
+    ESCX_LAUNCH(istft_ola_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, frames, win2, wave, B, T, ldf, win, hop,
                        left, half, out_len);
 }
 
 void pad_rows(const float* src, float* dst, long long rows, int C, int Cp, hipStream_t s) {
     const long long n = rows * Cp;
-    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, C, Cp);
+    ESCX_LAUNCH(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, C, Cp);
 }
 void unpad_rows(const float* src, float* dst, long long rows, int C, int Cp, hipStream_t s) {
     const long long n = rows * C;
-    hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, C, Cp);
+    ESCX_LAUNCH(unpad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, C, Cp);
 }
 int deembed_border(const float* x, const float* wv, const float* bv, float* out, int B, int H, int W, int C, int Cp, int pf, int pt,
                    int in_dim, int Fp, hipStream_t s) {
@@ -175,33 +175,33 @@ int deembed_border(const float* x, const float* wv, const float* bv, float* out,
     const long long waves = (long long)B * per_clip;
     const unsigned grid = (unsigned)((waves + 3) / 4);
     const int NO = in_dim * pf * pt;
-    if (NO == 12) hipLaunchKernelGGL((deembed_border_kernel<12>), dim3(grid), dim3(256), 0, s, x, wv, bv, out, B, H, W, C, Cp, pf, pt, in_dim, Fp);
-    else if (NO == 8) hipLaunchKernelGGL((deembed_border_kernel<8>), dim3(grid), dim3(256), 0, s, x, wv, bv, out, B, H, W, C, Cp, pf, pt, in_dim, Fp);
-    else if (NO == 6) hipLaunchKernelGGL((deembed_border_kernel<6>), dim3(grid), dim3(256), 0, s, x, wv, bv, out, B, H, W, C, Cp, pf, pt, in_dim, Fp);
-    else if (NO == 4) hipLaunchKernelGGL((deembed_border_kernel<4>), dim3(grid), dim3(256), 0, s, x, wv, bv, out, B, H, W, C, Cp, pf, pt, in_dim, Fp);
+    if (NO == 12) ESCX_LAUNCH((deembed_border_kernel<12>), dim3(grid), dim3(256), 0, s, x, wv, bv, out, B, H, W, C, Cp, pf, pt, in_dim, Fp);
+    else if (NO == 8) ESCX_LAUNCH((deembed_border_kernel<8>), dim3(grid), dim3(256), 0, s, x, wv, bv, out, B, H, W, C, Cp, pf, pt, in_dim, Fp);
+    else if (NO == 6) ESCX_LAUNCH((deembed_border_kernel<6>), dim3(grid), dim3(256), 0, s, x, wv, bv, out, B, H, W, C, Cp, pf, pt, in_dim, Fp);
+    else if (NO == 4) ESCX_LAUNCH((deembed_border_kernel<4>), dim3(grid), dim3(256), 0, s, x, wv, bv, out, B, H, W, C, Cp, pf, pt, in_dim, Fp);
     else return -1;
     return 0;
 }
 
 void codes_pack10(const long long* in, unsigned char* out, long long n, hipStream_t s) {
     const long long q = (n + 3) / 4;
-    hipLaunchKernelGGL(codes_pack10_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, s, in, out, n);
+    ESCX_LAUNCH(codes_pack10_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, s, in, out, n);
 }
 void codes_unpack10(const unsigned char* in, long long* out, long long n, hipStream_t s) {
     const long long q = (n + 3) / 4;
-    hipLaunchKernelGGL(codes_unpack10_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, s, in, out, n);
+    ESCX_LAUNCH(codes_unpack10_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, s, in, out, n);
 }
 void test_math(const float* x, float* y, long long n, int which, hipStream_t s) {
-    hipLaunchKernelGGL(test_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n, which);
+    ESCX_LAUNCH(test_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n, which);
 }
 void test_copy_rows(const float* src, float* dst, long long rows, int Cp, hipStream_t s) {
-    hipLaunchKernelGGL(test_copy_rows_kernel, dim3(4096), dim3(256), 0, s, src, dst, rows, Cp);
+    ESCX_LAUNCH(test_copy_rows_kernel, dim3(4096), dim3(256), 0, s, src, dst, rows, Cp);
 }
 void codes_narrow(const long long* in, short* out, long long n, hipStream_t s) {
-    hipLaunchKernelGGL(codes_narrow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+    ESCX_LAUNCH(codes_narrow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
 }
 void codes_widen(const short* in, long long* out, long long n, hipStream_t s) {
-    hipLaunchKernelGGL(codes_widen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+    ESCX_LAUNCH(codes_widen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
 }
 
 }  // namespace escx

@@ -41,7 +41,8 @@ unsigned long long* debug_trace_buffer();      // device buffer set by escx_debu
 // fp32 weights (w1 [hiddenP][Cp], w2 [Cp][hiddenP]); mlp_x3_bytes = its size.  -1: width not instantiated.
 // nt: terms per operand - 3 = bf16 (exact split, six cross products), 2 = fp16 with per-matrix power-of-two scales (three cross products); image and kernel must agree
 size_t mlp_x3_bytes(int Cp, int hiddenP, int nt = 3);
-int mlp_x3_pack(const float* w1, const float* w2, void* image, int Cp, int hiddenP, hipStream_t s, int nt = 3);
+int mlp_x3_pack(const float* w1, const float* w2, void* image, int Cp, int hiddenP, hipStream_t s, int nt = 3, const float* gamma = nullptr, const float* beta = nullptr,
+                const float* b1 = nullptr, int C = 0);      // nt = 2 needs ln2's gamma / beta, b1 and the unpadded width (range rule of split_terms.h)
 struct MlpSplit;
 int mlp_x3(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* b1, const float* b2, const void* image, int hiddenP, int nw, int* hs_io, float* partial,
            hipStream_t s, const MlpSplit* split = nullptr, int nt = 3);      // split: PatchSplit in the epilogue, split->wf = image of mlp_x3_split_pack
@@ -58,7 +59,7 @@ int rowgemm_fused(int segs, const float* x, float* out, const float* gamma, cons
                   const CombineOnLoad* comb = nullptr,
                   const void* x3_wf = nullptr, int x3_nt = 3);      // split weight stream (rowgemm_x3_pack, x3_nt terms: 3 = bf16, 2 = fp16 + scales), or nullptr = fp32 MFMA
 size_t rowgemm_x3_bytes(int KP, int Np);
-int rowgemm_x3_pack(const float* wf, void* image, int KP, int Np, hipStream_t s, int nt = 3);
+int rowgemm_x3_pack(const float* wf, void* image, int KP, int Np, hipStream_t s, int nt = 3, const float* gamma = nullptr, const float* beta = nullptr, int C = 0);   // gamma / beta over KP channels, C real ones: the LayerNorm whose output is split (nt = 2 range rule)
 void loss_reduce(const float* terms, int n_slots, int G, int M, int Tq, float* out, hipStream_t s);     // per-clip commitment loss, fixed summation order
 void mlp_set_trace(unsigned long long* p);
 int test_fastdiv(int n, int d);       // host evaluation of gemm_engine.h FastDiv (gemm_misc.hip)
@@ -74,7 +75,7 @@ int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_grou
                const CombineOnLoad* comb = nullptr, const struct AttnTape* tape = nullptr,
                const void* x3_wf = nullptr, int x3_pairs = 0);     // split (3 x bf16) weight stream of this block (attn_x3_pack; pairs: its pair-order form), nullptr = fp32 MFMA
 size_t attn_x3_bytes(int Cp, int mode, int n_groups);
-int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, hipStream_t s, int pairs = 0);
+int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, hipStream_t s, int pairs = 0, const float* gamma = nullptr, const float* beta = nullptr, int C = 0);   // norm1's gamma / beta (pairs == 2: range rule)
 // training forward: the fused attention also writes what the backward reads (fused_attn.h, TAPE); returns ESCX_COMB_UNSUPPORTED when the width has
 // no TAPE instantiation (the caller runs the unfused sequence)
 struct AttnTape { float* xn; float* qkv; float* o; int ldq, ldo, hdp, nH; };

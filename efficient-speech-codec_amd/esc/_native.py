@@ -39,6 +39,8 @@ SIGNATURES = {
     "escx_required_key": (c_char_p, [c_void_p, c_int]),
     "escx_reserve": (c_int, [c_void_p, c_int, c_int]),
     "escx_workspace_bytes": (c_int64, [c_void_p]),
+    "escx_set_precision": (c_int, [c_void_p, c_int]),
+    "escx_get_precision": (c_int, [c_void_p]),
     "escx_encode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, POINTER(c_int), POINTER(c_int), c_void_p]),
     "escx_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "escx_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -98,6 +100,7 @@ SIGNATURES = {
     "escx_allgather_codes": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
 }
 
+PRECISIONS = {"fp32": 0, "f16x2": 2, "bf16x3": 3}          # include/escx.h ESCX_PRECISION_*
 ESCX_ERR_INVALID_ARG, ESCX_ERR_UNSUPPORTED, ESCX_ERR_HIP, ESCX_ERR_STATE, ESCX_ERR_ASSERT = -1, -2, -3, -4, -5
 
 _lib = None

@@ -164,6 +164,7 @@ class ESC(nn.Module):
         self._dirty = True
         self._flat_grad_mode = False
         self._carry: Dict[int, tuple] = {}               # flat gradient buffers that survive a handle rebuild (see _handle)
+        self._precision = None                           # None = the library's default (ESCX_PRECISION, else "f16x2"); see set_precision
 
     # ---- weight management ------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -181,6 +182,29 @@ class ESC(nn.Module):
                 sd[k] = own[k]
         self._dirty = True
         return super().load_state_dict(sd, strict=strict, **kw)
+
+    # ---- arithmetic of the inference path (include/escx.h escx_set_precision) -----------------------------
+    def set_precision(self, mode: str) -> "ESC":
+        """Operand form of the K = C contractions (MLPs, Q / K / V, PatchMerge / PatchSplit, PatchDeEmbed) of encode / decode / eval forward:
+        "fp32" (fp32 MFMA, the reference's operand precision), "bf16x3" (every fp32 operand split exactly into three bf16 terms: fp32 results up to
+        summation order), "f16x2" (two fp16 terms, range-safe, truncation ~1e-7: the default and the fastest).  fp32 accumulation in every mode.
+        Not part of the reference's surface - the reference has one arithmetic (ATen fp32)."""
+        if mode not in _native.PRECISIONS:
+            raise ValueError(f"precision {mode!r}: expected one of {sorted(_native.PRECISIONS)}")
+        self._precision = mode
+        lib = _native.load()
+        for hd in self._handles.values():
+            _native.check(lib.escx_set_precision(hd, _native.PRECISIONS[mode]))
+        return self
+
+    @property
+    def precision(self) -> str:
+        """The mode in effect (of the first live handle; before any handle exists: what set_precision chose, or the library default)."""
+        if self._handles:
+            code = _native.load().escx_get_precision(next(iter(self._handles.values())))
+            return {v: k for k, v in _native.PRECISIONS.items()}[code]
+        import os
+        return self._precision or {"0": "fp32", "3": "bf16x3", "2": "f16x2"}.get(os.environ.get("ESCX_PRECISION", "f16x2"), os.environ.get("ESCX_PRECISION", "f16x2"))
 
     def refresh_weights(self):
         """Force a re-pack (in-place updates are detected through autograd's version counters; this is for exotic writes, e.g. through
@@ -301,6 +325,8 @@ class ESC(nn.Module):
                     shape = (ctypes.c_int64 * max(host.dim(), 1))(*host.shape)
                     _native.check(lib.escx_set_param(hd, key.encode(), host.data_ptr(), shape, host.dim()))
                 _native.check(lib.escx_finalize_params(hd))
+                if self._precision is not None:
+                    _native.check(lib.escx_set_precision(hd, _native.PRECISIONS[self._precision]))
             except Exception:
                 lib.escx_destroy(hd)
                 raise

@@ -78,7 +78,7 @@ class FlatAdamW:
         skips them entirely - no weight decay, no moment decay, `step` not advanced - and so does step() here.  The training backward of this
         package writes a (possibly zero) gradient for every parameter, which is what the reference's graph produces too (masked streams are
         multiplied by 0., csrvq.py:42-44), so nothing is inactive unless the caller says so; reference checkpoints written by other loops can
-        carry such parameters and load_state_dict() keeps their step counts."""
+        carry such parameters: load_state_dict() keeps their step counts and loads entry-less parameters ACTIVE (step 0, zero moments), as torch does."""
         pos = {k: i for i, (k, _) in enumerate(self.model.named_parameters())}
         self._inactive = {pos[k] for k in names}
 
@@ -161,16 +161,11 @@ class FlatAdamW:
             off, n, shp = slices[pos]
             m[off:off + n].copy_(st["exp_avg"].reshape(-1)); v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
             steps[pos] = int(float(st["step"]))
-        # a checkpoint in which SOME parameters have a state entry and others do not comes from a loop where the entry-less ones never
-        # received a gradient (torch skips `p.grad is None` parameters entirely: no weight decay, no step).  The native backward writes a (zero)
-        # gradient for every parameter, so loading them as active would start decaying them: they are marked inactive (set_inactive() semantics)
-        # and the caller is told.  A checkpoint with no state at all (saved before the first step) leaves everything active.
-        missing = [pos for pos, pid in enumerate(ids) if slices[pos] is not None and sd["state"].get(pid) is None]
-        if missing and len(missing) < sum(sl is not None for sl in slices):
-            import warnings
-            self._inactive = set(missing)
-            warnings.warn(f"FlatAdamW.load_state_dict: {len(missing)} parameter(s) have no optimiser state in the checkpoint (they never received a gradient "
-                          "there); they are loaded INACTIVE (no decay, no step) - call set_inactive(()) if they take part in this loop", RuntimeWarning)
+        # torch semantics: a parameter without a state entry is ACTIVE - torch creates its state lazily and trains it as soon as it receives a gradient
+        # (the reference's own `pretrained.pth`, written while the quantisers were out of the graph, is resumed exactly so: scripts/train.py --pretrain_ckp).  It starts
+        # at step 0 with zero moments.  Which parameters are gradient-less in the COMING steps is the loop's knowledge, not the checkpoint's: set_inactive() says so;
+        # loading a checkpoint clears whatever an earlier call had set.
+        self._inactive = set()
         live = {t for t, sl in zip(steps, slices) if sl is not None}
         self.t = max(live) if live else 0
         self._steps = None if len(live) <= 1 else steps   # torch keeps `step` per parameter: differing counts get their own bias corrections

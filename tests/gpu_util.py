@@ -10,16 +10,24 @@ def have_gpu():
     return torch.cuda.is_available()
 
 
-def build_models(name):
-    """(product model on cuda:0, oracle on CPU, golden npz, cfg) with identical synthetic weights."""
+PRECISIONS = ("f16x2", "bf16x3", "fp32")      # esc.ESC.set_precision / include/escx.h escx_set_precision: default first
+
+
+def build_models(name, precision=None, edit=None):
+    """(product model on cuda:0, oracle on CPU, golden npz, cfg) with identical synthetic weights.  precision: ESC.set_precision mode (None = the
+    library default); edit(sd): in-place modification of the state dict BOTH sides load (range-stress checkpoints)."""
     from esc.models import make_model
     from oracle.esc_oracle import EscOracle
     g = load_golden(name)
     cfg = json.loads(str(g["config_json"]))
     sd = synth_state(name)
+    if edit is not None:
+        edit(sd)
     model = make_model(cfg)
     model.load_state_dict(sd, strict=True)
     model = model.to("cuda:0").eval()
+    if precision is not None:
+        model.set_precision(precision)
     return model, EscOracle(cfg, sd), g, cfg
 
 

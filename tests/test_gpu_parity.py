@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import NEAR_TIE, attribute_with_continuation, build_models, code_report, mismatch_summary, rel_rms, rms, unattributable
+from gpu_util import NEAR_TIE, PRECISIONS, attribute_with_continuation, build_models, code_report, mismatch_summary, rel_rms, rms, unattributable
 from conftest import load_golden
 from esc import synth, _native
 
@@ -131,15 +131,17 @@ def test_every_transformer_layer(which, W, request):
         assert err < ACT_TOL, f"{which} layer {lid} ({pfx}) H={H} W={W}: rel rms {err:.3e}"
 
 
-def test_layer_accuracy_against_fp64(base):
-    """Precision of the device arithmetic, measured: every TransformerLayer of ESC-Base against the oracle evaluated in FLOAT64, next to the error of
-    the oracle's own float32 evaluation (the reference's arithmetic: ATen sgemm) against the same float64 result.  Round 5: the fused MLPs run their
-    contractions on the bf16 matrix cores with every fp32 operand split exactly into three bf16 terms (fused_mlp_x3.h; six exact cross products,
-    fp32 accumulation) - fp32-grade arithmetic, not a bf16 approximation, and this is the test that says so: the device error must not exceed twice the
-    reference's own float32 error (+ 1e-7).  Printed per layer; ESCX_MLP_X3=0 (fp32 MFMA everywhere) passes the same bound."""
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_layer_accuracy_against_fp64(precision):
+    """Precision of the device arithmetic, measured per mode of escx_set_precision: every TransformerLayer of ESC-Base against the oracle evaluated in FLOAT64,
+    next to the error of the oracle's own float32 evaluation (the reference's arithmetic: ATen sgemm) against the same float64 result.  "f16x2" (default): two fp16
+    terms per operand, three cross products - NOT an exact split (truncation ~1e-7), measured 0.65-0.87x the reference's own error; "bf16x3": three bf16 terms, exact
+    split, six cross products (0.88-1.03x); "fp32": the fp32 MFMA.  Bound (tightened from 2x): device error <= 1.1 x the reference's float32 error + 1e-7."""
     from oracle import esc_oracle as O
-    model, orc, g, cfg = base
+    model, orc, g, cfg = build_models("base", precision)
+    assert model.precision == precision
     lib, hd = _h(model)
+    assert lib.escx_get_precision(hd) == _native.PRECISIONS[precision]
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in orc.sd.items()}
     torch.manual_seed(23)
     W = 20
@@ -152,10 +154,10 @@ def test_layer_accuracy_against_fp64(base):
         xg = x.cuda()
         _native.check(lib.escx_transformer_layer(hd, lid, _ptr(xg), 2, H, W, _ptr(y), ctypes.byref(Hn), None))
         e_dev, e_cpu = rel_rms(y.cpu().double(), ref64), rel_rms(ref32.double(), ref64)
-        print(f"[fp64] layer {lid:2d} {pfx:22s} C={C:3d}: device {e_dev:.2e}   reference float32 {e_cpu:.2e}   ratio {e_dev / max(e_cpu, 1e-30):.2f}")
-        worst = max(worst, e_dev / (2 * e_cpu + 1e-7))
-        assert e_dev <= 2 * e_cpu + 1e-7, f"layer {lid} ({pfx}): device error {e_dev:.3e} vs float32 reference error {e_cpu:.3e}"
-    print(f"[fp64] worst device error / bound: {worst:.2f}")
+        print(f"[fp64 {precision}] layer {lid:2d} {pfx:22s} C={C:3d}: device {e_dev:.2e}   reference float32 {e_cpu:.2e}   ratio {e_dev / max(e_cpu, 1e-30):.2f}")
+        worst = max(worst, e_dev / (1.1 * e_cpu + 1e-7))
+        assert e_dev <= 1.1 * e_cpu + 1e-7, f"layer {lid} ({pfx}) [{precision}]: device error {e_dev:.3e} vs float32 reference error {e_cpu:.3e}"
+    print(f"[fp64 {precision}] worst device error / bound: {worst:.2f}")
 
 
 def test_merge_with_odd_height(base):
@@ -300,9 +302,11 @@ def erf_ref_scaled(x64):
 
 
 # ---------------------------------------------------------------- whole path vs golden ------------------------
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["tiny", "base", "large"])
-def test_codes_bit_exact_and_audio_vs_golden(name):
-    model, orc, g, cfg = build_models(name)
+def test_codes_bit_exact_and_audio_vs_golden(name, precision):
+    """The golden vectors of the REAL reference (oracle/gen_golden.py): codes bit-exact for every num_streams, audio within 1e-4 RMS - in every precision mode."""
+    model, orc, g, cfg = build_models(name, precision)
     S = cfg["max_streams"]
     if name == "tiny":
         cases = [(torch.from_numpy(synth.pcm_to_float(g[f"L{L}_pcm"])), g[f"L{L}_codes"], g[f"L{L}_margins"],
@@ -505,13 +509,14 @@ def test_large_batch36_against_the_oracle():
     assert same.any() and rms(wave[idx].cpu().numpy()[same], ow[same]) <= AUDIO_TOL
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["base", "large"])
-def test_unfiltered_reference_clips(name):
+def test_unfiltered_reference_clips(name, precision):
     """tests/golden/unfiltered.npz (oracle/gen_unfiltered_golden.py): the first clips by tag, NO margin-based selection, codes and
     margins from the real reference (margins down to 3e-7 for Base).  Requirement: no difference that is not a reference near-tie;
     the report names every difference with its margin."""
     import json
-    model, orc, g, cfg = build_models(name)
+    model, orc, g, cfg = build_models(name, precision)
     u = load_golden("unfiltered")
     tags = json.loads(str(u[f"{name}_tags"]))
     pcm = np.stack([(synth.noise_clip_int16 if k == "noise" else synth.voiced_clip_int16)(t, 48000) for k, t in tags])
@@ -521,14 +526,15 @@ def test_unfiltered_reference_clips(name):
     got = codes.cpu().numpy()
     bad, forced, cont = attribute_with_continuation(orc, x.cpu(), got, ref, m, cfg["max_streams"])
     same = (got == ref).reshape(len(tags), -1).all(1)
-    print(f"[unfiltered {name}] {int(same.sum())}/{len(tags)} clips bit-exact, reference min margin {m.min():.2e}, "
+    print(f"[unfiltered {name} {precision}] {int(same.sum())}/{len(tags)} clips bit-exact, reference min margin {m.min():.2e}, "
           f"{int((m < 1e-5).sum())} codes under 1e-5; " + mismatch_summary(got, ref, m))
     assert not bad, "\n".join(bad[:10])
     wave = model.decode(torch.from_numpy(ref).cuda(), shape).cpu().numpy()
     assert rms(wave[:, ::16], u[f"{name}_audio_sub"]) <= AUDIO_TOL
 
 
-def test_clustered_codebooks_against_the_reference():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_clustered_codebooks_against_the_reference(precision):
     """VERDICT r4 item 4b / SURVEY hard part 1: parity on trained-like margin statistics.  tests/golden/clustered.npz holds what the REAL reference
     emits for ESC-Base when every codebook row has a near-duplicate at relative distance 1e-4 ... 1e-6 (esc/synth.py cluster_codebook;
     oracle/gen_clustered_golden.py): ~13 000 of its 16 200 argmin margins are below 1e-5, ~5 600 below 1e-6.  Requirement: ZERO unattributable
@@ -543,7 +549,7 @@ def test_clustered_codebooks_against_the_reference():
     sd = {}
     for k, v in synth.clustered_state_dict(load_manifest("base")).items():
         sd[k] = torch.hann_window(v.shape[0]) if k.endswith(".window") else torch.from_numpy(np.ascontiguousarray(v))
-    model = make_model(cfg); model.load_state_dict(sd, strict=True); model = model.to("cuda:0").eval()
+    model = make_model(cfg); model.load_state_dict(sd, strict=True); model = model.to("cuda:0").eval().set_precision(precision)
     orc = EscOracle(cfg, sd)
     u = load_golden("clustered")
     tags = json.loads(str(u["tags"]))
@@ -557,7 +563,7 @@ def test_clustered_codebooks_against_the_reference():
                  for e in (4, 5, 6, 7, 8)}
     by_decade["exact ties (0)"] = (int((first & (m[:, 0] == 0)).sum()), int((m[:, 0] == 0).sum()))
     bad, forced, cont = attribute_with_continuation(orc, x, got, ref, m, cfg["max_streams"])
-    print(f"[clustered] {int((got != ref).sum())} of {ref.size} codes differ from the reference fixture ({forced} attributed near-ties forced, {len(cont)} clips continued); "
+    print(f"[clustered {precision}] {int((got != ref).sum())} of {ref.size} codes differ from the reference fixture ({forced} attributed near-ties forced, {len(cont)} clips continued); "
           f"stream-0 flips / codes per reference-margin decade: {by_decade}; reference margins under 1e-5: {int((m < 1e-5).sum())}")
     assert not bad, "\n".join(bad[:10])
     # the near-duplicates decode to (almost) the same vectors: the device's own round trip stays within the audio tolerance of the reference's
@@ -820,12 +826,15 @@ def test_allgather_codes_through_the_c_abi_one_rank_rccl(base):
         rccl.ncclCommDestroy(comm)
 
 
-def _parity_sweep(model_name, n):
+_SWEEP_ORACLE = {}       # (model, family, first clip, clips) -> (oracle codes, margins): the precision modes sweep the same clips, the oracle runs once
+
+
+def _parity_sweep(model_name, n, precision=None):
     """n noise + n voiced clips in batches of 36 against the oracle, every code; a difference must sit on a reference near-tie (margin < 2e-6) in the
     earliest differing stream of its clip, and the later streams of such a clip are verified against the oracle CONTINUED from the device's choice."""
-    model, orc, g, cfg = build_models(model_name)
+    model, orc, g, cfg = build_models(model_name, precision)
     Trace = __import__("oracle.esc_oracle", fromlist=["Trace"]).Trace
-    tot = dict(model=model_name, clips=0, exact=0, codes=0, diff=0, under_1e5=0, under_2e6=0)
+    tot = dict(model=model_name, precision=model.precision, clips=0, exact=0, codes=0, diff=0, under_1e5=0, under_2e6=0)
     min_margin = 1.0
     for fam, fn in (("noise", synth.noise_clip_int16), ("voiced", synth.voiced_clip_int16)):
         for lo in range(0, n, 36):
@@ -833,10 +842,13 @@ def _parity_sweep(model_name, n):
             pcm = np.stack([fn(f"sweep-{fam}-{lo + i}", 48000) for i in range(k)])
             x = torch.from_numpy(synth.pcm_to_float(pcm))
             codes, shape = model.encode(x.cuda(), 6)
-            tr = Trace()
-            oc, _ = orc.encode(x, 6, trace=tr)
-            m = torch.stack(tr.margins, dim=1).numpy()
-            got, ref = codes.cpu().numpy(), oc.numpy()
+            key = (model_name, fam, lo, k)
+            if key not in _SWEEP_ORACLE:
+                tr = Trace()
+                oc, _ = orc.encode(x, 6, trace=tr)
+                _SWEEP_ORACLE[key] = (oc.numpy(), torch.stack(tr.margins, dim=1).numpy())
+            ref, m = _SWEEP_ORACLE[key]
+            got = codes.cpu().numpy()
             # every differing code must be a reference near-tie - in its own stream, or in the reference CONTINUED from the device's choice at an
             # attributed near-tie of an earlier stream (the later streams of such a clip see a different residual): nothing stays unverified
             bad, forced, cont = attribute_with_continuation(orc, x, got, ref, m, 6)
@@ -844,36 +856,104 @@ def _parity_sweep(model_name, n):
             tot["forced"] = tot.get("forced", 0) + forced; tot["continued"] = tot.get("continued", 0) + len(cont)
             tot["clips"] += k; tot["exact"] += int((got == ref).reshape(k, -1).all(1).sum()); tot["codes"] += got.size; tot["diff"] += int((got != ref).sum())
             tot["under_1e5"] += int((m < 1e-5).sum()); tot["under_2e6"] += int((m < 2e-6).sum()); min_margin = min(min_margin, float(m.min()))
-            print(f"[sweep {model_name} {fam} {lo}..{lo + k}] exact {tot['exact']}/{tot['clips']} clips, smallest reference margin so far {min_margin:.2e}", flush=True)
+            print(f"[sweep {model_name} {tot['precision']} {fam} {lo}..{lo + k}] exact {tot['exact']}/{tot['clips']} clips, smallest reference margin so far {min_margin:.2e}", flush=True)
     print(f"[sweep] {tot}; smallest reference margin {min_margin:.2e}")
     return tot
 
 
-def _near_tie_budget(tot):
+def _near_tie_budget(tot, strict=False):
     """Every differing code has already been attributed (reference margin < 2e-6 in the earliest differing stream, later streams verified against the oracle
-    continued from the device's choice) - this guard only bounds HOW MANY near-ties resolve the other way.  A flip needs a near-tie, so the budget is a third of the
-    sweep's codes with a reference margin under 2e-6 (at least 1): with ~1e-7 of fp32 noise on either side and margins spread over [0, 2e-6) about one in ten is
-    expected.  Observed (profiles/r5_parity_sweep_*): Base-576 4 clips of 45 such codes, Large-288 0 of 25 (two-term fp16 forms); 3 / 45 and 1 / 25 with the
-    three-term bf16 forms; 0 / 45 and 2 / 25 on the all-fp32-MFMA path."""
+    continued from the device's choice) - this guard bounds HOW MANY near-ties resolve the other way.  VERDICT r5 weak #3 / ADVICE r5: tightened to what was
+    observed - at most 1 % of the clips AND at most a sixth of the sweep's codes with a reference margin under 2e-6 (never less than one clip: a single flip is
+    fp32 summation-order noise under any arithmetic).  Observed (profiles/r5_parity_sweep_*, r6_*): Base-576 4 clips (0.7 %) of 45 such codes and Base-1152 5 clips
+    (0.4 %), Large-576 3 clips (0.5 %) with two fp16 terms; 3 / 576 and 1 / 288 with three bf16 terms; 0 / 576 and 2 / 288 (0.7 %, 25 such codes) on the fp32 MFMA.
+    strict: the arm that must stay bit-exact on every clip (ESC-Base on the fp32 MFMA: 576 / 576 in every sweep so far)."""
     flipped = tot["clips"] - tot["exact"]
-    assert flipped <= max(1, tot["under_2e6"] // 3), tot
+    if strict:
+        assert flipped == 0, tot
+    assert flipped <= max(1, min((tot["clips"] + 99) // 100, tot["under_2e6"] // 6)), tot
 
 
 @pytest.mark.gpu
-def test_parity_sweep_base_always_on():
-    """the sweep is part of every GPU run - 72 noise + 72 voiced 3 s clips of ESC-Base against the oracle, every code
-    (ESCX_PARITY_SWEEP=<clips per family> widens it: 288 is the sweep whose log is committed under profiles/).  ESC-Base has been bit-exact on
-    every clip of every sweep so far; the rule tolerates an attributed near-tie, the count is printed."""
-    tot = _parity_sweep("base", int(os.environ.get("ESCX_PARITY_SWEEP", "72")))
-    _near_tie_budget(tot)
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_parity_sweep_base_always_on(precision):
+    """the sweep is part of every GPU run, in every precision mode - ESC-Base against the oracle, every code: 72 noise + 72 voiced
+    3 s clips in the default mode, the first 36 + 36 of the same clips in the other two (ESCX_PARITY_SWEEP=<clips per family> widens all three: 288 is the sweep
+    whose log is committed under profiles/).  The fp32-MFMA arm is the strict one: ESC-Base has been bit-exact on every clip there in every sweep."""
+    n = int(os.environ.get("ESCX_PARITY_SWEEP", "72" if precision == PRECISIONS[0] else "36"))
+    _near_tie_budget(_parity_sweep("base", n, precision), strict=(precision == "fp32"))
 
 
 @pytest.mark.gpu
-def test_parity_sweep_large_always_on():
-    """The same for ESC-Large (depth 4, where the two attributed near-tie clips of the 288-clip sweep live): 18 + 18 clips in every GPU run
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_parity_sweep_large_always_on(precision):
+    """The same for ESC-Large (depth 4, where the attributed near-tie clips of the fp32-MFMA sweep live): 18 + 18 clips in every mode
     (ESCX_PARITY_SWEEP_LARGE=<clips per family> widens it; 144 = the committed sweep)."""
-    tot = _parity_sweep("large", int(os.environ.get("ESCX_PARITY_SWEEP_LARGE", "18")))
-    _near_tie_budget(tot)
+    _near_tie_budget(_parity_sweep("large", int(os.environ.get("ESCX_PARITY_SWEEP_LARGE", "18")), precision))
+
+
+def _scale_keys(sd, factor, which):
+    """Multiplies the named parameter families of EVERY SwinBlock / scale change in place (range-stress checkpoints)."""
+    n = 0
+    for k in sd:
+        if any(k.endswith(w) for w in which):
+            sd[k] = sd[k] * factor
+            n += 1
+    assert n > 0
+    return n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("case", ["ln_gain_x1e5", "fc1_x1e6", "all_small_x1e-4", "deembed_in_x1e6"])
+def test_range_stress_checkpoints(case, precision):
+    """VERDICT r5 weak #2 / ADVICE r5 (fp16 range of the two-term split): checkpoints whose activations leave fp16's comfortable range, in every precision mode,
+    against the oracle (which loads the SAME checkpoint and computes in fp32 like the reference):
+      ln_gain_x1e5     every LayerNorm gamma / beta x 1e5  -> LayerNorm outputs of 1e5 ... 5e5 (> 65504): an unscaled fp16 split gives inf -> NaN -> code 0
+                       (the Q / K / V weights are scaled x 1e-5 with it: the attention logits stay O(1) - 1e10 times larger logits would turn every softmax into an argmax that
+                       flips on fp32 rounding noise under ANY arithmetic, the reference's included; the split still sees 1e5-sized activations against 1e-5-sized weights)
+      fc1_x1e6         every fc1 weight / bias x 1e6       -> GELU outputs of ~1e6
+      all_small_x1e-4  LayerNorm gamma / beta and fc1 x 1e-4 -> every split activation ~1e-4: low terms of an unscaled split would be fp16 subnormals (14-bit operands)
+      deembed_in_x1e6  last decoder block's fc2 weight / bias x 1e6 -> the un-normalised tokens entering PatchDeEmbed reach ~1e6
+    (tagged builds: ESCX_X2_NO_ACT_SCALE=1 switches the activation scales of the two-term mode off - the first two cases then fail, which is what makes this a test:
+    profiles/r6_range_rule_off.txt)
+    Requirement (the same rule as everywhere): finite outputs, no code differs from the oracle except on an attributed reference near-tie, audio of the reference's
+    codes within 1e-4 RMS relative to the reference audio's own RMS (the stressed networks emit audio of arbitrary scale)."""
+    ln = ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "subsample.norm.weight", "subsample.norm.bias")
+    fc1 = ("mlp.linear_1.weight", "mlp.linear_1.bias")
+
+    def edit(sd):
+        if case == "ln_gain_x1e5":
+            _scale_keys(sd, 1e5, ln)
+            _scale_keys(sd, 1e-5, ("attn.qkv.weight",))
+        elif case == "fc1_x1e6":
+            _scale_keys(sd, 1e6, fc1)
+        elif case == "all_small_x1e-4":
+            _scale_keys(sd, 1e-4, ln + fc1)
+        else:
+            _scale_keys(sd, 1e6, ("decoder.post_nn.swint_blocks.1.mlp.linear_2.weight", "decoder.post_nn.swint_blocks.1.mlp.linear_2.bias"))
+
+    model, orc, g, cfg = build_models("base", precision, edit)
+    Trace = __import__("oracle.esc_oracle", fromlist=["Trace"]).Trace
+    pcm = np.stack([synth.noise_clip_int16(f"range-{i}", 48000) for i in range(2)] + [synth.voiced_clip_int16(f"range-v{i}", 48000) for i in range(2)])
+    x = torch.from_numpy(synth.pcm_to_float(pcm))
+    codes, shape = model.encode(x.cuda(), 6)
+    key = ("range", case)
+    if key not in _SWEEP_ORACLE:
+        tr = Trace()
+        oc, _ = orc.encode(x, 6, trace=tr)
+        _SWEEP_ORACLE[key] = (oc.numpy(), torch.stack(tr.margins, dim=1).numpy(), orc.decode(oc, shape).numpy())
+    ref, m, ow = _SWEEP_ORACLE[key]
+    got = codes.cpu().numpy()
+    assert got.min() >= 0 and got.max() < 1024
+    bad, forced, cont = attribute_with_continuation(orc, x, got, ref, m, 6)
+    same = (got == ref).reshape(len(pcm), -1).all(1)
+    print(f"[range {case} {precision}] {int(same.sum())}/{len(pcm)} clips bit-exact, reference min margin {m.min():.2e}; " + mismatch_summary(got, ref, m))
+    assert not bad, "\n".join(bad[:10])
+    wave = model.decode(torch.from_numpy(ref).cuda(), shape)
+    assert torch.isfinite(wave).all(), "non-finite audio"
+    ref_rms = float(np.sqrt(np.mean(ow.astype(np.float64) ** 2)))
+    assert np.isfinite(ref_rms) and rms(wave.cpu().numpy(), ow) <= AUDIO_TOL * max(ref_rms, 1.0), (rms(wave.cpu().numpy(), ow), ref_rms)
 
 
 def _ab_arms(arms, tmp_path, extra_env=None):
@@ -898,13 +978,15 @@ def test_fallback_kernel_forms_against_the_default(tmp_path):
     attn_gs_off (the C = 384 attention without the head-group split: another projection order) keeps the codes, audio within 1e-6 RMS."""
     arms = {"default": {}, "pvq_three_launch": {"ESCX_PVQ_FUSED": "0", "ESCX_PVQ_TABLE": "0"}, "pvq_fused_mfma_up": {"ESCX_PVQ_TABLE": "0"},
             "pvq_tables_only": {"ESCX_PVQ_FUSED": "0"}, "pvq_up_engine": {"ESCX_PVQ_FUSED": "0", "ESCX_PVQ_TABLE": "0", "ESCX_PVQ_UP_KERNEL": "0"},
-            "attn_gs_off": {"ESCX_ATTN_GS_TOKENS": "0"}, "all_fp32_mfma": {"ESCX_MLP_X3": "0", "ESCX_ATTN_X3": "0", "ESCX_ROWGEMM_X3": "0"},
-            "bf16_three_terms": {"ESCX_X3_TERMS": "3"}}
+            "attn_gs_off": {"ESCX_ATTN_GS_TOKENS": "0"}, "all_fp32_mfma": {"ESCX_PRECISION": "fp32"}, "per_family_switches_fp32": {"ESCX_MLP_X3": "0", "ESCX_ATTN_X3": "0", "ESCX_ROWGEMM_X3": "0"},
+            "bf16_three_terms": {"ESCX_PRECISION": "bf16x3"}, "bf16_three_terms_r5_spelling": {"ESCX_X3_TERMS": "3"}}
     got = _ab_arms(arms, tmp_path)
     ref = got["default"]
     for name in ("pvq_three_launch", "pvq_fused_mfma_up", "pvq_tables_only", "pvq_up_engine"):
         assert np.array_equal(got[name]["codes"], ref["codes"]) and np.array_equal(got[name]["wave"], ref["wave"]), f"{name} is not bit-identical to the default"
     # all_fp32_mfma: every contraction on the fp32 MFMA; bf16_three_terms: the exact three-term bf16 split instead of the default two fp16 terms (DESIGN.md section 10): other summation orders
+    # the environment variables only set the DEFAULT mode of new handles (escx_set_precision is the contract); both spellings select the same arithmetic
+    assert np.array_equal(got["all_fp32_mfma"]["wave"], got["per_family_switches_fp32"]["wave"]) and np.array_equal(got["bf16_three_terms"]["wave"], got["bf16_three_terms_r5_spelling"]["wave"])
     for name in ("attn_gs_off", "all_fp32_mfma", "bf16_three_terms"):
         assert np.array_equal(got[name]["codes"], ref["codes"]), f"{name}: codes differ from the default"
         rms = float(np.sqrt(np.mean((got[name]["wave"].astype(np.float64) - ref["wave"]) ** 2)))
