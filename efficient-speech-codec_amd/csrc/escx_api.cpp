@@ -1366,7 +1366,7 @@ static int ensure_pvq_tables(escx_handle_s* h, hipStream_t st) {
             // matrix time saved, and at C = 192 the kernel drops to one wave per SIMD (profiles/r5_attn_ab.txt)
             static const bool pairs_on = [] { const char* e = ESCX_TUNE_ENV("ESCX_ATTN_X3_PAIRS"); return e && e[0] == '1'; }();
             bw.x3a_pairs = pairs_on && nt == 3 && L.attn_mode != 2 && L.Cp != 48 && L.n_groups % 2 == 0 && (L.n_groups % 3 != 0 || (L.n_groups / 3) % 2 == 0);
-            if (attn_x3_pack(bw.waf, bw.x3a_buf, L.Cp, L.attn_mode, L.n_groups, st, bw.x3a_pairs ? 1 : (nt == 2 ? 2 : 0), no_act_scale ? nullptr : bw.ln1_g, bw.ln1_b, L.C) == 0) bw.x3a = bw.x3a_buf;
+            if (attn_x3_pack(bw.waf, bw.x3a_buf, L.Cp, L.attn_mode, L.n_groups, st, bw.x3a_pairs ? 1 : (nt == 2 ? 2 : 0), no_act_scale ? nullptr : bw.ln1_g, bw.ln1_b, L.C, bw.baf) == 0) bw.x3a = bw.x3a_buf;
         }
     // the split weight streams of PatchMerge / PatchSplit (fused_rowgemm.h rowgemm_x3_kernel)
     for (Layer& L : h->layers) {

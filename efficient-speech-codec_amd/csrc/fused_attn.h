@@ -86,16 +86,34 @@ __global__ __launch_bounds__(256) void attn_x3p_pack_kernel(const f32x4* __restr
 // NT = 2 (split_terms.h): two fp16 terms per weight, scaled by the power of two of the block's max |w| - the stream then ends with two 16-byte slots,
 // [0] bits of max |w| (absmax_bits_kernel over the fp32 fragment stream, before this kernel), [1] {2^-k / sx, 2^k sx, sx, 0} written here: sx = the power-of-two scale of
 // the LayerNorm output that is split against these weights (range rule of split_terms.h; bound from the norm's gamma / beta over n_ln padded channels, C real ones).
+// NT = 2, attention streams (bqkv given): the OUTPUT-PROJECTION tiles are stored in two-term form as well (round 6) - fragment `to` of a projection tile keeps its 1 KiB: lane
+// (channel l15, dims 4 lg .. 4 lg + 3 of the head group) holds {hi(w0, w1), hi(w2, w3), lo(w0, w1), lo(w2, w3)} of its four scaled weights, the operand of a 32-deep fp16
+// MFMA step whose other four k-slots per lane are zero (fused_attn.h proj_accumulate).  Attention streams carry THREE maxima in slot [0] - max |w| over the Q / K / V tiles
+// (their scale 2^k), over the V tiles alone, over the projection tiles (their own scale 2^kp) - and a third slot: [1] = {2^-k / sx, 2^k sx, sx, so}, [2] = {2^-kp / so};
+// so = the power-of-two scale of the O^T tiles, from |O| <= max |V| <= C max |w_V| B_x + max |b| (a softmax row is a convex combination of V rows).
 __global__ __launch_bounds__(256) void attn_x3_pack_kernel(const f32x4* __restrict__ waf, bf16x8* __restrict__ out, int n_tiles, int TPG, int KK, int KS, int TF, unsigned proj_mask, int NT = 3,
-                                                           const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr, int n_ln = 0, int C = 0) {
+                                                           const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr, int n_ln = 0, int C = 0,
+                                                           const float* __restrict__ bqkv = nullptr, int n_bqkv = 0) {
     const int per_tile = (KS > KK ? KS : KK) * 64;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)n_tiles * per_tile) return;
     const int tile = (int)(idx / per_tile), r = (int)(idx - (long long)tile * per_tile), f = r >> 6, lane = r & 63;
     const f32x4* src = waf + (size_t)tile * KK * 64;
     bf16x8* dst = out + (size_t)tile * TF * 64;
-    if ((proj_mask >> (tile % TPG)) & 1) {              // projection tile: fp32 fragments, copied
-        if (f < KK) reinterpret_cast<f32x4*>(dst)[f * 64 + lane] = src[f * 64 + lane];
+    if ((proj_mask >> (tile % TPG)) & 1) {              // projection tile: fp32 fragments, copied - or (two-term attention stream) split lane by lane
+        if (f < KK) {
+            const f32x4 w = src[f * 64 + lane];
+            if (NT == 2 && bqkv) {
+                const float sc = x2_scale(reinterpret_cast<const unsigned*>(out + (size_t)n_tiles * TF * 64)[2]);       // the projection tiles' own scale
+                const float v[8] = {w[0], w[1], w[2], w[3], 0.f, 0.f, 0.f, 0.f};
+                bf16x8 t[2];
+                split_terms<2>(v, t, sc);
+                const f32x4 hi = __builtin_bit_cast(f32x4, t[0]), lo = __builtin_bit_cast(f32x4, t[1]);
+                reinterpret_cast<f32x4*>(dst)[f * 64 + lane] = f32x4{hi[0], hi[1], lo[0], lo[1]};
+            } else {
+                reinterpret_cast<f32x4*>(dst)[f * 64 + lane] = w;
+            }
+        }
         return;
     }
     if (f >= KS) return;
@@ -117,8 +135,17 @@ __global__ __launch_bounds__(256) void attn_x3_pack_kernel(const f32x4* __restri
         split_terms<2>(v, t, sc);
         dst[(f * 2 + 0) * 64 + lane] = t[0]; dst[(f * 2 + 1) * 64 + lane] = t[1];
         if (idx == 0) {
-            const float sx = gamma ? act_pow2_scale(ln_out_bound(gamma, beta, n_ln, C)) : 1.0f;
-            float* o = reinterpret_cast<float*>(tail + 1); o[0] = (1.0f / sc) * (1.0f / sx); o[1] = sc * sx; o[2] = sx; o[3] = 0.f;
+            const float bx = gamma ? ln_out_bound(gamma, beta, n_ln, C) : 0.f;
+            const float sx = gamma ? act_pow2_scale(bx) : 1.0f;
+            float so = 1.0f;
+            const unsigned* mxs = reinterpret_cast<const unsigned*>(tail);
+            if (bqkv && gamma) {
+                float mb = 0.f;
+                for (int i = 0; i < n_bqkv; ++i) mb = fmaxf(mb, fabsf(bqkv[i]));
+                so = act_pow2_scale((float)C * __uint_as_float(mxs[1]) * bx + mb);
+            }
+            float* o = reinterpret_cast<float*>(tail + 1); o[0] = (1.0f / sc) * (1.0f / sx); o[1] = sc * sx; o[2] = sx; o[3] = so;
+            if (bqkv) { o[4] = (1.0f / x2_scale(mxs[2])) * (1.0f / so); o[5] = 0.f; o[6] = 0.f; o[7] = 0.f; }
         }
     }
 }
@@ -149,7 +176,7 @@ struct AttnArgs {
     float* tape_xn; float* tape_qkv; float* tape_o; int ldq, ldo, hdp, nH;
     const void* x3_wf;          // X3 instantiations: the split weight stream (attn_x3_pack_kernel), else unused
     int x3_pairs;               // the stream is in pair order [Q0 K0 V0 Q1 K1 V1 P_lo P_hi] (attn_x3p_pack_kernel): X3P instantiations
-    const float* x3_scale;      // NT = 2 instantiations: {2^-k / sx, 2^k sx, sx} of the block's weight stream (its last 16 bytes; sx = scale of the LayerNorm output, split_terms.h)
+    const float* x3_scale;      // NT = 2 instantiations: {2^-k / sx, 2^k sx, sx, so | 2^-kp / so} of the block's weight stream (its last 32 bytes; sx / so = scales of the LayerNorm output / of the O^T tiles, split_terms.h)
 };
 
 // One 16-byte piece of a block-input row: plain, or combined on the fly from the hidden-split MLP's slabs (see AttnArgs).
@@ -262,8 +289,8 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void at
     const int nW = a.nWh * a.nWw;
     f32x4 xf[X3 ? 1 : TMW][X3 ? 1 : KK];
     bf16x8 xs[X3 ? TMW : 1][NT][X3 ? KS : 1];                // X3: LayerNorm output split into NT terms, lane (slot l15, group lg) holds channels 32 s + 8 lg .. + 7
-    float x2_dn = 1.f, x2_up = 1.f, x2_sx = 1.f;   // NT = 2: 2^-k / sx, 2^k sx of the block's scaled weights, sx = the power-of-two scale of the LayerNorm output
-    if constexpr (NT == 2) { x2_dn = a.x3_scale[0]; x2_up = a.x3_scale[1]; x2_sx = a.x3_scale[2]; }
+    float x2_dn = 1.f, x2_up = 1.f, x2_sx = 1.f, x2_so = 1.f;   // NT = 2: 2^-k / sx, 2^k sx of the block's scaled weights, sx / so = the power-of-two scales of the LayerNorm output / the O^T tiles
+    if constexpr (NT == 2) { x2_dn = a.x3_scale[0]; x2_up = a.x3_scale[1]; x2_sx = a.x3_scale[2]; x2_so = a.x3_scale[3]; }
     int tok[TMW];                               // this lane's token row (element offset / CP), or -1
     bool lastH[TMW], lastW[TMW];
 #pragma unroll
@@ -505,6 +532,36 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void at
     };
     auto proj_accumulate = [&](const f32x4* o) {
         const f32x4* tb = wb + (size_t)(((tile - 1) % UT) * TF) * 64;       // X3: the projection tile's fp32 fragments, read straight from LDS
+        if constexpr (X3 && NT == 2) {
+            // Two-term projection (round 6): the head group's 16 dims are the REAL half of a 32-deep fp16 step - a lane's four O^T values (dims 4 lg + r) fill four of its
+            // eight k-slots, the other four are zero on both operands, so no value changes lane.  3 MFMAs of 16 cycles per output tile instead of 4 fp32 MFMAs of 32.
+            bf16x8 os[TMW][2];
+#pragma unroll
+            for (int t = 0; t < TMW; ++t) {
+                const float v8[8] = {o[t][0], o[t][1], o[t][2], o[t][3], 0.f, 0.f, 0.f, 0.f};
+                split_terms<2>(v8, os[t], x2_so);
+            }
+#pragma unroll
+            for (int to = 0; to < KK; to += 2) {
+                const f32x4 w = tb[to * 64], wn = (to + 1 < KK) ? tb[(to + 1) * 64] : zero4();
+                dma_pinned();
+                const bf16x8 wh = __builtin_bit_cast(bf16x8, f32x4{w[0], w[1], 0.f, 0.f}), wl = __builtin_bit_cast(bf16x8, f32x4{w[2], w[3], 0.f, 0.f});
+                const bf16x8 wnh = __builtin_bit_cast(bf16x8, f32x4{wn[0], wn[1], 0.f, 0.f}), wnl = __builtin_bit_cast(bf16x8, f32x4{wn[2], wn[3], 0.f, 0.f});
+#define ESCX_PJ2(WH, WL, TO) _Pragma("unroll") for (int t = 0; t < TMW; ++t) acc[TO][t] = mma_x<2>(WH, os[t][1], acc[TO][t]); \
+                             _Pragma("unroll") for (int t = 0; t < TMW; ++t) acc[TO][t] = mma_x<2>(WL, os[t][0], acc[TO][t]); \
+                             _Pragma("unroll") for (int t = 0; t < TMW; ++t) acc[TO][t] = mma_x<2>(WH, os[t][0], acc[TO][t]);
+                if (to + 1 < KK) {      // two output tiles interleaved: no back-to-back MFMAs on one accumulator
+#pragma unroll
+                    for (int t = 0; t < TMW; ++t) { acc[to][t] = mma_x<2>(wh, os[t][1], acc[to][t]); acc[to + 1][t] = mma_x<2>(wnh, os[t][1], acc[to + 1][t]); }
+#pragma unroll
+                    for (int t = 0; t < TMW; ++t) { acc[to][t] = mma_x<2>(wl, os[t][0], acc[to][t]); acc[to + 1][t] = mma_x<2>(wnl, os[t][0], acc[to + 1][t]); }
+#pragma unroll
+                    for (int t = 0; t < TMW; ++t) { acc[to][t] = mma_x<2>(wh, os[t][0], acc[to][t]); acc[to + 1][t] = mma_x<2>(wnh, os[t][0], acc[to + 1][t]); }
+                } else { ESCX_PJ2(wh, wl, to) }
+#undef ESCX_PJ2
+            }
+            return;
+        }
 #pragma unroll
         for (int to = 0; to < KK; to += 2) {    // two output tiles per step: no back-to-back MFMAs on one accumulator
             f32x4 w, wn = zero4();
@@ -732,6 +789,13 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, TMW, X3>())) void at
 #undef ESCX_SGB_MFMA
 
     // ---- 3. bias + shortcut, scatter through the map ----------------------------------------------
+    if constexpr (X3 && NT == 2) {              // the two-term projection's sums carry 2^k so: back (exact)
+        const float dn_proj = a.x3_scale[4];     // 2^-kp / so
+#pragma unroll
+        for (int o = 0; o < KK; ++o)
+#pragma unroll
+            for (int t = 0; t < TMW; ++t) acc[o][t] *= dn_proj;
+    }
     if (GS > 1) {
 #pragma unroll
         for (int t = 0; t < TMW; ++t) {
@@ -820,8 +884,8 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, 1, X3>())) void attn
     }
     f32x4 xf[X3 ? 1 : KK];
     bf16x8 xs[NT][X3 ? KS : 1];
-    float x2_dn = 1.f, x2_up = 1.f, x2_sx = 1.f;
-    if constexpr (NT == 2) { x2_dn = a.x3_scale[0]; x2_up = a.x3_scale[1]; x2_sx = a.x3_scale[2]; }
+    float x2_dn = 1.f, x2_up = 1.f, x2_sx = 1.f, x2_so = 1.f;
+    if constexpr (NT == 2) { x2_dn = a.x3_scale[0]; x2_up = a.x3_scale[1]; x2_sx = a.x3_scale[2]; x2_so = a.x3_scale[3]; }
     if constexpr (X3) {
         const float* xrow = a.src + (size_t)(tok < 0 ? 0 : tok) * CP;
         float xv[KS][8];
@@ -1061,6 +1125,23 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, 1, X3>())) void attn
         }
         begin_tile();
         const f32x4* ptb = wb + (size_t)(((tile - 1) % UT) * TF) * 64;      // X3: the projection tile's fp32 fragments, read straight from LDS
+        if constexpr (X3 && NT == 2) {          // two-term projection on the fp16 MFMA (attn_fused_kernel proj_accumulate)
+            const float v8[8] = {o[0], o[1], o[2], o[3], 0.f, 0.f, 0.f, 0.f};
+            bf16x8 os[2];
+            split_terms<2>(v8, os, x2_so);
+#pragma unroll
+            for (int to = 0; to < KK; to += 2) {
+                const f32x4 w = ptb[to * 64], wn = (to + 1 < KK) ? ptb[(to + 1) * 64] : zero4();
+                dma_pinned();
+                const bf16x8 wh = __builtin_bit_cast(bf16x8, f32x4{w[0], w[1], 0.f, 0.f}), wl = __builtin_bit_cast(bf16x8, f32x4{w[2], w[3], 0.f, 0.f});
+                const bf16x8 wnh = __builtin_bit_cast(bf16x8, f32x4{wn[0], wn[1], 0.f, 0.f}), wnl = __builtin_bit_cast(bf16x8, f32x4{wn[2], wn[3], 0.f, 0.f});
+                acc[to] = mma_x<2>(wh, os[1], acc[to]); if (to + 1 < KK) acc[to + 1] = mma_x<2>(wnh, os[1], acc[to + 1]);
+                acc[to] = mma_x<2>(wl, os[0], acc[to]); if (to + 1 < KK) acc[to + 1] = mma_x<2>(wnl, os[0], acc[to + 1]);
+                acc[to] = mma_x<2>(wh, os[0], acc[to]); if (to + 1 < KK) acc[to + 1] = mma_x<2>(wnh, os[0], acc[to + 1]);
+            }
+            cur = nxt;
+            continue;
+        }
 #pragma unroll
         for (int to = 0; to < KK; to += 2) {
             f32x4 w, wn = zero4();
@@ -1080,6 +1161,11 @@ __global__ __launch_bounds__(64 * NW, (attn_min_waves_x<CP, 1, X3>())) void attn
 #undef ESCX_SGB_VMEM
 #undef ESCX_SGB_MFMA
 
+    if constexpr (X3 && NT == 2) {
+        const float dn_proj = a.x3_scale[4];     // 2^-kp / so
+#pragma unroll
+        for (int o = 0; o < KK; ++o) acc[o] *= dn_proj;
+    }
     if (GS > 1) {
         if (tok >= 0) {
             float* pr = a.partial + ((size_t)gs * a.rows + tok) * CP + 4 * lg;

@@ -156,12 +156,12 @@ __global__ __launch_bounds__(256) void mlp_x3_split_pack_kernel(const f32x4* __r
 template <int CP> constexpr int mlp_x3_min_waves() { return CP <= 96 ? 4 : (CP <= 192 ? 2 : 1); }
 
 // SPLIT: PatchSplit in the epilogue (as fused_mlp.h SPLIT): LayerNorm(C) of x + mlp(x) in registers, Linear(C -> 2 C') with split operands, two-row scatter; x is not written.
-// PIPE (round 6; narrow layers whose pair of hidden tiles is ONE weight stage, CP <= 96): the main loop is software-pipelined over the pairs - iteration p issues the fc1
-// MFMAs of pair p + 1, the GELU + operand split of pair p (VALU) and the fc2 MFMAs of pair p - 1 as three INDEPENDENT instruction streams, so that one wave keeps the
-// matrix pipe, the VALU and the LDS busy at the same time instead of walking fc1 -> GELU -> fc2 in dependence order (round 5: both pipes ~50 % busy, in phase across the
-// barrier-synchronised waves of a workgroup).  Every accumulator sees the same products in the same order: bit-identical to the unpipelined loop.  The weight stage of a
-// pair is staged as two pieces (fc1 fragments, fc2 fragments) in two double-buffered rings of the same total size.
-template <int CP, int NW, bool SPLIT = false, int NT = 3, bool PIPE = false>
+// Round 6, measured and rejected (profiles/r6_mlp_pipe_ab.txt): a software-pipelined main loop for the one-stage widths - iteration p issuing the fc1 MFMAs of pair p + 1,
+// the GELU + split of pair p and the fc2 MFMAs of pair p - 1 as three independent streams (two double-buffered rings, biases loaded one iteration ahead), with a packed
+// v_pk_fma_f32 GELU.  Bit-identical, 110 registers, still four waves per SIMD, and 6-18 % SLOWER alone (C = 45 0.884 -> 0.937 ms per step, C = 72 0.468 -> 0.510, C = 96
+// 0.473 -> 0.558): on this chip VALU and MFMA issue do not overlap (profiles/r1_ubench_mfma_valu.txt: time = 32 N_mfma + ~4 N_valu at any occupancy; v_pk_fma_f32 costs two
+// v_fma_f32), so re-ordering independent work buys nothing and the fill / drain iterations and two more stage barriers per row tile are pure cost.
+template <int CP, int NW, bool SPLIT = false, int NT = 3>
 __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kernel(MlpArgs a) {
     constexpr int KS = mlp_x3_ks(CP), KK = CP / 16, CH = mlp_x3_frags(CP, NT), NOP = (KK + 1) / 2;
     constexpr bool SINGLE = mlp_x3_single(CP, NT);
@@ -206,24 +206,7 @@ __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kern
         for (int c = wave; c < cnt; c += NW)
             __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(dst + c * 64), 16, 0, 0);
     };
-    // PIPE: ring 1 = [2][F1] fc1 fragments of pairs p + 1 / p + 2, ring 2 = [2][F2] fc2 fragments of pairs p - 1 / p
-    constexpr int F1 = N2 * KS, F2 = CH - F1;
-    static_assert(!PIPE || SINGLE, "the pipelined loop needs the one-stage-per-pair layout");
-    auto issue_f1 = [&](int p) {
-        if (p >= p1) return;
-        const bf16x8* src = wsrc + ((size_t)p * CH) * 64 + lane;
-        bf16x8* dst = &x3_wbuf[(((p - p0) & 1) * F1) * 64];
-        for (int c = wave; c < F1; c += NW)
-            __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(dst + c * 64), 16, 0, 0);
-    };
-    auto issue_f2 = [&](int p) {
-        if (p >= p1) return;
-        const bf16x8* src = wsrc + ((size_t)p * CH + F1) * 64 + lane;
-        bf16x8* dst = &x3_wbuf[(2 * F1 + ((p - p0) & 1) * F2) * 64];
-        for (int c = wave; c < F2; c += NW)
-            __builtin_amdgcn_global_load_lds((const void*)(src + c * 64), (__attribute__((address_space(3))) void*)(dst + c * 64), 16, 0, 0);
-    };
-    if constexpr (PIPE) { issue_f1(p0); issue_f1(p0 + 1); } else issue(0);
+    issue(0);
     f32x4 x2sc = {1.f, 1.f, 1.f, 1.f};          // NT = 2: {2^-k1, 2^-k2, 2^k1, 2^k2} of this block's weight image
     float x2sx = 1.f, x2sh = 1.f;               // NT = 2: power-of-two scales of the LayerNorm output / the GELU output (range rule, split_terms.h); folded into x2sc
     if constexpr (NT == 2) {
@@ -295,91 +278,6 @@ __global__ __launch_bounds__(64 * NW, (mlp_x3_min_waves<CP>())) void mlp_x3_kern
         ++g;
         return wb;
     };
-    if constexpr (PIPE) {
-        // the three streams of one pair, on explicit operands
-        // fc1 biases are loaded ONE ITERATION AHEAD, before the iteration's weight DMAs are issued: a load that follows the DMAs in program order can only be waited for
-        // with vmcnt(0), i.e. together with the next stage's fragments (loads return in order) - that would put the DMA latency back on the critical path
-        auto load_bias = [&](int p, f32x4& b0, f32x4& b1v) { const int q = p < p1 ? p : p1 - 1; b0 = ld4(a.b1 + 32 * q + 4 * lg); b1v = ld4(a.b1 + 32 * q + 16 + 4 * lg); };
-        auto fc1_pair = [&](f32x4 b0, f32x4 b1v, const bf16x8* wb, f32x4& h0, f32x4& h1) {          // wb: ring-1 slot of the pair (+ lane)
-            h0 = b0; h1 = b1v;
-            if constexpr (NT == 2) { h0 *= x2sc[2]; h1 *= x2sc[2]; }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const bf16x8* wf = wb + (size_t)(s * N2) * 64;
-                bf16x8 w0[NT], w1[NT];
-#pragma unroll
-                for (int i = 0; i < NT; ++i) { w0[i] = wf[i * 64]; w1[i] = wf[(NT + i) * 64]; }
-#define ESCX_X3_FC1(I, J) h0 = mma_x<NT>(w0[I], xs[J][s], h0); h1 = mma_x<NT>(w1[I], xs[J][s], h1);
-                if constexpr (NT == 3) { ESCX_X3_TERMS(ESCX_X3_FC1) } else { ESCX_X2_TERMS(ESCX_X3_FC1) }
-#undef ESCX_X3_FC1
-            }
-        };
-        auto gelu_split = [&](f32x4 h0, f32x4 h1, bf16x8 (&hs3)[NT]) {
-            float hv[8];
-            if constexpr (NT == 2) { h0 *= x2sc[0]; h1 *= x2sc[0]; }
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {                      // packed-fp32 GELU (gelu_bf2: bit-identical to gelu_bf)
-                const f32x2 g0 = gelu_bf2(f32x2{h0[e], h0[e + 1]}), g1 = gelu_bf2(f32x2{h1[e], h1[e + 1]});
-                hv[e] = g0[0]; hv[e + 1] = g0[1]; hv[4 + e] = g1[0]; hv[4 + e + 1] = g1[1];
-            }
-            if constexpr (NT == 2) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) hv[e] *= x2sh;
-            }
-            split_rows<NT>(hv, hs3);
-        };
-        auto fc2_pair = [&](const bf16x8* w2b, const bf16x8 (&hs3)[NT]) {              // w2b: ring-2 slot of the pair (+ lane)
-#pragma unroll
-            for (int op = 0; op < NOP; ++op) {
-                const int o = 2 * op;
-                const bf16x8* wf = w2b + (size_t)(op * N2) * 64;
-                bf16x8 wa[NT], wn[NT];
-#pragma unroll
-                for (int i = 0; i < NT; ++i) { wa[i] = wf[i * 64]; if (o + 1 < KK) wn[i] = wf[(NT + i) * 64]; }
-#define ESCX_X3_FC2(I, J) acc[o] = mma_x<NT>(wa[I], hs3[J], acc[o]); if (o + 1 < KK) acc[o + 1] = mma_x<NT>(wn[I], hs3[J], acc[o + 1]);
-                if constexpr (NT == 3) { ESCX_X3_TERMS(ESCX_X3_FC2) } else { ESCX_X2_TERMS(ESCX_X3_FC2) }
-#undef ESCX_X3_FC2
-            }
-        };
-        auto ring1 = [&](int p) -> const bf16x8* { return &x3_wbuf[(((p - p0) & 1) * F1) * 64 + lane]; };
-        auto ring2 = [&](int p) -> const bf16x8* { return &x3_wbuf[(2 * F1 + ((p - p0) & 1) * F2) * 64 + lane]; };
-        auto stage_sync = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); };
-        f32x4 hc0, hc1, hn0, hn1, bc0, bc1, bn0, bn1;
-        bf16x8 hs_prev[NT], hs_cur[NT];
-        load_bias(p0, bc0, bc1);
-        // fill: fc1 of the first pair (its fragments and the next pair's are already on their way)
-        stage_sync();
-        load_bias(p0 + 1, bn0, bn1);
-        fc1_pair(bc0, bc1, ring1(p0), hc0, hc1);
-        // first iteration: fc1(p0 + 1) || GELU(p0)
-        stage_sync();
-        bc0 = bn0; bc1 = bn1; load_bias(p0 + 2, bn0, bn1);
-        issue_f1(p0 + 2); issue_f2(p0);
-        fc1_pair(bc0, bc1, ring1(p0 + 1), hn0, hn1);
-        gelu_split(hc0, hc1, hs_prev);
-        hc0 = hn0; hc1 = hn1;
-        // steady state: fc1(p + 1) || GELU(p) || fc2(p - 1)
-        for (int p = p0 + 1; p + 1 < p1; ++p) {
-            stage_sync();
-            bc0 = bn0; bc1 = bn1; load_bias(p + 2, bn0, bn1);
-            issue_f1(p + 2); issue_f2(p);
-            fc1_pair(bc0, bc1, ring1(p + 1), hn0, hn1);
-            gelu_split(hc0, hc1, hs_cur);
-            fc2_pair(ring2(p - 1), hs_prev);
-            hc0 = hn0; hc1 = hn1;
-#pragma unroll
-            for (int i = 0; i < NT; ++i) hs_prev[i] = hs_cur[i];
-        }
-        // last pair: GELU(p1 - 1) || fc2(p1 - 2)
-        stage_sync();
-        issue_f2(p1 - 1);
-        gelu_split(hc0, hc1, hs_cur);
-        fc2_pair(ring2(p1 - 2), hs_prev);
-        // drain: fc2(p1 - 1)
-        stage_sync();
-        fc2_pair(ring2(p1 - 1), hs_cur);
-        g = 0;
-    } else
     for (int p = p0; p < p1; ++p) {
         const f32x4 bias0 = ld4(a.b1 + 32 * p + 4 * lg), bias1 = ld4(a.b1 + 32 * p + 16 + 4 * lg);
         const bf16x8* wb = nullptr;

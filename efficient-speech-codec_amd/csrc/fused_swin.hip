@@ -185,15 +185,9 @@ int mlp_x3_pack(const float* w1, const float* w2, void* image, int Cp, int hidde
     return 0;
 }
 
-// Software-pipelined main loop (fused_mlp_x3.h PIPE) for the widths whose pair is one weight stage; ESCX_MLP_X3_PIPE=0: the round-5 loop (A/B, fallback; bit-identical results)
-static bool mlp_x3_pipe_on() { static const bool v = [] { const char* e = getenv("ESCX_MLP_X3_PIPE"); return !(e && e[0] == '0'); }(); return v; }
-
-template <int CP, int NW, int NT = 3, bool PIPE = false>
+template <int CP, int NW, int NT = 3>
 static void launch_mlp_x3(const MlpArgs& a, hipStream_t s) {
-    if constexpr (!PIPE && mlp_x3_single(CP, NT)) {
-        if (mlp_x3_pipe_on() && a.HS <= 1 && a.HT / 2 >= 2) { launch_mlp_x3<CP, NW, NT, true>(a, s); return; }
-    }
-    auto kern = mlp_x3_kernel<CP, NW, false, NT, PIPE>;
+    auto kern = mlp_x3_kernel<CP, NW, false, NT>;
     constexpr int lds = 2 * mlp_x3_stage_frags(CP, NT) * 1024;
     if constexpr (lds > 48 * 1024) {            // function attributes are per device: one flag per device
         static std::atomic<unsigned> done{0};
@@ -228,12 +222,9 @@ int mlp_x3_split_pack(const float* wf, void* image, int Cp, int Np, hipStream_t 
     return 0;
 }
 
-template <int CP, int NW, int NT = 3, bool PIPE = false>
+template <int CP, int NW, int NT = 3>
 static void launch_mlp_x3_split(const MlpArgs& a, hipStream_t s) {
-    if constexpr (!PIPE && mlp_x3_single(CP, NT)) {
-        if (mlp_x3_pipe_on() && a.HT / 2 >= 2) { launch_mlp_x3_split<CP, NW, NT, true>(a, s); return; }
-    }
-    auto kern = mlp_x3_kernel<CP, NW, true, NT, PIPE>;
+    auto kern = mlp_x3_kernel<CP, NW, true, NT>;
     constexpr int lds = 2 * mlp_x3_stage_frags(CP, NT) * 1024;
     if constexpr (lds > 48 * 1024) {
         static std::atomic<unsigned> done{0};
@@ -447,7 +438,7 @@ int rowgemm_x3_pack(const float* wf, void* image, int KP, int Np, hipStream_t s,
         ESCX_LAUNCH(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, wf, n, mx);
     }
     ESCX_LAUNCH(attn_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(wf), reinterpret_cast<bf16x8*>(image),
-                       NT, 1, KK, KS, 3 * KS, 0u, nt == 2 ? 2 : 3, gamma, beta, KP, C);
+                       NT, 1, KK, KS, 3 * KS, 0u, nt == 2 ? 2 : 3, gamma, beta, KP, C, (const float*)nullptr, 0);
     return 0;
 }
 
@@ -649,11 +640,11 @@ static int launch_attn_packed(const AttnArgs& a, hipStream_t s) {
     return 0;
 }
 
-size_t attn_x3_bytes(int Cp, int mode, int n_groups) { return (size_t)n_groups * (mode == 2 ? 8 : 4) * attn_x3_tf(Cp) * 1024 + 32; }      // + trailer of the two-term form (max |w|, scales)
+size_t attn_x3_bytes(int Cp, int mode, int n_groups) { return (size_t)n_groups * (mode == 2 ? 8 : 4) * attn_x3_tf(Cp) * 1024 + 48; }      // + trailer of the two-term form (three maxima, scales: fused_attn.h attn_x3_pack_kernel)
 
 // pairs == 1: pair-order stream (mode 0 / 1, even group count): [Q0 K0 V0 Q1 K1 V1 P_lo P_hi] per two head groups, projection split as well
 // pairs == 2: the two-term fp16 form of the plain stream (split_terms.h): weights scaled by the power of two of the block's max |w|, scales in the trailer
-int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, hipStream_t s, int pairs, const float* gamma, const float* beta, int C) {
+int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, hipStream_t s, int pairs, const float* gamma, const float* beta, int C, const float* bqkv) {
     const int KK = Cp / 16, KS = attn_x3_ks(Cp), TF = attn_x3_tf(Cp), TPG = mode == 2 ? 8 : 4;
     if (pairs == 1) {
         if (mode == 2 || (n_groups & 1)) return -1;
@@ -669,12 +660,16 @@ int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, 
     (void)hipMemsetAsync(image, 0, attn_x3_bytes(Cp, mode, n_groups), s);
     const long long total = (long long)n_tiles * (KS > KK ? KS : KK) * 64;
     if (pairs == 2) {
-        unsigned* mx = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(image) + attn_x3_bytes(Cp, mode, n_groups) - 32);
+        unsigned* mx = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(image) + attn_x3_bytes(Cp, mode, n_groups) - 48);
         const long long n = (long long)n_tiles * KK * 64 * 4;
-        ESCX_LAUNCH(absmax_bits_kernel, dim3((unsigned)std::min<long long>(256, (n + 255) / 256)), dim3(256), 0, s, waf, n, mx);
+        const unsigned all = (1u << TPG) - 1, vmask = mode == 2 ? ((1u << 4) | (1u << 6)) : (1u << 2);
+        const dim3 grid((unsigned)std::min<long long>(256, (n + 255) / 256));
+        ESCX_LAUNCH(absmax_tiles_bits_kernel, grid, dim3(256), 0, s, waf, n, KK * 256, TPG, all & ~proj_mask, mx);
+        ESCX_LAUNCH(absmax_tiles_bits_kernel, grid, dim3(256), 0, s, waf, n, KK * 256, TPG, vmask, mx + 1);
+        ESCX_LAUNCH(absmax_tiles_bits_kernel, grid, dim3(256), 0, s, waf, n, KK * 256, TPG, proj_mask, mx + 2);
     }
     ESCX_LAUNCH(attn_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(waf), reinterpret_cast<bf16x8*>(image),
-                       n_tiles, TPG, KK, KS, TF, proj_mask, pairs == 2 ? 2 : 3, gamma, beta, Cp, C);
+                       n_tiles, TPG, KK, KS, TF, proj_mask, pairs == 2 ? 2 : 3, gamma, beta, Cp, C, bqkv, n_groups * (mode == 2 ? 6 : 3) * 16);
     return 0;
 }
 
@@ -690,7 +685,7 @@ int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_grou
                comb ? comb->partial : nullptr, comb ? comb->bias : nullptr, comb ? comb->stride : 0, comb ? comb->n : 0,
                tape ? tape->xn : nullptr, tape ? tape->qkv : nullptr, tape ? tape->o : nullptr, tape ? tape->ldq : 0, tape ? tape->ldo : 0,
                tape ? tape->hdp : 0, tape ? tape->nH : 0, (comb || tape) ? nullptr : x3_wf, x3_pairs == 1 ? 1 : 0,
-               (!comb && !tape && x3_wf && x3_pairs == 2) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(x3_wf) + attn_x3_bytes(Cp, mode, n_groups) - 16) : nullptr};
+               (!comb && !tape && x3_wf && x3_pairs == 2) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(x3_wf) + attn_x3_bytes(Cp, mode, n_groups) - 32) : nullptr};
     if (tape && nw < 0) return ESCX_COMB_UNSUPPORTED;      // the packed H = 2 form has no tape stores
     // H == 2 scale with no padding along W: two half-real windows share one tile (nw < 0 encodes "packing allowed", |nw| waves)
     if (nw < 0) {

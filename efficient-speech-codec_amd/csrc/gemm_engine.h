@@ -366,21 +366,6 @@ __device__ __forceinline__ float gelu_bf(float x) {
     return fmaf(-fabsf(x), __builtin_amdgcn_exp2f(r), fmaxf(x, 0.0f));      // |x| and the negation are operand modifiers: 11 ops
 }
 
-// Two values per instruction (v_pk_fma_f32: the packed-fp32 VALU rate of CDNA3 / CDNA4): the SAME eight fused multiply-adds, exp2 and final fma per element as gelu_bf,
-// so the result is bit-identical; 8 values cost 8 |x| + 8 max + 32 + 4 packed fmas + 8 exp2 = 60 VALU instructions instead of 88.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_bf2(f32x2 x) {
-    const f32x2 a = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
-    f32x2 r = {-1.6904631365832756e-06f, -1.6904631365832756e-06f};
-    constexpr float c[8] = {2.5084045773837715e-05f, -0.0001144662601291202f, -0.0003233331080991775f, 0.007333371322602034f, -0.052714187651872635f, -0.4591154456138611f,
-                            -1.151123285293579f, 1.126017423302983e-06f - 1.0f};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { const f32x2 cc = {c[i], c[i]}; r = __builtin_elementwise_fma(r, a, cc); }
-    const f32x2 e = {__builtin_amdgcn_exp2f(r[0]), __builtin_amdgcn_exp2f(r[1])};
-    const f32x2 m = {fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
-    return __builtin_elementwise_fma(-a, e, m);
-}
-
 struct EpiStore {               // out[m][n] = v (+ bias[n])
     float* out; int ldo; const float* bias;
     __device__ __forceinline__ void store(int m, int n, f32x4 v, int) const {

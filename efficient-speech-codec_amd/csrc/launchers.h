@@ -75,7 +75,7 @@ int attn_fused(const float* src, float* dst, int Cp, int C, int mode, int n_grou
                const CombineOnLoad* comb = nullptr, const struct AttnTape* tape = nullptr,
                const void* x3_wf = nullptr, int x3_pairs = 0);     // split (3 x bf16) weight stream of this block (attn_x3_pack; pairs: its pair-order form), nullptr = fp32 MFMA
 size_t attn_x3_bytes(int Cp, int mode, int n_groups);
-int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, hipStream_t s, int pairs = 0, const float* gamma = nullptr, const float* beta = nullptr, int C = 0);   // norm1's gamma / beta (pairs == 2: range rule)
+int attn_x3_pack(const float* waf, void* image, int Cp, int mode, int n_groups, hipStream_t s, int pairs = 0, const float* gamma = nullptr, const float* beta = nullptr, int C = 0, const float* bqkv = nullptr);   // norm1's gamma / beta and the tile biases (pairs == 2: range rule; the output projection in two-term form too)
 // training forward: the fused attention also writes what the backward reads (fused_attn.h, TAPE); returns ESCX_COMB_UNSUPPORTED when the width has
 // no TAPE instantiation (the caller runs the unfused sequence)
 struct AttnTape { float* xn; float* qkv; float* o; int ldq, ldo, hdp, nH; };

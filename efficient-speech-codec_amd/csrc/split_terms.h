@@ -80,6 +80,15 @@ static __global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
+// the same over the tiles of a fragment stream whose kind (tile index mod tpg) is selected by `mask` (attention streams: Q / K / V tiles, V tiles, projection tiles)
+static __global__ __launch_bounds__(256) void absmax_tiles_bits_kernel(const float* __restrict__ w, long long n, int tile_floats, int tpg, unsigned mask, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        if ((mask >> (int)((i / tile_floats) % tpg)) & 1) m = max(m, __float_as_uint(fabsf(w[i])));
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
 // bits of max_r sum_c w[r][c]^2 -> *out (one wave per row; the fc1 bound of the range rule)
 static __global__ __launch_bounds__(256) void rownorm2_max_bits_kernel(const float* __restrict__ w, int rows, int cols, int ld, unsigned* __restrict__ out) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
