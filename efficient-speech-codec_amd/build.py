@@ -16,7 +16,7 @@ OUT_DIR = os.path.join(HERE, "esc", "lib")
 TAG = os.environ.get("ESCX_BUILD_TAG", "")
 OBJ_DIR = os.path.join(HERE, "build" + ("_" + TAG if TAG else ""))
 LIB = os.path.join(OUT_DIR, "libescx" + ("_" + TAG if TAG else "") + ".so")
-SOURCES = ["escx_api.cpp", "collective.cpp", "train.hip", "disc.hip", "gemm_swin.hip", "gemm_misc.hip", "kernels_misc.hip", "fused_swin.hip"]
+SOURCES = ["escx_api.cpp", "escx_params.cpp", "escx_profile.cpp", "collective.cpp", "train.hip", "disc.hip", "gemm_swin.hip", "gemm_misc.hip", "kernels_misc.hip", "fused_swin.hip"]
 HEADERS = ["tune_env.h", "launch_prof.h", "split_terms.h", "fused_pvq.h", "fused_mlp_x3.h", "train_kernels.h", "train_mlp_fused.h", "disc_kernels.h", "gemm_bf16.h", "conv32_halo.h", "gemm_engine.h", "kernels.h", "launchers.h", "escx_internal.h", "fused_mlp.h", "fused_attn.h", "fused_rowgemm.h", "fused_deembed.h", os.path.join("..", "..", "include", "escx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + os.environ.get("ESCX_EXTRA_CXXFLAGS", "").split()     # tuning builds only

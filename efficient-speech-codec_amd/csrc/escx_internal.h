@@ -109,6 +109,10 @@ int check_ready(escx_handle_s* h);
 float* stream_scratch(hipStream_t st, int slot, size_t floats);
 int launch_ok(const char* what);
 int build_gather_map(escx_handle_s* h);
+// escx_params.cpp, used by the launch sequences of escx_api.cpp
+void use_set(escx_handle_s* h, int i);          // makes workspace set i the current one (the inherited WsFields)
+int n_parts(escx_handle_s* h, int B);           // batch parts (streams) a batch of B clips runs as
+int ensure_ws(escx_handle_s* h, int B, int T, Shapes* s);      // reserve on demand, select set 0, derive the shapes
 }
 
 struct escx_handle_s : escx::WsFields {      // the inherited fields are the CURRENT set (swapped by use_set)

@@ -20,7 +20,19 @@ from .codecs import _Node, _attach
 
 BANDS = [(0.0, 0.1), (0.1, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0)]
 _PRECISIONS = {"fp32": 0, "bf16": 1, "split": 2}
-_DEFAULT_CONV_PRECISION = _PRECISIONS[__import__("os").environ.get("ESCX_DISC_PRECISION", "split")]      # see Discriminator.set_conv_precision
+
+
+def _default_conv_precision() -> int:
+    """ESCX_DISC_PRECISION (fp32 | bf16 | split) names the default of NEW Discriminator objects; anything else is an error that says so (not a bare
+    KeyError at import time).  The Python host defaults to "split" (fp32-grade, three exact bf16 terms); a C host that never calls escx_disc_set_precision gets mode 0
+    (fp32 MFMA) - INTEGRATION.md section 2 spells the difference out."""
+    v = __import__("os").environ.get("ESCX_DISC_PRECISION", "split")
+    if v not in _PRECISIONS:
+        raise ValueError(f"ESCX_DISC_PRECISION={v!r}: expected one of {sorted(_PRECISIONS)}")
+    return _PRECISIONS[v]
+
+
+_DEFAULT_CONV_PRECISION = _default_conv_precision()      # see Discriminator.set_conv_precision
 
 
 def _conv_specs(periods, fft_sizes, n_bands):

@@ -59,7 +59,6 @@ timeout 600 python tools/small_batch.py > $O/small_batch.txt 2>&1
 timeout 1200 bash tools/sq_util.sh > /dev/null 2>&1; cp gpurun_out/sq_util.txt $O/sq_util.txt 2>/dev/null
 SQ_BENCH_ARGS="--mode train --steps 2 --warmup 1 --profile-steps 2 --no-cpu-baseline" SQ_OUT=sq_util_train.txt SQ_TOP=45 ESCX_TRAIN_PARTS=1 timeout 1500 bash tools/sq_util.sh > /dev/null 2>&1; cp gpurun_out/sq_util_train.txt $O/sq_util_train.txt 2>/dev/null
 # round 5: GEMM-engine micro-benchmark with the 32x32x2 MFMA arm, the fused-PVQ phase trace when the tuning build is present, the wide parity sweeps
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -I efficient-speech-codec_amd/csrc -I tools tools/ubench_gemm.hip -o /tmp/ubench_gemm 2>/dev/null && timeout 600 /tmp/ubench_gemm > $O/ubench_gemm.txt 2>&1
 timeout 1800 bash tools/r5_sweeps.sh > $O/sweeps_tail.txt 2>&1; cp gpurun_out/r5_sweeps/base576.log $O/parity_sweep_base576.log 2>/dev/null; cp gpurun_out/r5_sweeps/large288.log $O/parity_sweep_large288.log 2>/dev/null
 find $O -name "*.csv" ! -name "*kernel_stats.csv" -delete; rm -rf $O/prof $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/cal_fetch $O/cal_write
 ls -la $O
