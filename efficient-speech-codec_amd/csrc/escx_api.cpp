@@ -21,9 +21,15 @@ using namespace escx;
 // Clips are independent end to end, so the halves never exchange data; overlapping them lets one half's kernels fill
 // the CUs the other half's tail workgroups leave idle (a 36-clip layer launches only ~1.3-2.6 workgroups per CU).
 template <class F>
-static int run_halves(escx_handle_s* h, int B, hipStream_t st, F part) {
+static int run_halves(escx_handle_s* h, int B, int T, hipStream_t st, F part) {
     const int k = std::min(n_parts(h, B), h->n_sets);
-    if (k <= 1) { use_set(h, 0); return part(0, B, st); }
+    // a part walks its clips in passes of at most `pass` clips (escx_params.cpp pass_clips: the workspace sets are sized for one pass)
+    const int pass = std::max(1, std::min(pass_clips(h, B, T), h->sets[0].shp.B));
+    auto run_part = [&](int b0, int nb, hipStream_t si) -> int {
+        for (int off = 0; off < nb; off += pass) { const int r = part(b0 + off, std::min(pass, nb - off), si); if (r) return r; }
+        return 0;
+    };
+    if (k <= 1) { use_set(h, 0); return run_part(0, B, st); }
     const int per = (B + k - 1) / k;
     // Event timing stays valid under concurrency (each kernel is bracketed on its own stream); ESCX_PROF_SERIAL=1 puts the
     // parts back to back on the caller's stream when isolated per-kernel durations are wanted.
@@ -40,17 +46,23 @@ static int run_halves(escx_handle_s* h, int B, hipStream_t st, F part) {
         if (e != hipSuccess && rc == 0) { set_error("run_halves: %s: %s", what, hipGetErrorString(e)); rc = ESCX_ERR_HIP; }
         return e != hipSuccess;
     };
-    for (int i = 0; i < k && !rc; ++i) {
-        const int b0 = i * per, nb = std::min(per, B - b0);
-        if (nb <= 0) break;
-        const bool side = concurrent && i > 0;
-        hipStream_t si = side ? h->sx[i] : st;
-        if (side && hip_fail(hipStreamWaitEvent(si, h->ev_fork, 0), "fork wait")) break;
-        use_set(h, i);
-        if (side) started[i] = true;
-        const int prc = part(b0, nb, si);
-        if (prc && !rc) rc = prc;
+    // fork every side stream, then enqueue the passes ROUND-ROBIN over the parts (pass j of part 0, pass j of part 1, ...): the host feeds both streams from the
+    // start instead of queueing a whole part (hundreds of launches for a 288-clip batch) before the other stream sees its first kernel
+    for (int i = 1; i < k && concurrent && !rc; ++i) {
+        if (i * per >= B) break;
+        if (hip_fail(hipStreamWaitEvent(h->sx[i], h->ev_fork, 0), "fork wait")) break;
+        started[i] = true;
     }
+    for (int off = 0; off < per && !rc; off += pass)
+        for (int i = 0; i < k && !rc; ++i) {
+            const int b0 = i * per, nb = std::min(per, B - b0);
+            if (off >= nb) continue;
+            const bool side = concurrent && i > 0;
+            if (side && !started[i]) continue;
+            use_set(h, i);
+            const int prc = part(b0 + off, std::min(pass, nb - off), side ? h->sx[i] : st);
+            if (prc && !rc) rc = prc;
+        }
     for (int i = 1; i < k; ++i) {
         if (!started[i]) continue;
         if (hipEventRecord(h->ev_join[i], h->sx[i]) != hipSuccess || hipStreamWaitEvent(st, h->ev_join[i], 0) != hipSuccess) {
@@ -571,7 +583,7 @@ extern "C" int escx_encode(escx_handle h, const float* wave, int B, int L, int S
     Shapes s; if ((rc = ensure_ws(h, B, frames_of(h, L), &s))) return rc;
     const long long cstride = (long long)S * h->cfg.group_size * s.Tq;
     if ((rc = ensure_pvq_tables(h, (hipStream_t)stream))) return rc;
-    rc = run_halves(h, B, (hipStream_t)stream, [&](int b0, int nb, hipStream_t st) -> int {
+    rc = run_halves(h, B, s.T, (hipStream_t)stream, [&](int b0, int nb, hipStream_t st) -> int {
         Shapes sp = s; sp.B = nb; int r;
         if ((r = run_stft(h, wave + (size_t)b0 * L, nb, L, sp.T, h->spec, st))) return r;
         if ((r = run_encoder(h, sp, st))) return r;
@@ -612,7 +624,7 @@ extern "C" int escx_decode(escx_handle h, const int64_t* codes, int B, int S, in
     const int T2 = c.patch_t * fw, out_len = c.hop_length * (T2 - 1);
     const long long cstride = (long long)S * c.group_size * (fw / c.overlap);
     if ((rc = ensure_pvq_tables(h, (hipStream_t)stream))) return rc;
-    rc = run_halves(h, B, (hipStream_t)stream, [&](int b0, int nb, hipStream_t st) -> int {
+    rc = run_halves(h, B, s.T, (hipStream_t)stream, [&](int b0, int nb, hipStream_t st) -> int {
         int r;
         if ((r = run_csvq_decode(h, (const long long*)codes + b0 * cstride, nb, S, fh, fw, h->rspec, st))) return r;
         if ((r = run_istft(h, h->rspec, nb, T2, wave_out + (size_t)b0 * out_len, st))) return r;
@@ -639,7 +651,7 @@ static int forward_impl(escx_handle h, const float* wave, const float* feat, int
     const long long bstride = (long long)S * G * s.Tq, sstride = (long long)G * s.Tq;
     const int T2 = c.patch_t * s.W, out_len = c.hop_length * (T2 - 1);
     if ((rc = ensure_pvq_tables(h, (hipStream_t)stream))) return rc;
-    return run_halves(h, B, (hipStream_t)stream, [&](int b0, int nb, hipStream_t st) -> int {
+    return run_halves(h, B, s.T, (hipStream_t)stream, [&](int b0, int nb, hipStream_t st) -> int {
         Shapes sp = s; sp.B = nb; int r;
         long long* cd = (long long*)codes + b0 * bstride;
         if (wave) { if ((r = run_stft(h, wave + (size_t)b0 * L, nb, L, sp.T, h->spec, st))) return r; }
@@ -728,7 +740,7 @@ extern "C" int escx_patch_embed(escx_handle h, const float* spec, int B, int T, 
 
 // stage-level calls run the whole batch on set 0, so ask for a workspace whose HALF holds B clips
 static int stage_ws_for_w(escx_handle_s* h, int B, int W, Shapes* s) {
-    int rc = ensure_ws(h, h->parts * B, frames_for_width(h, W), s);
+    int rc = ensure_ws(h, h->parts * B, frames_for_width(h, W), s, B);
     if (!rc) s->B = B;
     return rc;
 }

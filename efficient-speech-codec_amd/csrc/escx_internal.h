@@ -112,7 +112,8 @@ int build_gather_map(escx_handle_s* h);
 // escx_params.cpp, used by the launch sequences of escx_api.cpp
 void use_set(escx_handle_s* h, int i);          // makes workspace set i the current one (the inherited WsFields)
 int n_parts(escx_handle_s* h, int B);           // batch parts (streams) a batch of B clips runs as
-int ensure_ws(escx_handle_s* h, int B, int T, Shapes* s);      // reserve on demand, select set 0, derive the shapes
+int ensure_ws(escx_handle_s* h, int B, int T, Shapes* s, int min_set_clips = 0);      // reserve on demand (a set holds at least min_set_clips clips), select set 0, derive the shapes
+int pass_clips(escx_handle_s* h, int B, int T);  // clips one pass of one part handles (<= clips of the part)
 }
 
 struct escx_handle_s : escx::WsFields {      // the inherited fields are the CURRENT set (swapped by use_set)
@@ -171,6 +172,7 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     int cap_clips = 0;               // total clips (over all parts) the current workspace was reserved for
     int parts = 2;                   // ESCX_STREAMS=k (1..4): batch split into k parts on k streams; 1 = single stream
     bool parts_forced = false;       // ESCX_STREAMS given: use it for every batch size
+    int chunk_frames = 10818;        // (18 clips of 3 s) a part walks its clips in passes of at most chunk_frames / T clips (0 = one pass): see run_halves (escx_api.cpp); ESCX_CHUNK_FRAMES
     hipStream_t sx[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};   // extra streams (part 0 runs on the caller's stream)
     hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
 

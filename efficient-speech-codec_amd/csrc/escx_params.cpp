@@ -132,6 +132,7 @@ extern "C" int escx_create(const escx_config* cfg, int device, escx_handle* out)
     { const char* e = ESCX_TUNE_ENV("ESCX_MLP_HS"); if (e && e[0]) h->mlp_hs = atoi(e); }
     { const char* e = ESCX_TUNE_ENV("ESCX_ATTN_GS"); if (e && e[0]) h->attn_gs = atoi(e); }
     { const char* e = getenv("ESCX_STREAMS"); if (e && e[0]) { h->parts = std::min(std::max(atoi(e), 1), (int)escx_handle_s::MAX_PARTS); h->parts_forced = true; } }
+    { const char* e = getenv("ESCX_CHUNK_FRAMES"); if (e && e[0]) h->chunk_frames = atoi(e); }
     { const char* e = getenv("ESCX_DEEMBED_TWO_STAGE"); h->deembed_two_stage = (e && e[0] == '1'); }
     { const char* e = getenv("ESCX_DEEMBED_GEMM"); h->deembed_halo = !(e && e[0] == '1'); }
     { const char* e = ESCX_TUNE_ENV("ESCX_ATTN_NW"); if (e && e[0]) h->attn_nw = atoi(e); }
@@ -761,10 +762,19 @@ void escx::use_set(escx_handle_s* h, int i) { static_cast<WsFields&>(*h) = h->se
 // parts' tails returns (measured, tools/small_batch.py: B = 2 4.52 -> 4.12 ms, B = 4 4.96 -> 4.67 ms; from B = 8 up two parts win).  The
 // arithmetic of a clip does not depend on how the batch is split, so the codes stay identical either way.
 int escx::n_parts(escx_handle_s* h, int B) { return std::max(1, std::min((h->parts_forced || B >= 6) ? h->parts : 1, B)); }
-static int set_clips(escx_handle_s* h, int B) { const int k = n_parts(h, B); return (B + k - 1) / k; }
+// Clips a workspace set must hold = clips of one PASS of a part.  Round 6: a part of a large batch walks its clips in passes of at most chunk_frames / T clips, so that the
+// activations a pass hands from kernel to kernel stay within reach of the 256 MB memory-side cache (18 clips x 601 frames: the C = 45 maps are 66 MB each) - at 144 clips per
+// part they are 530 MB and every kernel re-reads its input from HBM, which is why 288 clips ran 4 % SLOWER per clip than 36 (profiles/r6_chunk_ab.txt).  Clips are
+// independent end to end: the pass structure changes no arithmetic.
+int escx::pass_clips(escx_handle_s* h, int B, int T) {
+    const int k = n_parts(h, B), per = (B + k - 1) / k;
+    if (h->chunk_frames <= 0 || T <= 0) return per;
+    return std::max(1, std::min(per, h->chunk_frames / T));
+}
+static int set_clips(escx_handle_s* h, int B, int T) { return pass_clips(h, B, T); }
 
 static bool ws_fits(escx_handle_s* h, int B, int T) {
-    const int need = set_clips(h, B), sets = n_parts(h, B);
+    const int need = set_clips(h, B, T), sets = n_parts(h, B);
     for (int i = 0; i < sets; ++i) {
         const WsFields& S = h->sets[i];
         // capacity, not equality: every buffer is sized by (clips, frames) maxima and grows monotonically with both, so a shorter
@@ -778,7 +788,7 @@ static bool ws_fits(escx_handle_s* h, int B, int T) {
 // the batch: 5 clips run as one part of 5, 8 clips as two parts of 4)
 static int reserve_frames(escx_handle_s* h, int Btotal, int T, int set_clips_min = 0, int sets_min = 0) {
     ESCX_HIP(hipSetDevice(h->device));
-    const int B = std::max(set_clips(h, Btotal), set_clips_min), sets = std::max(n_parts(h, Btotal), sets_min);
+    const int B = std::max(set_clips(h, Btotal, T), set_clips_min), sets = std::max(n_parts(h, Btotal), sets_min);
     Shapes s;
     int rc = make_shapes(h, B, T, &s);
     if (rc) return rc;
@@ -912,9 +922,9 @@ int escx::check_infer_ready(escx_handle_s* h) {
     return 0;
 }
 
-int escx::ensure_ws(escx_handle_s* h, int B, int T, Shapes* s) {
-    if (!ws_fits(h, B, T)) {
-        int rc = reserve_frames(h, B, T);
+int escx::ensure_ws(escx_handle_s* h, int B, int T, Shapes* s, int min_set_clips) {
+    if (!ws_fits(h, B, T) || h->sets[0].shp.B < min_set_clips) {
+        int rc = reserve_frames(h, B, T, min_set_clips);
         if (rc) return rc;
     }
     use_set(h, 0);
