@@ -27,7 +27,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace escx
 
 extern "C" const char* escx_last_error(void) { return g_err.c_str(); }
-extern "C" const char* escx_version(void) { return "escx 0.2 (gfx950, fp32 accumulate; fp32 MFMA + split-operand bf16 MFMA)"; }
+extern "C" const char* escx_version(void) { return "escx 0.3 (gfx950, fp32 accumulate; escx_set_precision: fp32 MFMA | three bf16 terms | two fp16 terms)"; }
 
 // ------------------------------------------------------------------------------------------------
 // configuration -> geometry

@@ -87,8 +87,9 @@ int64_t escx_workspace_bytes(escx_handle h);
 /* ---- arithmetic of the code-emitting path ------------------------------------------------------
  * The reference computes every contraction in fp32 on ATen sgemm / bmm (esc/modules/transformer/attention.py:215-272, esc/modules/transformer/scale.py:42-145,
  * esc/modules/vq/codebook.py:31-40).  This library accumulates in fp32 everywhere; what can be chosen PER HANDLE is the form of the operands of the dense contractions
- * with K = C - fc1 / fc2 of every FeedForward, the Q / K / V projections of every WindowAttention, PatchMerge / PatchSplit and the composed PatchDeEmbed convolution
- * (the attention's scores / P.V / output projection, the codebook search of Codebook.quantize_to_code, PatchEmbed and the STFT / ISTFT GEMMs always run on the fp32 MFMA):
+ * with K = C - fc1 / fc2 of every FeedForward, the Q / K / V projections (and, in the two-term mode, the output projection) of every WindowAttention, PatchMerge /
+ * PatchSplit and, in the two-term mode, the composed PatchDeEmbed convolution (the attention's scores and P.V, the codebook search of Codebook.quantize_to_code,
+ * PatchEmbed and the STFT / ISTFT GEMMs run on the fp32 MFMA in every mode):
  *   ESCX_PRECISION_FP32    every contraction on v_mfma_f32_16x16x4_f32 with fp32 operands.
  *   ESCX_PRECISION_BF16X3  every fp32 operand split EXACTLY into three bf16 terms (a = a1 + a2 + a3; bf16 has fp32's exponent range, so there is no range condition);
  *                          the six leading cross products are accumulated in fp32 on v_mfma_f32_16x16x32_bf16, smallest first.  Dropped terms < 2^-24 of a product:
@@ -97,7 +98,7 @@ int64_t escx_workspace_bytes(escx_handle h);
  *                          NOT exact: truncation ~1e-7 of the result magnitude, below fp32 accumulation rounding (measured: tests/test_gpu_parity.py
  *                          test_layer_accuracy_against_fp64).  Range-safe by construction: every operand is multiplied by a power of two chosen from a bound that
  *                          holds for ANY finite input (weights: max |w|; LayerNorm outputs: max |gamma| sqrt(C) + max |beta|; GELU outputs: Cauchy-Schwarz on fc1;
- *                          de-embedding input: the tile's own max) and the accumulator by its inverse - exact operations - so no finite input overflows fp16 and
+ *                          attention outputs: the V bound; de-embedding input: the tile's own max) and the accumulator by its inverse - exact operations - so no finite input overflows fp16 and
  *                          low terms stay normal numbers (csrc/split_terms.h).  No silent NaN, no fallback, no host synchronisation.
  * The mode is a property of the handle: it takes effect with the next call (the split weight images are re-derived on that call's stream) and a clip's codes do not
  * depend on the batch or shard it is processed in under any mode.  New handles start in the mode named by the environment variable ESCX_PRECISION (fp32 | bf16x3 | f16x2)

@@ -4,7 +4,9 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/round; rm -rf $O; mkdir -p $O
 cd $R
-timeout 2700 python -m pytest tests -x -q -m gpu --durations=8 > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
+timeout 2700 python -m pytest tests -x -q -m gpu --durations=12 -rP > $O/pytest_gpu_full.txt 2>&1; tail -3 $O/pytest_gpu_full.txt
+# the reports the parity tests print (per precision mode), and the summary lines
+grep -aE "^\[(sweep|fp64|range|unfiltered|clustered|batch36|bench36|voiced|large36|configs)|^[0-9]+ passed|^FAILED|^ERROR|slowest|^[0-9.]+s call" $O/pytest_gpu_full.txt > $O/pytest_gpu.txt
 timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench.err | tail -1 > $O/bench.json; cut -c1-400 $O/bench.json
 ESCX_BENCH_BREAKDOWN=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --skip-other-workloads 2>&1 | grep "^#" > $O/event_breakdown_isolated.txt
 ESCX_STREAMS=1 ESCX_BENCH_BREAKDOWN=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --skip-other-workloads 2>&1 | grep "^#" > $O/event_breakdown_1stream.txt
@@ -12,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --skip-isolated --skip-single-clip --skip-other-workloads"
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/prof -o p -- $CMD > $O/prof.log 2>&1
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv 2>/dev/null
-tail -1 $O/prof.log | cut -c1-300 > $O/prof_bench_line.txt
+grep -a "^{" $O/prof.log | tail -1 > $O/prof_bench_line.txt      # the WHOLE JSON line the traced process printed (round 5 kept 300 characters of it)
 PC="python $R/bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --skip-single-clip --skip-other-workloads"
 timeout 900 rocprofv3 --pmc FETCH_SIZE -f csv -d $O/pmc_fetch -o f -- $PC > $O/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE -f csv -d $O/pmc_write -o w -- $PC > $O/pmc_write.log 2>&1
@@ -59,6 +61,6 @@ timeout 600 python tools/small_batch.py > $O/small_batch.txt 2>&1
 timeout 1200 bash tools/sq_util.sh > /dev/null 2>&1; cp gpurun_out/sq_util.txt $O/sq_util.txt 2>/dev/null
 SQ_BENCH_ARGS="--mode train --steps 2 --warmup 1 --profile-steps 2 --no-cpu-baseline" SQ_OUT=sq_util_train.txt SQ_TOP=45 ESCX_TRAIN_PARTS=1 timeout 1500 bash tools/sq_util.sh > /dev/null 2>&1; cp gpurun_out/sq_util_train.txt $O/sq_util_train.txt 2>/dev/null
 # round 5: GEMM-engine micro-benchmark with the 32x32x2 MFMA arm, the fused-PVQ phase trace when the tuning build is present, the wide parity sweeps
-timeout 1800 bash tools/r5_sweeps.sh > $O/sweeps_tail.txt 2>&1; cp gpurun_out/r5_sweeps/base576.log $O/parity_sweep_base576.log 2>/dev/null; cp gpurun_out/r5_sweeps/large288.log $O/parity_sweep_large288.log 2>/dev/null
+# round 6: the wide oracle sweeps run in their own call (tools/r6_sweeps.sh: Base-576 and Large-288 in all three precision modes)
 find $O -name "*.csv" ! -name "*kernel_stats.csv" -delete; rm -rf $O/prof $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/cal_fetch $O/cal_write
 ls -la $O
