@@ -76,6 +76,26 @@ def test_reference_error_behaviour_on_host():
         m(torch.zeros(1, 48000), torch.zeros(1, 192, 601, 2), 6)
 
 
+def test_precision_contract_on_host(monkeypatch):
+    """include/escx.h escx_set_precision / ESC.set_precision: three named modes, anything else is a ValueError; before a handle exists the property reports what was chosen
+    (or the library default, which the environment may name); the header's mode numbers are the binding's."""
+    import re
+    from conftest import ROOT
+    from esc import ESC, _native
+    header = open(os.path.join(ROOT, "include", "escx.h")).read()
+    for name, code in (("FP32", 0), ("F16X2", 2), ("BF16X3", 3)):
+        assert re.search(rf"#define ESCX_PRECISION_{name}\s+{code}\b", header)
+    assert _native.PRECISIONS == {"fp32": 0, "f16x2": 2, "bf16x3": 3}
+    monkeypatch.delenv("ESCX_PRECISION", raising=False)
+    m = ESC()
+    assert m.precision == "f16x2"
+    assert m.set_precision("bf16x3") is m and m.precision == "bf16x3"
+    with pytest.raises(ValueError, match="precision"):
+        m.set_precision("bf16")
+    monkeypatch.setenv("ESCX_PRECISION", "fp32")
+    assert ESC().precision == "fp32"
+
+
 def test_synthetic_weights_are_deterministic():
     from esc import synth
     a = synth.synth_tensor("encoder.pre_nn.swint_blocks.0.attn.qkv.weight", (135, 45))
