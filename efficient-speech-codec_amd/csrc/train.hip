@@ -606,7 +606,8 @@ extern "C" int64_t escx_train_tape_generation(escx_handle h) { return (h && h->t
 
 namespace {
 // one pass over B clips on stream st, tape = tape_of(h) in the arena h->tape (the caller points both at the part it wants)
-int train_forward_impl(escx_handle_s* h, const float* wave, int B, int L, int S, int freeze, int64_t* codes_out, float* wave_out, float* raw_feat,
+// feat != nullptr: the spectrum is given ((B, T, in_dim, F) frame-major, forward(x, x_feat=...) of codecs.py:33-34) and the STFT is skipped; L = hop * (T - 1) then
+int train_forward_impl(escx_handle_s* h, const float* wave, const float* feat, int B, int L, int S, int freeze, int64_t* codes_out, float* wave_out, float* raw_feat,
                        float* recon_feat, float* cm_loss, float* cb_loss, hipStream_t st) {
     int rc = 0;
     const escx_config& c = h->cfg;
@@ -636,6 +637,8 @@ int train_forward_impl(escx_handle_s* h, const float* wave, int B, int L, int S,
     T.terms = tp.take((size_t)Smax * G * B * s.Tq);
     T.codes = reinterpret_cast<long long*>(tp.take((size_t)B * Smax * G * s.Tq * 2));
     if (!T.codes) ESCX_FAIL(ESCX_ERR_STATE, "training tape too small");
+    if (feat) pad_rows(feat, T.spec, (long long)B * s.T * c.in_dim, h->F, h->Fp, st);
+    else
     PROF("T.stft", 2.0 * B * s.T * c.win_length * 2 * h->F, ((double)B * L + (double)B * s.T * 2 * h->F) * 4,
          gemm_frames(wave, B, L, s.T, c.hop_length, h->left - h->n_fft / 2, h->dft_w, c.in_dim * h->Fp, h->winP, T.spec, st));
     if (raw_feat) unpad_rows(T.spec, raw_feat, (long long)B * s.T * c.in_dim, h->F, h->Fp, st);
@@ -730,14 +733,14 @@ int train_parts_for(escx_handle_s* h, int B) {
 }
 }  // namespace
 
-extern "C" int escx_train_forward(escx_handle h, const float* flat_dev, const float* wave, int B, int L, int S, int freeze, int64_t* codes_out,
-                                  float* wave_out, float* raw_feat, float* recon_feat, float* cm_loss, float* cb_loss, void* stream) {
+static int train_forward_entry(escx_handle h, const float* flat_dev, const float* wave, const float* feat, int B, int L, int S, int freeze, int64_t* codes_out,
+                               float* wave_out, float* raw_feat, float* recon_feat, float* cm_loss, float* cb_loss, void* stream) {
     int rc = check_ready(h); if (rc) return rc;
-    if (!wave || !codes_out || !wave_out) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
+    if ((!wave && !feat) || !codes_out || !wave_out) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
     const escx_config& c = h->cfg;
     if (B < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "batch must be positive");
     if (S < 1 || S > c.max_streams) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "num_streams=%d outside [1, %d]", S, c.max_streams);
-    if (L <= h->n_fft / 2) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_samples=%d too short for reflect padding of %d", L, h->n_fft / 2);
+    if (wave && L <= h->n_fft / 2) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_samples=%d too short for reflect padding of %d", L, h->n_fft / 2);
     hipStream_t st = (hipStream_t)stream;
     if (flat_dev && (rc = refresh_from_flat(h, flat_dev, st))) return rc;
     if ((rc = build_gather_map(h))) return rc;
@@ -753,7 +756,7 @@ extern "C" int escx_train_forward(escx_handle h, const float* flat_dev, const fl
     }
     if (R.parts == 1) {
         R.cur = &R.single;
-        rc = train_forward_impl(h, wave, B, L, S, freeze, codes_out, wave_out, raw_feat, recon_feat, cm_loss, cb_loss, st);
+        rc = train_forward_impl(h, wave, feat, B, L, S, freeze, codes_out, wave_out, raw_feat, recon_feat, cm_loss, cb_loss, st);
         R.valid = rc == 0;
         return rc;
     }
@@ -776,7 +779,7 @@ extern "C" int escx_train_forward(escx_handle h, const float* flat_dev, const fl
         const int b0 = R.first[p], nb = R.first[p + 1] - b0;
         std::swap(h->tape, R.arena[p]);
         R.cur = &R.part[p];
-        rc = train_forward_impl(h, wave + (size_t)b0 * L, nb, L, S, freeze, codes_out + b0 * per_codes, wave_out + b0 * per_wave_out,
+        rc = train_forward_impl(h, wave ? wave + (size_t)b0 * L : nullptr, feat ? feat + b0 * per_raw : nullptr, nb, L, S, freeze, codes_out + b0 * per_codes, wave_out + b0 * per_wave_out,
                                 raw_feat ? raw_feat + b0 * per_raw : nullptr, recon_feat ? recon_feat + b0 * per_recon : nullptr,
                                 cm_loss ? cm_loss + b0 : nullptr, cb_loss ? cb_loss + b0 : nullptr, p ? R.aux[p] : st);
         std::swap(h->tape, R.arena[p]);
@@ -789,6 +792,21 @@ extern "C" int escx_train_forward(escx_handle h, const float* flat_dev, const fl
     }
     R.valid = rc == 0;
     return rc;
+}
+
+extern "C" int escx_train_forward(escx_handle h, const float* flat_dev, const float* wave, int B, int L, int S, int freeze, int64_t* codes_out,
+                                  float* wave_out, float* raw_feat, float* recon_feat, float* cm_loss, float* cb_loss, void* stream) {
+    if (!wave) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
+    return train_forward_entry(h, flat_dev, wave, nullptr, B, L, S, freeze, codes_out, wave_out, raw_feat, recon_feat, cm_loss, cb_loss, stream);
+}
+
+// ESC.forward in training mode with a precomputed spectrum (forward(x, x_feat=...), codecs.py:33-34): feat_dev is (B, T, in_dim, F) frame-major like escx_forward_feat's
+extern "C" int escx_train_forward_feat(escx_handle h, const float* flat_dev, const float* feat, int B, int n_frames, int S, int freeze, int64_t* codes_out,
+                                       float* wave_out, float* recon_feat, float* cm_loss, float* cb_loss, void* stream) {
+    if (!h) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null handle");
+    if (!feat) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "null pointer");
+    if (n_frames < h->cfg.patch_t) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_frames=%d shorter than one patch", n_frames);
+    return train_forward_entry(h, flat_dev, nullptr, feat, B, h->cfg.hop_length * (n_frames - 1), S, freeze, codes_out, wave_out, nullptr, recon_feat, cm_loss, cb_loss, stream);
 }
 
 namespace {

@@ -71,6 +71,7 @@ SIGNATURES = {
     "escx_flat_param_total": (c_int64, [c_void_p]),
     "escx_load_flat_params": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "escx_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "escx_train_forward_feat": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "escx_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "escx_train_tape_bytes": (c_int64, [c_void_p]),
     "escx_train_tape_generation": (c_int64, [c_void_p]),

@@ -491,13 +491,17 @@ class ESC(nn.Module):
     def _forward_train(self, x, x_feat, S, freeze):
         """Training-mode forward (codecs.py:30-46 with csrvq.py:97-129, codebook.py:57-75, quantization.py:53-64): differentiable w.r.t.
         every parameter through `_TrainStep`; `codes` holds all max_streams streams (every quantiser runs in training mode)."""
-        if x_feat is not None:
-            raise NotImplementedError("training with a precomputed spectrum (x_feat) is not implemented; pass the waveform")
         if x.dim() != 2:
             raise ValueError("x must have shape (Bs, L)")
+        if x_feat is not None and (x_feat.dim() != 4 or x_feat.shape[1] != self.in_freq or x_feat.shape[3] != self.in_dim or x_feat.shape[0] != x.shape[0]):
+            raise ValueError(f"x_feat must have shape (Bs, {self.in_freq}, T, {self.in_dim})")
         self._need_gpu(x, "x")
+        feat = None
+        if x_feat is not None:          # codecs.py:33-34: the given spectrum replaces the STFT of x; layout (Bs, F, T, 2) as in eval mode (_forward_from_feat)
+            self._need_gpu(x_feat, "x_feat")
+            feat = x_feat.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous()      # frame-major (Bs, T, 2, F): the library's spectrum layout
         params = tuple(self.parameters())
-        recon, recon_fm, raw_fm, cm, cb, codes = _TrainStep.apply(self, x.to(torch.float32).contiguous(), S, freeze, *params)
+        recon, recon_fm, raw_fm, cm, cb, codes = _TrainStep.apply(self, x.to(torch.float32).contiguous(), feat, S, freeze, *params)
         return {"cm_loss": cm, "cb_loss": cb, "raw_audio": x, "recon_audio": recon,
                 "raw_feat": raw_fm.permute(0, 2, 3, 1), "recon_feat": recon_fm.permute(0, 2, 3, 1), "codes": codes}
 
@@ -516,7 +520,7 @@ class _TrainStep(torch.autograd.Function):
     d loss / d parameter for every nn.Parameter (views of one flat gradient buffer, the library's canonical order)."""
 
     @staticmethod
-    def forward(ctx, model, x, S, freeze, *params):
+    def forward(ctx, model, x, feat, S, freeze, *params):
         dev = x.device
         lib, hd = model._handle(dev, for_training=True)
         flat = model._ensure_flat(dev, lib, hd)
@@ -524,6 +528,8 @@ class _TrainStep(torch.autograd.Function):
         model._packed_version[idx] = None               # the training refresh skips the host-folded inference layouts
         c = model.cfg
         B, L = x.shape
+        if feat is not None:            # the spectrum decides the geometry (codecs.py:33-34): T frames <-> hop * (T - 1) samples
+            L = model.hop_length * (feat.shape[1] - 1)
         _, W = model.latent_shape(L)
         if W % c["overlap"] != 0:
             raise AssertionError("Time dimension must be multiple of overlap")       # quantization.py:407
@@ -531,15 +537,20 @@ class _TrainStep(torch.autograd.Function):
         T = 1 + L // model.hop_length
         codes = torch.empty((B, c["max_streams"], c["group_size"], W // c["overlap"]), dtype=torch.int64, device=dev)
         recon = torch.empty((B, model.hop_length * (pt * W - 1)), dtype=torch.float32, device=dev)
-        raw_fm = torch.empty((B, T, model.in_dim, model.in_freq), dtype=torch.float32, device=dev)
+        raw_fm = feat if feat is not None else torch.empty((B, T, model.in_dim, model.in_freq), dtype=torch.float32, device=dev)
         recon_fm = torch.empty((B, pt * W, model.in_dim, model.in_freq), dtype=torch.float32, device=dev)
         cm = torch.empty((B,), dtype=torch.float32, device=dev)
         cb = torch.empty((B,), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _native.check(lib.escx_train_forward(hd, ctypes.c_void_p(flat.data_ptr()), ctypes.c_void_p(x.data_ptr()), B, L, int(S), int(bool(freeze)),
+            if feat is not None:
+                _native.check(lib.escx_train_forward_feat(hd, ctypes.c_void_p(flat.data_ptr()), ctypes.c_void_p(feat.data_ptr()), B, T, int(S), int(bool(freeze)),
+                                                          ctypes.c_void_p(codes.data_ptr()), ctypes.c_void_p(recon.data_ptr()), ctypes.c_void_p(recon_fm.data_ptr()),
+                                                          ctypes.c_void_p(cm.data_ptr()), ctypes.c_void_p(cb.data_ptr()), model._stream(dev)))
+            else:
+                _native.check(lib.escx_train_forward(hd, ctypes.c_void_p(flat.data_ptr()), ctypes.c_void_p(x.data_ptr()), B, L, int(S), int(bool(freeze)),
                                                  ctypes.c_void_p(codes.data_ptr()), ctypes.c_void_p(recon.data_ptr()), ctypes.c_void_p(raw_fm.data_ptr()),
-                                                 ctypes.c_void_p(recon_fm.data_ptr()), ctypes.c_void_p(cm.data_ptr()), ctypes.c_void_p(cb.data_ptr()),
-                                                 model._stream(dev)))
+                                                     ctypes.c_void_p(recon_fm.data_ptr()), ctypes.c_void_p(cm.data_ptr()), ctypes.c_void_p(cb.data_ptr()),
+                                                     model._stream(dev)))
         ctx.model, ctx.dev, ctx.idx = model, dev, idx
         ctx.tape_generation = int(lib.escx_train_tape_generation(hd))
         ctx.mark_non_differentiable(raw_fm, codes)
@@ -568,10 +579,10 @@ class _TrainStep(torch.autograd.Function):
                 st["gfresh"] = False
             else:
                 st["gflat"].add_(gflat)
-            return (None, None, None, None) + (None,) * len(params)
+            return (None, None, None, None, None) + (None,) * len(params)
         by_id = {id(params[k]): gflat[off:off + n].view(params[k].shape) for k, off, n in st["layout"]}
         grads = tuple(by_id.get(id(q)) for q in model.parameters())
-        return (None, None, None, None) + grads
+        return (None, None, None, None, None) + grads
 
 
 model_dict = {"csvq+swinT": ESC}

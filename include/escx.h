@@ -201,6 +201,10 @@ int escx_load_flat_params(escx_handle h, const float* flat_params_dev, int full,
 int escx_train_forward(escx_handle h, const float* flat_params_dev, const float* wave_dev, int batch, int n_samples, int num_streams,
                        int freeze_codebook, int64_t* codes_dev, float* wave_out_dev, float* raw_feat_dev, float* recon_feat_dev,
                        float* cm_loss_dev, float* cb_loss_dev, void* stream);
+/* The same with a precomputed spectrum instead of the waveform (forward(x, x_feat=...) in training mode, codecs.py:33-34): feat_dev is (B, T, in_dim, F) f32 frame-major,
+ * i.e. the reference's x_feat (B,F,T,2) permuted (0,2,3,1); the STFT is skipped, everything downstream (tape, backward) is escx_train_forward's. */
+int escx_train_forward_feat(escx_handle h, const float* flat_params_dev, const float* feat_dev, int batch, int n_frames, int num_streams, int freeze_codebook,
+                            int64_t* codes_dev, float* wave_out_dev, float* recon_feat_dev, float* cm_loss_dev, float* cb_loss_dev, void* stream);
 /* Backward of the last escx_train_forward.  Upstream gradients (any may be NULL = zero): d_wave (B, out_len), d_recon_feat (B,2W,2,F),
  * d_cm_loss / d_cb_loss (B,).  grad_flat_dev receives d loss / d parameter in the flat layout (overwritten, not accumulated). */
 int escx_train_backward(escx_handle h, const float* d_wave_dev, const float* d_recon_feat_dev, const float* d_cm_loss_dev,

@@ -72,8 +72,10 @@ def test_reference_error_behaviour_on_host():
     m.train()                                                        # training mode is implemented on the device only, like the rest
     with pytest.raises(RuntimeError, match="HIP device"):
         m(torch.zeros(1, 48000), None, 6)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="HIP device"):            # training with a precomputed spectrum (codecs.py:33-34) is a device path too (round 6: escx_train_forward_feat)
         m(torch.zeros(1, 48000), torch.zeros(1, 192, 601, 2), 6)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 48000), torch.zeros(1, 2, 192, 601), 6)
 
 
 def test_precision_contract_on_host(monkeypatch):

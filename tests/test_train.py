@@ -102,13 +102,13 @@ def test_train_fixture_covers_every_parameter():
 
 
 # ------------------------------------------------------------------------------------------------ GPU: the HIP training step
-def _product_step(name, S, freeze, x, w, smooth=None):
+def _product_step(name, S, freeze, x, w, smooth=None, x_feat=None):
     from esc.models import make_model
     from esc.modules import ComplexSTFTLoss, MelSpectrogramLoss
     model = make_model(_cfg(name))
     model.load_state_dict(synth_state(name))
     model = model.cuda().train()
-    out = model(**dict(x=x.cuda(), x_feat=None, num_streams=S, freeze_codebook=freeze))
+    out = model(**dict(x=x.cuda(), x_feat=x_feat, num_streams=S, freeze_codebook=freeze))
     losses = {"cm": out["cm_loss"].detach().cpu().numpy(), "cb": out["cb_loss"].detach().cpu().numpy()}
     if smooth is None:
         mel = MelSpectrogramLoss()(out["raw_audio"], out["recon_audio"])
@@ -673,6 +673,30 @@ def test_training_step_is_run_to_run_deterministic():
         gan.discriminator_loss(fake, real).mean().backward()
         dg.append({k: p.grad.detach().clone() for k, p in disc.named_parameters()})
     assert all(torch.equal(dg[0][k], dg[1][k]) for k in dg[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("parts", ["1", "2"])
+def test_training_step_with_a_precomputed_spectrum(monkeypatch, parts):
+    """forward(x, x_feat=...) in TRAINING mode (codecs.py:33-34; round 6: escx_train_forward_feat): the spectrum the library's own STFT produces, handed back as x_feat in the
+    reference's (Bs, F, T, 2) layout, gives bit for bit the step of the waveform call - losses, codes, every gradient - in the one-part and in the two-part form;
+    a spectrum of another clip changes it; raw_feat is the given spectrum."""
+    g = load_golden("train")
+    w = json.loads(str(g["weights_json"]))
+    x = _clips(g, "base")
+    x = torch.cat([x, 0.5 * x.flip(0)], dim=0)
+    monkeypatch.setenv("ESCX_TRAIN_PARTS", parts)
+    monkeypatch.setenv("ESCX_TRAIN_PARTS_MIN_BATCH", "2")
+    _, out0, l0, g0 = _product_step("base", 6, False, x, w)
+    feat = out0["raw_feat"].detach().permute(0, 2, 3, 1).contiguous()          # (Bs, 2, F, T) -> the reference's x_feat layout (Bs, F, T, 2)
+    assert feat.shape[1:] == (192, 1 + x.shape[1] // 80, 2)
+    _, out1, l1, g1 = _product_step("base", 6, False, x, w, x_feat=feat)
+    assert torch.equal(out1["raw_feat"], out0["raw_feat"]) and torch.equal(out1["codes"], out0["codes"]) and torch.equal(out1["recon_audio"], out0["recon_audio"])
+    assert all(np.array_equal(l0[k], l1[k]) for k in l0) and all(np.array_equal(g0[k], g1[k]) for k in g0)
+    _, out2, l2, _ = _product_step("base", 6, False, x, w, x_feat=feat.flip(0).contiguous())
+    assert not torch.equal(out2["recon_audio"], out0["recon_audio"])
+    with pytest.raises(ValueError):
+        _product_step("base", 6, False, x, w, x_feat=feat.permute(0, 3, 1, 2).contiguous())
 
 
 @pytest.mark.gpu
