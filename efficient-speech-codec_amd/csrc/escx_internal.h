@@ -45,6 +45,7 @@ struct BlockW {                      // one SwinBlock, packed
     void* x3a = nullptr;             // fused_attn.h X3: Q / K / V tiles split into terms
     void* x3w = nullptr;             // fused_mlp_x3.h: fc1 / fc2 split into terms
     void *x3a_buf = nullptr, *x3w_buf = nullptr;
+    void* x3w_train = nullptr;       // training forward (train.hip): the fused MLP's weights split exactly into three bf16 terms, re-packed after every parameter refresh
 };
 
 struct Layer {                       // one TransformerLayer (attention.py:9-91)
@@ -165,6 +166,7 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     long long* grad_seg = nullptr; int grad_nseg = 0; long long grad_seg_total = 0;     // device table [nseg][2] = (first element, arena offset) for the one-launch scatter
     escx::Arena tape;                            // activations kept between escx_train_forward and escx_train_backward
     void* train_state = nullptr;                 // TrainTape* (train.hip)
+    bool train_x3_stale = true;                  // BlockW::x3w_train images are out of date (finalisation, device-side parameter refresh)
     bool pvq_tab_stale = true;                   // de-quantisation tables (Quant::tab) are out of date: rebuilt on the caller's stream by the next inference entry
     long long* iota_codes = nullptr;             // [G][Ksz] int64, codes[g][k] = k: the pseudo-vectors the tables are built from
     bool composed_stale = false;                 // weights were refreshed on the device: the fp64-folded de-embedding of the inference path is out of date

@@ -189,7 +189,7 @@ extern "C" void escx_destroy(escx_handle h) {
     for (Quant& q : h->quants) if (q.tab) (void)hipFree(q.tab);
     for (Layer& L : h->layers) { if (L.sub_x3_buf) (void)hipFree(L.sub_x3_buf); if (L.sub_x3s_buf) (void)hipFree(L.sub_x3s_buf); }
     if (h->dch_x2_buf) (void)hipFree(h->dch_x2_buf);
-    for (Layer& L : h->layers) for (BlockW& bw : L.blocks) { if (bw.x3w_buf) (void)hipFree(bw.x3w_buf); if (bw.x3a_buf) (void)hipFree(bw.x3a_buf); }
+    for (Layer& L : h->layers) for (BlockW& bw : L.blocks) { if (bw.x3w_buf) (void)hipFree(bw.x3w_buf); if (bw.x3a_buf) (void)hipFree(bw.x3a_buf); if (bw.x3w_train) (void)hipFree(bw.x3w_train); }
     if (h->iota_codes) (void)hipFree(h->iota_codes);
     if (h->gmap) (void)hipFree(h->gmap);
     if (h->garena) (void)hipFree(h->garena);
@@ -612,6 +612,7 @@ static int pack_image(escx_handle_s* h, std::vector<float>& image, std::vector<s
             pk.host[ogq + f4] = (float)g4;
         }
     }
+    h->train_x3_stale = true;
     h->pvq_tab_stale = true;
 
     image.swap(pk.host);

@@ -238,8 +238,9 @@ static void launch_mlp_x3_split(const MlpArgs& a, hipStream_t s) {
 // *hs_io: requested hidden split in, split used out (> 1: x untouched, partial[hs][M][Cp] filled, the caller runs rows_combine) - as mlp_fused
 // split: PatchSplit in the epilogue (split->wf = the image of mlp_x3_split_pack); ESCX_COMB_UNSUPPORTED when the width has no such instantiation
 int mlp_x3(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* b1, const float* b2, const void* image, int hiddenP, int nw, int* hs_io, float* partial,
-           hipStream_t s, const MlpSplit* split, int nt) {
+           hipStream_t s, const MlpSplit* split, int nt, float* out) {
     if (!image || hiddenP % 32 || (nt != 2 && nt != 3)) return -1;
+    if (out && (split || (hs_io && *hs_io > 1))) return -1;             // out-of-place: the plain form only (training forward: x1 -> x2)
     if (split) {
         if ((hs_io && *hs_io > 1) || !split->wf || !(Cp == 80 || Cp == 96 || Cp == 144)) return ESCX_COMB_UNSUPPORTED;
         MlpArgs a{};
@@ -258,7 +259,7 @@ int mlp_x3(float* x, int M, int C, int Cp, const float* gamma, const float* beta
     if (hs > 1 && (!partial || (hiddenP / 32) % hs)) hs = 1;
     if (hs_io) *hs_io = hs;
     MlpArgs a{};
-    a.x = x; a.gamma = gamma; a.beta = beta; a.b1 = b1; a.b2 = b2; a.M = M; a.C = C; a.HT = hiddenP / 16; a.eps = 1e-5f; a.HS = hs; a.partial = partial; a.x3_w = image;
+    a.x = x; a.gamma = gamma; a.beta = beta; a.b1 = b1; a.b2 = b2; a.M = M; a.C = C; a.HT = hiddenP / 16; a.eps = 1e-5f; a.HS = hs; a.partial = partial; a.x3_w = image; a.out = out;
 #ifdef ESCX_EXPERIMENTAL
     // two row tiles per wave (mlp_x3_rows_kernel, bit-identical, measured slower) for the narrow maps without a hidden split: ESCX_MLP_X3_TM=2
     static const int tm_env = [] { const char* e = ESCX_TUNE_ENV("ESCX_MLP_X3_TM"); return e ? atoi(e) : 1; }();

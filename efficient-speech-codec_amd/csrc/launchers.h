@@ -45,7 +45,7 @@ int mlp_x3_pack(const float* w1, const float* w2, void* image, int Cp, int hidde
                 const float* b1 = nullptr, int C = 0);      // nt = 2 needs ln2's gamma / beta, b1 and the unpadded width (range rule of split_terms.h)
 struct MlpSplit;
 int mlp_x3(float* x, int M, int C, int Cp, const float* gamma, const float* beta, const float* b1, const float* b2, const void* image, int hiddenP, int nw, int* hs_io, float* partial,
-           hipStream_t s, const MlpSplit* split = nullptr, int nt = 3);      // split: PatchSplit in the epilogue, split->wf = image of mlp_x3_split_pack
+           hipStream_t s, const MlpSplit* split = nullptr, int nt = 3, float* out = nullptr);      // split: PatchSplit in the epilogue, split->wf = image of mlp_x3_split_pack
 size_t mlp_x3_split_bytes(int Cp, int Np);
 int mlp_x3_split_pack(const float* wf, void* image, int Cp, int Np, hipStream_t s);
 void rows_combine(float* dst, const float* src, const float* partial, const float* bias, long long M, int Cp, int n, hipStream_t s);

@@ -334,6 +334,28 @@ inline bool mlp_train_fused(const Layer& L) {
     return on && ((L.Cp == 48 && L.hiddenP == 192) || (on72 && L.Cp == 80 && L.hiddenP == 288));
 }
 
+// Forward of those layers (round 6): the split-operand kernel of the inference path (fused_mlp_x3.h) in its EXACT three-term bf16 form - fp32 results up to summation
+// order, no range rule needed - on weight images re-packed after every parameter refresh (pack_train_mlp_images, 10 launches per step for ESC-Base).  The backward
+// recomputes the hidden tile from x1 on the fp32 MFMA: the two evaluations of h_pre differ by fp32 rounding (~1e-7), which moves the gradient like any re-association.
+// ESCX_TRAIN_MLP_X3=0: the fp32-MFMA fused kernel (fused_mlp.h), as before.
+inline bool mlp_train_x3() {
+    static const bool on = [] { const char* e = getenv("ESCX_TRAIN_MLP_X3"); return !(e && e[0] == '0'); }();
+    return on;
+}
+int pack_train_mlp_images(escx_handle_s* h, hipStream_t st) {
+    if (!mlp_train_x3() || !h->train_x3_stale) return 0;
+    for (Layer& L : h->layers) {
+        if (!mlp_train_fused(L)) continue;
+        for (BlockW& bw : L.blocks) {
+            if (!bw.x3w_train) ESCX_HIP(hipMalloc(&bw.x3w_train, mlp_x3_bytes(L.Cp, L.hiddenP, 3)));
+            if (mlp_x3_pack(bw.w1, bw.w2, bw.x3w_train, L.Cp, L.hiddenP, st, 3, nullptr, nullptr, nullptr, L.C) != 0)
+                ESCX_FAIL(ESCX_ERR_STATE, "split MLP image for Cp = %d could not be packed", L.Cp);
+        }
+    }
+    h->train_x3_stale = false;
+    return launch_ok("pack_train_mlp_images");
+}
+
 // One workgroup per CU (~150 KB of LDS), persistent over the row tiles.  C = 45: 12 hidden tiles = 12 compute waves, LayerNorm backward inside.
 // C = 72: 18 hidden tiles as 2 x 9 (grid.y = 2): the workgroups write d xn partial slabs (`slabs`: 2 * M * Cp floats), which are summed into `dxn`
 // and go through the stand-alone LayerNorm backward.  `part`: grid.x x (2 * hiddenP * Cp + hiddenP + Cp) floats + the reduced E.
@@ -472,6 +494,10 @@ int layer_fwd(escx_handle_s* h, const Layer& L, LayerTape& LT, const float* x_in
         }
         if (fmlp) {       // LN2 + fc1 + GELU + fc2 + residual in one kernel: x1 -> x2 (x1 itself is what the backward recomputes from)
             int hs = 1, frc = 0;
+            if (mlp_train_x3() && bw.x3w_train && !h->train_x3_stale)
+                PROF("T.mlp_x3" + tg, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
+                     frc = mlp_x3(bt.x1, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.b1, bw.b2, bw.x3w_train, L.hiddenP, (M + 15) / 16 >= 8 * 512 ? 8 : 4, &hs, nullptr, st, nullptr, 3, bt.x2));
+            else
             PROF("T.mlp_fused" + tg, 4 * dM * dC * L.hidden, 2 * dM * dC * f4,
                  frc = mlp_fused(bt.x1, M, L.C, L.Cp, bw.ln2_g, bw.ln2_b, bw.w1f, bw.b1, bw.w2f, bw.b2, bw.wcf, L.hiddenP, 3, &hs, nullptr, st, bt.x2));
             if (frc) ESCX_FAIL(ESCX_ERR_STATE, "fused MLP not instantiated for Cp = %d", L.Cp);
@@ -562,6 +588,7 @@ int refresh_from_flat(escx_handle_s* h, const float* flat, hipStream_t st) {
     } else {
         h->composed_stale = true;       // no folded form for this geometry: the inference path needs escx_load_flat_params(full = 1)
     }
+    h->train_x3_stale = true;
     h->pvq_tab_stale = true;            // derived inference state (de-quantisation tables, split MLP weight images): rebuilt by the next inference entry
     return launch_ok("refresh_from_flat");
 }
@@ -744,6 +771,7 @@ static int train_forward_entry(escx_handle h, const float* flat_dev, const float
     hipStream_t st = (hipStream_t)stream;
     if (flat_dev && (rc = refresh_from_flat(h, flat_dev, st))) return rc;
     if ((rc = build_gather_map(h))) return rc;
+    if ((rc = pack_train_mlp_images(h, st))) return rc;         // before the batch parts fork
     TrainRoot& R = *root_of(h);
     R.valid = false;
     ++R.generation;
