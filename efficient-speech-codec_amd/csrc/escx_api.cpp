@@ -153,7 +153,8 @@ static int mlp_split_nw(int M, int hs) {
 // attention.py:48-91 (layer), 129-178 (block): LN1 -> pad -> roll -> windows -> attention -> reverse -> residual -> MLP.
 static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float* y, int B, int H, int W, int* Hout, hipStream_t st) {
     const int tokens = H * W, M = B * tokens;
-    const int Hp = rup(H, 4), Wp = rup(W, 4), slots = Hp * Wp, Ms = B * slots;
+    const int ws = h->ws, NW2 = ws * ws;
+    const int Hp = rup(H, ws), Wp = rup(W, ws), slots = Hp * Wp, Ms = B * slots;
     float* cur = L.scale ? h->work : y;
     const float* src = x_in;
     int rc;
@@ -176,7 +177,7 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
     };
     for (size_t j = 0; j < L.blocks.size(); ++j) {
         const BlockW& bw = L.blocks[j];
-        const int shift = (j % 2 == 0) ? 0 : 2;                               // attention.py:29
+        const int shift = (j % 2 == 0) ? 0 : ws / 2;                          // attention.py:29
         const int* map;
         if ((rc = get_map(h, H, W, shift, &map))) return rc;
         const std::string tag = h->prof ? "[C=" + std::to_string(L.C) + "]" : std::string();
@@ -213,6 +214,10 @@ static int run_layer(escx_handle_s* h, const Layer& L, const float* x_in, float*
         PROF("gemm_qkv" + tag, 2 * dMs * dC * 3 * dC, (dMs * 4 * dC + 3 * dC * dC) * f4,
              gemm_qkv(h->xn, L.Cp, Ms, bw.wqkv, L.Nqkv, L.Cp, h->qkv, bw.bqkv, L.nH * L.hdp, 1.0f / std::sqrt((float)L.hd), st));
         int arc = 0;
+        if (ws != 4)
+        PROF("window_attn_any" + tag, 4 * dMs * NW2 * dC, dMs * 4 * dC * f4,
+             arc = window_attention_any(h->qkv, bw.bias_tab, h->obuf, Ms / NW2, ws, L.nH, L.hd, L.hdp, L.Nqkv, L.Ko, Hp / ws, Wp / ws, shift, st));
+        else
         PROF("window_attn" + tag, 4 * dMs * 16 * dC, dMs * 4 * dC * f4,
              arc = window_attention(h->qkv, bw.bias_tab, h->obuf, Ms / 16, L.nH, L.hdp, L.Nqkv, L.Ko, Hp / 4, Wp / 4, shift > 0, st));
         if (arc) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "head_dim %d unsupported by the attention kernel", L.hd);

@@ -142,6 +142,7 @@ struct escx_handle_s : escx::WsFields {      // the inherited fields are the CUR
     bool mlp_split_fold = true;      // ESCX_MLP_SPLIT_FOLD=0: PatchSplit as its own launch instead of the MLP epilogue
     bool pvq_fused = true, pvq_up_kernel = true;      // ESCX_PVQ_FUSED=0: three-launch quantiser; ESCX_PVQ_UP_KERNEL=0: the GEMM engine's generic up-projection
     bool prof_serial = false;        // ESCX_PROF_SERIAL=1: profiled runs put the batch parts back to back
+    int ws = 4;                      // window_size of the configuration (4: fused kernels; other sizes: unfused sequence with window_attention_any_kernel)
     bool attn_pack = true;           // ESCX_NO_ATTN_PACK=1: do not pack half-real windows of the H == 2 scale
 
     escx::Arena wts;                 // packed weights

@@ -45,7 +45,10 @@ static int build_geometry(escx_handle_s* h) {
     const escx_config& c = h->cfg;
     const int n = c.n_scales;
     if (n < 2 || n > ESCX_MAX_SCALES) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_scales=%d out of range", n);
-    if (c.window_size != 4) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "only window_size=4 is implemented (got %d)", c.window_size);
+    // attention.py:93-127, 246-256 are generic in window_size.  4 (every shipped yaml) runs the fused MFMA kernels; any other size in [2, 16] runs the unfused launch
+    // sequence with window_attention_any_kernel (inference only: the training step exists for 4 x 4 windows).
+    if (c.window_size < 2 || c.window_size > 16) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "window_size=%d outside [2, 16]", c.window_size);
+    h->ws = c.window_size;
     if (c.max_streams != n) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "max_streams (%d) must equal len(h_dims) (%d): one decoder block per "
                                       "residual stream (csrvq.py:108-122)", c.max_streams, n);
     if (c.in_freq % c.patch_f != 0) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "in_freq must be divisible by patch_size[0]");
@@ -69,6 +72,7 @@ static int build_geometry(escx_handle_s* h) {
         if (L.hd <= 8) { L.attn_mode = 1; L.n_groups = (nH + 1) / 2; }
         else if (L.hd <= 16) { L.attn_mode = 0; L.n_groups = nH; }
         else if (L.hd <= 32) { L.attn_mode = 2; L.n_groups = nH; }
+        if (c.window_size != 4) { L.attn_mode = -1; L.n_groups = 0; }        // no fused attention: 16-token windows are its tile
         L.hidden = (int)(C * c.mlp_ratio); L.hiddenP = rup(L.hidden, 16);
         L.scale = scale; L.Cout = Cout; L.CoutP = rup(Cout, 16);
         L.blocks.resize(c.swin_depth);
@@ -267,7 +271,8 @@ static int pack_image(escx_handle_s* h, std::vector<float>& image, std::vector<s
             const std::string p = L.prefix + "swint_blocks." + std::to_string(j) + ".";
             BlockW& bw = L.blocks[j];
             GETP(n1w, p + "norm1.weight", C); GETP(n1b, p + "norm1.bias", C);
-            GETP(tab, p + "attn.relative_position_bias_table", 49, nH);
+            const int ws = c.window_size, NW2 = ws * ws;
+            GETP(tab, p + "attn.relative_position_bias_table", (2 * ws - 1) * (2 * ws - 1), nH);
             GETP(qw, p + "attn.qkv.weight", 3 * C, C); GETP(qb, p + "attn.qkv.bias", 3 * C);
             GETP(pw, p + "attn.proj.weight", C, C); GETP(pb, p + "attn.proj.bias", C);
             GETP(n2w, p + "norm2.weight", C); GETP(n2b, p + "norm2.bias", C);
@@ -283,11 +288,11 @@ static int pack_image(escx_handle_s* h, std::vector<float>& image, std::vector<s
                 std::copy(qw->data.begin() + (size_t)src * C, qw->data.begin() + (size_t)(src + 1) * C, pk.host.begin() + o + (size_t)dst * Cp);
                 pk.host[ob + dst] = qb->data[src];
             }
-            // relative position bias gathered per head: index = (dh+3)*7 + (dw+3)  (attention.py:195-205)
-            o = slot(&bw.bias_tab, (size_t)nH * 256);
-            for (int hh = 0; hh < nH; ++hh) for (int i = 0; i < 16; ++i) for (int jj = 0; jj < 16; ++jj) {
-                const int idx = ((i >> 2) - (jj >> 2) + 3) * 7 + ((i & 3) - (jj & 3) + 3);
-                pk.host[o + ((size_t)hh * 16 + i) * 16 + jj] = tab->data[(size_t)idx * nH + hh];
+            // relative position bias gathered per head: index = (dh + ws - 1) * (2 ws - 1) + (dw + ws - 1)  (attention.py:195-205)
+            o = slot(&bw.bias_tab, (size_t)nH * NW2 * NW2);
+            for (int hh = 0; hh < nH; ++hh) for (int i = 0; i < NW2; ++i) for (int jj = 0; jj < NW2; ++jj) {
+                const int idx = ((i / ws) - (jj / ws) + ws - 1) * (2 * ws - 1) + ((i % ws) - (jj % ws) + ws - 1);
+                pk.host[o + ((size_t)hh * NW2 + i) * NW2 + jj] = tab->data[(size_t)idx * nH + hh];
             }
             o = gslot(&bw.wproj, (size_t)Cp * L.Ko);
             for (int r = 0; r < C; ++r) for (int hh = 0; hh < nH; ++hh) for (int d = 0; d < hd; ++d)
@@ -733,21 +738,22 @@ int escx::get_map(escx_handle_s* h, int H, int W, int shift, const int** out) {
     if (it != h->maps.end()) { *out = it->second; return 0; }
     std::vector<int> m;
     if (shift >= 10) {                          // inverse of the window map: token -> slot (LayerNorm backward of the training step)
-        const int sh0 = shift - 10;
-        const int Hp = rup(H, 4), Wp = rup(W, 4), nWw = Wp / 4;
+        const int sh0 = shift - 10, ws = h->ws;
+        const int Hp = rup(H, ws), Wp = rup(W, ws), nWw = Wp / ws;
         m.assign((size_t)H * W, 0);
         for (int hh = 0; hh < Hp; ++hh) for (int ww = 0; ww < Wp; ++ww) {
             const int sh = (hh + sh0) % Hp, sw = (ww + sh0) % Wp;
-            const int slot = (((hh >> 2) * nWw + (ww >> 2)) << 4) + ((hh & 3) << 2) + (ww & 3);
+            const int slot = ((hh / ws) * nWw + (ww / ws)) * ws * ws + (hh % ws) * ws + (ww % ws);
             if (sh < H && sw < W) m[(size_t)sh * W + sw] = slot;
         }
     } else
     if (shift >= 0) {                           // window slots -> source token (attention.py:139-155, 246-250)
-        const int Hp = rup(H, 4), Wp = rup(W, 4), nWw = Wp / 4;
+        const int ws = h->ws;
+        const int Hp = rup(H, ws), Wp = rup(W, ws), nWw = Wp / ws;
         m.resize((size_t)Hp * Wp);
         for (int hh = 0; hh < Hp; ++hh) for (int ww = 0; ww < Wp; ++ww) {
             const int sh = (hh + shift) % Hp, sw = (ww + shift) % Wp;       // roll(-shift) over the PADDED map
-            const int slot = (((hh >> 2) * nWw + (ww >> 2)) << 4) + ((hh & 3) << 2) + (ww & 3);
+            const int slot = ((hh / ws) * nWw + (ww / ws)) * ws * ws + (hh % ws) * ws + (ww % ws);
             m[slot] = (sh < H && sw < W) ? sh * W + sw : -1;
         }
     } else {                                    // PatchMerge rows (scale.py:104-112)
@@ -822,7 +828,7 @@ static int reserve_frames(escx_handle_s* h, int Btotal, int T, int set_clips_min
         else if (li < 2 * n - 1) H = s.encH[n - 1 - (li - n)];
         else H = s.encH[0];
         if ((rc = get_map(h, H, s.W, 0, &dummy))) return rc;
-        if ((rc = get_map(h, H, s.W, 2, &dummy))) return rc;
+        if ((rc = get_map(h, H, s.W, h->ws / 2, &dummy))) return rc;
         if (Ly.scale == 1 && (rc = get_map(h, H, s.W, -1, &dummy))) return rc;
     }
     if (ws_fits(h, Btotal, T)) return ESCX_OK;
@@ -850,7 +856,7 @@ static int reserve_frames(escx_handle_s* h, int Btotal, int T, int set_clips_min
         if (li < n) H = s.encH[std::max(li - 1, 0)];
         else if (li < 2 * n - 1) H = s.encH[n - 1 - (li - n)];
         else H = s.encH[0];
-        const size_t tokens = (size_t)B * H * s.W, slots = (size_t)B * rup(H, 4) * rup(s.W, 4);
+        const size_t tokens = (size_t)B * H * s.W, slots = (size_t)B * rup(H, h->ws) * rup(s.W, h->ws);
         work = std::max(work, tokens * Ly.Cp);
         xn = std::max({xn, slots * Ly.Cp, tokens * Ly.Cp, Ly.scale == 1 ? (size_t)B * ((H + 1) / 2) * s.W * 2 * Ly.Cp : 0});
         qkv = std::max(qkv, slots * Ly.Nqkv);

@@ -153,6 +153,52 @@ __global__ __launch_bounds__(256) void window_attention_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Window attention for ANY window size (attention.py:215-244 with the mask of attention.py:56-75): the fallback of the unfused path for window_size != 4.  Every shipped
+// configuration uses 4 x 4 windows (the MFMA kernels above / fused_attn.h); this form exists so that a checkpoint trained with another window size loads and runs.
+// One wave per (window, head); a lane owns query rows lane, lane + 64, ... and walks the N = ws^2 keys three times (row maximum, denominator, P . V with the
+// normalised probabilities - the reference's softmax-then-matmul order), sequential fp32 FMAs in dimension / key order.  q is pre-scaled by the Q-K-V GEMM's epilogue.
+// bias: [head][N][N] gathered from the relative-position table at packing time.  Slots of padded positions hold zero rows (LayerNorm gather), exactly as the reference pads.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void window_attention_any_kernel(const float* __restrict__ qkv, const float* __restrict__ bias, float* __restrict__ out, int nH, int hd,
+                                                                  int hdp, int ldq, int ldo, int ws, int nWh, int nWw, int shift) {
+    const int win = blockIdx.x, h = blockIdx.y, N = ws * ws;
+    const int wloc = win % (nWh * nWw), wh = wloc / nWw, ww = wloc - wh * nWw;
+    const int Hp = nWh * ws, Wp = nWw * ws;
+    const float* base = qkv + (size_t)win * N * ldq + h * hdp;
+    const int kOff = nH * hdp, vOff = 2 * nH * hdp;
+    const float* bh = bias + (size_t)h * N * N;
+    auto region = [&](int p, int P) { return p < P - ws ? 0 : (p < P - shift ? 1 : 2); };       // attention.py:59-64
+    for (int i = threadIdx.x; i < N; i += 64) {
+        const float* q = base + (size_t)i * ldq;
+        const int labq = shift > 0 ? 3 * region(wh * ws + i / ws, Hp) + region(ww * ws + i % ws, Wp) : 0;
+        auto score = [&](int j) {
+            const float* k = base + (size_t)j * ldq + kOff;
+            float s = 0.f;
+            for (int d = 0; d < hd; ++d) s = __builtin_fmaf(q[d], k[d], s);
+            s += bh[(size_t)i * N + j];
+            if (shift > 0) { const int labk = 3 * region(wh * ws + j / ws, Hp) + region(ww * ws + j % ws, Wp); s += (labk != labq) ? -100.0f : 0.0f; }
+            return s;
+        };
+        float mx = -__builtin_inff();
+        for (int j = 0; j < N; ++j) mx = fmaxf(mx, score(j));
+        float den = 0.f;
+        for (int j = 0; j < N; ++j) den += expf(score(j) - mx);
+        const float inv = 1.0f / den;
+        float* orow = out + ((size_t)win * N + i) * ldo + h * hdp;
+        for (int d0 = 0; d0 < hdp; d0 += 4) {
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+            for (int j = 0; j < N; ++j) {
+                const float p = expf(score(j) - mx) * inv;
+                const float* v = base + (size_t)j * ldq + vOff + d0;
+                o0 = __builtin_fmaf(p, v[0], o0); o1 = __builtin_fmaf(p, v[1], o1); o2 = __builtin_fmaf(p, v[2], o2); o3 = __builtin_fmaf(p, v[3], o3);
+            }
+            orow[d0] = o0; orow[d0 + 1] = o1; orow[d0 + 2] = o2; orow[d0 + 3] = o3;     // dims hd .. hdp - 1: the V pad columns are zero
+        }
+        if (h == 0) for (int c = nH * hdp; c < ldo; ++c) out[((size_t)win * N + i) * ldo + c] = 0.f;     // K padding of the projection GEMM
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Codebook search (codebook.py:20-43): for 16 framed vectors of one product-VQ group per block,
 //   z = sum of split-K partials (fixed order) ; zn = z / max(||z||, 1e-12)
 //   dist[n] = (sum zn^2 - (2 zn).c_n) + ||c_n||^2  with c_n the pre-normalised code ; argmin, lowest index

@@ -42,6 +42,13 @@ int window_attention(const float* qkv, const float* bias, float* out, int total_
 #undef ESCX_ATT
 }
 
+int window_attention_any(const float* qkv, const float* bias, float* out, int total_windows, int ws, int nH, int hd, int hdp, int ldq, int ldo, int nWh, int nWw,
+                         int shift, hipStream_t s) {
+    if (total_windows < 1 || nH < 1 || nH > 65535 || ws < 1) return -1;
+    ESCX_LAUNCH(window_attention_any_kernel, dim3((unsigned)total_windows, (unsigned)nH), dim3(64), 0, s, qkv, bias, out, nH, hd, hdp, ldq, ldo, ws, nWh, nWw, shift);
+    return 0;
+}
+
 int pvq_search(const float* zpart, int splits, int M, int ldz, const float* cbn, const float* c2, const float* cbraw, int G, int Ksz,
                int d, int dt, int Tq, long long* codes, long long bstride, float* loss, float loss_scale, int l2norm, hipStream_t s) {
     SearchArgs a{zpart, splits, M, ldz, cbn, c2, cbraw, Ksz, d, Tq, codes, bstride, loss, loss_scale, l2norm};

@@ -105,6 +105,9 @@ void ln_rows(int mode, const float* src, float* dst, const float* gamma, const f
              int src_rows_per_clip, int total_rows, int C, int Cp, hipStream_t s);
 int window_attention(const float* qkv, const float* bias, float* out, int total_windows, int nH, int hdp, int ldq, int ldo, int nWh,
                      int nWw, int shifted, hipStream_t s);
+// any window size (kernels.h window_attention_any_kernel): the fallback for window_size != 4; bias [head][ws^2][ws^2], shift = 0 or ws / 2
+int window_attention_any(const float* qkv, const float* bias, float* out, int total_windows, int ws, int nH, int hd, int hdp, int ldq, int ldo, int nWh, int nWw,
+                         int shift, hipStream_t s);
 // One product-VQ stream in ONE launch (fused_pvq.h): frame + residual + down-projection (split-K slices = waves, added in slice order in LDS) + normalise +
 // codebook search + de-quantise + up-projection + un-frame + add.  out == nullptr: codes only; out may alias dec.  -1: geometry not covered.
 // wdf: down-projection in fragment order; tab / gq: de-quantisation table and float4 -> group map (escx_internal.h Quant), tab == nullptr: up-projection on the MFMA

@@ -768,6 +768,7 @@ static int train_forward_entry(escx_handle h, const float* flat_dev, const float
     if (B < 1) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "batch must be positive");
     if (S < 1 || S > c.max_streams) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "num_streams=%d outside [1, %d]", S, c.max_streams);
     if (wave && L <= h->n_fft / 2) ESCX_FAIL(ESCX_ERR_INVALID_ARG, "n_samples=%d too short for reflect padding of %d", L, h->n_fft / 2);
+    if (h->ws != 4) ESCX_FAIL(ESCX_ERR_UNSUPPORTED, "the training step is implemented for window_size=4 (got %d): inference only for other window sizes", h->ws);
     hipStream_t st = (hipStream_t)stream;
     if (flat_dev && (rc = refresh_from_flat(h, flat_dev, st))) return rc;
     if ((rc = build_gather_map(h))) return rc;

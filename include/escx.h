@@ -51,7 +51,7 @@ typedef struct {
     int32_t patch_f, patch_t;               /* 3, 2                                        */
     int32_t swin_heads[ESCX_MAX_SCALES];    /* encoder order: 3,6,12,24,24                 */
     int32_t swin_depth;                     /* 2 (Base) / 4 (Large)                        */
-    int32_t window_size;                    /* 4 (only 4 is implemented)                   */
+    int32_t window_size;                    /* 2 .. 16; 4 = fused kernels, other sizes: unfused fallback, inference only */
     float   mlp_ratio;                      /* 4.0                                         */
     int32_t overlap;                        /* 2                                           */
     int32_t group_size;                     /* 3                                           */

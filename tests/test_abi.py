@@ -54,6 +54,22 @@ def test_state_dict_contract(name):
     assert model.max_bps == (9.0 if name != "tiny" else model.max_bps)
 
 
+@pytest.mark.parametrize("ws", [2, 3, 8])
+def test_state_dict_contract_other_window_sizes(ws):
+    """window_size != 4: the key -> shape contract (bias table (2 ws - 1)^2 x heads, index buffer ws^2 x ws^2) against the REAL reference's manifests (oracle/gen_window_golden.py)."""
+    from esc.models import make_model
+    cfg = json.loads(str(load_golden("window")[f"ws{ws}_config_json"]))
+    model = make_model(cfg)
+    man = load_manifest(f"window_ws{ws}")
+    sd = model.state_dict()
+    assert set(sd) == set(man)
+    for k, v in sd.items():
+        assert list(v.shape) == man[k], k
+    model.load_state_dict(synth_state(f"window_ws{ws}"), strict=True)
+    idx = [v for k, v in model.state_dict().items() if k.endswith("relative_position_index")][0]
+    assert tuple(idx.shape) == (ws * ws, ws * ws) and int(idx.max()) == (2 * ws - 1) ** 2 - 1
+
+
 def test_reference_error_behaviour_on_host():
     from esc import ESC
     from esc.models import make_model

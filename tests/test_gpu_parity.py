@@ -3,6 +3,7 @@
 Tolerances: integer codes bit-exact; audio <= 1e-4 RMS (north_star); intermediate fp32 activations are compared
 relative to their own RMS at 2e-5 (pure fp32 re-association noise)."""
 import ctypes
+import json
 import os
 
 import numpy as np
@@ -10,7 +11,7 @@ import pytest
 import torch
 
 from gpu_util import NEAR_TIE, PRECISIONS, attribute_with_continuation, build_models, code_report, mismatch_summary, rel_rms, rms, unattributable
-from conftest import load_golden
+from conftest import load_golden, synth_state
 from esc import synth, _native
 
 pytestmark = pytest.mark.gpu
@@ -326,6 +327,66 @@ def test_codes_bit_exact_and_audio_vs_golden(name, precision):
             got = wave if s == S else wave[:, ::8]
             assert got.shape == gold.shape
             assert rms(got, gold) <= AUDIO_TOL, f"{name} S={s}: audio rms {rms(got, gold):.3e}"
+
+
+@pytest.mark.parametrize("ws", [2, 3, 8])
+def test_other_window_sizes_vs_golden(ws):
+    """window_size != 4 (attention.py:93-127, 246-256): the unfused launch sequence with window_attention_any_kernel against fixtures of the REAL reference
+    (oracle/gen_window_golden.py; tiny configuration, 2 x 2 / 3 x 3 / 8 x 8 windows, W = 32 and 30 frames) and against the oracle's encoder maps; the training step refuses."""
+    from esc.models import make_model
+    from oracle.esc_oracle import EscOracle, Trace
+    g = load_golden("window")
+    cfg = json.loads(str(g[f"ws{ws}_config_json"]))
+    sd = synth_state(f"window_ws{ws}")
+    model = make_model(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    orc = EscOracle(cfg, sd)
+    for precision in PRECISIONS:
+        model.set_precision(precision)
+        for L in (1280, 1200):
+            x = torch.from_numpy(synth.pcm_to_float(g[f"ws{ws}_L{L}_pcm"]))
+            ref = g[f"ws{ws}_L{L}_codes"].astype(np.int64)
+            for s in (1, 2, 3):
+                codes, shape = model.encode(x.cuda(), s)
+                assert tuple(shape) == tuple(g[f"ws{ws}_L{L}_feat_shape"])
+                assert np.array_equal(codes.cpu().numpy(), ref[:, :s]), f"ws {ws} L {L} S {s} {precision}: " + code_report(codes.cpu().numpy(), ref[:, :s], g[f"ws{ws}_L{L}_margins"][:, :s])
+                wave = model.decode(torch.from_numpy(ref[:, :s].copy()).cuda(), shape).cpu().numpy()
+                assert rms(wave if s == 3 else wave[:, ::8], g[f"ws{ws}_L{L}_audio_s{s}"]) <= AUDIO_TOL
+            out = model(**dict(x=x.cuda(), x_feat=None, num_streams=3))
+            assert np.array_equal(out["codes"].cpu().numpy(), ref)
+    model.train()
+    with pytest.raises(NotImplementedError, match="window_size"):
+        model(**dict(x=x.cuda(), x_feat=None, num_streams=3, freeze_codebook=False))
+
+
+def test_window_size_8_on_the_base_geometry_against_the_oracle():
+    """ESC-Base with 8 x 8 windows (the 2- and 4-row maps are padded to 8 rows, 300 frames to 304), two 1 s clips: codes against the oracle - pinned for other window
+    sizes by tests/golden/window.npz - identical or attributed near-ties continued through all six streams; audio of the oracle's codes within the bound."""
+    from esc.models import make_model
+    from esc.models.codecs import state_manifest
+    from oracle.esc_oracle import EscOracle, Trace
+    cfg = dict(json.loads(str(load_golden("base")["config_json"])), window_size=8)
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict({k: list(v) for k, v in state_manifest(cfg).items()}).items()}
+    for k in sd:
+        if k.endswith(".window"):
+            sd[k] = torch.hann_window(sd[k].shape[0])
+    model = make_model(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    orc = EscOracle(cfg, sd)
+    pcm = np.stack([synth.noise_clip_int16("ws8-base-0", 16000), synth.voiced_clip_int16("ws8-base-1", 16000)])
+    x = torch.from_numpy(synth.pcm_to_float(pcm))
+    tr = Trace()
+    ref, shape = orc.encode(x, 6, trace=tr)
+    margins = torch.stack(tr.margins, dim=1).numpy()
+    codes, gshape = model.encode(x.cuda(), 6)
+    assert tuple(gshape) == tuple(shape)
+    findings, forced, _ = attribute_with_continuation(orc, x, codes.cpu().numpy(), ref.numpy(), margins, 6)
+    assert not findings, findings[:5]
+    assert forced <= 2, f"{forced} near-tie codes resolved the other way in two clips"
+    wave = model.decode(ref.cuda(), shape).cpu().numpy()
+    assert rms(wave, orc.decode(ref, shape).numpy()) <= AUDIO_TOL
 
 
 @pytest.mark.parametrize("L", [16000, 24000])

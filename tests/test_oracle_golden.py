@@ -203,3 +203,26 @@ def test_oracle_continuation_from_a_forced_code():
     if m2 >= near:                                           # the corrupted position is not itself a near-tie under this tolerance
         bad, _, cont = attribute_with_continuation(orc, x, wrong.numpy(), ref.numpy(), margins, 3, tol=near)
         assert cont == [0] and len(bad) == 1 and "after continuation" in bad[0] and "stream 2" in bad[0]
+
+
+@pytest.mark.parametrize("ws", [2, 3, 8])
+def test_other_window_sizes(ws):
+    """window_size != 4 (attention.py:93-127, 246-256 are generic in it): fixtures of the REAL reference (oracle/gen_window_golden.py) on the tiny configuration with 2 x 2,
+    3 x 3 (pads every map) and 8 x 8 windows (pads the 4-row map), W = 32 and W = 30 frames: codes exact, audio, encoder maps."""
+    g = load_golden("window")
+    cfg = json.loads(str(g[f"ws{ws}_config_json"]))
+    assert cfg["window_size"] == ws
+    orc = EscOracle(cfg, synth_state(f"window_ws{ws}"))
+    for L in (1280, 1200):
+        x = torch.from_numpy(synth.pcm_to_float(g[f"ws{ws}_L{L}_pcm"]))
+        codes, shape = orc.encode(x, 3)
+        assert tuple(shape) == tuple(g[f"ws{ws}_L{L}_feat_shape"])
+        assert torch.equal(codes, torch.from_numpy(g[f"ws{ws}_L{L}_codes"].astype(np.int64))), f"ws {ws} L {L}"
+        for s in (1, 2, 3):
+            a = orc.decode(codes[:, :s], shape).numpy()
+            assert _rms(a if s == 3 else a[:, ::8], g[f"ws{ws}_L{L}_audio_s{s}"]) <= 1e-6
+        tr = Trace()
+        orc.encode(x, 3, trace=tr)
+        for i, hmap in enumerate(tr.enc_hs):
+            np.testing.assert_allclose(hmap.numpy(), g[f"ws{ws}_L{L}_enc{i}"], atol=2e-6, rtol=1e-5)
+        np.testing.assert_allclose(torch.stack(tr.margins, dim=1).numpy(), g[f"ws{ws}_L{L}_margins"], atol=1e-5)
