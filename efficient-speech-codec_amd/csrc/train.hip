@@ -339,8 +339,8 @@ inline bool mlp_train_fused(const Layer& L) {
 // recomputes the hidden tile from x1 on the fp32 MFMA: the two evaluations of h_pre differ by fp32 rounding (~1e-7), which moves the gradient like any re-association.
 // ESCX_TRAIN_MLP_X3=0: the fp32-MFMA fused kernel (fused_mlp.h), as before.
 inline bool mlp_train_x3() {
-    static const bool on = [] { const char* e = getenv("ESCX_TRAIN_MLP_X3"); return !(e && e[0] == '0'); }();
-    return on;
+    const char* e = getenv("ESCX_TRAIN_MLP_X3");                 // read per call: tests switch it
+    return !(e && e[0] == '0');
 }
 int pack_train_mlp_images(escx_handle_s* h, hipStream_t st) {
     if (!mlp_train_x3() || !h->train_x3_stale) return 0;
@@ -369,8 +369,11 @@ int mlp_bwd_fused(escx_handle_s* h, const Layer& L, const BlockW& bw, const floa
     if ((size_t)grid * per + n1 > DW_PART_FLOATS) ESCX_FAIL(ESCX_ERR_STATE, "dW scratch too small for the fused MLP backward");
     MlpBwdArgs a{x1, dy, dx1, dx1s, slot_of, bw.ln2_g, bw.ln2_b, bw.w1, bw.b1, bw.w2T, bw.w1T, part, slabs, M, L.C, L.hiddenP, tokens, slots, 1e-5f, 0};
     { static const int dbg = [] { const char* e = ESCX_TUNE_ENV("ESCX_MLPBWD_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
-    if (split) hipLaunchKernelGGL((mlp_bwd_fused_kernel<80, 9, 2>), dim3(grid, 2), dim3(64 * 12), 0, st, a);
-    else hipLaunchKernelGGL((mlp_bwd_fused_kernel<48, 12, 1>), dim3(grid), dim3(64 * 15), 0, st, a);
+    // two-term fp16 form of the two channel contractions (train_mlp_fused.h X2; ESCX_TRAIN_MLPBWD_X2=0: all five contractions on the fp32 MFMA, as before)
+    const char* x2e = getenv("ESCX_TRAIN_MLPBWD_X2");            // read per call: tests switch it
+    const bool x2 = !(x2e && x2e[0] == '0');
+    if (split) { if (x2) hipLaunchKernelGGL((mlp_bwd_fused_kernel<80, 9, 2, true>), dim3(grid, 2), dim3(64 * 12), 0, st, a); else hipLaunchKernelGGL((mlp_bwd_fused_kernel<80, 9, 2>), dim3(grid, 2), dim3(64 * 12), 0, st, a); }
+    else { if (x2) hipLaunchKernelGGL((mlp_bwd_fused_kernel<48, 12, 1, true>), dim3(grid), dim3(64 * 15), 0, st, a); else hipLaunchKernelGGL((mlp_bwd_fused_kernel<48, 12, 1>), dim3(grid), dim3(64 * 15), 0, st, a); }
     float* Etot = part + (size_t)grid * per;
     hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, part, grid, n1, L.hiddenP, L.Cp, Etot, G(h, bw.w2),
                        G(h, bw.b1), G(h, bw.b2));

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 #include "gemm_engine.h"
 #include "train_kernels.h"
+#include "split_terms.h"
 
 namespace escx {
 
@@ -66,14 +67,41 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // then a partial sum over a part of the hidden units, so the finisher only adds its NC waves' shares and writes them to slab y - the caller sums the HS slabs and runs
 // the stand-alone LayerNorm backward.  The finisher then reads nothing of the staged tile, the ring needs two slots instead of three, and the normalised rows are not
 // staged row-major (LDS: 156 KB at C = 72 with NC = 9).  W1's second operand layout is re-read from L1 per tile there instead of living in 20 registers.
-template <int CP, int NC, int HS>
+// X2 (round 6, third session): the two contractions over the CHANNELS - h_pre = xn W1^T and d h_act = dy W2, 2 x KC x 4 fp32 MFMAs of 32 cycles per row tile and wave - run
+// on v_mfma_f32_16x16x32_f16 with both operands split into two fp16 terms and three cross products (split_terms.h NT = 2): 2 x KS x 3 instructions of ~17 cycles.  The range
+// rule holds by construction, with powers of two only: a wave scales ITS weight tiles by their own maximum (once per launch; a hidden tile's columns are independent, so a
+// per-tile scale is exact), the x1 stager scales the LayerNorm output by the bound max |gamma| sqrt(C) + max |beta|, the dy stager scales every 16-row gradient tile by the
+// tile's own maximum (block floating point: gradients have no a-priori bound); the accumulators are multiplied back by the inverse powers of two.  The stagers split ONCE per
+// row tile for all the compute waves and write the terms in MFMA fragment order ([k step][term][lane][8 halves]: conflict-free ds_read_b128), instead of the fp32 rows.
+// The three contractions over rows / hidden units (K = 16) stay on the fp32 MFMA: a 32-deep step would be half empty and their operands are produced per wave.
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4_f16(const f32x4 v, float scale, uint2& hi, uint2& lo) {
+#pragma clang fp contract(off)
+    half4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float x = v[e] * scale; const _Float16 x1 = (_Float16)x; h[e] = x1; l[e] = (_Float16)(x - (float)x1); }
+    hi = __builtin_bit_cast(uint2, h); lo = __builtin_bit_cast(uint2, l);
+}
+__device__ __forceinline__ float wave_max(float m) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return m;
+}
+
+template <int CP, int NC, int HS, bool X2 = false>
 __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs a) {
     constexpr int KC = CP / 16;                 // channel tiles
+    constexpr int KS = (CP + 31) / 32;          // X2: 32-deep k steps
     constexpr int SLD = CP + 4, TLD = 20;       // row strides (dwords) of the row-major / transposed staged copies
     constexpr int NSTG = HS > 1 ? 2 : 3;
-    constexpr bool W1E_REG = CP <= 48;
-    struct Stage { float xn[16 * SLD]; float xh[HS > 1 ? 4 : 16 * SLD]; float dy[16 * SLD]; float xhT[CP * TLD]; float dyT[CP * TLD]; float rstd[16]; };
+    constexpr bool W1E_REG = CP <= 48 && !X2;   // X2: the split weight fragments take the registers (the second layout of W1 is re-read from L1 per tile, as at C = 72)
+    struct Stage {
+        bf16x8 xnp[X2 ? KS * 2 * 64 : 1], dyp[X2 ? KS * 2 * 64 : 1];      // X2: split terms of the LayerNorm output / of dy, fragment order
+        float xn[X2 ? 4 : 16 * SLD]; float xh[HS > 1 ? 4 : 16 * SLD]; float dy[(X2 && HS > 1) ? 4 : 16 * SLD]; float xhT[CP * TLD]; float dyT[CP * TLD]; float rstd[16];
+        float inv_dy[4];                                                  // X2: 1 / (power-of-two scale of this tile's dy)
+    };
     __shared__ Stage stg[NSTG];
+    __shared__ float sx_s[2];                   // X2: power-of-two scale of the LayerNorm output and its inverse
     __shared__ float red[2][NC][16 * SLD];
     __shared__ float tr[NC][16 * TLD];
     __shared__ float gam_s[CP], bet_s[CP];
@@ -85,6 +113,12 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
     const float invC = 1.0f / (float)a.C;
     if (threadIdx.x < CP) { gam_s[threadIdx.x] = a.gamma[threadIdx.x]; bet_s[threadIdx.x] = a.beta[threadIdx.x]; }
     __syncthreads();
+    if constexpr (X2) {
+        if (threadIdx.x == 0) { const float sx = act_pow2_scale(ln_out_bound(gam_s, bet_s, CP, a.C)); sx_s[0] = sx; sx_s[1] = 1.0f / sx; }
+        __syncthreads();
+    }
+    // X2: where the 4 channels (16 ct + 4 g ..) of row b go in fragment order: k step ct / 2, lane (b, k group 2 (ct & 1) + g / 2), halves 4 (g & 1) .. + 3
+    auto frag_slot = [&](int ct, int term) { return (((ct >> 1) * 2 + term) * 64 + (2 * (ct & 1) + (g >> 1)) * 16 + b) * 2 + (g & 1); };
     auto tile_row = [&](int t) { return ((int)blockIdx.x + t * (int)gridDim.x) * 16 + b; };
     auto ring_next = [&](int i) { return i + 1 == NSTG ? 0 : i + 1; };
 
@@ -126,7 +160,15 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
                     S.xhT[(16 * ct + 4 * g + e) * TLD + b] = xh[e];
                 }
                 if (HS == 1) st4(&S.xh[b * SLD + 16 * ct + 4 * g], xh);
-                st4(&S.xn[b * SLD + 16 * ct + 4 * g], xn);
+                if constexpr (X2) {
+                    uint2 hi, lo;
+                    split4_f16(xn, sx_s[0], hi, lo);
+                    reinterpret_cast<uint2*>(S.xnp)[frag_slot(ct, 0)] = hi; reinterpret_cast<uint2*>(S.xnp)[frag_slot(ct, 1)] = lo;
+                } else st4(&S.xn[b * SLD + 16 * ct + 4 * g], xn);
+            }
+            if constexpr (X2) {                  // K padding of the last 32-deep step: zero halves
+#pragma unroll
+                for (int ct = KC; ct < 2 * KS; ++ct) { reinterpret_cast<uint2*>(S.xnp)[frag_slot(ct, 0)] = uint2{0u, 0u}; reinterpret_cast<uint2*>(S.xnp)[frag_slot(ct, 1)] = uint2{0u, 0u}; }
             }
             if (g == 0) S.rstd[b] = live ? rstd : 0.f;
         };
@@ -150,12 +192,31 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
 #pragma unroll
         for (int ct = 0; ct < KC; ++ct) sdy[ct] = zero4();
         auto store = [&](Stage& S) {
+            float dsc = 1.0f;
+            if constexpr (X2) {                  // block floating point: this tile's own maximum -> power of two (1 for an all-zero tile)
+                float m = 0.f;
+#pragma unroll
+                for (int ct = 0; ct < KC; ++ct)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(pre[ct][e]));
+                dsc = x2_scale(__float_as_uint(wave_max(m)));
+                if (lane == 0) S.inv_dy[0] = 1.0f / dsc;
+            }
 #pragma unroll
             for (int ct = 0; ct < KC; ++ct) {
                 sdy[ct] += pre[ct];
-                st4(&S.dy[b * SLD + 16 * ct + 4 * g], pre[ct]);
+                if constexpr (!(X2 && HS > 1)) st4(&S.dy[b * SLD + 16 * ct + 4 * g], pre[ct]);
+                if constexpr (X2) {
+                    uint2 hi, lo;
+                    split4_f16(pre[ct], dsc, hi, lo);
+                    reinterpret_cast<uint2*>(S.dyp)[frag_slot(ct, 0)] = hi; reinterpret_cast<uint2*>(S.dyp)[frag_slot(ct, 1)] = lo;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) S.dyT[(16 * ct + 4 * g + e) * TLD + b] = pre[ct][e];
+            }
+            if constexpr (X2) {
+#pragma unroll
+                for (int ct = KC; ct < 2 * KS; ++ct) { reinterpret_cast<uint2*>(S.dyp)[frag_slot(ct, 0)] = uint2{0u, 0u}; reinterpret_cast<uint2*>(S.dyp)[frag_slot(ct, 1)] = uint2{0u, 0u}; }
             }
         };
         load(0); store(stg[0]); load(1);
@@ -236,13 +297,38 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
     } else {
         // ---- compute wave w: hidden tile w ----
         const int ht = (int)blockIdx.y * NC + wave;                      // this wave's hidden tile
-        f32x4 W1a[KC], W2c[KC], W1e[W1E_REG ? KC : 1], dW1T[KC], dW2[KC];
+        f32x4 W1a[X2 ? 1 : KC], W2c[X2 ? 1 : KC], W1e[W1E_REG ? KC : 1], dW1T[KC], dW2[KC];
+        bf16x8 w1s[X2 ? KS : 1][2], w2s[X2 ? KS : 1][2];       // X2: this wave's rows of W1 / W2^T as two fp16 terms, column operand of the 32-deep steps: lane (hidden b, k group g)
+        float inv1 = 1.f, inv2 = 1.f;                           // X2: 1 / (weight scale x activation scale), powers of two
 #pragma unroll
         for (int ct = 0; ct < KC; ++ct) {
-            W1a[ct] = ld4(a.w1 + (size_t)(16 * ht + b) * CP + 16 * ct + 4 * g);
-            W2c[ct] = ld4(a.w2T + (size_t)(16 * ht + b) * CP + 16 * ct + 4 * g);
+            if constexpr (!X2) {
+                W1a[ct] = ld4(a.w1 + (size_t)(16 * ht + b) * CP + 16 * ct + 4 * g);
+                W2c[ct] = ld4(a.w2T + (size_t)(16 * ht + b) * CP + 16 * ct + 4 * g);
+            }
             if (W1E_REG) W1e[ct] = ld4(a.w1T + (size_t)(16 * ct + b) * a.hiddenP + 16 * ht + 4 * g);
             dW1T[ct] = zero4(); dW2[ct] = zero4();
+        }
+        if constexpr (X2) {
+            float v1[KS][8], v2[KS][8], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int c0 = 32 * s + 8 * g;
+                f32x4 p0 = zero4(), p1 = zero4(), q0 = zero4(), q1 = zero4();
+                if (c0 < CP) {                                  // CP % 16 == 0 and c0 % 8 == 0: both halves inside the row or both outside
+                    const float* r1 = a.w1 + (size_t)(16 * ht + b) * CP + c0; const float* r2 = a.w2T + (size_t)(16 * ht + b) * CP + c0;
+                    p0 = ld4(r1); p1 = ld4(r1 + 4); q0 = ld4(r2); q1 = ld4(r2 + 4);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v1[s][e] = p0[e]; v1[s][4 + e] = p1[e]; v2[s][e] = q0[e]; v2[s][4 + e] = q1[e];
+                    m1 = fmaxf(m1, fmaxf(fabsf(p0[e]), fabsf(p1[e]))); m2 = fmaxf(m2, fmaxf(fabsf(q0[e]), fabsf(q1[e])));
+                }
+            }
+            const float s1 = x2_scale(__float_as_uint(wave_max(m1))), s2 = x2_scale(__float_as_uint(wave_max(m2)));
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { split_terms<2>(v1[s], w1s[s], s1); split_terms<2>(v2[s], w2s[s], s2); }
+            inv1 = (1.0f / s1) * sx_s[1]; inv2 = 1.0f / s2;
         }
         const float* w1e_src = a.w1T + (size_t)b * a.hiddenP + 16 * ht + 4 * g;    // + 16 * ct * hiddenP per channel tile
         const float bias1 = a.b1[16 * ht + b];
@@ -253,6 +339,20 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
         for (int it = 0; it < n_it; ++it) {
             const Stage& S = stg[sidx];
             f32x4 hp = {bias1, bias1, bias1, bias1}, dh = zero4();
+            if constexpr (X2) {
+                f32x4 ha = zero4();
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const bf16x8 xh_ = S.xnp[(s * 2 + 0) * 64 + lane], xl_ = S.xnp[(s * 2 + 1) * 64 + lane];
+                    const bf16x8 dh_ = S.dyp[(s * 2 + 0) * 64 + lane], dl_ = S.dyp[(s * 2 + 1) * 64 + lane];
+                    ha = mma_x<2>(xl_, w1s[s][0], ha); dh = mma_x<2>(dl_, w2s[s][0], dh);            // smallest terms first
+                    ha = mma_x<2>(xh_, w1s[s][1], ha); dh = mma_x<2>(dh_, w2s[s][1], dh);
+                    ha = mma_x<2>(xh_, w1s[s][0], ha); dh = mma_x<2>(dh_, w2s[s][0], dh);
+                }
+                const float i2 = inv2 * S.inv_dy[0];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { hp[r] = __builtin_fmaf(ha[r], inv1, bias1); dh[r] *= i2; }     // back from the power-of-two scales (exact)
+            } else {
 #pragma unroll
             for (int ct = 0; ct < KC; ++ct) {
                 const f32x4 xa = ld4(&S.xn[b * SLD + 16 * ct + 4 * g]);
@@ -262,6 +362,7 @@ __global__ __launch_bounds__(64 * (NC + 3)) void mlp_bwd_fused_kernel(MlpBwdArgs
                     hp = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[r], W1a[ct][r], hp, 0, 0, 0);        // h_pre[row 4g+r'][hid b]
                     dh = __builtin_amdgcn_mfma_f32_16x16x4f32(da[r], W2c[ct][r], dh, 0, 0, 0);        // d h_act
                 }
+            }
             }
             // the row-contraction operands are fetched BEFORE the GELU arithmetic so that their LDS latency hides under it (all waves of the
             // workgroup run in lockstep behind the per-tile barrier: an exposed LDS round trip is paid by every SIMD at the same time)

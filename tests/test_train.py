@@ -720,3 +720,37 @@ def test_two_part_training_pass_equals_the_one_part_pass(monkeypatch):
     num = sum(float(((g2[k].astype(np.float64) - g1[k]) ** 2).sum()) for k in g1)
     den = sum(float((g1[k].astype(np.float64) ** 2).sum()) for k in g1)
     assert (num / den) ** 0.5 < 1e-5, (num / den) ** 0.5
+
+
+@pytest.mark.gpu
+def test_split_operand_mlp_kernels_of_the_training_step_against_the_fp32_mfma_forms(monkeypatch):
+    """Round 6: the C = 45 / 72 layers run their MLP forward on the exact three-term split-operand kernel (ESCX_TRAIN_MLP_X3) and the two channel contractions of the fused
+    MLP backward on two fp16 terms with power-of-two block scaling (ESCX_TRAIN_MLPBWD_X2, train_mlp_fused.h).
+    (a) Backward switch alone - same forward, same tape: the whole gradient moves by the arithmetic error of two contractions (measured 1.7e-7 of its norm, worst tensor 1.1e-6 of
+        its own; bounds 2e-6 / 2e-5).
+    (b) Forward switch: losses to fp32 rounding; the gradient moves like under any fp32 re-association of the forward - the level of the reference's own fp32-vs-fp64 distance
+        (median 1e-3 ... 1e-2 per tensor on this model, _noise_floor), so it is held to 1e-2 of its norm, not to 1e-5."""
+    g = load_golden("train")
+    w = json.loads(str(g["weights_json"]))
+    x = _clips(g, "base")
+
+    def rel(ga, gb):
+        num = sum(float(((ga[k].astype(np.float64) - gb[k]) ** 2).sum()) for k in gb)
+        den = sum(float((gb[k].astype(np.float64) ** 2).sum()) for k in gb)
+        worst = max(((float(((ga[k].astype(np.float64) - gb[k]) ** 2).sum()) / max(float((gb[k].astype(np.float64) ** 2).sum()), 1e-30)) ** 0.5, k) for k in gb)
+        return (num / den) ** 0.5, worst
+
+    monkeypatch.setenv("ESCX_TRAIN_MLP_X3", "0"); monkeypatch.setenv("ESCX_TRAIN_MLPBWD_X2", "0")
+    _, _, l0, g0 = _product_step("base", 6, False, x, w)
+    monkeypatch.delenv("ESCX_TRAIN_MLP_X3")
+    _, _, lf, gf = _product_step("base", 6, False, x, w)           # split-operand forward, fp32-MFMA backward
+    monkeypatch.delenv("ESCX_TRAIN_MLPBWD_X2")
+    _, _, l1, g1 = _product_step("base", 6, False, x, w)           # both (the default)
+    for k in l0:
+        np.testing.assert_allclose(lf[k], l0[k], rtol=2e-6, atol=1e-7, err_msg=k)
+        assert np.array_equal(l1[k], lf[k]), k                      # the backward switch does not touch the forward
+    rb, wb = rel(g1, gf)
+    rf, wf = rel(gf, g0)
+    print(f"[train-x2] backward switch: whole gradient {rb:.2e}, worst tensor {wb[0]:.2e} at {wb[1]}; forward switch: whole gradient {rf:.2e}, worst tensor {wf[0]:.2e} at {wf[1]}")
+    assert 0 < rb < 2e-6 and wb[0] < 2e-5, (rb, wb)
+    assert 0 < rf < 1e-2, (rf, wf)
