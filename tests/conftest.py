@@ -12,6 +12,15 @@ for p in (os.path.join(ROOT, "efficient-speech-codec_amd"), ROOT):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The oracle (torch on the host cores) is what most of the GPU suite's wall time goes to.  A GPU box has 256 hardware threads and torch takes 128 of them by default: the oracle's
+# many small operators then run 4.5x (ESC-Base) to 40x (the tiny configuration) SLOWER than on 16 threads (measured on an MI355X box: four oracle-heavy tests 49 s on 16 threads,
+# 67 s on 32, 210-232 s on the default) - the same sweep bench.py's cpu_baseline does.  The fixtures were generated on 8 threads; the oracle is pinned to them at any thread count.
+try:
+    import torch as _torch
+    _torch.set_num_threads(min(16, os.cpu_count() or 1))
+except Exception:
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
