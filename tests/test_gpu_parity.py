@@ -919,7 +919,10 @@ def _near_tie_budget(tot, strict=False):
     observed - at most 1 % of the clips AND at most a sixth of the sweep's codes with a reference margin under 2e-6 (never less than one clip: a single flip is
     fp32 summation-order noise under any arithmetic).  Observed (profiles/r5_parity_sweep_*, r6_*): Base-576 4 clips (0.7 %) of 45 such codes and Base-1152 5 clips
     (0.4 %), Large-576 3 clips (0.5 %) with two fp16 terms; 3 / 576 and 1 / 288 with three bf16 terms; 0 / 576 and 2 / 288 (0.7 %, 25 such codes) on the fp32 MFMA.
-    strict: the arm that must stay bit-exact on every clip (ESC-Base on the fp32 MFMA: 576 / 576 in every sweep so far)."""
+    strict: the arm that must stay bit-exact on every clip - ESC-Base on the fp32 MFMA over the 72 always-on clips (bit-exact in every run so far).  The WIDE sweep
+    (ESCX_PARITY_SWEEP=288) is not strict: with the oracle on 128 host threads that arm was 576 / 576, with the oracle on 16 threads (tests/conftest.py) it is 574 / 576 + 2
+    attributed near-ties - the product's codes are the same in both runs, it is the ORACLE's fp32 summation order (torch's CPU matmul blocking) that resolves two reference
+    near-ties the other way.  A code on a margin under 2e-6 is not determined by the reference's arithmetic either."""
     flipped = tot["clips"] - tot["exact"]
     if strict:
         assert flipped == 0, tot
@@ -931,9 +934,9 @@ def _near_tie_budget(tot, strict=False):
 def test_parity_sweep_base_always_on(precision):
     """the sweep is part of every GPU run, in every precision mode - ESC-Base against the oracle, every code: 36 noise + 36 voiced
     3 s clips, the same in every mode (the oracle runs once) (ESCX_PARITY_SWEEP=<clips per family> widens all three: 288 is the sweep
-    whose log is committed under profiles/).  The fp32-MFMA arm is the strict one: ESC-Base has been bit-exact on every clip there in every sweep."""
+    whose log is committed under profiles/).  The fp32-MFMA arm is the strict one at the always-on width: ESC-Base has been bit-exact on each of these 72 clips in every run."""
     n = int(os.environ.get("ESCX_PARITY_SWEEP", "36"))
-    _near_tie_budget(_parity_sweep("base", n, precision), strict=(precision == "fp32"))
+    _near_tie_budget(_parity_sweep("base", n, precision), strict=(precision == "fp32" and n <= 36))
 
 
 @pytest.mark.gpu
